@@ -1,0 +1,95 @@
+"""Oracle ESS / log-Z / resampling — TEST INFRASTRUCTURE, never imported by the product.
+
+* effective_sample_size ........ fab/utils/numerical.py:18-23
+* log_Z ........................ fab/sampling_methods/ais.py:83-84
+* resample (multinomial) ....... fab/sampling_methods/base.py:121-124 ->
+  torch.distributions.Categorical.sample_n -> torch.multinomial (CPU kernel: sequential
+  fp32 cumsum, divide by the total, last bucket forced to 1, float64 uniforms,
+  lower-bound binary search).
+* fixed-point CDF resamplers (multinomial at any N, systematic) — the build's own scalable
+  definition (the reference has no systematic resampler): oracle == spec.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+FIX_BITS = 36  # fixed-point fractional bits of the scalable CDF; sum of 2^26 weights <= 2^62
+
+
+def effective_sample_size(log_w: torch.Tensor) -> torch.Tensor:
+    assert log_w.dim() == 1
+    w = F.softmax(log_w, dim=0)
+    return 1 / torch.sum(w ** 2) / log_w.shape[0]
+
+
+def log_Z(log_w: torch.Tensor, batch_size: int) -> torch.Tensor:
+    lz = torch.logsumexp(log_w, dim=0)
+    return lz - torch.log(torch.ones_like(lz) * batch_size)
+
+
+# ---------------------------------------------------------------------------------------
+# torch-compatible multinomial: exact restatement of what the reference's `resample`
+# consumes from the CPU generator and returns.
+# ---------------------------------------------------------------------------------------
+def categorical_probs(log_w: torch.Tensor) -> torch.Tensor:
+    """probs of torch.distributions.Categorical(logits=log_w) (fp32)."""
+    logits = log_w - log_w.logsumexp(dim=-1, keepdim=True)
+    return F.softmax(logits, dim=-1)
+
+
+def multinomial_torch_compat(probs: np.ndarray, u: np.ndarray) -> np.ndarray:
+    """idx_k = first j with c[j] >= u_k, c = sequential fp32 cumsum(probs)/sum, c[-1]=1."""
+    probs = np.asarray(probs, dtype=np.float32)
+    c = np.empty_like(probs)
+    s = np.float32(0)
+    for j in range(probs.shape[0]):          # sequential fp32 accumulation
+        s = np.float32(s + probs[j])
+        c[j] = s
+    c = (c / s).astype(np.float32)
+    c[-1] = np.float32(1)
+    # c (fp32) compared with u (fp64) in double precision, as the CPU kernel does
+    return np.searchsorted(c.astype(np.float64), np.asarray(u, np.float64), side="left").astype(np.int64)
+
+
+# ---------------------------------------------------------------------------------------
+# scalable fixed-point definition (associative integer prefix sums => bit-exact under any
+# parallel scan order).  p_i = fl32(exp(fl64(w_i) - fl64(max w)))  (correctly rounded exp
+# via float64), q_i = floor(p_i * 2^36) as uint64, C = inclusive prefix sum of q.
+# ---------------------------------------------------------------------------------------
+def fixed_point_weights(log_w: np.ndarray) -> np.ndarray:
+    lw = np.asarray(log_w, dtype=np.float32).astype(np.float64)
+    finite = np.isfinite(lw)
+    m = lw[finite].max() if finite.any() else 0.0
+    with np.errstate(invalid="ignore", over="ignore"):
+        p = np.exp(lw - m)
+    p = np.where(~finite, 0.0, p).astype(np.float32)   # nan / +-inf -> weight 0
+    return np.floor(p.astype(np.float64) * float(1 << FIX_BITS)).astype(np.uint64)
+
+
+def fixed_point_cdf(log_w: np.ndarray) -> np.ndarray:
+    return np.cumsum(fixed_point_weights(log_w), dtype=np.uint64)
+
+
+def _thresholds_multinomial(u: np.ndarray, total: int) -> np.ndarray:
+    t = np.floor(np.asarray(u, np.float64) * np.float64(total)).astype(np.uint64)
+    return np.minimum(t, np.uint64(total - 1))
+
+
+def multinomial_fixed(log_w: np.ndarray, u: np.ndarray) -> np.ndarray:
+    """idx_k = first j with C[j] > floor(u_k * total)."""
+    C = fixed_point_cdf(log_w)
+    total = int(C[-1])
+    assert total > 0
+    return np.searchsorted(C, _thresholds_multinomial(u, total), side="right").astype(np.int64)
+
+
+def systematic_fixed(log_w: np.ndarray, u0: float, n_out: int = None) -> np.ndarray:
+    """Systematic resampling on the fixed-point CDF: t_k = floor((k + u0) * (total / n_out))."""
+    C = fixed_point_cdf(log_w)
+    total = int(C[-1])
+    assert total > 0
+    n_out = len(C) if n_out is None else n_out
+    step = np.float64(total) / np.float64(n_out)
+    t = np.floor((np.arange(n_out, dtype=np.float64) + np.float64(u0)) * step).astype(np.uint64)
+    t = np.minimum(t, np.uint64(total - 1))
+    return np.searchsorted(C, t, side="right").astype(np.int64)

@@ -1,0 +1,323 @@
+"""Generate golden fixtures by RUNNING THE IMPORTED REFERENCE (fab-torch) in this container.
+
+Usage (build container only — /root/reference does not exist on the GPU box):
+    python tests/golden/make_golden.py
+
+The reference's AIS / HMC / Metropolis / Point / targets / ESS / resample code is imported
+from /root/reference (with the three absent third-party modules stubbed)
+and driven with the oracle RealNVP (oracle/flow.py) as its ``base_distribution`` plug-in —
+the reference only needs the `Distribution` interface (fab/sampling_methods/ais.py:23,56-62).
+All noise the reference draws is captured by wrapping torch's RNG entry points, so that the
+fixtures hold (inputs, noise, outputs) triples.  Only DATA is written: small .npz files.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+for name in ["wandb", "normflows", "nflows", "nflows.flows"]:
+    sys.modules[name] = types.ModuleType(name)
+sys.modules["normflows"].NormalizingFlow = object
+sys.modules["nflows"].flows = sys.modules["nflows.flows"]
+sys.modules["nflows.flows"].Flow = object
+sys.path.insert(0, "/root/reference")
+
+from fab import AnnealedImportanceSampler, HamiltonianMonteCarlo, Metropolis  # noqa: E402
+from fab.sampling_methods.base import (Point, get_intermediate_log_prob,  # noqa: E402
+                                       get_grad_intermediate_log_prob, resample, create_point)
+from fab.target_distributions.many_well import ManyWellEnergy  # noqa: E402
+from fab.target_distributions.gmm import GMM  # noqa: E402
+from fab.utils.numerical import effective_sample_size  # noqa: E402
+
+from oracle import flow as oflow  # noqa: E402
+
+
+def npz(name, **kw):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in kw.items()})
+    print(f"wrote {name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def flow_state(nf):
+    return {"flow." + k: v for k, v in nf.state_dict().items()}
+
+
+class Capture:
+    """Wrap the RNG entry points the reference uses and record every draw."""
+
+    def __init__(self):
+        self.randn_like, self.expo, self.randn, self.rand = [], [], [], []
+
+    def __enter__(self):
+        self._o = (torch.randn_like, torch.distributions.Exponential.sample, torch.randn, torch.rand)
+        o_rl, o_ex, o_rn, o_ra = self._o
+        cap = self
+
+        def randn_like(x, *a, **k):
+            t = o_rl(x, *a, **k); cap.randn_like.append(t.clone()); return t
+
+        def expo(self_, shape=torch.Size()):
+            t = o_ex(self_, shape); cap.expo.append(t.clone()); return t
+
+        def randn(*a, **k):
+            t = o_rn(*a, **k); cap.randn.append(t.clone()); return t
+
+        def rand(*a, **k):
+            t = o_ra(*a, **k); cap.rand.append(t.clone()); return t
+
+        torch.randn_like = randn_like
+        torch.distributions.Exponential.sample = expo
+        torch.randn = randn
+        torch.rand = rand
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.distributions.Exponential.sample, torch.randn, torch.rand = self._o
+
+
+class EpsFlow:
+    """`Distribution` adapter: deterministic base noise for the oracle flow."""
+
+    def __init__(self, nf, eps):
+        self.nf, self.eps = nf, eps
+
+    def sample_and_log_prob(self, shape):
+        assert shape[0] == self.eps.shape[0]
+        with torch.no_grad():
+            return self.nf.sample_eps(self.eps)
+
+    def log_prob(self, x):
+        return self.nf.log_prob(x)
+
+    def sample(self, shape):
+        return self.sample_and_log_prob(shape)[0]
+
+    @property
+    def event_shape(self):
+        return self.nf.q0.shape
+
+
+def make_flow(dim, n_layers, nodes, seed):
+    torch.manual_seed(seed)
+    nf = oflow.make_realnvp(dim, n_layers, nodes)
+    oflow.randomize_last_layers(nf, std=0.05, seed=seed + 1)
+    return nf
+
+
+def g1_beta():
+    out = {}
+    for M in (1, 4, 8, 12):
+        for sp in ("linear", "geometric"):
+            ais = AnnealedImportanceSampler.__new__(AnnealedImportanceSampler)
+            ais.n_intermediate_distributions = M
+            out[f"{sp}_{M}"] = ais.setup_distribution_spacing(sp, M)
+    npz("g1_beta.npz", **out)
+
+
+def g2_intermediate():
+    torch.manual_seed(11)
+    B, D = 64, 6
+    pt = Point(torch.randn(B, D), torch.randn(B) * 3, torch.randn(B) * 5, torch.randn(B, D), torch.randn(B, D) * 4)
+    betas = torch.tensor(np.linspace(0, 1, 6))
+    out = dict(x=pt.x, log_q=pt.log_q, log_p=pt.log_p, grad_log_q=pt.grad_log_q, grad_log_p=pt.grad_log_p,
+               betas=betas)
+    for ai, alpha in enumerate((2.0, 0.5)):
+        for p_target in (False, True):
+            for bi, beta in enumerate(betas):
+                out[f"lp_a{ai}_p{int(p_target)}_b{bi}"] = get_intermediate_log_prob(pt, beta, alpha, p_target)
+                out[f"gr_a{ai}_p{int(p_target)}_b{bi}"] = get_grad_intermediate_log_prob(pt, beta, alpha, p_target)
+    npz("g2_intermediate.npz", **out)
+
+
+def g3_targets():
+    torch.manual_seed(12)
+    out = {}
+    for D in (6, 32):
+        t = ManyWellEnergy(dim=D, use_gpu=False)
+        x = torch.randn(64, D) * 1.5
+        x[0] = 1.7
+        x[1, 0::2] = 1.7; x[1, 1::2] = 0.0
+        x[2] = float("nan"); x[3, 0] = float("inf"); x[4] = 40.0
+        xg = x.clone().requires_grad_(True)
+        lp = t.log_prob(xg)
+        g = torch.autograd.grad(lp, xg, torch.ones_like(lp))[0]
+        out[f"mw{D}_x"], out[f"mw{D}_lp"], out[f"mw{D}_g"] = x, lp, g
+        out[f"mw{D}_logZ"] = t.log_Z
+    torch.manual_seed(0)
+    gmm = GMM(dim=2, n_mixes=40, loc_scaling=40.0, log_var_scaling=1.0, use_gpu=False,
+              true_expectation_estimation_n_samples=1000)
+    torch.manual_seed(13)
+    x = torch.randn(96, 2) * 30
+    x[0] = 0.0
+    x[1] = 1e4                      # triggers the -inf mask (log_prob < -1e4)
+    x[2] = float("nan")
+    out["gmm_locs"] = gmm.locs
+    out["gmm_scales"] = torch.diagonal(gmm.scale_trils, dim1=-2, dim2=-1)
+    out["gmm_x"], out["gmm_lp"] = x, gmm.log_prob(x)
+    npz("g3_targets.npz", **out)
+
+
+def g4_ess():
+    torch.manual_seed(14)
+    out = {}
+    vecs = [torch.tensor([0., 1., 2., 3.]), torch.randn(64) * 3, torch.randn(1024) * 10 + 150,
+            torch.cat([torch.randn(30), torch.tensor([-float("inf")] * 2)]), torch.zeros(17)]
+    for i, lw in enumerate(vecs):
+        out[f"lw{i}"] = lw
+        out[f"ess{i}"] = effective_sample_size(lw)
+        lz = torch.logsumexp(lw, dim=0)
+        out[f"logZ{i}"] = lz - torch.log(torch.ones_like(lz) * lw.shape[0])
+    npz("g4_ess.npz", **out)
+
+
+def g5_multinomial():
+    out = {}
+    for N in (64, 1024, 4096):
+        torch.manual_seed(100 + N)
+        lw = torch.randn(N) * 3
+        x = torch.arange(N, dtype=torch.float32)[:, None].repeat(1, 2)
+        st = torch.get_rng_state()
+        xs = resample(x, lw)                                   # the reference's own resample()
+        torch.set_rng_state(st)
+        u = torch.rand(N, dtype=torch.float64)                 # the uniforms multinomial consumed
+        probs = torch.distributions.Categorical(logits=lw).probs
+        out[f"lw_{N}"], out[f"u_{N}"], out[f"probs_{N}"] = lw, u, probs
+        out[f"idx_{N}"] = xs[:, 0].to(torch.int64)
+    npz("g5_multinomial.npz", **out)
+
+
+def tuned_hmc(M, D, nf, target, eps, L, n_outer, alpha, p_target, tune=True):
+    return HamiltonianMonteCarlo(n_ais_intermediate_distributions=M, dim=D, base_log_prob=nf.log_prob,
+                                 target_log_prob=target.log_prob, alpha=alpha, p_target=p_target,
+                                 epsilon=eps, n_outer=n_outer, L=L, eval_mode=not tune)
+
+
+def g6_hmc():
+    for tag, D, K, nodes, eps, n_outer in (("d6", 6, 3, 5, 0.22, 1), ("d32", 32, 2, 1, 0.22, 1),
+                                           ("d6_outer2", 6, 3, 5, 0.22, 2)):
+        nf = make_flow(D, K, nodes, seed=20 + D)
+        target = ManyWellEnergy(dim=D, use_gpu=False)
+        M, L, B, alpha = 4, 5, 64, 2.0
+        hmc = tuned_hmc(M, D, nf, target, eps, L, n_outer, alpha, False)
+        torch.manual_seed(21)
+        with torch.no_grad():
+            x0, _ = nf.sample_eps(torch.randn(B, D))
+        pt = create_point(x0, nf.log_prob, target.log_prob, with_grad=True)
+        i = 2
+        beta = torch.tensor(np.linspace(0, 1, M + 2))[i]
+        out = dict(beta=beta, i=i, L=L, n_outer=n_outer, alpha=alpha, p_target=0, M=M,
+                   in_x=pt.x.clone(), in_log_q=pt.log_q.clone(), in_log_p=pt.log_p.clone(),
+                   in_gq=pt.grad_log_q.clone(), in_gp=pt.grad_log_p.clone(),
+                   in_epsilons=hmc.epsilons.clone(), in_common_epsilon=hmc.common_epsilon.clone(),
+                   mass=hmc.mass_vector.clone())
+        with Capture() as cap:
+            res = hmc.transition(pt, i, beta)
+        out.update(noise_p=torch.stack(cap.randn_like), noise_e=torch.stack(cap.expo),
+                   out_x=res.x, out_log_q=res.log_q, out_log_p=res.log_p, out_gq=res.grad_log_q,
+                   out_gp=res.grad_log_p, out_epsilons=hmc.epsilons, out_common_epsilon=hmc.common_epsilon,
+                   p_accept=torch.stack([v.reshape(()) for v in hmc.first_dist_p_accepts])
+                   if i == 1 else torch.zeros(n_outer))
+        out.update(flow_state(nf))
+        npz(f"g6_hmc_{tag}.npz", **out)
+
+
+def g7_metropolis():
+    D, K, nodes = 2, 2, 8
+    nf = make_flow(D, K, nodes, seed=30)
+    torch.manual_seed(0)
+    target = GMM(dim=2, n_mixes=40, loc_scaling=40.0, log_var_scaling=1.0, use_gpu=False,
+                 true_expectation_estimation_n_samples=1000)
+    M, B, alpha, n_updates = 4, 64, 2.0, 3
+    met = Metropolis(n_ais_intermediate_distributions=M, dim=D, base_log_prob=nf.log_prob,
+                     target_log_prob=target.log_prob, n_updates=n_updates, alpha=alpha, p_target=False,
+                     max_step_size=5.0, min_step_size=1.0, adjust_step_size=True)
+    torch.manual_seed(31)
+    with torch.no_grad():
+        x0, lq0 = nf.sample_eps(torch.randn(B, D))
+        x0 = x0 * 10
+    pt = create_point(x0, nf.log_prob, target.log_prob, with_grad=False)
+    i = 3
+    beta = torch.tensor(np.linspace(0, 1, M + 2))[i]
+    out = dict(beta=beta, i=i, n_updates=n_updates, alpha=alpha, p_target=0, M=M,
+               in_x=pt.x.clone(), in_log_q=pt.log_q.clone(), in_log_p=pt.log_p.clone(),
+               in_noise_scalings=met.noise_scalings.clone(),
+               gmm_locs=target.locs, gmm_scales=torch.diagonal(target.scale_trils, dim1=-2, dim2=-1))
+    with Capture() as cap:
+        res = met.transition(pt, i, beta)
+    out.update(noise_x=torch.stack(cap.randn), noise_u=torch.stack(cap.rand),
+               out_x=res.x, out_log_q=res.log_q, out_log_p=res.log_p, out_noise_scalings=met.noise_scalings)
+    out.update(flow_state(nf))
+    npz("g7_metropolis.npz", **out)
+
+
+def g8_full_chain():
+    # (a) ManyWell-6, HMC, M=4, geometric + linear; (b) ManyWell-32, HMC, M=8; (c) GMM-2, Metropolis M=4
+    for tag, D, K, nodes, M, spacing, eps, p_target in (
+            ("mw6_hmc_m4", 6, 3, 5, 4, "linear", 0.2, False),
+            ("mw6_hmc_m8geo_ptarget", 6, 3, 5, 8, "geometric", 0.2, True),
+            ("mw32_hmc_m8", 32, 2, 1, 8, "linear", 0.2, False)):
+        nf = make_flow(D, K, nodes, seed=40 + D)
+        target = ManyWellEnergy(dim=D, use_gpu=False)
+        B, L, alpha = 64, 5, 2.0
+        hmc = tuned_hmc(M, D, nf, target, eps, L, 1, alpha, p_target)
+        torch.manual_seed(41)
+        eps0 = torch.randn(B, D)
+        ais = AnnealedImportanceSampler(EpsFlow(nf, eps0), target.log_prob, hmc, p_target=p_target,
+                                        alpha=alpha, n_intermediate_distributions=M,
+                                        distribution_spacing_type=spacing)
+        in_eps, in_ceps = hmc.epsilons.clone(), hmc.common_epsilon.clone()
+        with Capture() as cap:
+            pt, log_w = ais.sample_and_log_weights(B)
+        info = ais.get_logging_info()
+        out = dict(M=M, L=L, alpha=alpha, p_target=int(p_target), spacing=spacing, eps0=eps0,
+                   B_space=ais.B_space, in_epsilons=in_eps, in_common_epsilon=in_ceps,
+                   noise_p=torch.stack(cap.randn_like)[:, None], noise_e=torch.stack(cap.expo)[:, None],
+                   out_x=pt.x, out_log_q=pt.log_q, out_log_p=pt.log_p, out_gq=pt.grad_log_q,
+                   out_gp=pt.grad_log_p, log_w=log_w, out_epsilons=hmc.epsilons,
+                   out_common_epsilon=hmc.common_epsilon, ess_base=info["ess_base"],
+                   ess_ais=info["ess_ais"], log_Z=info["log_Z"],
+                   dist0_p_accept_0=info["dist0_p_accept_0"],
+                   average_distance_dist0=info["average_distance_dist0"])
+        out.update(flow_state(nf))
+        npz(f"g8_ais_{tag}.npz", **out)
+
+    # Metropolis / GMM (cfg 1 shape: D=2, M=4)
+    D, K, nodes, M, B, alpha = 2, 2, 8, 4, 64, 2.0
+    nf = make_flow(D, K, nodes, seed=50)
+    with torch.no_grad():
+        nf.q0.log_scale += 2.0         # spread the base over the GMM support
+    torch.manual_seed(0)
+    target = GMM(dim=2, n_mixes=40, loc_scaling=40.0, log_var_scaling=1.0, use_gpu=False,
+                 true_expectation_estimation_n_samples=1000)
+    met = Metropolis(n_ais_intermediate_distributions=M, dim=D, base_log_prob=nf.log_prob,
+                     target_log_prob=target.log_prob, n_updates=2, alpha=alpha, p_target=False,
+                     max_step_size=5.0, min_step_size=2.0, adjust_step_size=True)
+    torch.manual_seed(51)
+    eps0 = torch.randn(B, D)
+    ais = AnnealedImportanceSampler(EpsFlow(nf, eps0), target.log_prob, met, p_target=False, alpha=alpha,
+                                    n_intermediate_distributions=M)
+    in_ns = met.noise_scalings.clone()
+    with Capture() as cap:
+        pt, log_w = ais.sample_and_log_weights(B)
+    info = ais.get_logging_info()
+    out = dict(M=M, n_updates=2, alpha=alpha, p_target=0, eps0=eps0, B_space=ais.B_space,
+               in_noise_scalings=in_ns, noise_x=torch.stack(cap.randn).reshape(M, 2, B, D),
+               noise_u=torch.stack(cap.rand).reshape(M, 2, B), out_x=pt.x, out_log_q=pt.log_q,
+               out_log_p=pt.log_p, log_w=log_w, out_noise_scalings=met.noise_scalings,
+               ess_base=info["ess_base"], ess_ais=info["ess_ais"], log_Z=info["log_Z"],
+               gmm_locs=target.locs, gmm_scales=torch.diagonal(target.scale_trils, dim1=-2, dim2=-1))
+    out.update(flow_state(nf))
+    npz("g8_ais_gmm_metropolis.npz", **out)
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(1)      # deterministic reduction order in the fixtures
+    g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
+    g6_hmc(); g7_metropolis(); g8_full_chain()

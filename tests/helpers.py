@@ -1,0 +1,55 @@
+"""Shared helpers for the test-suite (fixtures loading, tolerances)."""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# BASELINE.json north_star: "log-weights and flow log-probs within 1e-4 relative fp32"
+RTOL = 1e-4
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def close(a, b, rtol=RTOL, atol_scale=1.0):
+    """max|a-b| <= rtol * max(1, max|b|)  — relative to the magnitude of the reference tensor."""
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    if a.shape != b.shape:
+        return False
+    if not np.array_equal(np.isfinite(a), np.isfinite(b)):
+        return False
+    fin = np.isfinite(b)
+    if not fin.any():
+        return True
+    scale = max(1.0, float(np.abs(b[fin]).max())) * atol_scale
+    return float(np.abs(a[fin].astype(np.float64) - b[fin].astype(np.float64)).max()) <= rtol * scale
+
+
+def max_rel_err(a, b):
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    fin = np.isfinite(b)
+    scale = max(1.0, float(np.abs(b[fin]).max())) if fin.any() else 1.0
+    return float(np.abs(a[fin].astype(np.float64) - b[fin].astype(np.float64)).max()) / scale if fin.any() else 0.0
+
+
+def oracle_flow_from_golden(g):
+    """Rebuild the oracle RealNVP whose state_dict is stored in a fixture under 'flow.*'."""
+    from oracle import flow as oflow
+    sd = {k[len("flow."):]: torch.tensor(v) for k, v in g.items() if k.startswith("flow.")}
+    D = sd["q0.loc"].shape[1]
+    K = len([k for k in sd if k.endswith(".log_S")])
+    W = sd["flows.0.flows.1.param_map.net.0.weight"].shape[0]
+    assert W % D == 0
+    nf = oflow.make_realnvp(D, K, W // D)
+    nf.load_state_dict(sd)
+    return nf
