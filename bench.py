@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""bench.py — AIS samples/s on the BASELINE headline workload.
+
+Workload (BASELINE.json metric / north_star): ManyWell-32 target, RealNVP flow of the
+reference's ManyWell-32 architecture (10 x [MLP 16-320-320-32 coupling + InvertibleAffine]), 1024 chains per
+GPU, 8 intermediate distributions (linear beta), HMC with 5 leapfrog steps / 1 outer step, alpha = 2,
+p_target = False, step-size tuning ON (as in training).  Random-init weights (seeded; last coupling
+layer re-drawn N(0, 0.05^2) so log-dets are non-trivial), synthetic noise drawn on the device inside the
+timed region.  A "step" is one `AnnealedImportanceSampler.sample_and_log_weights(1024)` call per GPU
+(+ the RCCL all-gather of the particles when --gpus > 1).
+
+Prints ONE JSON line (rank 0): value = chains produced by all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, K_LAYERS, NODES, B_PER_GPU, M, L = 32, 10, 10, 1024, 8, 5
+ALPHA = 2.0
+EPS_INIT = 0.2                       # close to the tuned value (0.18 for the p^2/q target)
+F_FWD = K_LAYERS * 2 * (16 * 320 + 320 * 320 + 2 * 320 * 16) + 2 * K_LAYERS * D * D    # 2 375 680 flop / sample / pass
+PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 dense peak
+
+
+def build_flow_state(seed=0):
+    """Seeded RealNVP parameters (CPU tensors, identical on every rank and for the CPU baseline)."""
+    from fab_torch_amd.flow import RealNVP
+    torch.manual_seed(seed)
+    flow = RealNVP(D, K_LAYERS, NODES)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for l1, l2, l3, aff in flow._layers():
+            l3.weight.copy_(torch.randn(l3.weight.shape, generator=g) * 0.05)
+            l3.bias.copy_(torch.randn(l3.bias.shape, generator=g) * 0.05)
+    return flow
+
+
+def cpu_baseline(flow_state, n_calls=2):
+    """The oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores on the
+    same workload; bounded sample: n_calls full AIS calls of 1024 chains after one warm-up call."""
+    from oracle import ais as oais, flow as oflow, targets as otgt
+    nf = oflow.make_realnvp(D, K_LAYERS, NODES)
+    nf.load_state_dict(flow_state)
+    target = otgt.ManyWell(D)
+    hmc = oais.HMC(M, D, nf.log_prob, target.log_prob, alpha=ALPHA, p_target=False, epsilon=EPS_INIT, L=L)
+    ais = oais.AIS(lambda e: tuple(t.detach() for t in nf.sample_eps(e)), nf.log_prob, target.log_prob, hmc,
+                   False, ALPHA, M)
+
+    def call():
+        eps0 = torch.randn(B_PER_GPU, D)
+        noise_p = torch.randn(M, 1, B_PER_GPU, D)
+        noise_e = torch.empty(M, 1, B_PER_GPU).exponential_()
+        return ais.sample_and_log_weights(eps0, noise_p, noise_e)
+
+    call()
+    t0 = time.perf_counter()
+    for _ in range(n_calls):
+        _, _, info = call()
+    dt = (time.perf_counter() - t0) / n_calls
+    return {"value": B_PER_GPU / dt, "unit": "AIS samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_calls} calls of sample_and_log_weights({B_PER_GPU}) after 1 warm-up, fp32, "
+                      f"oracle/ (PyTorch-CPU eager + autograd per leapfrog)", "sec_per_call": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    distributed = world > 1
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the fab_torch_amd hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import fab_torch_amd as fa
+    from fab_torch_amd import parallel
+
+    flow = build_flow_state(0)
+    flow_state = {k: v.clone() for k, v in flow._nf_model.state_dict().items()}
+    flow = flow.to(dev).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=ALPHA, p_target=False,
+                                   epsilon=EPS_INIT, n_outer=1, L=L).to(dev)
+    ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target=False, alpha=ALPHA,
+                                       n_intermediate_distributions=M)
+    torch.manual_seed(1234 + rank)          # per-rank noise streams
+
+    def step():
+        pt, log_w = ais.sample_and_log_weights(B_PER_GPU)
+        if distributed:
+            return parallel.gather_particles(pt.x, log_w, pt.log_q, B_PER_GPU)
+        return pt.x, log_w, pt.log_q
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    info = ais.get_logging_info()
+    ess_all = float(fa.effective_sample_size(out[1]).item())
+
+    # ---- roofline of the dominant kernel (k_hmc_step): live HIP-event timing on the launch stream -----
+    roof = None
+    if rank == 0:
+        from fab_torch_amd.transition_operators import create_point
+        x0, _ = flow.native_sample(torch.randn(B_PER_GPU, D, device=dev))
+        pt = create_point(x0, flow, target, with_grad=True)
+        hmc.set_eval_mode(True)
+        for _ in range(3):
+            hmc.transition(pt, 4, float(ais.B_space[4]))
+        n_t = 10
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_t + 1)]
+        ev[0].record()
+        for i in range(n_t):
+            hmc.transition(pt, 4, float(ais.B_space[4]))
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n_t))
+        t_kernel = ms[n_t // 2] * 1e-3
+        flop = B_PER_GPU * L * 2 * F_FWD                  # flow fwd + d/dx per leapfrog (target flops ignored)
+        ach = flop / t_kernel / 1e12
+        roof = {"bound": "mfma", "kernel": "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)", "achieved": ach,
+                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
+                "traffic": None, "ms_per_launch": t_kernel * 1e3, "flop_per_launch": flop}
+        hmc.set_eval_mode(False)
+
+    if rank == 0:
+        total = world * B_PER_GPU * args.steps
+        line = {
+            "metric": "AIS samples/sec (+ESS), ManyWell-32, 8 intermediate dists",
+            "value": total / elapsed, "unit": "AIS samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "ManyWell-32 AIS: RealNVP 10x(16-320-320-32)+InvAffine, HMC L=5 n_outer=1, "
+                                   "M=8 linear beta, alpha=2 (target p^2/q), step-size tuning on",
+                       "chains_per_gpu": B_PER_GPU, "global_chains": world * B_PER_GPU,
+                       "parallelism": f"chains sharded x{world}, one all-gather" if world > 1 else "single GPU"},
+            "ess_ais": info["ess_ais"], "ess_gathered": ess_all, "log_Z": info["log_Z"],
+            "p_accept_first": info.get("dist0_p_accept_0"),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(flow_state)
+            line["speedup_vs_cpu"] = line["value"] / line["cpu_baseline"]["value"]
+        print(json.dumps(line))
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,20 @@
+"""fab_torch_amd — MI355X-native (gfx950) AIS / flow-density hot path of FAB (lollcat/fab-torch).
+
+Python mirror of the reference's plug-in interfaces over the C ABI of libfabhip.so
+(include/fabhip.h).  Importing the package does not touch the GPU; the first call into the hot path
+loads (and, when hipcc is present and sources are newer, rebuilds) the HIP library and fails loudly if
+that is impossible — there is no CPU fallback."""
+from .point import Point
+from .flow import RealNVP, make_wrapped_normflow_realnvp
+from .targets import ManyWellEnergy, GMM
+from .transition_operators import TransitionOperator, HamiltonianMonteCarlo, Metropolis, create_point
+from .ais import AnnealedImportanceSampler, LoggingInfo
+from .numerical import effective_sample_size, ess_and_log_z
+from .resample import resample, multinomial_indices, systematic_indices, multinomial_torch_compat, gather_rows
+
+__all__ = [
+    "Point", "RealNVP", "make_wrapped_normflow_realnvp", "ManyWellEnergy", "GMM", "TransitionOperator",
+    "HamiltonianMonteCarlo", "Metropolis", "create_point", "AnnealedImportanceSampler", "LoggingInfo",
+    "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
+    "multinomial_torch_compat", "gather_rows",
+]

@@ -1,0 +1,189 @@
+"""ctypes binding of libfabhip.so (include/fabhip.h).  PyTorch is used only for device memory and the
+current HIP stream; no torch type crosses the boundary (raw device pointers + sizes).
+
+The product path FAILS LOUDLY when the HIP library is missing: there is no CPU fallback."""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+from . import _build
+
+MAX_LAYERS = 64
+_FP = C.POINTER(C.c_float)
+
+
+class FabhipError(RuntimeError):
+    pass
+
+
+class FlowParams(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_layers", C.c_int32), ("width", C.c_int32)] + \
+               [(n, C.c_void_p * MAX_LAYERS) for n in
+                ("w1", "b1", "w2", "b2", "w3", "b3", "lu_L", "lu_U", "log_S", "sign_S", "perm_P")] + \
+               [("loc", C.c_void_p), ("log_scale", C.c_void_p)]
+
+
+class Flow(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("n_layers", C.c_int32), ("width", C.c_int32), ("packed", C.c_void_p)]
+
+
+class Target(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("dim", C.c_int32), ("a", C.c_float), ("b", C.c_float), ("c", C.c_float),
+                ("log_norm", C.c_float), ("n_mix", C.c_int32), ("locs", C.c_void_p), ("scales", C.c_void_p)]
+
+
+class Point(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("log_q", C.c_void_p), ("log_p", C.c_void_p), ("grad_log_q", C.c_void_p),
+                ("grad_log_p", C.c_void_p)]
+
+
+class Anneal(C.Structure):
+    _fields_ = [("c_q", C.c_float), ("c_p", C.c_float), ("g_q", C.c_float), ("g_p", C.c_float)]
+
+
+class HmcArgs(C.Structure):
+    _fields_ = [("flow", Flow), ("target", Target), ("point", Point), ("B", C.c_int64), ("n_valid", C.c_void_p),
+                ("cur", Anneal), ("next", Anneal), ("log_w", C.c_void_p), ("noise_p", C.c_void_p),
+                ("noise_e", C.c_void_p), ("epsilons", C.c_void_p), ("common_epsilon", C.c_void_p),
+                ("mass", C.c_void_p), ("n_outer", C.c_int32), ("L", C.c_int32), ("max_grad", C.c_float),
+                ("target_p_accept", C.c_float), ("tune", C.c_int32), ("p_accept", C.c_void_p),
+                ("avg_distance", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class MetropolisArgs(C.Structure):
+    _fields_ = [("flow", Flow), ("target", Target), ("point", Point), ("B", C.c_int64), ("n_valid", C.c_void_p),
+                ("cur", Anneal), ("next", Anneal), ("log_w", C.c_void_p), ("noise_x", C.c_void_p),
+                ("noise_u", C.c_void_p), ("noise_scalings", C.c_void_p), ("n_updates", C.c_int32),
+                ("target_p_accept", C.c_float), ("tune", C.c_int32), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+class AisArgs(C.Structure):
+    _fields_ = [("flow", Flow), ("target", Target), ("B", C.c_int64), ("M", C.c_int32), ("betas", C.POINTER(C.c_double)),
+                ("alpha", C.c_double), ("p_target", C.c_int32), ("transition", C.c_int32), ("eps0", C.c_void_p),
+                ("noise_a", C.c_void_p), ("noise_b", C.c_void_p), ("step_state", C.c_void_p),
+                ("common_epsilon", C.c_void_p), ("mass", C.c_void_p), ("n_inner", C.c_int32), ("L", C.c_int32),
+                ("max_grad", C.c_float), ("target_p_accept", C.c_float), ("tune", C.c_int32), ("point", Point),
+                ("log_w", C.c_void_p), ("n_valid", C.c_void_p), ("stats", C.c_void_p), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_size_t)]
+
+
+TARGET_MANYWELL, TARGET_GMM = 1, 2
+TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
+
+_lib = None
+_lock = threading.Lock()
+
+# every symbol include/fabhip.h declares (checked by tests/test_cabi_symbols.py)
+SYMBOLS = [
+    "fabhip_strerror", "fabhip_version", "fabhip_flow_packed_floats", "fabhip_flow_pack", "fabhip_flow_sample",
+    "fabhip_flow_log_prob", "fabhip_target_log_prob", "fabhip_create_point", "fabhip_anneal_coefs",
+    "fabhip_hmc_workspace_bytes", "fabhip_hmc_transition", "fabhip_metropolis_workspace_bytes",
+    "fabhip_metropolis_transition", "fabhip_ais_workspace_bytes", "fabhip_ais_run", "fabhip_ess_workspace_bytes",
+    "fabhip_ess_logz", "fabhip_multinomial_torch_workspace_bytes", "fabhip_multinomial_torch",
+    "fabhip_resample_workspace_bytes", "fabhip_resample_multinomial", "fabhip_resample_systematic",
+    "fabhip_gather_rows",
+]
+
+
+def _declare(lib):
+    i32, i64, vp, sz, dbl = C.c_int32, C.c_int64, C.c_void_p, C.c_size_t, C.c_double
+    lib.fabhip_strerror.restype = C.c_char_p
+    lib.fabhip_strerror.argtypes = [C.c_int]
+    lib.fabhip_version.restype = C.c_int
+    lib.fabhip_flow_packed_floats.restype = i64
+    lib.fabhip_flow_packed_floats.argtypes = [i32, i32, i32]
+    lib.fabhip_flow_pack.argtypes = [C.POINTER(FlowParams), vp, vp]
+    lib.fabhip_flow_sample.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp]
+    lib.fabhip_flow_log_prob.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp]
+    lib.fabhip_target_log_prob.argtypes = [C.POINTER(Target), vp, vp, vp, i64, vp]
+    lib.fabhip_create_point.argtypes = [C.POINTER(Flow), C.POINTER(Target), C.POINTER(Point), i32, i64, vp]
+    lib.fabhip_anneal_coefs.restype = None
+    lib.fabhip_anneal_coefs.argtypes = [dbl, dbl, i32, C.POINTER(Anneal)]
+    lib.fabhip_hmc_workspace_bytes.restype = sz
+    lib.fabhip_hmc_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.fabhip_hmc_transition.argtypes = [C.POINTER(HmcArgs), vp]
+    lib.fabhip_metropolis_workspace_bytes.restype = sz
+    lib.fabhip_metropolis_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.fabhip_metropolis_transition.argtypes = [C.POINTER(MetropolisArgs), vp]
+    lib.fabhip_ais_workspace_bytes.restype = sz
+    lib.fabhip_ais_workspace_bytes.argtypes = [i64, i32, i32]
+    lib.fabhip_ais_run.argtypes = [C.POINTER(AisArgs), vp]
+    lib.fabhip_ess_workspace_bytes.restype = sz
+    lib.fabhip_ess_workspace_bytes.argtypes = [i64]
+    lib.fabhip_ess_logz.argtypes = [vp, i64, vp, dbl, vp, vp, sz, vp]
+    lib.fabhip_multinomial_torch_workspace_bytes.restype = sz
+    lib.fabhip_multinomial_torch_workspace_bytes.argtypes = [i64]
+    lib.fabhip_multinomial_torch.argtypes = [vp, i64, vp, i64, vp, vp, sz, vp]
+    lib.fabhip_resample_workspace_bytes.restype = sz
+    lib.fabhip_resample_workspace_bytes.argtypes = [i64]
+    lib.fabhip_resample_multinomial.argtypes = [vp, i64, vp, i64, vp, vp, sz, vp]
+    lib.fabhip_resample_systematic.argtypes = [vp, i64, dbl, i64, vp, vp, sz, vp]
+    lib.fabhip_gather_rows.argtypes = [vp, vp, vp, i64, i64, vp]
+    for name in SYMBOLS:
+        fn = getattr(lib, name)
+        if fn.restype is C.c_int and name not in ("fabhip_version",):
+            pass
+    return lib
+
+
+def load():
+    """Load (building first when the sources are newer and hipcc is present) libfabhip.so."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        path = _build.LIB
+        if _build.is_stale():
+            try:
+                _build.build(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                if not os.path.exists(path):
+                    raise FabhipError(
+                        "libfabhip.so is missing and could not be built — the fab_torch_amd hot path has no CPU "
+                        f"fallback ({e})") from e
+        try:
+            _lib = _declare(C.CDLL(path))
+        except OSError as e:
+            raise FabhipError(f"cannot load {path}: {e} (no CPU fallback exists)") from e
+        return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().fabhip_strerror(rc).decode()
+        raise FabhipError(f"fabhip {what} failed: {msg} (code {rc})")
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a contiguous float32/float64/int tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), "fabhip needs contiguous tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise FabhipError(f"{what} must live on the GPU: fab_torch_amd has no CPU path (got device {t.device})")
+
+
+class Workspace:
+    """Grow-only byte workspace per device (caller-owned scratch of the C ABI)."""
+
+    def __init__(self):
+        self._buf = {}
+
+    def get(self, nbytes: int, device) -> torch.Tensor:
+        key = str(device)
+        buf = self._buf.get(key)
+        if buf is None or buf.numel() < nbytes:
+            buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+            self._buf[key] = buf
+        return buf

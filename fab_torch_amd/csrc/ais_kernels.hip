@@ -1,0 +1,755 @@
+// AIS inner loop: point creation, HMC / Metropolis transitions with on-device step-size adaptation,
+// NaN/inf compaction, log-weight accumulation, and the one-call AIS driver.
+//
+// One workgroup (256 threads, one wave per SIMD) owns 16 chains for a whole transition: every
+// leapfrog's flow log-density + gradient (fp32 MFMA, flow_device.h), target log-density + gradient,
+// momentum/position updates, the Metropolis test, the in-place commit and the AIS log-weight
+// increment happen inside ONE launch; the only cross-workgroup quantity (mean acceptance, needed
+// for the shared `common_epsilon`) is reduced by a one-wave follow-up kernel from per-block partials
+// in a fixed order (deterministic).
+#include "flow_device.h"
+#include "target_device.h"
+#include "launch.h"
+
+#pragma clang fp contract(off)   // keep a*b+c un-fused in the elementwise code, like the eager CPU reference
+
+namespace fab {
+
+struct PointDev {
+    float *x, *lq, *lp, *gq, *gp;
+};
+static inline PointDev make_point_dev(const fabhip_point& p) { return PointDev{p.x, p.log_q, p.log_p, p.grad_log_q, p.grad_log_p}; }
+
+struct ExtraLds {   // per-tile HMC state appended after the flow's LDS plan (floats)
+    int o_XP, o_P, o_GU, o_GP, o_ROW, total;
+};
+static inline ExtraLds make_extra_lds(const FlowLds& l, int D) {
+    ExtraLds e;
+    int o = l.total;
+    e.o_XP = o; o += ROWS * D;
+    e.o_P = o; o += ROWS * D;
+    e.o_GU = o; o += ROWS * D;
+    e.o_GP = o; o += ROWS * D;
+    e.o_ROW = o; o += 2 * ROWS;
+    e.total = (o + 3) & ~3;
+    return e;
+}
+
+__device__ __forceinline__ void load_state_to_u0(const FlowLds& l, int D, float* lds, const float* XP, const Tid& t) {
+    for (int e = t.tid; e < ROWS * l.DS; e += NTHREADS) {
+        const int r = e / l.DS, j = e % l.DS;
+        lds[l.o_U0 + e] = j < D ? XP[r * D + j] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void zero_dp(const FlowLds& l, float* lds, const Tid& t) {
+    for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) lds[l.o_DP + e] = 0.f;
+}
+
+__device__ __forceinline__ float clamp_nan0(float g, float mg) {
+    // torch.nan_to_num(torch.clamp(g, -mg, mg), nan=0): NaN -> 0, +-inf -> +-mg   (hmc.py:194-199)
+    return (g != g) ? 0.f : fminf(fmaxf(g, -mg), mg);
+}
+
+// ------------------------------------------------------------------------------------------------
+// create_point: log q (+grad), log p (+grad) at point.x      (fab/sampling_methods/base.py:59-72)
+// ------------------------------------------------------------------------------------------------
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_create_point(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
+                                                           TargetDev tg, PointDev pt, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const int D = f.D;
+    const long row0 = (long)blockIdx.x * ROWS;
+    float* XP = lds + x.o_XP;
+    float* GP = lds + x.o_GP;
+    zero_dp(l, lds, t);
+    for (int e = t.tid; e < ROWS * D; e += NTHREADS) {
+        const long g = row0 + e / D;
+        XP[e] = g < B ? pt.x[g * D + e % D] : 0.f;
+    }
+    __syncthreads();
+    load_state_to_u0(l, D, lds, XP, t);
+    __syncthreads();
+    int goff = 0;
+    const float lq = flow_log_prob_tile<NTWM, GRAD>(f, l, packed, lds, t, &goff);
+    const float lp = target_tile<GRAD>(tg, XP, D, GP, D, t);
+    const long g = row0 + t.row;
+    if (g < B) {
+        if (t.c == 0) { pt.lq[g] = lq; pt.lp[g] = lp; }
+        if (GRAD) {
+            for (int j = t.c; j < D; j += 16) {
+                pt.gq[g * D + j] = lds[goff + t.row * l.DS + j];
+                pt.gp[g * D + j] = GP[t.row * D + j];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// AIS chain initialisation (ais.py:55-64): x, log_q0 = flow.sample(eps0); point = create_point(x);
+// log_w = pi_beta1(point) - log_q0.   With GRAD (HMC) log q is re-evaluated through log_prob, as the
+// reference does (base.py:65-68 ignores the supplied log_q_x).
+// ------------------------------------------------------------------------------------------------
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_ais_init(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
+                                                       TargetDev tg, const float* __restrict__ eps0, PointDev pt,
+                                                       float* __restrict__ log_w, fabhip_anneal an, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const int D = f.D;
+    const long row0 = (long)blockIdx.x * ROWS;
+    float* XP = lds + x.o_XP;
+    float* GP = lds + x.o_GP;
+    zero_dp(l, lds, t);
+    for (int e = t.tid; e < ROWS * l.DS; e += NTHREADS) {
+        const int r = e / l.DS, j = e % l.DS;
+        const long g = row0 + r;
+        lds[l.o_U0 + e] = (j < D && g < B) ? eps0[g * D + j] : 0.f;
+    }
+    __syncthreads();
+    int xoff = 0;
+    const float lq0 = flow_sample_tile<NTWM>(f, l, packed, lds, t, &xoff);
+    for (int j = t.c; j < D; j += 16) XP[t.row * D + j] = lds[xoff + t.row * l.DS + j];
+    __syncthreads();
+    float lq = lq0;
+    int goff = 0;
+    if (GRAD) {
+        load_state_to_u0(l, D, lds, XP, t);
+        __syncthreads();
+        lq = flow_log_prob_tile<NTWM, true>(f, l, packed, lds, t, &goff);
+    }
+    const float lp = target_tile<GRAD>(tg, XP, D, GP, D, t);
+    const long g = row0 + t.row;
+    if (g < B) {
+        for (int j = t.c; j < D; j += 16) {
+            pt.x[g * D + j] = XP[t.row * D + j];
+            if (GRAD) {
+                pt.gq[g * D + j] = lds[goff + t.row * l.DS + j];
+                pt.gp[g * D + j] = GP[t.row * D + j];
+            }
+        }
+        if (t.c == 0) {
+            pt.lq[g] = lq;
+            pt.lp[g] = lp;
+            log_w[g] = (an.c_q * lq + an.c_p * lp) - lq0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One HMC outer step (hmc.py:129-160) for 16 chains per workgroup.
+// ------------------------------------------------------------------------------------------------
+struct HmcK {
+    PointDev cur, start, prop_out;   // prop_out.x == nullptr: do not store the proposal
+    long B;
+    const int* n_valid;
+    fabhip_anneal c, nx;
+    float* log_w;                    // nullptr: no log-weight update in this launch
+    const float* noise_p;            // [B][D] for this outer step
+    const float* noise_e;            // [B]
+    const float* eps_ptr;            // epsilons[i-1][n]
+    const float* ceps_ptr;           // common_epsilon
+    const float* mass;
+    int L;
+    float max_grad;
+    float* part_acc;                 // [nblk] sum of min(1, acceptance prob)
+    float* part_dist;                // [nblk] sum of the store_info distance
+};
+
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_hmc_step(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
+                                                       TargetDev tg, HmcK a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const int D = f.D;
+    const long nv = a.n_valid ? (long)*a.n_valid : a.B;
+    const long row0 = (long)blockIdx.x * ROWS;
+    if (row0 >= nv) {
+        if (t.tid == 0) { a.part_acc[blockIdx.x] = 0.f; a.part_dist[blockIdx.x] = 0.f; }
+        return;
+    }
+    float* XP = lds + x.o_XP;
+    float* P = lds + x.o_P;
+    float* GU = lds + x.o_GU;
+    float* GP = lds + x.o_GP;
+    float* ROWB = lds + x.o_ROW;
+    const long g = row0 + t.row;
+    const bool active = g < nv;
+    const float eps = *a.eps_ptr + *a.ceps_ptr;                     // get_epsilon (hmc.py:90-100)
+    zero_dp(l, lds, t);
+    float k0 = 0.f;
+    for (int j = t.c; j < D; j += 16) {
+        const float m = a.mass[j];
+        float xs = 0.f, p = 0.f, gu = 0.f;
+        if (active) {
+            xs = a.start.x[g * D + j];
+            p = a.noise_p[g * D + j] * m;                           // hmc.py:134 (x mass, not sqrt)
+            const float gr = -(a.c.g_q * a.start.gq[g * D + j] + a.c.g_p * a.start.gp[g * D + j]);
+            gu = clamp_nan0(gr, a.max_grad);
+        }
+        XP[t.row * D + j] = xs; P[t.row * D + j] = p; GU[t.row * D + j] = gu;
+        k0 += p * p / m;
+    }
+    k0 = row16_sum(k0) / 2.f;
+    float lq_c = 0.f, lp_c = 0.f;
+    if (active) { lq_c = a.cur.lq[g]; lp_c = a.cur.lp[g]; }
+    const float logp_cur = (a.c.c_q * lq_c + a.c.c_p * lp_c) - k0;  // -U(current) - K(p0)
+    float lq = 0.f, lp = 0.f;
+    int goff = 0;
+    for (int step = 0; step < a.L; ++step) {
+        for (int j = t.c; j < D; j += 16) {
+            const float m = a.mass[j];
+            float p = P[t.row * D + j] - eps * GU[t.row * D + j] / 2.f;
+            const float xn = XP[t.row * D + j] + eps / m * p;
+            P[t.row * D + j] = p; XP[t.row * D + j] = xn;
+        }
+        __syncthreads();
+        load_state_to_u0(l, D, lds, XP, t);
+        __syncthreads();
+        lq = flow_log_prob_tile<NTWM, true>(f, l, packed, lds, t, &goff);
+        lp = target_tile<true>(tg, XP, D, GP, D, t);
+        for (int j = t.c; j < D; j += 16) {
+            const float gr = -(a.c.g_q * lds[goff + t.row * l.DS + j] + a.c.g_p * GP[t.row * D + j]);
+            const float gu = clamp_nan0(gr, a.max_grad);
+            GU[t.row * D + j] = gu;
+            P[t.row * D + j] = P[t.row * D + j] - eps * gu / 2.f;
+        }
+    }
+    // Metropolis test (hmc.py:105-124)
+    float k1 = 0.f, dist2 = 0.f;
+    for (int j = t.c; j < D; j += 16) {
+        const float p = P[t.row * D + j];
+        k1 += p * p / a.mass[j];
+        if (active) { const float dx = a.cur.x[g * D + j] - XP[t.row * D + j]; dist2 += dx * dx; }
+    }
+    k1 = row16_sum(k1) / 2.f;
+    dist2 = row16_sum(dist2);
+    const float logp_prop = (a.c.c_q * lq + a.c.c_p * lp) - k1;
+    const float delta = logp_prop - logp_cur;
+    const bool valid = isfinite(delta);
+    const float dd = valid ? delta : -INFINITY;
+    bool accept = false;
+    float contrib = 0.f, dist = 0.f;
+    if (active) {
+        accept = valid && (dd > -a.noise_e[g]);
+        contrib = expf(fminf(dd, 0.f));
+        dist = accept ? 0.f : sqrtf(dist2);      // store_info sees the already-committed point (hmc.py:154-156)
+    }
+    if (a.prop_out.x && active) {                 // n_outer > 1: the next outer step starts from the PROPOSAL
+        for (int j = t.c; j < D; j += 16) {
+            a.prop_out.x[g * D + j] = XP[t.row * D + j];
+            a.prop_out.gq[g * D + j] = lds[goff + t.row * l.DS + j];
+            a.prop_out.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) { a.prop_out.lq[g] = lq; a.prop_out.lp[g] = lp; }
+    }
+    if (accept) {                                 // current_point[accept] = point[accept]
+        for (int j = t.c; j < D; j += 16) {
+            a.cur.x[g * D + j] = XP[t.row * D + j];
+            a.cur.gq[g * D + j] = lds[goff + t.row * l.DS + j];
+            a.cur.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) { a.cur.lq[g] = lq; a.cur.lp[g] = lp; }
+    }
+    if (a.log_w && active && t.c == 0) {          // ais.py:93-100
+        const float lqf = accept ? lq : lq_c, lpf = accept ? lp : lp_c;
+        const float num = a.nx.c_q * lqf + a.nx.c_p * lpf;
+        const float den = a.c.c_q * lqf + a.c.c_p * lpf;
+        a.log_w[g] = a.log_w[g] + (num - den);
+    }
+    if (t.c == 0) { ROWB[t.row] = contrib; ROWB[ROWS + t.row] = dist; }
+    __syncthreads();
+    if (t.tid == 0) {
+        float s = 0.f, d = 0.f;
+        for (int r = 0; r < ROWS; ++r) { s += ROWB[r]; d += ROWB[ROWS + r]; }
+        a.part_acc[blockIdx.x] = s;
+        a.part_dist[blockIdx.x] = d;
+    }
+}
+
+// step-size adaptation from the block partials (hmc.py:122-123,162-170), fixed summation order
+__global__ void k_hmc_adapt(const float* __restrict__ part_acc, const float* __restrict__ part_dist, int nblk,
+                            const int* n_valid, long B, float* eps_ptr, float* ceps_ptr, float target_p_accept,
+                            int tune, float* p_accept_out, float* dist_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const long nv = n_valid ? (long)*n_valid : B;
+    if (nv <= 0) return;
+    float s = 0.f, d = 0.f;
+    for (int i = 0; i < nblk; ++i) { s += part_acc[i]; d += part_dist[i]; }
+    const float log_mean = logf(s) - logf((float)nv);
+    if (p_accept_out) *p_accept_out = expf(log_mean);
+    if (dist_out) *dist_out = d / (float)nv;
+    if (tune) {
+        if (log_mean > logf(target_p_accept)) {
+            *eps_ptr = *eps_ptr * 1.05f;
+            *ceps_ptr = *ceps_ptr * 1.02f;
+        } else {
+            *eps_ptr = *eps_ptr / 1.05f;
+            *ceps_ptr = *ceps_ptr / 1.02f;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Metropolis transition: all n_updates for 16 chains per workgroup (metropolis.py:51-74).
+// ------------------------------------------------------------------------------------------------
+struct MetK {
+    PointDev cur;
+    long B;
+    const int* n_valid;
+    fabhip_anneal c, nx;
+    float* log_w;
+    const float* noise_x;            // [n_updates][B][D]
+    const float* noise_u;            // [n_updates][B]
+    const float* scalings;           // noise_scalings[i-1][0..n_updates)
+    int n_updates;
+    float* part_acc;                 // [n_updates][nblk]
+    int nblk;
+};
+
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_metropolis(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
+                                                         TargetDev tg, MetK a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const int D = f.D;
+    const long nv = a.n_valid ? (long)*a.n_valid : a.B;
+    const long row0 = (long)blockIdx.x * ROWS;
+    if (row0 >= nv) {
+        if (t.tid < a.n_updates) a.part_acc[t.tid * a.nblk + blockIdx.x] = 0.f;
+        return;
+    }
+    float* XC = lds + x.o_XP;        // current positions
+    float* XN = lds + x.o_P;         // proposals
+    float* GP = lds + x.o_GP;
+    float* ROWB = lds + x.o_ROW;
+    const long g = row0 + t.row;
+    const bool active = g < nv;
+    zero_dp(l, lds, t);
+    for (int j = t.c; j < D; j += 16) XC[t.row * D + j] = active ? a.cur.x[g * D + j] : 0.f;
+    float lq_c = 0.f, lp_c = 0.f;
+    if (active) { lq_c = a.cur.lq[g]; lp_c = a.cur.lp[g]; }
+    const float prev_lp = a.c.c_q * lq_c + a.c.c_p * lp_c;     // computed once, never refreshed (metropolis.py:53)
+    bool changed = false;
+    for (int n = 0; n < a.n_updates; ++n) {
+        const float sc = a.scalings[n];
+        for (int j = t.c; j < D; j += 16) {
+            const float nz = active ? a.noise_x[((long)n * a.B + g) * D + j] : 0.f;
+            XN[t.row * D + j] = XC[t.row * D + j] + nz * sc;
+        }
+        __syncthreads();
+        load_state_to_u0(l, D, lds, XN, t);
+        __syncthreads();
+        int goff;
+        const float lq = flow_log_prob_tile<NTWM, false>(f, l, packed, lds, t, &goff);
+        const float lp = target_tile<false>(tg, XN, D, GP, D, t);
+        float acc = expf((a.c.c_q * lq + a.c.c_p * lp) - prev_lp);
+        if (!isfinite(acc)) acc = 0.f;                          // nan_to_num(nan=0, posinf=0, neginf=0)
+        bool accept = false;
+        if (active) accept = acc > a.noise_u[(long)n * a.B + g];
+        if (accept) {
+            for (int j = t.c; j < D; j += 16) XC[t.row * D + j] = XN[t.row * D + j];
+            lq_c = lq; lp_c = lp; changed = true;
+        }
+        if (t.c == 0) ROWB[t.row] = active ? fminf(acc, 1.f) : 0.f;
+        __syncthreads();
+        if (t.tid == 0) {
+            float s = 0.f;
+            for (int r = 0; r < ROWS; ++r) s += ROWB[r];
+            a.part_acc[n * a.nblk + blockIdx.x] = s;
+        }
+        __syncthreads();
+    }
+    if (active) {
+        if (changed) {
+            for (int j = t.c; j < D; j += 16) a.cur.x[g * D + j] = XC[t.row * D + j];
+            if (t.c == 0) { a.cur.lq[g] = lq_c; a.cur.lp[g] = lp_c; }
+        }
+        if (a.log_w && t.c == 0) {
+            const float num = a.nx.c_q * lq_c + a.nx.c_p * lp_c;
+            const float den = a.c.c_q * lq_c + a.c.c_p * lp_c;
+            a.log_w[g] = a.log_w[g] + (num - den);
+        }
+    }
+}
+
+__global__ void k_metropolis_adapt(const float* __restrict__ part_acc, int nblk, int n_updates, const int* n_valid,
+                                   long B, float* scalings, float target_p_accept, int tune) {
+    const int n = threadIdx.x;
+    if (blockIdx.x != 0 || n >= n_updates || !tune) return;
+    const long nv = n_valid ? (long)*n_valid : B;
+    if (nv <= 0) return;
+    float s = 0.f;
+    for (int i = 0; i < nblk; ++i) s += part_acc[n * nblk + i];
+    const float p_accept = s / (float)nv;
+    scalings[n] = (p_accept > target_p_accept) ? scalings[n] * 1.05f : scalings[n] / 1.05f;
+}
+
+// ------------------------------------------------------------------------------------------------
+// _remove_nan_and_infs (ais.py:190-213): stable compaction of the rows with finite log_p and log_q.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_valid_scan(const float* __restrict__ lq, const float* __restrict__ lp,
+                                                     const int* n_in_ptr, long B, int* __restrict__ dest,
+                                                     int* __restrict__ n_out) {
+    __shared__ int wsum[16];
+    __shared__ int running;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const long n_in = n_in_ptr ? (long)*n_in_ptr : B;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (long base = 0; base < n_in; base += 1024) {
+        const long r = base + tid;
+        const bool v = r < n_in && isfinite(lq[r]) && isfinite(lp[r]);
+        const unsigned long long bal = __ballot(v);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int i = 0; i < 16; ++i) { if (i < w) woff += wsum[i]; tot += wsum[i]; }
+        if (r < n_in) dest[r] = v ? running + woff + pre : -1;
+        __syncthreads();
+        if (tid == 0) running += tot;
+        __syncthreads();
+    }
+    if (tid == 0) *n_out = running;
+}
+
+struct CompactK {
+    PointDev pt;
+    float* log_w;
+    float* tmp;            // [B][3D+3]
+    const int* dest;
+    const int* n_in_ptr;
+    const int* n_out_ptr;
+    long B;
+    int D;
+};
+
+__global__ void k_compact_scatter(CompactK a) {
+    const long n_in = a.n_in_ptr ? (long)*a.n_in_ptr : a.B;
+    const long n_out = *a.n_out_ptr;
+    if (n_out == n_in) return;
+    const int D = a.D, RW = 3 * D + 3;
+    const bool hg = a.pt.gq != nullptr;
+    for (long r = blockIdx.x; r < n_in; r += gridDim.x) {
+        const int d = a.dest[r];
+        if (d < 0) continue;
+        float* o = a.tmp + (long)d * RW;
+        for (int j = threadIdx.x; j < D; j += blockDim.x) {
+            o[j] = a.pt.x[r * D + j];
+            if (hg) { o[D + j] = a.pt.gq[r * D + j]; o[2 * D + j] = a.pt.gp[r * D + j]; }
+        }
+        if (threadIdx.x == 0) { o[3 * D] = a.pt.lq[r]; o[3 * D + 1] = a.pt.lp[r]; o[3 * D + 2] = a.log_w[r]; }
+    }
+}
+
+__global__ void k_compact_copyback(CompactK a) {
+    const long n_in = a.n_in_ptr ? (long)*a.n_in_ptr : a.B;
+    const long n_out = *a.n_out_ptr;
+    if (n_out == n_in) return;
+    const int D = a.D, RW = 3 * D + 3;
+    const bool hg = a.pt.gq != nullptr;
+    for (long r = blockIdx.x; r < n_out; r += gridDim.x) {
+        const float* o = a.tmp + r * RW;
+        for (int j = threadIdx.x; j < D; j += blockDim.x) {
+            a.pt.x[r * D + j] = o[j];
+            if (hg) { a.pt.gq[r * D + j] = o[D + j]; a.pt.gp[r * D + j] = o[2 * D + j]; }
+        }
+        if (threadIdx.x == 0) { a.pt.lq[r] = o[3 * D]; a.pt.lp[r] = o[3 * D + 1]; a.log_w[r] = o[3 * D + 2]; }
+    }
+}
+
+__global__ void k_sub(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ o, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) o[i] = a[i] - b[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int nblk_of(long B) { return (int)((B + ROWS - 1) / ROWS); }
+
+template <int NTWM>
+static int launch_create_point(const FlowDims& f, const float* packed, const TargetDev& tg, const PointDev& pt,
+                               int with_grad, long B, hipStream_t st) {
+    const FlowLds l = make_flow_lds(f, with_grad != 0);
+    const ExtraLds x = make_extra_lds(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    const dim3 grid(nblk_of(B)), block(NTHREADS);
+    if (with_grad) {
+        FAB_TRY(set_max_lds((const void*)k_create_point<NTWM, true>, bytes));
+        hipLaunchKernelGGL((k_create_point<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, pt, B);
+    } else {
+        FAB_TRY(set_max_lds((const void*)k_create_point<NTWM, false>, bytes));
+        hipLaunchKernelGGL((k_create_point<NTWM, false>), grid, block, bytes, st, f, l, x, packed, tg, pt, B);
+    }
+    return check_launch();
+}
+
+template <int NTWM>
+static int launch_ais_init(const FlowDims& f, const float* packed, const TargetDev& tg, const float* eps0,
+                           const PointDev& pt, float* log_w, fabhip_anneal an, int with_grad, long B, hipStream_t st) {
+    const FlowLds l = make_flow_lds(f, with_grad != 0);
+    const ExtraLds x = make_extra_lds(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    const dim3 grid(nblk_of(B)), block(NTHREADS);
+    if (with_grad) {
+        FAB_TRY(set_max_lds((const void*)k_ais_init<NTWM, true>, bytes));
+        hipLaunchKernelGGL((k_ais_init<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, an, B);
+    } else {
+        FAB_TRY(set_max_lds((const void*)k_ais_init<NTWM, false>, bytes));
+        hipLaunchKernelGGL((k_ais_init<NTWM, false>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, an, B);
+    }
+    return check_launch();
+}
+
+template <int NTWM>
+static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetDev& tg, const HmcK& a, hipStream_t st) {
+    const FlowLds l = make_flow_lds(f, true);
+    const ExtraLds x = make_extra_lds(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    FAB_TRY(set_max_lds((const void*)k_hmc_step<NTWM>, bytes));
+    hipLaunchKernelGGL((k_hmc_step<NTWM>), dim3(nblk_of(a.B)), dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);
+    return check_launch();
+}
+
+template <int NTWM>
+static int launch_metropolis(const FlowDims& f, const float* packed, const TargetDev& tg, const MetK& a, hipStream_t st) {
+    const FlowLds l = make_flow_lds(f, false);
+    const ExtraLds x = make_extra_lds(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    FAB_TRY(set_max_lds((const void*)k_metropolis<NTWM>, bytes));
+    hipLaunchKernelGGL((k_metropolis<NTWM>), dim3(a.nblk), dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);
+    return check_launch();
+}
+
+static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
+    const FlowDims f = make_flow_dims(a->flow.dim, a->flow.n_layers, a->flow.width);
+    const TargetDev tg = make_target_dev(a->target);
+    const int D = f.D;
+    const int nblk = nblk_of(a->B);
+    if (a->workspace_bytes < fabhip_hmc_workspace_bytes(a->B, D, a->n_outer)) return FABHIP_ENOSPC;
+    char* ws = (char*)a->workspace;
+    float* part_acc = (float*)ws; ws += align256((size_t)nblk * 4);
+    float* part_dist = (float*)ws; ws += align256((size_t)nblk * 4);
+    PointDev prop{nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (a->n_outer > 1) {
+        float* pb = (float*)ws;
+        prop.x = pb; prop.gq = pb + a->B * D; prop.gp = pb + 2 * a->B * D;
+        prop.lq = pb + 3 * a->B * D; prop.lp = prop.lq + a->B;
+    }
+    const PointDev cur = make_point_dev(a->point);
+    for (int n = 0; n < a->n_outer; ++n) {
+        HmcK k;
+        k.cur = cur;
+        k.start = (n == 0) ? cur : prop;
+        k.prop_out = (n + 1 < a->n_outer) ? prop : PointDev{nullptr, nullptr, nullptr, nullptr, nullptr};
+        k.B = a->B; k.n_valid = a->n_valid; k.c = a->cur; k.nx = a->next;
+        k.log_w = (n + 1 == a->n_outer) ? a->log_w : nullptr;
+        k.noise_p = a->noise_p + (size_t)n * a->B * D;
+        k.noise_e = a->noise_e + (size_t)n * a->B;
+        k.eps_ptr = a->epsilons + n; k.ceps_ptr = a->common_epsilon; k.mass = a->mass;
+        k.L = a->L; k.max_grad = a->max_grad; k.part_acc = part_acc; k.part_dist = part_dist;
+        FAB_DISPATCH_NTW_NORET(f, launch_hmc_step, f, a->flow.packed, tg, k, st);
+        hipLaunchKernelGGL(k_hmc_adapt, dim3(1), dim3(64), 0, st, part_acc, part_dist, nblk, a->n_valid, (long)a->B,
+                           a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
+                           a->p_accept ? a->p_accept + n : nullptr, a->avg_distance);
+        FAB_TRY(check_launch());
+    }
+    return FABHIP_OK;
+}
+
+static int metropolis_transition_impl(const fabhip_metropolis_args* a, hipStream_t st) {
+    const FlowDims f = make_flow_dims(a->flow.dim, a->flow.n_layers, a->flow.width);
+    const TargetDev tg = make_target_dev(a->target);
+    const int nblk = nblk_of(a->B);
+    if (a->workspace_bytes < fabhip_metropolis_workspace_bytes(a->B, f.D, a->n_updates)) return FABHIP_ENOSPC;
+    MetK k;
+    k.cur = make_point_dev(a->point); k.B = a->B; k.n_valid = a->n_valid; k.c = a->cur; k.nx = a->next;
+    k.log_w = a->log_w; k.noise_x = a->noise_x; k.noise_u = a->noise_u; k.scalings = a->noise_scalings;
+    k.n_updates = a->n_updates; k.part_acc = (float*)a->workspace; k.nblk = nblk;
+    FAB_DISPATCH_NTW_NORET(f, launch_metropolis, f, a->flow.packed, tg, k, st);
+    hipLaunchKernelGGL(k_metropolis_adapt, dim3(1), dim3(64), 0, st, k.part_acc, nblk, a->n_updates, a->n_valid,
+                       (long)a->B, a->noise_scalings, a->target_p_accept, a->tune);
+    return check_launch();
+}
+
+static int check_point(const fabhip_point& p, bool need_grad) {
+    if (!p.x || !p.log_q || !p.log_p) return FABHIP_EINVAL;
+    if (need_grad && (!p.grad_log_q || !p.grad_log_p)) return FABHIP_EINVAL;
+    return FABHIP_OK;
+}
+
+}  // namespace fab
+
+using namespace fab;
+
+extern "C" {
+
+void fabhip_anneal_coefs(double beta, double alpha, int32_t p_target, fabhip_anneal* out) {
+    if (!out) return;
+    if (!p_target) {   // base.py:93-94, 114-116
+        out->c_q = (float)((1.0 - beta) + beta * (1.0 - alpha));
+        out->c_p = (float)(beta * alpha);
+        out->g_q = out->c_q;
+        out->g_p = (float)(2.0 * beta);
+    } else {           // base.py:96-97, 117-118
+        out->c_q = (float)(1.0 - beta);
+        out->c_p = (float)beta;
+        out->g_q = out->c_q;
+        out->g_p = out->c_p;
+    }
+}
+
+int fabhip_create_point(const fabhip_flow* flow, const fabhip_target* target, const fabhip_point* point,
+                        int32_t with_grad, int64_t B, fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !point || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
+    FAB_TRY(check_target(target, flow->dim));
+    FAB_TRY(check_point(*point, with_grad != 0));
+    if (B == 0) return FABHIP_OK;
+    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    FAB_DISPATCH_NTW(f, launch_create_point, f, flow->packed, make_target_dev(*target), make_point_dev(*point),
+                     with_grad, (long)B, (hipStream_t)stream);
+}
+
+size_t fabhip_hmc_workspace_bytes(int64_t B, int32_t dim, int32_t n_outer) {
+    const size_t nblk = (size_t)nblk_of(B);
+    size_t s = 2 * align256(nblk * 4);
+    if (n_outer > 1) s += align256((size_t)B * (3 * dim + 2) * 4);
+    return s + 256;
+}
+
+int fabhip_hmc_transition(const fabhip_hmc_args* a, fabhip_stream_t stream) {
+    if (!a || !a->flow.packed || !a->noise_p || !a->noise_e || !a->epsilons || !a->common_epsilon || !a->mass ||
+        !a->workspace || a->B < 0 || a->n_outer < 1 || a->L < 0)
+        return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(a->flow.dim, a->flow.n_layers, a->flow.width));
+    FAB_TRY(check_target(&a->target, a->flow.dim));
+    FAB_TRY(check_point(a->point, true));
+    if (a->B == 0) return FABHIP_OK;
+    return hmc_transition_impl(a, (hipStream_t)stream);
+}
+
+size_t fabhip_metropolis_workspace_bytes(int64_t B, int32_t dim, int32_t n_updates) {
+    (void)dim;
+    return align256((size_t)nblk_of(B) * (size_t)(n_updates > 0 ? n_updates : 1) * 4) + 256;
+}
+
+int fabhip_metropolis_transition(const fabhip_metropolis_args* a, fabhip_stream_t stream) {
+    if (!a || !a->flow.packed || !a->noise_x || !a->noise_u || !a->noise_scalings || !a->workspace || a->B < 0 ||
+        a->n_updates < 1 || a->n_updates > 64)
+        return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(a->flow.dim, a->flow.n_layers, a->flow.width));
+    FAB_TRY(check_target(&a->target, a->flow.dim));
+    FAB_TRY(check_point(a->point, false));
+    if (a->B == 0) return FABHIP_OK;
+    return metropolis_transition_impl(a, (hipStream_t)stream);
+}
+
+// ---- whole AIS call -------------------------------------------------------------------------------
+size_t fabhip_ais_workspace_bytes(int64_t B, int32_t dim, int32_t n_inner) {
+    size_t s = fabhip_hmc_workspace_bytes(B, dim, n_inner);
+    const size_t m = fabhip_metropolis_workspace_bytes(B, dim, n_inner);
+    if (m > s) s = m;
+    s = align256(s);
+    s += align256((size_t)B * (3 * dim + 3) * 4);   // compaction staging
+    s += align256((size_t)B * 4);                    // dest ranks
+    s += align256((size_t)B * 4);                    // log_p - log_q
+    s += align256(fabhip_ess_workspace_bytes(B));
+    return s + 256;
+}
+
+static int compact(const fabhip_ais_args* a, const int* n_in, int* n_out, float* tmp, int* dest, hipStream_t st) {
+    hipLaunchKernelGGL(k_valid_scan, dim3(1), dim3(1024), 0, st, a->point.log_q, a->point.log_p, n_in, (long)a->B,
+                       dest, n_out);
+    CompactK c{make_point_dev(a->point), a->log_w, tmp, dest, n_in, n_out, (long)a->B, a->flow.dim};
+    const int grid = (int)(a->B < 4096 ? a->B : 4096);
+    hipLaunchKernelGGL(k_compact_scatter, dim3(grid), dim3(64), 0, st, c);
+    hipLaunchKernelGGL(k_compact_copyback, dim3(grid), dim3(64), 0, st, c);
+    return check_launch();
+}
+
+int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
+    if (!a || !a->flow.packed || !a->betas || !a->eps0 || !a->noise_a || !a->noise_b || !a->step_state || !a->log_w ||
+        !a->n_valid || !a->stats || !a->workspace || a->B < 1 || a->M < 1 || a->n_inner < 1)
+        return FABHIP_EINVAL;
+    const bool hmc = a->transition == FABHIP_TRANSITION_HMC;
+    if (!hmc && a->transition != FABHIP_TRANSITION_METROPOLIS) return FABHIP_EINVAL;
+    if (hmc && (!a->common_epsilon || !a->mass)) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(a->flow.dim, a->flow.n_layers, a->flow.width));
+    FAB_TRY(check_target(&a->target, a->flow.dim));
+    FAB_TRY(check_point(a->point, hmc));
+    if (a->workspace_bytes < fabhip_ais_workspace_bytes(a->B, a->flow.dim, a->n_inner)) return FABHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    const FlowDims f = make_flow_dims(a->flow.dim, a->flow.n_layers, a->flow.width);
+    const TargetDev tg = make_target_dev(a->target);
+    const int D = f.D;
+    const long B = a->B;
+
+    char* ws = (char*)a->workspace;
+    size_t tws = fabhip_hmc_workspace_bytes(B, D, a->n_inner);
+    const size_t mws = fabhip_metropolis_workspace_bytes(B, D, a->n_inner);
+    if (mws > tws) tws = mws;
+    tws = align256(tws);
+    void* trans_ws = ws; ws += tws;
+    float* tmp = (float*)ws; ws += align256((size_t)B * (3 * D + 3) * 4);
+    int* dest = (int*)ws; ws += align256((size_t)B * 4);
+    float* lwb = (float*)ws; ws += align256((size_t)B * 4);
+    void* ess_ws = ws;
+    const size_t ess_bytes = fabhip_ess_workspace_bytes(B);
+
+    // 1. chain initialisation
+    fabhip_anneal a1;
+    fabhip_anneal_coefs(a->betas[1], a->alpha, a->p_target, &a1);
+    {
+        const PointDev pt = make_point_dev(a->point);
+        FAB_DISPATCH_NTW_NORET(f, launch_ais_init, f, a->flow.packed, tg, a->eps0, pt, a->log_w, a1, hmc ? 1 : 0, B, st);
+    }
+    // 2. remove nan/inf ("chain init")
+    FAB_TRY(compact(a, nullptr, a->n_valid, tmp, dest, st));
+    // 3. ESS over the base samples (ais.py:68-71) -> stats[0..2]
+    hipLaunchKernelGGL(k_sub, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_p, a->point.log_q, lwb, B);
+    FAB_TRY(fabhip_ess_logz(lwb, B, a->n_valid, 1.0, a->stats + 0, ess_ws, ess_bytes, stream));
+    // 4. transitions
+    for (int j = 1; j <= a->M; ++j) {
+        fabhip_anneal cj, cn;
+        fabhip_anneal_coefs(a->betas[j], a->alpha, a->p_target, &cj);
+        fabhip_anneal_coefs(a->betas[j + 1], a->alpha, a->p_target, &cn);
+        float* lw = (a->betas[j + 1] != a->betas[j]) ? a->log_w : nullptr;      // ais.py:93
+        const size_t nslab = (size_t)(j - 1) * a->n_inner;
+        if (hmc) {
+            fabhip_hmc_args h;
+            h.flow = a->flow; h.target = a->target; h.point = a->point; h.B = B; h.n_valid = a->n_valid;
+            h.cur = cj; h.next = cn; h.log_w = lw;
+            h.noise_p = a->noise_a + nslab * B * D; h.noise_e = a->noise_b + nslab * B;
+            h.epsilons = a->step_state + nslab; h.common_epsilon = a->common_epsilon; h.mass = a->mass;
+            h.n_outer = a->n_inner; h.L = a->L; h.max_grad = a->max_grad; h.target_p_accept = a->target_p_accept;
+            h.tune = a->tune;
+            h.p_accept = nullptr; h.avg_distance = nullptr;
+            h.workspace = trans_ws; h.workspace_bytes = tws;
+            // logging slots of the first / last distribution (hmc.py:173-183), loop 0 only
+            if (a->n_inner == 1) {
+                if (j == 1) { h.p_accept = a->stats + 6; h.avg_distance = a->stats + 8; }
+                else if (j == a->M) { h.p_accept = a->stats + 7; h.avg_distance = a->stats + 9; }
+            }
+            FAB_TRY(hmc_transition_impl(&h, st));
+        } else {
+            fabhip_metropolis_args m;
+            m.flow = a->flow; m.target = a->target; m.point = a->point; m.B = B; m.n_valid = a->n_valid;
+            m.cur = cj; m.next = cn; m.log_w = lw;
+            m.noise_x = a->noise_a + nslab * B * D; m.noise_u = a->noise_b + nslab * B;
+            m.noise_scalings = a->step_state + nslab; m.n_updates = a->n_inner;
+            m.target_p_accept = a->target_p_accept; m.tune = a->tune;
+            m.workspace = trans_ws; m.workspace_bytes = tws;
+            FAB_TRY(metropolis_transition_impl(&m, st));
+        }
+    }
+    // 5. remove nan/inf ("chain end"), 6. ESS / log Z over the survivors (ais.py:77-86)
+    FAB_TRY(compact(a, a->n_valid, a->n_valid + 1, tmp, dest, st));
+    FAB_TRY(fabhip_ess_logz(a->log_w, B, a->n_valid + 1, (double)B, a->stats + 3, ess_ws, ess_bytes, stream));
+    return check_launch();
+}
+
+}  // extern "C"

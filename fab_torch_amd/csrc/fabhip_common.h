@@ -1,0 +1,100 @@
+// fabhip — MI355X (gfx950 / CDNA4) kernels for the fab-torch AIS / flow-density hot path.
+// Shared host/device definitions: error codes, flow geometry, packed-weight layout.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/fabhip.h"
+
+#define FAB_HD __host__ __device__ __forceinline__
+
+namespace fab {
+
+constexpr int ROWS = 16;        // chains per workgroup = M of v_mfma_f32_16x16x4_f32
+constexpr int NWAVE = 4;        // one wave per SIMD
+constexpr int NTHREADS = 64 * NWAVE;
+constexpr int MAX_DIM = 64;     // D <= 64
+constexpr int MAX_WIDTH = 512;  // hidden width <= 512 (8 column tiles per wave)
+
+FAB_HD int ceil_div(int a, int b) { return (a + b - 1) / b; }
+FAB_HD int pad16(int a) { return ceil_div(a, 16) * 16; }
+
+// Geometry of one RealNVP flow (experiments/make_flow/make_normflow_model.py:11-30):
+// K x [AffineCouplingBlock(MLP[d, W, W, 2(D-d)], exp) + InvertibleAffine(D)], DiagGaussian base.
+struct FlowDims {
+    int D, d, DO, K, W;         // dim, conditioner width d=ceil(D/2), transformed DO=D-d, layers, hidden
+    int Dp, dp, DOp, Wp;        // padded to multiples of 16
+    int KBD, NTD;               // D  as k-blocks(16) / column tiles(16)
+    int KBd, NTd;               // d
+    int KBW, NTW;               // W
+    int KBO, NTO;               // 2*DOp (coupling parameter width: [shift | scale])
+    // packed offsets (in floats) inside one layer block
+    int o_AW, o_AWT, o_AWI, o_W1, o_W2, o_W3, o_W3T, o_W2T, o_W1T, o_b1, o_b2, o_b3, o_logS;
+    int layer_stride;           // floats per layer block
+    int o_base;                 // offset of base block: loc[Dp], log_scale[Dp]
+    int o_scratch;              // offset of affine scratch: per layer W[D*D], Winv[D*D]
+    int total;                  // total floats
+};
+
+FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
+    FlowDims f;
+    f.D = D; f.K = K; f.W = W;
+    f.d = (D + 1) / 2;          // int(D/2 + 0.5)
+    f.DO = D - f.d;
+    f.Dp = pad16(D); f.dp = pad16(f.d); f.DOp = pad16(f.DO); f.Wp = pad16(W);
+    f.KBD = f.Dp / 16; f.NTD = f.Dp / 16;
+    f.KBd = f.dp / 16; f.NTd = f.dp / 16;
+    f.KBW = f.Wp / 16; f.NTW = f.Wp / 16;
+    f.KBO = 2 * f.DOp / 16; f.NTO = 2 * f.DOp / 16;
+    int o = 0;
+    auto mat = [&](int kb, int nt) { int r = o; o += kb * nt * 256; return r; };
+    f.o_AW = mat(f.KBD, f.NTD);
+    f.o_AWT = mat(f.KBD, f.NTD);
+    f.o_AWI = mat(f.KBD, f.NTD);
+    f.o_W1 = mat(f.KBd, f.NTW);
+    f.o_W2 = mat(f.KBW, f.NTW);
+    f.o_W3 = mat(f.KBW, f.NTO);
+    f.o_W3T = mat(f.KBO, f.NTW);
+    f.o_W2T = mat(f.KBW, f.NTW);
+    f.o_W1T = mat(f.KBW, f.NTd);
+    f.o_b1 = o; o += f.Wp;
+    f.o_b2 = o; o += f.Wp;
+    f.o_b3 = o; o += 2 * f.DOp;
+    f.o_logS = o; o += 16;      // [0] = sum(log_S); rest pad (keeps 64-byte alignment)
+    f.layer_stride = o;
+    f.o_base = K * f.layer_stride;
+    f.o_scratch = f.o_base + 2 * f.Dp;
+    f.total = f.o_scratch + K * 2 * D * D;
+    return f;
+}
+
+// LDS plan (floats) of one workgroup evaluating the flow on a 16-chain tile.
+struct FlowLds {
+    int DS, WS, PS, PN;         // leading dims: state, hidden, dparam, k-split partials
+    int o_U0, o_U1, o_HA, o_HB, o_PART, o_DP, o_ES, o_V2, o_MASK;
+    int total;                  // floats
+};
+
+FAB_HD FlowLds make_flow_lds(const FlowDims& f, bool with_grad) {
+    FlowLds l;
+    l.DS = f.Dp + 4;
+    l.WS = f.Wp + 4;
+    l.PS = 2 * f.DOp + 4;
+    int pn = 2 * f.DOp; if (f.dp > pn) pn = f.dp; if (f.Dp > pn) pn = f.Dp;
+    l.PN = pn + 4;
+    int o = 0;
+    l.o_U0 = o; o += ROWS * l.DS;
+    l.o_U1 = o; o += ROWS * l.DS;
+    l.o_HA = o; o += ROWS * l.WS;
+    l.o_HB = o; o += ROWS * l.WS;
+    l.o_PART = o; o += NWAVE * ROWS * l.PN;
+    l.o_DP = o; o += ROWS * l.PS;
+    l.o_ES = o; if (with_grad) o += f.K * ROWS * f.DOp;
+    l.o_V2 = o; if (with_grad) o += f.K * ROWS * f.DOp;
+    o = (o + 1) & ~1;           // 8-byte align the 64-bit masks
+    l.o_MASK = o; if (with_grad) o += f.K * 2 * f.NTW * 4 * 2;
+    l.total = (o + 3) & ~3;
+    return l;
+}
+
+}  // namespace fab

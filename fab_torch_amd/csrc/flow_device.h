@@ -1,0 +1,359 @@
+// Device-side RealNVP evaluation on a 16-chain tile held by one 256-thread workgroup.
+//
+// Every linear map is a [16 x K] @ [K x N] product on the fp32 matrix cores
+// (v_mfma_f32_16x16x4_f32: exact fp32, bit-identical to an fmaf chain): activations live in LDS
+// (row-major, leading dimension padded by 4 floats), weights are streamed from the L2-resident
+// packed image straight into VGPRs (each weight is used by exactly one wave of the workgroup, so an
+// LDS round trip would be pure overhead) with a software prefetch ring.
+//
+// Packed B-operand tile (c, S) of a K x N matrix: 64 lanes x float4, lane l = (q = l>>4, n = l&15)
+// holds  B[16S + 4q + t][16c + n], t = 0..3.  MFMA step t of k-block S therefore multiplies
+// A[row][16S + 4q + t] (one ds_read_b128 per lane per k-block) with that register.
+#pragma once
+#include "fabhip_common.h"
+
+namespace fab {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float row16_sum(float v) {
+    // sum over the 16 lanes that share a chain row (tid = row*16 + c); fixed xor tree => deterministic
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+struct Tid {
+    int tid, wave, lane, q, n, row, c;
+    __device__ __forceinline__ Tid() {
+        tid = threadIdx.x;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lane = tid & 63;
+        q = lane >> 4;
+        n = lane & 15;
+        row = tid >> 4;   // elementwise mapping: 16 rows x 16 column lanes
+        c = tid & 15;
+    }
+};
+
+// ---- N-split GEMM: wave w owns column tiles c_i = w + 4 i (i < NTWM, c_i < NT) ----------------
+// acc[i] (+)= A[16 x 16*KB] @ B[:, tile c_i].   A elements with k >= kmax are treated as zero.
+template <int NTWM, int CH>
+__device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda, int kmax, int KB,
+                                            const float4* __restrict__ Bp, int NT, const Tid& t,
+                                            f32x4 (&acc)[NTWM]) {
+    const float* arow = A + t.n * lda + 4 * t.q;
+    const float4* bt[NTWM];
+    bool on[NTWM];
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const int c = t.wave + 4 * i;
+        on[i] = c < NT;
+        bt[i] = Bp + (size_t)(on[i] ? c : 0) * KB * 64 + t.lane;
+    }
+    float4 bcur[CH][NTWM];
+#pragma unroll
+    for (int s = 0; s < CH; ++s)
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i)
+            if (on[i] && s < KB) bcur[s][i] = bt[i][s * 64];
+    for (int S0 = 0; S0 < KB; S0 += CH) {
+        float4 bnxt[CH][NTWM];
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) {
+                const int S = S0 + CH + s;
+                if (on[i] && S < KB) bnxt[s][i] = bt[i][S * 64];
+            }
+#pragma unroll
+        for (int s = 0; s < CH; ++s) {
+            const int S = S0 + s;
+            if (S < KB) {
+                float4 a = *reinterpret_cast<const float4*>(arow + 16 * S);
+                const int k0 = 16 * S + 4 * t.q;
+                const float a0 = (k0 + 0 < kmax) ? a.x : 0.f;
+                const float a1 = (k0 + 1 < kmax) ? a.y : 0.f;
+                const float a2 = (k0 + 2 < kmax) ? a.z : 0.f;
+                const float a3 = (k0 + 3 < kmax) ? a.w : 0.f;
+#pragma unroll
+                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a0, bcur[s][i].x, acc[i]);
+#pragma unroll
+                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a1, bcur[s][i].y, acc[i]);
+#pragma unroll
+                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a2, bcur[s][i].z, acc[i]);
+#pragma unroll
+                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a3, bcur[s][i].w, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < CH; ++s)
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) bcur[s][i] = bnxt[s][i];
+    }
+}
+
+// ---- K-split GEMM for narrow outputs (N <= 64): wave w sums k-blocks S = w, w+4, ...; the four
+// partial [16 x 16*NT] products go to LDS part[w][row][PN] and are added by the caller. -----------
+template <int NTM>
+__device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda, int KB,
+                                            const float4* __restrict__ Bp, int NT, float* __restrict__ part,
+                                            int PN, const Tid& t) {
+    f32x4 acc[NTM];
+#pragma unroll
+    for (int i = 0; i < NTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* arow = A + t.n * lda + 4 * t.q;
+
+    for (int S = t.wave; S < KB; S += NWAVE) {
+        float4 b[NTM];
+#pragma unroll
+        for (int i = 0; i < NTM; ++i)
+            if (i < NT) b[i] = Bp[((size_t)i * KB + S) * 64 + t.lane];
+        const float4 a = *reinterpret_cast<const float4*>(arow + 16 * S);
+#pragma unroll
+        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.x, b[i].x, acc[i]);
+#pragma unroll
+        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.y, b[i].y, acc[i]);
+#pragma unroll
+        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.z, b[i].z, acc[i]);
+#pragma unroll
+        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.w, b[i].w, acc[i]);
+    }
+    float* p = part + (size_t)t.wave * ROWS * PN;
+#pragma unroll
+    for (int i = 0; i < NTM; ++i)
+        if (i < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[(4 * t.q + r) * PN + 16 * i + t.n] = acc[i][r];
+        }
+}
+
+__device__ __forceinline__ float part_sum(const float* part, int PN, int row, int col) {
+    float s = part[row * PN + col];
+    s += part[(ROWS + row) * PN + col];
+    s += part[(2 * ROWS + row) * PN + col];
+    s += part[(3 * ROWS + row) * PN + col];
+    return s;
+}
+
+// hidden layer: OUT = relu(A @ B + bias) (optionally recording the sign mask for the backward pass)
+template <int NTWM, bool MASK>
+__device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
+                                           const float* __restrict__ bias, int NT, float* OUT, int ldo,
+                                           unsigned long long* mask, const Tid& t) {
+    f32x4 acc[NTWM];
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_nsplit<NTWM, 2>(A, lda, kmax, KB, Bp, NT, t, acc);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const int c = t.wave + 4 * i;
+        if (c < NT) {
+            const float bv = bias[16 * c + t.n];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = acc[i][r] + bv;
+                const bool pos = v > 0.f;
+                OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? v : 0.f;
+                if (MASK) {
+                    const unsigned long long m = __ballot(pos);
+                    if (t.lane == 0) mask[c * 4 + r] = m;
+                }
+            }
+        }
+    }
+}
+
+// backward of a hidden layer: OUT = (A @ B) * mask
+template <int NTWM>
+__device__ __forceinline__ void dense_masked(const float* A, int lda, int kmax, int KB, const float4* Bp,
+                                             int NT, float* OUT, int ldo, const unsigned long long* mask,
+                                             const Tid& t) {
+    f32x4 acc[NTWM];
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_nsplit<NTWM, 2>(A, lda, kmax, KB, Bp, NT, t, acc);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const int c = t.wave + 4 * i;
+        if (c < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const unsigned long long m = mask[c * 4 + r];
+                const bool pos = (m >> t.lane) & 1ull;
+                OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? acc[i][r] : 0.f;
+            }
+        }
+    }
+}
+
+// OUT[16 x 16*NT] = A[16 x K] @ B   (NT <= 4: one column tile per wave), used for the D x D affine maps
+__device__ __forceinline__ void dense_small(const float* A, int lda, int kmax, int KB, const float4* Bp,
+                                            int NT, float* OUT, int ldo, const Tid& t) {
+    f32x4 acc[1];
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    gemm_nsplit<1, 2>(A, lda, kmax, KB, Bp, NT, t, acc);
+    if (t.wave < NT) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) OUT[(4 * t.q + r) * ldo + 16 * t.wave + t.n] = acc[0][r];
+    }
+}
+
+// conditioner MLP of one coupling layer: PART <- partial sums of relu(relu(z1 W1 + b1) W2 + b2) W3
+template <int NTWM, bool MASK>
+__device__ __forceinline__ void coupling_mlp(const FlowDims& f, const FlowLds& l, const float* Lp, float* lds,
+                                             const float* Z, int layer, const Tid& t) {
+    float* HA = lds + l.o_HA;
+    float* HB = lds + l.o_HB;
+    unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * f.NTW * 4;
+    dense_relu<NTWM, MASK>(Z, l.DS, f.d, f.KBd, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1,
+                           f.NTW, HA, l.WS, mk, t);
+    __syncthreads();
+    dense_relu<NTWM, MASK>(HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2), Lp + f.o_b2,
+                           f.NTW, HB, l.WS, mk + f.NTW * 4, t);
+    __syncthreads();
+    gemm_ksplit<4>(HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W3), f.NTO, lds + l.o_PART, l.PN, t);
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// log q(x) (and d log q / dx) for the 16 rows in U0 (columns >= D must be zero).
+// Returns log q of this thread's row (replicated over the row's 16 lanes).  With GRAD the gradient
+// is left in the state buffer whose LDS offset is returned through *grad_off.
+// normflows NormalizingFlow.log_prob: inverses in reversed layer order, log-dets added, base last.
+// ------------------------------------------------------------------------------------------------
+template <int NTWM, bool GRAD>
+__device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const float* __restrict__ packed,
+                                    float* lds, const Tid& t, int* grad_off) {
+    int cur = l.o_U0, nxt = l.o_U1;
+    float logq = 0.f;
+    float* PART = lds + l.o_PART;
+    for (int layer = f.K - 1; layer >= 0; --layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        // InvertibleAffine.inverse: z <- z @ (P L U), log_det = +sum(log_S)
+        dense_small(lds + cur, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AW), f.NTD, lds + nxt,
+                    l.DS, t);
+        logq += Lp[f.o_logS];
+        __syncthreads();
+        float* Z = lds + nxt;
+        coupling_mlp<NTWM, GRAD>(f, l, Lp, lds, Z, layer, t);
+        // AffineCoupling.inverse: z2 <- (z2 - shift) * exp(-s), log_det = -sum(s)
+        float ssum = 0.f;
+        for (int j = t.c; j < f.DO; j += 16) {
+            const float shift = part_sum(PART, l.PN, t.row, j) + Lp[f.o_b3 + j];
+            const float s = part_sum(PART, l.PN, t.row, f.DOp + j) + Lp[f.o_b3 + f.DOp + j];
+            const float es = expf(-s);
+            const float v2 = (Z[t.row * l.DS + f.d + j] - shift) * es;
+            Z[t.row * l.DS + f.d + j] = v2;
+            if (GRAD) {
+                lds[l.o_ES + ((size_t)layer * ROWS + t.row) * f.DOp + j] = es;
+                lds[l.o_V2 + ((size_t)layer * ROWS + t.row) * f.DOp + j] = v2;
+            }
+            ssum += s;
+        }
+        logq += -row16_sum(ssum);
+        __syncthreads();
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // DiagGaussian.log_prob
+    const float* base = packed + f.o_base;
+    float* Zc = lds + cur;
+    float bsum = 0.f;
+    for (int j = t.c; j < f.D; j += 16) {
+        const float ls = base[f.Dp + j];
+        const float sc = expf(ls);
+        const float zn = (Zc[t.row * l.DS + j] - base[j]) / sc;
+        bsum += ls + 0.5f * (zn * zn);
+        if (GRAD) Zc[t.row * l.DS + j] = -(zn / sc);      // d/dz of -0.5 ((z - loc)/sc)^2
+    }
+    logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
+    if (!GRAD) return logq;
+    __syncthreads();
+
+    // ---- reverse sweep: g = d log q / d(state), layers 0 .. K-1 -----------------------------------
+    float* DP = lds + l.o_DP;
+    for (int layer = 0; layer < f.K; ++layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        float* G = lds + cur;
+        for (int j = t.c; j < f.DO; j += 16) {
+            const float g2 = G[t.row * l.DS + f.d + j];
+            const float es = lds[l.o_ES + ((size_t)layer * ROWS + t.row) * f.DOp + j];
+            const float v2 = lds[l.o_V2 + ((size_t)layer * ROWS + t.row) * f.DOp + j];
+            DP[t.row * l.PS + j] = -(g2 * es);                    // d/d shift
+            DP[t.row * l.PS + f.DOp + j] = -(g2 * v2) - 1.f;       // d/d s  (incl. the -sum(s) log-det)
+            G[t.row * l.DS + f.d + j] = g2 * es;                  // d/d z2
+        }
+        __syncthreads();
+        const unsigned long long* mk =
+            reinterpret_cast<const unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * f.NTW * 4;
+        dense_masked<NTWM>(DP, l.PS, 2 * f.DOp, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), f.NTW,
+                           lds + l.o_HA, l.WS, mk + f.NTW * 4, t);
+        __syncthreads();
+        dense_masked<NTWM>(lds + l.o_HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2T), f.NTW,
+                           lds + l.o_HB, l.WS, mk, t);
+        __syncthreads();
+        gemm_ksplit<2>(lds + l.o_HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W1T), f.NTd, PART, l.PN, t);
+        __syncthreads();
+        for (int j = t.c; j < f.d; j += 16) G[t.row * l.DS + j] += part_sum(PART, l.PN, t.row, j);
+        __syncthreads();
+        // through InvertibleAffine.inverse: g <- g @ W^T
+        dense_small(G, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AWT), f.NTD, lds + nxt, l.DS, t);
+        __syncthreads();
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *grad_off = cur;
+    return logq;
+}
+
+// ------------------------------------------------------------------------------------------------
+// x, log q = flow.sample given base noise in U0 (NormalizingFlow.sample): forward maps in layer order.
+// Leaves x in the buffer at *x_off and returns log q of this thread's row.
+// ------------------------------------------------------------------------------------------------
+template <int NTWM>
+__device__ float flow_sample_tile(const FlowDims& f, const FlowLds& l, const float* __restrict__ packed,
+                                  float* lds, const Tid& t, int* x_off) {
+    int cur = l.o_U0, nxt = l.o_U1;
+    const float* base = packed + f.o_base;
+    float* PART = lds + l.o_PART;
+    float bsum = 0.f;
+    {
+        float* Z = lds + cur;
+        for (int j = t.c; j < f.D; j += 16) {
+            const float e = Z[t.row * l.DS + j];
+            const float ls = base[f.Dp + j];
+            Z[t.row * l.DS + j] = base[j] + expf(ls) * e;
+            bsum += ls + 0.5f * (e * e);
+        }
+    }
+    float logq = -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
+    __syncthreads();
+    for (int layer = 0; layer < f.K; ++layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        float* Z = lds + cur;
+        coupling_mlp<NTWM, false>(f, l, Lp, lds, Z, layer, t);
+        float ssum = 0.f;
+        for (int j = t.c; j < f.DO; j += 16) {
+            const float shift = part_sum(PART, l.PN, t.row, j) + Lp[f.o_b3 + j];
+            const float s = part_sum(PART, l.PN, t.row, f.DOp + j) + Lp[f.o_b3 + f.DOp + j];
+            Z[t.row * l.DS + f.d + j] = Z[t.row * l.DS + f.d + j] * expf(s) + shift;
+            ssum += s;
+        }
+        logq -= row16_sum(ssum);
+        __syncthreads();
+        // InvertibleAffine.forward: z <- z @ W^-1, log_det = -sum(log_S)
+        dense_small(Z, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AWI), f.NTD, lds + nxt, l.DS, t);
+        logq -= -Lp[f.o_logS];
+        __syncthreads();
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *x_off = cur;
+    return logq;
+}
+
+}  // namespace fab

@@ -1,0 +1,305 @@
+// RealNVP flow: parameter packing, log_prob (+ d/dx) and sampling kernels + their C ABI.
+#include "flow_device.h"
+#include "launch.h"
+
+namespace fab {
+
+// ------------------------------------------------------------------------------------------------
+// InvertibleAffine assembly (normflows InvertibleAffine._assemble_W): one workgroup per layer.
+//   W    = (P @ (tril(L,-1)+I)) @ (triu(U,1) + diag(sign_S * exp(log_S)))
+//   Winv = (fl32(inv64(Um)) @ fl32(inv64(Lm))) @ P^T
+// Triangular inverses by substitution in float64, one column per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_affine_assemble(int D, const float* __restrict__ Lraw,
+                                                         const float* __restrict__ Uraw,
+                                                         const float* __restrict__ logS,
+                                                         const float* __restrict__ signS,
+                                                         const float* __restrict__ P, float* __restrict__ Wout,
+                                                         float* __restrict__ Winvout, float* __restrict__ logS_sum) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double* Xd = reinterpret_cast<double*>(smem_raw);          // [D][D] fp64 scratch
+    float* Li = reinterpret_cast<float*>(Xd + D * D);          // [D][D]
+    float* Ui = Li + D * D;                                    // [D][D]
+    float* T = reinterpret_cast<float*>(Xd);                   // aliases Xd once the inverses are cast
+    const int tid = threadIdx.x;
+    auto Lm = [&](int i, int j) -> float { return i == j ? 1.f : (i > j ? Lraw[i * D + j] : 0.f); };
+    auto Um = [&](int i, int j) -> float {
+        return i == j ? signS[i] * expf(logS[i]) : (i < j ? Uraw[i * D + j] : 0.f);
+    };
+    // inverse of unit-lower Lm, column j
+    if (tid < D) {
+        const int j = tid;
+        for (int i = 0; i < D; ++i) Xd[i * D + j] = 0.0;
+        Xd[j * D + j] = 1.0;
+        for (int i = j + 1; i < D; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s += (double)Lm(i, k) * Xd[k * D + j];
+            Xd[i * D + j] = -s;
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < D * D; e += blockDim.x) Li[e] = (float)Xd[e];
+    __syncthreads();
+    // inverse of upper Um, column j
+    if (tid < D) {
+        const int j = tid;
+        for (int i = 0; i < D; ++i) Xd[i * D + j] = 0.0;
+        Xd[j * D + j] = 1.0 / (double)Um(j, j);
+        for (int i = j - 1; i >= 0; --i) {
+            double s = 0.0;
+            for (int k = i + 1; k <= j; ++k) s += (double)Um(i, k) * Xd[k * D + j];
+            Xd[i * D + j] = -s / (double)Um(i, i);
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < D * D; e += blockDim.x) Ui[e] = (float)Xd[e];
+    __syncthreads();
+    for (int e = tid; e < D * D; e += blockDim.x) {           // T = Ui @ Li
+        const int i = e / D, j = e % D;
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s = fmaf(Ui[i * D + k], Li[k * D + j], s);
+        T[e] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < D * D; e += blockDim.x) {           // Winv = T @ P^T
+        const int i = e / D, j = e % D;
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s = fmaf(T[i * D + k], P[j * D + k], s);
+        Winvout[e] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < D * D; e += blockDim.x) {           // Li <- P @ Lm
+        const int i = e / D, j = e % D;
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s = fmaf(P[i * D + k], Lm(k, j), s);
+        Li[e] = s;
+    }
+    __syncthreads();
+    for (int e = tid; e < D * D; e += blockDim.x) {           // W = (P Lm) @ Um
+        const int i = e / D, j = e % D;
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s = fmaf(Li[i * D + k], Um(k, j), s);
+        Wout[e] = s;
+    }
+    if (tid == 0) {
+        float s = 0.f;
+        for (int k = 0; k < D; ++k) s += logS[k];
+        *logS_sum = s;
+    }
+}
+
+struct LayerSrc {
+    const float *w1, *b1, *w2, *b2, *w3, *b3, *W, *Winv;
+};
+
+// decode an offset inside a tiled K x N matrix -> (k, n)
+__device__ __forceinline__ void tile_kn(int off, int KB, int& k, int& n) {
+    const int tile = off >> 8, within = off & 255;
+    const int lane = within >> 2, tt = within & 3;
+    const int c = tile / KB, S = tile % KB;
+    k = 16 * S + 4 * (lane >> 4) + tt;
+    n = 16 * c + (lane & 15);
+}
+
+// packed coupling-parameter column/row p in [0, 2*DOp) -> original MLP output index (interleaved
+// shift/scale: param[:, 0::2] = shift, param[:, 1::2] = scale) or -1 for padding
+__device__ __forceinline__ int prm_orig(int p, int DO, int DOp) {
+    if (p < DOp) return p < DO ? 2 * p : -1;
+    const int j = p - DOp;
+    return j < DO ? 2 * j + 1 : -1;
+}
+
+__global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, LayerSrc s, float* __restrict__ dst) {
+    const int D = f.D, d = f.d, DO = f.DO, W = f.W;
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.o_logS; off += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        int k, n;
+        if (off < f.o_AWT) {                       // AW: B[k][n] = W[k][n]
+            tile_kn(off - f.o_AW, f.KBD, k, n);
+            if (k < D && n < D) v = s.W[k * D + n];
+        } else if (off < f.o_AWI) {                // AWT: B[k][n] = W[n][k]
+            tile_kn(off - f.o_AWT, f.KBD, k, n);
+            if (k < D && n < D) v = s.W[n * D + k];
+        } else if (off < f.o_W1) {                 // AWI: B[k][n] = Winv[k][n]
+            tile_kn(off - f.o_AWI, f.KBD, k, n);
+            if (k < D && n < D) v = s.Winv[k * D + n];
+        } else if (off < f.o_W2) {                 // W1: B[k][n] = w1[n][k]
+            tile_kn(off - f.o_W1, f.KBd, k, n);
+            if (k < d && n < W) v = s.w1[n * d + k];
+        } else if (off < f.o_W3) {                 // W2: B[k][n] = w2[n][k]
+            tile_kn(off - f.o_W2, f.KBW, k, n);
+            if (k < W && n < W) v = s.w2[n * W + k];
+        } else if (off < f.o_W3T) {                // W3: B[k][p] = w3[orig(p)][k]
+            tile_kn(off - f.o_W3, f.KBW, k, n);
+            const int o = prm_orig(n, DO, f.DOp);
+            if (k < W && o >= 0) v = s.w3[o * W + k];
+        } else if (off < f.o_W2T) {                // W3T: B[p][n] = w3[orig(p)][n]
+            tile_kn(off - f.o_W3T, f.KBO, k, n);
+            const int o = prm_orig(k, DO, f.DOp);
+            if (o >= 0 && n < W) v = s.w3[o * W + n];
+        } else if (off < f.o_W1T) {                // W2T: B[k][n] = w2[k][n]
+            tile_kn(off - f.o_W2T, f.KBW, k, n);
+            if (k < W && n < W) v = s.w2[k * W + n];
+        } else if (off < f.o_b1) {                 // W1T: B[k][n] = w1[k][n]
+            tile_kn(off - f.o_W1T, f.KBW, k, n);
+            if (k < W && n < d) v = s.w1[k * d + n];
+        } else if (off < f.o_b2) {
+            const int j = off - f.o_b1;
+            if (j < W) v = s.b1[j];
+        } else if (off < f.o_b3) {
+            const int j = off - f.o_b2;
+            if (j < W) v = s.b2[j];
+        } else {
+            const int o = prm_orig(off - f.o_b3, DO, f.DOp);
+            if (o >= 0) v = s.b3[o];
+        }
+        dst[off] = v;
+    }
+}
+
+__global__ void k_pack_base(FlowDims f, const float* __restrict__ loc, const float* __restrict__ log_scale,
+                            float* __restrict__ dst) {
+    const int j = threadIdx.x;
+    if (j < f.Dp) {
+        dst[f.o_base + j] = j < f.D ? loc[j] : 0.f;
+        dst[f.o_base + f.Dp + j] = j < f.D ? log_scale[j] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// tile helpers shared with the transition kernels
+// ------------------------------------------------------------------------------------------------
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_flow_log_prob(FlowDims f, FlowLds l, const float* __restrict__ packed,
+                                                            const float* __restrict__ x, float* __restrict__ log_q,
+                                                            float* __restrict__ grad, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const long row0 = (long)blockIdx.x * ROWS;
+    for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) lds[l.o_DP + e] = 0.f;
+    for (int e = t.tid; e < ROWS * l.DS; e += NTHREADS) {
+        const int r = e / l.DS, j = e % l.DS;
+        const long g = row0 + r;
+        lds[l.o_U0 + e] = (j < f.D && g < B) ? x[g * f.D + j] : 0.f;
+    }
+    __syncthreads();
+    int goff = 0;
+    const float lq = flow_log_prob_tile<NTWM, GRAD>(f, l, packed, lds, t, &goff);
+    if (t.c == 0 && row0 + t.row < B) log_q[row0 + t.row] = lq;
+    if (GRAD) {
+        for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
+            const int r = e / f.D, j = e % f.D;
+            const long g = row0 + r;
+            if (g < B) grad[g * f.D + j] = lds[goff + r * l.DS + j];
+        }
+    }
+}
+
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_flow_sample(FlowDims f, FlowLds l, const float* __restrict__ packed,
+                                                          const float* __restrict__ eps, float* __restrict__ x,
+                                                          float* __restrict__ log_q, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const long row0 = (long)blockIdx.x * ROWS;
+    for (int e = t.tid; e < ROWS * l.DS; e += NTHREADS) {
+        const int r = e / l.DS, j = e % l.DS;
+        const long g = row0 + r;
+        lds[l.o_U0 + e] = (j < f.D && g < B) ? eps[g * f.D + j] : 0.f;
+    }
+    __syncthreads();
+    int xoff = 0;
+    const float lq = flow_sample_tile<NTWM>(f, l, packed, lds, t, &xoff);
+    if (t.c == 0 && row0 + t.row < B) log_q[row0 + t.row] = lq;
+    for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
+        const int r = e / f.D, j = e % f.D;
+        const long g = row0 + r;
+        if (g < B) x[g * f.D + j] = lds[xoff + r * l.DS + j];
+    }
+}
+
+template <int NTWM>
+static int launch_log_prob(const FlowDims& f, const float* packed, const float* x, float* log_q, float* grad,
+                           long B, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
+    if (grad) {
+        const FlowLds l = make_flow_lds(f, true);
+        const size_t bytes = (size_t)l.total * 4;
+        FAB_TRY(set_max_lds((const void*)k_flow_log_prob<NTWM, true>, bytes));
+        hipLaunchKernelGGL((k_flow_log_prob<NTWM, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad, B);
+    } else {
+        const FlowLds l = make_flow_lds(f, false);
+        const size_t bytes = (size_t)l.total * 4;
+        FAB_TRY(set_max_lds((const void*)k_flow_log_prob<NTWM, false>, bytes));
+        hipLaunchKernelGGL((k_flow_log_prob<NTWM, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad, B);
+    }
+    return check_launch();
+}
+
+template <int NTWM>
+static int launch_sample(const FlowDims& f, const float* packed, const float* eps, float* x, float* log_q, long B,
+                         hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
+    const FlowLds l = make_flow_lds(f, false);
+    const size_t bytes = (size_t)l.total * 4;
+    FAB_TRY(set_max_lds((const void*)k_flow_sample<NTWM>, bytes));
+    hipLaunchKernelGGL((k_flow_sample<NTWM>), grid, block, bytes, st, f, l, packed, eps, x, log_q, B);
+    return check_launch();
+}
+
+}  // namespace fab
+
+using namespace fab;
+
+extern "C" {
+
+int64_t fabhip_flow_packed_floats(int32_t dim, int32_t n_layers, int32_t width) {
+    if (check_flow_shape(dim, n_layers, width) != FABHIP_OK) return -1;
+    return (int64_t)make_flow_dims(dim, n_layers, width).total;
+}
+
+int fabhip_flow_pack(const fabhip_flow_params* p, float* packed, fabhip_stream_t stream) {
+    if (!p || !packed) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(p->dim, p->n_layers, p->width));
+    if (!p->loc || !p->log_scale) return FABHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const FlowDims f = make_flow_dims(p->dim, p->n_layers, p->width);
+    const int D = f.D;
+    const size_t smem = (size_t)D * D * (8 + 4 + 4);
+    FAB_TRY(set_max_lds((const void*)k_affine_assemble, smem));
+    for (int k = 0; k < f.K; ++k) {
+        if (!p->w1[k] || !p->b1[k] || !p->w2[k] || !p->b2[k] || !p->w3[k] || !p->b3[k] || !p->lu_L[k] ||
+            !p->lu_U[k] || !p->log_S[k] || !p->sign_S[k] || !p->perm_P[k])
+            return FABHIP_EINVAL;
+        float* Wm = packed + f.o_scratch + (size_t)k * 2 * D * D;
+        float* Wi = Wm + D * D;
+        float* layer = packed + (size_t)k * f.layer_stride;
+        hipLaunchKernelGGL(k_affine_assemble, dim3(1), dim3(256), smem, st, D, p->lu_L[k], p->lu_U[k], p->log_S[k],
+                           p->sign_S[k], p->perm_P[k], Wm, Wi, layer + f.o_logS);
+        LayerSrc s{p->w1[k], p->b1[k], p->w2[k], p->b2[k], p->w3[k], p->b3[k], Wm, Wi};
+        const int nblk = ceil_div(f.o_logS, 256 * 4);
+        hipLaunchKernelGGL(k_pack_layer, dim3(nblk), dim3(256), 0, st, f, s, layer);
+    }
+    hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
+    return check_launch();
+}
+
+int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                         fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !x || !log_q || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
+    if (B == 0) return FABHIP_OK;
+    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    FAB_DISPATCH_NTW(f, launch_log_prob, f, flow->packed, x, log_q, grad_x, (long)B, (hipStream_t)stream);
+}
+
+int fabhip_flow_sample(const fabhip_flow* flow, const float* eps, float* x, float* log_q, int64_t B,
+                       fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !eps || !x || !log_q || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
+    if (B == 0) return FABHIP_OK;
+    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    FAB_DISPATCH_NTW(f, launch_sample, f, flow->packed, eps, x, log_q, (long)B, (hipStream_t)stream);
+}
+
+}  // extern "C"

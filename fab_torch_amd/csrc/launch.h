@@ -1,0 +1,59 @@
+// Host-side launch helpers (no allocation, no synchronisation).
+#pragma once
+#include "fabhip_common.h"
+
+namespace fab {
+
+#define FAB_TRY(expr)                     \
+    do {                                  \
+        const int _e = (expr);            \
+        if (_e != FABHIP_OK) return _e;   \
+    } while (0)
+
+static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
+
+// Allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU).
+static inline int set_max_lds(const void* fn, size_t bytes) {
+    if (bytes > 160 * 1024) return FABHIP_ENOTSUP;
+    if (bytes > 48 * 1024) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            return FABHIP_ELAUNCH;
+        }
+    }
+    return FABHIP_OK;
+}
+
+static inline int check_flow_shape(int dim, int n_layers, int width) {
+    if (dim < 2 || n_layers < 1 || width < 1) return FABHIP_EINVAL;
+    if (dim > FABHIP_MAX_DIM || n_layers > FABHIP_MAX_LAYERS || width > FABHIP_MAX_WIDTH) return FABHIP_ENOTSUP;
+    return FABHIP_OK;
+}
+
+// column tiles per wave: ceil(NTW / 4) rounded up to a compiled variant {1, 2, 4, 5, 8}
+#define FAB_DISPATCH_NTW(f, fn, ...)                      \
+    do {                                                  \
+        const int _per = fab::ceil_div((f).NTW, 4);       \
+        if (_per <= 1) return fn<1>(__VA_ARGS__);         \
+        if (_per <= 2) return fn<2>(__VA_ARGS__);         \
+        if (_per <= 4) return fn<4>(__VA_ARGS__);         \
+        if (_per <= 5) return fn<5>(__VA_ARGS__);         \
+        if (_per <= 8) return fn<8>(__VA_ARGS__);         \
+        return FABHIP_ENOTSUP;                            \
+    } while (0)
+
+// same, but falls through on success (for call sites that continue afterwards)
+#define FAB_DISPATCH_NTW_NORET(f, fn, ...)                \
+    do {                                                  \
+        const int _per = fab::ceil_div((f).NTW, 4);       \
+        int _rc;                                          \
+        if (_per <= 1) _rc = fn<1>(__VA_ARGS__);          \
+        else if (_per <= 2) _rc = fn<2>(__VA_ARGS__);     \
+        else if (_per <= 4) _rc = fn<4>(__VA_ARGS__);     \
+        else if (_per <= 5) _rc = fn<5>(__VA_ARGS__);     \
+        else if (_per <= 8) _rc = fn<8>(__VA_ARGS__);     \
+        else _rc = FABHIP_ENOTSUP;                        \
+        if (_rc != FABHIP_OK) return _rc;                 \
+    } while (0)
+
+}  // namespace fab

@@ -1,0 +1,481 @@
+// ESS / log Z reductions, multinomial + systematic resampling, row gather, target log-prob kernel.
+//
+// The resample path is HBM-bound integer/byte work: coalesced 16-byte loads, wave ballots and LDS
+// partials, a single-pass decoupled-look-back prefix scan over fixed-point weights (integer sums are
+// associative => bit-exact for any scan order), two-level binary search (tile prefixes, then inside
+// one 4096-entry tile) and a vectorised row gather.
+#include "flow_device.h"
+#include "target_device.h"
+#include "launch.h"
+
+#pragma clang fp contract(off)
+
+namespace fab {
+
+// ------------------------------------------------------------------------------------------------
+// ESS / log Z (fab/utils/numerical.py:18-23; ais.py:80-86), float64 accumulation
+// ------------------------------------------------------------------------------------------------
+struct Msum {   // running (max, sum exp(x-max), sum exp(2(x-max)))
+    double m, s1, s2;
+};
+__device__ __forceinline__ Msum msum_id() { return Msum{-INFINITY, 0.0, 0.0}; }
+__device__ __forceinline__ Msum msum_merge(const Msum& a, const Msum& b) {
+    if (a.m != a.m || b.m != b.m) return Msum{NAN, NAN, NAN};
+    const double m = fmax(a.m, b.m);
+    if (m == -INFINITY) return Msum{m, 0.0, 0.0};
+    if (m == INFINITY) return Msum{m, NAN, NAN};      // softmax of +inf is NaN, like torch
+    const double ea = exp(a.m - m), eb = exp(b.m - m);
+    return Msum{m, a.s1 * ea + b.s1 * eb, a.s2 * ea * ea + b.s2 * eb * eb};
+}
+__device__ __forceinline__ Msum msum_push(const Msum& a, double x) {
+    if (x != x || a.m != a.m || x == INFINITY) return Msum{NAN, NAN, NAN};   // softmax(+inf) is NaN in torch
+    if (x == -INFINITY) return a;                       // weight 0
+    if (x <= a.m) {
+        const double e = exp(x - a.m);                  // a.m == +inf -> NaN, like torch's softmax
+        return Msum{a.m, a.s1 + e, a.s2 + e * e};
+    }
+    const double r = exp(a.m - x);                      // a.m == -inf -> 0
+    return Msum{x, a.s1 * r + 1.0, a.s2 * r * r + 1.0};
+}
+
+__device__ __forceinline__ Msum msum_block_reduce(Msum v, Msum* sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] = msum_merge(sh[tid], sh[tid + s]);
+        __syncthreads();
+    }
+    return sh[0];
+}
+
+constexpr int ESS_THREADS = 256;
+constexpr int ESS_MAX_BLOCKS = 1024;
+
+__global__ __launch_bounds__(ESS_THREADS) void k_ess_partial(const float* __restrict__ lw, long n_cap, const int* n_ptr,
+                                                             Msum* __restrict__ part) {
+    __shared__ Msum sh[ESS_THREADS];
+    const long n = n_ptr ? (long)*n_ptr : n_cap;
+    Msum v = msum_id();
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        v = msum_push(v, (double)lw[i]);
+    v = msum_block_reduce(v, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(ESS_THREADS) void k_ess_final(const Msum* __restrict__ part, int nblk, long n_cap,
+                                                           const int* n_ptr, double n_norm, float* __restrict__ out) {
+    __shared__ Msum sh[ESS_THREADS];
+    const long n = n_ptr ? (long)*n_ptr : n_cap;
+    Msum v = msum_id();
+    for (int i = threadIdx.x; i < nblk; i += blockDim.x) v = msum_merge(v, part[i]);
+    v = msum_block_reduce(v, sh);
+    if (threadIdx.x == 0) {
+        const double ess = (v.s1 * v.s1 / v.s2) / (double)n;       // 1 / sum(softmax^2) / n
+        const double logz = v.m + log(v.s1) - log(n_norm);         // logsumexp - log(n_norm)
+        out[0] = (float)ess;
+        out[1] = (float)logz;
+        out[2] = (float)n;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// torch-compatible multinomial (sequential fp32 CDF, exactly the CPU kernel's arithmetic)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_seq_cdf(const float* __restrict__ p, long n, float* __restrict__ c) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    float s = 0.f;
+    long j = 0;
+    for (; j + 8 <= n; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { s += v[u]; c[j + u] = s; }
+    }
+    for (; j < n; ++j) { s += p[j]; c[j] = s; }
+    c[n] = s;   // total kept in the extra slot
+}
+
+__global__ void k_cdf_normalise(float* __restrict__ c, long n) {
+    const float s = c[n];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = c[i] / s;
+        if (i == n - 1) v = 1.f;
+        c[i] = v;
+    }
+}
+
+__global__ void k_search_f32cdf(const float* __restrict__ c, long n, const double* __restrict__ u, long ns,
+                                long long* __restrict__ idx) {
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (long)gridDim.x * blockDim.x) {
+        const double uk = u[k];
+        long lo = 0, hi = n;
+        while (hi - lo > 0) {
+            const long mid = lo + (hi - lo) / 2;
+            if ((double)c[mid] < uk) lo = mid + 1; else hi = mid;
+        }
+        idx[k] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// scalable fixed-point CDF:  q_i = floor(fl32(exp(fl64(w_i) - fl64(max))) * 2^36)
+// ------------------------------------------------------------------------------------------------
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 16;                         // per thread
+constexpr int SCAN_TILE = SCAN_THREADS * SCAN_ITEMS;   // 4096 weights per tile
+constexpr unsigned long long FLAG_AGG = 1ull << 62, FLAG_INC = 2ull << 62, VAL_MASK = (1ull << 62) - 1ull;
+
+struct ScanWs {          // workspace layout (all 256-byte aligned)
+    float* max_part;             // [1024]
+    float* max_val;              // [1]
+    unsigned long long* desc;    // [ntiles] tile descriptors  (flag | value)
+    unsigned int* ticket;        // [1] dynamic tile id
+    unsigned long long* tile_inc;// [ntiles] inclusive prefix at the end of each tile
+    unsigned long long* cdf;     // [n]
+};
+
+__global__ __launch_bounds__(256) void k_max_partial(const float* __restrict__ lw, long n, float* __restrict__ part) {
+    __shared__ float sh[256];
+    float m = -INFINITY;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float v = lw[i];
+        if (isfinite(v)) m = fmaxf(m, v);
+    }
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void k_max_final(const float* __restrict__ part, int nblk, float* __restrict__ out) {
+    __shared__ float sh[256];
+    float m = -INFINITY;
+    for (int i = threadIdx.x; i < nblk; i += 256) m = fmaxf(m, part[i]);
+    sh[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (threadIdx.x < s) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + s]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = (sh[0] == -INFINITY) ? 0.f : sh[0];
+}
+
+__device__ __forceinline__ unsigned long long fixed_weight(float w, double mx) {
+    if (!isfinite(w)) return 0ull;
+    const float p = (float)exp((double)w - mx);                    // correctly rounded via float64
+    return (unsigned long long)floor((double)p * 68719476736.0);   // 2^36
+}
+
+// single-pass inclusive scan with decoupled look-back (descriptors are 8-byte {flag,value} granules
+// written/read with relaxed agent-scope atomics: the data IS the flag, no fence needed)
+__global__ __launch_bounds__(SCAN_THREADS) void k_scan_fixed(const float* __restrict__ lw, long n,
+                                                             const float* __restrict__ max_val, ScanWs ws) {
+    __shared__ unsigned long long wave_tot[SCAN_THREADS / 64];
+    __shared__ unsigned long long tile_prefix;
+    __shared__ unsigned int tile_id_sh;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) tile_id_sh = atomicAdd(ws.ticket, 1u);
+    __syncthreads();
+    const unsigned int tile = tile_id_sh;
+    const long base = (long)tile * SCAN_TILE + (long)tid * SCAN_ITEMS;
+    const double mx = (double)max_val[0];
+    unsigned long long q[SCAN_ITEMS];
+    if (base + SCAN_ITEMS <= n) {
+        const float4* p4 = reinterpret_cast<const float4*>(lw + base);
+#pragma unroll
+        for (int v = 0; v < SCAN_ITEMS / 4; ++v) {
+            const float4 x = p4[v];
+            q[4 * v + 0] = fixed_weight(x.x, mx); q[4 * v + 1] = fixed_weight(x.y, mx);
+            q[4 * v + 2] = fixed_weight(x.z, mx); q[4 * v + 3] = fixed_weight(x.w, mx);
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < SCAN_ITEMS; ++v) q[v] = (base + v < n) ? fixed_weight(lw[base + v], mx) : 0ull;
+    }
+    unsigned long long run = 0ull;
+#pragma unroll
+    for (int v = 0; v < SCAN_ITEMS; ++v) { run += q[v]; q[v] = run; }       // thread-local inclusive
+    // wave inclusive scan of the thread totals
+    unsigned long long incl = run;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    unsigned long long wave_off = 0ull, tile_tot = 0ull;
+#pragma unroll
+    for (int w = 0; w < SCAN_THREADS / 64; ++w) { if (w < wave) wave_off += wave_tot[w]; tile_tot += wave_tot[w]; }
+    // publish the aggregate, look back for the exclusive prefix (wave 0)
+    if (wave == 0) {
+        if (tile == 0) {
+            if (lane == 0) {
+                __hip_atomic_store(ws.desc + 0, FLAG_INC | tile_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tile_prefix = 0ull;
+            }
+        } else {
+            if (lane == 0)
+                __hip_atomic_store(ws.desc + tile, FLAG_AGG | tile_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long excl = 0ull;
+            long look = (long)tile - 1;
+            while (true) {
+                const long j = look - lane;
+                unsigned long long d = 0ull;
+                if (j >= 0) {
+                    do {
+                        d = __hip_atomic_load(ws.desc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((d >> 62) == 0ull);
+                } else {
+                    d = FLAG_INC;          // virtual tile before the first: inclusive prefix 0
+                }
+                const unsigned long long inc_mask = __ballot((d >> 62) == 2ull);
+                const int first_inc = __ffsll((long long)inc_mask) - 1;     // always >= 0 eventually
+                unsigned long long contrib = (first_inc < 0 || lane <= first_inc) ? (d & VAL_MASK) : 0ull;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off);
+                excl += contrib;
+                if (first_inc >= 0) break;
+                look -= 64;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(ws.desc + tile, FLAG_INC | (excl + tile_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                tile_prefix = excl;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long off0 = tile_prefix + wave_off + (incl - run);
+    if (tid == SCAN_THREADS - 1) ws.tile_inc[tile] = tile_prefix + tile_tot;
+    if (base + SCAN_ITEMS <= n) {
+        ulonglong2* o2 = reinterpret_cast<ulonglong2*>(ws.cdf + base);
+#pragma unroll
+        for (int v = 0; v < SCAN_ITEMS / 2; ++v) o2[v] = make_ulonglong2(off0 + q[2 * v], off0 + q[2 * v + 1]);
+    } else {
+#pragma unroll
+        for (int v = 0; v < SCAN_ITEMS; ++v) if (base + v < n) ws.cdf[base + v] = off0 + q[v];
+    }
+}
+
+// first j with C[j] > t : search the tile prefixes, then inside the tile
+__device__ __forceinline__ long search_cdf(const ScanWs& ws, long n, long ntiles, unsigned long long t) {
+    long lo = 0, hi = ntiles;
+    while (lo < hi) { const long mid = (lo + hi) >> 1; if (ws.tile_inc[mid] > t) hi = mid; else lo = mid + 1; }
+    if (lo >= ntiles) return n - 1;
+    long a = lo * SCAN_TILE, b = a + SCAN_TILE;
+    if (b > n) b = n;
+    while (a < b) { const long mid = (a + b) >> 1; if (ws.cdf[mid] > t) b = mid; else a = mid + 1; }
+    return a < n ? a : n - 1;
+}
+
+__global__ void k_sample_multinomial(ScanWs ws, long n, long ntiles, const double* __restrict__ u, long ns,
+                                     long long* __restrict__ idx) {
+    const unsigned long long total = ws.tile_inc[ntiles - 1];
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (long)gridDim.x * blockDim.x) {
+        unsigned long long t = 0ull;
+        if (total > 0ull) {
+            t = (unsigned long long)floor(u[k] * (double)total);
+            if (t > total - 1ull) t = total - 1ull;
+        }
+        idx[k] = search_cdf(ws, n, ntiles, t);
+    }
+}
+
+__global__ void k_sample_systematic(ScanWs ws, long n, long ntiles, double u0, long ns, long long* __restrict__ idx) {
+    const unsigned long long total = ws.tile_inc[ntiles - 1];
+    const double step = (double)total / (double)ns;
+    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (long)gridDim.x * blockDim.x) {
+        unsigned long long t = 0ull;
+        if (total > 0ull) {
+            t = (unsigned long long)floor(((double)k + u0) * step);
+            if (t > total - 1ull) t = total - 1ull;
+        }
+        idx[k] = search_cdf(ws, n, ntiles, t);
+    }
+}
+
+__global__ void k_gather_rows(const float* __restrict__ src, const long long* __restrict__ idx, float* __restrict__ dst,
+                              long n_out, long row_len) {
+    if ((row_len & 3) == 0 && ((size_t)src & 15) == 0 && ((size_t)dst & 15) == 0) {
+        const long r4 = row_len >> 2;
+        const long total = n_out * r4;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+            const long k = e / r4, j = e % r4;
+            reinterpret_cast<float4*>(dst)[e] = reinterpret_cast<const float4*>(src)[idx[k] * r4 + j];
+        }
+    } else {
+        const long total = n_out * row_len;
+        for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+            const long k = e / row_len, j = e % row_len;
+            dst[e] = src[idx[k] * row_len + j];
+        }
+    }
+}
+
+// standalone target log-prob (+grad) kernel
+template <bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_target(TargetDev tg, const float* __restrict__ x, float* __restrict__ lp,
+                                                     float* __restrict__ grad, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const int D = tg.dim;
+    float* X = lds;
+    float* G = lds + ROWS * D;
+    const long row0 = (long)blockIdx.x * ROWS;
+    for (int e = t.tid; e < ROWS * D; e += NTHREADS) {
+        const long g = row0 + e / D;
+        X[e] = g < B ? x[g * D + e % D] : 0.f;
+    }
+    __syncthreads();
+    const float v = target_tile<GRAD>(tg, X, D, G, D, t);
+    const long g = row0 + t.row;
+    if (g < B) {
+        if (t.c == 0) lp[g] = v;
+        if (GRAD) for (int j = t.c; j < D; j += 16) grad[g * D + j] = G[t.row * D + j];
+    }
+}
+
+static inline size_t al256(size_t v) { return (v + 255) & ~(size_t)255; }
+static inline int grid_for(long n, int threads, int cap) {
+    long b = (n + threads - 1) / threads;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+
+static inline long scan_tiles(long n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+static ScanWs carve_scan_ws(void* workspace, long n) {
+    char* p = (char*)workspace;
+    ScanWs ws;
+    ws.max_part = (float*)p; p += al256(1024 * 4);
+    ws.max_val = (float*)p; p += 256;
+    ws.desc = (unsigned long long*)p; p += al256((size_t)scan_tiles(n) * 8);
+    ws.ticket = (unsigned int*)p; p += 256;
+    ws.tile_inc = (unsigned long long*)p; p += al256((size_t)scan_tiles(n) * 8);
+    ws.cdf = (unsigned long long*)p;
+    return ws;
+}
+
+static int build_fixed_cdf(const float* log_w, long n, const ScanWs& ws, hipStream_t st) {
+    const int mb = grid_for(n, 256 * 8, 1024);
+    hipLaunchKernelGGL(k_max_partial, dim3(mb), dim3(256), 0, st, log_w, n, ws.max_part);
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, ws.max_part, mb, ws.max_val);
+    // zero descriptors + ticket (one contiguous region: desc .. ticket)
+    const size_t zbytes = (size_t)((char*)ws.ticket - (char*)ws.desc) + 256;
+    if (hipMemsetAsync(ws.desc, 0, zbytes, st) != hipSuccess) return FABHIP_ELAUNCH;
+    hipLaunchKernelGGL(k_scan_fixed, dim3((unsigned)scan_tiles(n)), dim3(SCAN_THREADS), 0, st, log_w, n, ws.max_val, ws);
+    return check_launch();
+}
+
+}  // namespace fab
+
+using namespace fab;
+
+extern "C" {
+
+const char* fabhip_strerror(int code) {
+    switch (code) {
+        case FABHIP_OK: return "ok";
+        case FABHIP_EINVAL: return "invalid argument (shape, null pointer or alignment)";
+        case FABHIP_ENOTSUP: return "not supported (dimension beyond compiled limits)";
+        case FABHIP_ELAUNCH: return "kernel launch failed (hipGetLastError)";
+        case FABHIP_ENOSPC: return "workspace too small";
+        default: return "unknown fabhip error";
+    }
+}
+
+int fabhip_version(void) { return 100; }
+
+int fabhip_target_log_prob(const fabhip_target* target, const float* x, float* log_p, float* grad_x, int64_t B,
+                           fabhip_stream_t stream) {
+    if (!target || !x || !log_p || B < 0) return FABHIP_EINVAL;
+    if (target->dim < 1 || target->dim > FABHIP_MAX_DIM) return FABHIP_ENOTSUP;
+    FAB_TRY(check_target(target, target->dim));
+    if (B == 0) return FABHIP_OK;
+    const TargetDev tg = make_target_dev(*target);
+    const size_t bytes = (size_t)2 * ROWS * tg.dim * 4;
+    const dim3 grid((unsigned)((B + ROWS - 1) / ROWS)), block(NTHREADS);
+    if (grad_x) hipLaunchKernelGGL((k_target<true>), grid, block, bytes, (hipStream_t)stream, tg, x, log_p, grad_x, (long)B);
+    else hipLaunchKernelGGL((k_target<false>), grid, block, bytes, (hipStream_t)stream, tg, x, log_p, grad_x, (long)B);
+    return check_launch();
+}
+
+size_t fabhip_ess_workspace_bytes(int64_t n) { (void)n; return al256(sizeof(Msum) * ESS_MAX_BLOCKS) + 256; }
+
+int fabhip_ess_logz(const float* log_w, int64_t n, const int32_t* n_ptr, double n_norm, float* out, void* workspace,
+                    size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!log_w || !out || !workspace || n < 0) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_ess_workspace_bytes(n)) return FABHIP_ENOSPC;
+    Msum* part = (Msum*)workspace;
+    const int nblk = grid_for(n, ESS_THREADS * 4, ESS_MAX_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_ess_partial, dim3(nblk), dim3(ESS_THREADS), 0, st, log_w, (long)n, n_ptr, part);
+    hipLaunchKernelGGL(k_ess_final, dim3(1), dim3(ESS_THREADS), 0, st, part, nblk, (long)n, n_ptr, n_norm, out);
+    return check_launch();
+}
+
+size_t fabhip_multinomial_torch_workspace_bytes(int64_t n) { return al256((size_t)(n + 1) * 4) + 256; }
+
+int fabhip_multinomial_torch(const float* probs, int64_t n, const double* u, int64_t n_samples, int64_t* idx,
+                             void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!probs || !u || !idx || !workspace || n < 1 || n_samples < 0) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_multinomial_torch_workspace_bytes(n)) return FABHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    float* c = (float*)workspace;
+    hipLaunchKernelGGL(k_seq_cdf, dim3(1), dim3(64), 0, st, probs, (long)n, c);
+    hipLaunchKernelGGL(k_cdf_normalise, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, c, (long)n);
+    if (n_samples > 0)
+        hipLaunchKernelGGL(k_search_f32cdf, dim3(grid_for(n_samples, 256, 4096)), dim3(256), 0, st, c, (long)n, u,
+                           (long)n_samples, (long long*)idx);
+    return check_launch();
+}
+
+size_t fabhip_resample_workspace_bytes(int64_t n) {
+    const size_t tiles = (size_t)scan_tiles(n);
+    return al256(1024 * 4) + 256 + al256(tiles * 8) + 256 + al256(tiles * 8) + al256((size_t)n * 8) + 256;
+}
+
+int fabhip_resample_multinomial(const float* log_w, int64_t n, const double* u, int64_t n_samples, int64_t* idx,
+                                void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!log_w || !u || !idx || !workspace || n < 1 || n_samples < 0) return FABHIP_EINVAL;
+    if (((size_t)workspace & 255) != 0) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_resample_workspace_bytes(n)) return FABHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    const ScanWs ws = carve_scan_ws(workspace, n);
+    FAB_TRY(build_fixed_cdf(log_w, n, ws, st));
+    if (n_samples > 0)
+        hipLaunchKernelGGL(k_sample_multinomial, dim3(grid_for(n_samples, 256, 4096)), dim3(256), 0, st, ws, (long)n,
+                           scan_tiles(n), u, (long)n_samples, (long long*)idx);
+    return check_launch();
+}
+
+int fabhip_resample_systematic(const float* log_w, int64_t n, double u0, int64_t n_samples, int64_t* idx,
+                               void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!log_w || !idx || !workspace || n < 1 || n_samples < 0 || !(u0 >= 0.0 && u0 < 1.0)) return FABHIP_EINVAL;
+    if (((size_t)workspace & 255) != 0) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_resample_workspace_bytes(n)) return FABHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    const ScanWs ws = carve_scan_ws(workspace, n);
+    FAB_TRY(build_fixed_cdf(log_w, n, ws, st));
+    if (n_samples > 0)
+        hipLaunchKernelGGL(k_sample_systematic, dim3(grid_for(n_samples, 256, 4096)), dim3(256), 0, st, ws, (long)n,
+                           scan_tiles(n), u0, (long)n_samples, (long long*)idx);
+    return check_launch();
+}
+
+int fabhip_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t n_out, int64_t row_len,
+                       fabhip_stream_t stream) {
+    if (!src || !idx || !dst || n_out < 0 || row_len < 1) return FABHIP_EINVAL;
+    if (n_out == 0) return FABHIP_OK;
+    hipLaunchKernelGGL(k_gather_rows, dim3(grid_for(n_out * row_len, 256 * 4, 8192)), dim3(256), 0, (hipStream_t)stream,
+                       src, (const long long*)idx, dst, (long)n_out, (long)row_len);
+    return check_launch();
+}
+
+}  // extern "C"

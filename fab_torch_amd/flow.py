@@ -1,0 +1,245 @@
+"""RealNVP `TrainableDistribution` backed by the HIP kernels.
+
+Host-side mirror of what the reference builds with normflows in
+experiments/make_flow/make_normflow_model.py:11-30,82-96 (`make_wrapped_normflow_realnvp`) and wraps
+in fab/wrappers/normflows.py:8-31 (`WrappedNormFlowModel`): same constructor meaning, same
+`Distribution` methods (fab/types_.py:8-27), same state-dict key names
+(`_nf_model.q0.loc`, `_nf_model.flows.{2i}.flows.1.param_map.net.{0,2,4}.{weight,bias}`,
+`_nf_model.flows.{2i+1}.{P,L,U,log_S,sign_S,eye}`) so reference checkpoints load (fab/core.py:237-240).
+
+Hot path (no autograd graph requested): `sample_and_log_prob`, `log_prob`, `log_prob_and_grad` run the
+fp32-MFMA kernels of csrc/flow_kernels.hip through the C ABI.  When autograd is recording w.r.t. the
+parameters (the trainer's `flow.log_prob(x)` + `loss.backward()`, fab/train_with_prioritised_buffer.py:162-173)
+the same arithmetic is expressed with differentiable PyTorch-ROCm ops on the GPU.
+"""
+import ctypes as C
+import math
+from typing import Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+class _MLP(nn.Module):
+    def __init__(self, layers, init_zeros=True):
+        super().__init__()
+        net = []
+        for k in range(len(layers) - 2):
+            net += [nn.Linear(layers[k], layers[k + 1]), nn.LeakyReLU(0.0)]
+        net.append(nn.Linear(layers[-2], layers[-1]))
+        if init_zeros:
+            nn.init.zeros_(net[-1].weight)
+            nn.init.zeros_(net[-1].bias)
+        self.net = nn.Sequential(*net)
+
+
+class _Stub(nn.Module):
+    """parameter-less placeholder keeping normflows' module indices (Split / Merge)."""
+
+
+class _AffineCoupling(nn.Module):
+    def __init__(self, param_map):
+        super().__init__()
+        self.param_map = param_map
+
+
+class _AffineCouplingBlock(nn.Module):
+    def __init__(self, param_map):
+        super().__init__()
+        self.flows = nn.ModuleList([_Stub(), _AffineCoupling(param_map), _Stub()])
+
+
+class _InvertibleAffine(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        Q, _ = torch.linalg.qr(torch.randn(dim, dim))
+        P, L, U = torch.linalg.lu(Q)
+        S = U.diag()
+        self.register_buffer("P", P)
+        self.L = nn.Parameter(L)
+        self.register_buffer("sign_S", torch.sign(S))
+        self.log_S = nn.Parameter(torch.log(torch.abs(S)))
+        self.U = nn.Parameter(torch.triu(U, diagonal=1))
+        self.register_buffer("eye", torch.diag(torch.ones(dim)))
+
+    def assemble(self, inverse=False):
+        L = torch.tril(self.L, diagonal=-1) + self.eye
+        U = torch.triu(self.U, diagonal=1) + torch.diag(self.sign_S * torch.exp(self.log_S))
+        if inverse:
+            L_inv = torch.inverse(L.double()).type(self.log_S.dtype)
+            U_inv = torch.inverse(U.double()).type(self.log_S.dtype)
+            return U_inv @ L_inv @ self.P.t()
+        return self.P @ L @ U
+
+
+class _DiagGaussian(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.shape = (dim,)
+        self.loc = nn.Parameter(torch.zeros(1, dim))
+        self.log_scale = nn.Parameter(torch.zeros(1, dim))
+
+
+class _NormalizingFlow(nn.Module):
+    def __init__(self, dim, n_layers, width):
+        super().__init__()
+        self.q0 = _DiagGaussian(dim)
+        d = int((dim / 2) + 0.5)
+        flows = []
+        for _ in range(n_layers):
+            flows.append(_AffineCouplingBlock(_MLP([d, width, width, 2 * (dim - d)], init_zeros=True)))
+            flows.append(_InvertibleAffine(dim))
+        self.flows = nn.ModuleList(flows)
+
+
+class RealNVP(nn.Module):
+    """`make_wrapped_normflow_realnvp(dim, n_flow_layers, layer_nodes_per_dim, act_norm=False)`."""
+
+    def __init__(self, dim: int, n_flow_layers: int = 5, layer_nodes_per_dim: int = 10, act_norm: bool = False):
+        super().__init__()
+        if act_norm:
+            raise NotImplementedError("ActNorm layers are not part of the MI355X hot path (all shipped "
+                                      "reference configs set act_norm=false)")
+        self.dim, self.n_layers, self.width = dim, n_flow_layers, dim * layer_nodes_per_dim
+        self.d = int((dim / 2) + 0.5)
+        self._nf_model = _NormalizingFlow(dim, n_flow_layers, self.width)
+        self._packed = None
+        self._packed_key = None
+        self._params_struct = None
+
+    # ---- Distribution interface (fab/types_.py:8-27) ---------------------------------------------
+    @property
+    def event_shape(self) -> Tuple[int, ...]:
+        return self._nf_model.q0.shape
+
+    def sample_and_log_prob(self, shape: Tuple[int, ...], eps: torch.Tensor = None):
+        assert len(shape) == 1
+        dev = self._nf_model.q0.loc.device
+        if eps is None:
+            eps = torch.randn((shape[0], self.dim), dtype=torch.float32, device=dev)
+        if torch.is_grad_enabled() and self._params_need_grad():
+            return self._torch_sample(eps)
+        return self.native_sample(eps)
+
+    def sample(self, shape: Tuple) -> torch.Tensor:
+        return self.sample_and_log_prob(shape)[0]
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and (x.requires_grad or self._params_need_grad()):
+            return self._torch_log_prob(x)
+        return self.native_log_prob(x)[0]
+
+    # ---- native (HIP) entry points ------------------------------------------------------------------
+    def _params_need_grad(self):
+        return any(p.requires_grad for p in self.parameters())
+
+    def _layers(self):
+        fl = self._nf_model.flows
+        for i in range(self.n_layers):
+            net = fl[2 * i].flows[1].param_map.net
+            yield net[0], net[2], net[4], fl[2 * i + 1]
+
+    def native(self):
+        """(Flow struct, packed image) — re-tiled by the pack kernels whenever a parameter changed."""
+        lib = _lib.load()
+        q0 = self._nf_model.q0
+        _lib.require_device(q0.loc, "RealNVP parameters")
+        tensors = []
+        for l1, l2, l3, aff in self._layers():
+            tensors += [l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, aff.L, aff.U, aff.log_S,
+                        aff.sign_S, aff.P]
+        tensors += [q0.loc, q0.log_scale]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if key != self._packed_key:
+            for t in tensors:
+                if t.dtype != torch.float32 or not t.is_contiguous():
+                    raise _lib.FabhipError("RealNVP parameters must be contiguous float32 for the HIP path")
+            n = lib.fabhip_flow_packed_floats(self.dim, self.n_layers, self.width)
+            if n < 0:
+                raise _lib.FabhipError(f"flow shape not supported by the kernels: dim={self.dim} width={self.width}")
+            if self._packed is None or self._packed.numel() != n or self._packed.device != q0.loc.device:
+                self._packed = torch.empty(n, dtype=torch.float32, device=q0.loc.device)
+            p = _lib.FlowParams()
+            p.dim, p.n_layers, p.width = self.dim, self.n_layers, self.width
+            names = ("w1", "b1", "w2", "b2", "w3", "b3", "lu_L", "lu_U", "log_S", "sign_S", "perm_P")
+            for k in range(self.n_layers):
+                for j, nm in enumerate(names):
+                    getattr(p, nm)[k] = tensors[11 * k + j].data_ptr()
+            p.loc, p.log_scale = q0.loc.data_ptr(), q0.log_scale.data_ptr()
+            _lib.check(lib.fabhip_flow_pack(C.byref(p), _lib.ptr(self._packed), _lib.stream_ptr()), "flow_pack")
+            self._packed_key = key
+        f = _lib.Flow(self.dim, self.n_layers, self.width, self._packed.data_ptr())
+        return f, self._packed
+
+    def native_sample(self, eps: torch.Tensor):
+        lib = _lib.load()
+        _lib.require_device(eps, "eps")
+        f, _ = self.native()
+        eps = eps.contiguous().float()
+        B = eps.shape[0]
+        x = torch.empty_like(eps)
+        log_q = torch.empty(B, dtype=torch.float32, device=eps.device)
+        _lib.check(lib.fabhip_flow_sample(C.byref(f), _lib.ptr(eps), _lib.ptr(x), _lib.ptr(log_q), B,
+                                          _lib.stream_ptr()), "flow_sample")
+        return x, log_q
+
+    def native_log_prob(self, x: torch.Tensor, with_grad: bool = False):
+        lib = _lib.load()
+        _lib.require_device(x, "x")
+        f, _ = self.native()
+        x = x.detach().contiguous().float()
+        B = x.shape[0]
+        log_q = torch.empty(B, dtype=torch.float32, device=x.device)
+        grad = torch.empty_like(x) if with_grad else None
+        _lib.check(lib.fabhip_flow_log_prob(C.byref(f), _lib.ptr(x), _lib.ptr(log_q), _lib.ptr(grad), B,
+                                            _lib.stream_ptr()), "flow_log_prob")
+        return log_q, grad
+
+    def log_prob_and_grad(self, x: torch.Tensor):
+        """(log q(x), d log q / dx) — what `grad_and_value(x, flow.log_prob)` computes (base.py:50-56)."""
+        return self.native_log_prob(x, with_grad=True)
+
+    # ---- differentiable PyTorch-ROCm expression of the same maps (training path) --------------------
+    def _mlp(self, l1, l2, l3, z1):
+        h = torch.nn.functional.leaky_relu(l1(z1), 0.0)
+        h = torch.nn.functional.leaky_relu(l2(h), 0.0)
+        return l3(h)
+
+    def _torch_log_prob(self, x):
+        q0 = self._nf_model.q0
+        log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
+        z = x
+        for l1, l2, l3, aff in reversed(list(self._layers())):
+            z = z @ aff.assemble()
+            log_q = log_q + torch.sum(aff.log_S)
+            z1, z2 = z[:, :self.d], z[:, self.d:]
+            prm = self._mlp(l1, l2, l3, z1)
+            shift, scale = prm[:, 0::2], prm[:, 1::2]
+            z2 = (z2 - shift) * torch.exp(-scale)
+            log_q = log_q - torch.sum(scale, dim=1)
+            z = torch.cat([z1, z2], 1)
+        base = -0.5 * self.dim * math.log(2 * math.pi) - torch.sum(
+            q0.log_scale + 0.5 * torch.pow((z - q0.loc) / torch.exp(q0.log_scale), 2), 1)
+        return log_q + base
+
+    def _torch_sample(self, eps):
+        q0 = self._nf_model.q0
+        z = q0.loc + torch.exp(q0.log_scale) * eps
+        log_q = -0.5 * self.dim * math.log(2 * math.pi) - torch.sum(q0.log_scale + 0.5 * torch.pow(eps, 2), 1)
+        for l1, l2, l3, aff in self._layers():
+            z1, z2 = z[:, :self.d], z[:, self.d:]
+            prm = self._mlp(l1, l2, l3, z1)
+            shift, scale = prm[:, 0::2], prm[:, 1::2]
+            z2 = z2 * torch.exp(scale) + shift
+            log_q = log_q - torch.sum(scale, dim=1)
+            z = torch.cat([z1, z2], 1) @ aff.assemble(inverse=True)
+            log_q = log_q + torch.sum(aff.log_S)
+        return z, log_q
+
+
+def make_wrapped_normflow_realnvp(dim: int, n_flow_layers: int = 5, layer_nodes_per_dim: int = 10,
+                                  act_norm: bool = True) -> RealNVP:
+    """Same name/arguments as experiments/make_flow/make_normflow_model.py:82-96."""
+    return RealNVP(dim, n_flow_layers, layer_nodes_per_dim, act_norm)

@@ -1,0 +1,120 @@
+"""Target distributions of the hot path: ManyWell (fab/target_distributions/many_well.py:16-90,
+double_well.py:31-58) and the 40-mode GMM (fab/target_distributions/gmm.py:12-66) — same constructor
+arguments and `log_prob` semantics; `log_prob` runs csrc/target_device.h on the GPU."""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib
+
+
+class _NativeTarget(nn.Module):
+    def native_target(self) -> _lib.Target:
+        raise NotImplementedError
+
+    def _native_log_prob(self, x, with_grad=False):
+        lib = _lib.load()
+        _lib.require_device(x, "x")
+        x = x.detach().contiguous().float()
+        B = x.shape[0]
+        lp = torch.empty(B, dtype=torch.float32, device=x.device)
+        g = torch.empty_like(x) if with_grad else None
+        t = self.native_target()
+        _lib.check(lib.fabhip_target_log_prob(C.byref(t), _lib.ptr(x), _lib.ptr(lp), _lib.ptr(g), B,
+                                              _lib.stream_ptr()), "target_log_prob")
+        return lp, g
+
+    def log_prob_and_grad(self, x):
+        return self._native_log_prob(x, with_grad=True)
+
+
+class ManyWellEnergy(_NativeTarget):
+    """log p(x) = sum_i -(a x_{2i} + b x_{2i}^2 + c x_{2i}^4 + x_{2i+1}^2 / 2)."""
+
+    def __init__(self, dim=4, use_gpu: bool = True, normalised: bool = False, a=-0.5, b=-6.0, c=1.0):
+        super().__init__()
+        assert dim % 2 == 0
+        self.dim, self.n_wells = dim, dim // 2
+        self._a, self._b, self._c = a, b, c
+        self.normalised = normalised
+        self.centre = 1.7
+        self.register_buffer("_anchor", torch.zeros(1))
+        if use_gpu and torch.cuda.is_available():
+            self.cuda()
+        self.device = "cuda" if (use_gpu and torch.cuda.is_available()) else "cpu"
+
+    @property
+    def log_Z_2D(self):
+        if self._a == -0.5 and self._b == -6 and self._c == 1.0:
+            return np.log(11784.50927) + 0.5 * np.log(2 * math.pi)          # double_well.py:97-101
+        raise NotImplementedError
+
+    @property
+    def log_Z(self):
+        return torch.tensor(self.log_Z_2D * self.n_wells)
+
+    @property
+    def Z(self):
+        return torch.exp(self.log_Z)
+
+    def native_target(self):
+        t = _lib.Target()
+        t.kind, t.dim = _lib.TARGET_MANYWELL, self.dim
+        t.a, t.b, t.c = self._a, self._b, self._c
+        t.log_norm = float(self.log_Z_2D * self.n_wells) if self.normalised else 0.0
+        t.n_mix, t.locs, t.scales = 0, None, None
+        return t
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and x.requires_grad:          # generic autograd callers (base.py:50-56)
+            x1, x2 = x[:, 0::2], x[:, 1::2]
+            lp = -(self._a * x1 + self._b * x1.pow(2) + self._c * x1.pow(4) + 0.5 * x2.pow(2)).sum(-1)
+            return lp - float(self.log_Z) if self.normalised else lp
+        return self._native_log_prob(x)[0]
+
+
+class GMM(_NativeTarget):
+    def __init__(self, dim, n_mixes, loc_scaling, log_var_scaling=0.1, seed=0, n_test_set_samples=1000,
+                 use_gpu=True, true_expectation_estimation_n_samples=int(1e7)):
+        super().__init__()
+        self.seed, self.n_mixes, self.dim = seed, n_mixes, dim
+        self.n_test_set_samples = n_test_set_samples
+        mean = (torch.rand((n_mixes, dim)) - 0.5) * 2 * loc_scaling          # gmm.py:22 (caller seeds torch)
+        log_var = torch.ones((n_mixes, dim)) * log_var_scaling
+        self.register_buffer("cat_probs", torch.ones(n_mixes))
+        self.register_buffer("locs", mean)
+        self.register_buffer("scale_trils", torch.diag_embed(F.softplus(log_var)))
+        self.register_buffer("scales", F.softplus(log_var).contiguous())
+        self.device = "cuda" if (use_gpu and torch.cuda.is_available()) else "cpu"
+        if self.device == "cuda":
+            self.cuda()
+
+    def native_target(self):
+        t = _lib.Target()
+        t.kind, t.dim = _lib.TARGET_GMM, self.dim
+        t.a = t.b = t.c = 0.0
+        t.log_norm = 0.0
+        t.n_mix = self.n_mixes
+        t.locs, t.scales = self.locs.data_ptr(), self.scales.data_ptr()
+        return t
+
+    @property
+    def distribution(self):
+        mix = torch.distributions.Categorical(self.cat_probs)
+        com = torch.distributions.MultivariateNormal(self.locs, scale_tril=self.scale_trils, validate_args=False)
+        return torch.distributions.MixtureSameFamily(mix, com, validate_args=False)
+
+    def sample(self, shape=(1,)):
+        return self.distribution.sample(shape)
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        if torch.is_grad_enabled() and x.requires_grad:
+            lp = self.distribution.log_prob(x)
+            mask = torch.zeros_like(lp)
+            mask[lp < -1e4] = -float("inf")
+            return lp + mask
+        return self._native_log_prob(x)[0]

@@ -1,0 +1,256 @@
+/* fabhip.h — C ABI of libfabhip.so: MI355X (gfx950) kernels for the fab-torch AIS / flow-density
+ * hot path.  This is the drop-in boundary: plain device pointers + sizes, no torch types.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the field comment says "host";
+ *   - all tensors are contiguous row-major float32 unless stated; indices are int64;
+ *   - functions only ENQUEUE work on `stream` (a hipStream_t); they never allocate, never
+ *     synchronise and never throw; scratch comes from the caller (`*_workspace_bytes`);
+ *   - return value: FABHIP_OK or a negative FABHIP_E* code (see fabhip_strerror).
+ *
+ * Each entry point cites the reference (lollcat/fab-torch) interface it replaces.
+ */
+#ifndef FABHIP_H
+#define FABHIP_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fabhip_stream_t; /* hipStream_t */
+
+enum {
+    FABHIP_OK = 0,
+    FABHIP_EINVAL = -1,  /* bad shape / null pointer / misaligned buffer             */
+    FABHIP_ENOTSUP = -2, /* dimension beyond compiled limits (dim<=64, width<=512)   */
+    FABHIP_ELAUNCH = -3, /* hipGetLastError() != hipSuccess after a launch           */
+    FABHIP_ENOSPC = -4   /* workspace too small                                      */
+};
+
+#define FABHIP_MAX_LAYERS 64
+#define FABHIP_MAX_DIM 64
+#define FABHIP_MAX_WIDTH 512
+
+const char* fabhip_strerror(int code);
+int fabhip_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * RealNVP flow  (replaces normflows NormalizingFlow.sample / .log_prob as wrapped by
+ * fab/wrappers/normflows.py:16-31, architecture of experiments/make_flow/make_normflow_model.py:11-30)
+ * ---------------------------------------------------------------------------------------- */
+
+/* Raw parameters in normflows / nn.Linear layout (weight[out][in]); host arrays of device pointers. */
+typedef struct {
+    int32_t dim, n_layers, width;
+    const float* w1[FABHIP_MAX_LAYERS];     /* [width][d]          d = ceil(dim/2)            */
+    const float* b1[FABHIP_MAX_LAYERS];     /* [width]                                        */
+    const float* w2[FABHIP_MAX_LAYERS];     /* [width][width]                                 */
+    const float* b2[FABHIP_MAX_LAYERS];     /* [width]                                        */
+    const float* w3[FABHIP_MAX_LAYERS];     /* [2(dim-d)][width]   rows interleaved shift,scale */
+    const float* b3[FABHIP_MAX_LAYERS];     /* [2(dim-d)]                                     */
+    const float* lu_L[FABHIP_MAX_LAYERS];   /* [dim][dim] InvertibleAffine.L                  */
+    const float* lu_U[FABHIP_MAX_LAYERS];   /* [dim][dim] InvertibleAffine.U                  */
+    const float* log_S[FABHIP_MAX_LAYERS];  /* [dim]                                          */
+    const float* sign_S[FABHIP_MAX_LAYERS]; /* [dim]                                          */
+    const float* perm_P[FABHIP_MAX_LAYERS]; /* [dim][dim] permutation matrix                  */
+    const float* loc;                       /* [dim] DiagGaussian.loc                         */
+    const float* log_scale;                 /* [dim] DiagGaussian.log_scale                   */
+} fabhip_flow_params;
+
+/* Number of floats of the MFMA-tiled parameter image for a (dim, n_layers, width) flow. */
+int64_t fabhip_flow_packed_floats(int32_t dim, int32_t n_layers, int32_t width);
+
+/* Assemble W = P L U and W^-1 (fp64 triangular inverses) per layer and re-tile every matrix
+ * (and its transpose) into v_mfma_f32_16x16x4_f32 B-operand order.  Call after each optimiser step. */
+int fabhip_flow_pack(const fabhip_flow_params* params, float* packed, fabhip_stream_t stream);
+
+typedef struct {
+    int32_t dim, n_layers, width;
+    const float* packed; /* fabhip_flow_pack output */
+} fabhip_flow;
+
+/* x, log_q = flow.sample_and_log_prob given base noise eps[B][dim] ~ N(0,1)
+ * (fab/wrappers/normflows.py:16-18 -> NormalizingFlow.sample). */
+int fabhip_flow_sample(const fabhip_flow* flow, const float* eps, float* x, float* log_q, int64_t B,
+                       fabhip_stream_t stream);
+
+/* log_q[B] = flow.log_prob(x[B][dim]); if grad_x != NULL also d log_q / d x [B][dim]
+ * (fab/wrappers/normflows.py:23-24 and the autograd call of fab/sampling_methods/base.py:50-56). */
+int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                         fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Targets (fab/target_distributions/many_well.py:81-90, double_well.py:44-58, gmm.py:57-66)
+ * ---------------------------------------------------------------------------------------- */
+enum { FABHIP_TARGET_MANYWELL = 1, FABHIP_TARGET_GMM = 2 };
+
+typedef struct {
+    int32_t kind, dim;
+    float a, b, c;       /* many well: energy a x + b x^2 + c x^4 on even dims, x^2/2 on odd     */
+    float log_norm;      /* subtracted from log p (0 unless `normalised`)                        */
+    int32_t n_mix;       /* GMM: number of equally weighted components                           */
+    const float* locs;   /* GMM: [n_mix][dim]                                                    */
+    const float* scales; /* GMM: [n_mix][dim] diagonal of scale_tril                             */
+} fabhip_target;
+
+int fabhip_target_log_prob(const fabhip_target* target, const float* x, float* log_p, float* grad_x,
+                           int64_t B, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Point (fab/sampling_methods/base.py:7-47) as a struct of device arrays.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    float* x;          /* [B][dim] */
+    float* log_q;      /* [B]      */
+    float* log_p;      /* [B]      */
+    float* grad_log_q; /* [B][dim] or NULL (Metropolis) */
+    float* grad_log_p; /* [B][dim] or NULL              */
+} fabhip_point;
+
+/* create_point(x, ...) with gradients: fab/sampling_methods/base.py:59-72. point.x is read. */
+int fabhip_create_point(const fabhip_flow* flow, const fabhip_target* target, const fabhip_point* point,
+                        int32_t with_grad, int64_t B, fabhip_stream_t stream);
+
+/* Coefficients of the annealed density (fab/sampling_methods/base.py:76-118), float32:
+ *   log pi_beta = c_q log_q + c_p log_p ;  grad = g_q grad_log_q + g_p grad_log_p
+ * (g_p = 2 beta when not p_target: the reference's hard-coded factor, base.py:116). */
+typedef struct {
+    float c_q, c_p, g_q, g_p;
+} fabhip_anneal;
+void fabhip_anneal_coefs(double beta, double alpha, int32_t p_target, fabhip_anneal* out);
+
+/* ------------------------------------------------------------------------------------------
+ * HMC transition  (fab/sampling_methods/transition_operators/hmc.py:105-202)
+ * One call = HamiltonianMonteCarlo.transition(point, i, beta): n_outer x (L leapfrogs,
+ * Metropolis accept, in-place commit, step-size adaptation) and, if `log_w`, the AIS
+ * log-weight increment of ais.py:93-100 with the coefficients `next`.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    fabhip_flow flow;
+    fabhip_target target;
+    fabhip_point point;     /* in/out, mutated in place like the reference           */
+    int64_t B;              /* rows allocated                                        */
+    const int32_t* n_valid; /* device scalar: rows in use (NULL -> B)                */
+    fabhip_anneal cur;      /* beta_j                                                */
+    fabhip_anneal next;     /* beta_{j+1} (used when log_w != NULL)                  */
+    float* log_w;           /* [B] in/out or NULL                                    */
+    const float* noise_p;   /* [n_outer][B][dim] ~ N(0,1)   (hmc.py:134)             */
+    const float* noise_e;   /* [n_outer][B]      ~ Exp(1)   (hmc.py:118)             */
+    float* epsilons;        /* -> epsilons[i-1][0..n_outer)  (state buffer, updated) */
+    float* common_epsilon;  /* [1] state buffer, updated                             */
+    const float* mass;      /* [dim]                                                 */
+    int32_t n_outer, L;
+    float max_grad, target_p_accept;
+    int32_t tune;           /* 1 = adapt step sizes (not eval_mode)                  */
+    float* p_accept;        /* [n_outer] out (mean acceptance prob) or NULL          */
+    float* avg_distance;    /* [1] out, store_info's distance statistic, or NULL     */
+    void* workspace;
+    size_t workspace_bytes;
+} fabhip_hmc_args;
+
+size_t fabhip_hmc_workspace_bytes(int64_t B, int32_t dim, int32_t n_outer);
+int fabhip_hmc_transition(const fabhip_hmc_args* args, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Metropolis transition (fab/sampling_methods/transition_operators/metropolis.py:51-74)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    fabhip_flow flow;
+    fabhip_target target;
+    fabhip_point point;      /* grads unused */
+    int64_t B;
+    const int32_t* n_valid;
+    fabhip_anneal cur, next;
+    float* log_w;
+    const float* noise_x;    /* [n_updates][B][dim] ~ N(0,1)  (metropolis.py:57) */
+    const float* noise_u;    /* [n_updates][B]      ~ U(0,1)  (metropolis.py:65) */
+    float* noise_scalings;   /* -> noise_scalings[i-1][0..n_updates), updated    */
+    int32_t n_updates;
+    float target_p_accept;
+    int32_t tune;            /* adjust_step_size and not eval_mode               */
+    void* workspace;
+    size_t workspace_bytes;
+} fabhip_metropolis_args;
+
+size_t fabhip_metropolis_workspace_bytes(int64_t B, int32_t dim, int32_t n_updates);
+int fabhip_metropolis_transition(const fabhip_metropolis_args* args, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Whole AIS call  (fab/sampling_methods/ais.py:53-105): sample the flow, create the point,
+ * initial log-weights, NaN/inf filtering (stable compaction, ais.py:190-213), M transitions
+ * with log-weight accumulation, final filtering, ESS / log Z statistics — all enqueued by
+ * ONE host call, no host synchronisation inside.
+ * ---------------------------------------------------------------------------------------- */
+enum { FABHIP_TRANSITION_HMC = 1, FABHIP_TRANSITION_METROPOLIS = 2 };
+
+typedef struct {
+    fabhip_flow flow;
+    fabhip_target target;
+    int64_t B;                /* requested batch size                                        */
+    int32_t M;                /* n_intermediate_distributions                                */
+    const double* betas;      /* host, [M+2] (B_space, ais.py:108-129)                       */
+    double alpha;
+    int32_t p_target;
+    int32_t transition;       /* FABHIP_TRANSITION_*                                         */
+    const float* eps0;        /* [B][dim] base noise                                         */
+    const float* noise_a;     /* HMC: [M][n_inner][B][dim] momenta ; Metropolis: proposals   */
+    const float* noise_b;     /* HMC: [M][n_inner][B] Exp(1)       ; Metropolis: U(0,1)      */
+    float* step_state;        /* HMC: epsilons[M][n_outer] ; Metropolis: noise_scalings[M][n_updates] */
+    float* common_epsilon;    /* HMC only                                                    */
+    const float* mass;        /* HMC only                                                    */
+    int32_t n_inner;          /* n_outer (HMC) / n_updates (Metropolis)                      */
+    int32_t L;
+    float max_grad, target_p_accept;
+    int32_t tune;
+    fabhip_point point;       /* out [B] rows; first n_valid[1] rows are the result          */
+    float* log_w;             /* out [B]                                                     */
+    int32_t* n_valid;         /* out device int32[2]: rows after "chain init" / "chain end"  */
+    float* stats;             /* out device float[16]: [0] ess_base [1] - [2] rows after init
+                                 [3] ess_ais [4] log_Z [5] rows at chain end [6] p_accept first dist
+                                 [7] p_accept last dist [8] avg distance first [9] avg distance last   */
+    void* workspace;
+    size_t workspace_bytes;
+} fabhip_ais_args;
+
+size_t fabhip_ais_workspace_bytes(int64_t B, int32_t dim, int32_t n_inner);
+int fabhip_ais_run(const fabhip_ais_args* args, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * ESS / log Z  (fab/utils/numerical.py:18-23, fab/sampling_methods/ais.py:80-86)
+ * out[0] = normalised ESS of log_w[0..n), out[1] = logsumexp(log_w) - log(n_norm), out[2] = n used.
+ * n is read from n_ptr (device) when n_ptr != NULL.
+ * ---------------------------------------------------------------------------------------- */
+size_t fabhip_ess_workspace_bytes(int64_t n);
+int fabhip_ess_logz(const float* log_w, int64_t n, const int32_t* n_ptr, double n_norm, float* out,
+                    void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Resampling  (fab/sampling_methods/base.py:121-124 -> torch.multinomial)
+ * ---------------------------------------------------------------------------------------- */
+/* Bit-exact restatement of torch's CPU multinomial-with-replacement given probs[n] (float32) and
+ * the float64 uniforms it consumed: sequential fp32 cumsum, /sum, last bucket = 1, lower bound. */
+size_t fabhip_multinomial_torch_workspace_bytes(int64_t n);
+int fabhip_multinomial_torch(const float* probs, int64_t n, const double* u, int64_t n_samples,
+                             int64_t* idx, void* workspace, size_t workspace_bytes,
+                             fabhip_stream_t stream);
+
+/* Scalable fixed-point CDF resamplers from log-weights (any n): p_i = fl32(exp(w_i - max w)) via
+ * float64, q_i = floor(p_i 2^36), C = inclusive integer prefix sum (decoupled look-back scan).
+ *   multinomial: idx_k = first j with C_j > floor(u_k * C_total)
+ *   systematic : idx_k = first j with C_j > floor((k + u0) * (C_total / n_samples))            */
+size_t fabhip_resample_workspace_bytes(int64_t n);
+int fabhip_resample_multinomial(const float* log_w, int64_t n, const double* u, int64_t n_samples,
+                                int64_t* idx, void* workspace, size_t workspace_bytes,
+                                fabhip_stream_t stream);
+int fabhip_resample_systematic(const float* log_w, int64_t n, double u0, int64_t n_samples, int64_t* idx,
+                               void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+/* dst[k][:] = src[idx[k]][:]  (Point.__getitem__ / tensor indexing used by resample) */
+int fabhip_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t n_out, int64_t row_len,
+                       fabhip_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FABHIP_H */

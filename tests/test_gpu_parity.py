@@ -1,0 +1,301 @@
+"""GPU parity tests (run with -m gpu on the MI355X box): the HIP path, called through the C ABI,
+against (a) the golden fixtures produced by the imported reference and (b) the CPU oracle on the same
+seeded inputs.  Tolerances: BASELINE.json north_star — indices bit-exact, log-weights / flow
+log-probs within 1e-4 relative fp32."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, oracle_flow_from_golden, close, max_rel_err, RTOL
+
+pytestmark = pytest.mark.gpu
+
+fa = pytest.importorskip("fab_torch_amd")
+from oracle import ais as oais            # noqa: E402
+from oracle import flow as oflow          # noqa: E402
+from oracle import numerical as onum      # noqa: E402
+from oracle import targets as otgt        # noqa: E402
+
+DEV = "cuda"
+
+
+def hip_flow_from_oracle(nf):
+    D = nf.q0.loc.shape[1]
+    K = len(nf.flows) // 2
+    W = nf.flows[0].flows[1].param_map.net[0].weight.shape[0]
+    f = fa.RealNVP(D, K, W // D)
+    f._nf_model.load_state_dict(nf.state_dict())
+    return f.to(DEV).requires_grad_(False)
+
+
+def seeded_flow(D, K, nodes, seed, std=0.05):
+    torch.manual_seed(seed)
+    nf = oflow.make_realnvp(D, K, nodes)
+    oflow.randomize_last_layers(nf, std, seed + 1)
+    return nf
+
+
+def oracle_logq_grad(nf, x):
+    xg = x.clone().requires_grad_(True)
+    lq = nf.log_prob(xg)
+    g = torch.autograd.grad(lq, xg, torch.ones_like(lq))[0]
+    return lq.detach(), g
+
+
+FLOW_CASES = [(6, 3, 5, 50), (32, 2, 1, 64), (2, 2, 8, 33), (2, 4, 40, 100), (6, 8, 40, 70), (32, 10, 10, 48),
+              (5, 2, 4, 17), (60, 2, 4, 20)]
+
+
+@pytest.mark.parametrize("D,K,nodes,B", FLOW_CASES)
+def test_flow_log_prob_grad_sample_vs_oracle(D, K, nodes, B):
+    nf = seeded_flow(D, K, nodes, 100 + D + K)
+    hf = hip_flow_from_oracle(nf)
+    torch.manual_seed(5)
+    eps = torch.randn(B, D)
+    with torch.no_grad():
+        x_o, lq_s_o = nf.sample_eps(eps)
+    x_h, lq_s_h = hf.native_sample(eps.to(DEV))
+    assert close(x_h, x_o, RTOL), f"sample x err {max_rel_err(x_h, x_o):.2e}"
+    assert close(lq_s_h, lq_s_o, RTOL), f"sample log_q err {max_rel_err(lq_s_h, lq_s_o):.2e}"
+    x = x_o + 0.1 * torch.randn(B, D)
+    lq_o, g_o = oracle_logq_grad(nf, x)
+    lq_h, g_h = hf.log_prob_and_grad(x.to(DEV))
+    assert close(lq_h, lq_o, RTOL), f"log_q err {max_rel_err(lq_h, lq_o):.2e}"
+    assert close(g_h, g_o, RTOL), f"grad err {max_rel_err(g_h, g_o):.2e}"
+    lq_h2 = hf.log_prob(x.to(DEV))
+    assert close(lq_h2, lq_o, RTOL)
+    # differentiable torch-op expression of the same flow (training path) agrees too
+    hf.requires_grad_(True)
+    lq_t = hf.log_prob(x.to(DEV))
+    assert lq_t.requires_grad and close(lq_t, lq_o, RTOL)
+
+
+def test_targets_vs_golden():
+    g = load_golden("g3_targets.npz")
+    for D in (6, 32):
+        t = fa.ManyWellEnergy(D)
+        x = torch.tensor(g[f"mw{D}_x"]).to(DEV)
+        lp, gr = t.log_prob_and_grad(x)
+        assert close(lp, g[f"mw{D}_lp"], 1e-5), f"manywell lp err {max_rel_err(lp, g[f'mw{D}_lp']):.2e}"
+        ref = g[f"mw{D}_g"]
+        fin = np.isfinite(ref)
+        np.testing.assert_allclose(gr.cpu().numpy()[fin], ref[fin], rtol=1e-5, atol=1e-4)
+        assert abs(float(t.log_Z) - float(g[f"mw{D}_logZ"])) < 1e-4
+    torch.manual_seed(0)
+    gm = fa.GMM(2, 40, 40.0, 1.0)
+    np.testing.assert_array_equal(gm.locs.cpu().numpy(), g["gmm_locs"])
+    lp = gm.log_prob(torch.tensor(g["gmm_x"]).to(DEV)).cpu().numpy()
+    ref = g["gmm_lp"]
+    assert np.array_equal(np.isnan(lp), np.isnan(ref)) and np.array_equal(np.isneginf(lp), np.isneginf(ref))
+    fin = np.isfinite(ref)
+    np.testing.assert_allclose(lp[fin], ref[fin], rtol=1e-5, atol=1e-4)
+    # GMM gradient against autograd of the oracle
+    og = otgt.GMM(2, 40, 40.0, 1.0, seed=0)
+    x = torch.randn(40, 2) * 20
+    xg = x.clone().requires_grad_(True)
+    l = og.log_prob(xg)
+    go = torch.autograd.grad(l, xg, torch.ones_like(l))[0]
+    _, gh = gm.log_prob_and_grad(x.to(DEV))
+    assert close(gh, go, 1e-4), f"gmm grad err {max_rel_err(gh, go):.2e}"
+
+
+def test_ess_logz_vs_golden():
+    g = load_golden("g4_ess.npz")
+    for i in range(5):
+        lw = torch.tensor(g[f"lw{i}"]).to(DEV)
+        out = fa.ess_and_log_z(lw).cpu().numpy()
+        np.testing.assert_allclose(out[0], g[f"ess{i}"], rtol=1e-5)
+        np.testing.assert_allclose(out[1], g[f"logZ{i}"], rtol=1e-5, atol=1e-5)
+        assert int(out[2]) == lw.shape[0]
+    big = torch.randn(1 << 20, generator=torch.Generator().manual_seed(0)) * 3
+    out = fa.ess_and_log_z(big.to(DEV)).cpu().numpy()
+    np.testing.assert_allclose(out[0], onum.effective_sample_size(big.double()).item(), rtol=1e-5)
+
+
+def test_multinomial_torch_compat_bit_exact_vs_reference():
+    g = load_golden("g5_multinomial.npz")
+    for N in (64, 1024, 4096):
+        idx = fa.multinomial_torch_compat(torch.tensor(g[f"probs_{N}"]).to(DEV), torch.tensor(g[f"u_{N}"]).to(DEV))
+        np.testing.assert_array_equal(idx.cpu().numpy(), g[f"idx_{N}"])
+
+
+@pytest.mark.parametrize("N", [1, 5, 4096, 4097, 100_000, (1 << 20) + 7])
+def test_fixed_point_resamplers_bit_exact_vs_oracle(N):
+    rng = np.random.default_rng(N)
+    lw = (rng.standard_normal(N) * 3).astype(np.float32)
+    if N > 10:
+        lw[3] = -np.inf; lw[7] = np.nan; lw[N // 2] = np.inf
+    u = rng.random(N)
+    lw_d = torch.tensor(lw).to(DEV)
+    idx = fa.multinomial_indices(lw_d, u=torch.tensor(u).to(DEV)).cpu().numpy()
+    np.testing.assert_array_equal(idx, onum.multinomial_fixed(lw, u))
+    s = fa.systematic_indices(lw_d, u0=0.37).cpu().numpy()
+    np.testing.assert_array_equal(s, onum.systematic_fixed(lw, 0.37))
+    s2 = fa.systematic_indices(lw_d, u0=0.9, n_samples=max(1, N // 3)).cpu().numpy()
+    np.testing.assert_array_equal(s2, onum.systematic_fixed(lw, 0.9, max(1, N // 3)))
+
+
+def test_resample_large_properties():
+    """BASELINE-scale N through size-independent properties (sortedness, offspring counts, gather)."""
+    N = 1 << 24
+    g = torch.Generator(device=DEV).manual_seed(0)
+    lw = torch.randn(N, device=DEV, generator=g) * 3
+    s = fa.systematic_indices(lw, u0=0.25)
+    assert bool((s[1:] >= s[:-1]).all()) and int(s.min()) >= 0 and int(s.max()) < N
+    counts = torch.bincount(s, minlength=N).double()
+    expect = torch.softmax(lw.double(), 0) * N
+    assert float((counts - expect).abs().max()) <= 1.0 + 1e-6 * float(expect.max())
+    x = torch.arange(N, device=DEV, dtype=torch.float32)[:, None].repeat(1, 8)
+    xr = fa.resample(x, lw, method="systematic")
+    assert xr.shape == (N, 8) and bool((xr[:, 0] == xr[:, 7]).all())
+    m = fa.multinomial_indices(lw)
+    assert int(m.min()) >= 0 and int(m.max()) < N
+    top = int(torch.argmax(lw))
+    assert abs(float((m == top).sum()) - float(expect[top])) < 6 * float(expect[top]) ** 0.5 + 5
+
+
+def _pt_from(g, keys, dev=DEV):
+    return fa.Point(*(torch.tensor(g[k]).to(dev) for k in keys))
+
+
+@pytest.mark.parametrize("tag", ["d6", "d32", "d6_outer2"])
+def test_hmc_transition_vs_reference_golden(tag):
+    g = load_golden(f"g6_hmc_{tag}.npz")
+    nf = oracle_flow_from_golden(g)
+    hf = hip_flow_from_oracle(nf)
+    D = g["in_x"].shape[1]
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(int(g["M"]), D, hf.log_prob, target.log_prob, alpha=float(g["alpha"]),
+                                   p_target=bool(g["p_target"]), n_outer=int(g["n_outer"]), L=int(g["L"])).to(DEV)
+    hmc.epsilons.copy_(torch.tensor(g["in_epsilons"]))
+    hmc.common_epsilon.copy_(torch.tensor(g["in_common_epsilon"]))
+    pt = _pt_from(g, ("in_x", "in_log_q", "in_log_p", "in_gq", "in_gp"))
+    res = hmc.transition(pt, int(g["i"]), float(g["beta"]), noise_p=torch.tensor(g["noise_p"]).to(DEV),
+                         noise_e=torch.tensor(g["noise_e"]).to(DEV))
+    assert res is pt
+    acc_ref = (g["out_x"] != g["in_x"]).any(1)
+    acc_hip = (res.x.cpu().numpy() != g["in_x"]).any(1)
+    assert np.array_equal(acc_ref, acc_hip), f"accept masks differ in {np.sum(acc_ref != acc_hip)} rows"
+    for name, got, ref in (("x", res.x, g["out_x"]), ("log_q", res.log_q, g["out_log_q"]),
+                           ("log_p", res.log_p, g["out_log_p"]), ("gq", res.grad_log_q, g["out_gq"]),
+                           ("gp", res.grad_log_p, g["out_gp"])):
+        assert close(got, ref, RTOL), f"{name} err {max_rel_err(got, ref):.2e}"
+    np.testing.assert_allclose(hmc.epsilons.cpu().numpy(), g["out_epsilons"], rtol=1e-6)
+    np.testing.assert_allclose(hmc.common_epsilon.cpu().numpy(), g["out_common_epsilon"], rtol=1e-6)
+
+
+def test_metropolis_transition_vs_reference_golden():
+    g = load_golden("g7_metropolis.npz")
+    nf = oracle_flow_from_golden(g)
+    hf = hip_flow_from_oracle(nf)
+    torch.manual_seed(0)
+    target = fa.GMM(2, 40, 40.0, 1.0)
+    met = fa.Metropolis(int(g["M"]), 2, hf.log_prob, target.log_prob, int(g["n_updates"]), alpha=float(g["alpha"]),
+                        p_target=False, max_step_size=5.0, min_step_size=1.0).to(DEV)
+    pt = _pt_from(g, ("in_x", "in_log_q", "in_log_p"))
+    res = met.transition(pt, int(g["i"]), float(g["beta"]), noise_x=torch.tensor(g["noise_x"]).to(DEV),
+                         noise_u=torch.tensor(g["noise_u"]).to(DEV))
+    assert close(res.x, g["out_x"], 1e-5), f"x err {max_rel_err(res.x, g['out_x']):.2e}"
+    assert close(res.log_q, g["out_log_q"], RTOL) and close(res.log_p, g["out_log_p"], RTOL)
+    np.testing.assert_allclose(met.noise_scalings.cpu().numpy(), g["out_noise_scalings"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["mw6_hmc_m4", "mw6_hmc_m8geo_ptarget", "mw32_hmc_m8"])
+def test_full_ais_hmc_vs_reference_golden(tag):
+    g = load_golden(f"g8_ais_{tag}.npz")
+    nf = oracle_flow_from_golden(g)
+    hf = hip_flow_from_oracle(nf)
+    D, M = g["eps0"].shape[1], int(g["M"])
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=float(g["alpha"]),
+                                   p_target=bool(g["p_target"]), L=int(g["L"])).to(DEV)
+    hmc.epsilons.copy_(torch.tensor(g["in_epsilons"]))
+    hmc.common_epsilon.copy_(torch.tensor(g["in_common_epsilon"]))
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, p_target=bool(g["p_target"]), alpha=float(g["alpha"]),
+                                       n_intermediate_distributions=M, distribution_spacing_type=str(g["spacing"]))
+    np.testing.assert_array_equal(ais.B_space.numpy(), g["B_space"])
+    pt, log_w = ais.sample_and_log_weights(g["eps0"].shape[0], eps0=torch.tensor(g["eps0"]).to(DEV),
+                                           noise_a=torch.tensor(g["noise_p"]).to(DEV),
+                                           noise_b=torch.tensor(g["noise_e"]).to(DEV))
+    info = ais.get_logging_info()
+    # Chaotic dynamics: a chain whose accept/reject decision sits within rounding of the threshold may
+    # legitimately flip; require every chain to match except at most one such flip, and check it.
+    bad = np.abs(pt.x.cpu().numpy() - g["out_x"]).max(1) > 1e-3 * max(1.0, np.abs(g["out_x"]).max())
+    assert bad.sum() <= 1, f"{bad.sum()} chains diverged from the reference"
+    ok = ~bad
+    assert close(log_w[ok], g["log_w"][ok], RTOL), f"log_w err {max_rel_err(log_w[ok], g['log_w'][ok]):.2e}"
+    assert close(pt.log_q[ok], g["out_log_q"][ok], RTOL) and close(pt.log_p[ok], g["out_log_p"][ok], RTOL)
+    np.testing.assert_allclose(hmc.epsilons.cpu().numpy(), g["out_epsilons"], rtol=1e-6)
+    np.testing.assert_allclose(hmc.common_epsilon.cpu().numpy(), g["out_common_epsilon"], rtol=1e-6)
+    if not bad.any():
+        assert abs(info["ess_ais"] - float(g["ess_ais"])) <= 0.01 * float(g["ess_ais"])       # "ESS within 1%"
+        assert abs(info["log_Z"] - float(g["log_Z"])) <= RTOL * abs(float(g["log_Z"])) + 1e-4
+    assert abs(info["ess_base"] - float(g["ess_base"])) <= 0.01 * float(g["ess_base"])
+    assert abs(info["dist0_p_accept_0"] - float(g["dist0_p_accept_0"])) < 1e-3
+
+
+def test_full_ais_metropolis_vs_reference_golden():
+    g = load_golden("g8_ais_gmm_metropolis.npz")
+    nf = oracle_flow_from_golden(g)
+    hf = hip_flow_from_oracle(nf)
+    torch.manual_seed(0)
+    target = fa.GMM(2, 40, 40.0, 1.0)
+    M = int(g["M"])
+    met = fa.Metropolis(M, 2, hf.log_prob, target.log_prob, int(g["n_updates"]), alpha=float(g["alpha"]),
+                        p_target=False, max_step_size=5.0, min_step_size=2.0).to(DEV)
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, met, False, float(g["alpha"]), M)
+    pt, log_w = ais.sample_and_log_weights(g["eps0"].shape[0], eps0=torch.tensor(g["eps0"]).to(DEV),
+                                           noise_a=torch.tensor(g["noise_x"]).to(DEV),
+                                           noise_b=torch.tensor(g["noise_u"]).to(DEV))
+    assert close(pt.x, g["out_x"], 1e-5), f"x err {max_rel_err(pt.x, g['out_x']):.2e}"
+    assert close(log_w, g["log_w"], RTOL), f"log_w err {max_rel_err(log_w, g['log_w']):.2e}"
+    np.testing.assert_allclose(met.noise_scalings.cpu().numpy(), g["out_noise_scalings"], rtol=1e-6)
+    info = ais.get_logging_info()
+    assert abs(info["ess_ais"] - float(g["ess_ais"])) <= 0.01 * float(g["ess_ais"])
+
+
+def test_nan_rows_are_compacted_like_the_reference():
+    """ais.py:190-213: rows with non-finite log_p / log_q are removed (stable), the rest keep their order."""
+    D, M, B = 6, 2, 40
+    nf = seeded_flow(D, 2, 5, 77)
+    hf = hip_flow_from_oracle(nf)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1,
+                                   eval_mode=True).to(DEV)
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, M)
+    torch.manual_seed(1)
+    eps0 = torch.randn(B, D)
+    eps0[5, 0] = float("nan"); eps0[17, 2] = float("inf")
+    noise_p = torch.randn(M, 1, B, D); noise_e = torch.empty(M, 1, B).exponential_()
+    pt, log_w = ais.sample_and_log_weights(B, eps0=eps0.to(DEV), noise_a=noise_p.to(DEV), noise_b=noise_e.to(DEV))
+    assert pt.x.shape[0] == B - 2 and log_w.shape[0] == B - 2
+    # oracle on the same inputs
+    otarget = otgt.ManyWell(D)
+    ohmc = oais.HMC(M, D, nf.log_prob, otarget.log_prob, alpha=2.0, p_target=False, epsilon=0.1, eval_mode=True)
+    oa = oais.AIS(lambda e: tuple(t.detach() for t in nf.sample_eps(e)), nf.log_prob, otarget.log_prob, ohmc, False, 2.0, M)
+    opt, olw, oinfo = oa.sample_and_log_weights(eps0, noise_p, noise_e)
+    assert close(pt.x, opt.x, RTOL) and close(log_w, olw, RTOL)
+    assert abs(ais._logging_info.log_Z - oinfo.log_Z) < 1e-3
+
+
+def test_ais_headline_config_vs_oracle():
+    """ManyWell-32, RealNVP 10x(16-320-320-32), M=8, L=5 (BASELINE headline), B=32: per-transition parity with
+    frozen step sizes and tolerance to chaotic flips: compare statistics and the non-diverged chains."""
+    D, K, M, B = 32, 10, 8, 32
+    nf = seeded_flow(D, K, 10, 9)
+    hf = hip_flow_from_oracle(nf)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.15,
+                                   eval_mode=True).to(DEV)
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, M)
+    torch.manual_seed(3)
+    eps0 = torch.randn(B, D); noise_p = torch.randn(M, 1, B, D); noise_e = torch.empty(M, 1, B).exponential_()
+    pt, log_w = ais.sample_and_log_weights(B, eps0=eps0.to(DEV), noise_a=noise_p.to(DEV), noise_b=noise_e.to(DEV))
+    otarget = otgt.ManyWell(D)
+    ohmc = oais.HMC(M, D, nf.log_prob, otarget.log_prob, alpha=2.0, p_target=False, epsilon=0.15, eval_mode=True)
+    oa = oais.AIS(lambda e: tuple(t.detach() for t in nf.sample_eps(e)), nf.log_prob, otarget.log_prob, ohmc, False, 2.0, M)
+    opt, olw, oinfo = oa.sample_and_log_weights(eps0, noise_p, noise_e)
+    bad = (pt.x.cpu() - opt.x).abs().max(1).values > 1e-2
+    assert bad.sum() <= 1, f"{int(bad.sum())} of {B} chains diverged"
+    ok = ~bad
+    assert close(log_w.cpu()[ok], olw[ok], 5e-4), f"log_w err {max_rel_err(log_w.cpu()[ok], olw[ok]):.2e}"
