@@ -18,6 +18,9 @@ constexpr int MAX_WIDTH = 512;  // hidden width <= 512 (8 column tiles per wave)
 
 FAB_HD int ceil_div(int a, int b) { return (a + b - 1) / b; }
 FAB_HD int pad16(int a) { return ceil_div(a, 16) * 16; }
+FAB_HD int pad32(int a) { return ceil_div(a, 32) * 32; }
+// hidden width is padded to 64 * (column tiles per wave), tiles per wave in {1, 2, 4, 5, 8}
+FAB_HD int ntw_variant(int W) { const int p = ceil_div(W, 64); return p <= 2 ? p : (p <= 4 ? 4 : (p <= 5 ? 5 : 8)); }
 
 // Geometry of one RealNVP flow (experiments/make_flow/make_normflow_model.py:11-30):
 // K x [AffineCouplingBlock(MLP[d, W, W, 2(D-d)], exp) + InvertibleAffine(D)], DiagGaussian base.
@@ -41,9 +44,11 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     f.D = D; f.K = K; f.W = W;
     f.d = (D + 1) / 2;          // int(D/2 + 0.5)
     f.DO = D - f.d;
-    f.Dp = pad16(D); f.dp = pad16(f.d); f.DOp = pad16(f.DO); f.Wp = pad16(W);
-    f.KBD = f.Dp / 16; f.NTD = f.Dp / 16;
-    f.KBd = f.dp / 16; f.NTd = f.dp / 16;
+    // K extents are padded to 32 (even k-block counts: 2-deep weight ring), the hidden width to
+    // 64 * tiles-per-wave (4-deep ring, every wave owns the same number of column tiles)
+    f.Dp = pad32(D); f.dp = pad32(f.d); f.DOp = pad16(f.DO); f.Wp = 64 * ntw_variant(W);
+    f.KBD = f.Dp / 16; f.NTD = pad16(D) / 16;
+    f.KBd = f.dp / 16; f.NTd = pad16(f.d) / 16;
     f.KBW = f.Wp / 16; f.NTW = f.Wp / 16;
     f.KBO = 2 * f.DOp / 16; f.NTO = 2 * f.DOp / 16;
     int o = 0;
@@ -80,7 +85,7 @@ FAB_HD FlowLds make_flow_lds(const FlowDims& f, bool with_grad) {
     l.DS = f.Dp + 4;
     l.WS = f.Wp + 4;
     l.PS = 2 * f.DOp + 4;
-    int pn = 2 * f.DOp; if (f.dp > pn) pn = f.dp; if (f.Dp > pn) pn = f.Dp;
+    int pn = 2 * f.DOp; if (16 * f.NTd > pn) pn = 16 * f.NTd;
     l.PN = pn + 4;
     int o = 0;
     l.o_U0 = o; o += ROWS * l.DS;

@@ -42,96 +42,85 @@ struct Tid {
     }
 };
 
-// ---- N-split GEMM: wave w owns column tiles c_i = w + 4 i (i < NTWM, c_i < NT) ----------------
-// acc[i] (+)= A[16 x 16*KB] @ B[:, tile c_i].   A elements with k >= kmax are treated as zero.
-template <int NTWM, int CH>
+// ---- N-split GEMM: wave w owns column tiles c_i = w + 4 i, i < NTWM (the tile count is padded to
+// 4*NTWM with zero tiles at pack time, so the hot loop has no predication at all).
+// acc[i] += A[16 x 16*KB] @ B[:, tile c_i];  KB % DEPTH == 0 (K padded at pack time).
+// Weight tiles are fetched DEPTH k-blocks ahead into a register ring (DEPTH*NTWM KiB in flight per
+// wave); the A fragment (one ds_read_b128 per k-block) is fetched one k-block ahead.
+template <int NTWM, int DEPTH, bool MASKK>
 __device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda, int kmax, int KB,
-                                            const float4* __restrict__ Bp, int NT, const Tid& t,
-                                            f32x4 (&acc)[NTWM]) {
+                                            const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM]) {
     const float* arow = A + t.n * lda + 4 * t.q;
-    const float4* bt[NTWM];
-    bool on[NTWM];
+    const float4* bt = Bp + (size_t)t.wave * KB * 64 + t.lane;     // tile c_i at bt + i*4*KB*64
+    const size_t tstride = (size_t)4 * KB * 64;
+    float4 ring[DEPTH][NTWM];
 #pragma unroll
-    for (int i = 0; i < NTWM; ++i) {
-        const int c = t.wave + 4 * i;
-        on[i] = c < NT;
-        bt[i] = Bp + (size_t)(on[i] ? c : 0) * KB * 64 + t.lane;
-    }
-    float4 bcur[CH][NTWM];
+    for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-    for (int s = 0; s < CH; ++s)
+        for (int i = 0; i < NTWM; ++i) ring[d][i] = bt[i * tstride + (size_t)d * 64];
+    float4 a_nxt = *reinterpret_cast<const float4*>(arow);
+    for (int S0 = 0; S0 < KB; S0 += DEPTH) {
 #pragma unroll
-        for (int i = 0; i < NTWM; ++i)
-            if (on[i] && s < KB) bcur[s][i] = bt[i][s * 64];
-    for (int S0 = 0; S0 < KB; S0 += CH) {
-        float4 bnxt[CH][NTWM];
-#pragma unroll
-        for (int s = 0; s < CH; ++s)
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) {
-                const int S = S0 + CH + s;
-                if (on[i] && S < KB) bnxt[s][i] = bt[i][S * 64];
-            }
-#pragma unroll
-        for (int s = 0; s < CH; ++s) {
-            const int S = S0 + s;
-            if (S < KB) {
-                float4 a = *reinterpret_cast<const float4*>(arow + 16 * S);
+        for (int d = 0; d < DEPTH; ++d) {
+            const int S = S0 + d;
+            float4 a = a_nxt;
+            const int Sn = (S + 1 < KB) ? S + 1 : S;
+            a_nxt = *reinterpret_cast<const float4*>(arow + 16 * Sn);
+            if (MASKK) {
                 const int k0 = 16 * S + 4 * t.q;
-                const float a0 = (k0 + 0 < kmax) ? a.x : 0.f;
-                const float a1 = (k0 + 1 < kmax) ? a.y : 0.f;
-                const float a2 = (k0 + 2 < kmax) ? a.z : 0.f;
-                const float a3 = (k0 + 3 < kmax) ? a.w : 0.f;
-#pragma unroll
-                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a0, bcur[s][i].x, acc[i]);
-#pragma unroll
-                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a1, bcur[s][i].y, acc[i]);
-#pragma unroll
-                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a2, bcur[s][i].z, acc[i]);
-#pragma unroll
-                for (int i = 0; i < NTWM; ++i) if (on[i]) acc[i] = mfma4(a3, bcur[s][i].w, acc[i]);
+                a.x = (k0 + 0 < kmax) ? a.x : 0.f;
+                a.y = (k0 + 1 < kmax) ? a.y : 0.f;
+                a.z = (k0 + 2 < kmax) ? a.z : 0.f;
+                a.w = (k0 + 3 < kmax) ? a.w : 0.f;
             }
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.x, ring[d][i].x, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.y, ring[d][i].y, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, ring[d][i].z, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, ring[d][i].w, acc[i]);
+            // refill this ring slot with k-block S + DEPTH (clamped: the tail re-reads the last block)
+            const int Sp = (S + DEPTH < KB) ? S + DEPTH : KB - 1;
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) ring[d][i] = bt[i * tstride + (size_t)Sp * 64];
         }
-#pragma unroll
-        for (int s = 0; s < CH; ++s)
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) bcur[s][i] = bnxt[s][i];
     }
 }
 
-// ---- K-split GEMM for narrow outputs (N <= 64): wave w sums k-blocks S = w, w+4, ...; the four
-// partial [16 x 16*NT] products go to LDS part[w][row][PN] and are added by the caller. -----------
-template <int NTM>
+// ---- K-split GEMM for narrow outputs (N = 16*NT <= 64): wave w sums k-blocks S = w, w+4, ... of
+// every column tile; the four partial [16 x 16*NT] products go to LDS part[w][row][PN] and are added by
+// the caller.  Tiles are the outer (runtime) loop so that no register array is indexed by NT.
 __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda, int KB,
                                             const float4* __restrict__ Bp, int NT, float* __restrict__ part,
                                             int PN, const Tid& t) {
-    f32x4 acc[NTM];
-#pragma unroll
-    for (int i = 0; i < NTM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* arow = A + t.n * lda + 4 * t.q;
-
-    for (int S = t.wave; S < KB; S += NWAVE) {
-        float4 b[NTM];
-#pragma unroll
-        for (int i = 0; i < NTM; ++i)
-            if (i < NT) b[i] = Bp[((size_t)i * KB + S) * 64 + t.lane];
-        const float4 a = *reinterpret_cast<const float4*>(arow + 16 * S);
-#pragma unroll
-        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.x, b[i].x, acc[i]);
-#pragma unroll
-        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.y, b[i].y, acc[i]);
-#pragma unroll
-        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.z, b[i].z, acc[i]);
-#pragma unroll
-        for (int i = 0; i < NTM; ++i) if (i < NT) acc[i] = mfma4(a.w, b[i].w, acc[i]);
-    }
     float* p = part + (size_t)t.wave * ROWS * PN;
-#pragma unroll
-    for (int i = 0; i < NTM; ++i)
-        if (i < NT) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) p[(4 * t.q + r) * PN + 16 * i + t.n] = acc[i][r];
+    for (int i = 0; i < NT; ++i) {
+        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+        const float4* bt = Bp + (size_t)i * KB * 64 + t.lane;
+        int S = t.wave;
+        for (; S + NWAVE < KB; S += 2 * NWAVE) {            // two independent accumulation chains
+            const float4 b0 = bt[(size_t)S * 64], b1 = bt[(size_t)(S + NWAVE) * 64];
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * S);
+            const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * (S + NWAVE));
+            acc0 = mfma4(a0.x, b0.x, acc0); acc1 = mfma4(a1.x, b1.x, acc1);
+            acc0 = mfma4(a0.y, b0.y, acc0); acc1 = mfma4(a1.y, b1.y, acc1);
+            acc0 = mfma4(a0.z, b0.z, acc0); acc1 = mfma4(a1.z, b1.z, acc1);
+            acc0 = mfma4(a0.w, b0.w, acc0); acc1 = mfma4(a1.w, b1.w, acc1);
         }
+        if (S < KB) {
+            const float4 b0 = bt[(size_t)S * 64];
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * S);
+            acc0 = mfma4(a0.x, b0.x, acc0);
+            acc0 = mfma4(a0.y, b0.y, acc0);
+            acc0 = mfma4(a0.z, b0.z, acc0);
+            acc0 = mfma4(a0.w, b0.w, acc0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[(4 * t.q + r) * PN + 16 * i + t.n] = acc0[r] + acc1[r];
+    }
 }
 
 __device__ __forceinline__ float part_sum(const float* part, int PN, int row, int col) {
@@ -143,52 +132,47 @@ __device__ __forceinline__ float part_sum(const float* part, int PN, int row, in
 }
 
 // hidden layer: OUT = relu(A @ B + bias) (optionally recording the sign mask for the backward pass)
-template <int NTWM, bool MASK>
+template <int NTWM, int DEPTH, bool MASKK, bool MASK>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
-                                           const float* __restrict__ bias, int NT, float* OUT, int ldo,
+                                           const float* __restrict__ bias, float* OUT, int ldo,
                                            unsigned long long* mask, const Tid& t) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_nsplit<NTWM, 2>(A, lda, kmax, KB, Bp, NT, t, acc);
+    gemm_nsplit<NTWM, DEPTH, MASKK>(A, lda, kmax, KB, Bp, t, acc);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
-        if (c < NT) {
-            const float bv = bias[16 * c + t.n];
+        const float bv = bias[16 * c + t.n];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = acc[i][r] + bv;
-                const bool pos = v > 0.f;
-                OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? v : 0.f;
-                if (MASK) {
-                    const unsigned long long m = __ballot(pos);
-                    if (t.lane == 0) mask[c * 4 + r] = m;
-                }
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[i][r] + bv;
+            const bool pos = v > 0.f;
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? v : 0.f;
+            if (MASK) {
+                const unsigned long long m = __ballot(pos);
+                if (t.lane == 0) mask[c * 4 + r] = m;
             }
         }
     }
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
-template <int NTWM>
-__device__ __forceinline__ void dense_masked(const float* A, int lda, int kmax, int KB, const float4* Bp,
-                                             int NT, float* OUT, int ldo, const unsigned long long* mask,
-                                             const Tid& t) {
+template <int NTWM, int DEPTH>
+__device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, const float4* Bp, float* OUT,
+                                             int ldo, const unsigned long long* mask, const Tid& t) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_nsplit<NTWM, 2>(A, lda, kmax, KB, Bp, NT, t, acc);
+    gemm_nsplit<NTWM, DEPTH, false>(A, lda, 0, KB, Bp, t, acc);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
-        if (c < NT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const unsigned long long m = mask[c * 4 + r];
-                const bool pos = (m >> t.lane) & 1ull;
-                OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? acc[i][r] : 0.f;
-            }
+        for (int r = 0; r < 4; ++r) {
+            const unsigned long long m = mask[c * 4 + r];
+            const bool pos = (m >> t.lane) & 1ull;
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? acc[i][r] : 0.f;
         }
     }
 }
@@ -196,10 +180,10 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int kmax, 
 // OUT[16 x 16*NT] = A[16 x K] @ B   (NT <= 4: one column tile per wave), used for the D x D affine maps
 __device__ __forceinline__ void dense_small(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                             int NT, float* OUT, int ldo, const Tid& t) {
-    f32x4 acc[1];
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_nsplit<1, 2>(A, lda, kmax, KB, Bp, NT, t, acc);
     if (t.wave < NT) {
+        f32x4 acc[1];
+        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        gemm_nsplit<1, 2, true>(A, lda, kmax, KB, Bp, t, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) OUT[(4 * t.q + r) * ldo + 16 * t.wave + t.n] = acc[0][r];
     }
@@ -212,13 +196,13 @@ __device__ __forceinline__ void coupling_mlp(const FlowDims& f, const FlowLds& l
     float* HA = lds + l.o_HA;
     float* HB = lds + l.o_HB;
     unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * f.NTW * 4;
-    dense_relu<NTWM, MASK>(Z, l.DS, f.d, f.KBd, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1,
-                           f.NTW, HA, l.WS, mk, t);
+    dense_relu<NTWM, 2, true, MASK>(Z, l.DS, f.d, f.KBd, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1,
+                                    HA, l.WS, mk, t);
     __syncthreads();
-    dense_relu<NTWM, MASK>(HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2), Lp + f.o_b2,
-                           f.NTW, HB, l.WS, mk + f.NTW * 4, t);
+    dense_relu<NTWM, 4, false, MASK>(HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2), Lp + f.o_b2,
+                                     HB, l.WS, mk + f.NTW * 4, t);
     __syncthreads();
-    gemm_ksplit<4>(HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W3), f.NTO, lds + l.o_PART, l.PN, t);
+    gemm_ksplit(HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W3), f.NTO, lds + l.o_PART, l.PN, t);
     __syncthreads();
 }
 
@@ -292,13 +276,13 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         __syncthreads();
         const unsigned long long* mk =
             reinterpret_cast<const unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * f.NTW * 4;
-        dense_masked<NTWM>(DP, l.PS, 2 * f.DOp, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), f.NTW,
-                           lds + l.o_HA, l.WS, mk + f.NTW * 4, t);
+        dense_masked<NTWM, 2>(DP, l.PS, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), lds + l.o_HA, l.WS,
+                              mk + f.NTW * 4, t);
         __syncthreads();
-        dense_masked<NTWM>(lds + l.o_HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2T), f.NTW,
-                           lds + l.o_HB, l.WS, mk, t);
+        dense_masked<NTWM, 4>(lds + l.o_HA, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2T), lds + l.o_HB,
+                              l.WS, mk, t);
         __syncthreads();
-        gemm_ksplit<2>(lds + l.o_HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W1T), f.NTd, PART, l.PN, t);
+        gemm_ksplit(lds + l.o_HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W1T), f.NTd, PART, l.PN, t);
         __syncthreads();
         for (int j = t.c; j < f.d; j += 16) G[t.row * l.DS + j] += part_sum(PART, l.PN, t.row, j);
         __syncthreads();

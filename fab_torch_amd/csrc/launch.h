@@ -33,7 +33,7 @@ static inline int check_flow_shape(int dim, int n_layers, int width) {
 // column tiles per wave: ceil(NTW / 4) rounded up to a compiled variant {1, 2, 4, 5, 8}
 #define FAB_DISPATCH_NTW(f, fn, ...)                      \
     do {                                                  \
-        const int _per = fab::ceil_div((f).NTW, 4);       \
+        const int _per = (f).NTW / 4;       \
         if (_per <= 1) return fn<1>(__VA_ARGS__);         \
         if (_per <= 2) return fn<2>(__VA_ARGS__);         \
         if (_per <= 4) return fn<4>(__VA_ARGS__);         \
@@ -45,7 +45,7 @@ static inline int check_flow_shape(int dim, int n_layers, int width) {
 // same, but falls through on success (for call sites that continue afterwards)
 #define FAB_DISPATCH_NTW_NORET(f, fn, ...)                \
     do {                                                  \
-        const int _per = fab::ceil_div((f).NTW, 4);       \
+        const int _per = (f).NTW / 4;       \
         int _rc;                                          \
         if (_per <= 1) _rc = fn<1>(__VA_ARGS__);          \
         else if (_per <= 2) _rc = fn<2>(__VA_ARGS__);     \
