@@ -42,6 +42,31 @@ struct Tid {
     }
 };
 
+// ---- weight-tile loads hidden from hipcc's s_waitcnt bookkeeping --------------------------------
+// hipcc drains vmcnt(0) at the head of every loop iteration that carries loads in flight, which
+// serialises a register prefetch ring.  The ring loads are therefore issued through inline asm and
+// waited for with hand-counted s_waitcnt vmcnt(N) (loads return in order, so N = number of ring loads
+// issued after the one needed; any other load in flight only makes the wait more conservative).
+__device__ __forceinline__ void gload16(f32x4& dst, const float4* p) {
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+}
+
+template <int N, int NT>
+__device__ __forceinline__ void wait_tiles(f32x4 (&r)[NT]) {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[0]) : "n"(N));
+    else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N));
+    else if constexpr (NT == 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
+    else if constexpr (NT == 5)
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(N));
+    else if constexpr (NT == 8)
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                     : "n"(N));
+    else static_assert(NT == 1, "unsupported tile count");
+}
+
 // ---- N-split GEMM: wave w owns column tiles c_i = w + 4 i, i < NTWM (the tile count is padded to
 // 4*NTWM with zero tiles at pack time, so the hot loop has no predication at all).
 // acc[i] += A[16 x 16*KB] @ B[:, tile c_i];  KB % DEPTH == 0 (K padded at pack time).
@@ -53,11 +78,11 @@ __device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda
     const float* arow = A + t.n * lda + 4 * t.q;
     const float4* bt = Bp + (size_t)t.wave * KB * 64 + t.lane;     // tile c_i at bt + i*4*KB*64
     const size_t tstride = (size_t)4 * KB * 64;
-    float4 ring[DEPTH][NTWM];
+    f32x4 ring[DEPTH][NTWM];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
-        for (int i = 0; i < NTWM; ++i) ring[d][i] = bt[i * tstride + (size_t)d * 64];
+        for (int i = 0; i < NTWM; ++i) gload16(ring[d][i], bt + i * tstride + (size_t)d * 64);
     float4 a_nxt = *reinterpret_cast<const float4*>(arow);
     for (int S0 = 0; S0 < KB; S0 += DEPTH) {
 #pragma unroll
@@ -73,6 +98,9 @@ __device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda
                 a.z = (k0 + 2 < kmax) ? a.z : 0.f;
                 a.w = (k0 + 3 < kmax) ? a.w : 0.f;
             }
+            // ring slot d holds k-block S; (DEPTH-1)*NTWM younger ring loads may stay in flight
+            wait_tiles<(DEPTH - 1) * NTWM, NTWM>(ring[d]);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.x, ring[d][i].x, acc[i]);
 #pragma unroll
@@ -81,12 +109,21 @@ __device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, ring[d][i].z, acc[i]);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, ring[d][i].w, acc[i]);
-            // refill this ring slot with k-block S + DEPTH (clamped: the tail re-reads the last block)
+            __builtin_amdgcn_sched_barrier(0);
+            // refill this slot with k-block S + DEPTH (clamped: the tail re-reads the last block, which
+            // keeps the in-flight count constant so that the hand-counted vmcnt stays exact)
             const int Sp = (S + DEPTH < KB) ? S + DEPTH : KB - 1;
 #pragma unroll
-            for (int i = 0; i < NTWM; ++i) ring[d][i] = bt[i * tstride + (size_t)Sp * 64];
+            for (int i = 0; i < NTWM; ++i) gload16(ring[d][i], bt + i * tstride + (size_t)Sp * 64);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
+    // The clamped tail loads are still in flight.  Drain them with the ring registers as operands of the
+    // wait: otherwise hipcc, which believes they are dead, may re-allocate them above the wait and the
+    // landing loads would clobber live values.
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) wait_tiles<0, NTWM>(ring[d]);
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // ---- K-split GEMM for narrow outputs (N = 16*NT <= 64): wave w sums k-blocks S = w, w+4, ... of

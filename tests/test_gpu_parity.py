@@ -299,3 +299,21 @@ def test_ais_headline_config_vs_oracle():
     assert bad.sum() <= 1, f"{int(bad.sum())} of {B} chains diverged"
     ok = ~bad
     assert close(log_w.cpu()[ok], olw[ok], 5e-4), f"log_w err {max_rel_err(log_w.cpu()[ok], olw[ok]):.2e}"
+
+
+@pytest.mark.parametrize("D,K,nodes", [(32, 10, 10), (60, 2, 4), (6, 8, 40)])
+def test_flow_kernels_are_deterministic_race_screen(D, K, nodes):
+    """Race screen: many workgroups at uneven load, repeated launches must be bitwise identical and match
+    the oracle on a subsample (the hand-counted vmcnt pipeline returns garbage when mis-synchronised)."""
+    nf = seeded_flow(D, K, nodes, 300 + D)
+    hf = hip_flow_from_oracle(nf)
+    torch.manual_seed(11)
+    x = torch.randn(4099, D)
+    xd = x.to(DEV)
+    lq0, g0 = hf.log_prob_and_grad(xd)
+    for _ in range(5):
+        lq, g = hf.log_prob_and_grad(xd)
+        assert torch.equal(lq, lq0) and torch.equal(g, g0)
+    idx = torch.arange(0, 4099, 41)
+    lq_o, g_o = oracle_logq_grad(nf, x[idx])
+    assert close(lq0.cpu()[idx], lq_o, RTOL) and close(g0.cpu()[idx], g_o, RTOL)
