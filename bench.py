@@ -5,7 +5,7 @@ Workload (BASELINE.json metric / north_star): ManyWell-32 target
 reference's ManyWell-32 architecture (10 x [MLP 16-320-320-32 coupling + InvertibleAffine]), 1024 chains per
 GPU, 8 intermediate distributions (linear beta), HMC with 5 leapfrog steps / 1 outer step, alpha = 2,
 p_target = False, step-size tuning ON (as in training).  Random-init weights (seeded; last coupling
-layer re-drawn N(0, 0.05^2) so log-dets are non-trivial), synthetic noise drawn on the device inside the
+layer re-drawn N(0, 0.01^2) so log-dets are non-trivial), synthetic noise drawn on the device inside the
 timed region.  A "step" is one `AnnealedImportanceSampler.sample_and_log_weights(1024)` call per GPU
 (+ the RCCL all-gather of the particles when --gpus > 1).
 
@@ -37,8 +37,8 @@ def build_flow_state(seed=0):
     g = torch.Generator().manual_seed(seed + 1)
     with torch.no_grad():
         for l1, l2, l3, aff in flow._layers():
-            l3.weight.copy_(torch.randn(l3.weight.shape, generator=g) * 0.05)
-            l3.bias.copy_(torch.randn(l3.bias.shape, generator=g) * 0.05)
+            l3.weight.copy_(torch.randn(l3.weight.shape, generator=g) * 0.01)
+            l3.bias.copy_(torch.randn(l3.bias.shape, generator=g) * 0.01)
     return flow
 
 
@@ -59,14 +59,25 @@ def cpu_baseline(flow_state, n_calls=2):
         noise_e = torch.empty(M, 1, B_PER_GPU).exponential_()
         return ais.sample_and_log_weights(eps0, noise_p, noise_e)
 
-    call()
+    # pick the thread count the eager CPU path likes best on this host (1 call each), then time n_calls
+    best_threads, best_dt = torch.get_num_threads(), float("inf")
+    for nt in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
+        torch.set_num_threads(nt)
+        call()
+        t0 = time.perf_counter()
+        call()
+        dt = time.perf_counter() - t0
+        if dt < best_dt:
+            best_threads, best_dt = nt, dt
+    torch.set_num_threads(best_threads)
     t0 = time.perf_counter()
     for _ in range(n_calls):
         _, _, info = call()
     dt = (time.perf_counter() - t0) / n_calls
-    return {"value": B_PER_GPU / dt, "unit": "AIS samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_calls} calls of sample_and_log_weights({B_PER_GPU}) after 1 warm-up, fp32, "
-                      f"oracle/ (PyTorch-CPU eager + autograd per leapfrog)", "sec_per_call": dt}
+    return {"value": B_PER_GPU / dt, "unit": "AIS samples/s", "cores": best_threads, "kind": "port",
+            "sample": f"{n_calls} calls of sample_and_log_weights({B_PER_GPU}) (after a thread-count sweep over "
+                      f"8/16/32/64, 2 calls each), fp32, oracle/ = PyTorch-CPU eager + autograd per leapfrog",
+            "sec_per_call": dt, "host_cpus": os.cpu_count()}
 
 
 def main():

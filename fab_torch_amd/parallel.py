@@ -45,7 +45,7 @@ def gather_particles(x, log_w, log_q, capacity: int, group=None):
     buf = pack_particles(x, log_w, log_q, capacity)
     if world == 1:
         return unpack_particles(buf)
-    out = torch.empty((world,) + tuple(buf.shape), dtype=buf.dtype, device=buf.device)
+    out = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
     dist.all_gather_into_tensor(out, buf, group=group)
     return unpack_particles(out)
 

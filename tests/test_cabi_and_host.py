@@ -1,0 +1,117 @@
+"""CPU-only checks of the C-ABI library and of the host-side mirror (no GPU compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import ROOT, close
+
+import fab_torch_amd as fa
+from fab_torch_amd import _lib
+from oracle import ais as oais
+from oracle import flow as oflow
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "fabhip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fabhip_[a-z_0-9]+)\s*\(", txt)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), f"libfabhip.so does not export {s}"
+    assert sorted(_lib.SYMBOLS) == syms, "fab_torch_amd/_lib.py SYMBOLS out of sync with include/fabhip.h"
+    assert lib.fabhip_version() >= 100
+    assert b"workspace" in lib.fabhip_strerror(-4)
+
+
+def test_geometry_queries_and_argument_validation_without_gpu():
+    lib = _lib.load()
+    n = lib.fabhip_flow_packed_floats(32, 10, 320)
+    assert n > 10 * (16 * 320 + 320 * 320 + 320 * 32) * 2            # both orientations, padded
+    assert lib.fabhip_flow_packed_floats(65, 2, 32) == -1              # dim beyond compiled limit
+    assert lib.fabhip_flow_packed_floats(32, 2, 513) == -1
+    assert lib.fabhip_hmc_workspace_bytes(1024, 32, 1) > 0
+    assert lib.fabhip_hmc_workspace_bytes(1024, 32, 2) > lib.fabhip_hmc_workspace_bytes(1024, 32, 1)
+    assert lib.fabhip_ais_workspace_bytes(1024, 32, 1) > lib.fabhip_hmc_workspace_bytes(1024, 32, 1)
+    assert lib.fabhip_resample_workspace_bytes(1 << 20) >= 8 * (1 << 20)
+    # null / bad arguments are rejected before any launch
+    assert lib.fabhip_flow_log_prob(None, None, None, None, 4, None) == -1
+    f = _lib.Flow(32, 2, 64, None)
+    assert lib.fabhip_flow_sample(C.byref(f), None, None, None, 4, None) == -1
+    assert lib.fabhip_gather_rows(None, None, None, 1, 1, None) == -1
+    assert lib.fabhip_ess_logz(None, 4, None, 4.0, None, None, 0, None) == -1
+
+
+def test_anneal_coefficients_match_the_reference_formulas():
+    lib = _lib.load()
+    for beta in (0.0, 0.2, 1 / 3, 1.0):
+        for alpha in (2.0, 0.5):
+            a = _lib.Anneal()
+            lib.fabhip_anneal_coefs(beta, alpha, 0, C.byref(a))
+            assert a.c_q == np.float32((1 - beta) + beta * (1 - alpha)) and a.c_p == np.float32(beta * alpha)
+            assert a.g_q == a.c_q and a.g_p == np.float32(2 * beta)       # base.py:116 quirk
+            lib.fabhip_anneal_coefs(beta, alpha, 1, C.byref(a))
+            assert a.c_q == np.float32(1 - beta) and a.c_p == np.float32(beta) and a.g_p == a.c_p
+
+
+def test_beta_schedule_and_constructor_contracts():
+    flow = fa.RealNVP(6, 2, 5)
+    target = fa.ManyWellEnergy(6, use_gpu=False)
+    hmc = fa.HamiltonianMonteCarlo(4, 6, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=1.0)
+    assert hmc.uses_grad_info and set(hmc.state_dict()) == {"common_epsilon", "epsilons", "mass_vector"}
+    np.testing.assert_allclose(hmc.epsilons.numpy(), 0.9) ; np.testing.assert_allclose(hmc.common_epsilon.numpy(), 0.1)
+    met = fa.Metropolis(4, 6, flow.log_prob, target.log_prob, n_updates=3, alpha=2.0, max_step_size=5.0, min_step_size=1.0)
+    assert not met.uses_grad_info and set(met.state_dict()) == {"noise_scalings"}
+    np.testing.assert_allclose(met.noise_scalings[0].numpy(), [5.0, 3.0, 1.0])
+    met.set_eval_mode(True)
+    assert met.eval_mode is False           # the reference inverts the flag (metropolis.py:39-41)
+    for M in (1, 4, 8):
+        for sp in ("linear", "geometric"):
+            ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, False, 2.0, M, sp)
+            np.testing.assert_array_equal(ais.B_space.numpy(), oais.beta_schedule(M, sp).numpy())
+    with pytest.raises(AssertionError):
+        fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target=False, alpha=None)
+    assert flow.event_shape == (6,)
+
+
+def test_hot_path_fails_loudly_without_a_gpu():
+    flow = fa.RealNVP(6, 2, 5).requires_grad_(False)
+    x = torch.randn(4, 6)
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.FabhipError):
+            flow.log_prob(x)
+        with pytest.raises(_lib.FabhipError):
+            fa.ManyWellEnergy(6, use_gpu=False).log_prob(x)
+        with pytest.raises(_lib.FabhipError):
+            fa.effective_sample_size(torch.randn(8))
+
+
+def test_state_dict_is_normflows_compatible_and_training_expression_matches_oracle():
+    torch.manual_seed(0)
+    nf = oflow.make_realnvp(6, 3, 5)
+    oflow.randomize_last_layers(nf, 0.1, 1)
+    flow = fa.RealNVP(6, 3, 5)
+    assert set(flow._nf_model.state_dict()) == set(nf.state_dict())
+    assert all(k.startswith("_nf_model.") for k in flow.state_dict())
+    flow._nf_model.load_state_dict(nf.state_dict())
+    x = torch.randn(16, 6)
+    lq = flow.log_prob(x)                    # parameters require grad -> differentiable torch expression
+    assert lq.requires_grad and close(lq, nf.log_prob(x).detach(), 1e-5)
+    lq.sum().backward()
+    ref = nf.log_prob(x).sum()
+    ref.backward()
+    g1 = flow._nf_model.flows[0].flows[1].param_map.net[0].weight.grad
+    g2 = nf.flows[0].flows[1].param_map.net[0].weight.grad
+    assert close(g1, g2, 1e-4)
+    eps = torch.randn(16, 6)
+    xs, lqs = flow.sample_and_log_prob((16,), eps=eps)
+    xo, lqo = nf.sample_eps(eps)
+    assert close(xs, xo.detach(), 1e-5) and close(lqs, lqo.detach(), 1e-5)
