@@ -7,6 +7,7 @@
 #include "flow_device.h"
 #include "target_device.h"
 #include "launch.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -31,10 +32,10 @@ __device__ __forceinline__ Msum msum_push(const Msum& a, double x) {
     if (x != x || a.m != a.m || x == INFINITY) return Msum{NAN, NAN, NAN};   // softmax(+inf) is NaN in torch
     if (x == -INFINITY) return a;                       // weight 0
     if (x <= a.m) {
-        const double e = exp(x - a.m);                  // a.m == +inf -> NaN, like torch's softmax
+        const double e = (double)expf((float)(x - a.m));   // fp32 exp (1e-7 rel), fp64 accumulation
         return Msum{a.m, a.s1 + e, a.s2 + e * e};
     }
-    const double r = exp(a.m - x);                      // a.m == -inf -> 0
+    const double r = (double)expf((float)(a.m - x));    // a.m == -inf -> 0
     return Msum{x, a.s1 * r + 1.0, a.s2 * r * r + 1.0};
 }
 
@@ -134,12 +135,22 @@ struct ScanWs {          // workspace layout (all 256-byte aligned)
     unsigned int* ticket;        // [1] dynamic tile id
     unsigned long long* tile_inc;// [ntiles] inclusive prefix at the end of each tile
     unsigned long long* cdf;     // [n]
+    int variant;                 // store-pattern variant (A/B experiments)
 };
 
 __global__ __launch_bounds__(256) void k_max_partial(const float* __restrict__ lw, long n, float* __restrict__ part) {
     __shared__ float sh[256];
     float m = -INFINITY;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const long n4 = (((size_t)lw & 15) == 0) ? (n >> 2) : 0;          // 16-byte vector body
+    const float4* p4 = reinterpret_cast<const float4*>(lw);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const float4 v = p4[i];
+        if (isfinite(v.x)) m = fmaxf(m, v.x);
+        if (isfinite(v.y)) m = fmaxf(m, v.y);
+        if (isfinite(v.z)) m = fmaxf(m, v.z);
+        if (isfinite(v.w)) m = fmaxf(m, v.w);
+    }
+    for (long i = 4 * n4 + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float v = lw[i];
         if (isfinite(v)) m = fmaxf(m, v);
     }
@@ -165,65 +176,115 @@ __global__ __launch_bounds__(256) void k_max_final(const float* __restrict__ par
     if (threadIdx.x == 0) out[0] = (sh[0] == -INFINITY) ? 0.f : sh[0];
 }
 
-__device__ __forceinline__ unsigned long long fixed_weight(float w, double mx) {
-    if (!isfinite(w)) return 0ull;
-    const float p = (float)exp((double)w - mx);                    // correctly rounded via float64
-    return (unsigned long long)floor((double)p * 68719476736.0);   // 2^36
+// Specified fp32 exponential of the resampler (oracle/numerical.py:exp_spec restates it op for op):
+//   r = x * log2(e); k = rint(r); f = r - k; p = 2^k * P6(f)   with every multiply and add individually rounded
+// (no FMA contraction in this file), x <= 0.  Deterministic on any IEEE machine => bit-exact parity of the
+// resulting fixed-point CDF; |p/exp(x) - 1| <= 2e-6 (3e-7 near the maximum).
+__device__ __forceinline__ float exp_spec(float x) {
+    const float r = x * 1.44269504088896341f;
+    const float k = rintf(r);
+    const float f = r - k;
+    float p = 1.5403530393381609e-4f;
+    p = p * f + 1.3333558146428443e-3f;
+    p = p * f + 9.6181291076284772e-3f;
+    p = p * f + 5.5504108664821580e-2f;
+    p = p * f + 2.4022650695910071e-1f;
+    p = p * f + 6.9314718055994531e-1f;
+    p = p * f + 1.0f;
+    return (k < -60.f) ? 0.f : ldexpf(p, (int)k);     // below 2^-60 the fixed-point weight is 0 anyway
 }
 
-// single-pass inclusive scan with decoupled look-back (descriptors are 8-byte {flag,value} granules
-// written/read with relaxed agent-scope atomics: the data IS the flag, no fence needed)
-__global__ __launch_bounds__(SCAN_THREADS) void k_scan_fixed(const float* __restrict__ lw, long n,
+__device__ __forceinline__ unsigned long long fixed_weight(float w, float mx) {
+    if (!isfinite(w)) return 0ull;
+    return (unsigned long long)(exp_spec(w - mx) * 68719476736.0f);   // floor(p * 2^36), exact scaling
+}
+
+__device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int off) {
+    const unsigned lo = __shfl_up((unsigned)v, off), hi = __shfl_up((unsigned)(v >> 32), off);
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long shfl_u64(unsigned long long v, int src) {
+    const unsigned lo = __shfl((unsigned)v, src), hi = __shfl((unsigned)(v >> 32), src);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// Single-pass inclusive scan with decoupled look-back.  One workgroup scans SCAN_BLOCK = 16384 weights
+// (one dynamic ticket + one look-back per 16384 items: a single atomic word saturates at ~88 tickets/us);
+// wave w owns search tile 4*blk + w (4096 consecutive weights) slab-wise — slab v = 256 consecutive
+// weights, lane l owns 4 of them — so every global load/store instruction of a wave is a fully coalesced
+// 1-2 KiB access.  Descriptors are 8-byte {flag,value} granules written/read with relaxed agent-scope
+// atomics: the data IS the flag.
+constexpr int SCAN_NW = 8;                              // waves per scan workgroup
+constexpr int SCAN_WAVE_ITEMS = 2048;                   // weights per wave (half a search tile)
+constexpr int SCAN_SLABS = SCAN_WAVE_ITEMS / 256;       // 8 slabs per wave
+constexpr int SCAN_BLOCK = SCAN_WAVE_ITEMS * SCAN_NW;   // 16384 weights per workgroup / ticket
+
+__global__ __launch_bounds__(64 * SCAN_NW) void k_scan_fixed(const float* __restrict__ lw, long n,
                                                              const float* __restrict__ max_val, ScanWs ws) {
-    __shared__ unsigned long long wave_tot[SCAN_THREADS / 64];
-    __shared__ unsigned long long tile_prefix;
-    __shared__ unsigned int tile_id_sh;
+    __shared__ unsigned long long wave_tot[SCAN_NW];
+    __shared__ unsigned long long blk_prefix;
+    __shared__ unsigned int blk_id_sh;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) tile_id_sh = atomicAdd(ws.ticket, 1u);
+    if (tid == 0) blk_id_sh = atomicAdd(ws.ticket, 1u);
     __syncthreads();
-    const unsigned int tile = tile_id_sh;
-    const long base = (long)tile * SCAN_TILE + (long)tid * SCAN_ITEMS;
-    const double mx = (double)max_val[0];
-    unsigned long long q[SCAN_ITEMS];
-    if (base + SCAN_ITEMS <= n) {
-        const float4* p4 = reinterpret_cast<const float4*>(lw + base);
+    const unsigned int blk = blk_id_sh;
+    const long wbase = (long)blk * SCAN_BLOCK + (long)wave * SCAN_WAVE_ITEMS;
+    const float mx = max_val[0];
+    unsigned long long q[SCAN_SLABS][4];
+    const bool vec = (wbase + SCAN_WAVE_ITEMS <= n) && (((size_t)lw & 15) == 0);
+    if (vec) {
 #pragma unroll
-        for (int v = 0; v < SCAN_ITEMS / 4; ++v) {
-            const float4 x = p4[v];
-            q[4 * v + 0] = fixed_weight(x.x, mx); q[4 * v + 1] = fixed_weight(x.y, mx);
-            q[4 * v + 2] = fixed_weight(x.z, mx); q[4 * v + 3] = fixed_weight(x.w, mx);
+        for (int h = 0; h < SCAN_SLABS; h += 8) {          // 8 loads in flight per lane
+            float4 x[8];
+#pragma unroll
+            for (int v = 0; v < 8; ++v) x[v] = *reinterpret_cast<const float4*>(lw + wbase + (h + v) * 256 + lane * 4);
+#pragma unroll
+            for (int v = 0; v < 8; ++v) {
+                q[h + v][0] = fixed_weight(x[v].x, mx); q[h + v][1] = fixed_weight(x[v].y, mx);
+                q[h + v][2] = fixed_weight(x[v].z, mx); q[h + v][3] = fixed_weight(x[v].w, mx);
+            }
         }
     } else {
 #pragma unroll
-        for (int v = 0; v < SCAN_ITEMS; ++v) q[v] = (base + v < n) ? fixed_weight(lw[base + v], mx) : 0ull;
-    }
-    unsigned long long run = 0ull;
+        for (int v = 0; v < SCAN_SLABS; ++v)
 #pragma unroll
-    for (int v = 0; v < SCAN_ITEMS; ++v) { run += q[v]; q[v] = run; }       // thread-local inclusive
-    // wave inclusive scan of the thread totals
-    unsigned long long incl = run;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const unsigned long long o = __shfl_up(incl, off);
-        if (lane >= off) incl += o;
+            for (int e = 0; e < 4; ++e) {
+                const long i = wbase + v * 256 + lane * 4 + e;
+                q[v][e] = (i < n) ? fixed_weight(lw[i], mx) : 0ull;
+            }
     }
-    if (lane == 63) wave_tot[wave] = incl;
+    // lane-local inclusive sums per slab, wave scan of the lane totals, running slab offsets
+    unsigned long long excl[SCAN_SLABS];
+    unsigned long long slab_off = 0ull;
+#pragma unroll
+    for (int v = 0; v < SCAN_SLABS; ++v) {
+        q[v][1] += q[v][0]; q[v][2] += q[v][1]; q[v][3] += q[v][2];
+        unsigned long long incl = q[v][3];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long o = shfl_up_u64(incl, off);
+            if (lane >= off) incl += o;
+        }
+        excl[v] = slab_off + (incl - q[v][3]);
+        slab_off += shfl_u64(incl, 63);
+    }
+    if (lane == 0) wave_tot[wave] = slab_off;      // wave (= search tile) total, identical in every lane
     __syncthreads();
-    unsigned long long wave_off = 0ull, tile_tot = 0ull;
+    unsigned long long wave_off = 0ull, blk_tot = 0ull;
 #pragma unroll
-    for (int w = 0; w < SCAN_THREADS / 64; ++w) { if (w < wave) wave_off += wave_tot[w]; tile_tot += wave_tot[w]; }
+    for (int w = 0; w < SCAN_NW; ++w) { if (w < wave) wave_off += wave_tot[w]; blk_tot += wave_tot[w]; }
     // publish the aggregate, look back for the exclusive prefix (wave 0)
     if (wave == 0) {
-        if (tile == 0) {
+        if (blk == 0) {
             if (lane == 0) {
-                __hip_atomic_store(ws.desc + 0, FLAG_INC | tile_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tile_prefix = 0ull;
+                __hip_atomic_store(ws.desc + 0, FLAG_INC | blk_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                blk_prefix = 0ull;
             }
         } else {
             if (lane == 0)
-                __hip_atomic_store(ws.desc + tile, FLAG_AGG | tile_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            unsigned long long excl = 0ull;
-            long look = (long)tile - 1;
+                __hip_atomic_store(ws.desc + blk, FLAG_AGG | blk_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long ex = 0ull;
+            long look = (long)blk - 1;
             while (true) {
                 const long j = look - lane;
                 unsigned long long d = 0ull;
@@ -232,33 +293,63 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_scan_fixed(const float* __rest
                         d = __hip_atomic_load(ws.desc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     } while ((d >> 62) == 0ull);
                 } else {
-                    d = FLAG_INC;          // virtual tile before the first: inclusive prefix 0
+                    d = FLAG_INC;          // virtual block before the first: inclusive prefix 0
                 }
                 const unsigned long long inc_mask = __ballot((d >> 62) == 2ull);
-                const int first_inc = __ffsll((long long)inc_mask) - 1;     // always >= 0 eventually
+                const int first_inc = __ffsll((long long)inc_mask) - 1;
                 unsigned long long contrib = (first_inc < 0 || lane <= first_inc) ? (d & VAL_MASK) : 0ull;
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) contrib += __shfl_xor(contrib, off);
-                excl += contrib;
+                for (int off = 32; off > 0; off >>= 1) contrib += shfl_u64(contrib, lane ^ off);
+                ex += contrib;
                 if (first_inc >= 0) break;
                 look -= 64;
             }
             if (lane == 0) {
-                __hip_atomic_store(ws.desc + tile, FLAG_INC | (excl + tile_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                tile_prefix = excl;
+                __hip_atomic_store(ws.desc + blk, FLAG_INC | (ex + blk_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                blk_prefix = ex;
             }
         }
     }
     __syncthreads();
-    const unsigned long long off0 = tile_prefix + wave_off + (incl - run);
-    if (tid == SCAN_THREADS - 1) ws.tile_inc[tile] = tile_prefix + tile_tot;
-    if (base + SCAN_ITEMS <= n) {
-        ulonglong2* o2 = reinterpret_cast<ulonglong2*>(ws.cdf + base);
+    const unsigned long long off0 = blk_prefix + wave_off;
+    // inclusive prefix at the end of every 4096-weight search tile (= two waves)
+    if (lane == 63 && (wave & 1) && wbase - SCAN_WAVE_ITEMS < n)
+        ws.tile_inc[((long)blk * SCAN_BLOCK + (long)(wave - 1) * SCAN_WAVE_ITEMS) / SCAN_TILE] = off0 + slab_off;
+    if (vec && ws.variant == 1) {
+        // fully contiguous 1-KiB store instructions: lane j stores items (2j, 2j+1) of each half slab, which
+        // live in lane j/2 (first half) / 32 + j/2 (second half) -> one lane exchange per value
+        const int srcA = lane >> 1, srcB = 32 + (lane >> 1);
+        const bool odd = lane & 1;
 #pragma unroll
-        for (int v = 0; v < SCAN_ITEMS / 2; ++v) o2[v] = make_ulonglong2(off0 + q[2 * v], off0 + q[2 * v + 1]);
+        for (int v = 0; v < SCAN_SLABS; ++v) {
+            const unsigned long long b = off0 + excl[v];
+            const unsigned long long c0 = b + q[v][0], c1 = b + q[v][1], c2 = b + q[v][2], c3 = b + q[v][3];
+            const unsigned long long lo = odd ? c2 : c0, hi = odd ? c3 : c1;   // what a consumer of MY data wants
+            // consumer lane j reads from lane src; the value it needs depends on ITS parity, so send both pairs
+            const unsigned long long a0 = shfl_u64(c0, srcA), a1 = shfl_u64(c1, srcA), a2 = shfl_u64(c2, srcA), a3 = shfl_u64(c3, srcA);
+            const unsigned long long b0 = shfl_u64(c0, srcB), b1 = shfl_u64(c1, srcB), b2 = shfl_u64(c2, srcB), b3 = shfl_u64(c3, srcB);
+            (void)lo; (void)hi;
+            ulonglong2* oA = reinterpret_cast<ulonglong2*>(ws.cdf + wbase + v * 256 + lane * 2);
+            ulonglong2* oB = reinterpret_cast<ulonglong2*>(ws.cdf + wbase + v * 256 + 128 + lane * 2);
+            *oA = odd ? make_ulonglong2(a2, a3) : make_ulonglong2(a0, a1);
+            *oB = odd ? make_ulonglong2(b2, b3) : make_ulonglong2(b0, b1);
+        }
+    } else if (vec) {
+#pragma unroll
+        for (int v = 0; v < SCAN_SLABS; ++v) {
+            ulonglong2* o2 = reinterpret_cast<ulonglong2*>(ws.cdf + wbase + v * 256 + lane * 4);
+            const unsigned long long b = off0 + excl[v];
+            o2[0] = make_ulonglong2(b + q[v][0], b + q[v][1]);
+            o2[1] = make_ulonglong2(b + q[v][2], b + q[v][3]);
+        }
     } else {
 #pragma unroll
-        for (int v = 0; v < SCAN_ITEMS; ++v) if (base + v < n) ws.cdf[base + v] = off0 + q[v];
+        for (int v = 0; v < SCAN_SLABS; ++v)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const long i = wbase + v * 256 + lane * 4 + e;
+                if (i < n) ws.cdf[i] = off0 + excl[v] + q[v][e];
+            }
     }
 }
 
@@ -286,16 +377,83 @@ __global__ void k_sample_multinomial(ScanWs ws, long n, long ntiles, const doubl
     }
 }
 
-__global__ void k_sample_systematic(ScanWs ws, long n, long ntiles, double u0, long ns, long long* __restrict__ idx) {
+// Systematic thresholds are sorted, so a chunk of 4096 consecutive samples lands in a short run of CDF
+// tiles: stage each tile (32 KiB) in LDS and binary-search there -> indices are written coalesced and the
+// work is balanced in SAMPLES whatever the weight distribution (a tile-driven variant was 1.75x slower on
+// heavy-tailed weights).  Chunks that span many (near-empty) tiles fall back to the global two-level search;
+// the total number of staged tiles is bounded by ntiles + nchunks.
+constexpr int SYS_CHUNK = 4096, SYS_PER_THREAD = SYS_CHUNK / 256, SYS_MAX_SPAN = 8;
+
+__global__ __launch_bounds__(256) void k_sample_systematic(ScanWs ws, long n, long ntiles, double u0, long ns,
+                                                           long long* __restrict__ idx) {
+    __shared__ unsigned long long cdf_sh[SCAN_TILE];
+    __shared__ long span_sh[2];
+    const int tid = threadIdx.x;
     const unsigned long long total = ws.tile_inc[ntiles - 1];
     const double step = (double)total / (double)ns;
-    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (long)gridDim.x * blockDim.x) {
-        unsigned long long t = 0ull;
-        if (total > 0ull) {
-            t = (unsigned long long)floor(((double)k + u0) * step);
-            if (t > total - 1ull) t = total - 1ull;
+    const long k0 = (long)blockIdx.x * SYS_CHUNK;
+    unsigned long long t[SYS_PER_THREAD];
+#pragma unroll
+    for (int m = 0; m < SYS_PER_THREAD; ++m) {
+        const long k = k0 + tid + 256 * m;
+        unsigned long long v = 0ull;
+        if (total > 0ull && k < ns) {
+            v = (unsigned long long)floor(((double)k + u0) * step);
+            if (v > total - 1ull) v = total - 1ull;
         }
-        idx[k] = search_cdf(ws, n, ntiles, t);
+        t[m] = v;
+    }
+    if (tid == 0) {                 // first / last tile touched by this chunk (thresholds are monotone in k)
+        const long kl = (k0 + SYS_CHUNK <= ns ? k0 + SYS_CHUNK : ns) - 1;
+        unsigned long long tl = 0ull;
+        if (total > 0ull) {
+            tl = (unsigned long long)floor(((double)kl + u0) * step);
+            if (tl > total - 1ull) tl = total - 1ull;
+        }
+        long lo = 0, hi = ntiles;
+        while (lo < hi) { const long mid = (lo + hi) >> 1; if (ws.tile_inc[mid] > t[0]) hi = mid; else lo = mid + 1; }
+        span_sh[0] = lo < ntiles ? lo : ntiles - 1;
+        lo = 0; hi = ntiles;
+        while (lo < hi) { const long mid = (lo + hi) >> 1; if (ws.tile_inc[mid] > tl) hi = mid; else lo = mid + 1; }
+        span_sh[1] = lo < ntiles ? lo : ntiles - 1;
+    }
+    __syncthreads();
+    const long ta = span_sh[0], tb = span_sh[1];
+    if (tb - ta + 1 > SYS_MAX_SPAN) {
+#pragma unroll
+        for (int m = 0; m < SYS_PER_THREAD; ++m) {
+            const long k = k0 + tid + 256 * m;
+            if (k < ns) idx[k] = search_cdf(ws, n, ntiles, t[m]);
+        }
+        return;
+    }
+    unsigned done = 0u;
+    for (long tile = ta; tile <= tb; ++tile) {
+        const long base = tile * SCAN_TILE;
+        const long len = (base + SCAN_TILE <= n) ? SCAN_TILE : n - base;
+        for (int i = tid * 2; i < SCAN_TILE; i += 512) {
+            if (i + 1 < len) {
+                const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(ws.cdf + base + i);
+                cdf_sh[i] = v.x; cdf_sh[i + 1] = v.y;
+            } else {
+                cdf_sh[i] = (i < len) ? ws.cdf[base + i] : ~0ull;
+                cdf_sh[i + 1] = ~0ull;
+            }
+        }
+        __syncthreads();
+        const unsigned long long c_end = ws.tile_inc[tile];
+#pragma unroll
+        for (int m = 0; m < SYS_PER_THREAD; ++m) {
+            const long k = k0 + tid + 256 * m;
+            if (k < ns && !((done >> m) & 1u) && (t[m] < c_end || tile == tb)) {
+                int a = 0, b = (int)len;
+                while (a < b) { const int mid = (a + b) >> 1; if (cdf_sh[mid] > t[m]) b = mid; else a = mid + 1; }
+                long r = base + a;
+                idx[k] = r < n ? r : n - 1;
+                done |= 1u << m;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -359,17 +517,18 @@ static ScanWs carve_scan_ws(void* workspace, long n) {
     ws.ticket = (unsigned int*)p; p += 256;
     ws.tile_inc = (unsigned long long*)p; p += al256((size_t)scan_tiles(n) * 8);
     ws.cdf = (unsigned long long*)p;
+    { const char* e = getenv("FABHIP_SCAN_VARIANT"); ws.variant = e ? atoi(e) : 1; }
     return ws;
 }
 
 static int build_fixed_cdf(const float* log_w, long n, const ScanWs& ws, hipStream_t st) {
-    const int mb = grid_for(n, 256 * 8, 1024);
+    const int mb = grid_for(n, 256 * 16, 1024);
     hipLaunchKernelGGL(k_max_partial, dim3(mb), dim3(256), 0, st, log_w, n, ws.max_part);
     hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, ws.max_part, mb, ws.max_val);
     // zero descriptors + ticket (one contiguous region: desc .. ticket)
     const size_t zbytes = (size_t)((char*)ws.ticket - (char*)ws.desc) + 256;
     if (hipMemsetAsync(ws.desc, 0, zbytes, st) != hipSuccess) return FABHIP_ELAUNCH;
-    hipLaunchKernelGGL(k_scan_fixed, dim3((unsigned)scan_tiles(n)), dim3(SCAN_THREADS), 0, st, log_w, n, ws.max_val, ws);
+    hipLaunchKernelGGL(k_scan_fixed, dim3((unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK)), dim3(64 * SCAN_NW), 0, st, log_w, n, ws.max_val, ws);
     return check_launch();
 }
 
@@ -464,7 +623,7 @@ int fabhip_resample_systematic(const float* log_w, int64_t n, double u0, int64_t
     const ScanWs ws = carve_scan_ws(workspace, n);
     FAB_TRY(build_fixed_cdf(log_w, n, ws, st));
     if (n_samples > 0)
-        hipLaunchKernelGGL(k_sample_systematic, dim3(grid_for(n_samples, 256, 4096)), dim3(256), 0, st, ws, (long)n,
+        hipLaunchKernelGGL(k_sample_systematic, dim3((unsigned)((n_samples + SYS_CHUNK - 1) / SYS_CHUNK)), dim3(256), 0, st, ws, (long)n,
                            scan_tiles(n), u0, (long)n_samples, (long long*)idx);
     return check_launch();
 }

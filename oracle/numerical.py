@@ -53,17 +53,37 @@ def multinomial_torch_compat(probs: np.ndarray, u: np.ndarray) -> np.ndarray:
 
 # ---------------------------------------------------------------------------------------
 # scalable fixed-point definition (associative integer prefix sums => bit-exact under any
-# parallel scan order).  p_i = fl32(exp(fl64(w_i) - fl64(max w)))  (correctly rounded exp
-# via float64), q_i = floor(p_i * 2^36) as uint64, C = inclusive prefix sum of q.
+# parallel scan order).  p_i = exp_spec(w_i - max w) — a *specified* fp32 exponential made of
+# individually rounded IEEE float32 multiplies/adds (reproducible bit for bit on any machine),
+# q_i = floor(p_i * 2^36) as uint64, C = inclusive prefix sum of q.
 # ---------------------------------------------------------------------------------------
+_EXP_C = [np.float32(c) for c in (1.5403530393381609e-4, 1.3333558146428443e-3, 9.6181291076284772e-3,
+                                  5.5504108664821580e-2, 2.4022650695910071e-1, 6.9314718055994531e-1, 1.0)]
+
+
+def exp_spec(x: np.ndarray) -> np.ndarray:
+    """fp32: r = x*log2(e); k = rint(r); f = r-k; 2^k * Horner6(f), each op rounded to float32 (x <= 0)."""
+    x = np.asarray(x, dtype=np.float32)
+    r = (x * np.float32(1.44269504088896341)).astype(np.float32)
+    k = np.rint(r).astype(np.float32)
+    f = (r - k).astype(np.float32)
+    p = np.full_like(f, _EXP_C[0])
+    for c in _EXP_C[1:]:
+        p = (p * f).astype(np.float32)
+        p = (p + c).astype(np.float32)
+    kk = np.maximum(k, np.float32(-100)).astype(np.int32)
+    out = np.ldexp(p, kk).astype(np.float32)
+    return np.where(k < np.float32(-60), np.float32(0), out).astype(np.float32)
+
+
 def fixed_point_weights(log_w: np.ndarray) -> np.ndarray:
-    lw = np.asarray(log_w, dtype=np.float32).astype(np.float64)
+    lw = np.asarray(log_w, dtype=np.float32)
     finite = np.isfinite(lw)
-    m = lw[finite].max() if finite.any() else 0.0
+    m = lw[finite].max() if finite.any() else np.float32(0)
     with np.errstate(invalid="ignore", over="ignore"):
-        p = np.exp(lw - m)
-    p = np.where(~finite, 0.0, p).astype(np.float32)   # nan / +-inf -> weight 0
-    return np.floor(p.astype(np.float64) * float(1 << FIX_BITS)).astype(np.uint64)
+        p = exp_spec(np.where(finite, lw - np.float32(m), np.float32(0)).astype(np.float32))
+    p = np.where(finite, p, np.float32(0)).astype(np.float32)          # nan / +-inf -> weight 0
+    return (p * np.float32(2.0 ** FIX_BITS)).astype(np.float32).astype(np.uint64)
 
 
 def fixed_point_cdf(log_w: np.ndarray) -> np.ndarray:
