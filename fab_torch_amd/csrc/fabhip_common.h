@@ -96,8 +96,7 @@ FAB_HD FlowLds make_flow_lds(const FlowDims& f, bool with_grad) {
     l.o_DP = o; o += ROWS * l.PS;
     l.o_ES = o; if (with_grad) o += f.K * ROWS * f.DOp;
     l.o_V2 = o; if (with_grad) o += f.K * ROWS * f.DOp;
-    o = (o + 1) & ~1;           // 8-byte align the 64-bit masks
-    l.o_MASK = o; if (with_grad) o += f.K * 2 * f.NTW * 4 * 2;
+    l.o_MASK = o; if (with_grad) o += f.K * 2 * NTHREADS;   // one 32-bit ReLU sign word per thread, layer and hidden GEMM
     l.total = (o + 3) & ~3;
     return l;
 }

@@ -51,6 +51,26 @@ __device__ __forceinline__ void gload16(f32x4& dst, const float4* p) {
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
 }
 
+__device__ __forceinline__ void gload4(float& dst, const float* p) {
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p));
+}
+
+template <int N, int NT>
+__device__ __forceinline__ void wait_vals(float (&r)[NT]) {       // vmcnt(N) with the registers as operands
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    if constexpr (NT == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(r[0]) : "n"(N));
+    else if constexpr (NT == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+v"(r[0]), "+v"(r[1]) : "n"(N));
+    else if constexpr (NT == 4)
+        asm volatile("s_waitcnt vmcnt(%4)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]) : "n"(N));
+    else if constexpr (NT == 5)
+        asm volatile("s_waitcnt vmcnt(%5)" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]) : "n"(N));
+    else if constexpr (NT == 8)
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7])
+                     : "n"(N));
+    else static_assert(NT == 1, "unsupported tile count");
+}
+
 template <int N, int NT>
 __device__ __forceinline__ void wait_tiles(f32x4 (&r)[NT]) {
     static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
@@ -72,18 +92,32 @@ __device__ __forceinline__ void wait_tiles(f32x4 (&r)[NT]) {
 // acc[i] += A[16 x 16*KB] @ B[:, tile c_i];  KB % DEPTH == 0 (K padded at pack time).
 // Weight tiles are fetched DEPTH k-blocks ahead into a register ring (DEPTH*NTWM KiB in flight per
 // wave); the A fragment (one ds_read_b128 per k-block) is fetched one k-block ahead.
-template <int NTWM, int DEPTH, bool MASKK>
+// With `bias` the accumulators start from bias[16 c_i + n] (loaded through the same hidden path, issued
+// BEFORE the ring so that the ring stays in flight while they are waited for) instead of the caller's values.
+template <int NTWM, int DEPTH, bool MASKK, bool BIAS = false>
 __device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda, int kmax, int KB,
-                                            const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM]) {
+                                            const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM],
+                                            const float* __restrict__ bias = nullptr) {
     const float* arow = A + t.n * lda + 4 * t.q;
     const float4* bt = Bp + (size_t)t.wave * KB * 64 + t.lane;     // tile c_i at bt + i*4*KB*64
     const size_t tstride = (size_t)4 * KB * 64;
+    float bv[NTWM];
+    if (BIAS) {
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) gload4(bv[i], bias + 16 * (t.wave + 4 * i) + t.n);
+    }
     f32x4 ring[DEPTH][NTWM];
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d)
 #pragma unroll
         for (int i = 0; i < NTWM; ++i) gload16(ring[d][i], bt + i * tstride + (size_t)d * 64);
     float4 a_nxt = *reinterpret_cast<const float4*>(arow);
+    if (BIAS) {
+        wait_vals<DEPTH * NTWM, NTWM>(bv);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){bv[i], bv[i], bv[i], bv[i]};
+    }
     for (int S0 = 0; S0 < KB; S0 += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
@@ -168,47 +202,53 @@ __device__ __forceinline__ float part_sum(const float* part, int PN, int row, in
     return s;
 }
 
-// hidden layer: OUT = relu(A @ B + bias) (optionally recording the sign mask for the backward pass)
+// depth of the weight ring of the W x W GEMMs (must divide KBW = 4 * NTWM): how many k-blocks of weights
+// are in flight per wave.  L2 misses go to the Infinity Cache (~1 us): 5 blocks x 640 MFMA-cycles cover it.
+#ifndef FAB_DEPTH_W5
+#define FAB_DEPTH_W5 4
+#endif
+template <int NTWM>
+__host__ __device__ constexpr int depth_w() { return NTWM == 5 ? FAB_DEPTH_W5 : (NTWM == 8 ? 2 : 4); }
+
+// hidden layer: OUT = relu(A @ B + bias).  With MASK the ReLU sign pattern of this lane's 4*NTWM outputs is
+// kept as one 32-bit word per thread (bit 4 i + r) for the reverse sweep: the same lane of the same wave
+// owns the same (tile, register) there, so no cross-lane exchange and a single LDS store per GEMM.
 template <int NTWM, int DEPTH, bool MASKK, bool MASK>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                            const float* __restrict__ bias, float* OUT, int ldo,
-                                           unsigned long long* mask, const Tid& t) {
+                                           unsigned* mask, const Tid& t) {
     f32x4 acc[NTWM];
-#pragma unroll
-    for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    gemm_nsplit<NTWM, DEPTH, MASKK>(A, lda, kmax, KB, Bp, t, acc);
+    gemm_nsplit<NTWM, DEPTH, MASKK, true>(A, lda, kmax, KB, Bp, t, acc, bias);
+    unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
-        const float bv = bias[16 * c + t.n];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float v = acc[i][r] + bv;
+            const float v = acc[i][r];
             const bool pos = v > 0.f;
             OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? v : 0.f;
-            if (MASK) {
-                const unsigned long long m = __ballot(pos);
-                if (t.lane == 0) mask[c * 4 + r] = m;
-            }
+            if (MASK) m |= (pos ? 1u : 0u) << (4 * i + r);
         }
     }
+    if (MASK) mask[t.tid] = m;
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
 template <int NTWM, int DEPTH>
 __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, const float4* Bp, float* OUT,
-                                             int ldo, const unsigned long long* mask, const Tid& t) {
+                                             int ldo, const unsigned* mask, const Tid& t) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const unsigned m = mask[t.tid];
     gemm_nsplit<NTWM, DEPTH, false>(A, lda, 0, KB, Bp, t, acc);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const unsigned long long m = mask[c * 4 + r];
-            const bool pos = (m >> t.lane) & 1ull;
+            const bool pos = (m >> (4 * i + r)) & 1u;
             OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? acc[i][r] : 0.f;
         }
     }
@@ -232,12 +272,12 @@ __device__ __forceinline__ void coupling_mlp(const FlowDims& f, const FlowLds& l
                                              const float* Z, int layer, const Tid& t) {
     float* HA = lds + l.o_HA;
     float* HB = lds + l.o_HB;
-    unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * f.NTW * 4;
+    unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
     dense_relu<NTWM, 2, true, MASK>(Z, l.DS, f.d, f.KBd, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1,
                                     HA, l.WS, mk, t);
     __syncthreads();
-    dense_relu<NTWM, 4, false, MASK>(HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2), Lp + f.o_b2,
-                                     HB, l.WS, mk + f.NTW * 4, t);
+    dense_relu<NTWM, depth_w<NTWM>(), false, MASK>(HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2), Lp + f.o_b2,
+                                     HB, l.WS, mk + NTHREADS, t);
     __syncthreads();
     gemm_ksplit(HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W3), f.NTO, lds + l.o_PART, l.PN, t);
     __syncthreads();
@@ -311,12 +351,11 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
             G[t.row * l.DS + f.d + j] = g2 * es;                  // d/d z2
         }
         __syncthreads();
-        const unsigned long long* mk =
-            reinterpret_cast<const unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * f.NTW * 4;
+        const unsigned* mk = reinterpret_cast<const unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
         dense_masked<NTWM, 2>(DP, l.PS, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), lds + l.o_HA, l.WS,
-                              mk + f.NTW * 4, t);
+                              mk + NTHREADS, t);
         __syncthreads();
-        dense_masked<NTWM, 4>(lds + l.o_HA, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2T), lds + l.o_HB,
+        dense_masked<NTWM, depth_w<NTWM>()>(lds + l.o_HA, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2T), lds + l.o_HB,
                               l.WS, mk, t);
         __syncthreads();
         gemm_ksplit(lds + l.o_HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W1T), f.NTd, PART, l.PN, t);
