@@ -84,7 +84,7 @@ SYMBOLS = [
     "fabhip_metropolis_transition", "fabhip_ais_workspace_bytes", "fabhip_ais_run", "fabhip_ess_workspace_bytes",
     "fabhip_ess_logz", "fabhip_multinomial_torch_workspace_bytes", "fabhip_multinomial_torch",
     "fabhip_resample_workspace_bytes", "fabhip_resample_multinomial", "fabhip_resample_systematic",
-    "fabhip_gather_rows",
+    "fabhip_gather_rows", "fabhip_debug_timeline",
 ]
 
 
@@ -122,6 +122,7 @@ def _declare(lib):
     lib.fabhip_resample_multinomial.argtypes = [vp, i64, vp, i64, vp, vp, sz, vp]
     lib.fabhip_resample_systematic.argtypes = [vp, i64, dbl, i64, vp, vp, sz, vp]
     lib.fabhip_gather_rows.argtypes = [vp, vp, vp, i64, i64, vp]
+    lib.fabhip_debug_timeline.argtypes = [vp, i32]
     for name in SYMBOLS:
         fn = getattr(lib, name)
         if fn.restype is C.c_int and name not in ("fabhip_version",):

@@ -37,6 +37,7 @@ struct FlowDims {
     int o_base;                 // offset of base block: loc[Dp], log_scale[Dp]
     int o_scratch;              // offset of affine scratch: per layer W[D*D], Winv[D*D]
     int total;                  // total floats
+    long long* timeline;        // dev-only: s_memtime stamps of workgroup 0 (nullptr in production)
 };
 
 FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
@@ -70,6 +71,7 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     f.o_base = K * f.layer_stride;
     f.o_scratch = f.o_base + 2 * f.Dp;
     f.total = f.o_scratch + K * 2 * D * D;
+    f.timeline = nullptr;
     return f;
 }
 

@@ -4,11 +4,16 @@
 // (v_mfma_f32_16x16x4_f32: exact fp32, bit-identical to an fmaf chain): activations live in LDS
 // (row-major, leading dimension padded by 4 floats), weights are streamed from the L2-resident
 // packed image straight into VGPRs (each weight is used by exactly one wave of the workgroup, so an
-// LDS round trip would be pure overhead) with a software prefetch ring.
+// LDS round trip would be pure overhead) through a software prefetch ring.
 //
 // Packed B-operand tile (c, S) of a K x N matrix: 64 lanes x float4, lane l = (q = l>>4, n = l&15)
 // holds  B[16S + 4q + t][16c + n], t = 0..3.  MFMA step t of k-block S therefore multiplies
 // A[row][16S + 4q + t] (one ds_read_b128 per lane per k-block) with that register.
+//
+// Every stage issues its own ring prologue right before its main loop.  (Issuing the NEXT stage's prologue
+// before the current epilogue + barrier was tried and removed: registers that are the target of an in-flight
+// hidden load must not be live across code hipcc is free to re-allocate / spill - it copies them before the
+// data lands.  Inside the tight MFMA loop the ring registers are pinned by the wait operands.)
 #pragma once
 #include "fabhip_common.h"
 
@@ -29,6 +34,9 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// dev-only timeline: workgroup 0 / thread 0 records s_memtime at stage boundaries of one layer
+#define FAB_TL(f, idx) do { if ((f).timeline && blockIdx.x == 0 && threadIdx.x == 0) (f).timeline[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+
 struct Tid {
     int tid, wave, lane, q, n, row, c;
     __device__ __forceinline__ Tid() {
@@ -42,15 +50,22 @@ struct Tid {
     }
 };
 
-// ---- weight-tile loads hidden from hipcc's s_waitcnt bookkeeping --------------------------------
-// hipcc drains vmcnt(0) at the head of every loop iteration that carries loads in flight, which
-// serialises a register prefetch ring.  The ring loads are therefore issued through inline asm and
-// waited for with hand-counted s_waitcnt vmcnt(N) (loads return in order, so N = number of ring loads
-// issued after the one needed; any other load in flight only makes the wait more conservative).
-__device__ __forceinline__ void gload16(f32x4& dst, const float4* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(dst) : "v"(p));
+// ---- loads hidden from hipcc's s_waitcnt bookkeeping ---------------------------------------------
+// hipcc drains vmcnt(0) at the head of every loop iteration that carries loads in flight (and in front of
+// every barrier), which serialises a register prefetch ring.  Weight / bias loads are therefore issued
+// through inline asm and waited for with hand-counted s_waitcnt vmcnt(N) (loads return in order, so N = the
+// number of hidden loads issued after the one needed; any other load in flight only makes the wait more
+// conservative).  Every wait names the destination registers as operands so that hipcc keeps them allocated
+// until the data has landed.
+__device__ __forceinline__ void gload16s(f32x4& dst, unsigned voff, const float4* sbase) {   // SGPR base + lane offset
+    asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
 }
-
+// First load of a group that uses a freshly computed scalar base: hipcc pads no hazards for instructions
+// inside an asm statement, and an SGPR written by a VALU op (v_readlane / v_readfirstlane, e.g. an SGPR-spill
+// restore) needs 5 wait states before a VMEM instruction reads it as its base.
+__device__ __forceinline__ void gload16s_first(f32x4& dst, unsigned voff, const float4* sbase) {
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(voff), "s"(sbase));
+}
 __device__ __forceinline__ void gload4(float& dst, const float* p) {
     asm volatile("global_load_dword %0, %1, off" : "=v"(dst) : "v"(p));
 }
@@ -87,36 +102,64 @@ __device__ __forceinline__ void wait_tiles(f32x4 (&r)[NT]) {
     else static_assert(NT == 1, "unsupported tile count");
 }
 
+// depth of the weight ring of the W x W GEMMs (must divide KBW = 4 * NTWM)
+template <int NTWM>
+__host__ __device__ constexpr int depth_w() { return NTWM == 8 ? 2 : 4; }
+
 // ---- N-split GEMM: wave w owns column tiles c_i = w + 4 i, i < NTWM (the tile count is padded to
 // 4*NTWM with zero tiles at pack time, so the hot loop has no predication at all).
-// acc[i] += A[16 x 16*KB] @ B[:, tile c_i];  KB % DEPTH == 0 (K padded at pack time).
-// Weight tiles are fetched DEPTH k-blocks ahead into a register ring (DEPTH*NTWM KiB in flight per
-// wave); the A fragment (one ds_read_b128 per k-block) is fetched one k-block ahead.
-// With `bias` the accumulators start from bias[16 c_i + n] (loaded through the same hidden path, issued
-// BEFORE the ring so that the ring stays in flight while they are waited for) instead of the caller's values.
-template <int NTWM, int DEPTH, bool MASKK, bool BIAS = false>
-__device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda, int kmax, int KB,
-                                            const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM],
-                                            const float* __restrict__ bias = nullptr) {
-    const float* arow = A + t.n * lda + 4 * t.q;
-    const float4* bt = Bp + (size_t)t.wave * KB * 64 + t.lane;     // tile c_i at bt + i*4*KB*64
-    const size_t tstride = (size_t)4 * KB * 64;
+// acc[i] (+)= A[16 x 16*KB] @ B[:, tile c_i];  KB % DEPTH == 0 (K padded at pack time).
+// WRing = the wave's register prefetch ring (DEPTH k-blocks x NTWM tiles) + the bias of its columns.
+template <int NTWM, int DEPTH>
+struct WRing {
+    f32x4 r[DEPTH][NTWM];
     float bv[NTWM];
+};
+
+template <int NTWM>
+__device__ __forceinline__ void tile_offsets(unsigned (&voff)[NTWM], int KB, const Tid& t) {
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) voff[i] = (unsigned)(((size_t)i * 4 * KB * 64 + t.lane) * 16);
+}
+
+// issue the ring prologue (k-blocks 0 .. DEPTH-1) and, with BIAS, the bias loads (issued first = oldest)
+template <int NTWM, int DEPTH, bool BIAS>
+__device__ __forceinline__ void ring_issue(WRing<NTWM, DEPTH>& w, const float4* __restrict__ Bp, int KB,
+                                           const float* __restrict__ bias, const Tid& t) {
+    const float4* bw = Bp + (size_t)t.wave * KB * 64;              // wave-uniform base of this wave's tile 0
+    unsigned voff[NTWM];
+    tile_offsets<NTWM>(voff, KB, t);
     if (BIAS) {
 #pragma unroll
-        for (int i = 0; i < NTWM; ++i) gload4(bv[i], bias + 16 * (t.wave + 4 * i) + t.n);
+        for (int i = 0; i < NTWM; ++i) gload4(w.bv[i], bias + 16 * (t.wave + 4 * i) + t.n);
     }
-    f32x4 ring[DEPTH][NTWM];
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d)
+    for (int d = 0; d < DEPTH; ++d) {
+        const float4* sb = bw + (size_t)d * 64;
+        gload16s_first(w.r[d][0], voff[0], sb);
 #pragma unroll
-        for (int i = 0; i < NTWM; ++i) gload16(ring[d][i], bt + i * tstride + (size_t)d * 64);
+        for (int i = 1; i < NTWM; ++i) gload16s(w.r[d][i], voff[i], sb);
+    }
+}
+
+// main loop on a ring whose prologue was issued earlier and after which NO other hidden load was issued.
+// Loop schedule per k-block S (ring slot d = S mod DEPTH), pinned with sched_barrier:
+//   wait slot d  |  NTWM MFMA (a.x)  |  refill the slot of block S-1 with block S-1+DEPTH  |  3 NTWM MFMA
+// so the refill's address arithmetic and load issue run in the shadow of the matrix pipe.
+template <int NTWM, int DEPTH, bool MASKK, bool BIAS>
+__device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __restrict__ A, int lda, int kmax,
+                                         int KB, const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM]) {
+    static_assert(DEPTH >= 2, "ring depth");
+    const float* arow = A + t.n * lda + 4 * t.q;
+    const float4* bw = Bp + (size_t)t.wave * KB * 64;
+    unsigned voff[NTWM];
+    tile_offsets<NTWM>(voff, KB, t);
     float4 a_nxt = *reinterpret_cast<const float4*>(arow);
     if (BIAS) {
-        wait_vals<DEPTH * NTWM, NTWM>(bv);
+        wait_vals<DEPTH * NTWM, NTWM>(w.bv);                       // the ring (younger) may stay in flight
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){bv[i], bv[i], bv[i], bv[i]};
+        for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){w.bv[i], w.bv[i], w.bv[i], w.bv[i]};
     }
     for (int S0 = 0; S0 < KB; S0 += DEPTH) {
 #pragma unroll
@@ -132,65 +175,91 @@ __device__ __forceinline__ void gemm_nsplit(const float* __restrict__ A, int lda
                 a.z = (k0 + 2 < kmax) ? a.z : 0.f;
                 a.w = (k0 + 3 < kmax) ? a.w : 0.f;
             }
-            // ring slot d holds k-block S; (DEPTH-1)*NTWM younger ring loads may stay in flight
-            wait_tiles<(DEPTH - 1) * NTWM, NTWM>(ring[d]);
+            // slot d was (re)filled during block S-DEPTH+1; DEPTH-2 younger refill groups may stay in flight
+            wait_tiles<(DEPTH - 2) * NTWM, NTWM>(w.r[d]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.x, ring[d][i].x, acc[i]);
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.y, ring[d][i].y, acc[i]);
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, ring[d][i].z, acc[i]);
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, ring[d][i].w, acc[i]);
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.x, w.r[d][i].x, acc[i]);
             __builtin_amdgcn_sched_barrier(0);
-            // refill this slot with k-block S + DEPTH (clamped: the tail re-reads the last block, which
-            // keeps the in-flight count constant so that the hand-counted vmcnt stays exact)
-            const int Sp = (S + DEPTH < KB) ? S + DEPTH : KB - 1;
+            if (S > 0) {
+                // refill the slot consumed by block S-1 with block S-1+DEPTH (clamped: the tail re-reads the
+                // last block, which keeps the in-flight count constant so the hand-counted vmcnt stays exact)
+                const int dp = (d + DEPTH - 1) % DEPTH;      // static after unrolling
+                const int Sp = (S - 1 + DEPTH < KB) ? S - 1 + DEPTH : KB - 1;
+                const float4* sb = bw + (size_t)Sp * 64;
+                gload16s_first(w.r[dp][0], voff[0], sb);
 #pragma unroll
-            for (int i = 0; i < NTWM; ++i) gload16(ring[d][i], bt + i * tstride + (size_t)Sp * 64);
+                for (int i = 1; i < NTWM; ++i) gload16s(w.r[dp][i], voff[i], sb);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.y, w.r[d][i].y, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, w.r[d][i].z, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, w.r[d][i].w, acc[i]);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    // The clamped tail loads are still in flight.  Drain them with the ring registers as operands of the
-    // wait: otherwise hipcc, which believes they are dead, may re-allocate them above the wait and the
+    // Refills (incl. the clamped tail) are still in flight.  Drain them with the ring registers as operands
+    // of the wait: otherwise hipcc, which believes they are dead, may re-allocate them above the wait and the
     // landing loads would clobber live values.
 #pragma unroll
-    for (int d = 0; d < DEPTH; ++d) wait_tiles<0, NTWM>(ring[d]);
+    for (int d = 0; d < DEPTH; ++d) wait_tiles<0, NTWM>(w.r[d]);
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// ---- K-split GEMM for narrow outputs (N = 16*NT <= 64): wave w sums k-blocks S = w, w+4, ... of
-// every column tile; the four partial [16 x 16*NT] products go to LDS part[w][row][PN] and are added by
-// the caller.  Tiles are the outer (runtime) loop so that no register array is indexed by NT.
-__device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda, int KB,
-                                            const float4* __restrict__ Bp, int NT, float* __restrict__ part,
-                                            int PN, const Tid& t) {
-    const float* arow = A + t.n * lda + 4 * t.q;
-    float* p = part + (size_t)t.wave * ROWS * PN;
-    for (int i = 0; i < NT; ++i) {
-        f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
-        const float4* bt = Bp + (size_t)i * KB * 64 + t.lane;
-        int S = t.wave;
-        for (; S + NWAVE < KB; S += 2 * NWAVE) {            // two independent accumulation chains
-            const float4 b0 = bt[(size_t)S * 64], b1 = bt[(size_t)(S + NWAVE) * 64];
-            const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * S);
-            const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * (S + NWAVE));
-            acc0 = mfma4(a0.x, b0.x, acc0); acc1 = mfma4(a1.x, b1.x, acc1);
-            acc0 = mfma4(a0.y, b0.y, acc0); acc1 = mfma4(a1.y, b1.y, acc1);
-            acc0 = mfma4(a0.z, b0.z, acc0); acc1 = mfma4(a1.z, b1.z, acc1);
-            acc0 = mfma4(a0.w, b0.w, acc0); acc1 = mfma4(a1.w, b1.w, acc1);
-        }
-        if (S < KB) {
-            const float4 b0 = bt[(size_t)S * 64];
-            const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * S);
-            acc0 = mfma4(a0.x, b0.x, acc0);
-            acc0 = mfma4(a0.y, b0.y, acc0);
-            acc0 = mfma4(a0.z, b0.z, acc0);
-            acc0 = mfma4(a0.w, b0.w, acc0);
-        }
+// ---- K-split GEMM for narrow outputs (N = 16*NT <= 64, K = 64*KW): wave w sums k-blocks S = w, w+4, ... of
+// every column tile; the four partial [16 x 16*NT] products go to LDS part[w][row][PN] and are added by the
+// caller.  Plain (compiler-tracked) loads in straight-line code: the weights of tile i+1 are requested before
+// tile i is multiplied.  (An inline-asm double buffer was tried here and is unsafe: hipcc copies registers
+// that are the target of an in-flight hidden load when their live ranges are split.)
+template <int KW>
+__device__ __forceinline__ void ksplit_load(float4 (&b)[KW], const float4* __restrict__ Bp, int tile, const Tid& t) {
+    const float4* bt = Bp + ((size_t)tile * 4 * KW + t.wave) * 64 + t.lane;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) p[(4 * t.q + r) * PN + 16 * i + t.n] = acc0[r] + acc1[r];
+    for (int s = 0; s < KW; ++s) b[s] = bt[(size_t)s * 4 * 64];
+}
+
+template <int KW>
+__device__ __forceinline__ void ksplit_mul(const float4 (&b)[KW], const float* __restrict__ arow,
+                                           float* __restrict__ pw, int PN, int tile, const Tid& t) {
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;               // two independent chains
+#pragma unroll
+    for (int s = 0; s < KW; ++s) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 16 * (t.wave + 4 * s));
+        if (s & 1) {
+            acc1 = mfma4(a.x, b[s].x, acc1); acc1 = mfma4(a.y, b[s].y, acc1);
+            acc1 = mfma4(a.z, b[s].z, acc1); acc1 = mfma4(a.w, b[s].w, acc1);
+        } else {
+            acc0 = mfma4(a.x, b[s].x, acc0); acc0 = mfma4(a.y, b[s].y, acc0);
+            acc0 = mfma4(a.z, b[s].z, acc0); acc0 = mfma4(a.w, b[s].w, acc0);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) pw[(4 * t.q + r) * PN + 16 * tile + t.n] = acc0[r] + acc1[r];
+}
+
+template <int KW>
+__device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda, const float4* __restrict__ Bp,
+                                            int NT, float* __restrict__ part, int PN, const Tid& t) {
+    const float* arow = A + t.n * lda + 4 * t.q;
+    float* pw = part + (size_t)t.wave * ROWS * PN;
+    float4 b0[KW], b1[KW];
+    ksplit_load<KW>(b0, Bp, 0, t);
+    if (NT > 1) ksplit_load<KW>(b1, Bp, 1, t);
+    __builtin_amdgcn_sched_barrier(0);
+    ksplit_mul<KW>(b0, arow, pw, PN, 0, t);
+    if (NT > 1) {
+        if (NT > 2) ksplit_load<KW>(b0, Bp, 2, t);
+        __builtin_amdgcn_sched_barrier(0);
+        ksplit_mul<KW>(b1, arow, pw, PN, 1, t);
+        if (NT > 2) {
+            if (NT > 3) ksplit_load<KW>(b1, Bp, 3, t);
+            __builtin_amdgcn_sched_barrier(0);
+            ksplit_mul<KW>(b0, arow, pw, PN, 2, t);
+            if (NT > 3) ksplit_mul<KW>(b1, arow, pw, PN, 3, t);
+        }
     }
 }
 
@@ -202,23 +271,18 @@ __device__ __forceinline__ float part_sum(const float* part, int PN, int row, in
     return s;
 }
 
-// depth of the weight ring of the W x W GEMMs (must divide KBW = 4 * NTWM): how many k-blocks of weights
-// are in flight per wave.  L2 misses go to the Infinity Cache (~1 us): 5 blocks x 640 MFMA-cycles cover it.
-#ifndef FAB_DEPTH_W5
-#define FAB_DEPTH_W5 4
-#endif
-template <int NTWM>
-__host__ __device__ constexpr int depth_w() { return NTWM == 5 ? FAB_DEPTH_W5 : (NTWM == 8 ? 2 : 4); }
-
-// hidden layer: OUT = relu(A @ B + bias).  With MASK the ReLU sign pattern of this lane's 4*NTWM outputs is
-// kept as one 32-bit word per thread (bit 4 i + r) for the reverse sweep: the same lane of the same wave
-// owns the same (tile, register) there, so no cross-lane exchange and a single LDS store per GEMM.
+// hidden layer: OUT = relu(A @ B + bias).  With MASK the
+// ReLU sign pattern of this lane's 4*NTWM outputs is kept as one 32-bit word per thread (bit 4 i + r) for the
+// reverse sweep: the same lane of the same wave owns the same (tile, register) there, so no cross-lane
+// exchange and a single LDS store per GEMM.
 template <int NTWM, int DEPTH, bool MASKK, bool MASK>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
-                                           const float* __restrict__ bias, float* OUT, int ldo,
-                                           unsigned* mask, const Tid& t) {
+                                           const float* __restrict__ bias, float* OUT, int ldo, unsigned* mask,
+                                           const Tid& t) {
     f32x4 acc[NTWM];
-    gemm_nsplit<NTWM, DEPTH, MASKK, true>(A, lda, kmax, KB, Bp, t, acc, bias);
+    WRing<NTWM, DEPTH> w;
+    ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
+    ring_run<NTWM, DEPTH, MASKK, true>(w, A, lda, kmax, KB, Bp, t, acc);
     unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
@@ -241,8 +305,10 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    WRing<NTWM, DEPTH> w;
+    ring_issue<NTWM, DEPTH, false>(w, Bp, KB, nullptr, t);
     const unsigned m = mask[t.tid];
-    gemm_nsplit<NTWM, DEPTH, false>(A, lda, 0, KB, Bp, t, acc);
+    ring_run<NTWM, DEPTH, false, false>(w, A, lda, 0, KB, Bp, t, acc);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
@@ -254,33 +320,18 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
     }
 }
 
-// OUT[16 x 16*NT] = A[16 x K] @ B   (NT <= 4: one column tile per wave), used for the D x D affine maps
-__device__ __forceinline__ void dense_small(const float* A, int lda, int kmax, int KB, const float4* Bp,
-                                            int NT, float* OUT, int ldo, const Tid& t) {
+// OUT[16 x 16*NT] = A[16 x K] @ B   (NT <= 4: one column tile per wave), used for the D x D affine maps.
+__device__ __forceinline__ void dense_small(const float* A, int lda, int kmax, int KB, const float4* Bp, int NT,
+                                            float* OUT, int ldo, const Tid& t) {
     if (t.wave < NT) {
         f32x4 acc[1];
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        gemm_nsplit<1, 2, true>(A, lda, kmax, KB, Bp, t, acc);
+        WRing<1, 2> w;
+        ring_issue<1, 2, false>(w, Bp, KB, nullptr, t);
+        ring_run<1, 2, true, false>(w, A, lda, kmax, KB, Bp, t, acc);
 #pragma unroll
         for (int r = 0; r < 4; ++r) OUT[(4 * t.q + r) * ldo + 16 * t.wave + t.n] = acc[0][r];
     }
-}
-
-// conditioner MLP of one coupling layer: PART <- partial sums of relu(relu(z1 W1 + b1) W2 + b2) W3
-template <int NTWM, bool MASK>
-__device__ __forceinline__ void coupling_mlp(const FlowDims& f, const FlowLds& l, const float* Lp, float* lds,
-                                             const float* Z, int layer, const Tid& t) {
-    float* HA = lds + l.o_HA;
-    float* HB = lds + l.o_HB;
-    unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
-    dense_relu<NTWM, 2, true, MASK>(Z, l.DS, f.d, f.KBd, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1,
-                                    HA, l.WS, mk, t);
-    __syncthreads();
-    dense_relu<NTWM, depth_w<NTWM>(), false, MASK>(HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2), Lp + f.o_b2,
-                                     HB, l.WS, mk + NTHREADS, t);
-    __syncthreads();
-    gemm_ksplit(HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W3), f.NTO, lds + l.o_PART, l.PN, t);
-    __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -292,19 +343,42 @@ __device__ __forceinline__ void coupling_mlp(const FlowDims& f, const FlowLds& l
 template <int NTWM, bool GRAD>
 __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const float* __restrict__ packed,
                                     float* lds, const Tid& t, int* grad_off) {
+    constexpr int DW = depth_w<NTWM>();
     int cur = l.o_U0, nxt = l.o_U1;
     float logq = 0.f;
     float* PART = lds + l.o_PART;
+    float* HA = lds + l.o_HA;
+    float* HB = lds + l.o_HB;
     for (int layer = f.K - 1; layer >= 0; --layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
-        // InvertibleAffine.inverse: z <- z @ (P L U), log_det = +sum(log_S)
+        const float4* W1 = reinterpret_cast<const float4*>(Lp + f.o_W1);
+        const float4* W2 = reinterpret_cast<const float4*>(Lp + f.o_W2);
+        const float4* W3 = reinterpret_cast<const float4*>(Lp + f.o_W3);
+        unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
+        const bool tl = (layer == f.K - 2);
+        if (tl) FAB_TL(f, 0);
+        // ---- InvertibleAffine.inverse: z <- z @ (P L U), log_det = +sum(log_S) --------------------------
         dense_small(lds + cur, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AW), f.NTD, lds + nxt,
                     l.DS, t);
         logq += Lp[f.o_logS];
+        if (tl) FAB_TL(f, 1);
         __syncthreads();
+        if (tl) FAB_TL(f, 2);
         float* Z = lds + nxt;
-        coupling_mlp<NTWM, GRAD>(f, l, Lp, lds, Z, layer, t);
-        // AffineCoupling.inverse: z2 <- (z2 - shift) * exp(-s), log_det = -sum(s)
+        // ---- conditioner MLP: relu(relu(z1 W1 + b1) W2 + b2) W3' ----------------------------------------
+        dense_relu<NTWM, 2, true, GRAD>(Z, l.DS, f.d, f.KBd, W1, Lp + f.o_b1, HA, l.WS, mk, t);
+        if (tl) FAB_TL(f, 3);
+        __syncthreads();
+        if (tl) FAB_TL(f, 4);
+        dense_relu<NTWM, DW, false, GRAD>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t);
+        if (tl) FAB_TL(f, 5);
+        __syncthreads();
+        if (tl) FAB_TL(f, 6);
+        gemm_ksplit<NTWM>(HB, l.WS, W3, f.NTO, PART, l.PN, t);
+        if (tl) FAB_TL(f, 7);
+        __syncthreads();
+        if (tl) FAB_TL(f, 8);
+        // ---- AffineCoupling.inverse: z2 <- (z2 - shift) * exp(-s), log_det = -sum(s) ----------------------
         float ssum = 0.f;
         for (int j = t.c; j < f.DO; j += 16) {
             const float shift = part_sum(PART, l.PN, t.row, j) + Lp[f.o_b3 + j];
@@ -319,10 +393,12 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
             ssum += s;
         }
         logq += -row16_sum(ssum);
+        if (tl) FAB_TL(f, 10);
         __syncthreads();
+        if (tl) FAB_TL(f, 11);
         const int tmp = cur; cur = nxt; nxt = tmp;
     }
-    // DiagGaussian.log_prob
+    // ---- DiagGaussian.log_prob -----------------------------------------------------------------------
     const float* base = packed + f.o_base;
     float* Zc = lds + cur;
     float bsum = 0.f;
@@ -335,13 +411,18 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
     }
     logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
     if (!GRAD) return logq;
-    __syncthreads();
 
     // ---- reverse sweep: g = d log q / d(state), layers 0 .. K-1 -----------------------------------
     float* DP = lds + l.o_DP;
     for (int layer = 0; layer < f.K; ++layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
+        const float4* W3T = reinterpret_cast<const float4*>(Lp + f.o_W3T);
+        const float4* W2T = reinterpret_cast<const float4*>(Lp + f.o_W2T);
+        const float4* W1T = reinterpret_cast<const float4*>(Lp + f.o_W1T);
+        const float4* AWT = reinterpret_cast<const float4*>(Lp + f.o_AWT);
         float* G = lds + cur;
+        const bool tl = (layer == 1);
+        if (tl) FAB_TL(f, 16);
         for (int j = t.c; j < f.DO; j += 16) {
             const float g2 = G[t.row * l.DS + f.d + j];
             const float es = lds[l.o_ES + ((size_t)layer * ROWS + t.row) * f.DOp + j];
@@ -350,21 +431,31 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
             DP[t.row * l.PS + f.DOp + j] = -(g2 * v2) - 1.f;       // d/d s  (incl. the -sum(s) log-det)
             G[t.row * l.DS + f.d + j] = g2 * es;                  // d/d z2
         }
+        if (tl) FAB_TL(f, 17);
         __syncthreads();
+        if (tl) FAB_TL(f, 18);
         const unsigned* mk = reinterpret_cast<const unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
-        dense_masked<NTWM, 2>(DP, l.PS, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), lds + l.o_HA, l.WS,
-                              mk + NTHREADS, t);
+        dense_masked<NTWM, 2>(DP, l.PS, f.KBO, W3T, HA, l.WS, mk + NTHREADS, t);
+        if (tl) FAB_TL(f, 19);
         __syncthreads();
-        dense_masked<NTWM, depth_w<NTWM>()>(lds + l.o_HA, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2T), lds + l.o_HB,
-                              l.WS, mk, t);
+        if (tl) FAB_TL(f, 20);
+        dense_masked<NTWM, DW>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t);
+        if (tl) FAB_TL(f, 21);
         __syncthreads();
-        gemm_ksplit(lds + l.o_HB, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W1T), f.NTd, PART, l.PN, t);
+        if (tl) FAB_TL(f, 22);
+        gemm_ksplit<NTWM>(HB, l.WS, W1T, f.NTd, PART, l.PN, t);
+        if (tl) FAB_TL(f, 23);
         __syncthreads();
+        if (tl) FAB_TL(f, 24);
         for (int j = t.c; j < f.d; j += 16) G[t.row * l.DS + j] += part_sum(PART, l.PN, t.row, j);
+        if (tl) FAB_TL(f, 25);
         __syncthreads();
-        // through InvertibleAffine.inverse: g <- g @ W^T
-        dense_small(G, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AWT), f.NTD, lds + nxt, l.DS, t);
+        if (tl) FAB_TL(f, 26);
+        // ---- through InvertibleAffine.inverse: g <- g @ W^T -----------------------------------------------
+        dense_small(G, l.DS, f.D, f.KBD, AWT, f.NTD, lds + nxt, l.DS, t);
+        if (tl) FAB_TL(f, 27);
         __syncthreads();
+        if (tl) FAB_TL(f, 28);
         const int tmp = cur; cur = nxt; nxt = tmp;
     }
     *grad_off = cur;
@@ -373,14 +464,18 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
 
 // ------------------------------------------------------------------------------------------------
 // x, log q = flow.sample given base noise in U0 (NormalizingFlow.sample): forward maps in layer order.
-// Leaves x in the buffer at *x_off and returns log q of this thread's row.
+// Leaves x in the buffer at *x_off and returns log q of this thread's row.  (Runs once per AIS call:
+// stages issue their own prologues, no cross-stage pipelining.)
 // ------------------------------------------------------------------------------------------------
 template <int NTWM>
 __device__ float flow_sample_tile(const FlowDims& f, const FlowLds& l, const float* __restrict__ packed,
                                   float* lds, const Tid& t, int* x_off) {
+    constexpr int DW = depth_w<NTWM>();
     int cur = l.o_U0, nxt = l.o_U1;
     const float* base = packed + f.o_base;
     float* PART = lds + l.o_PART;
+    float* HA = lds + l.o_HA;
+    float* HB = lds + l.o_HB;
     float bsum = 0.f;
     {
         float* Z = lds + cur;
@@ -395,8 +490,17 @@ __device__ float flow_sample_tile(const FlowDims& f, const FlowLds& l, const flo
     __syncthreads();
     for (int layer = 0; layer < f.K; ++layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
+        const float4* W1 = reinterpret_cast<const float4*>(Lp + f.o_W1);
+        const float4* W2 = reinterpret_cast<const float4*>(Lp + f.o_W2);
+        const float4* W3 = reinterpret_cast<const float4*>(Lp + f.o_W3);
+        const float4* AWI = reinterpret_cast<const float4*>(Lp + f.o_AWI);
         float* Z = lds + cur;
-        coupling_mlp<NTWM, false>(f, l, Lp, lds, Z, layer, t);
+        dense_relu<NTWM, 2, true, false>(Z, l.DS, f.d, f.KBd, W1, Lp + f.o_b1, HA, l.WS, nullptr, t);
+        __syncthreads();
+        dense_relu<NTWM, DW, false, false>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, nullptr, t);
+        __syncthreads();
+        gemm_ksplit<NTWM>(HB, l.WS, W3, f.NTO, PART, l.PN, t);
+        __syncthreads();
         float ssum = 0.f;
         for (int j = t.c; j < f.DO; j += 16) {
             const float shift = part_sum(PART, l.PN, t.row, j) + Lp[f.o_b3 + j];
@@ -407,7 +511,7 @@ __device__ float flow_sample_tile(const FlowDims& f, const FlowLds& l, const flo
         logq -= row16_sum(ssum);
         __syncthreads();
         // InvertibleAffine.forward: z <- z @ W^-1, log_det = -sum(log_S)
-        dense_small(Z, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AWI), f.NTD, lds + nxt, l.DS, t);
+        dense_small(Z, l.DS, f.D, f.KBD, AWI, f.NTD, lds + nxt, l.DS, t);
         logq -= -Lp[f.o_logS];
         __syncthreads();
         const int tmp = cur; cur = nxt; nxt = tmp;

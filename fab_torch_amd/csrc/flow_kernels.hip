@@ -1,6 +1,7 @@
 // RealNVP flow: parameter packing, log_prob (+ d/dx) and sampling kernels + their C ABI.
 #include "flow_device.h"
 #include "launch.h"
+#include <stdlib.h>
 
 namespace fab {
 
@@ -251,7 +252,15 @@ static int launch_sample(const FlowDims& f, const float* packed, const float* ep
 
 using namespace fab;
 
+// dev-only stage timeline (FABHIP_TIMELINE=1): 64 s_memtime stamps written by workgroup 0 of fabhip_flow_log_prob
+static long long* g_timeline = nullptr;
+
 extern "C" {
+
+int fabhip_debug_timeline(int64_t* host_out, int32_t n) {
+    if (!g_timeline || !host_out || n < 1 || n > 64) return FABHIP_EINVAL;
+    return hipMemcpy(host_out, g_timeline, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH;
+}
 
 int64_t fabhip_flow_packed_floats(int32_t dim, int32_t n_layers, int32_t width) {
     if (check_flow_shape(dim, n_layers, width) != FABHIP_OK) return -1;
@@ -289,7 +298,12 @@ int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, 
     if (!flow || !flow->packed || !x || !log_q || B < 0) return FABHIP_EINVAL;
     FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
     if (B == 0) return FABHIP_OK;
-    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    if (getenv("FABHIP_TIMELINE")) {          // diagnostics only: never set in production (allocates once)
+        if (!g_timeline && hipMalloc((void**)&g_timeline, 64 * 8) != hipSuccess) return FABHIP_ELAUNCH;
+        hipMemsetAsync(g_timeline, 0, 64 * 8, (hipStream_t)stream);
+        f.timeline = g_timeline;
+    }
     FAB_DISPATCH_NTW(f, launch_log_prob, f, flow->packed, x, log_q, grad_x, (long)B, (hipStream_t)stream);
 }
 

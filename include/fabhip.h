@@ -250,6 +250,11 @@ int fabhip_resample_systematic(const float* log_w, int64_t n, double u0, int64_t
 int fabhip_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t n_out, int64_t row_len,
                        fabhip_stream_t stream);
 
+/* Diagnostics (development only): with FABHIP_TIMELINE=1 in the environment fabhip_flow_log_prob records
+ * s_memtime stamps at the stage boundaries of one forward and one backward layer of workgroup 0;
+ * this call copies the first n (<= 64) stamps to the host (synchronises). */
+int fabhip_debug_timeline(int64_t* host_out, int32_t n);
+
 #ifdef __cplusplus
 }
 #endif
