@@ -10,11 +10,15 @@ from .targets import ManyWellEnergy, GMM
 from .transition_operators import TransitionOperator, HamiltonianMonteCarlo, Metropolis, create_point
 from .ais import AnnealedImportanceSampler, LoggingInfo
 from .numerical import effective_sample_size, ess_and_log_z
+from .core import FABModel
+from .buffer import PrioritisedReplayBuffer, sample_without_replacement
+from .train import PrioritisedBufferTrainer
 from .resample import resample, multinomial_indices, systematic_indices, multinomial_torch_compat, gather_rows
 
 __all__ = [
     "Point", "RealNVP", "make_wrapped_normflow_realnvp", "ManyWellEnergy", "GMM", "TransitionOperator",
     "HamiltonianMonteCarlo", "Metropolis", "create_point", "AnnealedImportanceSampler", "LoggingInfo",
     "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
-    "multinomial_torch_compat", "gather_rows",
+    "multinomial_torch_compat", "gather_rows", "FABModel", "PrioritisedReplayBuffer",
+    "sample_without_replacement", "PrioritisedBufferTrainer",
 ]

@@ -1,0 +1,93 @@
+"""Prioritised replay buffer on the device — same interface and semantics as
+fab/utils/prioritised_replay_buffer.py:20-153: ring buffer of (x, log_w, log_q_old); sampling without
+replacement by the Gumbel-top-k trick over log_w followed by a random permutation (:10-17); `adjust` adds
+the log-weight correction, refreshes log_q_old and kills entries whose correction is not finite (log_w = -inf,
+:117-131).  All tensors stay on the buffer device (the GPU): no host round trip per iteration.
+("Next" row of SURVEY.md section 8f: device-side PyTorch ops for now, a radix-select top-k kernel later.)"""
+from typing import Callable, Iterable, NamedTuple, Tuple
+
+import torch
+
+
+class ReplayData(NamedTuple):
+    x: torch.Tensor
+    log_w: torch.Tensor
+    log_q_old: torch.Tensor
+
+
+def sample_without_replacement(logits: torch.Tensor, n: int) -> torch.Tensor:
+    """Gumbel-max trick: top-n of logits + Gumbel(0,1) noise, in random order."""
+    u = torch.rand(logits.shape, device=logits.device, dtype=logits.dtype).clamp_(min=torch.finfo(logits.dtype).tiny)
+    z = -torch.log(-torch.log(u))
+    indices = torch.topk(z + logits, n, sorted=False).indices
+    return indices[torch.randperm(n, device=indices.device)]
+
+
+class PrioritisedReplayBuffer:
+    def __init__(self, dim: int, max_length: int, min_sample_length: int,
+                 initial_sampler: Callable[[], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], device: str = "cpu",
+                 sample_with_replacement: bool = False, fill_buffer_during_init: bool = True):
+        assert min_sample_length < max_length
+        self.dim, self.max_length, self.min_sample_length = dim, max_length, min_sample_length
+        self.buffer = ReplayData(x=torch.zeros(max_length, dim, device=device),
+                                 log_w=torch.zeros(max_length, device=device),
+                                 log_q_old=torch.zeros(max_length, device=device))
+        self.device = device
+        self.current_index = 0
+        self.is_full = False
+        self.can_sample = False
+        self.sample_with_replacement = sample_with_replacement
+        if fill_buffer_during_init:
+            while not self.can_sample:
+                self.add(*initial_sampler())
+        else:
+            print("Buffer not initialised, expected that checkpoint will be loaded.")
+
+    @torch.no_grad()
+    def add(self, x: torch.Tensor, log_w: torch.Tensor, log_q_old: torch.Tensor) -> None:
+        n = x.shape[0]
+        idx = (torch.arange(n, device=self.device) + self.current_index) % self.max_length
+        self.buffer.x[idx] = x.to(self.device)
+        self.buffer.log_w[idx] = log_w.to(self.device)
+        self.buffer.log_q_old[idx] = log_q_old.to(self.device)
+        new_index = self.current_index + n
+        if not self.is_full:
+            self.is_full = new_index >= self.max_length
+            self.can_sample = new_index >= self.min_sample_length
+        self.current_index = new_index % self.max_length
+
+    @torch.no_grad()
+    def sample(self, batch_size: int):
+        if not self.can_sample:
+            raise Exception("Buffer must be at minimum length before calling sample")
+        max_index = self.max_length if self.is_full else self.current_index
+        if self.sample_with_replacement:
+            indices = torch.distributions.Categorical(logits=self.buffer.log_w[:max_index]).sample((batch_size,))
+        else:
+            indices = sample_without_replacement(self.buffer.log_w[:max_index], batch_size)
+        return self.buffer.x[indices], self.buffer.log_w[indices], self.buffer.log_q_old[indices], indices
+
+    def sample_n_batches(self, batch_size: int, n_batches: int) -> Iterable[Tuple[torch.Tensor, ...]]:
+        x, log_w, log_q_old, indices = self.sample(batch_size * n_batches)
+        return list(zip(torch.chunk(x, n_batches), torch.chunk(log_w, n_batches), torch.chunk(log_q_old, n_batches),
+                        torch.chunk(indices, n_batches)))
+
+    @torch.no_grad()
+    def adjust(self, log_w_adjustment, log_q, indices):
+        valid = torch.isfinite(log_w_adjustment) & torch.isfinite(log_q)
+        vi = indices[valid].to(self.device)
+        self.buffer.log_w[vi] += log_w_adjustment[valid].to(self.device)
+        self.buffer.log_q_old[vi] = log_q[valid].to(self.device)
+        self.buffer.log_w[indices[~valid].to(self.device)] = -float("inf")
+
+    def save(self, path):
+        torch.save({'x': self.buffer.x.detach().cpu(), 'log_w': self.buffer.log_w.detach().cpu(),
+                    'log_q_old': self.buffer.log_q_old.detach().cpu(), 'current_index': self.current_index,
+                    'is_full': self.is_full, 'can_sample': self.can_sample}, path)
+
+    def load(self, path):
+        old = torch.load(path)
+        self.buffer.x.copy_(old['x'])
+        self.buffer.log_w.copy_(old['log_w'])
+        self.buffer.log_q_old.copy_(old['log_q_old'])
+        self.current_index, self.is_full, self.can_sample = old['current_index'], old['is_full'], old['can_sample']

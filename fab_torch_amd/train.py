@@ -1,0 +1,77 @@
+"""FAB training loop with the prioritised buffer — the iteration of
+fab/train_with_prioritised_buffer.py:138-216 (PrioritisedBufferTrainer.run) without the plotting / wandb /
+directory plumbing: AIS (fused HIP call) -> buffer.add -> Gumbel-top-k minibatches -> for each minibatch
+loss = -mean(clip(exp((1-alpha)(log q(x) - log_q_old))) * log q(x)), clipped-gradient optimiser step, buffer
+weight adjustment.  NaN loss / non-finite gradient norm skip the step like the reference (:172-181)."""
+from typing import Callable, Dict, List, Optional
+
+import torch
+
+from .buffer import PrioritisedReplayBuffer
+from .core import FABModel
+
+
+class PrioritisedBufferTrainer:
+    def __init__(self, model: FABModel, optimizer: torch.optim.Optimizer, buffer: PrioritisedReplayBuffer,
+                 alpha: float, n_batches_buffer_sampling: int = 2, optim_schedular=None,
+                 max_gradient_norm: Optional[float] = 5.0, w_adjust_max_clip: Optional[float] = 10.0,
+                 w_adjust_in_buffer_after_update: bool = False, logger: Optional[Callable[[Dict], None]] = None):
+        self.model, self.optimizer, self.buffer, self.alpha = model, optimizer, buffer, alpha
+        self.model.annealed_importance_sampler.p_target = False          # AIS targets p^alpha q^(1-alpha)
+        self.model.annealed_importance_sampler.transition_operator.p_target = False
+        self.optim_schedular = optim_schedular
+        self.max_gradient_norm = max_gradient_norm if max_gradient_norm else float("inf")
+        self.n_batches_buffer_sampling = n_batches_buffer_sampling
+        self.max_adjust_w_clip = w_adjust_max_clip
+        self.w_adjust_in_buffer_after_update = w_adjust_in_buffer_after_update
+        self.logger = logger
+        self.history: List[Dict] = []
+
+    def step(self, i: int, batch_size: int) -> Dict:
+        model, buf = self.model, self.buffer
+        self.optimizer.zero_grad()
+        point_ais, log_w_ais = model.annealed_importance_sampler.sample_and_log_weights(batch_size)
+        buf.add(point_ais.x.detach(), log_w_ais.detach(), point_ais.log_q.detach())
+        info = model.get_iter_info()
+        mini_dataset = buf.sample_n_batches(batch_size=batch_size, n_batches=self.n_batches_buffer_sampling)
+        loss = grad_norm = None
+        for (x, log_w, log_q_old, indices) in mini_dataset:
+            self.optimizer.zero_grad()
+            log_q_x = model.flow.log_prob(x)
+            log_w_adjust = (1 - self.alpha) * (log_q_x.detach() - log_q_old)
+            w_adjust_pre_clip = torch.exp(log_w_adjust)
+            w_adjust = (torch.clip(w_adjust_pre_clip, max=self.max_adjust_w_clip)
+                        if self.max_adjust_w_clip is not None else w_adjust_pre_clip)
+            loss = - torch.mean(w_adjust * log_q_x)
+            if torch.isfinite(loss):
+                loss.backward()
+                grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), self.max_gradient_norm)
+                if torch.isfinite(grad_norm):
+                    self.optimizer.step()
+                else:
+                    print("nan grad norm in replay step")
+            else:
+                print("nan loss in replay step")
+            if not self.w_adjust_in_buffer_after_update:
+                buf.adjust(log_w_adjust, log_q_x.detach(), indices)
+        info.update(loss=loss.item(), step=i, grad_norm=float(grad_norm) if grad_norm is not None else float("nan"),
+                    sampled_log_w_std=torch.std(log_w).item(), sampled_log_w_mean=torch.mean(log_w).item(),
+                    w_adjust_mean=torch.mean(w_adjust_pre_clip).item(), log_q_x_mean=torch.mean(log_q_x).item())
+        if self.w_adjust_in_buffer_after_update:
+            with torch.no_grad():
+                for (x, log_w, log_q_old, indices) in mini_dataset:
+                    log_q_new = model.flow.log_prob(x)
+                    buf.adjust((1 - self.alpha) * (log_q_new - log_q_old), log_q_new, indices)
+        if self.optim_schedular:
+            self.optim_schedular.step()
+        return info
+
+    def run(self, n_iterations: int, batch_size: int, start_iter: int = 0) -> List[Dict]:
+        if start_iter >= n_iterations:
+            raise Exception("Not running training as start_iter >= total training iterations")
+        for i in range(start_iter + 1, n_iterations + 1):
+            info = self.step(i, batch_size)
+            self.history.append(info)
+            if self.logger:
+                self.logger(info)
+        return self.history

@@ -317,7 +317,29 @@ def g8_full_chain():
     npz("g8_ais_gmm_metropolis.npz", **out)
 
 
+def g9_buffer():
+    """Deterministic part of the reference's PrioritisedReplayBuffer (add ring wrap-around, adjust incl. the
+    invalid-entry kill); sampling itself is random and is tested through properties."""
+    from fab.utils.prioritised_replay_buffer import PrioritisedReplayBuffer
+    torch.manual_seed(90)
+    dim, L = 3, 20
+    batches = [(torch.randn(8, dim), torch.randn(8), torch.randn(8)) for _ in range(4)]
+    it = iter(batches)
+    buf = PrioritisedReplayBuffer(dim, L, 10, lambda: next(it), fill_buffer_during_init=True)   # consumes 2 batches
+    buf.add(*batches[2]); buf.add(*batches[3])                                                   # wraps around
+    idx = torch.tensor([0, 5, 7, 19, 12])
+    adj = torch.tensor([0.5, float("nan"), -1.0, float("inf"), 2.0])
+    lq = torch.tensor([1.0, 2.0, float("nan"), 4.0, 5.0])
+    buf.adjust(adj, lq, idx)
+    out = dict(dim=dim, max_length=L, min_sample_length=10, idx=idx, adj=adj, lq=lq,
+               x=buf.buffer.x, log_w=buf.buffer.log_w, log_q_old=buf.buffer.log_q_old,
+               current_index=buf.current_index, is_full=int(buf.is_full), can_sample=int(buf.can_sample))
+    for k, (x, lw, lqo) in enumerate(batches):
+        out[f"b{k}_x"], out[f"b{k}_lw"], out[f"b{k}_lq"] = x, lw, lqo
+    npz("g9_buffer.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)      # deterministic reduction order in the fixtures
     g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
-    g6_hmc(); g7_metropolis(); g8_full_chain()
+    g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer()

@@ -1,0 +1,82 @@
+"""Host-side "next" rows: prioritised replay buffer against the reference's own buffer
+(golden fixture g9) + sampling properties; FABModel glue contracts.  CPU only (the buffer is device-agnostic)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden
+
+import fab_torch_amd as fa
+
+
+def test_buffer_add_wraparound_and_adjust_match_reference():
+    g = load_golden("g9_buffer.npz")
+    batches = [(torch.tensor(g[f"b{k}_x"]), torch.tensor(g[f"b{k}_lw"]), torch.tensor(g[f"b{k}_lq"])) for k in range(4)]
+    it = iter(batches)
+    buf = fa.PrioritisedReplayBuffer(int(g["dim"]), int(g["max_length"]), int(g["min_sample_length"]), lambda: next(it))
+    buf.add(*batches[2]); buf.add(*batches[3])
+    buf.adjust(torch.tensor(g["adj"]), torch.tensor(g["lq"]), torch.tensor(g["idx"]))
+    np.testing.assert_array_equal(buf.buffer.x.numpy(), g["x"])
+    np.testing.assert_array_equal(buf.buffer.log_w.numpy(), g["log_w"])
+    np.testing.assert_array_equal(buf.buffer.log_q_old.numpy(), g["log_q_old"])
+    assert buf.current_index == int(g["current_index"]) and buf.is_full == bool(g["is_full"])
+    assert buf.can_sample == bool(g["can_sample"])
+
+
+def test_buffer_sampling_properties():
+    torch.manual_seed(0)
+    dim, L = 2, 1000
+    data = (torch.randn(L, dim), torch.randn(L) * 2, torch.randn(L))
+    buf = fa.PrioritisedReplayBuffer(dim, L + 1, L - 1, lambda: data)
+    x, lw, lq, idx = buf.sample(300)
+    assert len(set(idx.tolist())) == 300 and idx.max() < L                  # without replacement
+    assert torch.equal(x, buf.buffer.x[idx]) and torch.equal(lw, buf.buffer.log_w[idx])
+    # prioritised: the selected set is biased towards large log-weights
+    assert lw.mean() > data[1].mean() + 0.5
+    buf.buffer.log_w[:500] = -float("inf")                                   # killed entries are never drawn
+    _, _, _, idx2 = buf.sample(400)
+    assert idx2.min() >= 500
+    parts = buf.sample_n_batches(50, 4)
+    assert len(parts) == 4 and all(p[0].shape == (50, dim) for p in parts)
+    with pytest.raises(Exception):
+        fa.PrioritisedReplayBuffer(dim, 10, 5, lambda: data, fill_buffer_during_init=False).sample(2)
+
+
+def test_fabmodel_contracts_without_gpu():
+    flow = fa.RealNVP(6, 2, 5)
+    target = fa.ManyWellEnergy(6, use_gpu=False)
+    with pytest.raises(Exception, match="transition operator must be provided"):
+        fa.FABModel(flow, target, 4)
+    hmc = fa.HamiltonianMonteCarlo(4, 6, flow.log_prob, target.log_prob, alpha=2.0, p_target=True)
+    model = fa.FABModel(flow, target, 4, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
+    ais = model.annealed_importance_sampler
+    assert ais.p_target is False and hmc.p_target is False and ais.n_intermediate_distributions == 4
+    model.set_ais_target(min_is_target=False)
+    assert ais.p_target is True and hmc.p_target is True
+    model.set_ais_target(min_is_target=True)
+    assert ais.p_target is False and hmc.p_target is False
+    assert list(model.parameters())[0] is list(flow.parameters())[0]
+    assert model.get_iter_info() == {}
+    x = torch.randn(8, 6)
+    loss = model.forward_kl(x)                                                # differentiable torch expression on CPU
+    loss.backward()
+    assert torch.isfinite(loss) and flow._nf_model.q0.loc.grad is not None
+
+
+def test_fabmodel_save_load_roundtrip(tmp_path):
+    flow = fa.RealNVP(6, 2, 5)
+    target = fa.ManyWellEnergy(6, use_gpu=False)
+    hmc = fa.HamiltonianMonteCarlo(4, 6, flow.log_prob, target.log_prob, alpha=2.0)
+    model = fa.FABModel(flow, target, 4, transition_operator=hmc)
+    with torch.no_grad():
+        hmc.epsilons.mul_(0.3); flow._nf_model.q0.loc.add_(1.5)
+    path = str(tmp_path / "model.pt")
+    model.save(path)
+    ckpt = torch.load(path)
+    assert set(ckpt) == {"flow", "trans_op"} and set(ckpt["trans_op"]) == {"common_epsilon", "epsilons", "mass_vector"}
+    flow2 = fa.RealNVP(6, 2, 5)
+    hmc2 = fa.HamiltonianMonteCarlo(4, 6, flow2.log_prob, target.log_prob, alpha=2.0)
+    model2 = fa.FABModel(flow2, target, 4, transition_operator=hmc2)
+    model2.load(path)
+    assert torch.equal(hmc2.epsilons, hmc.epsilons) and torch.equal(flow2._nf_model.q0.loc, flow._nf_model.q0.loc)
+    assert model2.annealed_importance_sampler.transition_operator is hmc2
