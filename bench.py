@@ -144,25 +144,42 @@ def main():
     roof = None
     if rank == 0:
         from fab_torch_amd.transition_operators import create_point
-        x0, _ = flow.native_sample(torch.randn(B_PER_GPU, D, device=dev))
-        pt = create_point(x0, flow, target, with_grad=True)
         hmc.set_eval_mode(True)
-        for _ in range(3):
-            hmc.transition(pt, 4, float(ais.B_space[4]))
-        n_t = 10
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_t + 1)]
-        ev[0].record()
-        for i in range(n_t):
-            hmc.transition(pt, 4, float(ais.B_space[4]))
-            ev[i + 1].record()
-        torch.cuda.synchronize()
-        ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n_t))
-        t_kernel = ms[n_t // 2] * 1e-3
+
+        def time_transition(n_chains, n_t=10):
+            x0, _ = flow.native_sample(torch.randn(n_chains, D, device=dev))
+            pt = create_point(x0, flow, target, with_grad=True)
+            for _ in range(3):
+                hmc.transition(pt, 4, float(ais.B_space[4]))
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_t + 1)]
+            ev[0].record()                                  # torch's current stream == the stream handed to the C ABI
+            for i in range(n_t):
+                hmc.transition(pt, 4, float(ais.B_space[4]))
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n_t))
+            return ms[n_t // 2] * 1e-3
+
+        t_kernel = time_transition(B_PER_GPU)
         flop = B_PER_GPU * L * 2 * F_FWD                  # flow fwd + d/dx per leapfrog (target flops ignored)
         ach = flop / t_kernel / 1e12
+        n_wg = (B_PER_GPU + 15) // 16                     # 16 chains per workgroup, one workgroup per CU
         roof = {"bound": "mfma", "kernel": "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)", "achieved": ach,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None, "ms_per_launch": t_kernel * 1e3, "flop_per_launch": flop}
+                "traffic": None, "ms_per_launch": t_kernel * 1e3, "flop_per_launch": flop,
+                "workgroups": n_wg, "frac_of_occupied_cus": ach / (PEAK_FP32_MFMA_TFLOPS * min(n_wg, 256) / 256)}
+        # HBM traffic per launch: separate rocprofv3 --pmc passes of tools/prof_hmc.py (same kernel, same shape),
+        # summarised by tools/pmc_summary.py and committed; not collectable from inside this process.
+        pmc = os.path.join(ROOT, "profiles", "r1", "hmc_step_pmc_summary.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
+            roof["traffic_source"] = "profiles/r1/hmc_step_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+        # the headline workload fills 64 of 256 CUs; the same kernel with one workgroup per CU (4096 chains):
+        t_full = time_transition(4096)
+        ach_full = 4096 * L * 2 * F_FWD / t_full / 1e12
+        roof["full_chip"] = {"chains": 4096, "ms_per_launch": t_full * 1e3, "achieved": ach_full,
+                             "frac": ach_full / PEAK_FP32_MFMA_TFLOPS}
         hmc.set_eval_mode(False)
 
     if rank == 0:

@@ -124,9 +124,7 @@ def _declare(lib):
     lib.fabhip_gather_rows.argtypes = [vp, vp, vp, i64, i64, vp]
     lib.fabhip_debug_timeline.argtypes = [vp, i32]
     for name in SYMBOLS:
-        fn = getattr(lib, name)
-        if fn.restype is C.c_int and name not in ("fabhip_version",):
-            pass
+        getattr(lib, name)                     # AttributeError here = header and library disagree
     return lib
 
 
