@@ -275,10 +275,10 @@ __device__ __forceinline__ float part_sum(const float* part, int PN, int row, in
 // ReLU sign pattern of this lane's 4*NTWM outputs is kept as one 32-bit word per thread (bit 4 i + r) for the
 // reverse sweep: the same lane of the same wave owns the same (tile, register) there, so no cross-lane
 // exchange and a single LDS store per GEMM.
-template <int NTWM, int DEPTH, bool MASKK, bool MASK>
+template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                            const float* __restrict__ bias, float* OUT, int ldo, unsigned* mask,
-                                           const Tid& t) {
+                                           const Tid& t, float* __restrict__ gout = nullptr, int ldg = 0) {
     f32x4 acc[NTWM];
     WRing<NTWM, DEPTH> w;
     ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
@@ -291,7 +291,9 @@ __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, in
         for (int r = 0; r < 4; ++r) {
             const float v = acc[i][r];
             const bool pos = v > 0.f;
-            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? v : 0.f;
+            const float o = pos ? v : 0.f;
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
+            if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;       // training tape (HBM)
             if (MASK) m |= (pos ? 1u : 0u) << (4 * i + r);
         }
     }
@@ -299,9 +301,10 @@ __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, in
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
-template <int NTWM, int DEPTH>
+template <int NTWM, int DEPTH, bool TAPE = false>
 __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, const float4* Bp, float* OUT,
-                                             int ldo, const unsigned* mask, const Tid& t) {
+                                             int ldo, const unsigned* mask, const Tid& t,
+                                             float* __restrict__ gout = nullptr, int ldg = 0) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -315,7 +318,9 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const bool pos = (m >> (4 * i + r)) & 1u;
-            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = pos ? acc[i][r] : 0.f;
+            const float o = pos ? acc[i][r] : 0.f;
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
+            if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
         }
     }
 }
@@ -340,9 +345,21 @@ __device__ __forceinline__ void dense_small(const float* A, int lda, int kmax, i
 // is left in the state buffer whose LDS offset is returned through *grad_off.
 // normflows NormalizingFlow.log_prob: inverses in reversed layer order, log-dets added, base last.
 // ------------------------------------------------------------------------------------------------
-template <int NTWM, bool GRAD>
+// copy a 16 x w block of an LDS matrix (leading dim ld) to the tape rows of this tile (coalesced)
+__device__ __forceinline__ void tape_copy(float* __restrict__ dst, int w, const float* src, int ld, const Tid& t) {
+    for (int e = t.tid; e < ROWS * w; e += NTHREADS) {
+        const int r = e / w, j = e - r * w;
+        dst[(long)r * w + j] = src[r * ld + j];
+    }
+}
+
+// With TAPE (requires GRAD) the quantities the parameter-gradient GEMMs need are also written to `tape`
+// (TapeDims layout, rows row0 .. row0+15): see fabhip_common.h.
+template <int NTWM, bool GRAD, bool TAPE = false>
 __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const float* __restrict__ packed,
-                                    float* lds, const Tid& t, int* grad_off) {
+                                    float* lds, const Tid& t, int* grad_off, const TapeDims* td = nullptr,
+                                    float* __restrict__ tape = nullptr, long row0 = 0) {
+    static_assert(!TAPE || GRAD, "the tape is written by the forward + reverse sweep");
     constexpr int DW = depth_w<NTWM>();
     int cur = l.o_U0, nxt = l.o_U1;
     float logq = 0.f;
@@ -357,6 +374,8 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
         const bool tl = (layer == f.K - 2);
         if (tl) FAB_TL(f, 0);
+        float* tl_layer = TAPE ? tape + (size_t)layer * td->layer_stride : nullptr;
+        if (TAPE) tape_copy(tl_layer + td->o_ZA + row0 * td->wz, td->wz, lds + cur, l.DS, t);
         // ---- InvertibleAffine.inverse: z <- z @ (P L U), log_det = +sum(log_S) --------------------------
         dense_small(lds + cur, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AW), f.NTD, lds + nxt,
                     l.DS, t);
@@ -365,12 +384,27 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         __syncthreads();
         if (tl) FAB_TL(f, 2);
         float* Z = lds + nxt;
+        if (TAPE) {                                   // z1 | ones column, and the ones columns of H1 / H2
+            float* Z1 = tl_layer + td->o_Z1 + row0 * td->w1;
+            const int w1 = td->w1, c1 = w1 - 16;
+            for (int e = t.tid; e < ROWS * w1; e += NTHREADS) {
+                const int r = e / w1, j = e - r * w1;
+                Z1[(long)r * w1 + j] = j < f.d ? Z[r * l.DS + j] : (j == c1 ? 1.f : 0.f);
+            }
+            const int r = t.tid >> 4, j = t.tid & 15;
+            const float one = j == 0 ? 1.f : 0.f;
+            tl_layer[td->o_H1 + (row0 + r) * td->wh + f.Wp + j] = one;
+            tl_layer[td->o_H2 + (row0 + r) * td->wh + f.Wp + j] = one;
+        }
         // ---- conditioner MLP: relu(relu(z1 W1 + b1) W2 + b2) W3' ----------------------------------------
-        dense_relu<NTWM, 2, true, GRAD>(Z, l.DS, f.d, f.KBd, W1, Lp + f.o_b1, HA, l.WS, mk, t);
+        dense_relu<NTWM, 2, true, GRAD, TAPE>(Z, l.DS, f.d, f.KBd, W1, Lp + f.o_b1, HA, l.WS, mk, t,
+                                              TAPE ? tl_layer + td->o_H1 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
         if (tl) FAB_TL(f, 3);
         __syncthreads();
         if (tl) FAB_TL(f, 4);
-        dense_relu<NTWM, DW, false, GRAD>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t);
+        dense_relu<NTWM, DW, false, GRAD, TAPE>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
+                                                TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr,
+                                                TAPE ? td->wh : 0);
         if (tl) FAB_TL(f, 5);
         __syncthreads();
         if (tl) FAB_TL(f, 6);
@@ -407,6 +441,7 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         const float sc = expf(ls);
         const float zn = (Zc[t.row * l.DS + j] - base[j]) / sc;
         bsum += ls + 0.5f * (zn * zn);
+        if (TAPE) tape[td->o_zbase + (row0 + t.row) * td->wz + j] = Zc[t.row * l.DS + j];
         if (GRAD) Zc[t.row * l.DS + j] = -(zn / sc);      // d/dz of -0.5 ((z - loc)/sc)^2
     }
     logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
@@ -435,11 +470,15 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         __syncthreads();
         if (tl) FAB_TL(f, 18);
         const unsigned* mk = reinterpret_cast<const unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
-        dense_masked<NTWM, 2>(DP, l.PS, f.KBO, W3T, HA, l.WS, mk + NTHREADS, t);
+        float* tl_layer = TAPE ? tape + (size_t)layer * td->layer_stride : nullptr;
+        if (TAPE) tape_copy(tl_layer + td->o_DP + row0 * td->wp, td->wp, DP, l.PS, t);
+        dense_masked<NTWM, 2, TAPE>(DP, l.PS, f.KBO, W3T, HA, l.WS, mk + NTHREADS, t,
+                                    TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0);
         if (tl) FAB_TL(f, 19);
         __syncthreads();
         if (tl) FAB_TL(f, 20);
-        dense_masked<NTWM, DW>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t);
+        dense_masked<NTWM, DW, TAPE>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t,
+                                     TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0);
         if (tl) FAB_TL(f, 21);
         __syncthreads();
         if (tl) FAB_TL(f, 22);
@@ -451,6 +490,7 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (tl) FAB_TL(f, 25);
         __syncthreads();
         if (tl) FAB_TL(f, 26);
+        if (TAPE) tape_copy(tl_layer + td->o_GZ + row0 * td->wz, td->wz, G, l.DS, t);
         // ---- through InvertibleAffine.inverse: g <- g @ W^T -----------------------------------------------
         dense_small(G, l.DS, f.D, f.KBD, AWT, f.NTD, lds + nxt, l.DS, t);
         if (tl) FAB_TL(f, 27);

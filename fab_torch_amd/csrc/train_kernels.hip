@@ -1,0 +1,379 @@
+// Flow training path: log q(x) with a tape, and the parameter gradients sum_b coef[b] * d log q(x_b) / d theta
+// (the backward of `flow.log_prob(x)` in fab/train_with_prioritised_buffer.py:162-177 and
+// fab/core.py:112-118, where coef = d loss / d log_q).
+//
+//   k_flow_log_prob_tape   forward + reverse sweep of the 16-chain tile kernel (flow_device.h, TAPE = true):
+//                          layer inputs / hidden activations / back-propagated deltas go to HBM once
+//   k_param_grad           every weight / bias gradient as a batch-reduction GEMM  C[p][q] = sum_b c_b Y[b][p] X[b][q]
+//                          on the matrix cores (v_mfma_f32_16x16x4_f32, 64 x 64 block per workgroup, LDS double
+//                          buffered, fixed summation order => deterministic), written straight into the flat
+//                          gradient image in the parameters' own (PyTorch [out][in]) layouts
+//   k_small_grads          InvertibleAffine: dW -> (dL, dU, dlog_S) through W = P (tril(L,-1)+I)(triu(U,1)+diag(s e^logS));
+//                          DiagGaussian: dloc, dlog_scale
+#include "flow_device.h"
+#include "launch.h"
+
+namespace fab {
+
+// ---- flat gradient image: per layer [w1 | b1 | w2 | b2 | w3 | b3 | L | U | log_S], then loc, log_scale ----------
+struct GradLayout {
+    long layer_stride, w1, b1, w2, b2, w3, b3, L, U, logS, loc, log_scale, total;
+};
+
+FAB_HD GradLayout make_grad_layout(const FlowDims& f) {
+    GradLayout g;
+    long o = 0;
+    g.w1 = o; o += (long)f.W * f.d;
+    g.b1 = o; o += f.W;
+    g.w2 = o; o += (long)f.W * f.W;
+    g.b2 = o; o += f.W;
+    g.w3 = o; o += (long)2 * f.DO * f.W;
+    g.b3 = o; o += 2 * f.DO;
+    g.L = o; o += (long)f.D * f.D;
+    g.U = o; o += (long)f.D * f.D;
+    g.logS = o; o += f.D;
+    g.layer_stride = o;
+    g.loc = (long)f.K * o;
+    g.log_scale = g.loc + f.D;
+    g.total = g.log_scale + f.D;
+    return g;
+}
+
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape(FlowDims f, FlowLds l, TapeDims td,
+                                                                 const float* __restrict__ packed,
+                                                                 const float* __restrict__ x,
+                                                                 float* __restrict__ log_q, float* __restrict__ grad,
+                                                                 float* __restrict__ tape, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    const long row0 = (long)blockIdx.x * ROWS;
+    for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) lds[l.o_DP + e] = 0.f;
+    for (int e = t.tid; e < ROWS * l.DS; e += NTHREADS) {
+        const int r = e / l.DS, j = e % l.DS;
+        const long g = row0 + r;
+        lds[l.o_U0 + e] = (j < f.D && g < B) ? x[g * f.D + j] : 0.f;
+        lds[l.o_U1 + e] = 0.f;
+    }
+    __syncthreads();
+    int goff = 0;
+    const float lq = flow_log_prob_tile<NTWM, true, true>(f, l, packed, lds, t, &goff, &td, tape, row0);
+    if (t.c == 0 && row0 + t.row < B) log_q[row0 + t.row] = lq;
+    if (grad) {
+        for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
+            const int r = e / f.D, j = e % f.D;
+            const long g = row0 + r;
+            if (g < B) grad[g * f.D + j] = lds[goff + r * l.DS + j];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch-reduction GEMMs.  One workgroup = one 64 x 64 block of one (layer, matrix); wave w owns rows
+// [16 w, 16 w + 16) of the block and all four 16-column tiles.
+// ------------------------------------------------------------------------------------------------
+constexpr int GK = 32;          // batch rows per LDS chunk
+constexpr int GLD = 80;         // LDS leading dim: 80 mod 64 = 16 -> the 4 k-groups of a wave hit disjoint banks
+
+struct GemmBlocks {
+    int n1, n2, n3, nA, per_layer;     // 64 x 64 blocks of G1 (dW1|db1), G2, G3, GA
+    int q1, q2, q3, qA;                // blocks along Q
+};
+
+FAB_HD GemmBlocks make_gemm_blocks(const FlowDims& f, const TapeDims& td) {
+    GemmBlocks g;
+    g.q1 = ceil_div(td.w1, 64); g.q2 = ceil_div(td.wh, 64); g.q3 = g.q2; g.qA = ceil_div(td.wz, 64);
+    g.n1 = ceil_div(td.we, 64) * g.q1;
+    g.n2 = ceil_div(td.we, 64) * g.q2;
+    g.n3 = ceil_div(td.wp, 64) * g.q3;
+    g.nA = ceil_div(td.wz, 64) * g.qA;
+    g.per_layer = g.n1 + g.n2 + g.n3 + g.nA;
+    return g;
+}
+
+__device__ __forceinline__ int prm_row(int p, int DO, int DOp) {      // packed [shift | scale] row -> interleaved row
+    if (p < DOp) return p < DO ? 2 * p : -1;
+    const int j = p - DOp;
+    return j < DO ? 2 * j + 1 : -1;
+}
+
+__global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, GemmBlocks gb, GradLayout gl,
+                                                    const float* __restrict__ tape, const float* __restrict__ coef,
+                                                    long B, float* __restrict__ grads, float* __restrict__ ga_ws) {
+    __shared__ __attribute__((aligned(16))) float Ys[2][GK * GLD];
+    __shared__ __attribute__((aligned(16))) float Xs[2][GK * GLD];
+    const int layer = blockIdx.x / gb.per_layer;
+    int b = blockIdx.x % gb.per_layer;
+    // largest problem first
+    int kind, qblocks;
+    if (b < gb.n2) { kind = 2; qblocks = gb.q2; }
+    else if ((b -= gb.n2) < gb.n1) { kind = 1; qblocks = gb.q1; }
+    else if ((b -= gb.n1) < gb.n3) { kind = 3; qblocks = gb.q3; }
+    else { b -= gb.n3; kind = 4; qblocks = gb.qA; }
+    const int p0 = 64 * (b / qblocks), q0 = 64 * (b % qblocks);
+    const float* Lt = tape + (size_t)layer * td.layer_stride;
+    const float *Y, *X;
+    int ldy, ldx, P, Q;
+    if (kind == 1) { Y = Lt + td.o_E1; ldy = P = td.we; X = Lt + td.o_Z1; ldx = Q = td.w1; }
+    else if (kind == 2) { Y = Lt + td.o_E2; ldy = P = td.we; X = Lt + td.o_H1; ldx = Q = td.wh; }
+    else if (kind == 3) { Y = Lt + td.o_DP; ldy = P = td.wp; X = Lt + td.o_H2; ldx = Q = td.wh; }
+    else { Y = Lt + td.o_ZA; ldy = P = td.wz; X = Lt + td.o_GZ; ldx = Q = td.wz; }
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kg = lane >> 4;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    const bool yok = p0 + lc < P, xok = q0 + lc < Q;
+    const bool pvalid = p0 + 16 * wave < P;
+    float4 ry[2], rx[2];
+    auto gload = [&](long k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long k = k0 + lr + 16 * h;
+            const bool in = k < td.Bp;
+            const float c = k < B ? coef[k] : 0.f;
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f), xv = y;
+            if (in && yok) y = *reinterpret_cast<const float4*>(Y + k * ldy + p0 + lc);
+            if (in && xok) xv = *reinterpret_cast<const float4*>(X + k * ldx + q0 + lc);
+            ry[h] = make_float4(y.x * c, y.y * c, y.z * c, y.w * c);
+            rx[h] = xv;
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&Ys[buf][(lr + 16 * h) * GLD + lc]) = ry[h];
+            *reinterpret_cast<float4*>(&Xs[buf][(lr + 16 * h) * GLD + lc]) = rx[h];
+        }
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nch = (int)((B + GK - 1) / GK);
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nch) gload((long)(ch + 1) * GK);
+        if (pvalid) {
+#pragma unroll
+            for (int s = 0; s < GK / 4; ++s) {
+                const float a = Ys[buf][(4 * s + kg) * GLD + 16 * wave + n];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = mfma4(a, Xs[buf][(4 * s + kg) * GLD + 16 * j + n], acc[j]);
+            }
+        }
+        if (ch + 1 < nch) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (!pvalid) return;
+    float* G = grads + (size_t)layer * gl.layer_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = q0 + 16 * j + n;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = p0 + 16 * wave + 4 * kg + r;
+            const float v = acc[j][r];
+            if (kind == 1) {
+                if (p < f.W) {
+                    if (q < f.d) G[gl.w1 + (long)p * f.d + q] = v;
+                    else if (q == td.w1 - 16) G[gl.b1 + p] = v;
+                }
+            } else if (kind == 2) {
+                if (p < f.W) {
+                    if (q < f.W) G[gl.w2 + (long)p * f.W + q] = v;
+                    else if (q == f.Wp) G[gl.b2 + p] = v;
+                }
+            } else if (kind == 3) {
+                const int row = prm_row(p, f.DO, f.DOp);
+                if (row >= 0) {
+                    if (q < f.W) G[gl.w3 + (long)row * f.W + q] = v;
+                    else if (q == f.Wp) G[gl.b3 + row] = v;
+                }
+            } else {
+                ga_ws[((size_t)layer * td.wz + p) * td.wz + q] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// blocks 0 .. K-1: InvertibleAffine layer `blockIdx.x`; block K: DiagGaussian base.
+// ------------------------------------------------------------------------------------------------
+struct AffineSrc {
+    const float *L, *U, *logS, *signS, *P;
+};
+
+__device__ float block_sum_256(float v, float* red) {             // deterministic tree, result to all threads
+    const int tid = threadIdx.x;
+    red[tid] = v;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) red[tid] += red[tid + s];
+        __syncthreads();
+    }
+    const float r = red[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void k_small_grads(FlowDims f, TapeDims td, GradLayout gl,
+                                                     const fabhip_flow_params* __restrict__ prm_dev_unused,
+                                                     AffineSrc src, int layer, const float* __restrict__ ga_ws,
+                                                     const float* __restrict__ tape, const float* __restrict__ packed,
+                                                     const float* __restrict__ coef, long B,
+                                                     float* __restrict__ grads) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    (void)prm_dev_unused;
+    const int tid = threadIdx.x, D = f.D;
+    float* red = sm;                    // [256]
+    if (layer >= 0) {
+        float* dW = red + 256;          // [D][D]
+        float* PL = dW + D * D;         // P @ Lm
+        float* Um = PL + D * D;
+        float* T = Um + D * D;          // dW @ Um^T
+        float cs = 0.f;
+        for (long k = tid; k < B; k += 256) cs += coef[k];
+        const float csum = block_sum_256(cs, red);
+        auto Lm = [&](int i, int j) -> float { return i == j ? 1.f : (i > j ? src.L[i * D + j] : 0.f); };
+        for (int e = tid; e < D * D; e += 256) {
+            const int i = e / D, j = e % D;
+            dW[e] = ga_ws[((size_t)layer * td.wz + i) * td.wz + j];
+            Um[e] = i == j ? src.signS[i] * expf(src.logS[i]) : (i < j ? src.U[e] : 0.f);
+            float s = 0.f;
+            for (int k = 0; k < D; ++k) s = fmaf(src.P[i * D + k], Lm(k, j), s);
+            PL[e] = s;
+        }
+        __syncthreads();
+        float* G = grads + (size_t)layer * gl.layer_stride;
+        for (int e = tid; e < D * D; e += 256) {
+            const int i = e / D, j = e % D;
+            float su = 0.f, st = 0.f;
+            for (int k = 0; k < D; ++k) {
+                su = fmaf(PL[k * D + i], dW[k * D + j], su);        // dUm = (P Lm)^T dW
+                st = fmaf(dW[i * D + k], Um[j * D + k], st);        // T = dW Um^T
+            }
+            T[e] = st;
+            G[gl.U + e] = i < j ? su : 0.f;
+            if (i == j) G[gl.logS + i] = su * Um[e] + csum;         // d/dlog_S of s e^{log_S} (+ the +sum(log_S) log-det)
+        }
+        __syncthreads();
+        for (int e = tid; e < D * D; e += 256) {
+            const int i = e / D, j = e % D;
+            float s = 0.f;
+            for (int k = 0; k < D; ++k) s = fmaf(src.P[k * D + i], T[k * D + j], s);   // dLm = P^T T
+            G[gl.L + e] = i > j ? s : 0.f;
+        }
+    } else {
+        // base: log p = const - sum_j (ls_j + 0.5 zn_j^2), zn = (z - loc) / e^{ls}
+        const float* base = packed + f.o_base;
+        const int j = tid & 63, g = tid >> 6;
+        float aloc = 0.f, als = 0.f;
+        if (j < D) {
+            const float loc = base[j], sc = expf(base[f.Dp + j]);
+            for (long k = g; k < B; k += 4) {
+                const float zn = (tape[td.o_zbase + k * td.wz + j] - loc) / sc;
+                const float c = coef[k];
+                aloc += c * (zn / sc);
+                als += c * (zn * zn - 1.f);
+            }
+        }
+        float* pa = sm + 256;            // [4][64] x 2
+        pa[g * 64 + j] = aloc;
+        pa[256 + g * 64 + j] = als;
+        __syncthreads();
+        if (tid < D) {
+            grads[gl.loc + tid] = (pa[tid] + pa[64 + tid]) + (pa[128 + tid] + pa[192 + tid]);
+            grads[gl.log_scale + tid] = (pa[256 + tid] + pa[320 + tid]) + (pa[384 + tid] + pa[448 + tid]);
+        }
+    }
+}
+
+template <int NTWM>
+static int launch_log_prob_tape(const FlowDims& f, const TapeDims& td, const float* packed, const float* x,
+                                float* log_q, float* grad, float* tape, long B, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
+    const FlowLds l = make_flow_lds(f, true);
+    const size_t bytes = (size_t)l.total * 4;
+    FAB_TRY(set_max_lds((const void*)k_flow_log_prob_tape<NTWM>, bytes));
+    hipLaunchKernelGGL((k_flow_log_prob_tape<NTWM>), grid, block, bytes, st, f, l, td, packed, x, log_q, grad, tape, B);
+    return check_launch();
+}
+
+static size_t tape_floats(const FlowDims& f, const TapeDims& td) {
+    return (size_t)td.total + (size_t)f.K * td.wz * td.wz;          // + the per-layer affine dW scratch
+}
+
+}  // namespace fab
+
+using namespace fab;
+
+extern "C" {
+
+int64_t fabhip_flow_grad_floats(int32_t dim, int32_t n_layers, int32_t width) {
+    if (check_flow_shape(dim, n_layers, width) != FABHIP_OK) return -1;
+    return (int64_t)make_grad_layout(make_flow_dims(dim, n_layers, width)).total;
+}
+
+int fabhip_flow_grad_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t* out13) {
+    if (!out13) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(dim, n_layers, width));
+    const GradLayout g = make_grad_layout(make_flow_dims(dim, n_layers, width));
+    const long v[13] = {g.layer_stride, g.w1, g.b1, g.w2, g.b2, g.w3, g.b3, g.L, g.U, g.logS, g.loc, g.log_scale,
+                        g.total};
+    for (int i = 0; i < 13; ++i) out13[i] = v[i];
+    return FABHIP_OK;
+}
+
+size_t fabhip_flow_tape_bytes(int32_t dim, int32_t n_layers, int32_t width, int64_t B) {
+    if (check_flow_shape(dim, n_layers, width) != FABHIP_OK || B < 0) return 0;
+    const FlowDims f = make_flow_dims(dim, n_layers, width);
+    return tape_floats(f, make_tape_dims(f, (long)B)) * sizeof(float);
+}
+
+int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                              void* tape, size_t tape_bytes, fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !x || !log_q || !tape || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
+    if (B == 0) return FABHIP_OK;
+    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    const TapeDims td = make_tape_dims(f, (long)B);
+    if (tape_bytes < tape_floats(f, td) * sizeof(float)) return FABHIP_ENOSPC;
+    FAB_DISPATCH_NTW(f, launch_log_prob_tape, f, td, flow->packed, x, log_q, grad_x, (float*)tape, (long)B,
+                     (hipStream_t)stream);
+}
+
+int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* flow, const void* tape,
+                           size_t tape_bytes, const float* coef, int64_t B, float* grads, fabhip_stream_t stream) {
+    if (!params || !flow || !flow->packed || !tape || !coef || !grads || B < 1) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
+    if (params->dim != flow->dim || params->n_layers != flow->n_layers || params->width != flow->width)
+        return FABHIP_EINVAL;
+    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    const TapeDims td = make_tape_dims(f, (long)B);
+    if (tape_bytes < tape_floats(f, td) * sizeof(float)) return FABHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    const GradLayout gl = make_grad_layout(f);
+    const GemmBlocks gb = make_gemm_blocks(f, td);
+    const float* tp = (const float*)tape;
+    float* ga = const_cast<float*>(tp) + td.total;
+    hipLaunchKernelGGL(k_param_grad, dim3((unsigned)(f.K * gb.per_layer)), dim3(256), 0, st, f, td, gb, gl, tp, coef,
+                       (long)B, grads, ga);
+    const size_t smem = (size_t)(256 + 4 * f.D * f.D) * 4 > (size_t)(256 + 512) * 4 ? (size_t)(256 + 4 * f.D * f.D) * 4
+                                                                                      : (size_t)(256 + 512) * 4;
+    FAB_TRY(set_max_lds((const void*)k_small_grads, smem));
+    for (int k = 0; k < f.K; ++k) {
+        if (!params->lu_L[k] || !params->lu_U[k] || !params->log_S[k] || !params->sign_S[k] || !params->perm_P[k])
+            return FABHIP_EINVAL;
+        const AffineSrc src{params->lu_L[k], params->lu_U[k], params->log_S[k], params->sign_S[k], params->perm_P[k]};
+        hipLaunchKernelGGL(k_small_grads, dim3(1), dim3(256), smem, st, f, td, gl, nullptr, src, k, ga, tp, flow->packed,
+                           coef, (long)B, grads);
+    }
+    const AffineSrc none{nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(k_small_grads, dim3(1), dim3(256), smem, st, f, td, gl, nullptr, none, -1, ga, tp, flow->packed,
+                       coef, (long)B, grads);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -39,7 +39,7 @@ def main():
     args = ap.parse_args()
     D, M, L, NB, alpha = 32, 4, 5, 8, 2.0
     torch.manual_seed(0)
-    flow = fa.make_wrapped_normflow_realnvp(D, n_flow_layers=10, layer_nodes_per_dim=10).to(DEV)
+    flow = fa.make_wrapped_normflow_realnvp(D, n_flow_layers=10, layer_nodes_per_dim=10, act_norm=False).to(DEV)
     target = fa.ManyWellEnergy(D)
     hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=alpha, p_target=False,
                                    epsilon=0.2, n_outer=1, L=L).to(DEV)
