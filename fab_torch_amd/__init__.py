@@ -13,6 +13,7 @@ from .numerical import effective_sample_size, ess_and_log_z
 from .core import FABModel
 from .buffer import PrioritisedReplayBuffer, sample_without_replacement
 from .train import PrioritisedBufferTrainer
+from .optim import FlatAdam
 from .resample import resample, multinomial_indices, systematic_indices, multinomial_torch_compat, gather_rows
 
 __all__ = [
@@ -20,5 +21,5 @@ __all__ = [
     "HamiltonianMonteCarlo", "Metropolis", "create_point", "AnnealedImportanceSampler", "LoggingInfo",
     "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
     "multinomial_torch_compat", "gather_rows", "FABModel", "PrioritisedReplayBuffer",
-    "sample_without_replacement", "PrioritisedBufferTrainer",
+    "sample_without_replacement", "PrioritisedBufferTrainer", "FlatAdam",
 ]

@@ -84,7 +84,9 @@ SYMBOLS = [
     "fabhip_metropolis_transition", "fabhip_ais_workspace_bytes", "fabhip_ais_run", "fabhip_ess_workspace_bytes",
     "fabhip_ess_logz", "fabhip_multinomial_torch_workspace_bytes", "fabhip_multinomial_torch",
     "fabhip_resample_workspace_bytes", "fabhip_resample_multinomial", "fabhip_resample_systematic",
-    "fabhip_gather_rows", "fabhip_debug_timeline",
+    "fabhip_gather_rows", "fabhip_debug_timeline", "fabhip_flow_grad_floats", "fabhip_flow_grad_layout",
+    "fabhip_flow_tape_bytes", "fabhip_flow_log_prob_tape", "fabhip_flow_param_grad",
+    "fabhip_adam_workspace_bytes", "fabhip_adam_clip_step",
 ]
 
 
@@ -123,8 +125,19 @@ def _declare(lib):
     lib.fabhip_resample_systematic.argtypes = [vp, i64, dbl, i64, vp, vp, sz, vp]
     lib.fabhip_gather_rows.argtypes = [vp, vp, vp, i64, i64, vp]
     lib.fabhip_debug_timeline.argtypes = [vp, i32]
+    lib.fabhip_flow_grad_floats.restype = i64
+    lib.fabhip_flow_grad_floats.argtypes = [i32, i32, i32]
+    lib.fabhip_flow_grad_layout.argtypes = [i32, i32, i32, C.POINTER(i64)]
+    lib.fabhip_flow_tape_bytes.restype = sz
+    lib.fabhip_flow_tape_bytes.argtypes = [i32, i32, i32, i64]
+    lib.fabhip_flow_log_prob_tape.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp, sz, vp]
+    lib.fabhip_flow_param_grad.argtypes = [C.POINTER(FlowParams), C.POINTER(Flow), vp, sz, vp, i64, vp, vp]
+    lib.fabhip_adam_workspace_bytes.restype = sz
+    lib.fabhip_adam_workspace_bytes.argtypes = [i64]
+    f32 = C.c_float
+    lib.fabhip_adam_clip_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp, vp, sz, vp]
     for name in SYMBOLS:
-        getattr(lib, name)                     # AttributeError here = header and library disagree
+        getattr(lib, name)                    # AttributeError here = header and library disagree
     return lib
 
 

@@ -74,11 +74,14 @@ class PrioritisedReplayBuffer:
 
     @torch.no_grad()
     def adjust(self, log_w_adjustment, log_q, indices):
-        valid = torch.isfinite(log_w_adjustment) & torch.isfinite(log_q)
-        vi = indices[valid].to(self.device)
-        self.buffer.log_w[vi] += log_w_adjustment[valid].to(self.device)
-        self.buffer.log_q_old[vi] = log_q[valid].to(self.device)
-        self.buffer.log_w[indices[~valid].to(self.device)] = -float("inf")
+        # same result as the reference's three masked index_puts (:117-131), written without boolean-mask
+        # indexing so that no host synchronisation happens inside the minibatch loop
+        indices = indices.to(self.device)
+        adj, log_q = log_w_adjustment.to(self.device), log_q.to(self.device)
+        valid = torch.isfinite(adj) & torch.isfinite(log_q)
+        neg_inf = torch.full_like(adj, -float("inf"))
+        self.buffer.log_w[indices] = torch.where(valid, self.buffer.log_w[indices] + adj, neg_inf)
+        self.buffer.log_q_old[indices] = torch.where(valid, log_q, self.buffer.log_q_old[indices])
 
     def save(self, path):
         torch.save({'x': self.buffer.x.detach().cpu(), 'log_w': self.buffer.log_w.detach().cpu(),

@@ -109,15 +109,17 @@ FAB_HD FlowLds make_flow_lds(const FlowDims& f, bool with_grad) {
 // more output column of the same GEMM.  All widths are multiples of 16 floats (64-byte rows).
 struct TapeDims {
     long Bp;
-    int wz, w1, wh, wp, we;     // ZA/GZ/zbase: 16 NTD | Z1: 16 NTd + 16 | H1/H2: Wp + 16 | DP: 2 DOp | E1/E2: Wp
+    int wz, w1, wh, wp, we, wb; // ZA/GZ: 16 NTD | Z1: 16 NTd + 16 | H1/H2: Wp + 16 | DP: 2 DOp | E1/E2: Wp | TB: 2 wz + 16
     long o_ZA, o_GZ, o_Z1, o_H1, o_H2, o_DP, o_E2, o_E1;     // offsets inside one layer block (floats)
-    long layer_stride, o_zbase, total;
+    // TB (after the layer blocks): [zn / sc | zn^2 - 1 | ones] of the base distribution, zn = (z - loc) / sc
+    long layer_stride, o_TB, total;
 };
 
 FAB_HD TapeDims make_tape_dims(const FlowDims& f, long B) {
     TapeDims t;
     t.Bp = (B + ROWS - 1) / ROWS * ROWS;
     t.wz = 16 * f.NTD; t.w1 = 16 * f.NTd + 16; t.wh = f.Wp + 16; t.wp = 2 * f.DOp; t.we = f.Wp;
+    t.wb = 2 * t.wz + 16;
     long o = 0;
     t.o_ZA = o; o += t.Bp * t.wz;
     t.o_GZ = o; o += t.Bp * t.wz;
@@ -128,8 +130,8 @@ FAB_HD TapeDims make_tape_dims(const FlowDims& f, long B) {
     t.o_E2 = o; o += t.Bp * t.we;
     t.o_E1 = o; o += t.Bp * t.we;
     t.layer_stride = o;
-    t.o_zbase = (long)f.K * t.layer_stride;
-    t.total = t.o_zbase + t.Bp * t.wz;
+    t.o_TB = (long)f.K * t.layer_stride;
+    t.total = t.o_TB + t.Bp * t.wb;
     return t;
 }
 

@@ -441,10 +441,15 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         const float sc = expf(ls);
         const float zn = (Zc[t.row * l.DS + j] - base[j]) / sc;
         bsum += ls + 0.5f * (zn * zn);
-        if (TAPE) tape[td->o_zbase + (row0 + t.row) * td->wz + j] = Zc[t.row * l.DS + j];
+        if (TAPE) {                                       // what d/dloc and d/dlog_scale reduce over the batch
+            float* TB = tape + td->o_TB + (row0 + t.row) * td->wb;
+            TB[j] = zn / sc;
+            TB[td->wz + j] = zn * zn - 1.f;
+        }
         if (GRAD) Zc[t.row * l.DS + j] = -(zn / sc);      // d/dz of -0.5 ((z - loc)/sc)^2
     }
     logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
+    if (TAPE) tape[td->o_TB + (row0 + t.row) * td->wb + 2 * td->wz + t.c] = t.c == 0 ? 1.f : 0.f;
     if (!GRAD) return logq;
 
     // ---- reverse sweep: g = d log q / d(state), layers 0 .. K-1 -----------------------------------

@@ -11,22 +11,43 @@ namespace fab {
 //   Winv = (fl32(inv64(Um)) @ fl32(inv64(Lm))) @ P^T
 // Triangular inverses by substitution in float64, one column per thread.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_affine_assemble(int D, const float* __restrict__ Lraw,
-                                                         const float* __restrict__ Uraw,
-                                                         const float* __restrict__ logS,
-                                                         const float* __restrict__ signS,
-                                                         const float* __restrict__ P, float* __restrict__ Wout,
-                                                         float* __restrict__ Winvout, float* __restrict__ logS_sum) {
+constexpr int LBATCH = 16;      // layers per launch (pointer tables travel as kernel arguments)
+struct AffineTab {
+    const float *L[LBATCH], *U[LBATCH], *logS[LBATCH], *signS[LBATCH], *P[LBATCH];
+};
+struct MlpTab {
+    const float *w1[LBATCH], *b1[LBATCH], *w2[LBATCH], *b2[LBATCH], *w3[LBATCH], *b3[LBATCH];
+};
+
+// workgroup y handles layer k0 + y: W / Winv to the scratch area of the packed image, sum(log_S) to the layer block
+__global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab tab, int k0, float* __restrict__ packed) {
+    const int D = f.D, layer = k0 + blockIdx.x;
+    const float* __restrict__ Lraw = tab.L[blockIdx.x];
+    const float* __restrict__ Uraw = tab.U[blockIdx.x];
+    const float* __restrict__ logS = tab.logS[blockIdx.x];
+    const float* __restrict__ signS = tab.signS[blockIdx.x];
+    const float* __restrict__ P = tab.P[blockIdx.x];
+    float* __restrict__ Wout = packed + f.o_scratch + (size_t)layer * 2 * D * D;
+    float* __restrict__ Winvout = Wout + D * D;
+    float* __restrict__ logS_sum = packed + (size_t)layer * f.layer_stride + f.o_logS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     double* Xd = reinterpret_cast<double*>(smem_raw);          // [D][D] fp64 scratch
     float* Li = reinterpret_cast<float*>(Xd + D * D);          // [D][D]
     float* Ui = Li + D * D;                                    // [D][D]
     float* T = reinterpret_cast<float*>(Xd);                   // aliases Xd once the inverses are cast
+    float* Ls = Ui + D * D;                                    // Lm, Um, P staged once (the loops below re-read them)
+    float* Us = Ls + D * D;
+    float* Ps = Us + D * D;
     const int tid = threadIdx.x;
-    auto Lm = [&](int i, int j) -> float { return i == j ? 1.f : (i > j ? Lraw[i * D + j] : 0.f); };
-    auto Um = [&](int i, int j) -> float {
-        return i == j ? signS[i] * expf(logS[i]) : (i < j ? Uraw[i * D + j] : 0.f);
-    };
+    for (int e = tid; e < D * D; e += blockDim.x) {
+        const int i = e / D, j = e % D;
+        Ls[e] = i == j ? 1.f : (i > j ? Lraw[e] : 0.f);
+        Us[e] = i == j ? signS[i] * expf(logS[i]) : (i < j ? Uraw[e] : 0.f);
+        Ps[e] = P[e];
+    }
+    __syncthreads();
+    auto Lm = [&](int i, int j) -> float { return Ls[i * D + j]; };
+    auto Um = [&](int i, int j) -> float { return Us[i * D + j]; };
     // inverse of unit-lower Lm, column j
     if (tid < D) {
         const int j = tid;
@@ -65,14 +86,14 @@ __global__ __launch_bounds__(256) void k_affine_assemble(int D, const float* __r
     for (int e = tid; e < D * D; e += blockDim.x) {           // Winv = T @ P^T
         const int i = e / D, j = e % D;
         float s = 0.f;
-        for (int k = 0; k < D; ++k) s = fmaf(T[i * D + k], P[j * D + k], s);
+        for (int k = 0; k < D; ++k) s = fmaf(T[i * D + k], Ps[j * D + k], s);
         Winvout[e] = s;
     }
     __syncthreads();
     for (int e = tid; e < D * D; e += blockDim.x) {           // Li <- P @ Lm
         const int i = e / D, j = e % D;
         float s = 0.f;
-        for (int k = 0; k < D; ++k) s = fmaf(P[i * D + k], Lm(k, j), s);
+        for (int k = 0; k < D; ++k) s = fmaf(Ps[i * D + k], Lm(k, j), s);
         Li[e] = s;
     }
     __syncthreads();
@@ -110,8 +131,12 @@ __device__ __forceinline__ int prm_orig(int p, int DO, int DOp) {
     return j < DO ? 2 * j + 1 : -1;
 }
 
-__global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, LayerSrc s, float* __restrict__ dst) {
+__global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed) {
     const int D = f.D, d = f.d, DO = f.DO, W = f.W;
+    const int y = blockIdx.y, layer = k0 + y;
+    float* __restrict__ dst = packed + (size_t)layer * f.layer_stride;
+    const float* Wm = packed + f.o_scratch + (size_t)layer * 2 * D * D;
+    const LayerSrc s{tab.w1[y], tab.b1[y], tab.w2[y], tab.b2[y], tab.w3[y], tab.b3[y], Wm, Wm + D * D};
     for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.o_logS; off += gridDim.x * blockDim.x) {
         float v = 0.f;
         int k, n;
@@ -274,20 +299,26 @@ int fabhip_flow_pack(const fabhip_flow_params* p, float* packed, fabhip_stream_t
     hipStream_t st = (hipStream_t)stream;
     const FlowDims f = make_flow_dims(p->dim, p->n_layers, p->width);
     const int D = f.D;
-    const size_t smem = (size_t)D * D * (8 + 4 + 4);
+    const size_t smem = (size_t)D * D * (8 + 4 * 5);
     FAB_TRY(set_max_lds((const void*)k_affine_assemble, smem));
-    for (int k = 0; k < f.K; ++k) {
+    for (int k = 0; k < f.K; ++k)
         if (!p->w1[k] || !p->b1[k] || !p->w2[k] || !p->b2[k] || !p->w3[k] || !p->b3[k] || !p->lu_L[k] ||
             !p->lu_U[k] || !p->log_S[k] || !p->sign_S[k] || !p->perm_P[k])
             return FABHIP_EINVAL;
-        float* Wm = packed + f.o_scratch + (size_t)k * 2 * D * D;
-        float* Wi = Wm + D * D;
-        float* layer = packed + (size_t)k * f.layer_stride;
-        hipLaunchKernelGGL(k_affine_assemble, dim3(1), dim3(256), smem, st, D, p->lu_L[k], p->lu_U[k], p->log_S[k],
-                           p->sign_S[k], p->perm_P[k], Wm, Wi, layer + f.o_logS);
-        LayerSrc s{p->w1[k], p->b1[k], p->w2[k], p->b2[k], p->w3[k], p->b3[k], Wm, Wi};
+    for (int k0 = 0; k0 < f.K; k0 += LBATCH) {             // all layers of a batch in one launch each
+        const int nl = f.K - k0 < LBATCH ? f.K - k0 : LBATCH;
+        AffineTab at;
+        MlpTab mt;
+        for (int y = 0; y < LBATCH; ++y) {
+            const int k = k0 + (y < nl ? y : 0);
+            at.L[y] = p->lu_L[k]; at.U[y] = p->lu_U[k]; at.logS[y] = p->log_S[k]; at.signS[y] = p->sign_S[k];
+            at.P[y] = p->perm_P[k];
+            mt.w1[y] = p->w1[k]; mt.b1[y] = p->b1[k]; mt.w2[y] = p->w2[k]; mt.b2[y] = p->b2[k];
+            mt.w3[y] = p->w3[k]; mt.b3[y] = p->b3[k];
+        }
+        hipLaunchKernelGGL(k_affine_assemble, dim3(nl), dim3(256), smem, st, f, at, k0, packed);
         const int nblk = ceil_div(f.o_logS, 256 * 4);
-        hipLaunchKernelGGL(k_pack_layer, dim3(nblk), dim3(256), 0, st, f, s, layer);
+        hipLaunchKernelGGL(k_pack_layer, dim3(nblk, nl), dim3(256), 0, st, f, mt, k0, packed);
     }
     hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();

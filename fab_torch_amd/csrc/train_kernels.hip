@@ -8,8 +8,8 @@
 //                          on the matrix cores (v_mfma_f32_16x16x4_f32, 64 x 64 block per workgroup, LDS double
 //                          buffered, fixed summation order => deterministic), written straight into the flat
 //                          gradient image in the parameters' own (PyTorch [out][in]) layouts
-//   k_small_grads          InvertibleAffine: dW -> (dL, dU, dlog_S) through W = P (tril(L,-1)+I)(triu(U,1)+diag(s e^logS));
-//                          DiagGaussian: dloc, dlog_scale
+//                          (the DiagGaussian's dloc / dlog_scale and sum(coef) are one more such GEMM against a ones column)
+//   k_affine_grads         InvertibleAffine: dW -> (dL, dU, dlog_S) through W = P (tril(L,-1)+I)(triu(U,1)+diag(s e^logS))
 #include "flow_device.h"
 #include "launch.h"
 
@@ -102,11 +102,12 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
                                                     long B, float* __restrict__ grads, float* __restrict__ ga_ws) {
     __shared__ __attribute__((aligned(16))) float Ys[2][GK * GLD];
     __shared__ __attribute__((aligned(16))) float Xs[2][GK * GLD];
-    const int layer = blockIdx.x / gb.per_layer;
+    int layer = blockIdx.x / gb.per_layer;
     int b = blockIdx.x % gb.per_layer;
-    // largest problem first
+    // largest problem first; the blocks after the K layers are the base distribution (kind 5)
     int kind, qblocks;
-    if (b < gb.n2) { kind = 2; qblocks = gb.q2; }
+    if (layer >= f.K) { b = blockIdx.x - f.K * gb.per_layer; layer = 0; kind = 5; qblocks = gb.q1; }
+    else if (b < gb.n2) { kind = 2; qblocks = gb.q2; }
     else if ((b -= gb.n2) < gb.n1) { kind = 1; qblocks = gb.q1; }
     else if ((b -= gb.n1) < gb.n3) { kind = 3; qblocks = gb.q3; }
     else { b -= gb.n3; kind = 4; qblocks = gb.qA; }
@@ -117,7 +118,8 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
     if (kind == 1) { Y = Lt + td.o_E1; ldy = P = td.we; X = Lt + td.o_Z1; ldx = Q = td.w1; }
     else if (kind == 2) { Y = Lt + td.o_E2; ldy = P = td.we; X = Lt + td.o_H1; ldx = Q = td.wh; }
     else if (kind == 3) { Y = Lt + td.o_DP; ldy = P = td.wp; X = Lt + td.o_H2; ldx = Q = td.wh; }
-    else { Y = Lt + td.o_ZA; ldy = P = td.wz; X = Lt + td.o_GZ; ldx = Q = td.wz; }
+    else if (kind == 4) { Y = Lt + td.o_ZA; ldy = P = td.wz; X = Lt + td.o_GZ; ldx = Q = td.wz; }
+    else { Y = tape + td.o_TB; ldy = P = td.wb; X = Lt + td.o_Z1; ldx = Q = td.w1; }   // x the ones column of Z1
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kg = lane >> 4;
     const int lr = tid >> 4, lc = (tid & 15) * 4;
@@ -191,8 +193,12 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
                     if (q < f.W) G[gl.w3 + (long)row * f.W + q] = v;
                     else if (q == f.Wp) G[gl.b3 + row] = v;
                 }
-            } else {
+            } else if (kind == 4) {
                 ga_ws[((size_t)layer * td.wz + p) * td.wz + q] = v;
+            } else if (q == td.w1 - 16) {                       // base: dloc | dlog_scale | sum(coef)
+                if (p < f.D) grads[gl.loc + p] = v;
+                else if (p >= td.wz && p < td.wz + f.D) grads[gl.log_scale + p - td.wz] = v;
+                else if (p == 2 * td.wz) ga_ws[(size_t)f.K * td.wz * td.wz] = v;
             }
         }
     }
@@ -201,92 +207,59 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
 // ------------------------------------------------------------------------------------------------
 // blocks 0 .. K-1: InvertibleAffine layer `blockIdx.x`; block K: DiagGaussian base.
 // ------------------------------------------------------------------------------------------------
+constexpr int LBATCH = 16;
 struct AffineSrc {
     const float *L, *U, *logS, *signS, *P;
 };
+struct AffineSrcTab {
+    const float *L[LBATCH], *U[LBATCH], *logS[LBATCH], *signS[LBATCH], *P[LBATCH];
+};
 
-__device__ float block_sum_256(float v, float* red) {             // deterministic tree, result to all threads
-    const int tid = threadIdx.x;
-    red[tid] = v;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-        if (tid < s) red[tid] += red[tid + s];
-        __syncthreads();
-    }
-    const float r = red[0];
-    __syncthreads();
-    return r;
-}
-
-__global__ __launch_bounds__(256) void k_small_grads(FlowDims f, TapeDims td, GradLayout gl,
-                                                     const fabhip_flow_params* __restrict__ prm_dev_unused,
-                                                     AffineSrc src, int layer, const float* __restrict__ ga_ws,
-                                                     const float* __restrict__ tape, const float* __restrict__ packed,
-                                                     const float* __restrict__ coef, long B,
-                                                     float* __restrict__ grads) {
+// one workgroup per InvertibleAffine layer: (dL, dU, dlog_S) from dW = ga_ws[layer]; everything staged in LDS
+__global__ __launch_bounds__(256) void k_affine_grads(FlowDims f, TapeDims td, GradLayout gl, AffineSrcTab tab,
+                                                      int k0, const float* __restrict__ ga_ws,
+                                                      float* __restrict__ grads) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    (void)prm_dev_unused;
-    const int tid = threadIdx.x, D = f.D;
-    float* red = sm;                    // [256]
-    if (layer >= 0) {
-        float* dW = red + 256;          // [D][D]
-        float* PL = dW + D * D;         // P @ Lm
-        float* Um = PL + D * D;
-        float* T = Um + D * D;          // dW @ Um^T
-        float cs = 0.f;
-        for (long k = tid; k < B; k += 256) cs += coef[k];
-        const float csum = block_sum_256(cs, red);
-        auto Lm = [&](int i, int j) -> float { return i == j ? 1.f : (i > j ? src.L[i * D + j] : 0.f); };
-        for (int e = tid; e < D * D; e += 256) {
-            const int i = e / D, j = e % D;
-            dW[e] = ga_ws[((size_t)layer * td.wz + i) * td.wz + j];
-            Um[e] = i == j ? src.signS[i] * expf(src.logS[i]) : (i < j ? src.U[e] : 0.f);
-            float s = 0.f;
-            for (int k = 0; k < D; ++k) s = fmaf(src.P[i * D + k], Lm(k, j), s);
-            PL[e] = s;
+    const int tid = threadIdx.x, D = f.D, DD = D * D;
+    const int y = blockIdx.x, layer = k0 + y;
+    const AffineSrc src{tab.L[y], tab.U[y], tab.logS[y], tab.signS[y], tab.P[y]};
+    float* dW = sm;                 // [D][D] each
+    float* Lm = dW + DD;
+    float* Um = Lm + DD;
+    float* Ps = Um + DD;
+    float* PL = Ps + DD;            // P @ Lm
+    float* T = PL + DD;             // dW @ Um^T
+    const float csum = ga_ws[(size_t)f.K * td.wz * td.wz];          // sum_b coef_b (k_param_grad, base block)
+    for (int e = tid; e < DD; e += 256) {
+        const int i = e / D, j = e - i * D;
+        dW[e] = ga_ws[((size_t)layer * td.wz + i) * td.wz + j];
+        Lm[e] = i == j ? 1.f : (i > j ? src.L[e] : 0.f);
+        Um[e] = i == j ? src.signS[i] * expf(src.logS[i]) : (i < j ? src.U[e] : 0.f);
+        Ps[e] = src.P[e];
+    }
+    __syncthreads();
+    for (int e = tid; e < DD; e += 256) {
+        const int i = e / D, j = e - i * D;
+        float s = 0.f, st = 0.f;
+        for (int k = 0; k < D; ++k) {
+            s = fmaf(Ps[i * D + k], Lm[k * D + j], s);
+            st = fmaf(dW[i * D + k], Um[j * D + k], st);            // T = dW Um^T
         }
-        __syncthreads();
-        float* G = grads + (size_t)layer * gl.layer_stride;
-        for (int e = tid; e < D * D; e += 256) {
-            const int i = e / D, j = e % D;
-            float su = 0.f, st = 0.f;
-            for (int k = 0; k < D; ++k) {
-                su = fmaf(PL[k * D + i], dW[k * D + j], su);        // dUm = (P Lm)^T dW
-                st = fmaf(dW[i * D + k], Um[j * D + k], st);        // T = dW Um^T
-            }
-            T[e] = st;
-            G[gl.U + e] = i < j ? su : 0.f;
-            if (i == j) G[gl.logS + i] = su * Um[e] + csum;         // d/dlog_S of s e^{log_S} (+ the +sum(log_S) log-det)
+        PL[e] = s;
+        T[e] = st;
+    }
+    __syncthreads();
+    float* G = grads + (size_t)layer * gl.layer_stride;
+    for (int e = tid; e < DD; e += 256) {
+        const int i = e / D, j = e - i * D;
+        float su = 0.f, sl = 0.f;
+        for (int k = 0; k < D; ++k) {
+            su = fmaf(PL[k * D + i], dW[k * D + j], su);            // dUm = (P Lm)^T dW
+            sl = fmaf(Ps[k * D + i], T[k * D + j], sl);             // dLm = P^T (dW Um^T)
         }
-        __syncthreads();
-        for (int e = tid; e < D * D; e += 256) {
-            const int i = e / D, j = e % D;
-            float s = 0.f;
-            for (int k = 0; k < D; ++k) s = fmaf(src.P[k * D + i], T[k * D + j], s);   // dLm = P^T T
-            G[gl.L + e] = i > j ? s : 0.f;
-        }
-    } else {
-        // base: log p = const - sum_j (ls_j + 0.5 zn_j^2), zn = (z - loc) / e^{ls}
-        const float* base = packed + f.o_base;
-        const int j = tid & 63, g = tid >> 6;
-        float aloc = 0.f, als = 0.f;
-        if (j < D) {
-            const float loc = base[j], sc = expf(base[f.Dp + j]);
-            for (long k = g; k < B; k += 4) {
-                const float zn = (tape[td.o_zbase + k * td.wz + j] - loc) / sc;
-                const float c = coef[k];
-                aloc += c * (zn / sc);
-                als += c * (zn * zn - 1.f);
-            }
-        }
-        float* pa = sm + 256;            // [4][64] x 2
-        pa[g * 64 + j] = aloc;
-        pa[256 + g * 64 + j] = als;
-        __syncthreads();
-        if (tid < D) {
-            grads[gl.loc + tid] = (pa[tid] + pa[64 + tid]) + (pa[128 + tid] + pa[192 + tid]);
-            grads[gl.log_scale + tid] = (pa[256 + tid] + pa[320 + tid]) + (pa[384 + tid] + pa[448 + tid]);
-        }
+        G[gl.U + e] = i < j ? su : 0.f;
+        G[gl.L + e] = i > j ? sl : 0.f;
+        if (i == j) G[gl.logS + i] = su * Um[e] + csum;             // d/dlog_S of s e^{log_S} (+ the +sum(log_S) log-det)
     }
 }
 
@@ -302,7 +275,7 @@ static int launch_log_prob_tape(const FlowDims& f, const TapeDims& td, const flo
 }
 
 static size_t tape_floats(const FlowDims& f, const TapeDims& td) {
-    return (size_t)td.total + (size_t)f.K * td.wz * td.wz;          // + the per-layer affine dW scratch
+    return (size_t)td.total + (size_t)f.K * td.wz * td.wz + 16;     // + per-layer affine dW scratch + sum(coef)
 }
 
 }  // namespace fab
@@ -358,22 +331,129 @@ int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* 
     const GemmBlocks gb = make_gemm_blocks(f, td);
     const float* tp = (const float*)tape;
     float* ga = const_cast<float*>(tp) + td.total;
-    hipLaunchKernelGGL(k_param_grad, dim3((unsigned)(f.K * gb.per_layer)), dim3(256), 0, st, f, td, gb, gl, tp, coef,
-                       (long)B, grads, ga);
-    const size_t smem = (size_t)(256 + 4 * f.D * f.D) * 4 > (size_t)(256 + 512) * 4 ? (size_t)(256 + 4 * f.D * f.D) * 4
-                                                                                      : (size_t)(256 + 512) * 4;
-    FAB_TRY(set_max_lds((const void*)k_small_grads, smem));
-    for (int k = 0; k < f.K; ++k) {
+    const int nbase = ceil_div(td.wb, 64) * gb.q1;               // base-distribution blocks after the K layers
+    hipLaunchKernelGGL(k_param_grad, dim3((unsigned)(f.K * gb.per_layer + nbase)), dim3(256), 0, st, f, td, gb, gl,
+                       tp, coef, (long)B, grads, ga);
+    const size_t smem = (size_t)6 * f.D * f.D * 4;
+    FAB_TRY(set_max_lds((const void*)k_affine_grads, smem));
+    for (int k = 0; k < f.K; ++k)
         if (!params->lu_L[k] || !params->lu_U[k] || !params->log_S[k] || !params->sign_S[k] || !params->perm_P[k])
             return FABHIP_EINVAL;
-        const AffineSrc src{params->lu_L[k], params->lu_U[k], params->log_S[k], params->sign_S[k], params->perm_P[k]};
-        hipLaunchKernelGGL(k_small_grads, dim3(1), dim3(256), smem, st, f, td, gl, nullptr, src, k, ga, tp, flow->packed,
-                           coef, (long)B, grads);
+    for (int k0 = 0; k0 < f.K; k0 += LBATCH) {
+        const int nl = f.K - k0 < LBATCH ? f.K - k0 : LBATCH;
+        AffineSrcTab tab;
+        for (int y = 0; y < LBATCH; ++y) {
+            const int k = k0 + (y < nl ? y : 0);
+            tab.L[y] = params->lu_L[k]; tab.U[y] = params->lu_U[k]; tab.logS[y] = params->log_S[k];
+            tab.signS[y] = params->sign_S[k]; tab.P[y] = params->perm_P[k];
+        }
+        hipLaunchKernelGGL(k_affine_grads, dim3(nl), dim3(256), smem, st, f, td, gl, tab, k0, ga, grads);
     }
-    const AffineSrc none{nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL(k_small_grads, dim3(1), dim3(256), smem, st, f, td, gl, nullptr, none, -1, ga, tp, flow->packed,
-                       coef, (long)B, grads);
     return check_launch();
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Optimiser step on the flat parameter image: global-norm gradient clipping
+// (torch.nn.utils.clip_grad_norm_, fab/train_with_prioritised_buffer.py:174) + Adam
+// (torch.optim.Adam single-tensor formulas) in two launches, no host synchronisation: a non-finite
+// gradient norm skips the update on the device (the reference skips it on the host, :175-179).
+// ------------------------------------------------------------------------------------------------
+namespace fab {
+
+constexpr int ADAM_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, long n, double* __restrict__ part) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    const long n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+        const float4 v = g4[i];
+        s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+    }
+    if (blockIdx.x == 0 && tid < (int)(n & 3)) { const float v = g[(n4 << 2) + tid]; s += (double)v * v; }
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) red[tid] += red[tid + k];
+        __syncthreads();
+    }
+    if (tid == 0) part[blockIdx.x] = red[0];
+}
+
+struct AdamK {
+    float lr, beta1, beta2, eps, max_norm;
+};
+
+__global__ __launch_bounds__(256) void k_adam_clip(float* __restrict__ theta, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, AdamK a,
+                                                   const double* __restrict__ part, int nparts,
+                                                   const int* __restrict__ step_count, float* __restrict__ norm_out) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    for (int i = tid; i < nparts; i += 256) s += part[i];
+    red[tid] = s;
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) red[tid] += red[tid + k];
+        __syncthreads();
+    }
+    const float total = (float)sqrt(red[0]);
+    if (blockIdx.x == 0 && tid == 0) *norm_out = total;
+    if (!isfinite(total)) return;                               // "nan grad norm": no step
+    float coef = 1.f;
+    if (a.max_norm > 0.f) { coef = a.max_norm / (total + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
+    // t = applied steps so far + 1 (a skipped step does not advance the bias correction, like the reference,
+    // which simply does not call optimizer.step()); bias corrections in double as torch computes them on the host
+    const double t = (double)(*step_count + 1);
+    const float step_size = (float)((double)a.lr / (1.0 - pow((double)a.beta1, t)));
+    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
+    for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = m[i] + (gi - m[i]) * (1.f - a.beta1);               // exp_avg.lerp_(grad, 1 - beta1)
+        const float vi = v[i] * a.beta2 + (1.f - a.beta2) * (gi * gi);       // mul_(beta2).addcmul_(g, g, 1 - beta2)
+        m[i] = mi;
+        v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+        theta[i] = theta[i] - step_size * (mi / denom);                      // addcdiv_(exp_avg, denom, -step_size)
+    }
+}
+
+__global__ void k_adam_commit(const float* __restrict__ norm, int* __restrict__ step_count) {
+    if (isfinite(*norm)) *step_count += 1;
+}
+
+}  // namespace fab
+
+extern "C" {
+
+size_t fabhip_adam_workspace_bytes(int64_t n) { (void)n; return (size_t)fab::ADAM_BLOCKS * sizeof(double) + 16; }
+
+int fabhip_adam_clip_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float eps, int32_t* step_count, float max_norm, float* grad_norm_out,
+                          void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!theta || !grad || !m || !v || n < 1 || !step_count || !workspace) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_adam_workspace_bytes(n)) return FABHIP_ENOSPC;
+    if (((uintptr_t)grad & 15) != 0) return FABHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    double* part = (double*)workspace;
+    const long per = 256 * 4;
+    int nb = (int)((n + per - 1) / per);
+    if (nb > fab::ADAM_BLOCKS) nb = fab::ADAM_BLOCKS;
+    hipLaunchKernelGGL(fab::k_sqnorm_partial, dim3(nb), dim3(256), 0, st, grad, (long)n, part);
+    fab::AdamK a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+    float* norm = grad_norm_out ? grad_norm_out : (float*)(part + fab::ADAM_BLOCKS);
+    int nb2 = (int)((n + 255) / 256);
+    if (nb2 > 2048) nb2 = 2048;
+    hipLaunchKernelGGL(fab::k_adam_clip, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
+                       (const int*)step_count, norm);
+    hipLaunchKernelGGL(fab::k_adam_commit, dim3(1), dim3(1), 0, st, (const float*)norm, (int*)step_count);
+    return fab::check_launch();
 }
 
 }  // extern "C"

@@ -10,7 +10,9 @@ in fab/wrappers/normflows.py:8-31 (`WrappedNormFlowModel`): same constructor mea
 Hot path (no autograd graph requested): `sample_and_log_prob`, `log_prob`, `log_prob_and_grad` run the
 fp32-MFMA kernels of csrc/flow_kernels.hip through the C ABI.  When autograd is recording w.r.t. the
 parameters (the trainer's `flow.log_prob(x)` + `loss.backward()`, fab/train_with_prioritised_buffer.py:162-173)
-the same arithmetic is expressed with differentiable PyTorch-ROCm ops on the GPU.
+`log_prob` runs the HIP forward with a tape and `backward` the parameter-gradient GEMM kernels of
+csrc/train_kernels.hip (`_LogProbWithTape`); `sample_and_log_prob` under autograd, and `train_path = "torch"`,
+use the same arithmetic expressed with differentiable PyTorch-ROCm ops on the GPU (the fp32 reference of the tests).
 """
 import ctypes as C
 import math
@@ -94,6 +96,50 @@ class _NormalizingFlow(nn.Module):
         self.flows = nn.ModuleList(flows)
 
 
+class _LogProbWithTape(torch.autograd.Function):
+    """log q(x) through fabhip_flow_log_prob_tape; backward = fabhip_flow_param_grad (one flat gradient image,
+    handed to autograd as views) and grad_output * d log q / dx.  Replaces the autograd graph the reference
+    builds for `flow.log_prob(x)` (fab/train_with_prioritised_buffer.py:162-173, fab/core.py:112-118)."""
+
+    @staticmethod
+    def forward(ctx, flow, x, *params):
+        lib = _lib.load()
+        _lib.require_device(x, "x")
+        f, packed = flow.native()
+        xd = x.detach().contiguous().float()
+        B = xd.shape[0]
+        log_q = torch.empty(B, dtype=torch.float32, device=xd.device)
+        grad_x = torch.empty_like(xd) if x.requires_grad else None
+        nbytes = lib.fabhip_flow_tape_bytes(flow.dim, flow.n_layers, flow.width, B)
+        tape = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=xd.device)
+        _lib.check(lib.fabhip_flow_log_prob_tape(C.byref(f), _lib.ptr(xd), _lib.ptr(log_q), _lib.ptr(grad_x), B,
+                                                 _lib.ptr(tape), nbytes, _lib.stream_ptr()), "flow_log_prob_tape")
+        ctx.flow, ctx.B, ctx.nbytes = flow, B, nbytes
+        ctx.key = flow._packed_key
+        ctx.save_for_backward(tape, grad_x if grad_x is not None else torch.empty(0, device=xd.device))
+        return log_q
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        flow = ctx.flow
+        tape, grad_x = ctx.saved_tensors
+        if flow._packed_key != ctx.key:
+            raise _lib.FabhipError("flow parameters were modified between log_prob(x) and backward()")
+        f, _ = flow.native()
+        coef = g.detach().contiguous().float()
+        n = lib.fabhip_flow_grad_floats(flow.dim, flow.n_layers, flow.width)
+        flat = torch.empty(n, dtype=torch.float32, device=coef.device)
+        _lib.check(lib.fabhip_flow_param_grad(C.byref(flow._params_struct), C.byref(f), _lib.ptr(tape), ctx.nbytes,
+                                              _lib.ptr(coef), ctx.B, _lib.ptr(flat), _lib.stream_ptr()),
+                   "flow_param_grad")
+        flow._last_flat_grad = flat
+        views = flow._grad_views(flat)
+        grads = [v if need else None for v, need in zip(views, ctx.needs_input_grad[2:])]
+        gx = coef[:, None] * grad_x if ctx.needs_input_grad[1] else None
+        return (None, gx, *grads)
+
+
 class RealNVP(nn.Module):
     """`make_wrapped_normflow_realnvp(dim, n_flow_layers, layer_nodes_per_dim, act_norm=False)`."""
 
@@ -108,6 +154,7 @@ class RealNVP(nn.Module):
         self._packed = None
         self._packed_key = None
         self._params_struct = None
+        self._grad_layout = None
 
     # ---- Distribution interface (fab/types_.py:8-27) ---------------------------------------------
     @property
@@ -128,8 +175,43 @@ class RealNVP(nn.Module):
 
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and (x.requires_grad or self._params_need_grad()):
+            if x.is_cuda and self.train_path == "hip":
+                return _LogProbWithTape.apply(self, x, *self._grad_tensors())
             return self._torch_log_prob(x)
         return self.native_log_prob(x)[0]
+
+    # ---- training path: HIP forward with a tape + parameter-gradient GEMMs (csrc/train_kernels.hip) -----
+    train_path = "hip"          # "torch": the differentiable PyTorch-ROCm expression below (reference for tests)
+
+    def _grad_tensors(self):
+        """Parameters in the order of the flat gradient image (fabhip_flow_grad_layout)."""
+        out = []
+        for l1, l2, l3, aff in self._layers():
+            out += [l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, aff.L, aff.U, aff.log_S]
+        q0 = self._nf_model.q0
+        return out + [q0.loc, q0.log_scale]
+
+    def _grad_views(self, flat: torch.Tensor):
+        """Views of the flat gradient image, one per tensor of `_grad_tensors()`."""
+        if self._grad_layout is None:
+            lay = (C.c_int64 * 13)()
+            _lib.check(_lib.load().fabhip_flow_grad_layout(self.dim, self.n_layers, self.width, lay), "grad_layout")
+            self._grad_layout = [int(v) for v in lay]
+        stride, w1, b1, w2, b2, w3, b3, oL, oU, oS, loc, lsc, _ = self._grad_layout
+        D, d, W = self.dim, self.d, self.width
+        shapes = [(w1, (W, d)), (b1, (W,)), (w2, (W, W)), (b2, (W,)), (w3, (2 * (D - d), W)), (b3, (2 * (D - d),)),
+                  (oL, (D, D)), (oU, (D, D)), (oS, (D,))]
+        views = []
+        for k in range(self.n_layers):
+            base = k * stride
+            for off, shp in shapes:
+                n = 1
+                for s in shp:
+                    n *= s
+                views.append(flat[base + off: base + off + n].view(shp))
+        views.append(flat[loc: loc + D].view(1, D))
+        views.append(flat[lsc: lsc + D].view(1, D))
+        return views
 
     # ---- native (HIP) entry points ------------------------------------------------------------------
     def _params_need_grad(self):
@@ -170,6 +252,7 @@ class RealNVP(nn.Module):
             p.loc, p.log_scale = q0.loc.data_ptr(), q0.log_scale.data_ptr()
             _lib.check(lib.fabhip_flow_pack(C.byref(p), _lib.ptr(self._packed), _lib.stream_ptr()), "flow_pack")
             self._packed_key = key
+            self._params_struct = p
         f = _lib.Flow(self.dim, self.n_layers, self.width, self._packed.data_ptr())
         return f, self._packed
 

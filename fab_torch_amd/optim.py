@@ -1,0 +1,96 @@
+"""FlatAdam — the trainer's `clip_grad_norm_` + `torch.optim.Adam.step()` pair
+(fab/train_with_prioritised_buffer.py:174-179) as two HIP launches on a flat parameter image.
+
+The flow's parameters are re-pointed (same `nn.Parameter` objects, same state-dict keys) into ONE contiguous
+float32 buffer laid out like the flat gradient image of `fabhip_flow_param_grad`; when the gradients of the step
+are that image (the usual case: one `flow.log_prob(x)` backward) the step reads it directly, otherwise the
+`.grad` tensors are concatenated first.  No host synchronisation: the gradient norm stays on the device and a
+non-finite norm skips the update inside the kernel."""
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from .flow import RealNVP
+
+
+class FlatAdam(torch.optim.Optimizer):
+    def __init__(self, flow: RealNVP, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+        self.flow = flow
+        self._params = flow._grad_tensors()
+        for p in self._params:
+            _lib.require_device(p, "RealNVP parameters (move the flow to the GPU before building FlatAdam)")
+        super().__init__(self._params, dict(lr=lr, betas=betas, eps=eps))
+        lib = _lib.load()
+        self.n = int(lib.fabhip_flow_grad_floats(flow.dim, flow.n_layers, flow.width))
+        dev = self._params[0].device
+        self.theta = torch.empty(self.n, dtype=torch.float32, device=dev)
+        views = flow._grad_views(self.theta)
+        with torch.no_grad():
+            for p, v in zip(self._params, views):
+                v.copy_(p.detach())
+                p.data = v                                   # the Parameter now lives inside theta
+        self._offsets = [v.data_ptr() - self.theta.data_ptr() for v in views]
+        self.m = torch.zeros_like(self.theta)
+        self.v = torch.zeros_like(self.theta)
+        self.steps = torch.zeros(1, dtype=torch.int32, device=dev)     # applied steps (device: skips happen there)
+        self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._ws = torch.empty(int(lib.fabhip_adam_workspace_bytes(self.n)), dtype=torch.uint8, device=dev)
+        flow._packed_key = None
+
+    def _check_alias(self):
+        base = self.theta.data_ptr()
+        for p, off in ((self._params[0], self._offsets[0]), (self._params[-1], self._offsets[-1])):
+            if p.data_ptr() != base + off:
+                raise _lib.FabhipError("the flow's parameters were re-allocated after FlatAdam was built "
+                                       "(e.g. by .to()/.cuda()); build the optimiser after moving the flow")
+
+    def _flat_grad(self) -> torch.Tensor:
+        """The flat gradient image if every .grad is (still) a view of one, else a concatenation."""
+        g0 = self._params[0].grad
+        if g0 is None:
+            raise _lib.FabhipError("FlatAdam.step(): parameters have no gradient")
+        base = g0.data_ptr() - self._offsets[0]
+        flat = getattr(self.flow, "_last_flat_grad", None)
+        if flat is not None and flat.data_ptr() == base and all(
+                p.grad is not None and p.grad.data_ptr() == base + off and p.grad.is_contiguous()
+                for p, off in zip(self._params, self._offsets)):
+            return flat
+        zero = None
+        parts = []
+        for p in self._params:
+            if p.grad is None:
+                zero = torch.zeros(1, device=self.theta.device) if zero is None else zero
+                parts.append(zero.expand(p.numel()))
+            else:
+                parts.append(p.grad.reshape(-1))
+        return torch.cat(parts).float().contiguous()
+
+    @torch.no_grad()
+    def step(self, closure=None, max_grad_norm: Optional[float] = None) -> torch.Tensor:
+        """Clip to `max_grad_norm` (None / inf: no clipping), then Adam.  Returns the gradient norm as a device
+        tensor (what clip_grad_norm_ returns); a non-finite norm leaves the parameters untouched."""
+        assert closure is None
+        self._check_alias()
+        g = self._flat_grad()
+        grp = self.param_groups[0]
+        mx = 0.0 if (max_grad_norm is None or max_grad_norm == float("inf")) else float(max_grad_norm)
+        lib = _lib.load()
+        _lib.check(lib.fabhip_adam_clip_step(_lib.ptr(self.theta), _lib.ptr(g), _lib.ptr(self.m), _lib.ptr(self.v),
+                                             self.n, float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
+                                             float(grp["eps"]), _lib.ptr(self.steps), mx, _lib.ptr(self.grad_norm),
+                                             _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "adam_clip_step")
+        self.flow._packed_key = None                          # parameters changed behind autograd's version counters
+        return self.grad_norm[0]
+
+    def state_dict(self):
+        return {"t": int(self.steps.item()), "m": self.m, "v": self.v, "param_groups": [{k: v for k, v in g.items() if k != "params"}
+                                                                        for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.steps.fill_(int(sd["t"]))
+        self.m.copy_(sd["m"])
+        self.v.copy_(sd["v"])
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)

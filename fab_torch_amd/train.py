@@ -9,6 +9,7 @@ import torch
 
 from .buffer import PrioritisedReplayBuffer
 from .core import FABModel
+from .optim import FlatAdam
 
 
 class PrioritisedBufferTrainer:
@@ -26,6 +27,7 @@ class PrioritisedBufferTrainer:
         self.w_adjust_in_buffer_after_update = w_adjust_in_buffer_after_update
         self.logger = logger
         self.history: List[Dict] = []
+        self._fused = isinstance(optimizer, FlatAdam)
 
     def step(self, i: int, batch_size: int) -> Dict:
         model, buf = self.model, self.buffer
@@ -43,7 +45,13 @@ class PrioritisedBufferTrainer:
             w_adjust = (torch.clip(w_adjust_pre_clip, max=self.max_adjust_w_clip)
                         if self.max_adjust_w_clip is not None else w_adjust_pre_clip)
             loss = - torch.mean(w_adjust * log_q_x)
-            if torch.isfinite(loss):
+            if self._fused:
+                # FlatAdam: clipping, the finite-norm check and Adam run on the device; a non-finite loss gives a
+                # non-finite gradient norm, which skips the update there (same outcome as the two host checks of
+                # the reference, :172-181, without synchronising every minibatch)
+                loss.backward()
+                grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm)
+            elif torch.isfinite(loss):
                 loss.backward()
                 grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), self.max_gradient_norm)
                 if torch.isfinite(grad_norm):

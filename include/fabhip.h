@@ -82,6 +82,38 @@ int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, 
                          fabhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Flow training path — the backward of `flow.log_prob(x)` w.r.t. the parameters, i.e. what
+ * `loss.backward()` does in fab/train_with_prioritised_buffer.py:162-177 (loss = -mean(w_adjust * log_q_x))
+ * and for fab/core.py:112-118 (fab_alpha_div_inner).  Two calls:
+ *   fabhip_flow_log_prob_tape : log_q (and optionally d log_q / dx) exactly as fabhip_flow_log_prob, plus a
+ *                               tape of per-layer activations / deltas in caller-owned device memory;
+ *   fabhip_flow_param_grad    : grads[theta] = sum_b coef[b] * d log_q(x_b) / d theta for every parameter,
+ *                               coef = d loss / d log_q (autograd's grad_output), written into one flat image:
+ *                               per layer [w1 | b1 | w2 | b2 | w3 | b3 | L | U | log_S] (each in the shape of
+ *                               the fabhip_flow_params tensor of that name), then loc, log_scale.
+ * fabhip_flow_grad_layout fills {layer_stride, w1, b1, w2, b2, w3, b3, L, U, log_S (offsets inside a layer
+ * block), loc, log_scale (absolute offsets), total}, all in floats.
+ * ---------------------------------------------------------------------------------------- */
+int64_t fabhip_flow_grad_floats(int32_t dim, int32_t n_layers, int32_t width);
+int fabhip_flow_grad_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t* out13);
+size_t fabhip_flow_tape_bytes(int32_t dim, int32_t n_layers, int32_t width, int64_t B);
+int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                              void* tape, size_t tape_bytes, fabhip_stream_t stream);
+int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* flow, const void* tape,
+                           size_t tape_bytes, const float* coef, int64_t B, float* grads, fabhip_stream_t stream);
+
+/* One optimiser step on a flat parameter image (the layout of fabhip_flow_grad_layout): global-norm clipping
+ * (torch.nn.utils.clip_grad_norm_(params, max_norm), fab/train_with_prioritised_buffer.py:174; max_norm <= 0 = off)
+ * followed by Adam (torch.optim.Adam defaults: no weight decay, no amsgrad).  The total gradient norm is written
+ * to grad_norm_out (device, may be NULL); when it is not finite nothing is updated — the reference's "nan grad
+ * norm" skip (:175-179) without a host round trip.  m, v: Adam moments, same length.  step_count: device int32,
+ * the number of applied steps so far (drives the bias correction); incremented here when the update is applied. */
+size_t fabhip_adam_workspace_bytes(int64_t n);
+int fabhip_adam_clip_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
+                          float beta2, float eps, int32_t* step_count, float max_norm, float* grad_norm_out,
+                          void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Targets (fab/target_distributions/many_well.py:81-90, double_well.py:44-58, gmm.py:57-66)
  * ---------------------------------------------------------------------------------------- */
 enum { FABHIP_TARGET_MANYWELL = 1, FABHIP_TARGET_GMM = 2 };

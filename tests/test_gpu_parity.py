@@ -70,6 +70,122 @@ def test_flow_log_prob_grad_sample_vs_oracle(D, K, nodes, B):
     assert lq_t.requires_grad and close(lq_t, lq_o, RTOL)
 
 
+def relu_kink_samples(nf, x, width, thr=2e-5):
+    """Rows of x for which some hidden pre-activation of the (fp64) oracle flow lies within thr of zero."""
+    import copy
+    nf64 = copy.deepcopy(nf).double()
+    near = torch.zeros(len(x), dtype=torch.bool)
+
+    def hook(mod, inp, out):
+        if out.shape[-1] == width:
+            near.__ior__((out.abs() < thr).any(dim=1))
+    hooks = [m.register_forward_hook(hook) for m in nf64.modules() if isinstance(m, torch.nn.Linear)]
+    with torch.no_grad():
+        nf64.log_prob(x.double())
+    for h in hooks:
+        h.remove()
+    return near
+
+
+def _param_grads(flow_module, params, x, coef, x_grad=False):
+    for p in params:
+        p.grad = None
+    xg = x.clone().requires_grad_(x_grad)
+    lq = flow_module.log_prob(xg)
+    (lq * coef).sum().backward()
+    return lq.detach(), [p.grad.detach().clone() for p in params], (xg.grad if x_grad else None)
+
+
+@pytest.mark.parametrize("D,K,nodes,B", [(6, 3, 5, 50), (2, 4, 40, 100), (5, 2, 4, 17), (32, 10, 10, 333),
+                                         (60, 2, 4, 40), (6, 8, 40, 1000)])
+def test_flow_parameter_gradients_vs_oracle_autograd(D, K, nodes, B):
+    """Training path (csrc/train_kernels.hip through fabhip_flow_log_prob_tape / fabhip_flow_param_grad):
+    sum_b coef_b d log q(x_b)/d theta for every parameter against torch autograd of the CPU oracle flow, and against
+    the PyTorch-ROCm expression of the flow on the GPU; tolerance 1e-4 of each tensor's largest entry.
+    Samples with a hidden pre-activation within 2e-5 of zero (fp64 oracle) get coefficient 0: there the ReLU
+    derivative depends on the fp32 summation order of whoever evaluates it (tools/diag_relu_kink.py: 3e-3 with
+    them, 2e-6 without, oracle and PyTorch-ROCm disagree with each other on such samples just the same)."""
+    nf = seeded_flow(D, K, nodes, 300 + D + K)
+    with torch.no_grad():                                 # non-trivial base / LU parameters too
+        g = torch.Generator().manual_seed(9)
+        nf.q0.loc.add_(0.3 * torch.randn(nf.q0.loc.shape, generator=g))
+        nf.q0.log_scale.add_(0.2 * torch.randn(nf.q0.log_scale.shape, generator=g))
+    hf = hip_flow_from_oracle(nf).requires_grad_(True)
+    torch.manual_seed(11)
+    with torch.no_grad():
+        x = nf.sample_eps(torch.randn(B, D))[0] + 0.1 * torch.randn(B, D)
+    coef = torch.randn(B) / B
+    near = relu_kink_samples(nf, x, D * nodes)
+    assert int(near.sum()) < B // 2
+    coef = torch.where(near, torch.zeros_like(coef), coef)
+    names = [n for n, _ in nf.named_parameters()]
+    lq_o, g_o, gx_o = _param_grads(nf, [p for _, p in nf.named_parameters()], x, coef, x_grad=True)
+    hip_params = dict(hf._nf_model.named_parameters())
+    assert set(hip_params) == set(names)
+    plist = [hip_params[n] for n in names]
+    assert hf.train_path == "hip"
+    lq_h, g_h, gx_h = _param_grads(hf, plist, x.to(DEV), coef.to(DEV), x_grad=True)
+    hf.train_path = "torch"
+    try:
+        lq_t, g_t, _ = _param_grads(hf, plist, x.to(DEV), coef.to(DEV))
+    finally:
+        hf.train_path = "hip"
+    assert close(lq_h, lq_o, RTOL) and close(gx_h, gx_o, RTOL)
+    assert any(float(b.abs().max()) > 1e-3 for b in g_o)
+    for n, a, b, c in zip(names, g_h, g_o, g_t):
+        scale = max(float(b.abs().max()), 1e-6)
+        err_o = float((a.cpu() - b).abs().max()) / scale
+        err_t = float((a - c).abs().max()) / scale
+        # the PyTorch-ROCm GEMMs themselves sit ~1e-3 from the CPU fp32 result on some tensors (measured 8e-4
+        # where the HIP path is at 2e-6), so that cross-check only guards against gross layout errors
+        assert err_o <= RTOL and err_t <= 5e-3, f"{n}: err vs oracle {err_o:.2e}, vs torch-GPU {err_t:.2e}"
+        assert a.shape == b.shape
+    # deterministic (fixed summation order, no atomics)
+    _, g_h2, _ = _param_grads(hf, plist, x.to(DEV), coef.to(DEV))
+    assert all(torch.equal(a, b) for a, b in zip(g_h, g_h2))
+
+
+def test_flat_adam_matches_clip_grad_norm_and_torch_adam():
+    """fabhip_adam_clip_step (FlatAdam) against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam on the same
+    gradients for several steps (fab/train_with_prioritised_buffer.py:174-179), incl. the skipped non-finite step."""
+    D, K, nodes, B = 6, 3, 5, 64
+    nf = seeded_flow(D, K, nodes, 77)
+    fl_a = hip_flow_from_oracle(nf).requires_grad_(True)
+    fl_b = hip_flow_from_oracle(nf).requires_grad_(True)
+    opt_a = fa.FlatAdam(fl_a, lr=1e-2)
+    opt_b = torch.optim.Adam(fl_b.parameters(), lr=1e-2)
+    sd_keys = set(fl_a.state_dict())
+    torch.manual_seed(3)
+    for it in range(6):
+        x = torch.randn(B, D, device=DEV)
+        coef = torch.randn(B, device=DEV) * (50.0 if it % 2 else 0.01)       # both sides of the clip threshold
+        if it == 4:
+            coef[3] = float("nan")
+        norms = []
+        for fl, opt in ((fl_a, opt_a), (fl_b, opt_b)):
+            opt.zero_grad()
+            (fl.log_prob(x) * coef).sum().backward()
+            if opt is opt_a:
+                norms.append(float(opt.step(max_grad_norm=1.0)))
+            else:
+                gn = torch.nn.utils.clip_grad_norm_(fl.parameters(), 1.0)
+                if torch.isfinite(gn):
+                    opt.step()
+                norms.append(float(gn))
+        if it == 4:
+            assert not np.isfinite(norms[0]) and not np.isfinite(norms[1])
+        else:
+            assert abs(norms[0] - norms[1]) <= 1e-5 * abs(norms[1]), norms
+        for (n, pa), (_, pb) in zip(fl_a.named_parameters(), fl_b.named_parameters()):
+            assert torch.isfinite(pa).all()
+            assert float((pa - pb).abs().max()) <= 2e-6 + 1e-5 * float(pb.abs().max()), (it, n)
+    assert set(fl_a.state_dict()) == sd_keys
+    # the kernels see the updated parameters
+    x = torch.randn(32, D, device=DEV)
+    with torch.no_grad():
+        assert close(fl_a.native_log_prob(x)[0], fl_a._torch_log_prob(x), RTOL)
+
+
 def test_targets_vs_golden():
     g = load_golden("g3_targets.npz")
     for D in (6, 32):

@@ -36,16 +36,21 @@ def main():
     ap.add_argument("--batch", type=int, default=2048)
     ap.add_argument("--buffer", type=int, default=512000)
     ap.add_argument("--min-buffer", type=int, default=65536)
+    ap.add_argument("--path", default="hip", choices=["hip", "torch"],
+                    help="flow.log_prob training path: HIP tape + parameter-gradient kernels, or torch autograd")
+    ap.add_argument("--optim", default="flat", choices=["flat", "torch"],
+                    help="FlatAdam (fused clip + Adam kernels) or clip_grad_norm_ + torch.optim.Adam")
     args = ap.parse_args()
     D, M, L, NB, alpha = 32, 4, 5, 8, 2.0
     torch.manual_seed(0)
     flow = fa.make_wrapped_normflow_realnvp(D, n_flow_layers=10, layer_nodes_per_dim=10, act_norm=False).to(DEV)
+    flow.train_path = args.path
     target = fa.ManyWellEnergy(D)
     hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=alpha, p_target=False,
                                    epsilon=0.2, n_outer=1, L=L).to(DEV)
     model = fa.FABModel(flow, target, M, alpha=alpha, transition_operator=hmc, loss_type="fab_alpha_div")
     ais = model.annealed_importance_sampler
-    opt = torch.optim.Adam(flow.parameters(), lr=3e-4)
+    opt = fa.FlatAdam(flow, lr=3e-4) if args.optim == "flat" else torch.optim.Adam(flow.parameters(), lr=3e-4)
 
     def init_sampler():
         pt, lw = ais.sample_and_log_weights(args.batch, logging=False)
@@ -73,12 +78,25 @@ def main():
                 loss.backward()
                 return adj
             adj = ph.time("loss_backward", loss_bwd)
-            ph.time("clip_adam", lambda: (torch.nn.utils.clip_grad_norm_(flow.parameters(), 100.0), opt.step()))
+            if args.optim == "flat":
+                ph.time("clip_adam", lambda: opt.step(max_grad_norm=100.0))
+            else:
+                ph.time("clip_adam", lambda: (torch.nn.utils.clip_grad_norm_(flow.parameters(), 100.0), opt.step()))
             ph.time("buffer_adjust", lambda: buf.adjust(adj, log_q.detach(), idx))
     n = args.iters
     per_iter = {k: v / n * 1e3 for k, v in ph.t.items()}
     per_iter["total"] = sum(per_iter.values())
-    print(json.dumps({"config": f"ManyWell-32 training iteration: batch {args.batch}, M={M}, L={L}, buffer "
+    # the same iteration through the trainer, no per-phase synchronisation (one .item() sync per iteration)
+    trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=alpha, n_batches_buffer_sampling=NB,
+                                          max_gradient_norm=100.0, w_adjust_max_clip=10.0)
+    trainer.run(2, args.batch)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    trainer.run(n, args.batch)
+    torch.cuda.synchronize()
+    per_iter["trainer_end_to_end"] = (time.perf_counter() - t0) / n * 1e3
+    print(json.dumps({"flow_train_path": args.path, "optimiser": args.optim,
+                      "config": f"ManyWell-32 training iteration: batch {args.batch}, M={M}, L={L}, buffer "
                                 f"{args.buffer}, {NB} minibatches", "buffer_fill_s": fill_s,
                       "ms_per_iteration": per_iter}))
 
