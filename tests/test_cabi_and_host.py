@@ -50,6 +50,33 @@ def test_geometry_queries_and_argument_validation_without_gpu():
     assert lib.fabhip_ess_logz(None, 4, None, 4.0, None, None, 0, None) == -1
 
 
+def test_training_path_layout_matches_the_parameter_shapes_without_gpu():
+    """fabhip_flow_grad_layout / _grad_views: the flat gradient image has exactly one slot per trainable scalar, in
+    the shapes of the normflows-compatible parameters; tape sizes grow with the batch; bad arguments rejected."""
+    lib = _lib.load()
+    for D, K, nodes in [(32, 10, 10), (6, 8, 40), (5, 3, 4), (2, 4, 40)]:
+        flow = fa.RealNVP(D, K, nodes)
+        n = lib.fabhip_flow_grad_floats(D, K, D * nodes)
+        tensors = flow._grad_tensors()
+        assert n == sum(p.numel() for p in tensors) == sum(p.numel() for p in flow.parameters())
+        views = flow._grad_views(torch.arange(n, dtype=torch.float32))
+        assert [tuple(v.shape) for v in views] == [tuple(p.shape) for p in tensors]
+        covered = torch.cat([v.reshape(-1) for v in views])
+        assert torch.equal(covered, torch.arange(n, dtype=torch.float32))          # disjoint, complete, ordered
+        t1 = lib.fabhip_flow_tape_bytes(D, K, D * nodes, 16)
+        t2 = lib.fabhip_flow_tape_bytes(D, K, D * nodes, 17)
+        assert 0 < t1 < t2 == lib.fabhip_flow_tape_bytes(D, K, D * nodes, 32)      # rows padded to the 16-chain tile
+    assert lib.fabhip_flow_grad_floats(65, 2, 32) == -1
+    assert lib.fabhip_flow_tape_bytes(65, 2, 32, 16) == 0
+    assert lib.fabhip_flow_grad_layout(32, 10, 320, None) == -1
+    f = _lib.Flow(32, 2, 64, None)
+    assert lib.fabhip_flow_log_prob_tape(C.byref(f), None, None, None, 4, None, 0, None) == -1
+    assert lib.fabhip_flow_param_grad(None, None, None, 0, None, 4, None, None) == -1
+    assert lib.fabhip_adam_clip_step(None, None, None, None, 4, 1e-3, 0.9, 0.999, 1e-8, None, 1.0, None, None, 0,
+                                     None) == -1
+    assert lib.fabhip_adam_workspace_bytes(1000) > 0
+
+
 def test_anneal_coefficients_match_the_reference_formulas():
     lib = _lib.load()
     for beta in (0.0, 0.2, 1 / 3, 1.0):

@@ -457,7 +457,8 @@ def test_flow_kernels_are_deterministic_race_screen(D, K, nodes):
     assert close(lq0.cpu()[idx], lq_o, RTOL) and close(g0.cpu()[idx], g_o, RTOL)
 
 
-def test_training_loop_end_to_end_on_manywell6():
+@pytest.mark.parametrize("optimiser", ["torch_adam", "flat_adam"])
+def test_training_loop_end_to_end_on_manywell6(optimiser):
     """FAB with the prioritised buffer (fab/train_with_prioritised_buffer.py:138-216) on the GPU: fused HIP AIS +
     differentiable flow.log_prob; the flow must improve (ESS of plain importance sampling from the flow goes up,
     forward KL estimate goes down) and the re-packed kernel image must follow the optimiser steps."""
@@ -480,7 +481,7 @@ def test_training_loop_end_to_end_on_manywell6():
         return float(fa.effective_sample_size(lp - lq))
 
     buf = fa.PrioritisedReplayBuffer(D, 20 * B, 4 * B, initial_sampler, device=DEV)
-    opt = torch.optim.Adam(flow.parameters(), lr=2e-3)
+    opt = torch.optim.Adam(flow.parameters(), lr=2e-3) if optimiser == "torch_adam" else fa.FlatAdam(flow, lr=2e-3)
     trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=2.0, n_batches_buffer_sampling=4,
                                           max_gradient_norm=100.0, w_adjust_max_clip=10.0)
     ess0 = flow_ess()
