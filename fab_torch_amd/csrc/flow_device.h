@@ -192,12 +192,15 @@ __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __r
                 for (int i = 1; i < NTWM; ++i) gload16s(w.r[dp][i], voff[i], sb);
             }
             __builtin_amdgcn_sched_barrier(0);
+#ifndef FAB_EXP_QUARTER_MFMA        // experiment only (wrong results): 1 MFMA per 16 B of weights, the load:MFMA
+                                    // ratio a 4-chain tile (v_mfma_f32_4x4x1) would have
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.y, w.r[d][i].y, acc[i]);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, w.r[d][i].z, acc[i]);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, w.r[d][i].w, acc[i]);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }

@@ -76,6 +76,83 @@ class ManyWellEnergy(_NativeTarget):
             return lp - float(self.log_Z) if self.normalised else lp
         return self._native_log_prob(x)[0]
 
+    # ---- evaluation helpers (many_well.py:61-147, double_well.py:61-95; host-side glue, torch on the device) ----
+    max_dim_for_all_modes = 40
+
+    def _eval_device(self):
+        return self._anchor.device
+
+    def sample(self, shape) -> torch.Tensor:
+        """Exact samples: per well, rejection sampling of the quartic coordinate (proposal 0.2 N(-1.7, .5) +
+        0.8 N(1.7, .5), envelope 3 Z as in double_well.py:61-82) and a standard normal for the other one."""
+        if not (self._a == -0.5 and self._b == -6 and self._c == 1.0):
+            raise NotImplementedError
+        assert len(shape) == 1
+        n, dev = int(shape[0]), self._eval_device()
+        need = n * self.n_wells
+        mix = torch.tensor([0.2, 0.8], device=dev)
+        means = torch.tensor([-1.7, 1.7], device=dev)
+        log_k = math.log(11784.50927 * 3)
+        got = []
+        have = 0
+        while have < need:
+            m = int((need - have) * 3.5) + 64                      # acceptance rate is 1/3
+            comp = torch.multinomial(mix, m, replacement=True)
+            z = means[comp] + 0.5 * torch.randn(m, device=dev)
+            log_prop = torch.logsumexp(torch.log(mix)[None, :] - 0.5 * ((z[:, None] - means[None, :]) / 0.5) ** 2
+                                       - math.log(0.5 * math.sqrt(2 * math.pi)), dim=1)
+            log_target = -z ** 4 + 6 * z ** 2 + 0.5 * z
+            keep = torch.rand(m, device=dev).log() < log_target - log_prop - log_k
+            got.append(z[keep])
+            have += int(keep.sum())
+        x1 = torch.cat(got)[:need].view(n, self.n_wells)
+        x = torch.empty(n, self.dim, device=dev)
+        x[:, 0::2] = x1
+        x[:, 1::2] = torch.randn(n, self.n_wells, device=dev)
+        return x
+
+    def get_modes_test_set_iterator(self, batch_size: int):
+        """Points placed at the modes (x_even = +-1.7, x_odd = 0): all 2^(dim/2) of them below 40 dims, 10^4 random
+        ones above (many_well.py:24-36, 68-79)."""
+        dev = self._eval_device()
+        if self.dim < self.max_dim_for_all_modes:
+            k = torch.arange(2 ** self.n_wells, device=dev)
+            bits = (k[:, None] >> torch.arange(self.n_wells - 1, -1, -1, device=dev)[None, :]) & 1
+        else:
+            bits = torch.randint(high=2, size=(int(1e4), self.n_wells), device=dev)
+        test_set = torch.zeros(bits.shape[0], self.dim, device=dev)
+        test_set[:, 0::2] = -self.centre + 2 * self.centre * bits.float()
+        return list(torch.split(test_set, batch_size))
+
+    def performance_metrics(self, samples, log_w: torch.Tensor, log_q_fn=None, batch_size=None):
+        """many_well.py:96-147: accuracy of the normalisation-constant estimate over 50 splits of log_w and, given
+        log_q_fn, mean flow log-prob on the mode test set / on exact samples and the forward KL estimate."""
+        del samples
+        n_runs = 50
+        n_vals = log_w.shape[0] // n_runs
+        lw = torch.stack(log_w[:n_vals * n_runs].split(n_runs), dim=-1)
+        log_Z = float(self.log_Z)
+        log_Z_estimate = torch.logsumexp(lw, dim=-1) - np.log(lw.shape[-1])
+        info = {"relative_MSE_Z_estimate": torch.mean(torch.abs(torch.exp(log_Z_estimate - log_Z) - 1)).item(),
+                "abs_MSE_log_Z_estimate": torch.mean(torch.abs(log_Z_estimate - log_Z)).item()}
+        if log_q_fn is not None:
+            assert batch_size is not None
+            n_batches = max(lw.shape[0] // batch_size, 1)
+            modes = self.get_modes_test_set_iterator(batch_size)
+            with torch.no_grad():
+                sum_modes = sum(float(torch.sum(log_q_fn(x))) for x in modes)
+                sum_exact = sum_kl = 0.0
+                for _ in range(n_batches):
+                    x = self.sample((batch_size,))
+                    lq = log_q_fn(x)
+                    sum_exact += float(torch.sum(lq))
+                    sum_kl += float(torch.sum(self.log_prob(x) - log_Z - lq))       # as written in many_well.py:137
+            n_eval = batch_size * n_batches
+            info.update(test_set_modes_mean_log_prob=sum_modes / sum(len(x) for x in modes),
+                        test_set_exact_mean_log_prob=sum_exact / n_eval, forward_kl=sum_kl / n_eval,
+                        eval_batch_size=n_eval)
+        return info
+
 
 class GMM(_NativeTarget):
     def __init__(self, dim, n_mixes, loc_scaling, log_var_scaling=0.1, seed=0, n_test_set_samples=1000,

@@ -339,7 +339,29 @@ def g9_buffer():
     npz("g9_buffer.npz", **out)
 
 
+def g10_manywell_eval():
+    """ManyWellEnergy evaluation helpers (many_well.py:24-36, 96-147): the mode test set, the log-Z metrics on a
+    seeded log_w, the log_q-dependent metrics with a fixed analytic log_q_fn, moments of the exact sampler."""
+    target = ManyWellEnergy(dim=6, use_gpu=False)
+    g = torch.Generator().manual_seed(5)
+    log_w = float(target.log_Z) + 0.3 * torch.randn(5000, generator=g)
+    info = target.performance_metrics(None, log_w)
+
+    def log_q_fn(x):                                          # N(0, 1.5^2 I)
+        return -0.5 * (x / 1.5).pow(2).sum(-1) - x.shape[-1] * np.log(1.5 * np.sqrt(2 * np.pi))
+    torch.manual_seed(6)
+    info_q = target.performance_metrics(None, log_w, log_q_fn, batch_size=2000)
+    torch.manual_seed(7)
+    xs = target.sample((200000,))
+    npz("g10_manywell_eval.npz", modes=target._test_set_modes, log_w=log_w, log_Z=float(target.log_Z),
+        relative_MSE_Z_estimate=info["relative_MSE_Z_estimate"], abs_MSE_log_Z_estimate=info["abs_MSE_log_Z_estimate"],
+        test_set_modes_mean_log_prob=info_q["test_set_modes_mean_log_prob"],
+        test_set_exact_mean_log_prob=info_q["test_set_exact_mean_log_prob"], forward_kl=info_q["forward_kl"],
+        eval_batch_size=info_q["eval_batch_size"], sample_mean=xs.mean(0), sample_std=xs.std(0),
+        sample_frac_deep_well=(xs[:, 0::2] > 0).float().mean())
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)      # deterministic reduction order in the fixtures
     g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
-    g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer()
+    g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval()

@@ -80,3 +80,25 @@ def test_fabmodel_save_load_roundtrip(tmp_path):
     model2.load(path)
     assert torch.equal(hmc2.epsilons, hmc.epsilons) and torch.equal(flow2._nf_model.q0.loc, flow._nf_model.q0.loc)
     assert model2.annealed_importance_sampler.transition_operator is hmc2
+
+
+def test_manywell_eval_helpers_match_reference_golden():
+    """ManyWellEnergy.get_modes_test_set_iterator / performance_metrics (log-Z part) / sample against fixtures
+    produced by the imported reference (tests/golden/make_golden.py:g10_manywell_eval); many_well.py:24-36,96-115."""
+    g = load_golden("g10_manywell_eval.npz")
+    target = fa.ManyWellEnergy(dim=6, use_gpu=False)
+    modes = torch.cat(target.get_modes_test_set_iterator(batch_size=3))
+    assert np.array_equal(modes.numpy(), g["modes"])
+    assert abs(float(target.log_Z) - float(g["log_Z"])) < 1e-5
+    info = target.performance_metrics(None, torch.tensor(g["log_w"]))
+    assert abs(info["relative_MSE_Z_estimate"] - float(g["relative_MSE_Z_estimate"])) < 1e-6
+    assert abs(info["abs_MSE_log_Z_estimate"] - float(g["abs_MSE_log_Z_estimate"])) < 1e-6
+    # the exact sampler draws from the same distribution (different RNG stream): moments within 5 standard errors
+    torch.manual_seed(0)
+    n = 200_000
+    xs = target.sample((n,))
+    assert xs.shape == (n, 6)
+    se = g["sample_std"] / np.sqrt(n) * np.sqrt(2)
+    assert np.all(np.abs(xs.mean(0).numpy() - g["sample_mean"]) < 5 * se)
+    assert np.all(np.abs(xs.std(0).numpy() - g["sample_std"]) < 0.01)
+    assert abs(float((xs[:, 0::2] > 0).float().mean()) - float(g["sample_frac_deep_well"])) < 0.005

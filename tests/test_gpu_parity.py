@@ -178,6 +178,7 @@ def test_flat_adam_matches_clip_grad_norm_and_torch_adam():
             assert abs(norms[0] - norms[1]) <= 1e-5 * abs(norms[1]), norms
         for (n, pa), (_, pb) in zip(fl_a.named_parameters(), fl_b.named_parameters()):
             assert torch.isfinite(pa).all()
+            pa, pb = pa.detach(), pb.detach()
             assert float((pa - pb).abs().max()) <= 2e-6 + 1e-5 * float(pb.abs().max()), (it, n)
     assert set(fl_a.state_dict()) == sd_keys
     # the kernels see the updated parameters
@@ -496,3 +497,29 @@ def test_training_loop_end_to_end_on_manywell6(optimiser):
         a = flow.native_log_prob(x)[0]
     b = flow._torch_log_prob(x).detach()
     assert close(a, b, RTOL)
+
+
+def test_manywell_performance_metrics_and_eval_info_on_gpu():
+    """many_well.py:96-147 / core.py:191-220: full performance_metrics with a log_q_fn against the reference's
+    numbers (g10; the exact sampler uses another RNG stream -> statistical tolerance), and FABModel.get_eval_info
+    running the fused sampler with the p target."""
+    g = load_golden("g10_manywell_eval.npz")
+    target = fa.ManyWellEnergy(dim=6)
+
+    def log_q_fn(x):
+        return -0.5 * (x / 1.5).pow(2).sum(-1) - x.shape[-1] * np.log(1.5 * np.sqrt(2 * np.pi))
+    torch.manual_seed(1)
+    info = target.performance_metrics(None, torch.tensor(g["log_w"], device=DEV), log_q_fn, batch_size=2000)
+    assert abs(info["test_set_modes_mean_log_prob"] - float(g["test_set_modes_mean_log_prob"])) < 1e-4
+    assert info["eval_batch_size"] == int(g["eval_batch_size"])
+    assert abs(info["test_set_exact_mean_log_prob"] - float(g["test_set_exact_mean_log_prob"])) < 0.1
+    assert abs(info["forward_kl"] - float(g["forward_kl"])) < 0.15
+    flow = fa.RealNVP(6, 3, 5).to(DEV)
+    hmc = fa.HamiltonianMonteCarlo(2, 6, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.3,
+                                   L=3).to(DEV)
+    model = fa.FABModel(flow, target, 2, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
+    ev = model.get_eval_info(outer_batch_size=512, inner_batch_size=256)
+    assert {"eval_ess_flow", "eval_ess_ais", "flow_forward_kl", "ais_relative_MSE_Z_estimate",
+            "flow_test_set_modes_mean_log_prob"} <= set(ev)
+    assert all(np.isfinite(v) for v in ev.values()) and 0 < ev["eval_ess_ais"] <= 1
+    assert model.annealed_importance_sampler.p_target is False          # restored to the min-variance target
