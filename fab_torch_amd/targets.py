@@ -10,6 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib
+from .numerical import (quadratic_function, importance_weighted_expectation,
+                        effective_sample_size_over_p)
 
 
 class _NativeTarget(nn.Module):
@@ -160,6 +162,7 @@ class GMM(_NativeTarget):
         super().__init__()
         self.seed, self.n_mixes, self.dim = seed, n_mixes, dim
         self.n_test_set_samples = n_test_set_samples
+        self._true_expectation, self._true_expectation_n = None, int(true_expectation_estimation_n_samples)
         mean = (torch.rand((n_mixes, dim)) - 0.5) * 2 * loc_scaling          # gmm.py:22 (caller seeds torch)
         log_var = torch.ones((n_mixes, dim)) * log_var_scaling
         self.register_buffer("cat_probs", torch.ones(n_mixes))
@@ -195,3 +198,42 @@ class GMM(_NativeTarget):
             mask[lp < -1e4] = -float("inf")
             return lp + mask
         return self._native_log_prob(x)[0]
+
+    # ---- evaluation helpers (gmm.py:33-36, 54-100; host-side torch, not on the hot path) ---------------------------
+    expectation_function = staticmethod(quadratic_function)
+
+    @property
+    def true_expectation(self) -> torch.Tensor:
+        """E_p[quadratic_function] by plain Monte Carlo; the reference estimates it in the constructor
+        (gmm.py:30-33, 10^7 samples), here on first use."""
+        if self._true_expectation is None:
+            n, acc, done = self._true_expectation_n, 0.0, 0
+            while done < n:
+                m = min(n - done, 1 << 20)
+                acc += float(torch.sum(self.expectation_function(self.sample((m,))).double()))
+                done += m
+            self._true_expectation = torch.tensor(acc / n, dtype=torch.float32)
+        return self._true_expectation
+
+    @property
+    def test_set(self) -> torch.Tensor:
+        return self.sample((self.n_test_set_samples,))
+
+    def evaluate_expectation(self, samples, log_w):
+        expectation = importance_weighted_expectation(self.expectation_function, samples, log_w)
+        true_expectation = self.true_expectation.to(expectation.device)
+        return (expectation - true_expectation) / true_expectation
+
+    def performance_metrics(self, samples, log_w, log_q_fn=None, batch_size=None):
+        bias_normed = self.evaluate_expectation(samples, log_w)
+        bias_no_correction = self.evaluate_expectation(samples, torch.ones_like(log_w))
+        if log_q_fn:
+            with torch.no_grad():
+                log_q_test = log_q_fn(self.test_set)          # two independent draws of the test set, like the
+                log_p_test = self.log_prob(self.test_set)      # reference's property (gmm.py:54-56, 88-89)
+            return {"test_set_mean_log_prob": torch.mean(log_q_test).item(),
+                    "bias_normed": torch.abs(bias_normed).item(),
+                    "bias_no_correction": torch.abs(bias_no_correction).item(),
+                    "ess_over_p": effective_sample_size_over_p(log_p_test - log_q_test).item(),
+                    "kl_forward": torch.mean(log_p_test - log_q_test).item()}
+        return {"bias_normed": bias_normed.item(), "bias_no_correction": torch.abs(bias_no_correction).item()}

@@ -361,7 +361,24 @@ def g10_manywell_eval():
         sample_frac_deep_well=(xs[:, 0::2] > 0).float().mean())
 
 
+def g11_gmm_eval():
+    """GMM evaluation helpers (gmm.py:68-100, utils/numerical.py:25-64): quadratic_function on fixed points,
+    the importance-weighted expectation bias given the constructor's true_expectation, effective_sample_size_over_p."""
+    from fab.utils.numerical import quadratic_function, effective_sample_size_over_p
+    torch.manual_seed(0)
+    target = GMM(dim=2, n_mixes=40, loc_scaling=40.0, log_var_scaling=1.0, use_gpu=False,
+                 true_expectation_estimation_n_samples=int(2e5))
+    g = torch.Generator().manual_seed(3)
+    x = 30 * torch.randn(4000, 2, generator=g)
+    log_w = torch.randn(4000, generator=g)
+    info = target.performance_metrics(x, log_w)
+    npz("g11_gmm_eval.npz", locs=target.locs, x=x, log_w=log_w, fx=quadratic_function(x),
+        true_expectation=target.true_expectation, bias_normed=info["bias_normed"],
+        bias_no_correction=info["bias_no_correction"],
+        ess_over_p=effective_sample_size_over_p(0.5 * log_w))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)      # deterministic reduction order in the fixtures
     g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
-    g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval()
+    g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval(); g11_gmm_eval()

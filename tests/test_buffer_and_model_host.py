@@ -102,3 +102,26 @@ def test_manywell_eval_helpers_match_reference_golden():
     assert np.all(np.abs(xs.mean(0).numpy() - g["sample_mean"]) < 5 * se)
     assert np.all(np.abs(xs.std(0).numpy() - g["sample_std"]) < 0.01)
     assert abs(float((xs[:, 0::2] > 0).float().mean()) - float(g["sample_frac_deep_well"])) < 0.005
+
+
+def test_gmm_eval_helpers_match_reference_golden():
+    """quadratic_function / importance_weighted_expectation / GMM.performance_metrics / effective_sample_size_over_p
+    against the imported reference (g11; gmm.py:68-100, utils/numerical.py:25-64)."""
+    from fab_torch_amd.numerical import quadratic_function, effective_sample_size_over_p
+    g = load_golden("g11_gmm_eval.npz")
+    x, log_w = torch.tensor(g["x"]), torch.tensor(g["log_w"])
+    state = torch.get_rng_state()
+    fx = quadratic_function(x)
+    assert torch.equal(torch.get_rng_state(), state)           # unlike the reference, the global RNG is untouched
+    assert np.allclose(fx.numpy(), g["fx"], rtol=1e-6, atol=1e-3)
+    torch.manual_seed(0)
+    target = fa.GMM(dim=2, n_mixes=40, loc_scaling=40.0, log_var_scaling=1.0, use_gpu=False,
+                    true_expectation_estimation_n_samples=int(2e5))
+    assert np.array_equal(target.locs.numpy(), g["locs"])       # same seeded means as gmm.py:22
+    est = float(target.true_expectation)                        # own Monte-Carlo estimate: statistically equal
+    assert abs(est - float(g["true_expectation"])) < 0.03 * abs(float(g["true_expectation"]))
+    target._true_expectation = torch.tensor(float(g["true_expectation"]))
+    info = target.performance_metrics(x, log_w)
+    assert abs(info["bias_normed"] - float(g["bias_normed"])) < 1e-5
+    assert abs(info["bias_no_correction"] - float(g["bias_no_correction"])) < 1e-5
+    assert abs(float(effective_sample_size_over_p(0.5 * log_w)) - float(g["ess_over_p"])) < 1e-6
