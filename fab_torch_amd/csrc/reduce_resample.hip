@@ -334,6 +334,24 @@ __global__ __launch_bounds__(64 * SCAN_NW) void k_scan_fixed(const float* __rest
             *oA = odd ? make_ulonglong2(a2, a3) : make_ulonglong2(a0, a1);
             *oB = odd ? make_ulonglong2(b2, b3) : make_ulonglong2(b0, b1);
         }
+    } else if (vec && ws.variant == 2) {
+        // same pattern, streaming (non-temporal) stores: the CDF is consumed by a later kernel, not by this one
+        typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+        const int srcA = lane >> 1, srcB = 32 + (lane >> 1);
+        const bool odd = lane & 1;
+#pragma unroll
+        for (int v = 0; v < SCAN_SLABS; ++v) {
+            const unsigned long long b = off0 + excl[v];
+            const unsigned long long c0 = b + q[v][0], c1 = b + q[v][1], c2 = b + q[v][2], c3 = b + q[v][3];
+            const unsigned long long a0 = shfl_u64(c0, srcA), a1 = shfl_u64(c1, srcA), a2 = shfl_u64(c2, srcA), a3 = shfl_u64(c3, srcA);
+            const unsigned long long b0 = shfl_u64(c0, srcB), b1 = shfl_u64(c1, srcB), b2 = shfl_u64(c2, srcB), b3 = shfl_u64(c3, srcB);
+            u64x2* oA = reinterpret_cast<u64x2*>(ws.cdf + wbase + v * 256 + lane * 2);
+            u64x2* oB = reinterpret_cast<u64x2*>(ws.cdf + wbase + v * 256 + 128 + lane * 2);
+            const u64x2 vA = odd ? (u64x2){a2, a3} : (u64x2){a0, a1};
+            const u64x2 vB = odd ? (u64x2){b2, b3} : (u64x2){b0, b1};
+            __builtin_nontemporal_store(vA, oA);
+            __builtin_nontemporal_store(vB, oB);
+        }
     } else if (vec) {
 #pragma unroll
         for (int v = 0; v < SCAN_SLABS; ++v) {
@@ -350,6 +368,134 @@ __global__ __launch_bounds__(64 * SCAN_NW) void k_scan_fixed(const float* __rest
                 const long i = wbase + v * 256 + lane * 4 + e;
                 if (i < n) ws.cdf[i] = off0 + excl[v] + q[v][e];
             }
+    }
+}
+
+// Same scan, LDS-transposed: the wave's 2048 weights are loaded with fully coalesced 1-KiB instructions, turned
+// in LDS so that lane l owns the 32 CONSECUTIVE weights [32 l, 32 l + 32), summed serially in registers (one
+// 6-step wave scan per 2048 weights instead of one per 256), and the 2048 CDF values are turned back through
+// LDS into fully coalesced non-temporal 1-KiB stores.  Integer sums: bit-identical to k_scan_fixed.
+// LDS per wave: 64 lanes x 18 u64 (the CDF goes back in two halves of 16 values per lane; lane stride 144 B);
+// the float staging of the input (lane stride 36 floats = 144 B) aliases the same region.  73 KB per
+// workgroup -> two workgroups per CU.
+constexpr int SCAN_LSTRIDE = 18;                        // u64 per lane row (16 + 2 pad)
+constexpr int SCAN_FSTRIDE = 36;                        // floats per lane row of the input staging
+
+__global__ __launch_bounds__(64 * SCAN_NW) void k_scan_fixed_lds(const float* __restrict__ lw, long n,
+                                                                 const float* __restrict__ max_val, ScanWs ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long scan_lds[];
+    __shared__ unsigned long long wave_tot[SCAN_NW];
+    __shared__ unsigned long long blk_prefix;
+    __shared__ unsigned int blk_id_sh;
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) blk_id_sh = atomicAdd(ws.ticket, 1u);
+    __syncthreads();
+    const unsigned int blk = blk_id_sh;
+    const long wbase = (long)blk * SCAN_BLOCK + (long)wave * SCAN_WAVE_ITEMS;
+    const float mx = max_val[0];
+    unsigned long long* wl = scan_lds + (size_t)wave * 64 * SCAN_LSTRIDE;
+    float* wf = reinterpret_cast<float*>(wl);
+    const bool vec = (wbase + SCAN_WAVE_ITEMS <= n) && (((size_t)lw & 15) == 0);
+    unsigned long long run[32];                          // inclusive sums of this lane's 32 consecutive weights
+    if (vec) {
+        float4 x[8];
+#pragma unroll
+        for (int h = 0; h < 8; ++h) x[h] = *reinterpret_cast<const float4*>(lw + wbase + h * 256 + lane * 4);
+#pragma unroll
+        for (int h = 0; h < 8; ++h)                      // item 256 h + 4 lane -> row (8 h + lane / 8), column 4 (lane % 8)
+            *reinterpret_cast<float4*>(wf + (8 * h + (lane >> 3)) * SCAN_FSTRIDE + 4 * (lane & 7)) = x[h];
+    } else {
+        for (int i = lane; i < SCAN_WAVE_ITEMS; i += 64) {
+            const long g = wbase + i;
+            wf[(i >> 5) * SCAN_FSTRIDE + (i & 31)] = (g < n) ? lw[g] : -INFINITY;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long acc = 0ull;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float4 y = *reinterpret_cast<const float4*>(wf + lane * SCAN_FSTRIDE + 4 * k);
+        acc += fixed_weight(y.x, mx); run[4 * k + 0] = acc;
+        acc += fixed_weight(y.y, mx); run[4 * k + 1] = acc;
+        acc += fixed_weight(y.z, mx); run[4 * k + 2] = acc;
+        acc += fixed_weight(y.w, mx); run[4 * k + 3] = acc;
+    }
+    unsigned long long incl = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = shfl_up_u64(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const unsigned long long lane_excl = incl - acc;
+    const unsigned long long wtot = shfl_u64(incl, 63);
+    if (lane == 0) wave_tot[wave] = wtot;
+    __syncthreads();
+    unsigned long long wave_off = 0ull, blk_tot = 0ull;
+#pragma unroll
+    for (int w = 0; w < SCAN_NW; ++w) { if (w < wave) wave_off += wave_tot[w]; blk_tot += wave_tot[w]; }
+    if (wave == 0) {
+        if (blk == 0) {
+            if (lane == 0) {
+                __hip_atomic_store(ws.desc + 0, FLAG_INC | blk_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                blk_prefix = 0ull;
+            }
+        } else {
+            if (lane == 0)
+                __hip_atomic_store(ws.desc + blk, FLAG_AGG | blk_tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            unsigned long long ex = 0ull;
+            long look = (long)blk - 1;
+            while (true) {
+                const long j = look - lane;
+                unsigned long long d = 0ull;
+                if (j >= 0) {
+                    do {
+                        d = __hip_atomic_load(ws.desc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } while ((d >> 62) == 0ull);
+                } else {
+                    d = FLAG_INC;
+                }
+                const unsigned long long inc_mask = __ballot((d >> 62) == 2ull);
+                const int first_inc = __ffsll((long long)inc_mask) - 1;
+                unsigned long long contrib = (first_inc < 0 || lane <= first_inc) ? (d & VAL_MASK) : 0ull;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) contrib += shfl_u64(contrib, lane ^ off);
+                ex += contrib;
+                if (first_inc >= 0) break;
+                look -= 64;
+            }
+            if (lane == 0) {
+                __hip_atomic_store(ws.desc + blk, FLAG_INC | (ex + blk_tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                blk_prefix = ex;
+            }
+        }
+    }
+    __syncthreads();
+    const unsigned long long off0 = blk_prefix + wave_off;
+    if (lane == 63 && (wave & 1) && wbase - SCAN_WAVE_ITEMS < n)
+        ws.tile_inc[((long)blk * SCAN_BLOCK + (long)(wave - 1) * SCAN_WAVE_ITEMS) / SCAN_TILE] = off0 + wtot;
+    const unsigned long long base = off0 + lane_excl;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                        // values 16 h .. 16 h + 15 of every lane
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            *reinterpret_cast<u64x2*>(wl + lane * SCAN_LSTRIDE + 2 * k) =
+                (u64x2){base + run[16 * h + 2 * k], base + run[16 * h + 2 * k + 1]};
+        __builtin_amdgcn_wave_barrier();
+        if (vec) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {                // 8 lanes write one full 128-byte line of row 8 s + lane / 8
+                const int row = 8 * s + (lane >> 3), col = 2 * (lane & 7);
+                const u64x2 c = *reinterpret_cast<const u64x2*>(wl + row * SCAN_LSTRIDE + col);
+                __builtin_nontemporal_store(c, reinterpret_cast<u64x2*>(ws.cdf + wbase + 32 * row + 16 * h + col));
+            }
+        } else {
+            for (int i = lane; i < SCAN_WAVE_ITEMS / 2; i += 64) {
+                const long g = wbase + 32 * (i >> 4) + 16 * h + (i & 15);
+                if (g < n) ws.cdf[g] = wl[(i >> 4) * SCAN_LSTRIDE + (i & 15)];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -517,7 +663,7 @@ static ScanWs carve_scan_ws(void* workspace, long n) {
     ws.ticket = (unsigned int*)p; p += 256;
     ws.tile_inc = (unsigned long long*)p; p += al256((size_t)scan_tiles(n) * 8);
     ws.cdf = (unsigned long long*)p;
-    { const char* e = getenv("FABHIP_SCAN_VARIANT"); ws.variant = e ? atoi(e) : 1; }
+    { const char* e = getenv("FABHIP_SCAN_VARIANT"); ws.variant = e ? atoi(e) : 3; }   // 3 = LDS-transposed scan; 0-2 = register/shuffle variants (A/B)
     return ws;
 }
 
@@ -528,7 +674,18 @@ static int build_fixed_cdf(const float* log_w, long n, const ScanWs& ws, hipStre
     // zero descriptors + ticket (one contiguous region: desc .. ticket)
     const size_t zbytes = (size_t)((char*)ws.ticket - (char*)ws.desc) + 256;
     if (hipMemsetAsync(ws.desc, 0, zbytes, st) != hipSuccess) return FABHIP_ELAUNCH;
-    hipLaunchKernelGGL(k_scan_fixed, dim3((unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK)), dim3(64 * SCAN_NW), 0, st, log_w, n, ws.max_val, ws);
+    const dim3 grid((unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK)), block(64 * SCAN_NW);
+    if (ws.variant == 3) {
+        const size_t lds = (size_t)SCAN_NW * 64 * SCAN_LSTRIDE * sizeof(unsigned long long);
+        if (hipFuncSetAttribute((const void*)k_scan_fixed_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+            hipSuccess) {
+            (void)hipGetLastError();
+            return FABHIP_ELAUNCH;
+        }
+        hipLaunchKernelGGL(k_scan_fixed_lds, grid, block, lds, st, log_w, n, ws.max_val, ws);
+    } else {
+        hipLaunchKernelGGL(k_scan_fixed, grid, block, 0, st, log_w, n, ws.max_val, ws);
+    }
     return check_launch();
 }
 
