@@ -202,6 +202,7 @@ def main():
             line["speedup_vs_cpu"] = line["value"] / line["cpu_baseline"]["value"]
         print(json.dumps(line))
     if distributed:
+        dist.barrier()                      # rank 0 measured the roofline leg alone; leave together
         dist.destroy_process_group()
 
 
