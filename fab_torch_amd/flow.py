@@ -134,9 +134,11 @@ class _LogProbWithTape(torch.autograd.Function):
                                               _lib.ptr(coef), ctx.B, _lib.ptr(flat), _lib.stream_ptr()),
                    "flow_param_grad")
         flow._last_flat_grad = flat
+        gx = coef[:, None] * grad_x if ctx.needs_input_grad[1] else None
+        if len(ctx.needs_input_grad) == 3:                   # flat mode: one leaf holds every parameter (FlatAdam)
+            return None, gx, flat
         views = flow._grad_views(flat)
         grads = [v if need else None for v, need in zip(views, ctx.needs_input_grad[2:])]
-        gx = coef[:, None] * grad_x if ctx.needs_input_grad[1] else None
         return (None, gx, *grads)
 
 
@@ -155,6 +157,7 @@ class RealNVP(nn.Module):
         self._packed_key = None
         self._params_struct = None
         self._grad_layout = None
+        self._flat_leaf = None
 
     # ---- Distribution interface (fab/types_.py:8-27) ---------------------------------------------
     @property
@@ -176,6 +179,8 @@ class RealNVP(nn.Module):
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
         if torch.is_grad_enabled() and (x.requires_grad or self._params_need_grad()):
             if x.is_cuda and self.train_path == "hip":
+                if self._flat_leaf is not None:              # parameters live in one buffer (optim.FlatAdam)
+                    return _LogProbWithTape.apply(self, x, self._flat_leaf)
                 return _LogProbWithTape.apply(self, x, *self._grad_tensors())
             return self._torch_log_prob(x)
         return self.native_log_prob(x)[0]

@@ -38,6 +38,14 @@ class FlatAdam(torch.optim.Optimizer):
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self._ws = torch.empty(int(lib.fabhip_adam_workspace_bytes(self.n)), dtype=torch.uint8, device=dev)
         flow._packed_key = None
+        # one autograd leaf for the whole flow: flow.log_prob(x).backward() then delivers ONE flat gradient
+        # (theta.grad) instead of 112 per-parameter views (the per-parameter .grad stay None in this mode)
+        self.theta.requires_grad_(True)
+        flow._flat_leaf = self.theta
+
+    def zero_grad(self, set_to_none: bool = True):
+        super().zero_grad(set_to_none=True)
+        self.theta.grad = None
 
     def _check_alias(self):
         base = self.theta.data_ptr()
@@ -47,16 +55,27 @@ class FlatAdam(torch.optim.Optimizer):
                                        "(e.g. by .to()/.cuda()); build the optimiser after moving the flow")
 
     def _flat_grad(self) -> torch.Tensor:
-        """The flat gradient image if every .grad is (still) a view of one, else a concatenation."""
+        """theta.grad (flat mode), plus whatever reached the individual parameters through other autograd paths."""
+        extra = [p for p in self._params if p.grad is not None]
+        if self.theta.grad is not None:
+            g = self.theta.grad
+            if extra:
+                g = g + self._cat_grads()
+            return g.contiguous()
+        if not extra:
+            raise _lib.FabhipError("FlatAdam.step(): parameters have no gradient")
         g0 = self._params[0].grad
         if g0 is None:
-            raise _lib.FabhipError("FlatAdam.step(): parameters have no gradient")
+            return self._cat_grads()
         base = g0.data_ptr() - self._offsets[0]
         flat = getattr(self.flow, "_last_flat_grad", None)
         if flat is not None and flat.data_ptr() == base and all(
                 p.grad is not None and p.grad.data_ptr() == base + off and p.grad.is_contiguous()
                 for p, off in zip(self._params, self._offsets)):
             return flat
+        return self._cat_grads()
+
+    def _cat_grads(self) -> torch.Tensor:
         zero = None
         parts = []
         for p in self._params:
