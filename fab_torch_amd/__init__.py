@@ -12,7 +12,7 @@ from .ais import AnnealedImportanceSampler, LoggingInfo
 from .numerical import effective_sample_size, ess_and_log_z
 from .core import FABModel
 from .buffer import PrioritisedReplayBuffer, sample_without_replacement
-from .train import PrioritisedBufferTrainer
+from .train import PrioritisedBufferTrainer, Trainer
 from .optim import FlatAdam
 from .resample import resample, multinomial_indices, systematic_indices, multinomial_torch_compat, gather_rows
 
@@ -21,5 +21,5 @@ __all__ = [
     "HamiltonianMonteCarlo", "Metropolis", "create_point", "AnnealedImportanceSampler", "LoggingInfo",
     "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
     "multinomial_torch_compat", "gather_rows", "FABModel", "PrioritisedReplayBuffer",
-    "sample_without_replacement", "PrioritisedBufferTrainer", "FlatAdam",
+    "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam",
 ]

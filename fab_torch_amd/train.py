@@ -83,3 +83,71 @@ class PrioritisedBufferTrainer:
             if self.logger:
                 self.logger(info)
         return self.history
+
+
+class Trainer:
+    """The plain FAB loop of fab/train.py:16-136 (what the shipped ManyWell config runs: `fab_alpha_div` on fresh
+    AIS samples, no buffer): zero_grad -> model.loss(batch_size) -> backward -> clip -> step, with the NaN-loss and
+    non-finite-gradient skips, evaluation (`model.get_eval_info`) and checkpoints at linearly spaced iterations.
+    Plotting / tqdm / time limits are left to the caller."""
+
+    def __init__(self, model: FABModel, optimizer: torch.optim.Optimizer, optim_schedular=None,
+                 logger: Optional[Callable[[Dict], None]] = None, max_gradient_norm: Optional[float] = 5.0,
+                 save_path: str = ""):
+        self.model, self.optimizer, self.optim_schedular, self.logger = model, optimizer, optim_schedular, logger
+        self.max_gradient_norm = max_gradient_norm if max_gradient_norm else float("inf")
+        self.save_dir = save_path
+        self.history: List[Dict] = []
+        self._fused = isinstance(optimizer, FlatAdam)
+
+    def save_checkpoint(self, i: int):
+        import os
+        path = os.path.join(self.save_dir, "model_checkpoints", f"iter_{i}")
+        os.makedirs(path, exist_ok=False)
+        self.model.save(os.path.join(path, "model.pt"))
+        torch.save(self.optimizer.state_dict(), os.path.join(path, "optimizer.pt"))
+
+    def step(self, i: int, batch_size: int) -> Dict:
+        self.optimizer.zero_grad()
+        loss = self.model.loss(batch_size)
+        grad_norm = torch.tensor(float("nan"))
+        if self._fused:
+            loss.backward()
+            grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm)
+            if self.optim_schedular:
+                self.optim_schedular.step()
+        elif not torch.isnan(loss) and not torch.isinf(loss):
+            loss.backward()
+            grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_gradient_norm)
+            if torch.isfinite(grad_norm):
+                self.optimizer.step()
+            else:
+                print("encountered inf grad norm")
+            if self.optim_schedular:
+                self.optim_schedular.step()
+        else:
+            print("nan loss encountered")
+        self.optimizer.zero_grad()
+        info = self.model.get_iter_info()
+        info.update(loss=loss.item(), step=i, grad_norm=float(grad_norm))
+        return info
+
+    def run(self, n_iterations: int, batch_size: int, eval_batch_size: Optional[int] = None,
+            n_eval: Optional[int] = None, n_checkpoints: Optional[int] = None, start_iter: int = 0) -> List[Dict]:
+        import numpy as np
+        if start_iter >= n_iterations:
+            raise Exception("Not running training as start_iter >= total training iterations")
+        eval_iter = list(np.linspace(1, n_iterations, n_eval, dtype="int")) if n_eval is not None else []
+        ckpt_iter = list(np.linspace(1, n_iterations, n_checkpoints, dtype="int")) if n_checkpoints else []
+        if n_eval is not None:
+            assert eval_batch_size is not None
+        for i in range(start_iter + 1, n_iterations + 1):
+            info = self.step(i, batch_size)
+            if i in eval_iter:
+                info.update(self.model.get_eval_info(outer_batch_size=eval_batch_size, inner_batch_size=batch_size))
+            self.history.append(info)
+            if self.logger:
+                self.logger(info)
+            if i in ckpt_iter:
+                self.save_checkpoint(i)
+        return self.history

@@ -523,3 +523,31 @@ def test_manywell_performance_metrics_and_eval_info_on_gpu():
             "flow_test_set_modes_mean_log_prob"} <= set(ev)
     assert all(np.isfinite(v) for v in ev.values()) and 0 < ev["eval_ess_ais"] <= 1
     assert model.annealed_importance_sampler.p_target is False          # restored to the min-variance target
+
+
+@pytest.mark.parametrize("optimiser", ["torch_adam", "flat_adam"])
+def test_plain_trainer_fab_alpha_div_loss(optimiser, tmp_path):
+    """fab/train.py:96-136 with FABModel.loss = fab_alpha_div (core.py:112-128): the loss value equals
+    -mean(softmax(log_w) * log q(x)) recomputed with the PyTorch-ROCm expression on the same AIS samples, training
+    reduces nothing to NaN, evaluation info and checkpoints appear at the requested iterations."""
+    torch.manual_seed(0)
+    D, B = 6, 256
+    flow = fa.RealNVP(D, 3, 6).to(DEV)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(2, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.3, L=3).to(DEV)
+    model = fa.FABModel(flow, target, 2, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
+    # loss definition on fixed samples
+    pt, lw = model.annealed_importance_sampler.sample_and_log_weights(B)
+    loss_hip = model.fab_alpha_div_inner(pt, lw)
+    loss_ref = -torch.mean(torch.softmax(lw, dim=-1) * flow._torch_log_prob(pt.x))
+    assert abs(float(loss_hip) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
+    opt = torch.optim.Adam(flow.parameters(), lr=1e-3) if optimiser == "torch_adam" else fa.FlatAdam(flow, lr=1e-3)
+    trainer = fa.Trainer(model, opt, max_gradient_norm=100.0, save_path=str(tmp_path))
+    before = [p.detach().clone() for p in flow.parameters()]
+    hist = trainer.run(12, B, eval_batch_size=512, n_eval=2, n_checkpoints=2)
+    assert len(hist) == 12 and all(np.isfinite(h["loss"]) and np.isfinite(h["grad_norm"]) for h in hist)
+    assert "eval_ess_ais" in hist[0] and "eval_ess_ais" in hist[-1] and "eval_ess_ais" not in hist[5]
+    assert (tmp_path / "model_checkpoints" / "iter_1" / "model.pt").exists()
+    assert (tmp_path / "model_checkpoints" / "iter_12" / "optimizer.pt").exists()
+    assert any(float((a - b.detach()).abs().max()) > 0 for a, b in zip(before, flow.parameters()))
+    assert model.annealed_importance_sampler.p_target is False
