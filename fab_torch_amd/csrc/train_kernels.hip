@@ -102,11 +102,16 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
                                                     long B, float* __restrict__ grads, float* __restrict__ ga_ws) {
     __shared__ __attribute__((aligned(16))) float Ys[2][GK * GLD];
     __shared__ __attribute__((aligned(16))) float Xs[2][GK * GLD];
-    int layer = blockIdx.x / gb.per_layer;
-    int b = blockIdx.x % gb.per_layer;
+    // XCD-aware order: consecutive blockIdx go to different XCDs (blockIdx % 8), so give XCD x the x-th eighth of
+    // the logical block list -> the blocks that re-read the same Y / X panels share one L2
+    const int nlog = f.K * gb.per_layer;
+    int logical = blockIdx.x;
+    if ((int)blockIdx.x < (nlog & ~7)) logical = (blockIdx.x & 7) * (nlog >> 3) + (blockIdx.x >> 3);
+    int layer = logical / gb.per_layer;
+    int b = logical % gb.per_layer;
     // largest problem first; the blocks after the K layers are the base distribution (kind 5)
     int kind, qblocks;
-    if (layer >= f.K) { b = blockIdx.x - f.K * gb.per_layer; layer = 0; kind = 5; qblocks = gb.q1; }
+    if (layer >= f.K) { b = logical - f.K * gb.per_layer; layer = 0; kind = 5; qblocks = gb.q1; }
     else if (b < gb.n2) { kind = 2; qblocks = gb.q2; }
     else if ((b -= gb.n2) < gb.n1) { kind = 1; qblocks = gb.q1; }
     else if ((b -= gb.n1) < gb.n3) { kind = 3; qblocks = gb.q3; }
