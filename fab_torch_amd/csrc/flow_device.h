@@ -243,14 +243,34 @@ __device__ __forceinline__ void ksplit_mul(const float4 (&b)[KW], const float* _
     for (int r = 0; r < 4; ++r) pw[(4 * t.q + r) * PN + 16 * tile + t.n] = acc0[r] + acc1[r];
 }
 
+// weights of the first two column tiles of a K-split GEMM, requested by the producer stage before its epilogue
+// (plain, compiler-tracked loads: safe to keep live across any code)
 template <int KW>
+struct KsplitPre {
+    float4 b0[KW], b1[KW];
+};
+
+template <int KW>
+__device__ __forceinline__ void ksplit_prefetch(KsplitPre<KW>& pre, const float4* __restrict__ Bp, int NT, const Tid& t) {
+    ksplit_load<KW>(pre.b0, Bp, 0, t);
+    if (NT > 1) ksplit_load<KW>(pre.b1, Bp, 1, t);
+    __builtin_amdgcn_sched_barrier(0);          // keep the requests ahead of the producer's epilogue
+}
+
+template <int KW, bool PRE = false>
 __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda, const float4* __restrict__ Bp,
-                                            int NT, float* __restrict__ part, int PN, const Tid& t) {
+                                            int NT, float* __restrict__ part, int PN, const Tid& t,
+                                            const KsplitPre<KW>* pre = nullptr) {
     const float* arow = A + t.n * lda + 4 * t.q;
     float* pw = part + (size_t)t.wave * ROWS * PN;
     float4 b0[KW], b1[KW];
-    ksplit_load<KW>(b0, Bp, 0, t);
-    if (NT > 1) ksplit_load<KW>(b1, Bp, 1, t);
+    if (PRE) {
+#pragma unroll
+        for (int s = 0; s < KW; ++s) { b0[s] = pre->b0[s]; b1[s] = pre->b1[s]; }
+    } else {
+        ksplit_load<KW>(b0, Bp, 0, t);
+        if (NT > 1) ksplit_load<KW>(b1, Bp, 1, t);
+    }
     __builtin_amdgcn_sched_barrier(0);
     ksplit_mul<KW>(b0, arow, pw, PN, 0, t);
     if (NT > 1) {
@@ -278,14 +298,20 @@ __device__ __forceinline__ float part_sum(const float* part, int PN, int row, in
 // ReLU sign pattern of this lane's 4*NTWM outputs is kept as one 32-bit word per thread (bit 4 i + r) for the
 // reverse sweep: the same lane of the same wave owns the same (tile, register) there, so no cross-lane
 // exchange and a single LDS store per GEMM.
-template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false>
+// With KSP the weights of the K-split GEMM that consumes OUT are requested right after the main loop: that GEMM
+// reads only the columns this wave writes here (its k-blocks S = wave + 4 s are this wave's column tiles), so it
+// follows without a workgroup barrier and finds its first weights already on the way.
+template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, bool KSP = false>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                            const float* __restrict__ bias, float* OUT, int ldo, unsigned* mask,
-                                           const Tid& t, float* __restrict__ gout = nullptr, int ldg = 0) {
+                                           const Tid& t, float* __restrict__ gout = nullptr, int ldg = 0,
+                                           KsplitPre<NTWM>* pre = nullptr, const float4* Bnext = nullptr,
+                                           int NTnext = 0) {
     f32x4 acc[NTWM];
     WRing<NTWM, DEPTH> w;
     ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
     ring_run<NTWM, DEPTH, MASKK, true>(w, A, lda, kmax, KB, Bp, t, acc);
+    if (KSP) ksplit_prefetch<NTWM>(*pre, Bnext, NTnext, t);
     unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
@@ -304,10 +330,12 @@ __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, in
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
-template <int NTWM, int DEPTH, bool TAPE = false>
+template <int NTWM, int DEPTH, bool TAPE = false, bool KSP = false>
 __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, const float4* Bp, float* OUT,
                                              int ldo, const unsigned* mask, const Tid& t,
-                                             float* __restrict__ gout = nullptr, int ldg = 0) {
+                                             float* __restrict__ gout = nullptr, int ldg = 0,
+                                             KsplitPre<NTWM>* pre = nullptr, const float4* Bnext = nullptr,
+                                             int NTnext = 0) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -315,6 +343,7 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
     ring_issue<NTWM, DEPTH, false>(w, Bp, KB, nullptr, t);
     const unsigned m = mask[t.tid];
     ring_run<NTWM, DEPTH, false, false>(w, A, lda, 0, KB, Bp, t, acc);
+    if (KSP) ksplit_prefetch<NTWM>(*pre, Bnext, NTnext, t);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
@@ -405,13 +434,16 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (tl) FAB_TL(f, 3);
         __syncthreads();
         if (tl) FAB_TL(f, 4);
-        dense_relu<NTWM, DW, false, GRAD, TAPE>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
-                                                TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr,
-                                                TAPE ? td->wh : 0);
+        KsplitPre<NTWM> kp;
+        dense_relu<NTWM, DW, false, GRAD, TAPE, true>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS,
+                                                      mk + NTHREADS, t,
+                                                      TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr,
+                                                      TAPE ? td->wh : 0, &kp, W3, f.NTO);
         if (tl) FAB_TL(f, 5);
-        __syncthreads();
+        // no workgroup barrier: the K-split GEMM reads only this wave's own columns of HB (LDS is in-order per wave)
+        __builtin_amdgcn_wave_barrier();
         if (tl) FAB_TL(f, 6);
-        gemm_ksplit<NTWM>(HB, l.WS, W3, f.NTO, PART, l.PN, t);
+        gemm_ksplit<NTWM, true>(HB, l.WS, W3, f.NTO, PART, l.PN, t, &kp);
         if (tl) FAB_TL(f, 7);
         __syncthreads();
         if (tl) FAB_TL(f, 8);
@@ -485,12 +517,14 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (tl) FAB_TL(f, 19);
         __syncthreads();
         if (tl) FAB_TL(f, 20);
-        dense_masked<NTWM, DW, TAPE>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t,
-                                     TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0);
+        KsplitPre<NTWM> kp;
+        dense_masked<NTWM, DW, TAPE, true>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t,
+                                           TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0,
+                                           &kp, W1T, f.NTd);
         if (tl) FAB_TL(f, 21);
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();              // as in the forward sweep: own columns only, no barrier
         if (tl) FAB_TL(f, 22);
-        gemm_ksplit<NTWM>(HB, l.WS, W1T, f.NTd, PART, l.PN, t);
+        gemm_ksplit<NTWM, true>(HB, l.WS, W1T, f.NTd, PART, l.PN, t, &kp);
         if (tl) FAB_TL(f, 23);
         __syncthreads();
         if (tl) FAB_TL(f, 24);
