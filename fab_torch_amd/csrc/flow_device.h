@@ -243,17 +243,17 @@ __device__ __forceinline__ void ksplit_mul(const float4 (&b)[KW], const float* _
     for (int r = 0; r < 4; ++r) pw[(4 * t.q + r) * PN + 16 * tile + t.n] = acc0[r] + acc1[r];
 }
 
-// weights of the first two column tiles of a K-split GEMM, requested by the producer stage before its epilogue
+// weights of the first column tile of a K-split GEMM, requested by the producer stage before its epilogue
 // (plain, compiler-tracked loads: safe to keep live across any code)
 template <int KW>
 struct KsplitPre {
-    float4 b0[KW], b1[KW];
+    float4 b0[KW];
 };
 
 template <int KW>
 __device__ __forceinline__ void ksplit_prefetch(KsplitPre<KW>& pre, const float4* __restrict__ Bp, int NT, const Tid& t) {
+    (void)NT;                                   // only the first tile: more live registers slow the epilogue down
     ksplit_load<KW>(pre.b0, Bp, 0, t);
-    if (NT > 1) ksplit_load<KW>(pre.b1, Bp, 1, t);
     __builtin_amdgcn_sched_barrier(0);          // keep the requests ahead of the producer's epilogue
 }
 
@@ -266,11 +266,11 @@ __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda
     float4 b0[KW], b1[KW];
     if (PRE) {
 #pragma unroll
-        for (int s = 0; s < KW; ++s) { b0[s] = pre->b0[s]; b1[s] = pre->b1[s]; }
+        for (int s = 0; s < KW; ++s) b0[s] = pre->b0[s];
     } else {
         ksplit_load<KW>(b0, Bp, 0, t);
-        if (NT > 1) ksplit_load<KW>(b1, Bp, 1, t);
     }
+    if (NT > 1) ksplit_load<KW>(b1, Bp, 1, t);
     __builtin_amdgcn_sched_barrier(0);
     ksplit_mul<KW>(b0, arow, pw, PN, 0, t);
     if (NT > 1) {
@@ -294,6 +294,100 @@ __device__ __forceinline__ float part_sum(const float* part, int PN, int row, in
     return s;
 }
 
+// ---- short-K GEMMs (K = 16 KB, KB <= 4: the first conditioner layer and the first reverse GEMM): all of the
+// wave's weights fit in registers, so they are requested with plain (compiler-tracked) loads one stage EARLY and
+// stay live across the stage in between and its barrier; the stage itself is then MFMAs + epilogue only.
+template <int NTWM, int KB>
+struct SmallW {
+    float4 b[KB][NTWM];
+    float bv[NTWM];
+};
+
+template <int NTWM, int KB, bool BIAS>
+__device__ __forceinline__ void smallw_load(SmallW<NTWM, KB>& w, const float4* __restrict__ Bp,
+                                            const float* __restrict__ bias, const Tid& t) {
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const float4* bt = Bp + ((size_t)(t.wave + 4 * i) * KB) * 64 + t.lane;
+#pragma unroll
+        for (int S = 0; S < KB; ++S) w.b[S][i] = bt[(size_t)S * 64];
+        w.bv[i] = BIAS ? bias[16 * (t.wave + 4 * i) + t.n] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);          // the requests stay ahead of whatever follows
+}
+
+template <int NTWM, int KB, bool MASKK>
+__device__ __forceinline__ void smallw_mul(const SmallW<NTWM, KB>& w, const float* __restrict__ A, int lda, int kmax,
+                                           const Tid& t, f32x4 (&acc)[NTWM]) {
+    const float* arow = A + t.n * lda + 4 * t.q;
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){w.bv[i], w.bv[i], w.bv[i], w.bv[i]};
+#pragma unroll
+    for (int S = 0; S < KB; ++S) {
+        float4 a = *reinterpret_cast<const float4*>(arow + 16 * S);
+        if (MASKK) {
+            const int k0 = 16 * S + 4 * t.q;
+            a.x = (k0 + 0 < kmax) ? a.x : 0.f;
+            a.y = (k0 + 1 < kmax) ? a.y : 0.f;
+            a.z = (k0 + 2 < kmax) ? a.z : 0.f;
+            a.w = (k0 + 3 < kmax) ? a.w : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.x, w.b[S][i].x, acc[i]);
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.y, w.b[S][i].y, acc[i]);
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, w.b[S][i].z, acc[i]);
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, w.b[S][i].w, acc[i]);
+    }
+}
+
+// OUT = relu(A @ B + bias) with pre-loaded weights (same epilogue as dense_relu)
+template <int NTWM, int KB, bool MASK, bool TAPE>
+__device__ __forceinline__ void dense_relu_small(const SmallW<NTWM, KB>& w, const float* A, int lda, int kmax,
+                                                 float* OUT, int ldo, unsigned* mask, const Tid& t,
+                                                 float* __restrict__ gout, int ldg) {
+    f32x4 acc[NTWM];
+    smallw_mul<NTWM, KB, true>(w, A, lda, kmax, t, acc);
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const int c = t.wave + 4 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[i][r];
+            const bool pos = v > 0.f;
+            const float o = pos ? v : 0.f;
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
+            if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
+            if (MASK) m |= (pos ? 1u : 0u) << (4 * i + r);
+        }
+    }
+    if (MASK) mask[t.tid] = m;
+}
+
+// OUT = (A @ B) * mask with pre-loaded weights (same epilogue as dense_masked)
+template <int NTWM, int KB, bool TAPE>
+__device__ __forceinline__ void dense_masked_small(const SmallW<NTWM, KB>& w, const float* A, int lda, float* OUT,
+                                                   int ldo, const unsigned* mask, const Tid& t,
+                                                   float* __restrict__ gout, int ldg) {
+    f32x4 acc[NTWM];
+    const unsigned m = mask[t.tid];
+    smallw_mul<NTWM, KB, false>(w, A, lda, 0, t, acc);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const int c = t.wave + 4 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bool pos = (m >> (4 * i + r)) & 1u;
+            const float o = pos ? acc[i][r] : 0.f;
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
+            if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
+        }
+    }
+}
+
 // hidden layer: OUT = relu(A @ B + bias).  With MASK the
 // ReLU sign pattern of this lane's 4*NTWM outputs is kept as one 32-bit word per thread (bit 4 i + r) for the
 // reverse sweep: the same lane of the same wave owns the same (tile, register) there, so no cross-lane
@@ -301,17 +395,22 @@ __device__ __forceinline__ float part_sum(const float* part, int PN, int row, in
 // With KSP the weights of the K-split GEMM that consumes OUT are requested right after the main loop: that GEMM
 // reads only the columns this wave writes here (its k-blocks S = wave + 4 s are this wave's column tiles), so it
 // follows without a workgroup barrier and finds its first weights already on the way.
-template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, bool KSP = false>
+struct NoPost {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+// `post` runs between the main loop and the epilogue: the place to request (plain loads) weights of later stages,
+// whose latency then hides behind this epilogue and the stages in between.
+template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, class Post = NoPost>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                            const float* __restrict__ bias, float* OUT, int ldo, unsigned* mask,
                                            const Tid& t, float* __restrict__ gout = nullptr, int ldg = 0,
-                                           KsplitPre<NTWM>* pre = nullptr, const float4* Bnext = nullptr,
-                                           int NTnext = 0) {
+                                           Post post = Post()) {
     f32x4 acc[NTWM];
     WRing<NTWM, DEPTH> w;
     ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
     ring_run<NTWM, DEPTH, MASKK, true>(w, A, lda, kmax, KB, Bp, t, acc);
-    if (KSP) ksplit_prefetch<NTWM>(*pre, Bnext, NTnext, t);
+    post();
     unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
@@ -330,12 +429,10 @@ __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, in
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
-template <int NTWM, int DEPTH, bool TAPE = false, bool KSP = false>
+template <int NTWM, int DEPTH, bool TAPE = false, class Post = NoPost>
 __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, const float4* Bp, float* OUT,
                                              int ldo, const unsigned* mask, const Tid& t,
-                                             float* __restrict__ gout = nullptr, int ldg = 0,
-                                             KsplitPre<NTWM>* pre = nullptr, const float4* Bnext = nullptr,
-                                             int NTnext = 0) {
+                                             float* __restrict__ gout = nullptr, int ldg = 0, Post post = Post()) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -343,7 +440,7 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
     ring_issue<NTWM, DEPTH, false>(w, Bp, KB, nullptr, t);
     const unsigned m = mask[t.tid];
     ring_run<NTWM, DEPTH, false, false>(w, A, lda, 0, KB, Bp, t, acc);
-    if (KSP) ksplit_prefetch<NTWM>(*pre, Bnext, NTnext, t);
+    post();
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
@@ -398,9 +495,16 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
     float* PART = lds + l.o_PART;
     float* HA = lds + l.o_HA;
     float* HB = lds + l.o_HB;
+    // the first conditioner layer's weights (K = dp = 32 always: D <= 64) live in registers and are requested a
+    // whole long stage early (ahead of the previous layer's W x W GEMM), so that neither their latency nor
+    // hipcc's vmcnt(0) in front of the barriers in between costs anything
+    SmallW<NTWM, 2> w1r;
+    {
+        const float* Lp = packed + (size_t)(f.K - 1) * f.layer_stride;
+        smallw_load<NTWM, 2, true>(w1r, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1, t);
+    }
     for (int layer = f.K - 1; layer >= 0; --layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
-        const float4* W1 = reinterpret_cast<const float4*>(Lp + f.o_W1);
         const float4* W2 = reinterpret_cast<const float4*>(Lp + f.o_W2);
         const float4* W3 = reinterpret_cast<const float4*>(Lp + f.o_W3);
         unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
@@ -429,16 +533,22 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
             tl_layer[td->o_H2 + (row0 + r) * td->wh + f.Wp + j] = one;
         }
         // ---- conditioner MLP: relu(relu(z1 W1 + b1) W2 + b2) W3' ----------------------------------------
-        dense_relu<NTWM, 2, true, GRAD, TAPE>(Z, l.DS, f.d, f.KBd, W1, Lp + f.o_b1, HA, l.WS, mk, t,
+        dense_relu_small<NTWM, 2, GRAD, TAPE>(w1r, Z, l.DS, f.d, HA, l.WS, mk, t,
                                               TAPE ? tl_layer + td->o_H1 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
         if (tl) FAB_TL(f, 3);
         __syncthreads();
         if (tl) FAB_TL(f, 4);
         KsplitPre<NTWM> kp;
-        dense_relu<NTWM, DW, false, GRAD, TAPE, true>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS,
-                                                      mk + NTHREADS, t,
-                                                      TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr,
-                                                      TAPE ? td->wh : 0, &kp, W3, f.NTO);
+        auto post_fwd = [&]() {                           // after the W x W main loop, ahead of its epilogue:
+            ksplit_prefetch<NTWM>(kp, W3, f.NTO, t);      //   first tile of the K-split GEMM that follows
+            if (layer > 0) {                              //   next layer's W1, b1 (w1r was consumed above)
+                const float* Ln = packed + (size_t)(layer - 1) * f.layer_stride;
+                smallw_load<NTWM, 2, true>(w1r, reinterpret_cast<const float4*>(Ln + f.o_W1), Ln + f.o_b1, t);
+            }
+        };
+        dense_relu<NTWM, DW, false, GRAD, TAPE>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
+                                                TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr,
+                                                TAPE ? td->wh : 0, post_fwd);
         if (tl) FAB_TL(f, 5);
         // no workgroup barrier: the K-split GEMM reads only this wave's own columns of HB (LDS is in-order per wave)
         __builtin_amdgcn_wave_barrier();
@@ -489,9 +599,14 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
 
     // ---- reverse sweep: g = d log q / d(state), layers 0 .. K-1 -----------------------------------
     float* DP = lds + l.o_DP;
+    // first reverse GEMM (K = 2 DOp): with 2 k-blocks (D <= 32) its weights are register-resident and requested
+    // behind the previous layer's W x W main loop; with 4 k-blocks (D > 32) the streaming version is used (keeping
+    // a second, 85-register variant alive across the loop costs more than it hides)
+    SmallW<NTWM, 2> w3a;
+    const bool kbo2 = f.KBO == 2;
+    if (kbo2) smallw_load<NTWM, 2, false>(w3a, reinterpret_cast<const float4*>(packed + f.o_W3T), nullptr, t);
     for (int layer = 0; layer < f.K; ++layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
-        const float4* W3T = reinterpret_cast<const float4*>(Lp + f.o_W3T);
         const float4* W2T = reinterpret_cast<const float4*>(Lp + f.o_W2T);
         const float4* W1T = reinterpret_cast<const float4*>(Lp + f.o_W1T);
         const float4* AWT = reinterpret_cast<const float4*>(Lp + f.o_AWT);
@@ -512,15 +627,27 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         const unsigned* mk = reinterpret_cast<const unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
         float* tl_layer = TAPE ? tape + (size_t)layer * td->layer_stride : nullptr;
         if (TAPE) tape_copy(tl_layer + td->o_DP + row0 * td->wp, td->wp, DP, l.PS, t);
-        dense_masked<NTWM, 2, TAPE>(DP, l.PS, f.KBO, W3T, HA, l.WS, mk + NTHREADS, t,
-                                    TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0);
+        if (kbo2)
+            dense_masked_small<NTWM, 2, TAPE>(w3a, DP, l.PS, HA, l.WS, mk + NTHREADS, t,
+                                              TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0);
+        else
+            dense_masked<NTWM, 2, TAPE>(DP, l.PS, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), HA, l.WS,
+                                        mk + NTHREADS, t, TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr,
+                                        TAPE ? td->we : 0);
         if (tl) FAB_TL(f, 19);
         __syncthreads();
         if (tl) FAB_TL(f, 20);
         KsplitPre<NTWM> kp;
-        dense_masked<NTWM, DW, TAPE, true>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t,
-                                           TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0,
-                                           &kp, W1T, f.NTd);
+        auto post_bwd = [&]() {
+            ksplit_prefetch<NTWM>(kp, W1T, f.NTd, t);
+            if (kbo2 && layer + 1 < f.K)                  // next layer's W3'^T
+                smallw_load<NTWM, 2, false>(
+                    w3a, reinterpret_cast<const float4*>(packed + (size_t)(layer + 1) * f.layer_stride + f.o_W3T),
+                    nullptr, t);
+        };
+        dense_masked<NTWM, DW, TAPE>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t,
+                                     TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0,
+                                     post_bwd);
         if (tl) FAB_TL(f, 21);
         __builtin_amdgcn_wave_barrier();              // as in the forward sweep: own columns only, no barrier
         if (tl) FAB_TL(f, 22);
