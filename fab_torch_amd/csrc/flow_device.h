@@ -395,6 +395,17 @@ __device__ __forceinline__ void dense_masked_small(const SmallW<NTWM, KB>& w, co
 // With KSP the weights of the K-split GEMM that consumes OUT are requested right after the main loop: that GEMM
 // reads only the columns this wave writes here (its k-blocks S = wave + 4 s are this wave's column tiles), so it
 // follows without a workgroup barrier and finds its first weights already on the way.
+// OUT[16 x 16*NT] = A @ B for the D x D affine maps with pre-loaded weights (tile = wave, KB = 2: D <= 32)
+__device__ __forceinline__ void dense_small_pre(const SmallW<1, 2>& w, const float* A, int lda, int kmax, int NT,
+                                                float* OUT, int ldo, const Tid& t) {
+    if (t.wave < NT) {
+        f32x4 acc[1];
+        smallw_mul<1, 2, true>(w, A, lda, kmax, t, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) OUT[(4 * t.q + r) * ldo + 16 * t.wave + t.n] = acc[0][r];
+    }
+}
+
 struct NoPost {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -499,9 +510,12 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
     // whole long stage early (ahead of the previous layer's W x W GEMM), so that neither their latency nor
     // hipcc's vmcnt(0) in front of the barriers in between costs anything
     SmallW<NTWM, 2> w1r;
+    SmallW<1, 2> awr;                                     // the layer's D x D affine map (register path: D <= 32)
+    const bool kbd2 = f.KBD == 2;
     {
         const float* Lp = packed + (size_t)(f.K - 1) * f.layer_stride;
         smallw_load<NTWM, 2, true>(w1r, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1, t);
+        if (kbd2) smallw_load<1, 2, false>(awr, reinterpret_cast<const float4*>(Lp + f.o_AW), nullptr, t);
     }
     for (int layer = f.K - 1; layer >= 0; --layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
@@ -513,8 +527,9 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         float* tl_layer = TAPE ? tape + (size_t)layer * td->layer_stride : nullptr;
         if (TAPE) tape_copy(tl_layer + td->o_ZA + row0 * td->wz, td->wz, lds + cur, l.DS, t);
         // ---- InvertibleAffine.inverse: z <- z @ (P L U), log_det = +sum(log_S) --------------------------
-        dense_small(lds + cur, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AW), f.NTD, lds + nxt,
-                    l.DS, t);
+        if (kbd2) dense_small_pre(awr, lds + cur, l.DS, f.D, f.NTD, lds + nxt, l.DS, t);
+        else dense_small(lds + cur, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AW), f.NTD, lds + nxt,
+                         l.DS, t);
         logq += Lp[f.o_logS];
         if (tl) FAB_TL(f, 1);
         __syncthreads();
@@ -539,11 +554,19 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         __syncthreads();
         if (tl) FAB_TL(f, 4);
         KsplitPre<NTWM> kp;
+        float b3s[2], b3c[2];                             // coupling biases of this thread's columns (D - d <= 32)
         auto post_fwd = [&]() {                           // after the W x W main loop, ahead of its epilogue:
             ksplit_prefetch<NTWM>(kp, W3, f.NTO, t);      //   first tile of the K-split GEMM that follows
-            if (layer > 0) {                              //   next layer's W1, b1 (w1r was consumed above)
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {              //   biases of the coupling stage
+                const int j = t.c + 16 * it;
+                b3s[it] = j < f.DO ? Lp[f.o_b3 + j] : 0.f;
+                b3c[it] = j < f.DO ? Lp[f.o_b3 + f.DOp + j] : 0.f;
+            }
+            if (layer > 0) {                              //   next layer's W1, b1, affine (consumed above already)
                 const float* Ln = packed + (size_t)(layer - 1) * f.layer_stride;
                 smallw_load<NTWM, 2, true>(w1r, reinterpret_cast<const float4*>(Ln + f.o_W1), Ln + f.o_b1, t);
+                if (kbd2) smallw_load<1, 2, false>(awr, reinterpret_cast<const float4*>(Ln + f.o_AW), nullptr, t);
             }
         };
         dense_relu<NTWM, DW, false, GRAD, TAPE>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
@@ -559,17 +582,21 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (tl) FAB_TL(f, 8);
         // ---- AffineCoupling.inverse: z2 <- (z2 - shift) * exp(-s), log_det = -sum(s) ----------------------
         float ssum = 0.f;
-        for (int j = t.c; j < f.DO; j += 16) {
-            const float shift = part_sum(PART, l.PN, t.row, j) + Lp[f.o_b3 + j];
-            const float s = part_sum(PART, l.PN, t.row, f.DOp + j) + Lp[f.o_b3 + f.DOp + j];
-            const float es = expf(-s);
-            const float v2 = (Z[t.row * l.DS + f.d + j] - shift) * es;
-            Z[t.row * l.DS + f.d + j] = v2;
-            if (GRAD) {
-                lds[l.o_ES + ((size_t)layer * ROWS + t.row) * f.DOp + j] = es;
-                lds[l.o_V2 + ((size_t)layer * ROWS + t.row) * f.DOp + j] = v2;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int j = t.c + 16 * it;
+            if (j < f.DO) {
+                const float shift = part_sum(PART, l.PN, t.row, j) + b3s[it];
+                const float s = part_sum(PART, l.PN, t.row, f.DOp + j) + b3c[it];
+                const float es = expf(-s);
+                const float v2 = (Z[t.row * l.DS + f.d + j] - shift) * es;
+                Z[t.row * l.DS + f.d + j] = v2;
+                if (GRAD) {
+                    lds[l.o_ES + ((size_t)layer * ROWS + t.row) * f.DOp + j] = es;
+                    lds[l.o_V2 + ((size_t)layer * ROWS + t.row) * f.DOp + j] = v2;
+                }
+                ssum += s;
             }
-            ssum += s;
         }
         logq += -row16_sum(ssum);
         if (tl) FAB_TL(f, 10);
@@ -638,8 +665,10 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         __syncthreads();
         if (tl) FAB_TL(f, 20);
         KsplitPre<NTWM> kp;
+        SmallW<1, 2> awtr;                                // this layer's affine^T, used three short stages below
         auto post_bwd = [&]() {
             ksplit_prefetch<NTWM>(kp, W1T, f.NTd, t);
+            if (kbd2) smallw_load<1, 2, false>(awtr, AWT, nullptr, t);
             if (kbo2 && layer + 1 < f.K)                  // next layer's W3'^T
                 smallw_load<NTWM, 2, false>(
                     w3a, reinterpret_cast<const float4*>(packed + (size_t)(layer + 1) * f.layer_stride + f.o_W3T),
@@ -661,7 +690,8 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (tl) FAB_TL(f, 26);
         if (TAPE) tape_copy(tl_layer + td->o_GZ + row0 * td->wz, td->wz, G, l.DS, t);
         // ---- through InvertibleAffine.inverse: g <- g @ W^T -----------------------------------------------
-        dense_small(G, l.DS, f.D, f.KBD, AWT, f.NTD, lds + nxt, l.DS, t);
+        if (kbd2) dense_small_pre(awtr, G, l.DS, f.D, f.NTD, lds + nxt, l.DS, t);
+        else dense_small(G, l.DS, f.D, f.KBD, AWT, f.NTD, lds + nxt, l.DS, t);
         if (tl) FAB_TL(f, 27);
         __syncthreads();
         if (tl) FAB_TL(f, 28);
