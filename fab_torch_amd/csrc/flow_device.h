@@ -142,11 +142,51 @@ __device__ __forceinline__ void ring_issue(WRing<NTWM, DEPTH>& w, const float4* 
     }
 }
 
+// k-block 0 of a W x W GEMM (+ its bias), requested with plain loads one stage early: the main loop then starts
+// on data that is already there while the hidden ring loads of blocks 1 .. DEPTH-1 are still on their way.
+template <int NTWM>
+struct RingPre {
+    float4 b[NTWM];
+    float bv[NTWM];
+};
+
+template <int NTWM, bool BIAS>
+__device__ __forceinline__ void ringpre_load(RingPre<NTWM>& p, const float4* __restrict__ Bp, int KB,
+                                             const float* __restrict__ bias, const Tid& t) {
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        p.b[i] = Bp[((size_t)(t.wave + 4 * i) * KB) * 64 + t.lane];
+        p.bv[i] = BIAS ? bias[16 * (t.wave + 4 * i) + t.n] : 0.f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NTWM, int DEPTH>
+__device__ __forceinline__ void ring_issue_pre(WRing<NTWM, DEPTH>& w, const RingPre<NTWM>& p,
+                                               const float4* __restrict__ Bp, int KB, const Tid& t) {
+    const float4* bw = Bp + (size_t)t.wave * KB * 64;
+    unsigned voff[NTWM];
+    tile_offsets<NTWM>(voff, KB, t);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {                      // the compiler waits for the plain loads HERE, before any
+        w.r[0][i] = (f32x4){p.b[i].x, p.b[i].y, p.b[i].z, p.b[i].w};   // hidden load is in flight
+        w.bv[i] = p.bv[i];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int d = 1; d < DEPTH; ++d) {
+        const float4* sb = bw + (size_t)d * 64;
+        gload16s_first(w.r[d][0], voff[0], sb);
+#pragma unroll
+        for (int i = 1; i < NTWM; ++i) gload16s(w.r[d][i], voff[i], sb);
+    }
+}
+
 // main loop on a ring whose prologue was issued earlier and after which NO other hidden load was issued.
 // Loop schedule per k-block S (ring slot d = S mod DEPTH), pinned with sched_barrier:
 //   wait slot d  |  NTWM MFMA (a.x)  |  refill the slot of block S-1 with block S-1+DEPTH  |  3 NTWM MFMA
 // so the refill's address arithmetic and load issue run in the shadow of the matrix pipe.
-template <int NTWM, int DEPTH, bool MASKK, bool BIAS>
+template <int NTWM, int DEPTH, bool MASKK, bool BIAS, bool PRE = false>
 __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __restrict__ A, int lda, int kmax,
                                          int KB, const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM]) {
     static_assert(DEPTH >= 2, "ring depth");
@@ -156,8 +196,10 @@ __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __r
     tile_offsets<NTWM>(voff, KB, t);
     float4 a_nxt = *reinterpret_cast<const float4*>(arow);
     if (BIAS) {
-        wait_vals<DEPTH * NTWM, NTWM>(w.bv);                       // the ring (younger) may stay in flight
-        __builtin_amdgcn_sched_barrier(0);
+        if (!PRE) {
+            wait_vals<DEPTH * NTWM, NTWM>(w.bv);                   // the ring (younger) may stay in flight
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){w.bv[i], w.bv[i], w.bv[i], w.bv[i]};
     }
@@ -176,30 +218,46 @@ __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __r
                 a.w = (k0 + 3 < kmax) ? a.w : 0.f;
             }
             // slot d was (re)filled during block S-DEPTH+1; DEPTH-2 younger refill groups may stay in flight
-            wait_tiles<(DEPTH - 2) * NTWM, NTWM>(w.r[d]);
+            // (with PRE, block 0 came through plain loads and is complete: no wait in front of its MFMAs)
+            if (!(PRE && d == 0 && S0 == 0)) wait_tiles<(DEPTH - 2) * NTWM, NTWM>(w.r[d]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.x, w.r[d][i].x, acc[i]);
             __builtin_amdgcn_sched_barrier(0);
-            if (S > 0) {
-                // refill the slot consumed by block S-1 with block S-1+DEPTH (clamped: the tail re-reads the
-                // last block, which keeps the in-flight count constant so the hand-counted vmcnt stays exact)
+#ifndef FAB_EXP_QUARTER_MFMA        // experiment only (wrong results): 1 MFMA per 16 B of weights, the load:MFMA
+                                    // ratio a 4-chain tile (v_mfma_f32_4x4x1) would have
+            // refill the slot consumed by block S-1 with block S-1+DEPTH (clamped: the tail re-reads the last
+            // block, which keeps the in-flight count constant so the hand-counted vmcnt stays exact) - ONE load
+            // behind each MFMA of the a.y group, so that no gap between two MFMAs carries more than the matrix
+            // pipe's 32-cycle shadow hides (a block of 5 loads + address arithmetic stalled it ~100 cycles/k-block)
+            {
                 const int dp = (d + DEPTH - 1) % DEPTH;      // static after unrolling
+                const int Sp = (S - 1 + DEPTH < KB) ? S - 1 + DEPTH : KB - 1;
+                const float4* sb = bw + (size_t)Sp * 64;
+#pragma unroll
+                for (int i = 0; i < NTWM; ++i) {
+                    acc[i] = mfma4(a.y, w.r[d][i].y, acc[i]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (S > 0) {
+                        if (i == 0) gload16s_first(w.r[dp][0], voff[0], sb);
+                        else gload16s(w.r[dp][i], voff[i], sb);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, w.r[d][i].z, acc[i]);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, w.r[d][i].w, acc[i]);
+#else
+            if (S > 0) {
+                const int dp = (d + DEPTH - 1) % DEPTH;
                 const int Sp = (S - 1 + DEPTH < KB) ? S - 1 + DEPTH : KB - 1;
                 const float4* sb = bw + (size_t)Sp * 64;
                 gload16s_first(w.r[dp][0], voff[0], sb);
 #pragma unroll
                 for (int i = 1; i < NTWM; ++i) gload16s(w.r[dp][i], voff[i], sb);
             }
-            __builtin_amdgcn_sched_barrier(0);
-#ifndef FAB_EXP_QUARTER_MFMA        // experiment only (wrong results): 1 MFMA per 16 B of weights, the load:MFMA
-                                    // ratio a 4-chain tile (v_mfma_f32_4x4x1) would have
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.y, w.r[d][i].y, acc[i]);
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, w.r[d][i].z, acc[i]);
-#pragma unroll
-            for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, w.r[d][i].w, acc[i]);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -412,15 +470,16 @@ struct NoPost {
 
 // `post` runs between the main loop and the epilogue: the place to request (plain loads) weights of later stages,
 // whose latency then hides behind this epilogue and the stages in between.
-template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, class Post = NoPost>
+template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, class Post = NoPost, bool PRE = false>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                            const float* __restrict__ bias, float* OUT, int ldo, unsigned* mask,
                                            const Tid& t, float* __restrict__ gout = nullptr, int ldg = 0,
-                                           Post post = Post()) {
+                                           Post post = Post(), const RingPre<NTWM>* pre = nullptr) {
     f32x4 acc[NTWM];
     WRing<NTWM, DEPTH> w;
-    ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
-    ring_run<NTWM, DEPTH, MASKK, true>(w, A, lda, kmax, KB, Bp, t, acc);
+    if (PRE) ring_issue_pre<NTWM, DEPTH>(w, *pre, Bp, KB, t);
+    else ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
+    ring_run<NTWM, DEPTH, MASKK, true, PRE>(w, A, lda, kmax, KB, Bp, t, acc);
     post();
     unsigned m = 0u;
 #pragma unroll
@@ -440,17 +499,19 @@ __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, in
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
-template <int NTWM, int DEPTH, bool TAPE = false, class Post = NoPost>
+template <int NTWM, int DEPTH, bool TAPE = false, class Post = NoPost, bool PRE = false>
 __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, const float4* Bp, float* OUT,
                                              int ldo, const unsigned* mask, const Tid& t,
-                                             float* __restrict__ gout = nullptr, int ldg = 0, Post post = Post()) {
+                                             float* __restrict__ gout = nullptr, int ldg = 0, Post post = Post(),
+                                             const RingPre<NTWM>* pre = nullptr) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     WRing<NTWM, DEPTH> w;
-    ring_issue<NTWM, DEPTH, false>(w, Bp, KB, nullptr, t);
+    if (PRE) ring_issue_pre<NTWM, DEPTH>(w, *pre, Bp, KB, t);
+    else ring_issue<NTWM, DEPTH, false>(w, Bp, KB, nullptr, t);
     const unsigned m = mask[t.tid];
-    ring_run<NTWM, DEPTH, false, false>(w, A, lda, 0, KB, Bp, t, acc);
+    ring_run<NTWM, DEPTH, false, false, PRE>(w, A, lda, 0, KB, Bp, t, acc);
     post();
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
@@ -548,6 +609,8 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
             tl_layer[td->o_H2 + (row0 + r) * td->wh + f.Wp + j] = one;
         }
         // ---- conditioner MLP: relu(relu(z1 W1 + b1) W2 + b2) W3' ----------------------------------------
+        RingPre<NTWM> rp;                                 // block 0 + bias of the W x W GEMM below: lands during this stage
+        ringpre_load<NTWM, true>(rp, W2, f.KBW, Lp + f.o_b2, t);
         dense_relu_small<NTWM, 2, GRAD, TAPE>(w1r, Z, l.DS, f.d, HA, l.WS, mk, t,
                                               TAPE ? tl_layer + td->o_H1 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
         if (tl) FAB_TL(f, 3);
@@ -569,9 +632,9 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
                 if (kbd2) smallw_load<1, 2, false>(awr, reinterpret_cast<const float4*>(Ln + f.o_AW), nullptr, t);
             }
         };
-        dense_relu<NTWM, DW, false, GRAD, TAPE>(HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
-                                                TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr,
-                                                TAPE ? td->wh : 0, post_fwd);
+        dense_relu<NTWM, DW, false, GRAD, TAPE, decltype(post_fwd), true>(
+            HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
+            TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, post_fwd, &rp);
         if (tl) FAB_TL(f, 5);
         // no workgroup barrier: the K-split GEMM reads only this wave's own columns of HB (LDS is in-order per wave)
         __builtin_amdgcn_wave_barrier();
@@ -654,6 +717,8 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         const unsigned* mk = reinterpret_cast<const unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
         float* tl_layer = TAPE ? tape + (size_t)layer * td->layer_stride : nullptr;
         if (TAPE) tape_copy(tl_layer + td->o_DP + row0 * td->wp, td->wp, DP, l.PS, t);
+        RingPre<NTWM> rpb;                                // block 0 of the W x W GEMM below: lands during this stage
+        ringpre_load<NTWM, false>(rpb, W2T, f.KBW, nullptr, t);
         if (kbo2)
             dense_masked_small<NTWM, 2, TAPE>(w3a, DP, l.PS, HA, l.WS, mk + NTHREADS, t,
                                               TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0);
@@ -674,9 +739,9 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
                     w3a, reinterpret_cast<const float4*>(packed + (size_t)(layer + 1) * f.layer_stride + f.o_W3T),
                     nullptr, t);
         };
-        dense_masked<NTWM, DW, TAPE>(HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t,
-                                     TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0,
-                                     post_bwd);
+        dense_masked<NTWM, DW, TAPE, decltype(post_bwd), true>(
+            HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t, TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr,
+            TAPE ? td->we : 0, post_bwd, &rpb);
         if (tl) FAB_TL(f, 21);
         __builtin_amdgcn_wave_barrier();              // as in the forward sweep: own columns only, no barrier
         if (tl) FAB_TL(f, 22);
