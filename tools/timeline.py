@@ -29,4 +29,4 @@ for i in sorted(names):
     d = "" if prev is None or i in (0, 16) else f"+{(ts[i] - prev):7d} ticks"
     print(f"{i:2d} {names[i]:32s} {d}")
     prev = ts[i]
-print("fwd layer total ticks:", ts[11] - ts[0], " bwd layer total ticks:", ts[28] - ts[16], "(s_memtime: 100 MHz constant clock on gfx9 => 10 ns/tick)")
+print("fwd layer total ticks:", ts[11] - ts[0], " bwd layer total ticks:", ts[28] - ts[16], "(s_memtime ticks = shader cycles on gfx950, ~2.4 GHz: MI355X_MICROARCH.md)")
