@@ -1,0 +1,53 @@
+"""Per-transition HMC / Metropolis parity (HIP vs CPU oracle, identical inputs and noise) on the kernel shapes the
+golden fixtures do not reach: 8 column tiles per wave (W = 512), D > 32 (4 k-blocks for the D x D maps and the first
+reverse GEMM: the streaming code paths), narrow flows.  Same acceptance rule as the headline test: 1e-4 of the state
+scale, at most one chain per transition may differ through an accept decision within rounding of the threshold."""
+import pytest
+import torch
+
+from helpers import close, max_rel_err, RTOL
+from test_gpu_parity import seeded_flow, hip_flow_from_oracle, DEV
+
+pytestmark = pytest.mark.gpu
+
+fa = pytest.importorskip("fab_torch_amd")
+from oracle import ais as oais            # noqa: E402
+from oracle import targets as otgt        # noqa: E402
+
+
+@pytest.mark.parametrize("D,K,nodes,M,L,B", [(64, 2, 8, 3, 3, 24), (60, 3, 4, 2, 4, 20), (6, 8, 40, 3, 5, 40),
+                                             (32, 2, 16, 2, 3, 16), (4, 2, 4, 3, 2, 33)])
+def test_hmc_transitions_vs_oracle_on_other_kernel_shapes(D, K, nodes, M, L, B):
+    nf = seeded_flow(D, K, nodes, 40 + D + K)
+    hf = hip_flow_from_oracle(nf)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.12, L=L,
+                                   eval_mode=True).to(DEV)
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, M)
+    torch.manual_seed(13)
+    eps0 = torch.randn(B, D)
+    noise_p = torch.randn(M, 1, B, D)
+    noise_e = torch.empty(M, 1, B).exponential_()
+    otarget = otgt.ManyWell(D)
+    ohmc = oais.HMC(M, D, nf.log_prob, otarget.log_prob, alpha=2.0, p_target=False, epsilon=0.12, L=L, eval_mode=True)
+    oa = oais.AIS(lambda e: tuple(t.detach() for t in nf.sample_eps(e)), nf.log_prob, otarget.log_prob, ohmc, False,
+                  2.0, M)
+    oa.sample_and_log_weights(eps0, noise_p, noise_e, keep_snapshots=True)
+    snaps = oa.snapshots
+    for j in range(1, M + 1):
+        p_in, lw_in = snaps[j - 1]
+        p_ref, lw_ref = snaps[j]
+        pt = fa.Point(p_in.x.clone().to(DEV), p_in.log_q.clone().to(DEV), p_in.log_p.clone().to(DEV),
+                      p_in.grad_log_q.clone().to(DEV), p_in.grad_log_p.clone().to(DEV))
+        lw = lw_in.clone().to(DEV)
+        hmc.transition(pt, j, float(ais.B_space[j]), log_w=lw, beta_next=float(ais.B_space[j + 1]),
+                       noise_p=noise_p[j - 1].to(DEV), noise_e=noise_e[j - 1].to(DEV))
+        scale = max(1.0, float(p_ref.x.abs().max()))
+        err = (pt.x.cpu() - p_ref.x).abs().max(1).values / scale
+        flipped = err > 1e-4
+        assert flipped.sum() <= 1, f"transition {j}: {int(flipped.sum())} chains differ (max err {float(err.max()):.2e})"
+        ok = ~flipped
+        assert close(lw.cpu()[ok], lw_ref[ok], RTOL), f"transition {j}: log_w err {max_rel_err(lw.cpu()[ok], lw_ref[ok]):.2e}"
+        assert close(pt.log_q.cpu()[ok], p_ref.log_q[ok], RTOL)
+        assert close(pt.grad_log_q.cpu()[ok], p_ref.grad_log_q[ok], 5e-4)
+        assert close(pt.log_p.cpu()[ok], p_ref.log_p[ok], RTOL)

@@ -43,7 +43,7 @@ def oracle_logq_grad(nf, x):
 
 
 FLOW_CASES = [(6, 3, 5, 50), (32, 2, 1, 64), (2, 2, 8, 33), (2, 4, 40, 100), (6, 8, 40, 70), (32, 10, 10, 48),
-              (5, 2, 4, 17), (60, 2, 4, 20)]
+              (5, 2, 4, 17), (60, 2, 4, 20), (32, 2, 16, 40), (64, 2, 8, 24)]     # last two: W = 512 (8 tiles/wave)
 
 
 @pytest.mark.parametrize("D,K,nodes,B", FLOW_CASES)
@@ -97,7 +97,7 @@ def _param_grads(flow_module, params, x, coef, x_grad=False):
 
 
 @pytest.mark.parametrize("D,K,nodes,B", [(6, 3, 5, 50), (2, 4, 40, 100), (5, 2, 4, 17), (32, 10, 10, 333),
-                                         (60, 2, 4, 40), (6, 8, 40, 1000)])
+                                         (60, 2, 4, 40), (6, 8, 40, 1000), (32, 2, 16, 64)])
 def test_flow_parameter_gradients_vs_oracle_autograd(D, K, nodes, B):
     """Training path (csrc/train_kernels.hip through fabhip_flow_log_prob_tape / fabhip_flow_param_grad):
     sum_b coef_b d log q(x_b)/d theta for every parameter against torch autograd of the CPU oracle flow, and against
