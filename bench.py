@@ -83,8 +83,8 @@ def cpu_baseline(flow_state, n_calls=2):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -125,6 +125,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    t_spin = time.perf_counter()                # untimed: a fresh box needs ~0.2 s of work to reach steady clocks
+    while time.perf_counter() - t_spin < 0.3:   # (measured 105.7k vs 113.4k samples/s for a cold first process)
+        step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -139,6 +143,19 @@ def main():
         elapsed = float(tt.item())
     info = ais.get_logging_info()
     ess_all = float(fa.effective_sample_size(out[1]).item())
+    # second row of SURVEY.md section 8d: the same K steps with step-size tuning frozen (evaluation mode)
+    hmc.set_eval_mode(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed_eval = time.perf_counter() - t0
+    hmc.set_eval_mode(False)
+    if distributed:
+        tt = torch.tensor([elapsed_eval], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_eval = float(tt.item())
 
     # ---- roofline of the dominant kernel (k_hmc_step): live HIP-event timing on the launch stream -----
     roof = None
@@ -193,6 +210,7 @@ def main():
                                    "M=8 linear beta, alpha=2 (target p^2/q), step-size tuning on",
                        "chains_per_gpu": B_PER_GPU, "global_chains": world * B_PER_GPU,
                        "parallelism": f"chains sharded x{world}, one all-gather" if world > 1 else "single GPU"},
+            "value_eval_mode": total / elapsed_eval,
             "ess_ais": info["ess_ais"], "ess_gathered": ess_all, "log_Z": info["log_Z"],
             "p_accept_first": info.get("dist0_p_accept_0"),
             "roofline": roof,
