@@ -125,10 +125,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    t_spin = time.perf_counter()                # untimed: a fresh box needs ~0.2 s of work to reach steady clocks
-    while time.perf_counter() - t_spin < 0.3:   # (measured 105.7k vs 113.4k samples/s for a cold first process)
-        step()
-        torch.cuda.synchronize()
+    for _ in range(30):                         # untimed, same count on every rank (step() holds a collective): a fresh
+        step()                                  # box needs ~0.2 s of work to reach steady clocks (measured 105.7k vs
+    torch.cuda.synchronize()                    # 113.4k samples/s for a cold first process)
     for _ in range(args.warmup):
         step()
     barrier()
