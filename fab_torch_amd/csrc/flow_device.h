@@ -474,13 +474,17 @@ template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, class P
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                            const float* __restrict__ bias, float* OUT, int ldo, unsigned* mask,
                                            const Tid& t, float* __restrict__ gout = nullptr, int ldg = 0,
-                                           Post post = Post(), const RingPre<NTWM>* pre = nullptr) {
+                                           Post post = Post(), const RingPre<NTWM>* pre = nullptr,
+                                           long long* tlp = nullptr) {
     f32x4 acc[NTWM];
     WRing<NTWM, DEPTH> w;
     if (PRE) ring_issue_pre<NTWM, DEPTH>(w, *pre, Bp, KB, t);
     else ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
+    if (tlp && t.tid == 0) tlp[40] = (long long)__builtin_amdgcn_s_memtime();      // dev-only stage-internal stamps
     ring_run<NTWM, DEPTH, MASKK, true, PRE>(w, A, lda, kmax, KB, Bp, t, acc);
+    if (tlp && t.tid == 0) tlp[41] = (long long)__builtin_amdgcn_s_memtime();
     post();
+    if (tlp && t.tid == 0) tlp[42] = (long long)__builtin_amdgcn_s_memtime();
     unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
@@ -634,7 +638,8 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         };
         dense_relu<NTWM, DW, false, GRAD, TAPE, decltype(post_fwd), true>(
             HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
-            TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, post_fwd, &rp);
+            TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, post_fwd, &rp,
+            (tl && blockIdx.x == 0) ? f.timeline : nullptr);
         if (tl) FAB_TL(f, 5);
         // no workgroup barrier: the K-split GEMM reads only this wave's own columns of HB (LDS is in-order per wave)
         __builtin_amdgcn_wave_barrier();

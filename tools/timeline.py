@@ -30,3 +30,7 @@ for i in sorted(names):
     print(f"{i:2d} {names[i]:32s} {d}")
     prev = ts[i]
 print("fwd layer total ticks:", ts[11] - ts[0], " bwd layer total ticks:", ts[28] - ts[16], "(s_memtime ticks = shader cycles on gfx950, ~2.4 GHz: MI355X_MICROARCH.md)")
+if ts[40] and ts[41] and ts[42]:
+    print(f"inside the forward W x W GEMM: ring prologue issued at +{ts[40] - ts[4]} after the stage start, main loop "
+          f"{ts[41] - ts[40]} ticks (MFMA floor 12800 at W=320), post-loop requests {ts[42] - ts[41]}, "
+          f"epilogue {ts[5] - ts[42]}")
