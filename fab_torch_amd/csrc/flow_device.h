@@ -270,6 +270,150 @@ __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __r
     __builtin_amdgcn_sched_barrier(0);
 }
 
+// ---- W x W main loop, software-pipelined across stage boundaries -------------------------------------------------
+// Used when k-block 0 (+ bias) is already in ring slot 0 (RingPre, plain loads of the previous stage).  The vector
+// memory path of a CU takes ~16 cycles per 1-KiB wave load, so a burst of 15-25 loads costs ~1000 cycles when all
+// four waves issue it at once with the matrix pipe idle (measured: ring prologue 1.0k, post-loop requests 1.15k).
+// Here nothing is issued in a burst:
+//   * block 0 runs straight away and the hidden loads of blocks 1 .. DEPTH-1 go out one behind each of its MFMAs;
+//   * the requests of LATER stages (compiler-tracked plain loads, `inj(integral_constant<j>)`, j < NI) go out PER
+//     k-block a few at a time behind the MFMAs of the last k-blocks (fully unrolled tail: static register targets).
+// Extra loads in flight only make the hand-counted vmcnt waits more conservative (loads return in order).
+struct NoInject {
+    template <class J>
+    __device__ __forceinline__ void operator()(J) const {}
+};
+
+template <int V>
+struct IC {
+    static constexpr int value = V;
+};
+
+// one k-block.  MODE 1: first block (data present, no wait; issues the prologue of slots 1 .. DEPTH-1);
+// MODE 0: steady state (wait slot D, refill slot D-1 with block S-1+DEPTH, NJ injected requests from index JB)
+template <int NTWM, int DEPTH, int D, int MODE, int NJ, int JB, class Inject>
+__device__ __forceinline__ void kblock_pre(WRing<NTWM, DEPTH>& w, float4& a_nxt, const float* __restrict__ arow, int S,
+                                           int KB, const float4* __restrict__ bw, const unsigned (&voff)[NTWM],
+                                           f32x4 (&acc)[NTWM], Inject& inj) {
+    const float4 a = a_nxt;
+    const int Sn = (S + 1 < KB) ? S + 1 : S;
+    a_nxt = *reinterpret_cast<const float4*>(arow + 16 * Sn);
+    if (MODE == 0) wait_tiles<(DEPTH - 2) * NTWM, NTWM>(w.r[D]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {                      // group x
+        acc[i] = mfma4(a.x, w.r[D][i].x, acc[i]);
+        if (MODE == 1) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) gload16s_first(w.r[1][0], voff[0], bw + 64);
+            else gload16s(w.r[1][i], voff[i], bw + 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        constexpr int dp = (D + DEPTH - 1) % DEPTH;
+        const int Sp = (S - 1 + DEPTH < KB) ? S - 1 + DEPTH : KB - 1;
+        const float4* sb = bw + (size_t)Sp * 64;
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) {                  // group y (+ refill / prologue slot 2)
+            acc[i] = mfma4(a.y, w.r[D][i].y, acc[i]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MODE == 0) {
+                if (i == 0) gload16s_first(w.r[dp][0], voff[0], sb);
+                else gload16s(w.r[dp][i], voff[i], sb);
+            } else if (DEPTH > 2) {
+                if (i == 0) gload16s_first(w.r[2 % DEPTH][0], voff[0], bw + 2 * 64);
+                else gload16s(w.r[2 % DEPTH][i], voff[i], bw + 2 * 64);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {                      // group z (+ prologue slot 3 / injected requests)
+        acc[i] = mfma4(a.z, w.r[D][i].z, acc[i]);
+        if (MODE == 1 && DEPTH > 3) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (i == 0) gload16s_first(w.r[3 % DEPTH][0], voff[0], bw + 3 * 64);
+            else gload16s(w.r[3 % DEPTH][i], voff[i], bw + 3 * 64);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    static_assert(DEPTH == 2 || DEPTH == 4, "prologue interleave is written for ring depths 2 and 4");
+    if (NJ > 0) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NJ > 0) inj(IC<JB>());
+        if constexpr (NJ > 1) inj(IC<JB + 1>());
+        if constexpr (NJ > 2) inj(IC<JB + 2>());
+        if constexpr (NJ > 3) inj(IC<JB + 3>());
+        if constexpr (NJ > 4) inj(IC<JB + 4>());
+        if constexpr (NJ > 5) inj(IC<JB + 5>());
+        static_assert(NJ <= 6, "at most 6 injected requests per k-block");
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, w.r[D][i].w, acc[i]);   // group w
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NTWM, int DEPTH, int G, int PER, bool INJECT, class Inject, int D = 0>
+__device__ __forceinline__ void kgroup_pre(WRing<NTWM, DEPTH>& w, float4& a_nxt, const float* __restrict__ arow, int S0,
+                                           int KB, const float4* __restrict__ bw, const unsigned (&voff)[NTWM],
+                                           f32x4 (&acc)[NTWM], Inject& inj) {
+    // steady-state group: slots D .. DEPTH-1; INJECT: tail group G (requests (G*DEPTH + d)*PER ..)
+    if constexpr (D < DEPTH) {
+        kblock_pre<NTWM, DEPTH, D, 0, INJECT ? PER : 0, (G * DEPTH + D) * PER>(w, a_nxt, arow, S0 + D, KB, bw, voff, acc,
+                                                                              inj);
+        kgroup_pre<NTWM, DEPTH, G, PER, INJECT, Inject, D + 1>(w, a_nxt, arow, S0, KB, bw, voff, acc, inj);
+    }
+}
+
+template <int NTWM, int DEPTH, int PER, class Inject, int D = 1>
+__device__ __forceinline__ void kfirst_rest(WRing<NTWM, DEPTH>& w, float4& a_nxt, const float* __restrict__ arow, int KB,
+                                            const float4* __restrict__ bw, const unsigned (&voff)[NTWM],
+                                            f32x4 (&acc)[NTWM], Inject& inj) {
+    // blocks 1 .. DEPTH-1 of the first group; with a single group (KB == DEPTH) they carry the injected requests
+    if constexpr (D < DEPTH) {
+        kblock_pre<NTWM, DEPTH, D, 0, PER, (D - 1) * PER>(w, a_nxt, arow, D, KB, bw, voff, acc, inj);
+        kfirst_rest<NTWM, DEPTH, PER, Inject, D + 1>(w, a_nxt, arow, KB, bw, voff, acc, inj);
+    }
+}
+
+template <int NTWM, int DEPTH, int TG, int PER, class Inject, int G = 0>
+__device__ __forceinline__ void ktail_pre(WRing<NTWM, DEPTH>& w, float4& a_nxt, const float* __restrict__ arow, int KB,
+                                          const float4* __restrict__ bw, const unsigned (&voff)[NTWM],
+                                          f32x4 (&acc)[NTWM], Inject& inj) {
+    if constexpr (G < TG) {
+        kgroup_pre<NTWM, DEPTH, G, PER, true>(w, a_nxt, arow, KB - (TG - G) * DEPTH, KB, bw, voff, acc, inj);
+        ktail_pre<NTWM, DEPTH, TG, PER, Inject, G + 1>(w, a_nxt, arow, KB, bw, voff, acc, inj);
+    }
+}
+
+// acc (pre-set by the caller) += A[16 x 64 NTWM] @ B, K = 64 NTWM (KB = 4 NTWM k-blocks), NI injected requests
+template <int NTWM, int DEPTH, int NI, class Inject>
+__device__ __forceinline__ void ring_run_pre(WRing<NTWM, DEPTH>& w, const float* __restrict__ A, int lda,
+                                             const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM],
+                                             Inject& inj) {
+    constexpr int KB = 4 * NTWM, NG = KB / DEPTH;
+    static_assert(KB % DEPTH == 0, "ring depth must divide the k-block count");
+    constexpr int TG = NG - 1 < 12 / DEPTH ? NG - 1 : 12 / DEPTH;   // fully unrolled tail groups: up to 12 k-blocks
+    constexpr int TB = NG == 1 ? DEPTH - 1 : TG * DEPTH;  // k-blocks that carry injected requests
+    constexpr int PER = (NI + TB - 1) / TB;
+    const float* arow = A + t.n * lda + 4 * t.q;
+    const float4* bw = Bp + (size_t)t.wave * KB * 64;
+    unsigned voff[NTWM];
+    tile_offsets<NTWM>(voff, KB, t);
+    float4 a_nxt = *reinterpret_cast<const float4*>(arow);
+    kblock_pre<NTWM, DEPTH, 0, 1, 0, 0>(w, a_nxt, arow, 0, KB, bw, voff, acc, inj);
+    kfirst_rest<NTWM, DEPTH, NG == 1 ? PER : 0>(w, a_nxt, arow, KB, bw, voff, acc, inj);
+    for (int S0 = DEPTH; S0 < KB - TG * DEPTH; S0 += DEPTH)
+        kgroup_pre<NTWM, DEPTH, 0, 0, false>(w, a_nxt, arow, S0, KB, bw, voff, acc, inj);
+    ktail_pre<NTWM, DEPTH, TG, PER>(w, a_nxt, arow, KB, bw, voff, acc, inj);
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) wait_tiles<0, NTWM>(w.r[d]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // ---- K-split GEMM for narrow outputs (N = 16*NT <= 64, K = 64*KW): wave w sums k-blocks S = w, w+4, ... of
 // every column tile; the four partial [16 x 16*NT] products go to LDS part[w][row][PN] and are added by the
 // caller.  Plain (compiler-tracked) loads in straight-line code: the weights of tile i+1 are requested before
@@ -470,18 +614,28 @@ struct NoPost {
 
 // `post` runs between the main loop and the epilogue: the place to request (plain loads) weights of later stages,
 // whose latency then hides behind this epilogue and the stages in between.
-template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, class Post = NoPost, bool PRE = false>
+template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, class Post = NoPost, bool PRE = false,
+          int NI = 0, class Inject = NoInject>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
                                            const float* __restrict__ bias, float* OUT, int ldo, unsigned* mask,
                                            const Tid& t, float* __restrict__ gout = nullptr, int ldg = 0,
                                            Post post = Post(), const RingPre<NTWM>* pre = nullptr,
-                                           long long* tlp = nullptr) {
+                                           long long* tlp = nullptr, Inject inj = Inject()) {
     f32x4 acc[NTWM];
     WRing<NTWM, DEPTH> w;
-    if (PRE) ring_issue_pre<NTWM, DEPTH>(w, *pre, Bp, KB, t);
-    else ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
-    if (tlp && t.tid == 0) tlp[40] = (long long)__builtin_amdgcn_s_memtime();      // dev-only stage-internal stamps
-    ring_run<NTWM, DEPTH, MASKK, true, PRE>(w, A, lda, kmax, KB, Bp, t, acc);
+    if (PRE) {
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) {
+            w.r[0][i] = (f32x4){pre->b[i].x, pre->b[i].y, pre->b[i].z, pre->b[i].w};
+            acc[i] = (f32x4){pre->bv[i], pre->bv[i], pre->bv[i], pre->bv[i]};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tlp && t.tid == 0) tlp[40] = (long long)__builtin_amdgcn_s_memtime();  // dev-only stage-internal stamps
+        ring_run_pre<NTWM, DEPTH, NI>(w, A, lda, Bp, t, acc, inj);
+    } else {
+        ring_issue<NTWM, DEPTH, true>(w, Bp, KB, bias, t);
+        ring_run<NTWM, DEPTH, MASKK, true>(w, A, lda, kmax, KB, Bp, t, acc);
+    }
     if (tlp && t.tid == 0) tlp[41] = (long long)__builtin_amdgcn_s_memtime();
     post();
     if (tlp && t.tid == 0) tlp[42] = (long long)__builtin_amdgcn_s_memtime();
@@ -503,19 +657,26 @@ __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, in
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
-template <int NTWM, int DEPTH, bool TAPE = false, class Post = NoPost, bool PRE = false>
+template <int NTWM, int DEPTH, bool TAPE = false, class Post = NoPost, bool PRE = false, int NI = 0,
+          class Inject = NoInject>
 __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, const float4* Bp, float* OUT,
                                              int ldo, const unsigned* mask, const Tid& t,
                                              float* __restrict__ gout = nullptr, int ldg = 0, Post post = Post(),
-                                             const RingPre<NTWM>* pre = nullptr) {
+                                             const RingPre<NTWM>* pre = nullptr, Inject inj = Inject()) {
     f32x4 acc[NTWM];
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     WRing<NTWM, DEPTH> w;
-    if (PRE) ring_issue_pre<NTWM, DEPTH>(w, *pre, Bp, KB, t);
-    else ring_issue<NTWM, DEPTH, false>(w, Bp, KB, nullptr, t);
     const unsigned m = mask[t.tid];
-    ring_run<NTWM, DEPTH, false, false, PRE>(w, A, lda, 0, KB, Bp, t, acc);
+    if (PRE) {
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) w.r[0][i] = (f32x4){pre->b[i].x, pre->b[i].y, pre->b[i].z, pre->b[i].w};
+        __builtin_amdgcn_sched_barrier(0);
+        ring_run_pre<NTWM, DEPTH, NI>(w, A, lda, Bp, t, acc, inj);
+    } else {
+        ring_issue<NTWM, DEPTH, false>(w, Bp, KB, nullptr, t);
+        ring_run<NTWM, DEPTH, false, false>(w, A, lda, 0, KB, Bp, t, acc);
+    }
     post();
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
@@ -622,24 +783,37 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (tl) FAB_TL(f, 4);
         KsplitPre<NTWM> kp;
         float b3s[2], b3c[2];                             // coupling biases of this thread's columns (D - d <= 32)
-        auto post_fwd = [&]() {                           // after the W x W main loop, ahead of its epilogue:
-            ksplit_prefetch<NTWM>(kp, W3, f.NTO, t);      //   first tile of the K-split GEMM that follows
-#pragma unroll
-            for (int it = 0; it < 2; ++it) {              //   biases of the coupling stage
-                const int j = t.c + 16 * it;
-                b3s[it] = j < f.DO ? Lp[f.o_b3 + j] : 0.f;
-                b3c[it] = j < f.DO ? Lp[f.o_b3 + f.DOp + j] : 0.f;
-            }
-            if (layer > 0) {                              //   next layer's W1, b1, affine (consumed above already)
-                const float* Ln = packed + (size_t)(layer - 1) * f.layer_stride;
-                smallw_load<NTWM, 2, true>(w1r, reinterpret_cast<const float4*>(Ln + f.o_W1), Ln + f.o_b1, t);
-                if (kbd2) smallw_load<1, 2, false>(awr, reinterpret_cast<const float4*>(Ln + f.o_AW), nullptr, t);
+        // requests of the stages after this W x W GEMM, issued a few per k-block behind its last MFMAs:
+        //   [0, N)   first tile of the K-split GEMM that follows      [N, 3N)  next layer's W1 (2 k-blocks x N tiles)
+        //   [3N, 4N) next layer's b1      4N, 4N+1  next layer's affine map      4N+2 .. 4N+5  coupling biases
+        const float* Ln = packed + (size_t)(layer > 0 ? layer - 1 : 0) * f.layer_stride;
+        const bool nxt_layer = layer > 0;
+        auto inj_fwd = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, N = NTWM;
+            if constexpr (j < N) {
+                kp.b0[j] = W3[((size_t)t.wave + 4 * j) * 64 + t.lane];
+            } else if constexpr (j < 3 * N) {
+                constexpr int S = (j - N) / N, i = (j - N) % N;
+                if (nxt_layer)
+                    w1r.b[S][i] = reinterpret_cast<const float4*>(Ln + f.o_W1)[((size_t)(t.wave + 4 * i) * 2 + S) * 64 + t.lane];
+            } else if constexpr (j < 4 * N) {
+                constexpr int i = j - 3 * N;
+                if (nxt_layer) w1r.bv[i] = Ln[f.o_b1 + 16 * (t.wave + 4 * i) + t.n];
+            } else if constexpr (j < 4 * N + 2) {
+                constexpr int S = j - 4 * N;
+                if (nxt_layer && kbd2)
+                    awr.b[S][0] = reinterpret_cast<const float4*>(Ln + f.o_AW)[((size_t)t.wave * 2 + S) * 64 + t.lane];
+            } else if constexpr (j < 4 * N + 6) {
+                constexpr int it = (j - 4 * N - 2) & 1, sc = (j - 4 * N - 2) >> 1;
+                const int col = t.c + 16 * it;
+                const float v = col < f.DO ? Lp[f.o_b3 + sc * f.DOp + col] : 0.f;
+                if (sc) b3c[it] = v; else b3s[it] = v;
             }
         };
-        dense_relu<NTWM, DW, false, GRAD, TAPE, decltype(post_fwd), true>(
+        dense_relu<NTWM, DW, false, GRAD, TAPE, NoPost, true, 4 * NTWM + 6, decltype(inj_fwd)>(
             HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
-            TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, post_fwd, &rp,
-            (tl && blockIdx.x == 0) ? f.timeline : nullptr);
+            TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, NoPost(), &rp,
+            (tl && blockIdx.x == 0) ? f.timeline : nullptr, inj_fwd);
         if (tl) FAB_TL(f, 5);
         // no workgroup barrier: the K-split GEMM reads only this wave's own columns of HB (LDS is in-order per wave)
         __builtin_amdgcn_wave_barrier();
@@ -736,17 +910,26 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (tl) FAB_TL(f, 20);
         KsplitPre<NTWM> kp;
         SmallW<1, 2> awtr;                                // this layer's affine^T, used three short stages below
-        auto post_bwd = [&]() {
-            ksplit_prefetch<NTWM>(kp, W1T, f.NTd, t);
-            if (kbd2) smallw_load<1, 2, false>(awtr, AWT, nullptr, t);
-            if (kbo2 && layer + 1 < f.K)                  // next layer's W3'^T
-                smallw_load<NTWM, 2, false>(
-                    w3a, reinterpret_cast<const float4*>(packed + (size_t)(layer + 1) * f.layer_stride + f.o_W3T),
-                    nullptr, t);
+        awtr.bv[0] = 0.f;
+        //   [0, N) first tile of the K-split GEMM that follows   [N, 3N) next layer's W3'^T   3N, 3N+1 this affine^T
+        const float4* W3Tn = reinterpret_cast<const float4*>(
+            packed + (size_t)(layer + 1 < f.K ? layer + 1 : layer) * f.layer_stride + f.o_W3T);
+        const bool nxt_w3 = kbo2 && layer + 1 < f.K;
+        auto inj_bwd = [&](auto jc) {
+            constexpr int j = decltype(jc)::value, N = NTWM;
+            if constexpr (j < N) {
+                kp.b0[j] = W1T[((size_t)t.wave + 4 * j) * 64 + t.lane];
+            } else if constexpr (j < 3 * N) {
+                constexpr int S = (j - N) / N, i = (j - N) % N;
+                if (nxt_w3) w3a.b[S][i] = W3Tn[((size_t)(t.wave + 4 * i) * 2 + S) * 64 + t.lane];
+            } else if constexpr (j < 3 * N + 2) {
+                constexpr int S = j - 3 * N;
+                if (kbd2) awtr.b[S][0] = AWT[((size_t)t.wave * 2 + S) * 64 + t.lane];
+            }
         };
-        dense_masked<NTWM, DW, TAPE, decltype(post_bwd), true>(
+        dense_masked<NTWM, DW, TAPE, NoPost, true, 3 * NTWM + 2, decltype(inj_bwd)>(
             HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t, TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr,
-            TAPE ? td->we : 0, post_bwd, &rpb);
+            TAPE ? td->we : 0, NoPost(), &rpb, inj_bwd);
         if (tl) FAB_TL(f, 21);
         __builtin_amdgcn_wave_barrier();              // as in the forward sweep: own columns only, no barrier
         if (tl) FAB_TL(f, 22);
