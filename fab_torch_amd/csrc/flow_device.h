@@ -449,7 +449,7 @@ __device__ __forceinline__ void ksplit_mul(const float4 (&b)[KW], const float* _
 // (plain, compiler-tracked loads: safe to keep live across any code)
 template <int KW>
 struct KsplitPre {
-    float4 b0[KW];
+    float4 b0[KW], b1[KW];                      // b1 only where the producer injects it (PRE2)
 };
 
 template <int KW>
@@ -459,7 +459,7 @@ __device__ __forceinline__ void ksplit_prefetch(KsplitPre<KW>& pre, const float4
     __builtin_amdgcn_sched_barrier(0);          // keep the requests ahead of the producer's epilogue
 }
 
-template <int KW, bool PRE = false>
+template <int KW, bool PRE = false, bool PRE2 = false>
 __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda, const float4* __restrict__ Bp,
                                             int NT, float* __restrict__ part, int PN, const Tid& t,
                                             const KsplitPre<KW>* pre = nullptr) {
@@ -472,7 +472,12 @@ __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda
     } else {
         ksplit_load<KW>(b0, Bp, 0, t);
     }
-    if (NT > 1) ksplit_load<KW>(b1, Bp, 1, t);
+    if (PRE2) {
+#pragma unroll
+        for (int s = 0; s < KW; ++s) b1[s] = pre->b1[s];
+    } else if (NT > 1) {
+        ksplit_load<KW>(b1, Bp, 1, t);
+    }
     __builtin_amdgcn_sched_barrier(0);
     ksplit_mul<KW>(b0, arow, pw, PN, 0, t);
     if (NT > 1) {
@@ -808,9 +813,12 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
                 const int col = t.c + 16 * it;
                 const float v = col < f.DO ? Lp[f.o_b3 + sc * f.DOp + col] : 0.f;
                 if (sc) b3c[it] = v; else b3s[it] = v;
+            } else if constexpr (j < 5 * N + 6) {         // second tile of the K-split GEMM (its scale columns)
+                constexpr int sidx = j - 4 * N - 6;
+                kp.b1[sidx] = W3[((size_t)4 * N + t.wave + 4 * sidx) * 64 + t.lane];
             }
         };
-        dense_relu<NTWM, DW, false, GRAD, TAPE, NoPost, true, 4 * NTWM + 6, decltype(inj_fwd)>(
+        dense_relu<NTWM, DW, false, GRAD, TAPE, NoPost, true, 5 * NTWM + 6, decltype(inj_fwd)>(
             HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
             TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, NoPost(), &rp,
             (tl && blockIdx.x == 0) ? f.timeline : nullptr, inj_fwd);
@@ -818,7 +826,8 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         // no workgroup barrier: the K-split GEMM reads only this wave's own columns of HB (LDS is in-order per wave)
         __builtin_amdgcn_wave_barrier();
         if (tl) FAB_TL(f, 6);
-        gemm_ksplit<NTWM, true>(HB, l.WS, W3, f.NTO, PART, l.PN, t, &kp);
+        if (f.NTO == 2) gemm_ksplit<NTWM, true, true>(HB, l.WS, W3, 2, PART, l.PN, t, &kp);   // D - d <= 16: [shift | scale]
+        else gemm_ksplit<NTWM, true>(HB, l.WS, W3, f.NTO, PART, l.PN, t, &kp);
         if (tl) FAB_TL(f, 7);
         __syncthreads();
         if (tl) FAB_TL(f, 8);
