@@ -10,10 +10,13 @@
 // holds  B[16S + 4q + t][16c + n], t = 0..3.  MFMA step t of k-block S therefore multiplies
 // A[row][16S + 4q + t] (one ds_read_b128 per lane per k-block) with that register.
 //
-// Every stage issues its own ring prologue right before its main loop.  (Issuing the NEXT stage's prologue
-// before the current epilogue + barrier was tried and removed: registers that are the target of an in-flight
-// hidden load must not be live across code hipcc is free to re-allocate / spill - it copies them before the
-// data lands.  Inside the tight MFMA loop the ring registers are pinned by the wait operands.)
+// Two kinds of loads: (1) the weight ring of a main loop uses loads hipcc does not track (inline asm +
+// hand-counted vmcnt); registers that are the target of such an in-flight load must not be live across code
+// hipcc is free to re-allocate / spill (it copies them before the data lands), so a ring never outlives its
+// loop.  (2) Everything that has to arrive BEFORE its stage starts (short-K weights, D x D maps, biases, the
+// first k-block of the next ring, the first K-split tiles) uses plain compiler-tracked loads, which may stay live
+// across any code; they are issued a few at a time behind the MFMAs of the previous W x W main loop, never as a
+// burst (the CU's vector-memory path takes ~16 cycles per 1-KiB wave load).
 #pragma once
 #include "fabhip_common.h"
 
@@ -142,8 +145,8 @@ __device__ __forceinline__ void ring_issue(WRing<NTWM, DEPTH>& w, const float4* 
     }
 }
 
-// k-block 0 of a W x W GEMM (+ its bias), requested with plain loads one stage early: the main loop then starts
-// on data that is already there while the hidden ring loads of blocks 1 .. DEPTH-1 are still on their way.
+// k-block 0 of a W x W GEMM (+ its bias), requested with plain loads one stage early: the main loop (ring_run_pre)
+// then starts on data that is already there and issues the hidden loads of blocks 1 .. DEPTH-1 behind its MFMAs.
 template <int NTWM>
 struct RingPre {
     float4 b[NTWM];
@@ -161,32 +164,11 @@ __device__ __forceinline__ void ringpre_load(RingPre<NTWM>& p, const float4* __r
     __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int NTWM, int DEPTH>
-__device__ __forceinline__ void ring_issue_pre(WRing<NTWM, DEPTH>& w, const RingPre<NTWM>& p,
-                                               const float4* __restrict__ Bp, int KB, const Tid& t) {
-    const float4* bw = Bp + (size_t)t.wave * KB * 64;
-    unsigned voff[NTWM];
-    tile_offsets<NTWM>(voff, KB, t);
-#pragma unroll
-    for (int i = 0; i < NTWM; ++i) {                      // the compiler waits for the plain loads HERE, before any
-        w.r[0][i] = (f32x4){p.b[i].x, p.b[i].y, p.b[i].z, p.b[i].w};   // hidden load is in flight
-        w.bv[i] = p.bv[i];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int d = 1; d < DEPTH; ++d) {
-        const float4* sb = bw + (size_t)d * 64;
-        gload16s_first(w.r[d][0], voff[0], sb);
-#pragma unroll
-        for (int i = 1; i < NTWM; ++i) gload16s(w.r[d][i], voff[i], sb);
-    }
-}
-
 // main loop on a ring whose prologue was issued earlier and after which NO other hidden load was issued.
 // Loop schedule per k-block S (ring slot d = S mod DEPTH), pinned with sched_barrier:
 //   wait slot d  |  NTWM MFMA (a.x)  |  refill the slot of block S-1 with block S-1+DEPTH  |  3 NTWM MFMA
 // so the refill's address arithmetic and load issue run in the shadow of the matrix pipe.
-template <int NTWM, int DEPTH, bool MASKK, bool BIAS, bool PRE = false>
+template <int NTWM, int DEPTH, bool MASKK, bool BIAS>
 __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __restrict__ A, int lda, int kmax,
                                          int KB, const float4* __restrict__ Bp, const Tid& t, f32x4 (&acc)[NTWM]) {
     static_assert(DEPTH >= 2, "ring depth");
@@ -196,10 +178,8 @@ __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __r
     tile_offsets<NTWM>(voff, KB, t);
     float4 a_nxt = *reinterpret_cast<const float4*>(arow);
     if (BIAS) {
-        if (!PRE) {
-            wait_vals<DEPTH * NTWM, NTWM>(w.bv);                   // the ring (younger) may stay in flight
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        wait_vals<DEPTH * NTWM, NTWM>(w.bv);                       // the ring (younger) may stay in flight
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){w.bv[i], w.bv[i], w.bv[i], w.bv[i]};
     }
@@ -218,14 +198,11 @@ __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __r
                 a.w = (k0 + 3 < kmax) ? a.w : 0.f;
             }
             // slot d was (re)filled during block S-DEPTH+1; DEPTH-2 younger refill groups may stay in flight
-            // (with PRE, block 0 came through plain loads and is complete: no wait in front of its MFMAs)
-            if (!(PRE && d == 0 && S0 == 0)) wait_tiles<(DEPTH - 2) * NTWM, NTWM>(w.r[d]);
+            wait_tiles<(DEPTH - 2) * NTWM, NTWM>(w.r[d]);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.x, w.r[d][i].x, acc[i]);
             __builtin_amdgcn_sched_barrier(0);
-#ifndef FAB_EXP_QUARTER_MFMA        // experiment only (wrong results): 1 MFMA per 16 B of weights, the load:MFMA
-                                    // ratio a 4-chain tile (v_mfma_f32_4x4x1) would have
             // refill the slot consumed by block S-1 with block S-1+DEPTH (clamped: the tail re-reads the last
             // block, which keeps the in-flight count constant so the hand-counted vmcnt stays exact) - ONE load
             // behind each MFMA of the a.y group, so that no gap between two MFMAs carries more than the matrix
@@ -249,16 +226,6 @@ __device__ __forceinline__ void ring_run(WRing<NTWM, DEPTH>& w, const float* __r
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.z, w.r[d][i].z, acc[i]);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i) acc[i] = mfma4(a.w, w.r[d][i].w, acc[i]);
-#else
-            if (S > 0) {
-                const int dp = (d + DEPTH - 1) % DEPTH;
-                const int Sp = (S - 1 + DEPTH < KB) ? S - 1 + DEPTH : KB - 1;
-                const float4* sb = bw + (size_t)Sp * 64;
-                gload16s_first(w.r[dp][0], voff[0], sb);
-#pragma unroll
-                for (int i = 1; i < NTWM; ++i) gload16s(w.r[dp][i], voff[i], sb);
-            }
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -445,19 +412,12 @@ __device__ __forceinline__ void ksplit_mul(const float4 (&b)[KW], const float* _
     for (int r = 0; r < 4; ++r) pw[(4 * t.q + r) * PN + 16 * tile + t.n] = acc0[r] + acc1[r];
 }
 
-// weights of the first column tile of a K-split GEMM, requested by the producer stage before its epilogue
+// weights of the first column tiles of a K-split GEMM, requested from inside the producer's main loop
 // (plain, compiler-tracked loads: safe to keep live across any code)
 template <int KW>
 struct KsplitPre {
     float4 b0[KW], b1[KW];                      // b1 only where the producer injects it (PRE2)
 };
-
-template <int KW>
-__device__ __forceinline__ void ksplit_prefetch(KsplitPre<KW>& pre, const float4* __restrict__ Bp, int NT, const Tid& t) {
-    (void)NT;                                   // only the first tile: more live registers slow the epilogue down
-    ksplit_load<KW>(pre.b0, Bp, 0, t);
-    __builtin_amdgcn_sched_barrier(0);          // keep the requests ahead of the producer's epilogue
-}
 
 template <int KW, bool PRE = false, bool PRE2 = false>
 __device__ __forceinline__ void gemm_ksplit(const float* __restrict__ A, int lda, const float4* __restrict__ Bp,
