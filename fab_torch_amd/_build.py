@@ -53,6 +53,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
         return LIB
     hipcc = _hipcc()
     os.makedirs(BUILD, exist_ok=True)
+    # several ranks of one node may get here at once (torchrun on a box without a prebuilt library): one builds,
+    # the others wait on the lock and find the result
+    import fcntl
+    lock = open(os.path.join(BUILD, ".lock"), "w")
+    fcntl.flock(lock, fcntl.LOCK_EX)
+    try:
+        if not force and not is_stale():
+            return LIB
+        return _build_locked(hipcc, verbose)
+    finally:
+        fcntl.flock(lock, fcntl.LOCK_UN)
+        lock.close()
+
+
+def _build_locked(hipcc, verbose):
 
     def compile_one(src):
         obj = os.path.join(BUILD, src.replace(".hip", ".o"))
