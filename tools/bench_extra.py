@@ -90,7 +90,9 @@ def ais_config(name, D, K, nodes, B, M, kind, L=5, n_inner=1, eps=0.2, steps=10)
 
 if __name__ == "__main__":
     quick = "--quick" in sys.argv
-    res = {"resample": [resample_roofline(n) for n in ((1 << 20, 1 << 24) if quick else (1 << 20, 1 << 24, 1 << 26))]}
+    # SURVEY.md section 8d sizes: 1024 / 16384 (launch-latency bound, D = 32 rows) up to 2^26 (HBM bound, D = 8)
+    sizes = (1024, 16384, 1 << 20, 1 << 24) if quick else (1024, 16384, 1 << 20, 1 << 24, 1 << 26)
+    res = {"resample": [resample_roofline(n, D=32 if n <= (1 << 20) else 8) for n in sizes]}
     res["ais"] = [
         ais_config("cfg1 GMM-40 2D, RealNVP 4 layers W=80, 512 chains, M=4, Metropolis", 2, 4, 40, 512, 4, "metropolis"),
         ais_config("cfg2 ManyWell-6, RealNVP 8 layers W=240, 1024 chains, M=8, HMC L=5", 6, 8, 40, 1024, 8, "hmc"),
