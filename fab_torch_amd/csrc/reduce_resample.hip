@@ -83,19 +83,55 @@ __global__ __launch_bounds__(ESS_THREADS) void k_ess_final(const Msum* __restric
 // ------------------------------------------------------------------------------------------------
 // torch-compatible multinomial (sequential fp32 CDF, exactly the CPU kernel's arithmetic)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_seq_cdf(const float* __restrict__ p, long n, float* __restrict__ c) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    float s = 0.f;
-    long j = 0;
-    for (; j + 8 <= n; j += 8) {
-        float v[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) v[u] = p[j + u];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) { s += v[u]; c[j + u] = s; }
+// c[j] = fl32(c[j-1] + p[j]) is inherently serial (the rounding of every partial sum feeds the next one), and it
+// is what torch's CPU multinomial computes.  One lane runs the add chain out of LDS (float4 at a time, ~6 cycles per
+// element instead of a global-memory round trip per few elements); the second wave of the workgroup streams the
+// next chunk in and the previous chunk's results out meanwhile (double buffer, one barrier per 2048 elements).
+constexpr int SEQ_CH = 2048;
+
+__global__ __launch_bounds__(128) void k_seq_cdf(const float* __restrict__ p, long n, float* __restrict__ c) {
+    __shared__ __attribute__((aligned(16))) float buf[2][SEQ_CH];      // inputs  (double buffer)
+    __shared__ __attribute__((aligned(16))) float res[2][SEQ_CH];      // results (separate: lets the reads run ahead)
+    __shared__ float carry_sh;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const long nch = (n + SEQ_CH - 1) / SEQ_CH;
+    auto load_chunk = [&](long ch, float* dst) {
+        const long base = ch * SEQ_CH;
+        for (int i = lane; i < SEQ_CH; i += 64) dst[i] = (base + i < n) ? p[base + i] : 0.f;   // + 0.f is exact
+    };
+    auto store_chunk = [&](long ch, const float* src) {
+        const long base = ch * SEQ_CH;
+        for (int i = lane; i < SEQ_CH; i += 64)
+            if (base + i < n) c[base + i] = src[i];
+    };
+    if (wave == 1 && nch > 0) load_chunk(0, buf[0]);
+    if (tid == 0) carry_sh = 0.f;
+    __syncthreads();
+    for (long ch = 0; ch < nch; ++ch) {
+        if (wave == 0) {
+            if (lane == 0) {
+                float s = carry_sh;
+                const float4* __restrict__ vin = reinterpret_cast<const float4*>(buf[ch & 1]);
+                float4* __restrict__ vout = reinterpret_cast<float4*>(res[ch & 1]);
+#pragma unroll 8
+                for (int j = 0; j < SEQ_CH / 4; ++j) {
+                    float4 x = vin[j];
+                    s += x.x; x.x = s;
+                    s += x.y; x.y = s;
+                    s += x.z; x.z = s;
+                    s += x.w; x.w = s;
+                    vout[j] = x;
+                }
+                carry_sh = s;
+            }
+        } else {
+            if (ch > 0) store_chunk(ch - 1, res[(ch & 1) ^ 1]);
+            if (ch + 1 < nch) load_chunk(ch + 1, buf[(ch & 1) ^ 1]);
+        }
+        __syncthreads();
     }
-    for (; j < n; ++j) { s += p[j]; c[j] = s; }
-    c[n] = s;   // total kept in the extra slot
+    if (wave == 1 && nch > 0) store_chunk(nch - 1, res[(nch - 1) & 1]);
+    if (tid == 0) c[n] = carry_sh;   // total kept in the extra slot
 }
 
 __global__ void k_cdf_normalise(float* __restrict__ c, long n) {
@@ -744,7 +780,7 @@ int fabhip_multinomial_torch(const float* probs, int64_t n, const double* u, int
     if (workspace_bytes < fabhip_multinomial_torch_workspace_bytes(n)) return FABHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     float* c = (float*)workspace;
-    hipLaunchKernelGGL(k_seq_cdf, dim3(1), dim3(64), 0, st, probs, (long)n, c);
+    hipLaunchKernelGGL(k_seq_cdf, dim3(1), dim3(128), 0, st, probs, (long)n, c);
     hipLaunchKernelGGL(k_cdf_normalise, dim3(grid_for(n, 256, 2048)), dim3(256), 0, st, c, (long)n);
     if (n_samples > 0)
         hipLaunchKernelGGL(k_search_f32cdf, dim3(grid_for(n_samples, 256, 4096)), dim3(256), 0, st, c, (long)n, u,
