@@ -37,6 +37,23 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// ReLU epilogue helpers.  The sign pattern of a lane's 4*NTWM outputs is kept as one 32-bit word, first output in
+// bit 31: built with add-with-carry (m <- 2m + [v > 0], three VALU ops per value sharing one compare) and consumed
+// in the reverse sweep with add-carry-out (carry = top bit, m <- 2m: two ops per value).
+__device__ __forceinline__ float relu_bit(float v, unsigned& m) {
+    float o;
+    asm("v_cmp_lt_f32 vcc, 0, %2\n\tv_cndmask_b32 %0, 0, %2, vcc\n\tv_addc_co_u32 %1, vcc, %1, %1, vcc"
+        : "=&v"(o), "+v"(m)
+        : "v"(v)
+        : "vcc");
+    return o;                                   // v > 0 ? v : 0  (NaN -> 0, like the plain expression)
+}
+__device__ __forceinline__ float mask_bit(float v, unsigned& m) {
+    float o;
+    asm("v_add_co_u32 %1, vcc, %1, %1\n\tv_cndmask_b32 %0, 0, %2, vcc" : "=&v"(o), "+v"(m) : "v"(v) : "vcc");
+    return o;                                   // top bit of m ? v : 0, m <<= 1
+}
+
 // dev-only timeline: workgroup 0 / thread 0 records s_memtime at stage boundaries of one layer
 #define FAB_TL(f, idx) do { if ((f).timeline && blockIdx.x == 0 && threadIdx.x == 0) (f).timeline[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
 
@@ -524,14 +541,12 @@ __device__ __forceinline__ void dense_relu_small(const SmallW<NTWM, KB>& w, cons
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = acc[i][r];
-            const bool pos = v > 0.f;
-            const float o = pos ? v : 0.f;
+            const float o = MASK ? relu_bit(v, m) : (v > 0.f ? v : 0.f);
             OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
             if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
-            if (MASK) m |= (pos ? 1u : 0u) << (4 * i + r);
         }
     }
-    if (MASK) mask[t.tid] = m;
+    if (MASK) mask[t.tid] = m << (32 - 4 * NTWM);
 }
 
 // OUT = (A @ B) * mask with pre-loaded weights (same epilogue as dense_masked)
@@ -540,39 +555,25 @@ __device__ __forceinline__ void dense_masked_small(const SmallW<NTWM, KB>& w, co
                                                    int ldo, const unsigned* mask, const Tid& t,
                                                    float* __restrict__ gout, int ldg) {
     f32x4 acc[NTWM];
-    const unsigned m = mask[t.tid];
+    unsigned m = mask[t.tid];
     smallw_mul<NTWM, KB, false>(w, A, lda, 0, t, acc);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool pos = (m >> (4 * i + r)) & 1u;
-            const float o = pos ? acc[i][r] : 0.f;
+            const float o = mask_bit(acc[i][r], m);
             OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
             if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
         }
     }
 }
 
-// hidden layer: OUT = relu(A @ B + bias).  With MASK the
-// ReLU sign pattern of this lane's 4*NTWM outputs is kept as one 32-bit word per thread (bit 4 i + r) for the
-// reverse sweep: the same lane of the same wave owns the same (tile, register) there, so no cross-lane
-// exchange and a single LDS store per GEMM.
-// With KSP the weights of the K-split GEMM that consumes OUT are requested right after the main loop: that GEMM
-// reads only the columns this wave writes here (its k-blocks S = wave + 4 s are this wave's column tiles), so it
-// follows without a workgroup barrier and finds its first weights already on the way.
-// OUT[16 x 16*NT] = A @ B for the D x D affine maps with pre-loaded weights (tile = wave, KB = 2: D <= 32)
-__device__ __forceinline__ void dense_small_pre(const SmallW<1, 2>& w, const float* A, int lda, int kmax, int NT,
-                                                float* OUT, int ldo, const Tid& t) {
-    if (t.wave < NT) {
-        f32x4 acc[1];
-        smallw_mul<1, 2, true>(w, A, lda, kmax, t, acc);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) OUT[(4 * t.q + r) * ldo + 16 * t.wave + t.n] = acc[0][r];
-    }
-}
-
+// hidden layer: OUT = relu(A @ B + bias).  With MASK the ReLU sign pattern of this lane's 4*NTWM outputs is kept
+// as one 32-bit word per thread (first output in bit 31, see relu_bit / mask_bit) for the reverse sweep: the same
+// lane of the same wave owns the same (tile, register) there, so no cross-lane exchange and a single LDS store
+// per GEMM.  The K-split GEMM that consumes OUT reads only the columns this wave writes here (its k-blocks
+// S = wave + 4 s are this wave's column tiles), so it follows without a workgroup barrier.
 struct NoPost {
     __device__ __forceinline__ void operator()() const {}
 };
@@ -611,14 +612,12 @@ __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float v = acc[i][r];
-            const bool pos = v > 0.f;
-            const float o = pos ? v : 0.f;
+            const float o = MASK ? relu_bit(v, m) : (v > 0.f ? v : 0.f);
             OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
             if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;       // training tape (HBM)
-            if (MASK) m |= (pos ? 1u : 0u) << (4 * i + r);
         }
     }
-    if (MASK) mask[t.tid] = m;
+    if (MASK) mask[t.tid] = m << (32 - 4 * NTWM);
 }
 
 // backward of a hidden layer: OUT = (A @ B) * mask
@@ -632,7 +631,7 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     WRing<NTWM, DEPTH> w;
-    const unsigned m = mask[t.tid];
+    unsigned m = mask[t.tid];
     if (PRE) {
 #pragma unroll
         for (int i = 0; i < NTWM; ++i) w.r[0][i] = (f32x4){pre->b[i].x, pre->b[i].y, pre->b[i].z, pre->b[i].w};
@@ -648,8 +647,7 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
         const int c = t.wave + 4 * i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const bool pos = (m >> (4 * i + r)) & 1u;
-            const float o = pos ? acc[i][r] : 0.f;
+            const float o = mask_bit(acc[i][r], m);
             OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
             if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
         }
