@@ -569,17 +569,27 @@ __device__ __forceinline__ void dense_masked_small(const SmallW<NTWM, KB>& w, co
     }
 }
 
+// OUT[16 x 16*NT] = A @ B for the D x D affine maps with pre-loaded weights (tile = wave, KB = 2: D <= 32)
+__device__ __forceinline__ void dense_small_pre(const SmallW<1, 2>& w, const float* A, int lda, int kmax, int NT,
+                                                float* OUT, int ldo, const Tid& t) {
+    if (t.wave < NT) {
+        f32x4 acc[1];
+        smallw_mul<1, 2, true>(w, A, lda, kmax, t, acc);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) OUT[(4 * t.q + r) * ldo + 16 * t.wave + t.n] = acc[0][r];
+    }
+}
+
+struct NoPost {
+    __device__ __forceinline__ void operator()() const {}
+};
+
 // hidden layer: OUT = relu(A @ B + bias).  With MASK the ReLU sign pattern of this lane's 4*NTWM outputs is kept
 // as one 32-bit word per thread (first output in bit 31, see relu_bit / mask_bit) for the reverse sweep: the same
 // lane of the same wave owns the same (tile, register) there, so no cross-lane exchange and a single LDS store
 // per GEMM.  The K-split GEMM that consumes OUT reads only the columns this wave writes here (its k-blocks
 // S = wave + 4 s are this wave's column tiles), so it follows without a workgroup barrier.
-struct NoPost {
-    __device__ __forceinline__ void operator()() const {}
-};
-
-// `post` runs between the main loop and the epilogue: the place to request (plain loads) weights of later stages,
-// whose latency then hides behind this epilogue and the stages in between.
+// `post` runs between the main loop and the epilogue (unused hook); PRE: ring_run_pre with injected requests.
 template <int NTWM, int DEPTH, bool MASKK, bool MASK, bool TAPE = false, class Post = NoPost, bool PRE = false,
           int NI = 0, class Inject = NoInject>
 __device__ __forceinline__ void dense_relu(const float* A, int lda, int kmax, int KB, const float4* Bp,
