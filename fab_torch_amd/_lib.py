@@ -86,7 +86,7 @@ SYMBOLS = [
     "fabhip_resample_workspace_bytes", "fabhip_resample_multinomial", "fabhip_resample_systematic",
     "fabhip_gather_rows", "fabhip_debug_timeline", "fabhip_flow_grad_floats", "fabhip_flow_grad_layout",
     "fabhip_flow_tape_bytes", "fabhip_flow_log_prob_tape", "fabhip_flow_param_grad",
-    "fabhip_adam_workspace_bytes", "fabhip_adam_clip_step",
+    "fabhip_adam_workspace_bytes", "fabhip_adam_clip_step", "fabhip_topk_workspace_bytes", "fabhip_topk",
 ]
 
 
@@ -136,6 +136,9 @@ def _declare(lib):
     lib.fabhip_adam_workspace_bytes.argtypes = [i64]
     f32 = C.c_float
     lib.fabhip_adam_clip_step.argtypes = [vp, vp, vp, vp, i64, f32, f32, f32, f32, vp, f32, vp, vp, sz, vp]
+    lib.fabhip_topk_workspace_bytes.restype = sz
+    lib.fabhip_topk_workspace_bytes.argtypes = [i64, i64]
+    lib.fabhip_topk.argtypes = [vp, i64, i64, i32, vp, vp, vp, sz, vp]
     for name in SYMBOLS:
         getattr(lib, name)                    # AttributeError here = header and library disagree
     return lib

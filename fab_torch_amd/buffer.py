@@ -8,6 +8,10 @@ from typing import Callable, Iterable, NamedTuple, Tuple
 
 import torch
 
+from . import _lib
+
+_ws = _lib.Workspace()
+
 
 class ReplayData(NamedTuple):
     x: torch.Tensor
@@ -15,11 +19,33 @@ class ReplayData(NamedTuple):
     log_q_old: torch.Tensor
 
 
+TOPK_SORT_MAX = 16384     # sorted mode of fabhip_topk sorts the selection in one workgroup's LDS
+
+
+def topk_indices(keys: torch.Tensor, k: int, sorted: bool = False) -> torch.Tensor:
+    """Indices of the k largest keys — fabhip_topk (radix select + index-ordered compaction).  sorted=False: in
+    ascending index order; sorted=True (k <= 16384): descending key order, ties by ascending index."""
+    lib = _lib.load()
+    _lib.require_device(keys, "keys")
+    kf = keys.detach().contiguous().float()
+    n = kf.shape[0]
+    idx = torch.empty(k, dtype=torch.int64, device=kf.device)
+    nb = lib.fabhip_topk_workspace_bytes(n, k)
+    ws = _ws.get(nb, kf.device)
+    _lib.check(lib.fabhip_topk(_lib.ptr(kf), n, k, 1 if sorted else 0, _lib.ptr(idx), None, _lib.ptr(ws), nb,
+                               _lib.stream_ptr()), "topk")
+    return idx
+
+
 def sample_without_replacement(logits: torch.Tensor, n: int) -> torch.Tensor:
-    """Gumbel-max trick: top-n of logits + Gumbel(0,1) noise, in random order."""
+    """Gumbel-max trick: top-n of logits + Gumbel(0,1) noise, in random order
+    (fab/utils/prioritised_replay_buffer.py:10-17)."""
     u = torch.rand(logits.shape, device=logits.device, dtype=logits.dtype).clamp_(min=torch.finfo(logits.dtype).tiny)
     z = -torch.log(-torch.log(u))
-    indices = torch.topk(z + logits, n, sorted=False).indices
+    if logits.is_cuda:
+        indices = topk_indices(z + logits, n)             # a set, in index order: permuted right below
+    else:                                                 # host-resident buffers
+        indices = torch.topk(z + logits, n, sorted=False).indices
     return indices[torch.randperm(n, device=indices.device)]
 
 

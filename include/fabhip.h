@@ -282,6 +282,19 @@ int fabhip_resample_systematic(const float* log_w, int64_t n, double u0, int64_t
 int fabhip_gather_rows(const float* src, const int64_t* idx, float* dst, int64_t n_out, int64_t row_len,
                        fabhip_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Top-k selection — the `torch.topk(gumbel + logits, n)` of the prioritised buffer's sampling without
+ * replacement (fab/utils/prioritised_replay_buffer.py:10-17, called from :100-110 with n = n_batches * batch).
+ * sorted = 0: idx_out = the indices of the k largest keys in ascending index order (ties at the threshold: lowest
+ * indices first) — all the buffer needs, it permutes them randomly afterwards; any k <= n.
+ * sorted = 1: descending key order, ties by ascending index (torch.topk with sorted=True up to its unspecified tie
+ * order), k <= 16384 (one LDS-resident sort, else FABHIP_ENOTSUP); key_out (optional) = those keys.
+ * NaN ranks above +inf as in torch; n < 2^32.
+ * ---------------------------------------------------------------------------------------- */
+size_t fabhip_topk_workspace_bytes(int64_t n, int64_t k);
+int fabhip_topk(const float* keys, int64_t n, int64_t k, int32_t sorted, int64_t* idx_out, float* key_out,
+                void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+
 /* Diagnostics (development only): with FABHIP_TIMELINE=1 in the environment fabhip_flow_log_prob records
  * s_memtime stamps at the stage boundaries of one forward and one backward layer of workgroup 0;
  * this call copies the first n (<= 64) stamps to the host (synchronises). */
