@@ -87,6 +87,7 @@ SYMBOLS = [
     "fabhip_gather_rows", "fabhip_debug_timeline", "fabhip_flow_grad_floats", "fabhip_flow_grad_layout",
     "fabhip_flow_tape_bytes", "fabhip_flow_log_prob_tape", "fabhip_flow_param_grad",
     "fabhip_adam_workspace_bytes", "fabhip_adam_clip_step", "fabhip_topk_workspace_bytes", "fabhip_topk",
+    "fabhip_flow_pack_density",
 ]
 
 
@@ -98,6 +99,7 @@ def _declare(lib):
     lib.fabhip_flow_packed_floats.restype = i64
     lib.fabhip_flow_packed_floats.argtypes = [i32, i32, i32]
     lib.fabhip_flow_pack.argtypes = [C.POINTER(FlowParams), vp, vp]
+    lib.fabhip_flow_pack_density.argtypes = [C.POINTER(FlowParams), vp, vp]
     lib.fabhip_flow_sample.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp]
     lib.fabhip_flow_log_prob.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp]
     lib.fabhip_target_log_prob.argtypes = [C.POINTER(Target), vp, vp, vp, i64, vp]

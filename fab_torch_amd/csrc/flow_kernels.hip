@@ -20,7 +20,8 @@ struct MlpTab {
 };
 
 // workgroup y handles layer k0 + y: W / Winv to the scratch area of the packed image, sum(log_S) to the layer block
-__global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab tab, int k0, float* __restrict__ packed) {
+__global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab tab, int k0, float* __restrict__ packed,
+                                                         int with_inverse) {
     const int D = f.D, layer = k0 + blockIdx.x;
     const float* __restrict__ Lraw = tab.L[blockIdx.x];
     const float* __restrict__ Uraw = tab.U[blockIdx.x];
@@ -48,6 +49,7 @@ __global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab t
     __syncthreads();
     auto Lm = [&](int i, int j) -> float { return Ls[i * D + j]; };
     auto Um = [&](int i, int j) -> float { return Us[i * D + j]; };
+    if (with_inverse) {                                        // W^-1: only the sampling direction needs it
     // inverse of unit-lower Lm, column j
     if (tid < D) {
         const int j = tid;
@@ -90,6 +92,7 @@ __global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab t
         Winvout[e] = s;
     }
     __syncthreads();
+    }
     for (int e = tid; e < D * D; e += blockDim.x) {           // Li <- P @ Lm
         const int i = e / D, j = e % D;
         float s = 0.f;
@@ -292,7 +295,7 @@ int64_t fabhip_flow_packed_floats(int32_t dim, int32_t n_layers, int32_t width) 
     return (int64_t)make_flow_dims(dim, n_layers, width).total;
 }
 
-int fabhip_flow_pack(const fabhip_flow_params* p, float* packed, fabhip_stream_t stream) {
+static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_inverse, fabhip_stream_t stream) {
     if (!p || !packed) return FABHIP_EINVAL;
     FAB_TRY(check_flow_shape(p->dim, p->n_layers, p->width));
     if (!p->loc || !p->log_scale) return FABHIP_EINVAL;
@@ -316,12 +319,20 @@ int fabhip_flow_pack(const fabhip_flow_params* p, float* packed, fabhip_stream_t
             mt.w1[y] = p->w1[k]; mt.b1[y] = p->b1[k]; mt.w2[y] = p->w2[k]; mt.b2[y] = p->b2[k];
             mt.w3[y] = p->w3[k]; mt.b3[y] = p->b3[k];
         }
-        hipLaunchKernelGGL(k_affine_assemble, dim3(nl), dim3(256), smem, st, f, at, k0, packed);
+        hipLaunchKernelGGL(k_affine_assemble, dim3(nl), dim3(256), smem, st, f, at, k0, packed, with_inverse);
         const int nblk = ceil_div(f.o_logS, 256 * 4);
         hipLaunchKernelGGL(k_pack_layer, dim3(nblk, nl), dim3(256), 0, st, f, mt, k0, packed);
     }
     hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();
+}
+
+int fabhip_flow_pack(const fabhip_flow_params* p, float* packed, fabhip_stream_t stream) {
+    return flow_pack_impl(p, packed, 1, stream);
+}
+
+int fabhip_flow_pack_density(const fabhip_flow_params* p, float* packed, fabhip_stream_t stream) {
+    return flow_pack_impl(p, packed, 0, stream);
 }
 
 int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,

@@ -105,7 +105,7 @@ class _LogProbWithTape(torch.autograd.Function):
     def forward(ctx, flow, x, *params):
         lib = _lib.load()
         _lib.require_device(x, "x")
-        f, packed = flow.native()
+        f, packed = flow.native(need_inverse=False)
         xd = x.detach().contiguous().float()
         B = xd.shape[0]
         log_q = torch.empty(B, dtype=torch.float32, device=xd.device)
@@ -126,7 +126,7 @@ class _LogProbWithTape(torch.autograd.Function):
         tape, grad_x = ctx.saved_tensors
         if flow._packed_key != ctx.key:
             raise _lib.FabhipError("flow parameters were modified between log_prob(x) and backward()")
-        f, _ = flow.native()
+        f, _ = flow.native(need_inverse=False)
         coef = g.detach().contiguous().float()
         n = lib.fabhip_flow_grad_floats(flow.dim, flow.n_layers, flow.width)
         flat = torch.empty(n, dtype=torch.float32, device=coef.device)
@@ -158,6 +158,7 @@ class RealNVP(nn.Module):
         self._params_struct = None
         self._grad_layout = None
         self._flat_leaf = None
+        self._packed_has_inverse = False
 
     # ---- Distribution interface (fab/types_.py:8-27) ---------------------------------------------
     @property
@@ -228,8 +229,10 @@ class RealNVP(nn.Module):
             net = fl[2 * i].flows[1].param_map.net
             yield net[0], net[2], net[4], fl[2 * i + 1]
 
-    def native(self):
-        """(Flow struct, packed image) — re-tiled by the pack kernels whenever a parameter changed."""
+    def native(self, need_inverse: bool = True):
+        """(Flow struct, packed image) — re-tiled by the pack kernels whenever a parameter changed.
+        need_inverse=False (density evaluations only, e.g. the minibatch loop of the trainer) skips the W^-1
+        matrices; the next caller that samples gets a full re-pack."""
         lib = _lib.load()
         q0 = self._nf_model.q0
         _lib.require_device(q0.loc, "RealNVP parameters")
@@ -239,7 +242,7 @@ class RealNVP(nn.Module):
                         aff.sign_S, aff.P]
         tensors += [q0.loc, q0.log_scale]
         key = tuple((t.data_ptr(), t._version) for t in tensors)
-        if key != self._packed_key:
+        if key != self._packed_key or (need_inverse and not self._packed_has_inverse):
             for t in tensors:
                 if t.dtype != torch.float32 or not t.is_contiguous():
                     raise _lib.FabhipError("RealNVP parameters must be contiguous float32 for the HIP path")
@@ -255,7 +258,9 @@ class RealNVP(nn.Module):
                 for j, nm in enumerate(names):
                     getattr(p, nm)[k] = tensors[11 * k + j].data_ptr()
             p.loc, p.log_scale = q0.loc.data_ptr(), q0.log_scale.data_ptr()
-            _lib.check(lib.fabhip_flow_pack(C.byref(p), _lib.ptr(self._packed), _lib.stream_ptr()), "flow_pack")
+            pack = lib.fabhip_flow_pack if need_inverse else lib.fabhip_flow_pack_density
+            _lib.check(pack(C.byref(p), _lib.ptr(self._packed), _lib.stream_ptr()), "flow_pack")
+            self._packed_has_inverse = need_inverse
             self._packed_key = key
             self._params_struct = p
         f = _lib.Flow(self.dim, self.n_layers, self.width, self._packed.data_ptr())
@@ -276,7 +281,7 @@ class RealNVP(nn.Module):
     def native_log_prob(self, x: torch.Tensor, with_grad: bool = False):
         lib = _lib.load()
         _lib.require_device(x, "x")
-        f, _ = self.native()
+        f, _ = self.native(need_inverse=False)
         x = x.detach().contiguous().float()
         B = x.shape[0]
         log_q = torch.empty(B, dtype=torch.float32, device=x.device)

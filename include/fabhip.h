@@ -65,6 +65,10 @@ int64_t fabhip_flow_packed_floats(int32_t dim, int32_t n_layers, int32_t width);
 /* Assemble W = P L U and W^-1 (fp64 triangular inverses) per layer and re-tile every matrix
  * (and its transpose) into v_mfma_f32_16x16x4_f32 B-operand order.  Call after each optimiser step. */
 int fabhip_flow_pack(const fabhip_flow_params* params, float* packed, fabhip_stream_t stream);
+/* Same without the W^-1 matrices (their float64 triangular inverses are 80 % of the packing time): enough for
+ * fabhip_flow_log_prob / _log_prob_tape / the transition kernels between two optimiser steps of a minibatch loop;
+ * fabhip_flow_sample and fabhip_ais_run need a full fabhip_flow_pack first. */
+int fabhip_flow_pack_density(const fabhip_flow_params* params, float* packed, fabhip_stream_t stream);
 
 typedef struct {
     int32_t dim, n_layers, width;
