@@ -290,6 +290,35 @@ class RealNVP(nn.Module):
                                             _lib.stream_ptr()), "flow_log_prob")
         return log_q, grad
 
+    # ---- autograd-free training entry points (what `_LogProbWithTape` wraps) -----------------------------------------
+    def log_prob_with_tape(self, x: torch.Tensor):
+        """(log q(x), tape handle) through fabhip_flow_log_prob_tape, no autograd graph."""
+        lib = _lib.load()
+        _lib.require_device(x, "x")
+        f, _ = self.native(need_inverse=False)
+        xd = x.detach().contiguous().float()
+        B = xd.shape[0]
+        log_q = torch.empty(B, dtype=torch.float32, device=xd.device)
+        nbytes = lib.fabhip_flow_tape_bytes(self.dim, self.n_layers, self.width, B)
+        tape = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=xd.device)
+        _lib.check(lib.fabhip_flow_log_prob_tape(C.byref(f), _lib.ptr(xd), _lib.ptr(log_q), None, B, _lib.ptr(tape),
+                                                 nbytes, _lib.stream_ptr()), "flow_log_prob_tape")
+        return log_q, (tape, nbytes, B, self._packed_key)
+
+    def param_grad_flat(self, tape_handle, coef: torch.Tensor) -> torch.Tensor:
+        """sum_b coef[b] * d log q(x_b) / d theta as one flat gradient image (layout: `_grad_views`)."""
+        lib = _lib.load()
+        tape, nbytes, B, key = tape_handle
+        if self._packed_key != key:
+            raise _lib.FabhipError("flow parameters were modified between log_prob_with_tape(x) and param_grad_flat()")
+        f, _ = self.native(need_inverse=False)
+        c = coef.detach().contiguous().float()
+        flat = torch.empty(lib.fabhip_flow_grad_floats(self.dim, self.n_layers, self.width), dtype=torch.float32,
+                           device=c.device)
+        _lib.check(lib.fabhip_flow_param_grad(C.byref(self._params_struct), C.byref(f), _lib.ptr(tape), nbytes,
+                                              _lib.ptr(c), B, _lib.ptr(flat), _lib.stream_ptr()), "flow_param_grad")
+        return flat
+
     def log_prob_and_grad(self, x: torch.Tensor):
         """(log q(x), d log q / dx) — what `grad_and_value(x, flow.log_prob)` computes (base.py:50-56)."""
         return self.native_log_prob(x, with_grad=True)

@@ -87,12 +87,14 @@ class FlatAdam(torch.optim.Optimizer):
         return torch.cat(parts).float().contiguous()
 
     @torch.no_grad()
-    def step(self, closure=None, max_grad_norm: Optional[float] = None) -> torch.Tensor:
+    def step(self, closure=None, max_grad_norm: Optional[float] = None,
+             flat_grad: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Clip to `max_grad_norm` (None / inf: no clipping), then Adam.  Returns the gradient norm as a device
-        tensor (what clip_grad_norm_ returns); a non-finite norm leaves the parameters untouched."""
+        tensor (what clip_grad_norm_ returns); a non-finite norm leaves the parameters untouched.
+        `flat_grad`: a gradient image from `RealNVP.param_grad_flat` (no autograd involved), else the .grad fields."""
         assert closure is None
         self._check_alias()
-        g = self._flat_grad()
+        g = flat_grad if flat_grad is not None else self._flat_grad()
         grp = self.param_groups[0]
         mx = 0.0 if (max_grad_norm is None or max_grad_norm == float("inf")) else float(max_grad_norm)
         lib = _lib.load()

@@ -39,19 +39,31 @@ class PrioritisedBufferTrainer:
         loss = grad_norm = None
         for (x, log_w, log_q_old, indices) in mini_dataset:
             self.optimizer.zero_grad()
+            if self._fused:
+                # FlatAdam path, no autograd graph at all: w_adjust is detached in the reference's loss (:164-170), so
+                # d loss / d log_q_b = -w_adjust_b / B exactly, which is fed straight to the parameter-gradient
+                # kernels.  Clipping, the finite-norm check and Adam run on the device; a non-finite loss gives a
+                # non-finite gradient norm, which skips the update there (same outcome as the two host checks of the
+                # reference, :172-181, without synchronising every minibatch).
+                with torch.no_grad():
+                    log_q_x, tape = model.flow.log_prob_with_tape(x)
+                    log_w_adjust = (1 - self.alpha) * (log_q_x - log_q_old)
+                    w_adjust_pre_clip = torch.exp(log_w_adjust)
+                    w_adjust = (torch.clip(w_adjust_pre_clip, max=self.max_adjust_w_clip)
+                                if self.max_adjust_w_clip is not None else w_adjust_pre_clip)
+                    loss = - torch.mean(w_adjust * log_q_x)
+                    flat = model.flow.param_grad_flat(tape, w_adjust * (-1.0 / x.shape[0]))
+                grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm, flat_grad=flat)
+                if not self.w_adjust_in_buffer_after_update:
+                    buf.adjust(log_w_adjust, log_q_x, indices)
+                continue
             log_q_x = model.flow.log_prob(x)
             log_w_adjust = (1 - self.alpha) * (log_q_x.detach() - log_q_old)
             w_adjust_pre_clip = torch.exp(log_w_adjust)
             w_adjust = (torch.clip(w_adjust_pre_clip, max=self.max_adjust_w_clip)
                         if self.max_adjust_w_clip is not None else w_adjust_pre_clip)
             loss = - torch.mean(w_adjust * log_q_x)
-            if self._fused:
-                # FlatAdam: clipping, the finite-norm check and Adam run on the device; a non-finite loss gives a
-                # non-finite gradient norm, which skips the update there (same outcome as the two host checks of
-                # the reference, :172-181, without synchronising every minibatch)
-                loss.backward()
-                grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm)
-            elif torch.isfinite(loss):
+            if torch.isfinite(loss):
                 loss.backward()
                 grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), self.max_gradient_norm)
                 if torch.isfinite(grad_norm):

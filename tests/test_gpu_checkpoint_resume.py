@@ -65,3 +65,20 @@ def test_interrupted_run_resumes_bit_identically(optimiser, tmp_path):
     x = torch.randn(32, D, device=DEV)
     with torch.no_grad():
         assert torch.equal(flow.native_log_prob(x)[0], flow2.native_log_prob(x)[0])
+
+
+def test_autograd_free_training_entry_points_equal_the_autograd_function():
+    """RealNVP.log_prob_with_tape / param_grad_flat (what the fused trainer calls) against the torch.autograd.Function
+    wrapping the same kernels: identical log q and, for the same coefficients, a bitwise identical gradient image."""
+    flow, _, _, opt = make(3, "flat_adam")
+    x = torch.randn(200, D, device=DEV)
+    coef = torch.randn(200, device=DEV) / 200
+    opt.zero_grad()
+    lq_a = flow.log_prob(x)
+    (lq_a * coef).sum().backward()
+    g_a = opt.theta.grad.clone()
+    with torch.no_grad():
+        lq_b, tape = flow.log_prob_with_tape(x)
+        g_b = flow.param_grad_flat(tape, coef)
+    assert torch.equal(lq_a.detach(), lq_b) and torch.equal(g_a, g_b)
+    assert float(g_b.abs().max()) > 0
