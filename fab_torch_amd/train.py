@@ -121,8 +121,28 @@ class Trainer:
 
     def step(self, i: int, batch_size: int) -> Dict:
         self.optimizer.zero_grad()
-        loss = self.model.loss(batch_size)
         grad_norm = torch.tensor(float("nan"))
+        if self._fused and self.model.loss_type == "fab_alpha_div":
+            # fab_alpha_div (core.py:112-128) without an autograd graph: the AIS weights are detached, so
+            # d loss / d log_q_b = -sign(alpha) softmax(log_w)_b / B goes straight to the parameter-gradient kernels
+            model = self.model
+            with torch.no_grad():
+                model.set_ais_target(min_is_target=True)
+                point, log_w = model.annealed_importance_sampler.sample_and_log_weights(batch_size)
+                log_q_x, tape = model.flow.log_prob_with_tape(point.x)
+                w = torch.softmax(log_w, dim=-1)
+                sign = float(1.0 if model.alpha > 0 else (-1.0 if model.alpha < 0 else 0.0))
+                loss = -sign * torch.mean(w * log_q_x)
+                flat = model.flow.param_grad_flat(tape, w * (-sign / log_q_x.shape[0]))
+                model.set_ais_target(min_is_target=False)
+            grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm, flat_grad=flat)
+            if self.optim_schedular:
+                self.optim_schedular.step()
+            self.optimizer.zero_grad()
+            info = self.model.get_iter_info()
+            info.update(loss=loss.item(), step=i, grad_norm=float(grad_norm))
+            return info
+        loss = self.model.loss(batch_size)
         if self._fused:
             loss.backward()
             grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm)

@@ -82,3 +82,22 @@ def test_autograd_free_training_entry_points_equal_the_autograd_function():
         g_b = flow.param_grad_flat(tape, coef)
     assert torch.equal(lq_a.detach(), lq_b) and torch.equal(g_a, g_b)
     assert float(g_b.abs().max()) > 0
+
+
+def test_fused_fab_alpha_div_step_equals_the_autograd_step():
+    """Plain Trainer with FlatAdam: the autograd-free fab_alpha_div step against model.loss(B).backward() + the same
+    optimiser step on an identical copy fed the same device noise (fab/core.py:112-128, fab/train.py:100-111)."""
+    flow_a, _, model_a, opt_a = make(4, "flat_adam")
+    flow_b, _, model_b, opt_b = make(4, "flat_adam")
+    torch.manual_seed(77)
+    opt_a.zero_grad()
+    loss_a = model_a.loss(B)
+    loss_a.backward()
+    opt_a.step(max_grad_norm=50.0)
+    torch.manual_seed(77)
+    info = fa.Trainer(model_b, opt_b, max_gradient_norm=50.0).step(1, B)
+    assert abs(info["loss"] - float(loss_a.detach())) <= 1e-6 * max(1.0, abs(float(loss_a.detach())))
+    for (k, va), (_, vb) in zip(flow_a.state_dict().items(), flow_b.state_dict().items()):
+        assert torch.equal(va, vb), k
+    # like core.py:123-128, the sampler is left on the p target (evaluation) after the loss
+    assert model_b.annealed_importance_sampler.p_target is model_a.annealed_importance_sampler.p_target is True
