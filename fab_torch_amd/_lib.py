@@ -76,7 +76,7 @@ TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
 _lib = None
 _lock = threading.Lock()
 
-# every symbol include/fabhip.h declares (checked by tests/test_cabi_symbols.py)
+# every symbol include/fabhip.h declares (checked by tests/test_cabi_and_host.py)
 SYMBOLS = [
     "fabhip_strerror", "fabhip_version", "fabhip_flow_packed_floats", "fabhip_flow_pack", "fabhip_flow_sample",
     "fabhip_flow_log_prob", "fabhip_target_log_prob", "fabhip_create_point", "fabhip_anneal_coefs",

@@ -103,36 +103,20 @@ class _LogProbWithTape(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, flow, x, *params):
-        lib = _lib.load()
-        _lib.require_device(x, "x")
-        f, packed = flow.native(need_inverse=False)
-        xd = x.detach().contiguous().float()
-        B = xd.shape[0]
-        log_q = torch.empty(B, dtype=torch.float32, device=xd.device)
-        grad_x = torch.empty_like(xd) if x.requires_grad else None
-        nbytes = lib.fabhip_flow_tape_bytes(flow.dim, flow.n_layers, flow.width, B)
-        tape = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=xd.device)
-        _lib.check(lib.fabhip_flow_log_prob_tape(C.byref(f), _lib.ptr(xd), _lib.ptr(log_q), _lib.ptr(grad_x), B,
-                                                 _lib.ptr(tape), nbytes, _lib.stream_ptr()), "flow_log_prob_tape")
-        ctx.flow, ctx.B, ctx.nbytes = flow, B, nbytes
-        ctx.key = flow._packed_key
-        ctx.save_for_backward(tape, grad_x if grad_x is not None else torch.empty(0, device=xd.device))
+        if x.requires_grad:
+            log_q, handle, grad_x = flow.log_prob_with_tape(x, want_grad_x=True)
+        else:
+            (log_q, handle), grad_x = flow.log_prob_with_tape(x), None
+        ctx.flow, ctx.handle = flow, handle[1:]
+        ctx.save_for_backward(handle[0], grad_x if grad_x is not None else torch.empty(0, device=log_q.device))
         return log_q
 
     @staticmethod
     def backward(ctx, g):
-        lib = _lib.load()
         flow = ctx.flow
         tape, grad_x = ctx.saved_tensors
-        if flow._packed_key != ctx.key:
-            raise _lib.FabhipError("flow parameters were modified between log_prob(x) and backward()")
-        f, _ = flow.native(need_inverse=False)
         coef = g.detach().contiguous().float()
-        n = lib.fabhip_flow_grad_floats(flow.dim, flow.n_layers, flow.width)
-        flat = torch.empty(n, dtype=torch.float32, device=coef.device)
-        _lib.check(lib.fabhip_flow_param_grad(C.byref(flow._params_struct), C.byref(f), _lib.ptr(tape), ctx.nbytes,
-                                              _lib.ptr(coef), ctx.B, _lib.ptr(flat), _lib.stream_ptr()),
-                   "flow_param_grad")
+        flat = flow.param_grad_flat((tape,) + ctx.handle, coef)
         flow._last_flat_grad = flat
         gx = coef[:, None] * grad_x if ctx.needs_input_grad[1] else None
         if len(ctx.needs_input_grad) == 3:                   # flat mode: one leaf holds every parameter (FlatAdam)
@@ -291,19 +275,21 @@ class RealNVP(nn.Module):
         return log_q, grad
 
     # ---- autograd-free training entry points (what `_LogProbWithTape` wraps) -----------------------------------------
-    def log_prob_with_tape(self, x: torch.Tensor):
-        """(log q(x), tape handle) through fabhip_flow_log_prob_tape, no autograd graph."""
+    def log_prob_with_tape(self, x: torch.Tensor, want_grad_x: bool = False):
+        """(log q(x), tape handle[, d log q / dx]) through fabhip_flow_log_prob_tape, no autograd graph."""
         lib = _lib.load()
         _lib.require_device(x, "x")
         f, _ = self.native(need_inverse=False)
         xd = x.detach().contiguous().float()
         B = xd.shape[0]
         log_q = torch.empty(B, dtype=torch.float32, device=xd.device)
+        grad_x = torch.empty_like(xd) if want_grad_x else None
         nbytes = lib.fabhip_flow_tape_bytes(self.dim, self.n_layers, self.width, B)
         tape = torch.empty(max(nbytes, 4) // 4, dtype=torch.float32, device=xd.device)
-        _lib.check(lib.fabhip_flow_log_prob_tape(C.byref(f), _lib.ptr(xd), _lib.ptr(log_q), None, B, _lib.ptr(tape),
-                                                 nbytes, _lib.stream_ptr()), "flow_log_prob_tape")
-        return log_q, (tape, nbytes, B, self._packed_key)
+        _lib.check(lib.fabhip_flow_log_prob_tape(C.byref(f), _lib.ptr(xd), _lib.ptr(log_q), _lib.ptr(grad_x), B,
+                                                 _lib.ptr(tape), nbytes, _lib.stream_ptr()), "flow_log_prob_tape")
+        handle = (tape, nbytes, B, self._packed_key)
+        return (log_q, handle, grad_x) if want_grad_x else (log_q, handle)
 
     def param_grad_flat(self, tape_handle, coef: torch.Tensor) -> torch.Tensor:
         """sum_b coef[b] * d log q(x_b) / d theta as one flat gradient image (layout: `_grad_views`)."""
