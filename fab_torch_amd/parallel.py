@@ -22,6 +22,10 @@ def shard_sizes(total: int, world: int):
 def pack_particles(x: torch.Tensor, log_w: torch.Tensor, log_q: torch.Tensor, capacity: int) -> torch.Tensor:
     """[capacity, D+3]: x | log_w | log_q | valid-flag, rows beyond len(x) are padding (flag 0)."""
     n, D = x.shape
+    if n == capacity:                           # the usual case (no chain dropped): one concatenation kernel
+        lw = log_w.to(torch.float32)
+        return torch.cat((x.to(torch.float32), lw[:, None], log_q.to(torch.float32)[:, None],
+                          torch.ones_like(lw)[:, None]), dim=1)
     buf = torch.zeros((capacity, D + 3), dtype=torch.float32, device=x.device)
     buf[:n, :D] = x
     buf[:n, D] = log_w
