@@ -66,8 +66,10 @@ class AisArgs(C.Structure):
                 ("noise_a", C.c_void_p), ("noise_b", C.c_void_p), ("step_state", C.c_void_p),
                 ("common_epsilon", C.c_void_p), ("mass", C.c_void_p), ("n_inner", C.c_int32), ("L", C.c_int32),
                 ("max_grad", C.c_float), ("target_p_accept", C.c_float), ("tune", C.c_int32), ("point", Point),
-                ("log_w", C.c_void_p), ("n_valid", C.c_void_p), ("stats", C.c_void_p), ("workspace", C.c_void_p),
-                ("workspace_bytes", C.c_size_t)]
+                ("log_w", C.c_void_p), ("n_valid", C.c_void_p), ("stats", C.c_void_p),
+                ("p_accept_first", C.c_void_p), ("p_accept_last", C.c_void_p), ("avg_distance_first", C.c_void_p),
+                ("avg_distance_last", C.c_void_p), ("base_x", C.c_void_p), ("base_log_w", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
@@ -87,8 +89,9 @@ SYMBOLS = [
     "fabhip_gather_rows", "fabhip_debug_timeline", "fabhip_flow_grad_floats", "fabhip_flow_grad_layout",
     "fabhip_flow_tape_bytes", "fabhip_flow_log_prob_tape", "fabhip_flow_param_grad",
     "fabhip_adam_workspace_bytes", "fabhip_adam_clip_step", "fabhip_topk_workspace_bytes", "fabhip_topk",
-    "fabhip_flow_pack_density",
+    "fabhip_flow_pack_density", "fabhip_abi_sizes", "fabhip_flow_tape_layout",
 ]
+ABI_VERSION = 200          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):
@@ -132,6 +135,7 @@ def _declare(lib):
     lib.fabhip_flow_grad_layout.argtypes = [i32, i32, i32, C.POINTER(i64)]
     lib.fabhip_flow_tape_bytes.restype = sz
     lib.fabhip_flow_tape_bytes.argtypes = [i32, i32, i32, i64]
+    lib.fabhip_flow_tape_layout.argtypes = [i32, i32, i32, i64, C.POINTER(i64)]
     lib.fabhip_flow_log_prob_tape.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp, sz, vp]
     lib.fabhip_flow_param_grad.argtypes = [C.POINTER(FlowParams), C.POINTER(Flow), vp, sz, vp, i64, vp, vp]
     lib.fabhip_adam_workspace_bytes.restype = sz
@@ -143,6 +147,18 @@ def _declare(lib):
     lib.fabhip_topk.argtypes = [vp, i64, i64, i32, vp, vp, vp, sz, vp]
     for name in SYMBOLS:
         getattr(lib, name)                    # AttributeError here = header and library disagree
+    # a stale binary must never be driven with newer struct layouts: ABI revision + sizeof() of every argument struct
+    lib.fabhip_abi_sizes.restype = None
+    lib.fabhip_abi_sizes.argtypes = [C.POINTER(i64)]
+    ver = lib.fabhip_version()
+    if ver != ABI_VERSION:
+        raise FabhipError(f"libfabhip.so has ABI revision {ver}, this binding expects {ABI_VERSION}: rebuild it "
+                          "(python -m fab_torch_amd._build --force)")
+    sizes = (i64 * 8)()
+    lib.fabhip_abi_sizes(sizes)
+    mine = [C.sizeof(t) for t in (FlowParams, Flow, Target, Point, Anneal, HmcArgs, MetropolisArgs, AisArgs)]
+    if list(sizes) != mine:
+        raise FabhipError(f"struct layouts differ between libfabhip.so {list(sizes)} and the ctypes binding {mine}")
     return lib
 
 
@@ -157,10 +173,12 @@ def load():
             try:
                 _build.build(verbose=False)
             except Exception as e:  # noqa: BLE001
-                if not os.path.exists(path):
+                # never fall back to a binary built from other sources (kernel edits / struct changes would run
+                # against old code); FABHIP_ALLOW_STALE=1 is a developer escape hatch only
+                if not os.path.exists(path) or os.environ.get("FABHIP_ALLOW_STALE") != "1":
                     raise FabhipError(
-                        "libfabhip.so is missing and could not be built — the fab_torch_amd hot path has no CPU "
-                        f"fallback ({e})") from e
+                        "libfabhip.so is missing or stale (sources changed since it was built) and could not be "
+                        f"rebuilt — the fab_torch_amd hot path has no CPU fallback ({e})") from e
         try:
             _lib = _declare(C.CDLL(path))
         except OSError as e:
@@ -192,15 +210,21 @@ def require_device(t: torch.Tensor, what: str):
 
 
 class Workspace:
-    """Grow-only byte workspace per device (caller-owned scratch of the C ABI)."""
+    """Grow-only byte workspace per (device, HIP stream) — the caller-owned scratch of the C ABI.  Keyed by the
+    stream the work is enqueued on, so two streams (an evaluation stream next to the training stream, two threads)
+    never share scratch; a grown buffer replaces the old one only for its own stream, whose earlier kernels are
+    ordered before the next use, and the old tensor goes back to torch's caching allocator, which itself only
+    reuses a block on the stream it was allocated on."""
 
     def __init__(self):
         self._buf = {}
 
     def get(self, nbytes: int, device) -> torch.Tensor:
-        key = str(device)
+        dev = torch.device(device)
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (str(dev), stream)
         buf = self._buf.get(key)
         if buf is None or buf.numel() < nbytes:
-            buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=device)
+            buf = torch.empty(max(int(nbytes), 1 << 16), dtype=torch.uint8, device=dev)
             self._buf[key] = buf
         return buf

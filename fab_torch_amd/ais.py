@@ -70,9 +70,10 @@ class AnnealedImportanceSampler:
         target = _owner(self.target_log_prob, _NativeTarget, "target_log_prob")
         return flow, target
 
-    def run(self, batch_size: int, eps0=None, noise_a=None, noise_b=None):
+    def run(self, batch_size: int, eps0=None, noise_a=None, noise_b=None, base_out=None):
         """Enqueue one AIS call; returns device tensors (point fields sized [batch_size], log_w, n_valid[2],
-        stats[16]) without synchronising."""
+        stats[16]) without synchronising.  `base_out = (base_x [B, D], base_log_w [B])` additionally receives the
+        chains' starting points and their log p - log q (generate_eval_data, ais.py:152-166)."""
         lib = _lib.load()
         flow, target = self._native_parts()
         op = self.transition_operator
@@ -123,6 +124,13 @@ class AnnealedImportanceSampler:
         a.point = _lib.Point(x.data_ptr(), lq.data_ptr(), lp.data_ptr(), gq.data_ptr() if hmc else None,
                              gp.data_ptr() if hmc else None)
         a.log_w, a.n_valid, a.stats = log_w.data_ptr(), n_valid.data_ptr(), stats.data_ptr()
+        if hmc:          # per-outer-loop logging slots of the first / last distribution (hmc.py:173-183)
+            a.p_accept_first, a.p_accept_last = op._p_accept_first.data_ptr(), op._p_accept_last.data_ptr()
+            a.avg_distance_first, a.avg_distance_last = op._dist_first.data_ptr(), op._dist_last.data_ptr()
+        if base_out is not None:
+            bx, blw = base_out
+            assert bx.shape == (B, D) and blw.shape == (B,) and bx.is_contiguous() and blw.is_contiguous()
+            a.base_x, a.base_log_w = bx.data_ptr(), blw.data_ptr()
         nb = lib.fabhip_ais_workspace_bytes(B, D, n_inner)
         ws = self._ws.get(nb, dev)
         a.workspace, a.workspace_bytes = ws.data_ptr(), nb
@@ -132,7 +140,7 @@ class AnnealedImportanceSampler:
     def sample_and_log_weights(self, batch_size: int, logging: bool = True, eps0=None, noise_a=None, noise_b=None
                                ) -> Tuple[Point, torch.Tensor]:
         point, log_w, n_valid, stats = self.run(batch_size, eps0, noise_a, noise_b)
-        host = torch.cat([n_valid.float(), stats[:10]]).cpu()          # the single device->host read
+        host = torch.cat([n_valid.float(), stats[:6]]).cpu()          # the single device->host read
         n_init, n_end = int(host[0]), int(host[1])
         if n_init == 0:
             raise Exception("No valid points generated in sampling the chain init")
@@ -144,26 +152,34 @@ class AnnealedImportanceSampler:
         st = host[2:]
         if logging:
             self._logging_info = LoggingInfo(ess_base=float(st[0]), ess_ais=float(st[3]), log_Z=float(st[4]))
-        op = self.transition_operator
-        if isinstance(op, HamiltonianMonteCarlo) and op.n_outer == 1:
-            op._p_accept_first[0], op._p_accept_last[0] = stats[6], stats[7]
-            op._dist_first[0], op._dist_last[0] = stats[8], stats[9]
         return point, log_w.detach()
 
     def generate_eval_data(self, outer_batch_size: int, inner_batch_size: int):
-        """ais.py:132-188 — evaluation batches: flow samples + AIS samples with their log-weights."""
-        flow, target = self._native_parts()
-        base_samples, base_log_w_s, ais_samples, ais_log_w = [], [], [], []
+        """ais.py:132-188 — evaluation batches: the chains' starting points (flow samples) with log p - log q, and
+        the AIS samples with their log-weights.  Everything stays on the device: the batches are enqueued back to
+        back and the row counts of all of them are read with ONE device->host copy at the end (the reference
+        concatenates on the CPU after a `.cpu()` per batch); the returned tensors live on the GPU."""
+        flow, _ = self._native_parts()
         assert outer_batch_size % inner_batch_size == 0
-        for _ in range(outer_batch_size // inner_batch_size):
-            point, log_w, n_valid, stats = self.run(inner_batch_size)
-            # base samples: same x0 is not kept by the fused call -> draw an independent flow batch
-            xb, lqb = flow.native_sample(torch.randn((inner_batch_size, flow.dim), device=point.x.device))
-            lpb = target._native_log_prob(xb)[0]
-            ok = torch.isfinite(lpb) & torch.isfinite(lqb)
-            base_samples.append(xb[ok].cpu())
-            base_log_w_s.append((lpb - lqb)[ok].cpu())
-            n_end = int(n_valid[1])
-            ais_samples.append(point.x[:n_end].cpu())
-            ais_log_w.append(log_w[:n_end].cpu())
-        return (torch.cat(base_samples), torch.cat(base_log_w_s), torch.cat(ais_samples), torch.cat(ais_log_w))
+        n_batches = outer_batch_size // inner_batch_size
+        dev = flow._nf_model.q0.loc.device
+        B, D = inner_batch_size, flow.dim
+        base_x = torch.empty((n_batches, B, D), dtype=torch.float32, device=dev)
+        base_lw = torch.empty((n_batches, B), dtype=torch.float32, device=dev)
+        ais_x, ais_lw, counts = [], [], []
+        for i in range(n_batches):
+            point, log_w, n_valid, _ = self.run(B, base_out=(base_x[i], base_lw[i]))
+            ais_x.append(point.x)
+            ais_lw.append(log_w)
+            counts.append(n_valid)
+        host = torch.stack(counts).cpu()                       # the single synchronisation
+        if int(host[:, 0].min()) == 0:
+            raise Exception("No valid points generated in sampling the chain init")
+        n0 = [int(v) for v in host[:, 0]]
+        n1 = [int(v) if int(v) > 0 else n0[i] for i, v in enumerate(host[:, 1])]   # "chain end": print + keep (:170)
+        if any(int(v) == 0 for v in host[:, 1]):
+            print("No valid points generated in sampling the chain end")
+        return (torch.cat([base_x[i, :n0[i]] for i in range(n_batches)]),
+                torch.cat([base_lw[i, :n0[i]] for i in range(n_batches)]),
+                torch.cat([ais_x[i][:n1[i]] for i in range(n_batches)]),
+                torch.cat([ais_lw[i][:n1[i]] for i in range(n_batches)]))

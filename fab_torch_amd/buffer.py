@@ -37,16 +37,22 @@ def topk_indices(keys: torch.Tensor, k: int, sorted: bool = False) -> torch.Tens
     return idx
 
 
-def sample_without_replacement(logits: torch.Tensor, n: int) -> torch.Tensor:
+def sample_without_replacement(logits: torch.Tensor, n: int, gumbel: torch.Tensor = None,
+                               perm: torch.Tensor = None) -> torch.Tensor:
     """Gumbel-max trick: top-n of logits + Gumbel(0,1) noise, in random order
-    (fab/utils/prioritised_replay_buffer.py:10-17)."""
-    u = torch.rand(logits.shape, device=logits.device, dtype=logits.dtype).clamp_(min=torch.finfo(logits.dtype).tiny)
-    z = -torch.log(-torch.log(u))
-    if logits.is_cuda:
-        indices = topk_indices(z + logits, n)             # a set, in index order: permuted right below
-    else:                                                 # host-resident buffers
-        indices = torch.topk(z + logits, n, sorted=False).indices
-    return indices[torch.randperm(n, device=indices.device)]
+    (fab/utils/prioritised_replay_buffer.py:10-17).  `gumbel [len(logits)]` / `perm [n]` may be supplied (explicit
+    noise, as everywhere in this package: parity replays of the reference's draws); otherwise they come from the
+    device generator."""
+    if gumbel is None:
+        u = torch.rand(logits.shape, device=logits.device, dtype=logits.dtype).clamp_(min=torch.finfo(logits.dtype).tiny)
+        gumbel = -torch.log(-torch.log(u))
+    indices = topk_indices(gumbel.to(logits.device) + logits, n)    # a set, in index order (GPU only): permuted below
+    if perm is None:
+        return indices[torch.randperm(n, device=indices.device)]
+    # the reference permutes torch.topk(sorted=False)'s output, whose order is unspecified; a replay therefore has
+    # to present the SAME set in the reference's pre-permutation order, which the caller encodes in `perm` as
+    # positions into the ascending-index order used here (see tests/test_gpu_workloads.py)
+    return indices[perm.to(indices.device)]
 
 
 class PrioritisedReplayBuffer:
@@ -83,18 +89,20 @@ class PrioritisedReplayBuffer:
         self.current_index = new_index % self.max_length
 
     @torch.no_grad()
-    def sample(self, batch_size: int):
+    def sample(self, batch_size: int, gumbel: torch.Tensor = None, perm: torch.Tensor = None):
         if not self.can_sample:
             raise Exception("Buffer must be at minimum length before calling sample")
         max_index = self.max_length if self.is_full else self.current_index
         if self.sample_with_replacement:
-            indices = torch.distributions.Categorical(logits=self.buffer.log_w[:max_index]).sample((batch_size,))
+            from .resample import multinomial_indices         # Categorical(logits=log_w).sample_n (:95-97) on the GPU
+            indices = multinomial_indices(self.buffer.log_w[:max_index], batch_size)
         else:
-            indices = sample_without_replacement(self.buffer.log_w[:max_index], batch_size)
+            indices = sample_without_replacement(self.buffer.log_w[:max_index], batch_size, gumbel, perm)
         return self.buffer.x[indices], self.buffer.log_w[indices], self.buffer.log_q_old[indices], indices
 
-    def sample_n_batches(self, batch_size: int, n_batches: int) -> Iterable[Tuple[torch.Tensor, ...]]:
-        x, log_w, log_q_old, indices = self.sample(batch_size * n_batches)
+    def sample_n_batches(self, batch_size: int, n_batches: int, gumbel: torch.Tensor = None,
+                         perm: torch.Tensor = None) -> Iterable[Tuple[torch.Tensor, ...]]:
+        x, log_w, log_q_old, indices = self.sample(batch_size * n_batches, gumbel, perm)
         return list(zip(torch.chunk(x, n_batches), torch.chunk(log_w, n_batches), torch.chunk(log_q_old, n_batches),
                         torch.chunk(indices, n_batches)))
 

@@ -113,9 +113,8 @@ class FABModel:
             self.set_ais_target(min_is_target=False)
         base_samples, base_log_w, ais_samples, ais_log_w = \
             self.annealed_importance_sampler.generate_eval_data(outer_batch_size, inner_batch_size)
-        dev = next(self.flow.parameters()).device
-        info = {"eval_ess_flow": effective_sample_size(base_log_w.to(dev)).item(),
-                "eval_ess_ais": effective_sample_size(ais_log_w.to(dev)).item()}
+        info = dict(zip(("eval_ess_flow", "eval_ess_ais"),
+                        torch.stack([effective_sample_size(base_log_w), effective_sample_size(ais_log_w)]).tolist()))
         metrics = getattr(self.target_distribution, "performance_metrics", None)
         if metrics is not None:
             if not ais_only:

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(NTHREADS) void k_create_point(FlowDims f, FlowLds l
 template <int NTWM, bool GRAD>
 __global__ __launch_bounds__(NTHREADS) void k_ais_init(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
                                                        TargetDev tg, const float* __restrict__ eps0, PointDev pt,
-                                                       float* __restrict__ log_w, fabhip_anneal an, long B) {
+                                                       float* __restrict__ log_w, float* __restrict__ base_log_w,
+                                                       fabhip_anneal an, long B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid t;
     const int D = f.D;
@@ -133,6 +134,7 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init(FlowDims f, FlowLds l, Ex
             pt.lq[g] = lq;
             pt.lp[g] = lp;
             log_w[g] = (an.c_q * lq + an.c_p * lp) - lq0;
+            if (base_log_w) base_log_w[g] = lp - lq0;          // ais.py:160 (log q of the sampling pass)
         }
     }
 }
@@ -418,7 +420,8 @@ __global__ __launch_bounds__(1024) void k_valid_scan(const float* __restrict__ l
 struct CompactK {
     PointDev pt;
     float* log_w;
-    float* tmp;            // [B][3D+3]
+    float* extra;          // optional per-row scalar carried along (nullptr: none)
+    float* tmp;            // [B][3D+4]
     const int* dest;
     const int* n_in_ptr;
     const int* n_out_ptr;
@@ -430,7 +433,7 @@ __global__ void k_compact_scatter(CompactK a) {
     const long n_in = a.n_in_ptr ? (long)*a.n_in_ptr : a.B;
     const long n_out = *a.n_out_ptr;
     if (n_out == n_in) return;
-    const int D = a.D, RW = 3 * D + 3;
+    const int D = a.D, RW = 3 * D + 4;
     const bool hg = a.pt.gq != nullptr;
     for (long r = blockIdx.x; r < n_in; r += gridDim.x) {
         const int d = a.dest[r];
@@ -440,7 +443,10 @@ __global__ void k_compact_scatter(CompactK a) {
             o[j] = a.pt.x[r * D + j];
             if (hg) { o[D + j] = a.pt.gq[r * D + j]; o[2 * D + j] = a.pt.gp[r * D + j]; }
         }
-        if (threadIdx.x == 0) { o[3 * D] = a.pt.lq[r]; o[3 * D + 1] = a.pt.lp[r]; o[3 * D + 2] = a.log_w[r]; }
+        if (threadIdx.x == 0) {
+            o[3 * D] = a.pt.lq[r]; o[3 * D + 1] = a.pt.lp[r]; o[3 * D + 2] = a.log_w[r];
+            if (a.extra) o[3 * D + 3] = a.extra[r];
+        }
     }
 }
 
@@ -448,7 +454,7 @@ __global__ void k_compact_copyback(CompactK a) {
     const long n_in = a.n_in_ptr ? (long)*a.n_in_ptr : a.B;
     const long n_out = *a.n_out_ptr;
     if (n_out == n_in) return;
-    const int D = a.D, RW = 3 * D + 3;
+    const int D = a.D, RW = 3 * D + 4;
     const bool hg = a.pt.gq != nullptr;
     for (long r = blockIdx.x; r < n_out; r += gridDim.x) {
         const float* o = a.tmp + r * RW;
@@ -456,7 +462,10 @@ __global__ void k_compact_copyback(CompactK a) {
             a.pt.x[r * D + j] = o[j];
             if (hg) { a.pt.gq[r * D + j] = o[D + j]; a.pt.gp[r * D + j] = o[2 * D + j]; }
         }
-        if (threadIdx.x == 0) { a.pt.lq[r] = o[3 * D]; a.pt.lp[r] = o[3 * D + 1]; a.log_w[r] = o[3 * D + 2]; }
+        if (threadIdx.x == 0) {
+            a.pt.lq[r] = o[3 * D]; a.pt.lp[r] = o[3 * D + 1]; a.log_w[r] = o[3 * D + 2];
+            if (a.extra) a.extra[r] = o[3 * D + 3];
+        }
     }
 }
 
@@ -489,17 +498,18 @@ static int launch_create_point(const FlowDims& f, const float* packed, const Tar
 
 template <int NTWM>
 static int launch_ais_init(const FlowDims& f, const float* packed, const TargetDev& tg, const float* eps0,
-                           const PointDev& pt, float* log_w, fabhip_anneal an, int with_grad, long B, hipStream_t st) {
+                           const PointDev& pt, float* log_w, float* base_log_w, fabhip_anneal an, int with_grad, long B,
+                           hipStream_t st) {
     const FlowLds l = make_flow_lds(f, with_grad != 0);
     const ExtraLds x = make_extra_lds(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid(nblk_of(B)), block(NTHREADS);
     if (with_grad) {
         FAB_TRY(set_max_lds((const void*)k_ais_init<NTWM, true>, bytes));
-        hipLaunchKernelGGL((k_ais_init<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, an, B);
+        hipLaunchKernelGGL((k_ais_init<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, base_log_w, an, B);
     } else {
         FAB_TRY(set_max_lds((const void*)k_ais_init<NTWM, false>, bytes));
-        hipLaunchKernelGGL((k_ais_init<NTWM, false>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, an, B);
+        hipLaunchKernelGGL((k_ais_init<NTWM, false>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, base_log_w, an, B);
     }
     return check_launch();
 }
@@ -654,17 +664,18 @@ size_t fabhip_ais_workspace_bytes(int64_t B, int32_t dim, int32_t n_inner) {
     const size_t m = fabhip_metropolis_workspace_bytes(B, dim, n_inner);
     if (m > s) s = m;
     s = align256(s);
-    s += align256((size_t)B * (3 * dim + 3) * 4);   // compaction staging
+    s += align256((size_t)B * (3 * dim + 4) * 4);   // compaction staging
     s += align256((size_t)B * 4);                    // dest ranks
     s += align256((size_t)B * 4);                    // log_p - log_q
     s += align256(fabhip_ess_workspace_bytes(B));
     return s + 256;
 }
 
-static int compact(const fabhip_ais_args* a, const int* n_in, int* n_out, float* tmp, int* dest, hipStream_t st) {
+static int compact(const fabhip_ais_args* a, const int* n_in, int* n_out, float* tmp, int* dest, float* extra,
+                   hipStream_t st) {
     hipLaunchKernelGGL(k_valid_scan, dim3(1), dim3(1024), 0, st, a->point.log_q, a->point.log_p, n_in, (long)a->B,
                        dest, n_out);
-    CompactK c{make_point_dev(a->point), a->log_w, tmp, dest, n_in, n_out, (long)a->B, a->flow.dim};
+    CompactK c{make_point_dev(a->point), a->log_w, extra, tmp, dest, n_in, n_out, (long)a->B, a->flow.dim};
     const int grid = (int)(a->B < 4096 ? a->B : 4096);
     hipLaunchKernelGGL(k_compact_scatter, dim3(grid), dim3(64), 0, st, c);
     hipLaunchKernelGGL(k_compact_copyback, dim3(grid), dim3(64), 0, st, c);
@@ -694,7 +705,7 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
     if (mws > tws) tws = mws;
     tws = align256(tws);
     void* trans_ws = ws; ws += tws;
-    float* tmp = (float*)ws; ws += align256((size_t)B * (3 * D + 3) * 4);
+    float* tmp = (float*)ws; ws += align256((size_t)B * (3 * D + 4) * 4);
     int* dest = (int*)ws; ws += align256((size_t)B * 4);
     float* lwb = (float*)ws; ws += align256((size_t)B * 4);
     void* ess_ws = ws;
@@ -705,10 +716,14 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
     fabhip_anneal_coefs(a->betas[1], a->alpha, a->p_target, &a1);
     {
         const PointDev pt = make_point_dev(a->point);
-        FAB_DISPATCH_NTW_NORET(f, launch_ais_init, f, a->flow.packed, tg, a->eps0, pt, a->log_w, a1, hmc ? 1 : 0, B, st);
+        FAB_DISPATCH_NTW_NORET(f, launch_ais_init, f, a->flow.packed, tg, a->eps0, pt, a->log_w, a->base_log_w, a1,
+                               hmc ? 1 : 0, B, st);
     }
     // 2. remove nan/inf ("chain init")
-    FAB_TRY(compact(a, nullptr, a->n_valid, tmp, dest, st));
+    FAB_TRY(compact(a, nullptr, a->n_valid, tmp, dest, a->base_log_w, st));
+    if (a->base_x &&      // the compacted starting points (rows beyond n_valid[0] are don't-care)
+        hipMemcpyAsync(a->base_x, a->point.x, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return FABHIP_ELAUNCH;
     // 3. ESS over the base samples (ais.py:68-71) -> stats[0..2]
     hipLaunchKernelGGL(k_sub, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_p, a->point.log_q, lwb, B);
     FAB_TRY(fabhip_ess_logz(lwb, B, a->n_valid, 1.0, a->stats + 0, ess_ws, ess_bytes, stream));
@@ -729,11 +744,9 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
             h.tune = a->tune;
             h.p_accept = nullptr; h.avg_distance = nullptr;
             h.workspace = trans_ws; h.workspace_bytes = tws;
-            // logging slots of the first / last distribution (hmc.py:173-183), loop 0 only
-            if (a->n_inner == 1) {
-                if (j == 1) { h.p_accept = a->stats + 6; h.avg_distance = a->stats + 8; }
-                else if (j == a->M) { h.p_accept = a->stats + 7; h.avg_distance = a->stats + 9; }
-            }
+            // logging slots of the first / last distribution (hmc.py:173-183), one acceptance per outer loop
+            if (j == 1) { h.p_accept = a->p_accept_first; h.avg_distance = a->avg_distance_first; }
+            else if (j == a->M) { h.p_accept = a->p_accept_last; h.avg_distance = a->avg_distance_last; }
             FAB_TRY(hmc_transition_impl(&h, st));
         } else {
             fabhip_metropolis_args m;
@@ -747,7 +760,7 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
         }
     }
     // 5. remove nan/inf ("chain end"), 6. ESS / log Z over the survivors (ais.py:77-86)
-    FAB_TRY(compact(a, a->n_valid, a->n_valid + 1, tmp, dest, st));
+    FAB_TRY(compact(a, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, st));
     FAB_TRY(fabhip_ess_logz(a->log_w, B, a->n_valid + 1, (double)B, a->stats + 3, ess_ws, ess_bytes, stream));
     return check_launch();
 }

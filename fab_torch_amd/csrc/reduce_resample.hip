@@ -742,7 +742,15 @@ const char* fabhip_strerror(int code) {
     }
 }
 
-int fabhip_version(void) { return 100; }
+int fabhip_version(void) { return FABHIP_ABI_VERSION; }
+
+void fabhip_abi_sizes(int64_t out8[8]) {
+    if (!out8) return;
+    out8[0] = (int64_t)sizeof(fabhip_flow_params); out8[1] = (int64_t)sizeof(fabhip_flow);
+    out8[2] = (int64_t)sizeof(fabhip_target);      out8[3] = (int64_t)sizeof(fabhip_point);
+    out8[4] = (int64_t)sizeof(fabhip_anneal);      out8[5] = (int64_t)sizeof(fabhip_hmc_args);
+    out8[6] = (int64_t)sizeof(fabhip_metropolis_args); out8[7] = (int64_t)sizeof(fabhip_ais_args);
+}
 
 int fabhip_target_log_prob(const fabhip_target* target, const float* x, float* log_p, float* grad_x, int64_t B,
                            fabhip_stream_t stream) {

@@ -310,6 +310,16 @@ size_t fabhip_flow_tape_bytes(int32_t dim, int32_t n_layers, int32_t width, int6
     return tape_floats(f, make_tape_dims(f, (long)B)) * sizeof(float);
 }
 
+int fabhip_flow_tape_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t B, int64_t* out18) {
+    if (!out18 || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(dim, n_layers, width));
+    const TapeDims t = make_tape_dims(make_flow_dims(dim, n_layers, width), (long)B);
+    const long v[18] = {t.Bp, t.wz, t.w1, t.wh, t.wp, t.we, t.wb, t.o_ZA, t.o_GZ, t.o_Z1, t.o_H1, t.o_H2, t.o_DP,
+                        t.o_E2, t.o_E1, t.layer_stride, t.o_TB, t.total};
+    for (int i = 0; i < 18; ++i) out18[i] = v[i];
+    return FABHIP_OK;
+}
+
 int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
                               void* tape, size_t tape_bytes, fabhip_stream_t stream) {
     if (!flow || !flow->packed || !x || !log_q || !tape || B < 0) return FABHIP_EINVAL;

@@ -11,8 +11,10 @@ Hot path (no autograd graph requested): `sample_and_log_prob`, `log_prob`, `log_
 fp32-MFMA kernels of csrc/flow_kernels.hip through the C ABI.  When autograd is recording w.r.t. the
 parameters (the trainer's `flow.log_prob(x)` + `loss.backward()`, fab/train_with_prioritised_buffer.py:162-173)
 `log_prob` runs the HIP forward with a tape and `backward` the parameter-gradient GEMM kernels of
-csrc/train_kernels.hip (`_LogProbWithTape`); `sample_and_log_prob` under autograd, and `train_path = "torch"`,
-use the same arithmetic expressed with differentiable PyTorch-ROCm ops on the GPU (the fp32 reference of the tests).
+csrc/train_kernels.hip (`_LogProbWithTape`).  There is no CPU path and no stock-PyTorch density path: every entry
+raises `FabhipError` for tensors that are not on the GPU.  The one exception is documented at `_aten_sample`:
+the REPARAMETERISED sampling gradient needed only by the non-FAB baseline losses (`flow_reverse_kl`,
+`flow_alpha_2_div_nis`, fab/core.py:130-152) is expressed with ATen ops on the GPU.
 """
 import ctypes as C
 import math
@@ -155,23 +157,21 @@ class RealNVP(nn.Module):
         if eps is None:
             eps = torch.randn((shape[0], self.dim), dtype=torch.float32, device=dev)
         if torch.is_grad_enabled() and self._params_need_grad():
-            return self._torch_sample(eps)
+            return self._aten_sample(eps)
         return self.native_sample(eps)
 
     def sample(self, shape: Tuple) -> torch.Tensor:
         return self.sample_and_log_prob(shape)[0]
 
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        _lib.require_device(x, "x")
         if torch.is_grad_enabled() and (x.requires_grad or self._params_need_grad()):
-            if x.is_cuda and self.train_path == "hip":
-                if self._flat_leaf is not None:              # parameters live in one buffer (optim.FlatAdam)
-                    return _LogProbWithTape.apply(self, x, self._flat_leaf)
-                return _LogProbWithTape.apply(self, x, *self._grad_tensors())
-            return self._torch_log_prob(x)
+            if self._flat_leaf is not None:                  # parameters live in one buffer (optim.FlatAdam)
+                return _LogProbWithTape.apply(self, x, self._flat_leaf)
+            return _LogProbWithTape.apply(self, x, *self._grad_tensors())
         return self.native_log_prob(x)[0]
 
     # ---- training path: HIP forward with a tape + parameter-gradient GEMMs (csrc/train_kernels.hip) -----
-    train_path = "hip"          # "torch": the differentiable PyTorch-ROCm expression below (reference for tests)
 
     def _grad_tensors(self):
         """Parameters in the order of the flat gradient image (fabhip_flow_grad_layout)."""
@@ -309,36 +309,18 @@ class RealNVP(nn.Module):
         """(log q(x), d log q / dx) — what `grad_and_value(x, flow.log_prob)` computes (base.py:50-56)."""
         return self.native_log_prob(x, with_grad=True)
 
-    # ---- differentiable PyTorch-ROCm expression of the same maps (training path) --------------------
-    def _mlp(self, l1, l2, l3, z1):
-        h = torch.nn.functional.leaky_relu(l1(z1), 0.0)
-        h = torch.nn.functional.leaky_relu(l2(h), 0.0)
-        return l3(h)
-
-    def _torch_log_prob(self, x):
-        q0 = self._nf_model.q0
-        log_q = torch.zeros(len(x), dtype=x.dtype, device=x.device)
-        z = x
-        for l1, l2, l3, aff in reversed(list(self._layers())):
-            z = z @ aff.assemble()
-            log_q = log_q + torch.sum(aff.log_S)
-            z1, z2 = z[:, :self.d], z[:, self.d:]
-            prm = self._mlp(l1, l2, l3, z1)
-            shift, scale = prm[:, 0::2], prm[:, 1::2]
-            z2 = (z2 - shift) * torch.exp(-scale)
-            log_q = log_q - torch.sum(scale, dim=1)
-            z = torch.cat([z1, z2], 1)
-        base = -0.5 * self.dim * math.log(2 * math.pi) - torch.sum(
-            q0.log_scale + 0.5 * torch.pow((z - q0.loc) / torch.exp(q0.log_scale), 2), 1)
-        return log_q + base
-
-    def _torch_sample(self, eps):
+    # ---- reparameterised sampling gradient (baseline losses only, NOT on the FAB path) ------------------------------
+    def _aten_sample(self, eps):
+        """x, log q = flow.sample with an autograd graph w.r.t. the parameters, for `flow_reverse_kl` /
+        `flow_alpha_2_div_nis` (fab/core.py:130-152), the paper's non-FAB baselines.  GPU only (no CPU path)."""
+        _lib.require_device(eps, "eps")
         q0 = self._nf_model.q0
         z = q0.loc + torch.exp(q0.log_scale) * eps
         log_q = -0.5 * self.dim * math.log(2 * math.pi) - torch.sum(q0.log_scale + 0.5 * torch.pow(eps, 2), 1)
+        relu = torch.nn.functional.relu
         for l1, l2, l3, aff in self._layers():
             z1, z2 = z[:, :self.d], z[:, self.d:]
-            prm = self._mlp(l1, l2, l3, z1)
+            prm = l3(relu(l2(relu(l1(z1)))))
             shift, scale = prm[:, 0::2], prm[:, 1::2]
             z2 = z2 * torch.exp(scale) + shift
             log_q = log_q - torch.sum(scale, dim=1)

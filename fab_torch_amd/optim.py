@@ -95,6 +95,10 @@ class FlatAdam(torch.optim.Optimizer):
         assert closure is None
         self._check_alias()
         g = flat_grad if flat_grad is not None else self._flat_grad()
+        if g.numel() != self.n or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() \
+                or g.device != self.theta.device:
+            raise _lib.FabhipError(f"FlatAdam.step(): gradient image must be a contiguous float32 tensor of "
+                                   f"{self.n} elements on {self.theta.device} (got {tuple(g.shape)} {g.dtype} {g.device})")
         grp = self.param_groups[0]
         mx = 0.0 if (max_grad_norm is None or max_grad_norm == float("inf")) else float(max_grad_norm)
         lib = _lib.load()

@@ -34,6 +34,30 @@ class _NativeTarget(nn.Module):
         return self._native_log_prob(x, with_grad=True)
 
 
+class _TargetLogProb(torch.autograd.Function):
+    """log p(x) with d log p / dx from the same HIP launch (fabhip_target_log_prob): what generic autograd callers
+    such as `grad_and_value(x, target.log_prob)` (fab/sampling_methods/base.py:50-56) and the reverse-KL baseline
+    losses differentiate through."""
+
+    @staticmethod
+    def forward(ctx, target, x):
+        lp, g = target._native_log_prob(x, with_grad=True)
+        ctx.save_for_backward(g)
+        return lp
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        return None, grad_out[:, None] * g
+
+
+def _target_log_prob(target, x):
+    _lib.require_device(x, "x")
+    if torch.is_grad_enabled() and x.requires_grad:
+        return _TargetLogProb.apply(target, x)
+    return target._native_log_prob(x)[0]
+
+
 class ManyWellEnergy(_NativeTarget):
     """log p(x) = sum_i -(a x_{2i} + b x_{2i}^2 + c x_{2i}^4 + x_{2i+1}^2 / 2)."""
 
@@ -72,11 +96,7 @@ class ManyWellEnergy(_NativeTarget):
         return t
 
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
-        if torch.is_grad_enabled() and x.requires_grad:          # generic autograd callers (base.py:50-56)
-            x1, x2 = x[:, 0::2], x[:, 1::2]
-            lp = -(self._a * x1 + self._b * x1.pow(2) + self._c * x1.pow(4) + 0.5 * x2.pow(2)).sum(-1)
-            return lp - float(self.log_Z) if self.normalised else lp
-        return self._native_log_prob(x)[0]
+        return _target_log_prob(self, x)
 
     # ---- evaluation helpers (many_well.py:61-147, double_well.py:61-95; host-side glue, torch on the device) ----
     max_dim_for_all_modes = 40
@@ -192,12 +212,7 @@ class GMM(_NativeTarget):
         return self.distribution.sample(shape)
 
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
-        if torch.is_grad_enabled() and x.requires_grad:
-            lp = self.distribution.log_prob(x)
-            mask = torch.zeros_like(lp)
-            mask[lp < -1e4] = -float("inf")
-            return lp + mask
-        return self._native_log_prob(x)[0]
+        return _target_log_prob(self, x)
 
     # ---- evaluation helpers (gmm.py:33-36, 54-100; host-side torch, not on the hot path) ---------------------------
     expectation_function = staticmethod(quadratic_function)

@@ -16,8 +16,10 @@ class PrioritisedBufferTrainer:
     def __init__(self, model: FABModel, optimizer: torch.optim.Optimizer, buffer: PrioritisedReplayBuffer,
                  alpha: float, n_batches_buffer_sampling: int = 2, optim_schedular=None,
                  max_gradient_norm: Optional[float] = 5.0, w_adjust_max_clip: Optional[float] = 10.0,
-                 w_adjust_in_buffer_after_update: bool = False, logger: Optional[Callable[[Dict], None]] = None):
+                 w_adjust_in_buffer_after_update: bool = False, logger: Optional[Callable[[Dict], None]] = None,
+                 save_path: str = ""):
         self.model, self.optimizer, self.buffer, self.alpha = model, optimizer, buffer, alpha
+        self.save_dir = save_path
         self.model.annealed_importance_sampler.p_target = False          # AIS targets p^alpha q^(1-alpha)
         self.model.annealed_importance_sampler.transition_operator.p_target = False
         self.optim_schedular = optim_schedular
@@ -29,13 +31,20 @@ class PrioritisedBufferTrainer:
         self.history: List[Dict] = []
         self._fused = isinstance(optimizer, FlatAdam)
 
-    def step(self, i: int, batch_size: int) -> Dict:
+    def step(self, i: int, batch_size: int, noise: Optional[Dict] = None) -> Dict:
+        """One iteration of train_with_prioritised_buffer.py:138-198.  `noise` (optional, parity replays): the random
+        draws of the iteration as explicit inputs — eps0 / noise_a / noise_b for the AIS call, gumbel / perm for the
+        buffer's sampling without replacement."""
         model, buf = self.model, self.buffer
+        noise = noise or {}
         self.optimizer.zero_grad()
-        point_ais, log_w_ais = model.annealed_importance_sampler.sample_and_log_weights(batch_size)
+        point_ais, log_w_ais = model.annealed_importance_sampler.sample_and_log_weights(
+            batch_size, eps0=noise.get("eps0"), noise_a=noise.get("noise_a"), noise_b=noise.get("noise_b"))
         buf.add(point_ais.x.detach(), log_w_ais.detach(), point_ais.log_q.detach())
         info = model.get_iter_info()
-        mini_dataset = buf.sample_n_batches(batch_size=batch_size, n_batches=self.n_batches_buffer_sampling)
+        mini_dataset = buf.sample_n_batches(batch_size=batch_size, n_batches=self.n_batches_buffer_sampling,
+                                            gumbel=noise.get("gumbel"), perm=noise.get("perm"))
+        self.last_indices = torch.cat([m[3] for m in mini_dataset])
         loss = grad_norm = None
         for (x, log_w, log_q_old, indices) in mini_dataset:
             self.optimizer.zero_grad()
@@ -52,7 +61,11 @@ class PrioritisedBufferTrainer:
                     w_adjust = (torch.clip(w_adjust_pre_clip, max=self.max_adjust_w_clip)
                                 if self.max_adjust_w_clip is not None else w_adjust_pre_clip)
                     loss = - torch.mean(w_adjust * log_q_x)
-                    flat = model.flow.param_grad_flat(tape, w_adjust * (-1.0 / x.shape[0]))
+                    # a non-finite loss must skip the update even when the gradient image happens to be finite
+                    # (e.g. a row with log_q = -inf whose coefficient is 0 or clipped): poison the coefficients, the
+                    # on-device finite-norm check of fabhip_adam_clip_step then skips (reference :172-181)
+                    poison = torch.where(torch.isfinite(loss), 1.0, float("nan"))
+                    flat = model.flow.param_grad_flat(tape, w_adjust * (-1.0 / x.shape[0]) * poison)
                 grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm, flat_grad=flat)
                 if not self.w_adjust_in_buffer_after_update:
                     buf.adjust(log_w_adjust, log_q_x, indices)
@@ -76,24 +89,66 @@ class PrioritisedBufferTrainer:
                 buf.adjust(log_w_adjust, log_q_x.detach(), indices)
         info.update(loss=loss.item(), step=i, grad_norm=float(grad_norm) if grad_norm is not None else float("nan"),
                     sampled_log_w_std=torch.std(log_w).item(), sampled_log_w_mean=torch.mean(log_w).item(),
-                    w_adjust_mean=torch.mean(w_adjust_pre_clip).item(), log_q_x_mean=torch.mean(log_q_x).item())
+                    w_adjust_mean=torch.mean(w_adjust_pre_clip).item(), w_adjust_min=torch.min(w_adjust_pre_clip).item(),
+                    w_adjust_max=torch.max(w_adjust_pre_clip).item(), log_q_x_mean=torch.mean(log_q_x).item())
         if self.w_adjust_in_buffer_after_update:
             with torch.no_grad():
                 for (x, log_w, log_q_old, indices) in mini_dataset:
                     log_q_new = model.flow.log_prob(x)
                     buf.adjust((1 - self.alpha) * (log_q_new - log_q_old), log_q_new, indices)
-        if self.optim_schedular:
-            self.optim_schedular.step()
+        # NB: like the reference, this trainer never steps `optim_schedular` (it is only checkpointed, :59-68);
+        # fab/train.py:110-111 is the loop that steps it.
         return info
 
-    def run(self, n_iterations: int, batch_size: int, start_iter: int = 0) -> List[Dict]:
+    def save_checkpoint(self, i: int):
+        """model.pt / optimizer.pt / buffer.pt under model_checkpoints/iter_{i}/, scheduler.pt next to the
+        iteration directories (train_with_prioritised_buffer.py:59-68)."""
+        import os
+        ckpt_dir = os.path.join(self.save_dir, "model_checkpoints")
+        path = os.path.join(ckpt_dir, f"iter_{i}")
+        os.makedirs(path, exist_ok=False)
+        self.model.save(os.path.join(path, "model.pt"))
+        torch.save(self.optimizer.state_dict(), os.path.join(path, "optimizer.pt"))
+        self.buffer.save(os.path.join(path, "buffer.pt"))
+        if self.optim_schedular:
+            torch.save(self.optim_schedular.state_dict(), os.path.join(ckpt_dir, "scheduler.pt"))
+
+    def perform_eval(self, i: int, eval_batch_size: int, batch_size: int) -> Dict:
+        """train_with_prioritised_buffer.py:79-101: frozen step sizes; p as the AIS target, then the practical target."""
+        ais = self.model.annealed_importance_sampler
+        ais.transition_operator.set_eval_mode(True)
+        info_p = self.model.get_eval_info(outer_batch_size=eval_batch_size, inner_batch_size=batch_size,
+                                          set_p_target=True)
+        assert ais.p_target is False and ais.transition_operator.p_target is False
+        info_g = self.model.get_eval_info(outer_batch_size=eval_batch_size, inner_batch_size=batch_size,
+                                          set_p_target=False, ais_only=True)
+        ais.transition_operator.set_eval_mode(False)
+        out = {k + "_p_target": v for k, v in info_p.items()}
+        out.update({k + "_min_var_target": v for k, v in info_g.items()})
+        out.update(step=i)
+        return out
+
+    def run(self, n_iterations: int, batch_size: int, eval_batch_size: Optional[int] = None,
+            n_eval: Optional[int] = None, n_checkpoints: Optional[int] = None, start_iter: int = 0) -> List[Dict]:
+        import numpy as np
         if start_iter >= n_iterations:
             raise Exception("Not running training as start_iter >= total training iterations")
+        eval_iter = list(np.linspace(1, n_iterations, n_eval, dtype="int")) if n_eval is not None else []
+        ckpt_iter = list(np.linspace(1, n_iterations, n_checkpoints, dtype="int")) if n_checkpoints else []
+        if n_eval is not None:
+            assert eval_batch_size is not None
         for i in range(start_iter + 1, n_iterations + 1):
             info = self.step(i, batch_size)
             self.history.append(info)
             if self.logger:
                 self.logger(info)
+            if i in eval_iter:
+                ev = self.perform_eval(i, eval_batch_size, batch_size)
+                self.history.append(ev)
+                if self.logger:
+                    self.logger(ev)
+            if i in ckpt_iter:
+                self.save_checkpoint(i)
         return self.history
 
 
@@ -118,6 +173,9 @@ class Trainer:
         os.makedirs(path, exist_ok=False)
         self.model.save(os.path.join(path, "model.pt"))
         torch.save(self.optimizer.state_dict(), os.path.join(path, "optimizer.pt"))
+        if self.optim_schedular:
+            torch.save(self.optim_schedular.state_dict(),
+                       os.path.join(self.save_dir, "model_checkpoints", "scheduler.pt"))
 
     def step(self, i: int, batch_size: int) -> Dict:
         self.optimizer.zero_grad()
@@ -133,21 +191,25 @@ class Trainer:
                 w = torch.softmax(log_w, dim=-1)
                 sign = float(1.0 if model.alpha > 0 else (-1.0 if model.alpha < 0 else 0.0))
                 loss = -sign * torch.mean(w * log_q_x)
-                flat = model.flow.param_grad_flat(tape, w * (-sign / log_q_x.shape[0]))
+                poison = torch.where(torch.isfinite(loss), 1.0, float("nan"))     # non-finite loss => skipped update
+                flat = model.flow.param_grad_flat(tape, w * (-sign / log_q_x.shape[0]) * poison)
                 model.set_ais_target(min_is_target=False)
             grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm, flat_grad=flat)
-            if self.optim_schedular:
-                self.optim_schedular.step()
+            if self.optim_schedular:          # the host reads the loss for logging below anyway
+                if bool(torch.isfinite(loss)):
+                    self.optim_schedular.step()
             self.optimizer.zero_grad()
             info = self.model.get_iter_info()
             info.update(loss=loss.item(), step=i, grad_norm=float(grad_norm))
             return info
         loss = self.model.loss(batch_size)
-        if self._fused:
+        if self._fused and bool(torch.isfinite(loss)):
             loss.backward()
             grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm)
             if self.optim_schedular:
                 self.optim_schedular.step()
+        elif self._fused:
+            print("nan loss encountered")
         elif not torch.isnan(loss) and not torch.isinf(loss):
             loss.backward()
             grad_norm = torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_gradient_norm)

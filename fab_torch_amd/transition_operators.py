@@ -140,19 +140,24 @@ class HamiltonianMonteCarlo(TransitionOperator):
         return self.epsilons[i - 1, n] + self.common_epsilon
 
     def get_logging_info(self) -> dict:
-        M = self.n_ais_intermediate_distributions
+        """Keys of hmc.py:59-88; ONE device->host read for all of them."""
+        M, no = self.n_ais_intermediate_distributions, self.n_outer
+        eps_first = self.epsilons[-1, 0] + self.common_epsilon        # the reference's get_epsilon(0, 0): index -1
+        eps_last = self.epsilons[M - 2, 0] + self.common_epsilon if M > 1 else eps_first
+        host = torch.cat([self._p_accept_first, self._p_accept_last, self._dist_first, self._dist_last,
+                          eps_first.reshape(1), eps_last.reshape(1)]).tolist()
         d = {}
-        for n in range(self.n_outer):
-            d[f"dist0_p_accept_{n}"] = self._p_accept_first[n].item()
+        for n in range(no):
+            d[f"dist0_p_accept_{n}"] = host[n]
         if M > 1:
-            for n in range(self.n_outer):
-                d[f"dist{M - 1}_p_accept_{n}"] = self._p_accept_last[n].item()
-        d["epsilons_dist0_loop0"] = self.get_epsilon(0, 0).cpu().item()      # reference indexes epsilons[-1] here
+            for n in range(no):
+                d[f"dist{M - 1}_p_accept_{n}"] = host[no + n]
+        d["epsilons_dist0_loop0"] = host[2 * no + 2]
         if M > 1:
-            d[f"epsilons_dist{M - 1}_loop0"] = self.get_epsilon(M - 1, 0).cpu().item()
-        d["average_distance_dist0"] = self._dist_first.item()
+            d[f"epsilons_dist{M - 1}_loop0"] = host[2 * no + 3]
+        d["average_distance_dist0"] = host[2 * no]
         if M > 1:
-            d[f"average_distance_dist_{M - 1}"] = self._dist_last.item()
+            d[f"average_distance_dist_{M - 1}"] = host[2 * no + 1]
         return d
 
     def transition(self, point: Point, i: int, beta: float, log_w: torch.Tensor = None, beta_next=None,
@@ -217,8 +222,8 @@ class Metropolis(TransitionOperator):
         self.eval_mode = not eval_setting
 
     def get_logging_info(self) -> Dict:
-        return {"noise_scaling_0_0": self.noise_scalings[0, 0].cpu().item(),
-                "noise_scaling_0_-1": self.noise_scalings[0, -1].cpu().item()}
+        first, last = self.noise_scalings[0, [0, -1]].tolist()             # one device->host read
+        return {"noise_scaling_0_0": first, "noise_scaling_0_-1": last}
 
     def transition(self, point: Point, i: int, beta: float, log_w: torch.Tensor = None, beta_next=None,
                    noise_x: torch.Tensor = None, noise_u: torch.Tensor = None) -> Point:

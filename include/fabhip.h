@@ -34,7 +34,15 @@ enum {
 #define FABHIP_MAX_WIDTH 512
 
 const char* fabhip_strerror(int code);
+/* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
+ * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
+ * mismatch, so that a stale library can never be driven with newer struct layouts. */
+#define FABHIP_ABI_VERSION 200
 int fabhip_version(void);
+/* sizeof() of the argument structs as the library was compiled:
+ * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
+ *  fabhip_metropolis_args, fabhip_ais_args}. */
+void fabhip_abi_sizes(int64_t out8[8]);
 
 /* ------------------------------------------------------------------------------------------
  * RealNVP flow  (replaces normflows NormalizingFlow.sample / .log_prob as wrapped by
@@ -101,6 +109,12 @@ int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, 
 int64_t fabhip_flow_grad_floats(int32_t dim, int32_t n_layers, int32_t width);
 int fabhip_flow_grad_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t* out13);
 size_t fabhip_flow_tape_bytes(int32_t dim, int32_t n_layers, int32_t width, int64_t B);
+/* Layout of the tape (floats): row-major [Bp x width] matrices per layer block, then the base block TB.
+ * out18 = {Bp, wz, w1, wh, wp, we, wb (row widths of ZA/GZ, Z1, H1/H2, DP, E1/E2, TB),
+ *          o_ZA, o_GZ, o_Z1, o_H1, o_H2, o_DP, o_E2, o_E1 (offsets inside a layer block), layer_stride, o_TB, total}.
+ * H1 / H2 hold the hidden activations AFTER the ReLU (their first `width` columns), i.e. the ReLU decisions the
+ * gradients were computed with. */
+int fabhip_flow_tape_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t B, int64_t* out18);
 int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
                               void* tape, size_t tape_bytes, fabhip_stream_t stream);
 int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* flow, const void* tape,
@@ -244,8 +258,20 @@ typedef struct {
     float* log_w;             /* out [B]                                                     */
     int32_t* n_valid;         /* out device int32[2]: rows after "chain init" / "chain end"  */
     float* stats;             /* out device float[16]: [0] ess_base [1] - [2] rows after init
-                                 [3] ess_ais [4] log_Z [5] rows at chain end [6] p_accept first dist
-                                 [7] p_accept last dist [8] avg distance first [9] avg distance last   */
+                                 [3] ess_ais [4] log_Z [5] rows at chain end, rest reserved              */
+    /* HMC logging slots (hmc.py:173-183, store_info), device, each may be NULL: mean acceptance probability of
+     * every outer loop [n_inner] and store_info's mean distance [1], for the first (i = 1) and the last (i = M)
+     * intermediate distribution.  With M = 1 only the "first" pair is written, like the reference. */
+    float* p_accept_first;
+    float* p_accept_last;
+    float* avg_distance_first;
+    float* avg_distance_last;
+    /* Evaluation outputs (ais.py:152-166, generate_eval_data), each may be NULL: the chains' starting points after
+     * the "chain init" filtering, base_x [B][dim], and their importance weights w.r.t. the target,
+     * base_log_w [B] = log p(x0) - log q(x0) with log q as returned by the flow's sampling pass; the first
+     * n_valid[0] rows are the result. */
+    float* base_x;
+    float* base_log_w;
     void* workspace;
     size_t workspace_bytes;
 } fabhip_ais_args;

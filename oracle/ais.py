@@ -110,6 +110,7 @@ class HMC:
         self.n_outer, self.L = n_outer, L
         self.target_p_accept, self.max_grad, self.eval_mode = target_p_accept, max_grad, eval_mode
         self.last_accept = None          # bool mask of the last outer step (for tests)
+        self.last_margin = None
         self.last_p_accept = None
 
     uses_grad_info = True
@@ -139,6 +140,9 @@ class HMC:
             lp_cur = -self._U(current, beta) - torch.sum(current_p ** 2 / self.mass_vector, -1) / 2
             lp_prop = -self._U(point, beta) - torch.sum(p ** 2 / self.mass_vector, -1) / 2
             log_acc = lp_prop - lp_cur
+            # distance of the accept decision from its threshold (tests: a chain may only differ from this oracle
+            # through a decision that sits within rounding of the threshold)
+            self.last_margin = (log_acc + noise_e[n, : log_acc.shape[0]]).detach()
             valid = torch.isfinite(log_acc)
             log_acc = torch.nan_to_num(log_acc, nan=-float("inf"), posinf=-float("inf"),
                                        neginf=-float("inf"))
@@ -235,6 +239,7 @@ class AIS:
         with torch.no_grad():
             ess_base = effective_sample_size(point.log_p - point.log_q).item()
         snaps = [(point.clone(), log_w.clone())] if keep_snapshots else None
+        self.margins = [None]                 # per transition: accept-decision margins of the last outer step
         for j in range(1, self.M + 1):
             point = self.transition_operator.transition(point, j, self.B_space[j], noise_a[j - 1], noise_b[j - 1])
             if self.B_space[j + 1] != self.B_space[j]:
@@ -243,6 +248,7 @@ class AIS:
                 log_w = log_w + (num - den)
             if keep_snapshots:
                 snaps.append((point.clone(), log_w.clone()))
+                self.margins.append(getattr(self.transition_operator, "last_margin", None))
         point, log_w = remove_nan_and_infs(point, log_w, "chain end")
         with torch.no_grad():
             ess_ais = effective_sample_size(log_w).item()

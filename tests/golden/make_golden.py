@@ -179,7 +179,7 @@ def g4_ess():
 
 def g5_multinomial():
     out = {}
-    for N in (64, 1024, 4096):
+    for N in (64, 1024, 4096, 16384):                           # 16384 = BASELINE cfg 4's gathered particle count
         torch.manual_seed(100 + N)
         lw = torch.randn(N) * 3
         x = torch.arange(N, dtype=torch.float32)[:, None].repeat(1, 2)
@@ -378,7 +378,126 @@ def g11_gmm_eval():
         ess_over_p=effective_sample_size_over_p(0.5 * log_w))
 
 
+def g12_trainer_traces():
+    """R14: the reference's PrioritisedBufferTrainer.run (fab/train_with_prioritised_buffer.py:106-255) driven for 5
+    iterations on ManyWell-6 with the oracle flow as the trainable distribution, seeds {0, 1, 2}; every random draw
+    (flow base noise, HMC momenta / Exp(1), the buffer's Gumbel noise and permutation) is captured together with the
+    per-iteration loss, grad_norm, sampled indices and the buffer's log_w / log_q_old after the on-the-fly adjust."""
+    import torch.nn as nn
+    import fab.utils.prioritised_replay_buffer as prb
+    from fab.utils.prioritised_replay_buffer import PrioritisedReplayBuffer
+    from fab.train_with_prioritised_buffer import PrioritisedBufferTrainer
+    from fab.utils.logging import ListLogger
+    from fab import FABModel
+    from torch.distributions.transformed_distribution import TransformedDistribution
+
+    class OracleTrainable(nn.Module):
+        """TrainableDistribution adapter (fab/trainable_distributions/base.py:4) around the oracle RealNVP."""
+
+        def __init__(self, nf):
+            super().__init__()
+            self.nf = nf
+
+        def sample_and_log_prob(self, shape):
+            eps = torch.randn(shape[0], self.nf.q0.shape[0])             # captured (torch.randn)
+            with torch.no_grad():
+                return self.nf.sample_eps(eps)
+
+        def sample(self, shape):
+            return self.sample_and_log_prob(shape)[0]
+
+        def log_prob(self, x):
+            return self.nf.log_prob(x)
+
+        @property
+        def event_shape(self):
+            return self.nf.q0.shape
+
+    D, K, nodes, M, L, B, alpha, n_iter, n_batches = 6, 3, 5, 4, 5, 64, 2.0, 5, 2
+    buf_len, buf_min = 8 * B, 2 * B
+    for seed in (0, 1, 2):
+        nf = make_flow(D, K, nodes, seed=60 + seed)
+        flow = OracleTrainable(nf)
+        target = ManyWellEnergy(dim=D, use_gpu=False)
+        hmc = HamiltonianMonteCarlo(n_ais_intermediate_distributions=M, dim=D, base_log_prob=flow.log_prob,
+                                    target_log_prob=target.log_prob, alpha=alpha, p_target=False, epsilon=0.2,
+                                    n_outer=1, L=L)
+        model = FABModel(flow=flow, target_distribution=target, n_intermediate_distributions=M, alpha=alpha,
+                         transition_operator=hmc)
+        out = dict(D=D, K=K, nodes=nodes, M=M, L=L, B=B, alpha=alpha, n_iter=n_iter, n_batches=n_batches,
+                   buf_len=buf_len, buf_min=buf_min, lr=1e-3, max_gradient_norm=5.0, w_adjust_max_clip=10.0,
+                   in_epsilons=hmc.epsilons.clone(), in_common_epsilon=hmc.common_epsilon.clone())
+        out.update({k: v.detach().clone() for k, v in flow_state(nf).items()})     # the INITIAL parameters
+        ais = model.annealed_importance_sampler
+        calls = []
+        orig_call = ais.sample_and_log_weights
+
+        def recording_call(batch_size, logging=True):
+            with Capture() as cap:
+                res = orig_call(batch_size, logging)
+            calls.append(dict(eps0=cap.randn[0], noise_p=torch.stack(cap.randn_like)[:, None],
+                              noise_e=torch.stack(cap.expo)[:, None], x=res[0].x.clone(), log_w=res[1].clone(),
+                              log_q=res[0].log_q.clone()))
+            return res
+        ais.sample_and_log_weights = recording_call
+        gumbel, perms = [], []
+        o_ts, o_rp = TransformedDistribution.sample, torch.randperm
+
+        def ts(self_, shape=torch.Size()):
+            z = o_ts(self_, shape); gumbel.append(z.clone()); return z
+
+        def rp(*a, **k):
+            p_ = o_rp(*a, **k); perms.append(p_.clone()); return p_
+        torch.manual_seed(1000 + seed)
+
+        def initial_sampler():
+            pt, lw = ais.sample_and_log_weights(B, logging=False)
+            return pt.x, lw, pt.log_q
+        buffer = PrioritisedReplayBuffer(dim=D, max_length=buf_len, min_sample_length=buf_min,
+                                         initial_sampler=initial_sampler)
+        n_init_calls = len(calls)
+        opt = torch.optim.Adam(flow.parameters(), lr=1e-3)
+        logger = ListLogger()
+        trainer = PrioritisedBufferTrainer(model=model, optimizer=opt, buffer=buffer, alpha=alpha,
+                                           n_batches_buffer_sampling=n_batches, logger=logger,
+                                           max_gradient_norm=5.0, w_adjust_max_clip=10.0)
+        snaps = []
+        o_write = logger.write
+
+        def write(info):
+            o_write(info)
+            snaps.append((buffer.buffer.log_w.clone(), buffer.buffer.log_q_old.clone()))
+        logger.write = write
+        o_sample = buffer.sample
+        idx_log = []
+
+        def sample(batch_size):
+            r = o_sample(batch_size); idx_log.append(r[3].clone()); return r
+        buffer.sample = sample
+        TransformedDistribution.sample, torch.randperm = ts, rp
+        try:
+            trainer.run(n_iterations=n_iter, batch_size=B, save=False)
+        finally:
+            TransformedDistribution.sample, torch.randperm = o_ts, o_rp
+        assert len(calls) == n_init_calls + n_iter and len(gumbel) == n_iter == len(perms) == len(idx_log)
+        out["n_init_calls"] = n_init_calls
+        for c, d in enumerate(calls):
+            for k, v in d.items():
+                out[f"call{c}_{k}"] = v
+        hist = logger.history
+        for it in range(n_iter):
+            out[f"it{it}_gumbel"], out[f"it{it}_perm"], out[f"it{it}_indices"] = gumbel[it], perms[it], idx_log[it]
+            out[f"it{it}_buf_log_w"], out[f"it{it}_buf_log_q_old"] = snaps[it]
+            for key in ("loss", "grad_norm", "ess_ais", "ess_base", "log_Z", "w_adjust_mean", "log_q_x_mean",
+                        "sampled_log_w_mean"):
+                out[f"it{it}_{key}"] = hist[key][it]
+        out["out_epsilons"], out["out_common_epsilon"] = hmc.epsilons, hmc.common_epsilon
+        out.update({"final." + k: v for k, v in nf.state_dict().items()})
+        npz(f"g12_trainer_seed{seed}.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)      # deterministic reduction order in the fixtures
     g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
     g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval(); g11_gmm_eval()
+    g12_trainer_traces()

@@ -19,8 +19,10 @@ def load_golden(name):
         return {k: z[k] for k in z.files}
 
 
-def close(a, b, rtol=RTOL, atol_scale=1.0):
-    """max|a-b| <= rtol * max(1, max|b|)  — relative to the magnitude of the reference tensor."""
+def close(a, b, rtol=RTOL, atol=None, atol_scale=1.0):
+    """Element-wise |a-b| <= atol + rtol*|b| (numpy.isclose form) with rtol = 1e-4 (north_star) and a SMALL absolute
+    floor for entries near zero: atol = 1e-6 * max(1, rms(b)) by default (a few fp32 ulps of a typical entry) —
+    not a fraction of the largest entry of the tensor.  Non-finite patterns must agree exactly."""
     a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
     b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
     if a.shape != b.shape:
@@ -30,8 +32,22 @@ def close(a, b, rtol=RTOL, atol_scale=1.0):
     fin = np.isfinite(b)
     if not fin.any():
         return True
-    scale = max(1.0, float(np.abs(b[fin]).max())) * atol_scale
-    return float(np.abs(a[fin].astype(np.float64) - b[fin].astype(np.float64)).max()) <= rtol * scale
+    a64, b64 = a[fin].astype(np.float64), b[fin].astype(np.float64)
+    if atol is None:
+        atol = 1e-6 * max(1.0, float(np.sqrt(np.mean(b64 * b64)))) * atol_scale
+    return bool(np.all(np.abs(a64 - b64) <= atol + rtol * np.abs(b64)))
+
+
+def worst(a, b, rtol=RTOL):
+    """(max |a-b| / (atol + rtol |b|)) diagnostic for assertion messages: <= 1 passes `close`."""
+    a = a.detach().cpu().numpy() if torch.is_tensor(a) else np.asarray(a)
+    b = b.detach().cpu().numpy() if torch.is_tensor(b) else np.asarray(b)
+    fin = np.isfinite(b)
+    if not fin.any():
+        return 0.0
+    a64, b64 = a[fin].astype(np.float64), b[fin].astype(np.float64)
+    atol = 1e-6 * max(1.0, float(np.sqrt(np.mean(b64 * b64))))
+    return float(np.max(np.abs(a64 - b64) / (atol + rtol * np.abs(b64))))
 
 
 def max_rel_err(a, b):

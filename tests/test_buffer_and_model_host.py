@@ -23,23 +23,16 @@ def test_buffer_add_wraparound_and_adjust_match_reference():
     assert buf.can_sample == bool(g["can_sample"])
 
 
-def test_buffer_sampling_properties():
-    torch.manual_seed(0)
-    dim, L = 2, 1000
-    data = (torch.randn(L, dim), torch.randn(L) * 2, torch.randn(L))
-    buf = fa.PrioritisedReplayBuffer(dim, L + 1, L - 1, lambda: data)
-    x, lw, lq, idx = buf.sample(300)
-    assert len(set(idx.tolist())) == 300 and idx.max() < L                  # without replacement
-    assert torch.equal(x, buf.buffer.x[idx]) and torch.equal(lw, buf.buffer.log_w[idx])
-    # prioritised: the selected set is biased towards large log-weights
-    assert lw.mean() > data[1].mean() + 0.5
-    buf.buffer.log_w[:500] = -float("inf")                                   # killed entries are never drawn
-    _, _, _, idx2 = buf.sample(400)
-    assert idx2.min() >= 500
-    parts = buf.sample_n_batches(50, 4)
-    assert len(parts) == 4 and all(p[0].shape == (50, dim) for p in parts)
+def test_buffer_sampling_needs_the_gpu():
+    """Gumbel-top-k sampling is fabhip_topk: a host-resident buffer cannot be sampled (no torch.topk fallback).
+    The sampling properties themselves are checked on the GPU (tests/test_gpu_workloads.py)."""
+    from fab_torch_amd._lib import FabhipError
+    data = (torch.randn(100, 2), torch.randn(100), torch.randn(100))
+    buf = fa.PrioritisedReplayBuffer(2, 101, 99, lambda: data)
+    with pytest.raises(FabhipError, match="no CPU path"):
+        buf.sample(10)
     with pytest.raises(Exception):
-        fa.PrioritisedReplayBuffer(dim, 10, 5, lambda: data, fill_buffer_during_init=False).sample(2)
+        fa.PrioritisedReplayBuffer(2, 10, 5, lambda: data, fill_buffer_during_init=False).sample(2)
 
 
 def test_fabmodel_contracts_without_gpu():
@@ -58,9 +51,14 @@ def test_fabmodel_contracts_without_gpu():
     assert list(model.parameters())[0] is list(flow.parameters())[0]
     assert model.get_iter_info() == {}
     x = torch.randn(8, 6)
-    loss = model.forward_kl(x)                                                # differentiable torch expression on CPU
-    loss.backward()
-    assert torch.isfinite(loss) and flow._nf_model.q0.loc.grad is not None
+    from fab_torch_amd._lib import FabhipError
+    with pytest.raises(FabhipError, match="no CPU path"):                     # the product has no CPU / ATen density
+        model.forward_kl(x)
+    with pytest.raises(FabhipError, match="no CPU path"):
+        with torch.no_grad():
+            flow.log_prob(x)
+    with pytest.raises(FabhipError, match="no CPU path"):
+        target.log_prob(x)
 
 
 def test_fabmodel_save_load_roundtrip(tmp_path):

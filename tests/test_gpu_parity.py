@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_golden, oracle_flow_from_golden, close, max_rel_err, RTOL
+from helpers import load_golden, oracle_flow_from_golden, close, max_rel_err, worst, RTOL
+import aten_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -70,21 +71,46 @@ def test_flow_log_prob_grad_sample_vs_oracle(D, K, nodes, B):
     assert lq_t.requires_grad and close(lq_t, lq_o, RTOL)
 
 
-def relu_kink_samples(nf, x, width, thr=2e-5):
-    """Rows of x for which some hidden pre-activation of the (fp64) oracle flow lies within thr of zero."""
+def hip_relu_decisions(hf, x_dev):
+    """The ReLU decisions the HIP training forward took: H1 / H2 of the tape (fabhip_flow_tape_layout) are the hidden
+    activations after the ReLU, so `> 0` is the mask each gradient was computed with.  [K][2] bool [B, W] (CPU)."""
+    import ctypes as C
+    from fab_torch_amd import _lib
+    B = x_dev.shape[0]
+    with torch.no_grad():
+        _, handle = hf.log_prob_with_tape(x_dev)
+    tape = handle[0]
+    lay = (C.c_int64 * 18)()
+    _lib.check(_lib.load().fabhip_flow_tape_layout(hf.dim, hf.n_layers, hf.width, B, lay), "tape_layout")
+    Bp, wz, w1, wh, wp, we, wb, oZA, oGZ, oZ1, oH1, oH2, oDP, oE2, oE1, stride, oTB, total = [int(v) for v in lay]
+    out = []
+    for k in range(hf.n_layers):
+        blk = tape[k * stride:(k + 1) * stride]
+        h1 = blk[oH1:oH1 + Bp * wh].view(Bp, wh)[:B, :hf.width]
+        h2 = blk[oH2:oH2 + Bp * wh].view(Bp, wh)[:B, :hf.width]
+        out.append(((h1 > 0).cpu(), (h2 > 0).cpu()))
+    return out
+
+
+class _ForcedReLU(torch.nn.Module):
+    def __init__(self, mask):
+        super().__init__()
+        self.mask = mask
+
+    def forward(self, v):
+        return v * self.mask.to(v.dtype)
+
+
+def fp64_oracle_with_decisions(nf, decisions):
+    """float64 copy of the oracle flow whose ReLUs apply the given decisions: the exact gradient of the function
+    the HIP kernels evaluated, also for samples with a hidden pre-activation within rounding distance of zero
+    (where the derivative otherwise depends on the fp32 summation order of whoever evaluates it)."""
     import copy
     nf64 = copy.deepcopy(nf).double()
-    near = torch.zeros(len(x), dtype=torch.bool)
-
-    def hook(mod, inp, out):
-        if out.shape[-1] == width:
-            near.__ior__((out.abs() < thr).any(dim=1))
-    hooks = [m.register_forward_hook(hook) for m in nf64.modules() if isinstance(m, torch.nn.Linear)]
-    with torch.no_grad():
-        nf64.log_prob(x.double())
-    for h in hooks:
-        h.remove()
-    return near
+    for k, (m1, m2) in enumerate(decisions):
+        net = nf64.flows[2 * k].flows[1].param_map.net
+        net[1], net[3] = _ForcedReLU(m1), _ForcedReLU(m2)
+    return nf64
 
 
 def _param_grads(flow_module, params, x, coef, x_grad=False):
@@ -96,15 +122,23 @@ def _param_grads(flow_module, params, x, coef, x_grad=False):
     return lq.detach(), [p.grad.detach().clone() for p in params], (xg.grad if x_grad else None)
 
 
+class _Aten:
+    def __init__(self, hf):
+        self.hf = hf
+
+    def log_prob(self, x):
+        return aten_reference.log_prob(self.hf, x)
+
+
 @pytest.mark.parametrize("D,K,nodes,B", [(6, 3, 5, 50), (2, 4, 40, 100), (5, 2, 4, 17), (32, 10, 10, 333),
                                          (60, 2, 4, 40), (6, 8, 40, 1000), (32, 2, 16, 64)])
 def test_flow_parameter_gradients_vs_oracle_autograd(D, K, nodes, B):
     """Training path (csrc/train_kernels.hip through fabhip_flow_log_prob_tape / fabhip_flow_param_grad):
-    sum_b coef_b d log q(x_b)/d theta for every parameter against torch autograd of the CPU oracle flow, and against
-    the PyTorch-ROCm expression of the flow on the GPU; tolerance 1e-4 of each tensor's largest entry.
-    Samples with a hidden pre-activation within 2e-5 of zero (fp64 oracle) get coefficient 0: there the ReLU
-    derivative depends on the fp32 summation order of whoever evaluates it (tools/diag_relu_kink.py: 3e-3 with
-    them, 2e-6 without, oracle and PyTorch-ROCm disagree with each other on such samples just the same)."""
+    sum_b coef_b d log q(x_b)/d theta for every parameter and d log q / dx against torch autograd of a float64 copy of
+    the CPU oracle flow, on EVERY sample (no exclusions): the oracle's ReLUs apply the decisions the HIP forward
+    took (read back from its tape), so samples at a ReLU kink are compared too.  Tolerance: 1e-4 element-wise
+    relative + a 1e-6-of-rms absolute floor.  Cross-check against the ATen expression on the GPU (gross layout
+    errors only: its own GEMMs sit ~1e-3 from the CPU result on some tensors)."""
     nf = seeded_flow(D, K, nodes, 300 + D + K)
     with torch.no_grad():                                 # non-trivial base / LU parameters too
         g = torch.Generator().manual_seed(9)
@@ -115,31 +149,28 @@ def test_flow_parameter_gradients_vs_oracle_autograd(D, K, nodes, B):
     with torch.no_grad():
         x = nf.sample_eps(torch.randn(B, D))[0] + 0.1 * torch.randn(B, D)
     coef = torch.randn(B) / B
-    near = relu_kink_samples(nf, x, D * nodes)
-    assert int(near.sum()) < B // 2
-    coef = torch.where(near, torch.zeros_like(coef), coef)
+    nf64 = fp64_oracle_with_decisions(nf, hip_relu_decisions(hf, x.to(DEV)))
     names = [n for n, _ in nf.named_parameters()]
-    lq_o, g_o, gx_o = _param_grads(nf, [p for _, p in nf.named_parameters()], x, coef, x_grad=True)
+    assert [n for n, _ in nf64.named_parameters()] == names
+    lq_o, g_o, gx_o = _param_grads(nf64, [p for _, p in nf64.named_parameters()], x.double(), coef.double(),
+                                   x_grad=True)
     hip_params = dict(hf._nf_model.named_parameters())
     assert set(hip_params) == set(names)
     plist = [hip_params[n] for n in names]
-    assert hf.train_path == "hip"
     lq_h, g_h, gx_h = _param_grads(hf, plist, x.to(DEV), coef.to(DEV), x_grad=True)
-    hf.train_path = "torch"
-    try:
-        lq_t, g_t, _ = _param_grads(hf, plist, x.to(DEV), coef.to(DEV))
-    finally:
-        hf.train_path = "hip"
-    assert close(lq_h, lq_o, RTOL) and close(gx_h, gx_o, RTOL)
+    lq_t, g_t, _ = _param_grads(_Aten(hf), plist, x.to(DEV), coef.to(DEV))
+    assert close(lq_h, lq_o.float(), RTOL), worst(lq_h, lq_o.float())
+    assert close(gx_h, gx_o.float(), RTOL, atol_scale=10), worst(gx_h, gx_o.float())
     assert any(float(b.abs().max()) > 1e-3 for b in g_o)
     for n, a, b, c in zip(names, g_h, g_o, g_t):
-        scale = max(float(b.abs().max()), 1e-6)
-        err_o = float((a.cpu() - b).abs().max()) / scale
-        err_t = float((a - c).abs().max()) / scale
-        # the PyTorch-ROCm GEMMs themselves sit ~1e-3 from the CPU fp32 result on some tensors (measured 8e-4
-        # where the HIP path is at 2e-6), so that cross-check only guards against gross layout errors
-        assert err_o <= RTOL and err_t <= 5e-3, f"{n}: err vs oracle {err_o:.2e}, vs torch-GPU {err_t:.2e}"
+        b = b.float()
         assert a.shape == b.shape
+        # a gradient entry is a sum over B samples and up to W hidden units of fp32 products: the absolute floor is
+        # a few fp32 ulps of the tensor's typical entry, the relative part is the north-star 1e-4
+        assert close(a, b, RTOL, atol_scale=30), f"{n}: {worst(a, b):.2f} x tolerance vs the fp64 oracle"
+        scale = max(float(b.abs().max()), 1e-6)
+        err_t = float((a - c).abs().max()) / scale
+        assert err_t <= 5e-3, f"{n}: vs ATen-GPU {err_t:.2e}"
     # deterministic (fixed summation order, no atomics)
     _, g_h2, _ = _param_grads(hf, plist, x.to(DEV), coef.to(DEV))
     assert all(torch.equal(a, b) for a, b in zip(g_h, g_h2))
@@ -184,7 +215,7 @@ def test_flat_adam_matches_clip_grad_norm_and_torch_adam():
     # the kernels see the updated parameters
     x = torch.randn(32, D, device=DEV)
     with torch.no_grad():
-        assert close(fl_a.native_log_prob(x)[0], fl_a._torch_log_prob(x), RTOL)
+        assert close(fl_a.native_log_prob(x)[0], aten_reference.log_prob(fl_a, x), RTOL)
 
 
 def test_targets_vs_golden():
@@ -497,7 +528,7 @@ def test_training_loop_end_to_end_on_manywell6(optimiser):
     x = torch.randn(64, D, device=DEV)
     with torch.no_grad():
         a = flow.native_log_prob(x)[0]
-    b = flow._torch_log_prob(x).detach()
+    b = aten_reference.log_prob(flow, x).detach()
     assert close(a, b, RTOL)
 
 
@@ -541,7 +572,7 @@ def test_plain_trainer_fab_alpha_div_loss(optimiser, tmp_path):
     # loss definition on fixed samples
     pt, lw = model.annealed_importance_sampler.sample_and_log_weights(B)
     loss_hip = model.fab_alpha_div_inner(pt, lw)
-    loss_ref = -torch.mean(torch.softmax(lw, dim=-1) * flow._torch_log_prob(pt.x))
+    loss_ref = -torch.mean(torch.softmax(lw, dim=-1) * aten_reference.log_prob(flow, pt.x))
     assert abs(float(loss_hip) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
     opt = torch.optim.Adam(flow.parameters(), lr=1e-3) if optimiser == "torch_adam" else fa.FlatAdam(flow, lr=1e-3)
     trainer = fa.Trainer(model, opt, max_gradient_norm=100.0, save_path=str(tmp_path))

@@ -1,0 +1,306 @@
+"""GPU tests of the BASELINE.json workloads at their REAL sizes (run with -m gpu on the MI355X box).
+
+For each configuration (cfg1 GMM-40 / Metropolis 512 chains; cfg2 ManyWell-6 1024 chains; headline ManyWell-32 1024
+chains; cfg3 ManyWell-32 K=12 / M=12 / 2048 chains + one prioritised-buffer iteration; cfg4 16384 chains as 8
+emulated 2048-chain shards + gather; cfg5-shaped 60-D target, L=10, M=20, 4096 chains):
+  (1) an oracle-sized slice (the first 32 chains) is compared with the CPU oracle PER TRANSITION on identical inputs
+      and noise (teacher-forced: HMC on a quartic potential is chaotic), a chain may differ only through an accept
+      decision whose margin sits within rounding of the threshold;
+  (2) size-independent properties at the full size: the first 32 chains of the full-size run are BIT-IDENTICAL to the
+      32-chain run on the same noise rows (chains are independent in evaluation mode, so (1) extends to every tile of
+      the full batch), the run is bit-reproducible, nothing is dropped, ESS / log Z are those of the returned weights.
+Plus R14: the reference PrioritisedBufferTrainer traces (g12) replayed through fab_torch_amd's trainer."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, oracle_flow_from_golden, close, max_rel_err, worst, RTOL
+
+pytestmark = pytest.mark.gpu
+
+fa = pytest.importorskip("fab_torch_amd")
+from fab_torch_amd import parallel        # noqa: E402
+from oracle import ais as oais            # noqa: E402
+from oracle import flow as oflow          # noqa: E402
+from oracle import targets as otgt        # noqa: E402
+
+DEV = "cuda"
+SLICE = 32
+
+
+def seeded_flow(D, K, nodes, seed, std=0.05):
+    torch.manual_seed(seed)
+    nf = oflow.make_realnvp(D, K, nodes)
+    oflow.randomize_last_layers(nf, std, seed + 1)
+    return nf
+
+
+def hip_flow_from_oracle(nf):
+    D = nf.q0.loc.shape[1]
+    K = len(nf.flows) // 2
+    W = nf.flows[0].flows[1].param_map.net[0].weight.shape[0]
+    f = fa.RealNVP(D, K, W // D)
+    f._nf_model.load_state_dict(nf.state_dict())
+    return f.to(DEV).requires_grad_(False)
+
+
+class Workload:
+    def __init__(self, name, D, K, nodes, M, B, target="manywell", op="hmc", L=5, eps=0.12, seed=0, spacing="linear",
+                 n_inner=1, log_scale_shift=0.0):
+        self.name, self.D, self.M, self.B, self.op, self.L, self.n_inner = name, D, M, B, op, L, n_inner
+        self.nf = seeded_flow(D, K, nodes, 700 + seed)
+        if log_scale_shift:
+            with torch.no_grad():
+                self.nf.q0.log_scale += log_scale_shift
+        self.hf = hip_flow_from_oracle(self.nf)
+        if target == "manywell":
+            self.target, self.otarget = fa.ManyWellEnergy(D), otgt.ManyWell(D)
+        else:
+            torch.manual_seed(0)
+            self.target = fa.GMM(dim=D, n_mixes=40, loc_scaling=40.0, log_var_scaling=1.0,
+                                 true_expectation_estimation_n_samples=1000)
+            torch.manual_seed(0)
+            self.otarget = otgt.GMM(D, 40, 40.0, 1.0)
+        if op == "hmc":
+            self.hop = fa.HamiltonianMonteCarlo(M, D, self.hf.log_prob, self.target.log_prob, alpha=2.0, p_target=False,
+                                                epsilon=eps, L=L, n_outer=n_inner, eval_mode=True).to(DEV)
+            self.oop = oais.HMC(M, D, self.nf.log_prob, self.otarget.log_prob, alpha=2.0, p_target=False, epsilon=eps,
+                                L=L, n_outer=n_inner, eval_mode=True)
+        else:
+            self.hop = fa.Metropolis(M, D, self.hf.log_prob, self.target.log_prob, n_updates=n_inner, alpha=2.0,
+                                     p_target=False, max_step_size=eps, min_step_size=eps / 2,
+                                     adjust_step_size=False).to(DEV)
+            self.oop = oais.Metropolis(M, D, self.nf.log_prob, self.otarget.log_prob, n_inner, alpha=2.0, p_target=False,
+                                       max_step_size=eps, min_step_size=eps / 2, adjust_step_size=False)
+        self.ais = fa.AnnealedImportanceSampler(self.hf, self.target.log_prob, self.hop, False, 2.0, M, spacing)
+        self.oa = oais.AIS(lambda e: tuple(t.detach() for t in self.nf.sample_eps(e)), self.nf.log_prob,
+                           self.otarget.log_prob, self.oop, False, 2.0, M, spacing)
+        g = torch.Generator().manual_seed(900 + seed)
+        self.eps0 = torch.randn(B, D, generator=g)
+        self.noise_a = torch.randn(M, n_inner, B, D, generator=g)
+        self.noise_b = (torch.empty(M, n_inner, B).exponential_(generator=g) if op == "hmc"
+                        else torch.rand(M, n_inner, B, generator=g))
+
+    def run(self, rows=slice(None)):
+        e0, na, nb = self.eps0[rows], self.noise_a[:, :, rows], self.noise_b[:, :, rows]
+        pt, lw = self.ais.sample_and_log_weights(e0.shape[0], eps0=e0.to(DEV), noise_a=na.contiguous().to(DEV),
+                                                 noise_b=nb.contiguous().to(DEV))
+        return pt, lw, dict(self.ais._logging_info._asdict())
+
+
+def check_slice_vs_oracle_per_transition(w: Workload):
+    """(1) of the module docstring, on the first SLICE chains."""
+    b = SLICE
+    e0, na, nb = w.eps0[:b], w.noise_a[:, :, :b].contiguous(), w.noise_b[:, :, :b].contiguous()
+    opt, olw, oinfo = w.oa.sample_and_log_weights(e0, na, nb, keep_snapshots=True)
+    snaps, margins = w.oa.snapshots, w.oa.margins
+    assert snaps[0][0].x.shape[0] == b, "the oracle dropped a chain: pick another seed for this workload"
+    hmc = w.op == "hmc"
+    n_flipped = 0
+    for j in range(1, w.M + 1):
+        p_in, lw_in = snaps[j - 1]
+        p_ref, lw_ref = snaps[j]
+        g = (lambda t: t.clone().to(DEV)) if hmc else (lambda t: None)
+        pt = fa.Point(p_in.x.clone().to(DEV), p_in.log_q.clone().to(DEV), p_in.log_p.clone().to(DEV),
+                      g(p_in.grad_log_q) if hmc else None, g(p_in.grad_log_p) if hmc else None)
+        lw = lw_in.clone().to(DEV)
+        kw = (dict(noise_p=na[j - 1].to(DEV), noise_e=nb[j - 1].to(DEV)) if hmc
+              else dict(noise_x=na[j - 1].to(DEV), noise_u=nb[j - 1].to(DEV)))
+        w.hop.transition(pt, j, float(w.ais.B_space[j]), log_w=lw, beta_next=float(w.ais.B_space[j + 1]), **kw)
+        scale = max(1.0, float(p_ref.x.abs().max()))
+        err = (pt.x.cpu() - p_ref.x).abs().max(1).values / scale
+        flipped = err > 1e-4
+        if flipped.any():
+            # only a decision within rounding of its threshold may differ (HMC, single outer step: the margin is known)
+            assert hmc and w.n_inner == 1 and margins[j] is not None, f"{w.name} transition {j}: chains differ"
+            m = margins[j][flipped].abs()
+            assert float(m.max()) < 5e-2, f"{w.name} transition {j}: a chain differs with accept margin {float(m.max()):.3f}"
+        n_flipped += int(flipped.sum())
+        ok = ~flipped
+        assert close(lw.cpu()[ok], lw_ref[ok], RTOL), f"{w.name} tr {j}: log_w {worst(lw.cpu()[ok], lw_ref[ok]):.2f}x tol"
+        assert close(pt.log_q.cpu()[ok], p_ref.log_q[ok], RTOL), f"{w.name} tr {j}: log_q"
+        assert close(pt.log_p.cpu()[ok], p_ref.log_p[ok], RTOL), f"{w.name} tr {j}: log_p"
+    assert n_flipped <= max(1, w.M // 4), f"{w.name}: {n_flipped} threshold decisions differ over {w.M} transitions"
+    return opt, olw, oinfo
+
+
+def check_full_size_properties(w: Workload):
+    """(2) of the module docstring."""
+    pt, lw, info = w.run()
+    assert pt.x.shape == (w.B, w.D) and lw.shape == (w.B,), f"{w.name}: chains were dropped"
+    assert torch.isfinite(lw).all() and torch.isfinite(pt.x).all()
+    pt_s, lw_s, _ = w.run(slice(0, SLICE))
+    assert torch.equal(pt.x[:SLICE], pt_s.x) and torch.equal(lw[:SLICE], lw_s), \
+        f"{w.name}: the first {SLICE} chains of the {w.B}-chain run differ from the {SLICE}-chain run"
+    assert torch.equal(pt.log_q[:SLICE], pt_s.log_q) and torch.equal(pt.log_p[:SLICE], pt_s.log_p)
+    # a middle tile too (rows are independent of where their tile sits in the grid)
+    if w.B >= 4 * SLICE:
+        r = slice(w.B // 2 - 8, w.B // 2 - 8 + SLICE)          # straddles three 16-chain tiles
+        pt_m, lw_m, _ = w.run(r)
+        assert torch.equal(pt.x[r], pt_m.x) and torch.equal(lw[r], lw_m)
+    pt2, lw2, _ = w.run()
+    assert torch.equal(pt2.x, pt.x) and torch.equal(lw2, lw), f"{w.name}: not reproducible"
+    # logged statistics are those of the returned weights (numpy float64 restatement of numerical.py:18-23 / ais.py:84)
+    lw64 = lw.double().cpu().numpy()
+    wn = np.exp(lw64 - lw64.max()); wn /= wn.sum()
+    ess = 1.0 / np.sum(wn ** 2) / len(wn)
+    log_z = np.log(np.sum(np.exp(lw64 - lw64.max()))) + lw64.max() - np.log(w.B)
+    assert abs(info["ess_ais"] - ess) <= 1e-4 * ess and abs(info["log_Z"] - log_z) <= 1e-4 * max(1.0, abs(log_z))
+    return pt, lw, info
+
+
+WORKLOADS = {
+    # name: (D, K, nodes, M, B, target, op, L, eps, spacing, n_inner, log_scale_shift)
+    "cfg1_gmm40_metropolis_512": dict(D=2, K=4, nodes=40, M=4, B=512, target="gmm", op="metropolis", eps=5.0,
+                                      n_inner=1, log_scale_shift=2.0),
+    "cfg2_manywell6_1024": dict(D=6, K=8, nodes=40, M=8, B=1024, eps=0.15),
+    "headline_manywell32_1024": dict(D=32, K=10, nodes=10, M=8, B=1024, eps=0.12),
+    "cfg3_manywell32_k12_m12_2048": dict(D=32, K=12, nodes=10, M=12, B=2048, eps=0.12),
+    "cfg5shape_60d_l10_m20_4096": dict(D=60, K=12, nodes=4, M=20, B=4096, L=10, eps=0.06),
+}
+
+
+@pytest.mark.parametrize("name", list(WORKLOADS))
+def test_baseline_workload_slice_parity_and_full_size_properties(name):
+    w = Workload(name, seed=len(name), **WORKLOADS[name])
+    check_slice_vs_oracle_per_transition(w)
+    check_full_size_properties(w)
+
+
+def test_cfg4_sharded_16384_chains_gather_equals_single_run():
+    """BASELINE cfg 4: 16384 chains sharded 8 ways (2048 per rank), one all-gather of the packed particles.  The 8
+    shards are run one after the other on this GPU with the noise rows rank r would own, packed with
+    parallel.pack_particles, concatenated (= what all_gather_into_tensor returns) and unpacked: particles and
+    log-weights must be bit-identical to ONE 16384-chain run on the same noise (evaluation-mode step sizes, SURVEY
+    8e), so the global ESS / log Z equal the single-device run's."""
+    R, per = 8, 2048
+    w = Workload("cfg4", D=32, K=12, nodes=10, M=12, B=R * per, eps=0.12, seed=4)
+    check_slice_vs_oracle_per_transition(w)
+    pt, lw, info = check_full_size_properties(w)
+    bufs = []
+    for r in range(R):
+        p_r, lw_r, _ = w.run(slice(r * per, (r + 1) * per))
+        bufs.append(parallel.pack_particles(p_r.x, lw_r, p_r.log_q, per))
+    x_g, lw_g, lq_g = parallel.unpack_particles(torch.cat(bufs))
+    assert torch.equal(x_g, pt.x) and torch.equal(lw_g, lw) and torch.equal(lq_g, pt.log_q)
+    st = fa.ess_and_log_z(lw_g, n_norm=R * per).cpu()
+    assert abs(float(st[0]) - info["ess_ais"]) <= 1e-5 * info["ess_ais"]
+    assert abs(float(st[1]) - info["log_Z"]) <= 1e-5 * abs(info["log_Z"])
+    # resampling the gathered set (what a consumer of the gathered particles does next): bit-exact vs the oracle
+    from oracle import numerical as onum
+    idx = fa.systematic_indices(lw_g, u0=0.37).cpu().numpy()
+    assert np.array_equal(idx, onum.systematic_fixed(lw_g.cpu().numpy(), 0.37))
+
+
+def test_cfg3_one_prioritised_buffer_iteration_at_full_size():
+    """BASELINE cfg 3 (as SURVEY 0.1 re-scopes it): ManyWell-32, RealNVP K=12, M=12, 2048 chains, HMC, one iteration
+    of the prioritised-buffer trainer (AIS -> add -> Gumbel-top-k minibatches -> fused HIP training steps -> adjust).
+    Properties: the buffer holds the AIS particles, the sampled set is without replacement, parameters move, the
+    weight adjustment equals (1 - alpha)(log q_new - log q_old) recomputed with the oracle flow on a slice."""
+    D, K, M, B = 32, 12, 12, 2048
+    nf = seeded_flow(D, K, 10, 33)
+    hf = hip_flow_from_oracle(nf).requires_grad_(True)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.12, L=5).to(DEV)
+    model = fa.FABModel(hf, target, M, alpha=2.0, transition_operator=hmc)
+    ais = model.annealed_importance_sampler
+
+    def initial_sampler():
+        pt, lw = ais.sample_and_log_weights(B, logging=False)
+        return pt.x, lw, pt.log_q
+    torch.manual_seed(5)
+    buf = fa.PrioritisedReplayBuffer(D, 8 * B, 2 * B, initial_sampler, device=DEV)
+    opt = fa.FlatAdam(hf, lr=1e-4)
+    trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=2.0, n_batches_buffer_sampling=4)
+    before = opt.theta.detach().clone()
+    lw_before = buf.buffer.log_w.clone()
+    lq_before = buf.buffer.log_q_old.clone()
+    info = trainer.step(1, B)
+    assert np.isfinite(info["loss"]) and np.isfinite(info["grad_norm"]) and 0 < info["ess_ais"] <= 1
+    idx = trainer.last_indices
+    assert idx.shape == (4 * B,) and len(set(idx.tolist())) == 4 * B and int(idx.max()) < 3 * B
+    assert not torch.equal(opt.theta.detach(), before)
+    touched = torch.zeros(8 * B, dtype=torch.bool, device=DEV); touched[idx] = True
+    assert torch.equal(buf.buffer.log_w[~touched], lw_before[~touched])          # untouched entries keep their weight
+    # on a slice of the first minibatch (flow parameters = `before`): adjustment vs the oracle flow
+    sl = idx[:SLICE]
+    x_sl = buf.buffer.x[sl].cpu()
+    with torch.no_grad():
+        lq_new = nf.log_prob(x_sl)
+    adj = (1 - 2.0) * (lq_new - lq_before[sl].cpu())
+    assert close(buf.buffer.log_w[sl].cpu(), lw_before[sl].cpu() + adj, RTOL)
+    assert close(buf.buffer.log_q_old[sl].cpu(), lq_new, RTOL)
+
+
+def test_buffer_sampling_properties_on_gpu():
+    torch.manual_seed(0)
+    dim, L = 2, 1000
+    data = (torch.randn(L, dim, device=DEV), torch.randn(L, device=DEV) * 2, torch.randn(L, device=DEV))
+    buf = fa.PrioritisedReplayBuffer(dim, L + 1, L - 1, lambda: data, device=DEV)
+    x, lw, lq, idx = buf.sample(300)
+    assert len(set(idx.tolist())) == 300 and idx.max() < L                  # without replacement
+    assert torch.equal(x, buf.buffer.x[idx]) and torch.equal(lw, buf.buffer.log_w[idx])
+    assert lw.mean() > data[1].mean() + 0.5                                  # prioritised
+    buf.buffer.log_w[:500] = -float("inf")                                   # killed entries are never drawn
+    _, _, _, idx2 = buf.sample(400)
+    assert idx2.min() >= 500
+    parts = buf.sample_n_batches(50, 4)
+    assert len(parts) == 4 and all(p[0].shape == (50, dim) for p in parts)
+    # explicit noise: the selected SET is the top-n of gumbel + log_w, `perm` orders it
+    g = torch.randn(L, device=DEV)
+    _, _, _, idx3 = buf.sample(64, gumbel=g, perm=torch.arange(63, -1, -1, device=DEV))
+    ref = torch.topk(g + buf.buffer.log_w[:L], 64).indices.sort().values
+    assert torch.equal(idx3, ref.flip(0))
+
+
+@pytest.mark.parametrize("optimiser", ["torch_adam", "flat_adam"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_trainer_replays_reference_traces(seed, optimiser):
+    """R14: fab_torch_amd.PrioritisedBufferTrainer against the traces of the reference trainer
+    (fab/train_with_prioritised_buffer.py:138-216 run by tests/golden/make_golden.py:g12, 5 iterations, B = 64,
+    ManyWell-6) on the captured noise: per iteration the sampled index SET and order, loss, grad_norm, the buffer's
+    log_w / log_q_old after the on-the-fly adjust; final parameters and adapted step sizes."""
+    g = load_golden(f"g12_trainer_seed{seed}.npz")
+    D, M, L, B = int(g["D"]), int(g["M"]), int(g["L"]), int(g["B"])
+    alpha, n_iter, n_batches = float(g["alpha"]), int(g["n_iter"]), int(g["n_batches"])
+    nf = oracle_flow_from_golden(g)
+    hf = hip_flow_from_oracle(nf).requires_grad_(True)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=alpha, p_target=False, epsilon=0.2, L=L).to(DEV)
+    model = fa.FABModel(hf, target, M, alpha=alpha, transition_operator=hmc)
+    ais = model.annealed_importance_sampler
+    T = lambda k: torch.tensor(g[k]).to(DEV)          # noqa: E731
+    calls = iter(range(int(g["n_init_calls"])))
+
+    def initial_sampler():
+        c = next(calls)
+        pt, lw = ais.sample_and_log_weights(B, logging=False, eps0=T(f"call{c}_eps0"), noise_a=T(f"call{c}_noise_p"),
+                                            noise_b=T(f"call{c}_noise_e"))
+        assert close(lw, g[f"call{c}_log_w"], RTOL), f"initial call {c}: {worst(lw, g[f'call{c}_log_w']):.2f}x tol"
+        return pt.x, lw, pt.log_q
+    buf = fa.PrioritisedReplayBuffer(D, int(g["buf_len"]), int(g["buf_min"]), initial_sampler, device=DEV)
+    opt = (torch.optim.Adam(hf.parameters(), lr=float(g["lr"])) if optimiser == "torch_adam"
+           else fa.FlatAdam(hf, lr=float(g["lr"])))
+    trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=alpha, n_batches_buffer_sampling=n_batches,
+                                          max_gradient_norm=float(g["max_gradient_norm"]),
+                                          w_adjust_max_clip=float(g["w_adjust_max_clip"]))
+    n_init = int(g["n_init_calls"])
+    for it in range(n_iter):
+        c = n_init + it
+        ref_idx = torch.tensor(g[f"it{it}_indices"])
+        order = torch.searchsorted(ref_idx.sort().values, ref_idx)      # reference order as positions in the sorted set
+        info = trainer.step(it + 1, B, noise=dict(eps0=T(f"call{c}_eps0"), noise_a=T(f"call{c}_noise_p"),
+                                                  noise_b=T(f"call{c}_noise_e"), gumbel=T(f"it{it}_gumbel"),
+                                                  perm=order.to(DEV)))
+        assert torch.equal(trainer.last_indices.cpu(), ref_idx), f"iteration {it}: the sampled set differs"
+        for key in ("loss", "grad_norm", "ess_ais", "log_Z", "w_adjust_mean", "log_q_x_mean"):
+            ref = float(g[f"it{it}_{key}"])
+            assert abs(info[key] - ref) <= 2e-4 * max(1.0, abs(ref)), (it, key, info[key], ref)
+        assert close(buf.buffer.log_w, g[f"it{it}_buf_log_w"], RTOL), (it, worst(buf.buffer.log_w, g[f"it{it}_buf_log_w"]))
+        assert close(buf.buffer.log_q_old, g[f"it{it}_buf_log_q_old"], RTOL)
+    np.testing.assert_allclose(hmc.epsilons.cpu().numpy(), g["out_epsilons"], rtol=1e-6)
+    sd = hf._nf_model.state_dict()
+    for k, v in sd.items():
+        if ("final." + k) in g and v.dtype.is_floating_point:
+            ref = g["final." + k]
+            assert float((v.cpu() - torch.tensor(ref)).abs().max()) <= 2e-5 + 1e-4 * float(np.abs(ref).max()), k

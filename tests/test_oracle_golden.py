@@ -206,3 +206,44 @@ def test_g8_full_ais_metropolis_matches_reference():
     np.testing.assert_array_equal(met.noise_scalings.numpy(), g["out_noise_scalings"])
     assert abs(info.ess_ais - float(g["ess_ais"])) <= 0.01 * float(g["ess_ais"])
     assert abs(info.log_Z - float(g["log_Z"])) <= 1e-4 * abs(float(g["log_Z"])) + 1e-4
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_oracle_trainer_iteration_vs_reference_traces(seed):
+    """R14: oracle/train.py replays the reference PrioritisedBufferTrainer traces (g12: 5 iterations, B = 64, D = 6,
+    captured noise): sampled indices bit-exact, loss / grad_norm / buffer log_w / log_q_old after the adjust and the
+    final parameters to 1e-5 (same eager CPU ops)."""
+    from oracle import train as otrain
+    g = load_golden(f"g12_trainer_seed{seed}.npz")
+    D, M, L, B = int(g["D"]), int(g["M"]), int(g["L"]), int(g["B"])
+    alpha, n_iter, n_batches = float(g["alpha"]), int(g["n_iter"]), int(g["n_batches"])
+    nf = oracle_flow_from_golden(g)
+    target = otgt.ManyWell(D)
+    hmc = oais.HMC(M, D, nf.log_prob, target.log_prob, alpha=alpha, p_target=False, epsilon=0.2, L=L)
+    assert np.array_equal(hmc.epsilons.numpy(), g["in_epsilons"])
+    ais = oais.AIS(lambda e: tuple(t.detach() for t in nf.sample_eps(e)), nf.log_prob, target.log_prob, hmc,
+                   False, alpha, M)
+    buf = otrain.Buffer(D, int(g["buf_len"]), int(g["buf_min"]))
+    n_init = int(g["n_init_calls"])
+    T = torch.tensor
+    for c in range(n_init):                                   # initial_sampler fills the buffer (setup_run.py:119-122)
+        pt, lw, _ = ais.sample_and_log_weights(T(g[f"call{c}_eps0"]), T(g[f"call{c}_noise_p"]), T(g[f"call{c}_noise_e"]))
+        assert close(lw, g[f"call{c}_log_w"], 1e-5)
+        buf.add(pt.x.detach(), lw.detach(), pt.log_q.detach())
+    assert buf.can_sample
+    params = list(nf.parameters())
+    opt = torch.optim.Adam(params, lr=float(g["lr"]))
+    for it in range(n_iter):
+        c = n_init + it
+        noise = dict(eps0=T(g[f"call{c}_eps0"]), noise_p=T(g[f"call{c}_noise_p"]), noise_e=T(g[f"call{c}_noise_e"]),
+                     gumbel=T(g[f"it{it}_gumbel"]), perm=T(g[f"it{it}_perm"]))
+        out = otrain.train_iteration(ais, nf.log_prob, params, opt, buf, alpha, B, n_batches, noise,
+                                     float(g["max_gradient_norm"]), float(g["w_adjust_max_clip"]))
+        assert np.array_equal(out["indices"].numpy(), g[f"it{it}_indices"]), f"iteration {it}: sampled indices"
+        for key in ("loss", "grad_norm", "ess_ais", "log_Z", "w_adjust_mean", "log_q_x_mean"):
+            ref = float(g[f"it{it}_{key}"])
+            assert abs(out[key] - ref) <= 1e-5 * max(1.0, abs(ref)), (it, key, out[key], ref)
+        assert close(buf.log_w, g[f"it{it}_buf_log_w"], 1e-5) and close(buf.log_q_old, g[f"it{it}_buf_log_q_old"], 1e-5)
+    assert np.array_equal(hmc.epsilons.numpy(), g["out_epsilons"])
+    for k, v in nf.state_dict().items():
+        assert close(v, g["final." + k], 1e-5), k

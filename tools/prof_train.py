@@ -44,7 +44,12 @@ def main():
     D, M, L, NB, alpha = 32, 4, 5, 8, 2.0
     torch.manual_seed(0)
     flow = fa.make_wrapped_normflow_realnvp(D, n_flow_layers=10, layer_nodes_per_dim=10, act_norm=False).to(DEV)
-    flow.train_path = args.path
+    if args.path == "torch":          # comparison arm only: the ATen expression of tests/aten_reference.py
+        import sys, os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+        import aten_reference
+        hip_log_prob = flow.log_prob
+        flow.log_prob = lambda x: (aten_reference.log_prob(flow, x) if torch.is_grad_enabled() else hip_log_prob(x))
     target = fa.ManyWellEnergy(D)
     hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=alpha, p_target=False,
                                    epsilon=0.2, n_outer=1, L=L).to(DEV)
