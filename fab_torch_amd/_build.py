@@ -1,5 +1,6 @@
-"""Build libfabhip.so (HIP, gfx950) in-tree with hipcc.  No torch headers are involved: the library is
-a plain C-ABI shared object (include/fabhip.h) loaded through ctypes."""
+"""Build, in-tree with hipcc: (1) libfabhip.so — the HIP kernels (gfx950) behind the plain C ABI of include/fabhip.h,
+no torch headers involved; (2) _fabhip_torch.so — the TORCH_LIBRARY(fabhip) custom-op layer over that ABI
+(csrc/torch_ops.cpp, host C++ compiled against the running torch)."""
 import os
 import shutil
 import subprocess
@@ -24,12 +25,19 @@ def _hipcc():
 
 
 STAMP = LIB + ".srchash"
+TORCH_LIB = os.path.join(HERE, "_fabhip_torch.so")      # TORCH_LIBRARY(fabhip) op layer over the C ABI
+TORCH_SRC = "torch_ops.cpp"
 
 
 def _src_hash():
     import hashlib
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC))
+    try:                                     # the op layer is compiled against torch's headers
+        import torch
+        h.update(torch.__version__.encode())
+    except ImportError:
+        pass
     files.append(os.path.join(os.path.dirname(HERE), "include", "fabhip.h"))
     for f in files:
         with open(f, "rb") as fh:
@@ -41,7 +49,7 @@ def _src_hash():
 def is_stale():
     """True when libfabhip.so is missing or was built from different sources (content hash, not mtimes:
     the snapshot that travels to the GPU box does not preserve them)."""
-    if not (os.path.exists(LIB) and os.path.exists(STAMP)):
+    if not (os.path.exists(LIB) and os.path.exists(TORCH_LIB) and os.path.exists(STAMP)):
         return True
     with open(STAMP) as fh:
         return fh.read().strip() != _src_hash()
@@ -67,27 +75,56 @@ def build(force: bool = False, verbose: bool = True) -> str:
         lock.close()
 
 
+def _torch_flags():
+    import torch
+    from torch.utils import cpp_extension as ce
+    inc = []
+    for d in ce.include_paths():
+        inc += ["-I", d]
+    return ["-O2", "-std=c++17", "-fPIC", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
+            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", "-Wno-unused-result"] + inc + \
+           ["-I", "/opt/rocm/include"]
+
+
 def _build_locked(hipcc, verbose):
 
     def compile_one(src):
-        obj = os.path.join(BUILD, src.replace(".hip", ".o"))
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src == TORCH_SRC:                 # host C++ against torch's headers (no device code)
+            obj = os.path.join(BUILD, "torch_ops.o")
+            cmd = [hipcc] + _torch_flags() + ["-c", os.path.join(CSRC, src), "-o", obj]
+        else:
+            obj = os.path.join(BUILD, src.replace(".hip", ".o"))
+            cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-8000:]}")
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
+        objs = list(ex.map(compile_one, SOURCES + [TORCH_SRC]))
+    torch_obj = objs.pop()
     cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stderr[-8000:]}")
+    _link_torch_ops(hipcc, torch_obj)
     with open(STAMP, "w") as fh:
         fh.write(_src_hash())
     if verbose:
-        print(f"[fab_torch_amd] built {LIB}", file=sys.stderr)
+        print(f"[fab_torch_amd] built {LIB} and {TORCH_LIB}", file=sys.stderr)
     return LIB
+
+
+def _link_torch_ops(hipcc, obj):
+    """fab_torch_amd/_fabhip_torch.so: linked to libfabhip.so next to it (rpath $ORIGIN) and to the torch libraries
+    of the running interpreter."""
+    import torch
+    tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = [hipcc, "-shared", "-fPIC", obj, "-o", TORCH_LIB, "-L", HERE, "-lfabhip", "-L", tlib, "-lc10", "-ltorch_cpu",
+           "-ltorch", "-lc10_hip", "-ltorch_hip", "-Wl,-rpath,$ORIGIN"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"linking the torch op layer failed:\n{r.stderr[-8000:]}")
 
 
 if __name__ == "__main__":

@@ -1,7 +1,10 @@
-"""ctypes binding of libfabhip.so (include/fabhip.h).  PyTorch is used only for device memory and the
-current HIP stream; no torch type crosses the boundary (raw device pointers + sizes).
+"""ctypes binding of the C ABI of libfabhip.so (include/fabhip.h): raw device pointers + sizes, no torch type
+crosses the boundary.
 
-The product path FAILS LOUDLY when the HIP library is missing: there is no CPU fallback."""
+NOT used by the product modules - they call the TORCH_LIBRARY custom ops (`_ops.py`, csrc/torch_ops.cpp), which sit on
+the same C ABI.  This file is (a) the binding a maintainer of a non-torch host would write (INTEGRATION.md quotes
+it) and (b) what the test-suite uses to drive the C ABI directly: symbol/ABI checks on the CPU, and on the GPU the
+test that the custom ops and the raw C ABI give bit-identical results."""
 import ctypes as C
 import os
 import threading
@@ -9,13 +12,10 @@ import threading
 import torch
 
 from . import _build
+from ._ops import FabhipError, require_device  # noqa: F401  (one exception type for both bindings)
 
 MAX_LAYERS = 64
 _FP = C.POINTER(C.c_float)
-
-
-class FabhipError(RuntimeError):
-    pass
 
 
 class FlowParams(C.Structure):
@@ -202,11 +202,6 @@ def ptr(t):
         return None
     assert t.is_contiguous(), "fabhip needs contiguous tensors"
     return C.c_void_p(t.data_ptr())
-
-
-def require_device(t: torch.Tensor, what: str):
-    if not t.is_cuda:
-        raise FabhipError(f"{what} must live on the GPU: fab_torch_amd has no CPU path (got device {t.device})")
 
 
 class Workspace:

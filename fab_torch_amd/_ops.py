@@ -1,0 +1,129 @@
+"""Loader of the PyTorch-ROCm custom-op layer `torch.ops.fabhip.*` (csrc/torch_ops.cpp: TORCH_LIBRARY(fabhip) over
+the C ABI of libfabhip.so, include/fabhip.h).  Every product module reaches the HIP kernels through these ops:
+they are visible to the dispatcher (CUDA/HIP key only - a CPU tensor fails there), enqueue on torch's current HIP
+stream, take their scratch from the caching allocator (stream-ordered) and take part in autograd where a backward
+exists (`fabhip::realnvp_logprob_tape`, registered below with torch.library.register_autograd; its backward is
+`fabhip::realnvp_param_grad`).
+
+The product path FAILS LOUDLY when the extension is missing or stale: there is no CPU / ATen fallback."""
+import ctypes
+import os
+import threading
+
+import torch
+
+from . import _build
+
+ABI_VERSION = 200          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+
+TARGET_MANYWELL, TARGET_GMM = 1, 2
+TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
+
+
+class FabhipError(RuntimeError):
+    pass
+
+
+_ops = None
+_lock = threading.Lock()
+
+
+def load():
+    """torch.ops.fabhip, loading (and when sources changed and hipcc is present, rebuilding) the two libraries."""
+    global _ops
+    if _ops is not None:
+        return _ops
+    with _lock:
+        if _ops is not None:
+            return _ops
+        if _build.is_stale():
+            try:
+                _build.build(verbose=False)
+            except Exception as e:  # noqa: BLE001
+                # never run a binary built from other sources; FABHIP_ALLOW_STALE=1 is a developer escape hatch only
+                if not (os.path.exists(_build.LIB) and os.path.exists(_build.TORCH_LIB)) \
+                        or os.environ.get("FABHIP_ALLOW_STALE") != "1":
+                    raise FabhipError("libfabhip.so / _fabhip_torch.so are missing or stale (sources changed since they "
+                                      f"were built) and could not be rebuilt - there is no CPU fallback ({e})") from e
+        try:
+            ctypes.CDLL(_build.LIB, mode=ctypes.RTLD_GLOBAL)
+            torch.ops.load_library(_build.TORCH_LIB)
+        except OSError as e:
+            raise FabhipError(f"cannot load the fabhip libraries: {e} (no CPU fallback exists)") from e
+        ops = torch.ops.fabhip
+        ver = ops.abi_version()
+        if ver != ABI_VERSION:
+            raise FabhipError(f"libfabhip.so has ABI revision {ver}, the Python side expects {ABI_VERSION}: rebuild "
+                              "(python -m fab_torch_amd._build --force)")
+        _register_autograd()
+        _register_fakes()
+        _ops = ops
+        return _ops
+
+
+def require_device(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise FabhipError(f"{what} must live on the GPU: fab_torch_amd has no CPU path (got device {t.device})")
+
+
+# ---- autograd of the training op ---------------------------------------------------------------------------------
+def _tape_setup_context(ctx, inputs, output):
+    theta, x, packed, params, dim, n_layers, width, want_grad_x = inputs
+    log_q, grad_x, tape = output
+    ctx.dims = (dim, n_layers, width)
+    ctx.n_params = len(params)
+    ctx.have_gx = bool(want_grad_x)
+    ctx.save_for_backward(packed, tape, grad_x, *params)
+
+
+def _tape_backward(ctx, g_log_q, g_grad_x, g_tape):
+    """d loss / d theta = sum_b g_b d log q(x_b) / d theta as ONE flat image (fabhip_flow_param_grad: weight-gradient
+    GEMMs on the matrix cores + the LU chain rule); d loss / dx = g_b * d log q / dx from the forward's reverse sweep."""
+    packed, tape, grad_x = ctx.saved_tensors[:3]
+    params = list(ctx.saved_tensors[3:])
+    coef = g_log_q.detach().contiguous().float()
+    flat = torch.ops.fabhip.realnvp_param_grad(params, packed, *ctx.dims, tape, coef) if ctx.needs_input_grad[0] else None
+    gx = None
+    if ctx.needs_input_grad[1]:
+        if not ctx.have_gx:
+            raise FabhipError("realnvp_logprob_tape: x requires grad but the forward ran without want_grad_x")
+        gx = coef[:, None] * grad_x
+    return flat, gx, None, None, None, None, None, None
+
+
+def _register_autograd():
+    torch.library.register_autograd("fabhip::realnvp_logprob_tape", _tape_backward,
+                                    setup_context=_tape_setup_context)
+
+
+# ---- shape functions (torch.compile / fake tensors) for the tensor-in / tensor-out density ops ---------------------
+def _register_fakes():
+    rf = torch.library.register_fake
+
+    @rf("fabhip::realnvp_sample")
+    def _(packed, dim, n_layers, width, eps):
+        return torch.empty_like(eps), eps.new_empty((eps.shape[0],))
+
+    @rf("fabhip::realnvp_logprob_grad")
+    def _(packed, dim, n_layers, width, x, with_grad):
+        return x.new_empty((x.shape[0],)), (torch.empty_like(x) if with_grad else x.new_empty((0,)))
+
+    @rf("fabhip::target_logp_grad")
+    def _(target_kind, target_params, locs, scales, x, with_grad):
+        return x.new_empty((x.shape[0],)), (torch.empty_like(x) if with_grad else x.new_empty((0,)))
+
+    @rf("fabhip::ess_logz")
+    def _(log_w, n_ptr, n_norm):
+        return log_w.new_empty((3,))
+
+    @rf("fabhip::gather_rows")
+    def _(src, idx):
+        return src.new_empty((idx.shape[0],) + tuple(src.shape[1:]))
+
+    @rf("fabhip::resample_systematic")
+    def _(log_w, u0, n_samples):
+        return log_w.new_empty((n_samples,), dtype=torch.int64)
+
+    @rf("fabhip::resample_multinomial")
+    def _(log_w, u):
+        return log_w.new_empty((u.shape[0],), dtype=torch.int64)

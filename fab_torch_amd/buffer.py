@@ -8,9 +8,7 @@ from typing import Callable, Iterable, NamedTuple, Tuple
 
 import torch
 
-from . import _lib
-
-_ws = _lib.Workspace()
+from . import _ops
 
 
 class ReplayData(NamedTuple):
@@ -25,16 +23,8 @@ TOPK_SORT_MAX = 16384     # sorted mode of fabhip_topk sorts the selection in on
 def topk_indices(keys: torch.Tensor, k: int, sorted: bool = False) -> torch.Tensor:
     """Indices of the k largest keys — fabhip_topk (radix select + index-ordered compaction).  sorted=False: in
     ascending index order; sorted=True (k <= 16384): descending key order, ties by ascending index."""
-    lib = _lib.load()
-    _lib.require_device(keys, "keys")
-    kf = keys.detach().contiguous().float()
-    n = kf.shape[0]
-    idx = torch.empty(k, dtype=torch.int64, device=kf.device)
-    nb = lib.fabhip_topk_workspace_bytes(n, k)
-    ws = _ws.get(nb, kf.device)
-    _lib.check(lib.fabhip_topk(_lib.ptr(kf), n, k, 1 if sorted else 0, _lib.ptr(idx), None, _lib.ptr(ws), nb,
-                               _lib.stream_ptr()), "topk")
-    return idx
+    _ops.require_device(keys, "keys")
+    return _ops.load().topk(keys.detach().contiguous().float(), int(k), bool(sorted))
 
 
 def sample_without_replacement(logits: torch.Tensor, n: int, gumbel: torch.Tensor = None,

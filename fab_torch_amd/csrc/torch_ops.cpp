@@ -1,0 +1,523 @@
+// PyTorch-ROCm custom-op layer of fabhip: TORCH_LIBRARY(fabhip, ...) over the C ABI of libfabhip.so
+// (include/fabhip.h).  This is how the Python mirror of fab-torch's plug-in interfaces reaches the HIP kernels
+// (north_star: "called from Python through PyTorch-ROCm custom ops"; SURVEY.md section 8b, "Torch op layer").
+//
+//  * every op is registered for the CUDA (= HIP on ROCm) dispatch key ONLY: there is no CPU kernel, a CPU tensor
+//    fails in the dispatcher ("could not run fabhip::... with arguments from the 'CPU' backend");
+//  * ops only translate tensors into the raw-pointer argument structs of the C ABI, allocate outputs / scratch
+//    through torch's caching allocator (stream-ordered, so scratch is never shared between streams) and enqueue on
+//    the current HIP stream; no synchronisation, no host reads;
+//  * a non-zero fabhip return code becomes a c10::Error (Python RuntimeError) via TORCH_CHECK;
+//  * autograd for the training op (fabhip::realnvp_logprob_tape) is registered from Python with
+//    torch.library.register_autograd (fab_torch_amd/_ops.py); its backward is fabhip::realnvp_param_grad.
+//
+// Flow parameters travel as `Tensor[] params` in the order of fabhip_flow_params: per layer
+// {w1, b1, w2, b2, w3, b3, L, U, log_S, sign_S, P}, then {loc, log_scale}.  Targets travel as
+// (int kind, float[] {a, b, c, log_norm}, Tensor? locs, Tensor? scales).
+#include <ATen/ATen.h>
+#include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
+#include <c10/core/DeviceGuard.h>
+#include <torch/library.h>
+
+#include <vector>
+
+#include "../../include/fabhip.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+
+fabhip_stream_t stream_of(const Tensor& t) {
+    return (fabhip_stream_t)c10::hip::getCurrentHIPStreamMasqueradingAsCUDA(t.get_device()).stream();
+}
+
+void chk(int rc, const char* what) {
+    TORCH_CHECK(rc == FABHIP_OK, "fabhip ", what, " failed: ", fabhip_strerror(rc), " (code ", rc, ")");
+}
+
+void need(const Tensor& t, at::ScalarType st, const char* name) {
+    TORCH_CHECK(t.is_cuda(), "fabhip: ", name, " must live on the GPU (no CPU path)");
+    TORCH_CHECK(t.scalar_type() == st, "fabhip: ", name, " has dtype ", t.scalar_type(), ", expected ", st);
+    TORCH_CHECK(t.is_contiguous(), "fabhip: ", name, " must be contiguous");
+}
+const float* fp(const Tensor& t, const char* name) { need(t, at::kFloat, name); return t.data_ptr<float>(); }
+float* fpm(const Tensor& t, const char* name) { need(t, at::kFloat, name); return t.data_ptr<float>(); }
+float* fpm_opt(const optional<Tensor>& t, const char* name) { return t.has_value() ? fpm(*t, name) : nullptr; }
+const float* fp_opt(const optional<Tensor>& t, const char* name) { return t.has_value() ? fp(*t, name) : nullptr; }
+
+Tensor fempty(at::IntArrayRef shape, const Tensor& like) { return at::empty(shape, like.options().dtype(at::kFloat)); }
+Tensor scratch(size_t bytes, const Tensor& like) {
+    return at::empty({(int64_t)(bytes + 256)}, like.options().dtype(at::kByte));
+}
+void* aligned(const Tensor& ws) {
+    auto p = (uintptr_t)ws.data_ptr();
+    return (void*)((p + 255) & ~(uintptr_t)255);
+}
+
+fabhip_flow make_flow(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width) {
+    fabhip_flow f;
+    f.dim = (int32_t)dim; f.n_layers = (int32_t)n_layers; f.width = (int32_t)width;
+    f.packed = fp(packed, "packed flow image");
+    const int64_t n = fabhip_flow_packed_floats(f.dim, f.n_layers, f.width);
+    TORCH_CHECK(n > 0, "fabhip: flow shape not supported (dim ", dim, ", width ", width, ")");
+    TORCH_CHECK(packed.numel() == n, "fabhip: packed image has ", packed.numel(), " floats, expected ", n);
+    return f;
+}
+
+void fill_params(fabhip_flow_params& p, at::TensorList params, int64_t dim, int64_t n_layers, int64_t width) {
+    TORCH_CHECK(n_layers >= 1 && n_layers <= FABHIP_MAX_LAYERS, "fabhip: n_layers out of range");
+    TORCH_CHECK((int64_t)params.size() == 11 * n_layers + 2, "fabhip: expected ", 11 * n_layers + 2,
+                " parameter tensors (11 per layer + loc + log_scale), got ", params.size());
+    p.dim = (int32_t)dim; p.n_layers = (int32_t)n_layers; p.width = (int32_t)width;
+    for (int64_t k = 0; k < n_layers; ++k) {
+        const Tensor* t = &params[11 * k];
+        p.w1[k] = fp(t[0], "w1"); p.b1[k] = fp(t[1], "b1"); p.w2[k] = fp(t[2], "w2"); p.b2[k] = fp(t[3], "b2");
+        p.w3[k] = fp(t[4], "w3"); p.b3[k] = fp(t[5], "b3"); p.lu_L[k] = fp(t[6], "L"); p.lu_U[k] = fp(t[7], "U");
+        p.log_S[k] = fp(t[8], "log_S"); p.sign_S[k] = fp(t[9], "sign_S"); p.perm_P[k] = fp(t[10], "P");
+    }
+    p.loc = fp(params[11 * n_layers], "loc");
+    p.log_scale = fp(params[11 * n_layers + 1], "log_scale");
+}
+
+fabhip_target make_target(int64_t kind, at::ArrayRef<double> prm, const optional<Tensor>& locs,
+                          const optional<Tensor>& scales, int64_t dim) {
+    TORCH_CHECK(prm.size() == 4, "fabhip: target parameters are {a, b, c, log_norm}");
+    fabhip_target t;
+    t.kind = (int32_t)kind; t.dim = (int32_t)dim;
+    t.a = (float)prm[0]; t.b = (float)prm[1]; t.c = (float)prm[2]; t.log_norm = (float)prm[3];
+    t.n_mix = 0; t.locs = nullptr; t.scales = nullptr;
+    if (kind == FABHIP_TARGET_GMM) {
+        TORCH_CHECK(locs.has_value() && scales.has_value(), "fabhip: GMM target needs locs and scales");
+        t.locs = fp(*locs, "locs"); t.scales = fp(*scales, "scales");
+        t.n_mix = (int32_t)locs->size(0);
+        TORCH_CHECK(locs->dim() == 2 && locs->size(1) == dim && scales->sizes() == locs->sizes(), "fabhip: GMM shapes");
+    }
+    return t;
+}
+
+fabhip_anneal coefs(double beta, double alpha, bool p_target) {
+    fabhip_anneal a;
+    fabhip_anneal_coefs(beta, alpha, p_target ? 1 : 0, &a);
+    return a;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// geometry queries (no tensors: catch-all kernels)
+// ------------------------------------------------------------------------------------------------------------------
+int64_t abi_version() { return fabhip_version(); }
+int64_t flow_packed_floats(int64_t dim, int64_t n_layers, int64_t width) {
+    return fabhip_flow_packed_floats((int32_t)dim, (int32_t)n_layers, (int32_t)width);
+}
+int64_t flow_grad_floats(int64_t dim, int64_t n_layers, int64_t width) {
+    return fabhip_flow_grad_floats((int32_t)dim, (int32_t)n_layers, (int32_t)width);
+}
+std::vector<int64_t> flow_grad_layout(int64_t dim, int64_t n_layers, int64_t width) {
+    std::vector<int64_t> out(13);
+    chk(fabhip_flow_grad_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, out.data()), "flow_grad_layout");
+    return out;
+}
+std::vector<int64_t> flow_tape_layout(int64_t dim, int64_t n_layers, int64_t width, int64_t B) {
+    std::vector<int64_t> out(18);
+    chk(fabhip_flow_tape_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, B, out.data()), "flow_tape_layout");
+    return out;
+}
+std::vector<double> anneal_coefs(double beta, double alpha, bool p_target) {
+    const fabhip_anneal a = coefs(beta, alpha, p_target);
+    return {a.c_q, a.c_p, a.g_q, a.g_p};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RealNVP flow
+// ------------------------------------------------------------------------------------------------------------------
+void realnvp_pack(at::TensorList params, int64_t dim, int64_t n_layers, int64_t width, bool with_inverse,
+                  Tensor packed) {
+    c10::DeviceGuard g(packed.device());
+    fabhip_flow_params p;
+    fill_params(p, params, dim, n_layers, width);
+    make_flow(packed, dim, n_layers, width);
+    auto fn = with_inverse ? fabhip_flow_pack : fabhip_flow_pack_density;
+    chk(fn(&p, packed.data_ptr<float>(), stream_of(packed)), "flow_pack");
+}
+
+std::tuple<Tensor, Tensor> realnvp_sample(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width,
+                                          const Tensor& eps) {
+    c10::DeviceGuard g(eps.device());
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    TORCH_CHECK(eps.dim() == 2 && eps.size(1) == dim, "fabhip: eps must be [B, dim]");
+    const int64_t B = eps.size(0);
+    Tensor x = at::empty_like(eps), log_q = fempty({B}, eps);
+    chk(fabhip_flow_sample(&f, fp(eps, "eps"), x.data_ptr<float>(), log_q.data_ptr<float>(), B, stream_of(eps)),
+        "flow_sample");
+    return {x, log_q};
+}
+
+std::tuple<Tensor, Tensor> realnvp_logprob_grad(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width,
+                                                const Tensor& x, bool with_grad) {
+    c10::DeviceGuard g(x.device());
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0);
+    Tensor log_q = fempty({B}, x), grad = with_grad ? at::empty_like(x) : fempty({0}, x);
+    chk(fabhip_flow_log_prob(&f, fp(x, "x"), log_q.data_ptr<float>(), with_grad ? grad.data_ptr<float>() : nullptr, B,
+                             stream_of(x)),
+        "flow_log_prob");
+    return {log_q, grad};
+}
+
+// the differentiable training op: log q(x) with a tape; `theta` (the flat parameter image, or any tensor the
+// parameters are a differentiable function of) is not read - it is the autograd handle of the parameters
+std::tuple<Tensor, Tensor, Tensor> realnvp_logprob_tape(const Tensor& theta, const Tensor& x, const Tensor& packed,
+                                                        at::TensorList params, int64_t dim, int64_t n_layers,
+                                                        int64_t width, bool want_grad_x) {
+    (void)theta; (void)params;
+    c10::DeviceGuard g(x.device());
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0);
+    const size_t nbytes = fabhip_flow_tape_bytes(f.dim, f.n_layers, f.width, B);
+    Tensor log_q = fempty({B}, x), grad = want_grad_x ? at::empty_like(x) : fempty({0}, x);
+    Tensor tape = fempty({(int64_t)(nbytes / 4 + 1)}, x);
+    chk(fabhip_flow_log_prob_tape(&f, fp(x, "x"), log_q.data_ptr<float>(),
+                                  want_grad_x ? grad.data_ptr<float>() : nullptr, B, tape.data_ptr<float>(), nbytes,
+                                  stream_of(x)),
+        "flow_log_prob_tape");
+    return {log_q, grad, tape};
+}
+
+Tensor realnvp_param_grad(at::TensorList params, const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width,
+                          const Tensor& tape, const Tensor& coef) {
+    c10::DeviceGuard g(coef.device());
+    fabhip_flow_params p;
+    fill_params(p, params, dim, n_layers, width);
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    const int64_t B = coef.size(0);
+    const size_t nbytes = fabhip_flow_tape_bytes(f.dim, f.n_layers, f.width, B);
+    TORCH_CHECK((size_t)tape.numel() * 4 >= nbytes, "fabhip: tape too small for ", B, " rows");
+    Tensor flat = fempty({fabhip_flow_grad_floats(f.dim, f.n_layers, f.width)}, coef);
+    chk(fabhip_flow_param_grad(&p, &f, fp(tape, "tape"), nbytes, fp(coef, "coef"), B, flat.data_ptr<float>(),
+                               stream_of(coef)),
+        "flow_param_grad");
+    return flat;
+}
+
+void adam_clip_step(Tensor theta, const Tensor& grad, Tensor m, Tensor v, double lr, double beta1, double beta2,
+                    double eps, Tensor step_count, double max_norm, Tensor grad_norm) {
+    c10::DeviceGuard g(theta.device());
+    const int64_t n = theta.numel();
+    TORCH_CHECK(grad.numel() == n && m.numel() == n && v.numel() == n, "fabhip: adam image sizes differ");
+    need(step_count, at::kInt, "step_count");
+    const size_t nb = fabhip_adam_workspace_bytes(n);
+    Tensor ws = scratch(nb, theta);
+    chk(fabhip_adam_clip_step(fpm(theta, "theta"), fp(grad, "grad"), fpm(m, "m"), fpm(v, "v"), n, (float)lr,
+                              (float)beta1, (float)beta2, (float)eps, step_count.data_ptr<int32_t>(), (float)max_norm,
+                              fpm(grad_norm, "grad_norm"), aligned(ws), nb, stream_of(theta)),
+        "adam_clip_step");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// targets, points
+// ------------------------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor> target_logp_grad(int64_t kind, at::ArrayRef<double> prm, const optional<Tensor>& locs,
+                                            const optional<Tensor>& scales, const Tensor& x, bool with_grad) {
+    c10::DeviceGuard g(x.device());
+    TORCH_CHECK(x.dim() == 2, "fabhip: x must be [B, dim]");
+    const fabhip_target t = make_target(kind, prm, locs, scales, x.size(1));
+    const int64_t B = x.size(0);
+    Tensor lp = fempty({B}, x), grad = with_grad ? at::empty_like(x) : fempty({0}, x);
+    chk(fabhip_target_log_prob(&t, fp(x, "x"), lp.data_ptr<float>(), with_grad ? grad.data_ptr<float>() : nullptr, B,
+                               stream_of(x)),
+        "target_log_prob");
+    return {lp, grad};
+}
+
+std::tuple<Tensor, Tensor> manywell_logp_grad(const Tensor& x, double a, double b, double c, double log_norm) {
+    const double prm[4] = {a, b, c, log_norm};
+    return target_logp_grad(FABHIP_TARGET_MANYWELL, prm, c10::nullopt, c10::nullopt, x, true);
+}
+
+std::tuple<Tensor, Tensor> gmm_logp_grad(const Tensor& x, const Tensor& locs, const Tensor& scales) {
+    const double prm[4] = {0, 0, 0, 0};
+    return target_logp_grad(FABHIP_TARGET_GMM, prm, locs, scales, x, true);
+}
+
+std::tuple<Tensor, Tensor, Tensor, Tensor> create_point(const Tensor& packed, int64_t dim, int64_t n_layers,
+                                                        int64_t width, int64_t kind, at::ArrayRef<double> prm,
+                                                        const optional<Tensor>& locs, const optional<Tensor>& scales,
+                                                        const Tensor& x, bool with_grad) {
+    c10::DeviceGuard g(x.device());
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    const fabhip_target t = make_target(kind, prm, locs, scales, dim);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0);
+    Tensor lq = fempty({B}, x), lp = fempty({B}, x);
+    Tensor gq = with_grad ? at::empty_like(x) : fempty({0}, x), gp = with_grad ? at::empty_like(x) : fempty({0}, x);
+    fabhip_point p{const_cast<float*>(fp(x, "x")), lq.data_ptr<float>(), lp.data_ptr<float>(),
+                   with_grad ? gq.data_ptr<float>() : nullptr, with_grad ? gp.data_ptr<float>() : nullptr};
+    chk(fabhip_create_point(&f, &t, &p, with_grad ? 1 : 0, B, stream_of(x)), "create_point");
+    return {lq, lp, gq, gp};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// transitions (in place on the Point tensors, the step-size state and log_w)
+// ------------------------------------------------------------------------------------------------------------------
+void hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind,
+                    at::ArrayRef<double> prm, const optional<Tensor>& locs, const optional<Tensor>& scales, Tensor x,
+                    Tensor log_q, Tensor log_p, Tensor grad_log_q, Tensor grad_log_p, optional<Tensor> log_w,
+                    double beta, double beta_next, double alpha, bool p_target, const Tensor& noise_p,
+                    const Tensor& noise_e, Tensor epsilons_row, Tensor common_epsilon, const Tensor& mass, int64_t L,
+                    double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept,
+                    optional<Tensor> avg_distance) {
+    c10::DeviceGuard g(x.device());
+    fabhip_hmc_args a;
+    a.flow = make_flow(packed, dim, n_layers, width);
+    a.target = make_target(kind, prm, locs, scales, dim);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0), n_outer = epsilons_row.numel();
+    TORCH_CHECK(noise_p.numel() == n_outer * B * dim && noise_e.numel() == n_outer * B, "fabhip: HMC noise shapes");
+    a.point = fabhip_point{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), fpm(grad_log_q, "grad_log_q"),
+                           fpm(grad_log_p, "grad_log_p")};
+    a.B = B; a.n_valid = nullptr;
+    a.cur = coefs(beta, alpha, p_target); a.next = coefs(beta_next, alpha, p_target);
+    a.log_w = fpm_opt(log_w, "log_w");
+    a.noise_p = fp(noise_p, "noise_p"); a.noise_e = fp(noise_e, "noise_e");
+    a.epsilons = fpm(epsilons_row, "epsilons"); a.common_epsilon = fpm(common_epsilon, "common_epsilon");
+    a.mass = fp(mass, "mass");
+    a.n_outer = (int32_t)n_outer; a.L = (int32_t)L; a.max_grad = (float)max_grad;
+    a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
+    a.p_accept = fpm_opt(p_accept, "p_accept"); a.avg_distance = fpm_opt(avg_distance, "avg_distance");
+    const size_t nb = fabhip_hmc_workspace_bytes(B, (int32_t)dim, (int32_t)n_outer);
+    Tensor ws = scratch(nb, x);
+    a.workspace = aligned(ws); a.workspace_bytes = nb;
+    chk(fabhip_hmc_transition(&a, stream_of(x)), "hmc_transition");
+}
+
+void metropolis_transition(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind,
+                           at::ArrayRef<double> prm, const optional<Tensor>& locs, const optional<Tensor>& scales,
+                           Tensor x, Tensor log_q, Tensor log_p, optional<Tensor> log_w, double beta, double beta_next,
+                           double alpha, bool p_target, const Tensor& noise_x, const Tensor& noise_u,
+                           Tensor noise_scalings_row, double target_p_accept, bool tune) {
+    c10::DeviceGuard g(x.device());
+    fabhip_metropolis_args a;
+    a.flow = make_flow(packed, dim, n_layers, width);
+    a.target = make_target(kind, prm, locs, scales, dim);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0), n_updates = noise_scalings_row.numel();
+    TORCH_CHECK(noise_x.numel() == n_updates * B * dim && noise_u.numel() == n_updates * B,
+                "fabhip: Metropolis noise shapes");
+    a.point = fabhip_point{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), nullptr, nullptr};
+    a.B = B; a.n_valid = nullptr;
+    a.cur = coefs(beta, alpha, p_target); a.next = coefs(beta_next, alpha, p_target);
+    a.log_w = fpm_opt(log_w, "log_w");
+    a.noise_x = fp(noise_x, "noise_x"); a.noise_u = fp(noise_u, "noise_u");
+    a.noise_scalings = fpm(noise_scalings_row, "noise_scalings");
+    a.n_updates = (int32_t)n_updates; a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
+    const size_t nb = fabhip_metropolis_workspace_bytes(B, (int32_t)dim, (int32_t)n_updates);
+    Tensor ws = scratch(nb, x);
+    a.workspace = aligned(ws); a.workspace_bytes = nb;
+    chk(fabhip_metropolis_transition(&a, stream_of(x)), "metropolis_transition");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// the whole AIS call (ais.py:53-105): returns
+//   (x, log_q, log_p, grad_log_q, grad_log_p, log_w, n_valid int32[2], stats float[16], base_x, base_log_w)
+// grad_* are empty for Metropolis, base_* are empty unless want_base.
+// ------------------------------------------------------------------------------------------------------------------
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> ais_run(
+    const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind, at::ArrayRef<double> prm,
+    const optional<Tensor>& locs, const optional<Tensor>& scales, at::ArrayRef<double> betas, double alpha,
+    bool p_target, int64_t transition, const Tensor& eps0, const Tensor& noise_a, const Tensor& noise_b,
+    Tensor step_state, optional<Tensor> common_epsilon, const optional<Tensor>& mass, int64_t n_inner, int64_t L,
+    double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept_first, optional<Tensor> p_accept_last,
+    optional<Tensor> avg_distance_first, optional<Tensor> avg_distance_last, bool want_base) {
+    c10::DeviceGuard g(eps0.device());
+    fabhip_ais_args a;
+    a.flow = make_flow(packed, dim, n_layers, width);
+    a.target = make_target(kind, prm, locs, scales, dim);
+    TORCH_CHECK(eps0.dim() == 2 && eps0.size(1) == dim, "fabhip: eps0 must be [B, dim]");
+    const int64_t B = eps0.size(0), M = (int64_t)betas.size() - 2;
+    TORCH_CHECK(M >= 1, "fabhip: betas must hold M + 2 values");
+    TORCH_CHECK(noise_a.numel() == M * n_inner * B * dim && noise_b.numel() == M * n_inner * B, "fabhip: AIS noise shapes");
+    TORCH_CHECK(step_state.numel() == M * n_inner, "fabhip: step-size state must be [M, n_inner]");
+    const bool hmc = transition == FABHIP_TRANSITION_HMC;
+    a.B = B; a.M = (int32_t)M;
+    std::vector<double> bt(betas.begin(), betas.end());
+    a.betas = bt.data();
+    a.alpha = alpha; a.p_target = p_target ? 1 : 0; a.transition = (int32_t)transition;
+    a.eps0 = fp(eps0, "eps0"); a.noise_a = fp(noise_a, "noise_a"); a.noise_b = fp(noise_b, "noise_b");
+    a.step_state = fpm(step_state, "step_state");
+    a.common_epsilon = fpm_opt(common_epsilon, "common_epsilon");
+    a.mass = fp_opt(mass, "mass");
+    a.n_inner = (int32_t)n_inner; a.L = (int32_t)L; a.max_grad = (float)max_grad;
+    a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
+    Tensor x = fempty({B, dim}, eps0), lq = fempty({B}, eps0), lp = fempty({B}, eps0), log_w = fempty({B}, eps0);
+    Tensor gq = hmc ? fempty({B, dim}, eps0) : fempty({0}, eps0), gp = hmc ? fempty({B, dim}, eps0) : fempty({0}, eps0);
+    Tensor n_valid = at::zeros({2}, eps0.options().dtype(at::kInt)), stats = at::zeros({16}, eps0.options());
+    Tensor base_x = want_base ? fempty({B, dim}, eps0) : fempty({0}, eps0);
+    Tensor base_lw = want_base ? fempty({B}, eps0) : fempty({0}, eps0);
+    a.point = fabhip_point{x.data_ptr<float>(), lq.data_ptr<float>(), lp.data_ptr<float>(),
+                           hmc ? gq.data_ptr<float>() : nullptr, hmc ? gp.data_ptr<float>() : nullptr};
+    a.log_w = log_w.data_ptr<float>(); a.n_valid = n_valid.data_ptr<int32_t>(); a.stats = stats.data_ptr<float>();
+    a.p_accept_first = fpm_opt(p_accept_first, "p_accept_first");
+    a.p_accept_last = fpm_opt(p_accept_last, "p_accept_last");
+    a.avg_distance_first = fpm_opt(avg_distance_first, "avg_distance_first");
+    a.avg_distance_last = fpm_opt(avg_distance_last, "avg_distance_last");
+    a.base_x = want_base ? base_x.data_ptr<float>() : nullptr;
+    a.base_log_w = want_base ? base_lw.data_ptr<float>() : nullptr;
+    const size_t nb = fabhip_ais_workspace_bytes(B, (int32_t)dim, (int32_t)n_inner);
+    Tensor ws = scratch(nb, eps0);
+    a.workspace = aligned(ws); a.workspace_bytes = nb;
+    chk(fabhip_ais_run(&a, stream_of(eps0)), "ais_run");
+    return {x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw};
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// ESS / log Z, resampling, top-k
+// ------------------------------------------------------------------------------------------------------------------
+Tensor ess_logz(const Tensor& log_w, const optional<Tensor>& n_ptr, double n_norm) {
+    c10::DeviceGuard g(log_w.device());
+    const int64_t n = log_w.numel();
+    Tensor out = fempty({3}, log_w);
+    const size_t nb = fabhip_ess_workspace_bytes(n);
+    Tensor ws = scratch(nb, log_w);
+    const int32_t* np = nullptr;
+    if (n_ptr.has_value()) { need(*n_ptr, at::kInt, "n_ptr"); np = n_ptr->data_ptr<int32_t>(); }
+    chk(fabhip_ess_logz(fp(log_w, "log_w"), n, np, n_norm, out.data_ptr<float>(), aligned(ws), nb, stream_of(log_w)),
+        "ess_logz");
+    return out;
+}
+
+Tensor resample_multinomial(const Tensor& log_w, const Tensor& u) {
+    c10::DeviceGuard g(log_w.device());
+    need(u, at::kDouble, "u");
+    const int64_t n = log_w.numel(), ns = u.numel();
+    Tensor idx = at::empty({ns}, log_w.options().dtype(at::kLong));
+    const size_t nb = fabhip_resample_workspace_bytes(n);
+    Tensor ws = scratch(nb, log_w);
+    chk(fabhip_resample_multinomial(fp(log_w, "log_w"), n, u.data_ptr<double>(), ns, idx.data_ptr<int64_t>(),
+                                    aligned(ws), nb, stream_of(log_w)),
+        "resample_multinomial");
+    return idx;
+}
+
+Tensor resample_systematic(const Tensor& log_w, double u0, int64_t n_samples) {
+    c10::DeviceGuard g(log_w.device());
+    const int64_t n = log_w.numel();
+    Tensor idx = at::empty({n_samples}, log_w.options().dtype(at::kLong));
+    const size_t nb = fabhip_resample_workspace_bytes(n);
+    Tensor ws = scratch(nb, log_w);
+    chk(fabhip_resample_systematic(fp(log_w, "log_w"), n, u0, n_samples, idx.data_ptr<int64_t>(), aligned(ws), nb,
+                                   stream_of(log_w)),
+        "resample_systematic");
+    return idx;
+}
+
+Tensor multinomial_torch(const Tensor& probs, const Tensor& u) {
+    c10::DeviceGuard g(probs.device());
+    need(u, at::kDouble, "u");
+    const int64_t n = probs.numel(), ns = u.numel();
+    Tensor idx = at::empty({ns}, probs.options().dtype(at::kLong));
+    const size_t nb = fabhip_multinomial_torch_workspace_bytes(n);
+    Tensor ws = scratch(nb, probs);
+    chk(fabhip_multinomial_torch(fp(probs, "probs"), n, u.data_ptr<double>(), ns, idx.data_ptr<int64_t>(), aligned(ws),
+                                 nb, stream_of(probs)),
+        "multinomial_torch");
+    return idx;
+}
+
+Tensor gather_rows(const Tensor& src, const Tensor& idx) {
+    c10::DeviceGuard g(src.device());
+    need(idx, at::kLong, "idx");
+    TORCH_CHECK(src.dim() >= 1, "fabhip: gather_rows needs at least one dimension");
+    const int64_t rows = src.size(0), row_len = rows ? src.numel() / rows : 0, n_out = idx.numel();
+    std::vector<int64_t> shape(src.sizes().begin(), src.sizes().end());
+    shape[0] = n_out;
+    Tensor out = at::empty(shape, src.options());
+    if (n_out == 0 || row_len == 0) return out;
+    chk(fabhip_gather_rows(fp(src, "src"), idx.data_ptr<int64_t>(), out.data_ptr<float>(), n_out, row_len,
+                           stream_of(src)),
+        "gather_rows");
+    return out;
+}
+
+Tensor topk(const Tensor& keys, int64_t k, bool sorted) {
+    c10::DeviceGuard g(keys.device());
+    const int64_t n = keys.numel();
+    Tensor idx = at::empty({k}, keys.options().dtype(at::kLong));
+    const size_t nb = fabhip_topk_workspace_bytes(n, k);
+    Tensor ws = scratch(nb, keys);
+    chk(fabhip_topk(fp(keys, "keys"), n, k, sorted ? 1 : 0, idx.data_ptr<int64_t>(), nullptr, aligned(ws), nb,
+                    stream_of(keys)),
+        "topk");
+    return idx;
+}
+
+}  // namespace
+
+#define TGT "int target_kind, float[] target_params, Tensor? locs, Tensor? scales"
+#define FLW "Tensor packed, int dim, int n_layers, int width"
+
+TORCH_LIBRARY(fabhip, m) {
+    m.def("abi_version() -> int", abi_version);
+    m.def("flow_packed_floats(int dim, int n_layers, int width) -> int", flow_packed_floats);
+    m.def("flow_grad_floats(int dim, int n_layers, int width) -> int", flow_grad_floats);
+    m.def("flow_grad_layout(int dim, int n_layers, int width) -> int[]", flow_grad_layout);
+    m.def("flow_tape_layout(int dim, int n_layers, int width, int B) -> int[]", flow_tape_layout);
+    m.def("anneal_coefs(float beta, float alpha, bool p_target) -> float[]", anneal_coefs);
+
+    m.def("realnvp_pack(Tensor[] params, int dim, int n_layers, int width, bool with_inverse, Tensor(a!) packed) -> ()");
+    m.def("realnvp_sample(" FLW ", Tensor eps) -> (Tensor, Tensor)");
+    m.def("realnvp_logprob_grad(" FLW ", Tensor x, bool with_grad) -> (Tensor, Tensor)");
+    m.def("realnvp_logprob_tape(Tensor theta, Tensor x, Tensor packed, Tensor[] params, int dim, int n_layers, "
+          "int width, bool want_grad_x) -> (Tensor, Tensor, Tensor)");
+    m.def("realnvp_param_grad(Tensor[] params, " FLW ", Tensor tape, Tensor coef) -> Tensor");
+    m.def("adam_clip_step(Tensor(a!) theta, Tensor grad, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, "
+          "float eps, Tensor(d!) step_count, float max_norm, Tensor(e!) grad_norm) -> ()");
+
+    m.def("target_logp_grad(" TGT ", Tensor x, bool with_grad) -> (Tensor, Tensor)");
+    m.def("manywell_logp_grad(Tensor x, float a, float b, float c, float log_norm) -> (Tensor, Tensor)");
+    m.def("gmm_logp_grad(Tensor x, Tensor locs, Tensor scales) -> (Tensor, Tensor)");
+    m.def("create_point(" FLW ", " TGT ", Tensor x, bool with_grad) -> (Tensor, Tensor, Tensor, Tensor)");
+
+    m.def("hmc_transition(" FLW ", " TGT ", Tensor(a!) x, Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!) grad_log_q, "
+          "Tensor(e!) grad_log_p, Tensor(f!)? log_w, float beta, float beta_next, float alpha, bool p_target, "
+          "Tensor noise_p, Tensor noise_e, Tensor(g!) epsilons_row, Tensor(h!) common_epsilon, Tensor mass, int L, "
+          "float max_grad, float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance) -> ()");
+    m.def("metropolis_transition(" FLW ", " TGT ", Tensor(a!) x, Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!)? log_w, "
+          "float beta, float beta_next, float alpha, bool p_target, Tensor noise_x, Tensor noise_u, "
+          "Tensor(e!) noise_scalings_row, float target_p_accept, bool tune) -> ()");
+    m.def("ais_run(" FLW ", " TGT ", float[] betas, float alpha, bool p_target, int transition, Tensor eps0, "
+          "Tensor noise_a, Tensor noise_b, Tensor(a!) step_state, Tensor(b!)? common_epsilon, Tensor? mass, int n_inner, "
+          "int L, float max_grad, float target_p_accept, bool tune, Tensor(c!)? p_accept_first, Tensor(d!)? p_accept_last, "
+          "Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base) -> "
+          "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
+
+    m.def("ess_logz(Tensor log_w, Tensor? n_ptr, float n_norm) -> Tensor");
+    m.def("resample_multinomial(Tensor log_w, Tensor u) -> Tensor");
+    m.def("resample_systematic(Tensor log_w, float u0, int n_samples) -> Tensor");
+    m.def("multinomial_torch(Tensor probs, Tensor u) -> Tensor");
+    m.def("gather_rows(Tensor src, Tensor idx) -> Tensor");
+    m.def("topk(Tensor keys, int k, bool sorted) -> Tensor");
+}
+
+TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; deliberately no CPU registration
+    m.impl("realnvp_pack", realnvp_pack);
+    m.impl("realnvp_sample", realnvp_sample);
+    m.impl("realnvp_logprob_grad", realnvp_logprob_grad);
+    m.impl("realnvp_logprob_tape", realnvp_logprob_tape);
+    m.impl("realnvp_param_grad", realnvp_param_grad);
+    m.impl("adam_clip_step", adam_clip_step);
+    m.impl("target_logp_grad", target_logp_grad);
+    m.impl("manywell_logp_grad", manywell_logp_grad);
+    m.impl("gmm_logp_grad", gmm_logp_grad);
+    m.impl("create_point", create_point);
+    m.impl("hmc_transition", hmc_transition);
+    m.impl("metropolis_transition", metropolis_transition);
+    m.impl("ais_run", ais_run);
+    m.impl("ess_logz", ess_logz);
+    m.impl("resample_multinomial", resample_multinomial);
+    m.impl("resample_systematic", resample_systematic);
+    m.impl("multinomial_torch", multinomial_torch);
+    m.impl("gather_rows", gather_rows);
+    m.impl("topk", topk);
+}

@@ -2,24 +2,15 @@
 import torch
 import torch.nn.functional as F
 
-from . import _lib
-
-_ws = _lib.Workspace()
+from . import _ops
 
 
 def ess_and_log_z(log_w: torch.Tensor, n_norm: float = None) -> torch.Tensor:
     """Device float32[3]: (normalised ESS, logsumexp(log_w) - log(n_norm), n)."""
-    lib = _lib.load()
     assert log_w.dim() == 1
-    _lib.require_device(log_w, "log_w")
+    _ops.require_device(log_w, "log_w")
     lw = log_w.detach().contiguous().float()
-    n = lw.shape[0]
-    out = torch.empty(3, dtype=torch.float32, device=lw.device)
-    nb = lib.fabhip_ess_workspace_bytes(n)
-    ws = _ws.get(nb, lw.device)
-    _lib.check(lib.fabhip_ess_logz(_lib.ptr(lw), n, None, float(n if n_norm is None else n_norm), _lib.ptr(out),
-                                   _lib.ptr(ws), nb, _lib.stream_ptr()), "ess_logz")
-    return out
+    return _ops.load().ess_logz(lw, None, float(lw.shape[0] if n_norm is None else n_norm))
 
 
 def effective_sample_size(log_w: torch.Tensor, normalised=False) -> torch.Tensor:

@@ -6,12 +6,11 @@ float32 buffer laid out like the flat gradient image of `fabhip_flow_param_grad`
 are that image (the usual case: one `flow.log_prob(x)` backward) the step reads it directly, otherwise the
 `.grad` tensors are concatenated first.  No host synchronisation: the gradient norm stays on the device and a
 non-finite norm skips the update inside the kernel."""
-import ctypes as C
 from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _ops
 from .flow import RealNVP
 
 
@@ -20,10 +19,9 @@ class FlatAdam(torch.optim.Optimizer):
         self.flow = flow
         self._params = flow._grad_tensors()
         for p in self._params:
-            _lib.require_device(p, "RealNVP parameters (move the flow to the GPU before building FlatAdam)")
+            _ops.require_device(p, "RealNVP parameters (move the flow to the GPU before building FlatAdam)")
         super().__init__(self._params, dict(lr=lr, betas=betas, eps=eps))
-        lib = _lib.load()
-        self.n = int(lib.fabhip_flow_grad_floats(flow.dim, flow.n_layers, flow.width))
+        self.n = int(_ops.load().flow_grad_floats(flow.dim, flow.n_layers, flow.width))
         dev = self._params[0].device
         self.theta = torch.empty(self.n, dtype=torch.float32, device=dev)
         views = flow._grad_views(self.theta)
@@ -36,7 +34,6 @@ class FlatAdam(torch.optim.Optimizer):
         self.v = torch.zeros_like(self.theta)
         self.steps = torch.zeros(1, dtype=torch.int32, device=dev)     # applied steps (device: skips happen there)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
-        self._ws = torch.empty(int(lib.fabhip_adam_workspace_bytes(self.n)), dtype=torch.uint8, device=dev)
         flow._packed_key = None
         # one autograd leaf for the whole flow: flow.log_prob(x).backward() then delivers ONE flat gradient
         # (theta.grad) instead of 112 per-parameter views (the per-parameter .grad stay None in this mode)
@@ -51,7 +48,7 @@ class FlatAdam(torch.optim.Optimizer):
         base = self.theta.data_ptr()
         for p, off in ((self._params[0], self._offsets[0]), (self._params[-1], self._offsets[-1])):
             if p.data_ptr() != base + off:
-                raise _lib.FabhipError("the flow's parameters were re-allocated after FlatAdam was built "
+                raise _ops.FabhipError("the flow's parameters were re-allocated after FlatAdam was built "
                                        "(e.g. by .to()/.cuda()); build the optimiser after moving the flow")
 
     def _flat_grad(self) -> torch.Tensor:
@@ -63,7 +60,7 @@ class FlatAdam(torch.optim.Optimizer):
                 g = g + self._cat_grads()
             return g.contiguous()
         if not extra:
-            raise _lib.FabhipError("FlatAdam.step(): parameters have no gradient")
+            raise _ops.FabhipError("FlatAdam.step(): parameters have no gradient")
         g0 = self._params[0].grad
         if g0 is None:
             return self._cat_grads()
@@ -97,15 +94,13 @@ class FlatAdam(torch.optim.Optimizer):
         g = flat_grad if flat_grad is not None else self._flat_grad()
         if g.numel() != self.n or g.dtype != torch.float32 or not g.is_cuda or not g.is_contiguous() \
                 or g.device != self.theta.device:
-            raise _lib.FabhipError(f"FlatAdam.step(): gradient image must be a contiguous float32 tensor of "
+            raise _ops.FabhipError(f"FlatAdam.step(): gradient image must be a contiguous float32 tensor of "
                                    f"{self.n} elements on {self.theta.device} (got {tuple(g.shape)} {g.dtype} {g.device})")
         grp = self.param_groups[0]
         mx = 0.0 if (max_grad_norm is None or max_grad_norm == float("inf")) else float(max_grad_norm)
-        lib = _lib.load()
-        _lib.check(lib.fabhip_adam_clip_step(_lib.ptr(self.theta), _lib.ptr(g), _lib.ptr(self.m), _lib.ptr(self.v),
-                                             self.n, float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
-                                             float(grp["eps"]), _lib.ptr(self.steps), mx, _lib.ptr(self.grad_norm),
-                                             _lib.ptr(self._ws), self._ws.numel(), _lib.stream_ptr()), "adam_clip_step")
+        _ops.load().adam_clip_step(self.theta.detach(), g.detach(), self.m, self.v, float(grp["lr"]),
+                                   float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), self.steps, mx,
+                                   self.grad_norm)
         self.flow._packed_key = None                          # parameters changed behind autograd's version counters
         return self.grad_norm[0]
 

@@ -7,78 +7,40 @@
 * `multinomial_torch_compat(probs, u)`: bit-exact restatement of torch's CPU multinomial given the
   probabilities and the float64 uniforms it consumed (parity with the reference's RNG path).
 """
-import ctypes as C
 from typing import Union
 
 import torch
 
-from . import _lib
+from . import _ops
 from .point import Point
-
-_ws = _lib.Workspace()
-
-
-def _aligned_ws(nbytes, device):
-    buf = _ws.get(nbytes + 256, device)
-    off = (-buf.data_ptr()) % 256
-    return buf.data_ptr() + off
 
 
 def multinomial_indices(log_w: torch.Tensor, n_samples: int = None, u: torch.Tensor = None) -> torch.Tensor:
-    lib = _lib.load()
-    _lib.require_device(log_w, "log_w")
+    _ops.require_device(log_w, "log_w")
     lw = log_w.detach().contiguous().float()
-    n = lw.shape[0]
-    ns = n if n_samples is None else int(n_samples)
+    ns = lw.shape[0] if n_samples is None else int(n_samples)
     if u is None:
         u = torch.rand(ns, dtype=torch.float64, device=lw.device)
-    u = u.contiguous().double()
-    idx = torch.empty(ns, dtype=torch.int64, device=lw.device)
-    nb = lib.fabhip_resample_workspace_bytes(n)
-    _lib.check(lib.fabhip_resample_multinomial(_lib.ptr(lw), n, _lib.ptr(u), ns, _lib.ptr(idx),
-                                               C.c_void_p(_aligned_ws(nb, lw.device)), nb, _lib.stream_ptr()),
-               "resample_multinomial")
-    return idx
+    return _ops.load().resample_multinomial(lw, u.contiguous().double())
 
 
 def systematic_indices(log_w: torch.Tensor, u0: float = None, n_samples: int = None) -> torch.Tensor:
-    lib = _lib.load()
-    _lib.require_device(log_w, "log_w")
+    _ops.require_device(log_w, "log_w")
     lw = log_w.detach().contiguous().float()
-    n = lw.shape[0]
-    ns = n if n_samples is None else int(n_samples)
+    ns = lw.shape[0] if n_samples is None else int(n_samples)
     if u0 is None:
         u0 = float(torch.rand((), dtype=torch.float64))
-    idx = torch.empty(ns, dtype=torch.int64, device=lw.device)
-    nb = lib.fabhip_resample_workspace_bytes(n)
-    _lib.check(lib.fabhip_resample_systematic(_lib.ptr(lw), n, float(u0), ns, _lib.ptr(idx),
-                                              C.c_void_p(_aligned_ws(nb, lw.device)), nb, _lib.stream_ptr()),
-               "resample_systematic")
-    return idx
+    return _ops.load().resample_systematic(lw, float(u0), ns)
 
 
 def multinomial_torch_compat(probs: torch.Tensor, u: torch.Tensor) -> torch.Tensor:
-    lib = _lib.load()
-    _lib.require_device(probs, "probs")
-    p = probs.detach().contiguous().float()
-    u = u.contiguous().double()
-    n, ns = p.shape[0], u.shape[0]
-    idx = torch.empty(ns, dtype=torch.int64, device=p.device)
-    nb = lib.fabhip_multinomial_torch_workspace_bytes(n)
-    ws = _ws.get(nb, p.device)
-    _lib.check(lib.fabhip_multinomial_torch(_lib.ptr(p), n, _lib.ptr(u), ns, _lib.ptr(idx), _lib.ptr(ws), nb,
-                                            _lib.stream_ptr()), "multinomial_torch")
-    return idx
+    _ops.require_device(probs, "probs")
+    return _ops.load().multinomial_torch(probs.detach().contiguous().float(), u.contiguous().double())
 
 
 def gather_rows(src: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
-    lib = _lib.load()
-    s = src.contiguous().float()
-    s2 = s.reshape(s.shape[0], -1)
-    out = torch.empty((idx.shape[0], s2.shape[1]), dtype=torch.float32, device=s.device)
-    _lib.check(lib.fabhip_gather_rows(_lib.ptr(s2), _lib.ptr(idx.contiguous()), _lib.ptr(out), idx.shape[0],
-                                      s2.shape[1], _lib.stream_ptr()), "gather_rows")
-    return out.reshape((idx.shape[0],) + tuple(s.shape[1:]))
+    _ops.require_device(src, "src")
+    return _ops.load().gather_rows(src.contiguous().float(), idx.contiguous())
 
 
 def resample(x_or_point: Union[Point, torch.Tensor], log_w: torch.Tensor, method: str = "multinomial"):

@@ -1,7 +1,6 @@
 """Target distributions of the hot path: ManyWell (fab/target_distributions/many_well.py:16-90,
 double_well.py:31-58) and the 40-mode GMM (fab/target_distributions/gmm.py:12-66) — same constructor
 arguments and `log_prob` semantics; `log_prob` runs csrc/target_device.h on the GPU."""
-import ctypes as C
 import math
 
 import numpy as np
@@ -9,26 +8,20 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from . import _lib
+from . import _ops
 from .numerical import (quadratic_function, importance_weighted_expectation,
                         effective_sample_size_over_p)
 
 
 class _NativeTarget(nn.Module):
-    def native_target(self) -> _lib.Target:
+    def native_target(self):
+        """The target arguments of the ops: (kind, [a, b, c, log_norm], locs or None, scales or None)."""
         raise NotImplementedError
 
     def _native_log_prob(self, x, with_grad=False):
-        lib = _lib.load()
-        _lib.require_device(x, "x")
-        x = x.detach().contiguous().float()
-        B = x.shape[0]
-        lp = torch.empty(B, dtype=torch.float32, device=x.device)
-        g = torch.empty_like(x) if with_grad else None
-        t = self.native_target()
-        _lib.check(lib.fabhip_target_log_prob(C.byref(t), _lib.ptr(x), _lib.ptr(lp), _lib.ptr(g), B,
-                                              _lib.stream_ptr()), "target_log_prob")
-        return lp, g
+        _ops.require_device(x, "x")
+        lp, g = _ops.load().target_logp_grad(*self.native_target(), x.detach().contiguous().float(), bool(with_grad))
+        return lp, (g if with_grad else None)
 
     def log_prob_and_grad(self, x):
         return self._native_log_prob(x, with_grad=True)
@@ -52,7 +45,7 @@ class _TargetLogProb(torch.autograd.Function):
 
 
 def _target_log_prob(target, x):
-    _lib.require_device(x, "x")
+    _ops.require_device(x, "x")
     if torch.is_grad_enabled() and x.requires_grad:
         return _TargetLogProb.apply(target, x)
     return target._native_log_prob(x)[0]
@@ -88,12 +81,8 @@ class ManyWellEnergy(_NativeTarget):
         return torch.exp(self.log_Z)
 
     def native_target(self):
-        t = _lib.Target()
-        t.kind, t.dim = _lib.TARGET_MANYWELL, self.dim
-        t.a, t.b, t.c = self._a, self._b, self._c
-        t.log_norm = float(self.log_Z_2D * self.n_wells) if self.normalised else 0.0
-        t.n_mix, t.locs, t.scales = 0, None, None
-        return t
+        log_norm = float(self.log_Z_2D * self.n_wells) if self.normalised else 0.0
+        return _ops.TARGET_MANYWELL, [float(self._a), float(self._b), float(self._c), log_norm], None, None
 
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
         return _target_log_prob(self, x)
@@ -194,13 +183,7 @@ class GMM(_NativeTarget):
             self.cuda()
 
     def native_target(self):
-        t = _lib.Target()
-        t.kind, t.dim = _lib.TARGET_GMM, self.dim
-        t.a = t.b = t.c = 0.0
-        t.log_norm = 0.0
-        t.n_mix = self.n_mixes
-        t.locs, t.scales = self.locs.data_ptr(), self.scales.data_ptr()
-        return t
+        return _ops.TARGET_GMM, [0.0, 0.0, 0.0, 0.0], self.locs, self.scales
 
     @property
     def distribution(self):

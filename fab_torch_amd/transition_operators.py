@@ -4,32 +4,29 @@ same constructor arguments, `transition(point, i, beta) -> Point` (mutating the 
 reference), `uses_grad_info`, `get_logging_info()`, `set_eval_mode()`, state-dict buffers
 `common_epsilon[1]`, `epsilons[M, n_outer]`, `mass_vector[D]` / `noise_scalings[M, n_updates]`.
 
-A transition is ONE C-ABI call (fabhip_hmc_transition / fabhip_metropolis_transition): all leapfrogs,
+A transition is ONE custom-op call (torch.ops.fabhip.hmc_transition / metropolis_transition -> the C ABI): all leapfrogs,
 flow + target evaluations, accept/reject, commit and step-size adaptation run on the GPU; the step-size
 state lives in the registered device buffers and is updated in place (no host synchronisation).
 """
-import ctypes as C
 from typing import Dict, Optional, Union
 
 import torch
 
-from . import _lib
+from . import _ops
 from .flow import RealNVP
 from .point import Point
 from .targets import _NativeTarget
 
 
-def anneal_coefs(beta, alpha, p_target) -> _lib.Anneal:
-    a = _lib.Anneal()
-    _lib.load().fabhip_anneal_coefs(float(beta), float(alpha if alpha is not None else 0.0), int(bool(p_target)),
-                                    C.byref(a))
-    return a
+def anneal_coefs(beta, alpha, p_target):
+    """(c_q, c_p, g_q, g_p) of fab/sampling_methods/base.py:76-118 as float32 values (fabhip_anneal_coefs)."""
+    return tuple(_ops.load().anneal_coefs(float(beta), float(alpha if alpha is not None else 0.0), bool(p_target)))
 
 
 def _owner(fn, cls, what):
     obj = getattr(fn, "__self__", None)
     if not isinstance(obj, cls):
-        raise _lib.FabhipError(
+        raise _ops.FabhipError(
             f"{what} must be the bound `log_prob` of a fab_torch_amd {cls.__name__} for the HIP path "
             f"(got {fn!r}); there is no CPU / generic-callable fallback")
     return obj
@@ -45,7 +42,6 @@ class TransitionOperator(torch.nn.Module):
         self.n_ais_intermediate_distributions = n_ais_intermediate_distributions
         self.p_target = p_target
         super().__init__()
-        self._ws = _lib.Workspace()
 
     # resolved lazily so that the operator can be constructed before `.cuda()`
     @property
@@ -76,33 +72,20 @@ class TransitionOperator(torch.nn.Module):
 def create_point(x: torch.Tensor, flow: RealNVP, target: _NativeTarget, with_grad: bool,
                  log_q_x: Optional[torch.Tensor] = None) -> Point:
     """fab/sampling_methods/base.py:59-72 on the GPU (one fused launch)."""
-    lib = _lib.load()
-    _lib.require_device(x, "x")
+    _ops.require_device(x, "x")
     x = x.detach().contiguous().float()
-    B, D = x.shape
-    f, _ = flow.native()
-    t = target.native_target()
-    lq = torch.empty(B, dtype=torch.float32, device=x.device)
-    lp = torch.empty_like(lq)
-    gq = torch.empty_like(x) if with_grad else None
-    gp = torch.empty_like(x) if with_grad else None
-    p = _lib.Point(x.data_ptr(), lq.data_ptr(), lp.data_ptr(), gq.data_ptr() if with_grad else None,
-                   gp.data_ptr() if with_grad else None)
-    _lib.check(lib.fabhip_create_point(C.byref(f), C.byref(t), C.byref(p), int(with_grad), B, _lib.stream_ptr()),
-               "create_point")
+    lq, lp, gq, gp = _ops.load().create_point(*flow.native(), *target.native_target(), x, bool(with_grad))
     if not with_grad and log_q_x is not None:
         lq = log_q_x.detach()
-    return Point(x, lq, lp, gq, gp)
+    return Point(x, lq, lp, gq if with_grad else None, gp if with_grad else None)
 
 
-def _point_struct(point: Point, with_grad: bool) -> _lib.Point:
-    for t in (point.x, point.log_q, point.log_p):
-        _lib.require_device(t, "point")
+def _check_point(point: Point, with_grad: bool):
+    ts = [point.x, point.log_q, point.log_p] + ([point.grad_log_q, point.grad_log_p] if with_grad else [])
+    for t in ts:
+        _ops.require_device(t, "point")
         if not t.is_contiguous() or t.dtype != torch.float32:
-            raise _lib.FabhipError("Point tensors must be contiguous float32 (they are updated in place)")
-    gq = point.grad_log_q.data_ptr() if with_grad else None
-    gp = point.grad_log_p.data_ptr() if with_grad else None
-    return _lib.Point(point.x.data_ptr(), point.log_q.data_ptr(), point.log_p.data_ptr(), gq, gp)
+            raise _ops.FabhipError("Point tensors must be contiguous float32 (they are updated in place)")
 
 
 class HamiltonianMonteCarlo(TransitionOperator):
@@ -164,38 +147,25 @@ class HamiltonianMonteCarlo(TransitionOperator):
                    noise_p: torch.Tensor = None, noise_e: torch.Tensor = None) -> Point:
         """`noise_p [n_outer, B, D]` / `noise_e [n_outer, B]` may be supplied (parity tests); otherwise they are
         drawn from the device generator.  With `log_w`/`beta_next` the AIS increment (ais.py:93-100) is fused."""
-        lib = _lib.load()
         B, D = point.x.shape
         dev = point.x.device
         if noise_p is None:
             noise_p = torch.randn((self.n_outer, B, D), dtype=torch.float32, device=dev)
         if noise_e is None:
             noise_e = torch.empty((self.n_outer, B), dtype=torch.float32, device=dev).exponential_(1.0)
-        noise_p, noise_e = noise_p.contiguous(), noise_e.contiguous()
-        a = _lib.HmcArgs()
-        a.flow, _ = self.flow.native()
-        a.target = self.target.native_target()
-        a.point = _point_struct(point, True)
-        a.B, a.n_valid = B, None
-        a.cur = anneal_coefs(beta, self.alpha, self.p_target)
-        a.next = anneal_coefs(beta_next if beta_next is not None else beta, self.alpha, self.p_target)
-        a.log_w = log_w.data_ptr() if log_w is not None else None
-        a.noise_p, a.noise_e = noise_p.data_ptr(), noise_e.data_ptr()
-        a.epsilons = self.epsilons.data_ptr() + 4 * (i - 1) * self.n_outer
-        a.common_epsilon, a.mass = self.common_epsilon.data_ptr(), self.mass_vector.data_ptr()
-        a.n_outer, a.L = self.n_outer, self.L
-        a.max_grad, a.target_p_accept = self.max_grad, self.target_p_accept
-        a.tune = 0 if self.eval_mode else 1
+        _check_point(point, True)
         M = self.n_ais_intermediate_distributions
-        a.p_accept, a.avg_distance = None, None
+        p_accept, avg_distance = None, None
         if i == 1:
-            a.p_accept, a.avg_distance = self._p_accept_first.data_ptr(), self._dist_first.data_ptr()
+            p_accept, avg_distance = self._p_accept_first, self._dist_first
         elif i == M:
-            a.p_accept, a.avg_distance = self._p_accept_last.data_ptr(), self._dist_last.data_ptr()
-        nb = lib.fabhip_hmc_workspace_bytes(B, D, self.n_outer)
-        ws = self._ws.get(nb, dev)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), nb
-        _lib.check(lib.fabhip_hmc_transition(C.byref(a), _lib.stream_ptr()), "hmc_transition")
+            p_accept, avg_distance = self._p_accept_last, self._dist_last
+        _ops.load().hmc_transition(
+            *self.flow.native(), *self.target.native_target(), point.x, point.log_q, point.log_p, point.grad_log_q,
+            point.grad_log_p, log_w, float(beta), float(beta_next if beta_next is not None else beta),
+            float(self.alpha if self.alpha is not None else 0.0), bool(self.p_target), noise_p.contiguous(),
+            noise_e.contiguous(), self.epsilons[i - 1], self.common_epsilon, self.mass_vector, self.L,
+            float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance)
         return point
 
 
@@ -227,29 +197,16 @@ class Metropolis(TransitionOperator):
 
     def transition(self, point: Point, i: int, beta: float, log_w: torch.Tensor = None, beta_next=None,
                    noise_x: torch.Tensor = None, noise_u: torch.Tensor = None) -> Point:
-        lib = _lib.load()
         B, D = point.x.shape
         dev = point.x.device
         if noise_x is None:
             noise_x = torch.randn((self.n_updates, B, D), dtype=torch.float32, device=dev)
         if noise_u is None:
             noise_u = torch.rand((self.n_updates, B), dtype=torch.float32, device=dev)
-        noise_x, noise_u = noise_x.contiguous(), noise_u.contiguous()
-        a = _lib.MetropolisArgs()
-        a.flow, _ = self.flow.native()
-        a.target = self.target.native_target()
-        a.point = _point_struct(point, False)
-        a.B, a.n_valid = B, None
-        a.cur = anneal_coefs(beta, self.alpha, self.p_target)
-        a.next = anneal_coefs(beta_next if beta_next is not None else beta, self.alpha, self.p_target)
-        a.log_w = log_w.data_ptr() if log_w is not None else None
-        a.noise_x, a.noise_u = noise_x.data_ptr(), noise_u.data_ptr()
-        a.noise_scalings = self.noise_scalings.data_ptr() + 4 * (i - 1) * self.n_updates
-        a.n_updates = self.n_updates
-        a.target_p_accept = self.target_prob_accept
-        a.tune = 1 if (self.adjust_step_size and not self.eval_mode) else 0
-        nb = lib.fabhip_metropolis_workspace_bytes(B, D, self.n_updates)
-        ws = self._ws.get(nb, dev)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), nb
-        _lib.check(lib.fabhip_metropolis_transition(C.byref(a), _lib.stream_ptr()), "metropolis_transition")
+        _check_point(point, False)
+        _ops.load().metropolis_transition(
+            *self.flow.native(), *self.target.native_target(), point.x, point.log_q, point.log_p, log_w, float(beta),
+            float(beta_next if beta_next is not None else beta), float(self.alpha if self.alpha is not None else 0.0),
+            bool(self.p_target), noise_x.contiguous(), noise_u.contiguous(), self.noise_scalings[i - 1],
+            float(self.target_prob_accept), bool(self.adjust_step_size and not self.eval_mode))
         return point

@@ -1,0 +1,169 @@
+"""The PyTorch-ROCm custom-op layer (torch.ops.fabhip.*, csrc/torch_ops.cpp) against the raw C ABI of libfabhip.so
+driven through ctypes (fab_torch_amd/_lib.py) on the same inputs: results must be BIT-identical (the ops only
+marshal tensors into the C structs).  Plus: dispatcher behaviour (CUDA/HIP key only), stream handling, the
+registered autograd of fabhip::realnvp_logprob_tape, torch.library.opcheck."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+fa = pytest.importorskip("fab_torch_amd")
+from fab_torch_amd import _lib, _ops          # noqa: E402
+from oracle import flow as oflow              # noqa: E402
+
+DEV = "cuda"
+
+
+def _flow(D, K, nodes, seed):
+    torch.manual_seed(seed)
+    nf = oflow.make_realnvp(D, K, nodes)
+    oflow.randomize_last_layers(nf, 0.05, seed + 1)
+    f = fa.RealNVP(D, K, nodes)
+    f._nf_model.load_state_dict(nf.state_dict())
+    return f.to(DEV).requires_grad_(False)
+
+
+def _cabi_flow(flow):
+    packed, D, K, W = flow.native()
+    return _lib.Flow(D, K, W, packed.data_ptr()), packed
+
+
+def _sync_stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def test_ops_are_registered_for_the_hip_key_only():
+    ops = _ops.load()
+    assert ops.abi_version() == _ops.ABI_VERSION == _lib.load().fabhip_version()
+    with pytest.raises(NotImplementedError, match="CPU"):
+        ops.ess_logz(torch.randn(8), None, 8.0)
+    with pytest.raises(NotImplementedError, match="CPU"):
+        ops.manywell_logp_grad(torch.randn(4, 6), -0.5, -6.0, 1.0, 0.0)
+    with pytest.raises(RuntimeError, match="fabhip"):           # C-ABI error code -> c10::Error
+        ops.realnvp_sample(torch.zeros(7, device=DEV), 6, 2, 30, torch.randn(4, 6, device=DEV))
+
+
+@pytest.mark.parametrize("D,K,nodes,B", [(6, 3, 5, 50), (32, 10, 10, 77)])
+def test_realnvp_ops_equal_the_c_abi_bit_for_bit(D, K, nodes, B):
+    lib, ops = _lib.load(), _ops.load()
+    flow = _flow(D, K, nodes, 3)
+    f, packed = _cabi_flow(flow)
+    x = torch.randn(B, D, device=DEV)
+    lq_c = torch.empty(B, device=DEV); g_c = torch.empty(B, D, device=DEV)
+    _lib.check(lib.fabhip_flow_log_prob(C.byref(f), _lib.ptr(x), _lib.ptr(lq_c), _lib.ptr(g_c), B, _sync_stream()))
+    lq_o, g_o = ops.realnvp_logprob_grad(packed, D, K, flow.width, x, True)
+    assert torch.equal(lq_o, lq_c) and torch.equal(g_o, g_c)
+    eps = torch.randn(B, D, device=DEV)
+    xs_c = torch.empty(B, D, device=DEV); lqs_c = torch.empty(B, device=DEV)
+    _lib.check(lib.fabhip_flow_sample(C.byref(f), _lib.ptr(eps), _lib.ptr(xs_c), _lib.ptr(lqs_c), B, _sync_stream()))
+    xs_o, lqs_o = ops.realnvp_sample(packed, D, K, flow.width, eps)
+    assert torch.equal(xs_o, xs_c) and torch.equal(lqs_o, lqs_c)
+    # on a side stream: the op enqueues on torch's CURRENT stream
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        lq_s, _ = ops.realnvp_logprob_grad(packed, D, K, flow.width, x, False)
+    side.synchronize()
+    assert torch.equal(lq_s, lq_c)
+
+
+def test_ais_run_op_equals_the_c_abi_bit_for_bit():
+    lib, ops = _lib.load(), _ops.load()
+    D, K, nodes, M, B, L = 6, 3, 5, 4, 100, 5
+    flow = _flow(D, K, nodes, 5)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=L).to(DEV)
+    ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, False, 2.0, M)
+    torch.manual_seed(0)
+    eps0 = torch.randn(B, D, device=DEV); na = torch.randn(M, 1, B, D, device=DEV)
+    nb = torch.empty(M, 1, B, device=DEV).exponential_()
+    eps_in, ceps_in = hmc.epsilons.clone(), hmc.common_epsilon.clone()
+    # (1) the op, through the product class
+    pt, lw, n_valid, stats, _, _ = ais.run(B, eps0, na, nb)
+    eps_op, ceps_op = hmc.epsilons.clone(), hmc.common_epsilon.clone()
+    # (2) the raw C ABI through ctypes on the same inputs / the same initial step sizes
+    eps_c, ceps_c = eps_in.clone(), ceps_in.clone()
+    f, packed = _cabi_flow(flow)
+    a = _lib.AisArgs()
+    a.flow = f
+    kind, prm, _, _ = target.native_target()
+    a.target = _lib.Target(kind, D, prm[0], prm[1], prm[2], prm[3], 0, None, None)
+    betas = (C.c_double * (M + 2))(*[float(b) for b in ais.B_space])
+    a.B, a.M, a.betas, a.alpha, a.p_target, a.transition = B, M, betas, 2.0, 0, _lib.TRANSITION_HMC
+    a.eps0, a.noise_a, a.noise_b = eps0.data_ptr(), na.data_ptr(), nb.data_ptr()
+    a.step_state, a.common_epsilon, a.mass = eps_c.data_ptr(), ceps_c.data_ptr(), hmc.mass_vector.data_ptr()
+    a.n_inner, a.L, a.max_grad, a.target_p_accept, a.tune = 1, L, hmc.max_grad, hmc.target_p_accept, 1
+    f32 = dict(dtype=torch.float32, device=DEV)
+    x, lq, lp, lwc = torch.empty(B, D, **f32), torch.empty(B, **f32), torch.empty(B, **f32), torch.empty(B, **f32)
+    gq, gp = torch.empty(B, D, **f32), torch.empty(B, D, **f32)
+    nv, st = torch.zeros(2, dtype=torch.int32, device=DEV), torch.zeros(16, **f32)
+    a.point = _lib.Point(x.data_ptr(), lq.data_ptr(), lp.data_ptr(), gq.data_ptr(), gp.data_ptr())
+    a.log_w, a.n_valid, a.stats = lwc.data_ptr(), nv.data_ptr(), st.data_ptr()
+    nbytes = lib.fabhip_ais_workspace_bytes(B, D, 1)
+    ws = torch.empty(nbytes + 256, dtype=torch.uint8, device=DEV)
+    a.workspace, a.workspace_bytes = (ws.data_ptr() + 255) // 256 * 256, nbytes
+    _lib.check(lib.fabhip_ais_run(C.byref(a), _sync_stream()), "ais_run")
+    torch.cuda.synchronize()
+    assert torch.equal(nv, n_valid) and int(nv[1]) == B
+    for got, ref in ((pt.x, x), (pt.log_q, lq), (pt.log_p, lp), (pt.grad_log_q, gq), (pt.grad_log_p, gp), (lw, lwc),
+                     (stats[:6], st[:6]), (eps_op, eps_c), (ceps_op, ceps_c)):
+        assert torch.equal(got, ref)
+    # the op also reachable directly, by name
+    out = torch.ops.fabhip.ais_run(*flow.native(), *target.native_target(), [float(b) for b in ais.B_space], 2.0, False,
+                                   _ops.TRANSITION_HMC, eps0, na, nb, eps_in.clone(), ceps_in.clone(), hmc.mass_vector,
+                                   1, L, float(hmc.max_grad), float(hmc.target_p_accept), True, None, None, None, None,
+                                   False)
+    assert torch.equal(out[0], x) and torch.equal(out[5], lwc)
+
+
+def test_logprob_tape_autograd_matches_explicit_param_grad_and_opcheck():
+    ops = _ops.load()
+    D, K, nodes, B = 6, 3, 5, 40
+    flow = _flow(D, K, nodes, 9).requires_grad_(True)
+    x = torch.randn(B, D, device=DEV, requires_grad=True)
+    coef = torch.randn(B, device=DEV)
+    lq = flow.log_prob(x)                               # torch.ops.fabhip.realnvp_logprob_tape + registered autograd
+    assert lq.requires_grad
+    (lq * coef).sum().backward()
+    with torch.no_grad():
+        lq2, handle, gx = flow.log_prob_with_tape(x, want_grad_x=True)
+        flat = flow.param_grad_flat(handle, coef)
+    assert torch.equal(lq.detach(), lq2) and torch.equal(x.grad, coef[:, None] * gx)
+    views = flow._grad_views(flat)
+    for p, v in zip(flow._grad_tensors(), views):
+        assert torch.equal(p.grad, v), "autograd of the op != fabhip::realnvp_param_grad"
+    # registration sanity (schema, fake tensor where registered, autograd registration)
+    packed, _, _, W = flow.native(need_inverse=False)
+    torch.library.opcheck(torch.ops.fabhip.realnvp_logprob_grad.default, (packed, D, K, W, x.detach(), True),
+                          test_utils=("test_schema", "test_faketensor"))
+    theta = torch.cat([p.detach().reshape(-1) for p in flow._grad_tensors()]).requires_grad_(True)
+    torch.library.opcheck(torch.ops.fabhip.realnvp_logprob_tape.default,
+                          (theta, x.detach(), packed, [p.detach() for p in flow._param_list()], D, K, W, False),
+                          test_utils=("test_schema", "test_autograd_registration"))
+
+
+def test_target_and_resample_ops_equal_the_c_abi():
+    lib, ops = _lib.load(), _ops.load()
+    x = torch.randn(333, 32, device=DEV) * 1.5
+    lp, g = ops.manywell_logp_grad(x, -0.5, -6.0, 1.0, 0.0)
+    t = _lib.Target(_lib.TARGET_MANYWELL, 32, -0.5, -6.0, 1.0, 0.0, 0, None, None)
+    lp_c, g_c = torch.empty(333, device=DEV), torch.empty(333, 32, device=DEV)
+    _lib.check(lib.fabhip_target_log_prob(C.byref(t), _lib.ptr(x), _lib.ptr(lp_c), _lib.ptr(g_c), 333, _sync_stream()))
+    assert torch.equal(lp, lp_c) and torch.equal(g, g_c)
+    lw = torch.randn(100_003, device=DEV) * 3
+    idx = ops.resample_systematic(lw, 0.25, 100_003)
+    idx_c = torch.empty(100_003, dtype=torch.int64, device=DEV)
+    nb = lib.fabhip_resample_workspace_bytes(100_003)
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.fabhip_resample_systematic(_lib.ptr(lw), 100_003, 0.25, 100_003, _lib.ptr(idx_c),
+                                              C.c_void_p((ws.data_ptr() + 255) // 256 * 256), nb, _sync_stream()))
+    assert torch.equal(idx, idx_c)
+    st = ops.ess_logz(lw, None, float(lw.numel()))
+    st_c = torch.empty(3, device=DEV)
+    nb = lib.fabhip_ess_workspace_bytes(lw.numel())
+    ws = torch.empty(nb + 256, dtype=torch.uint8, device=DEV)
+    _lib.check(lib.fabhip_ess_logz(_lib.ptr(lw), lw.numel(), None, float(lw.numel()), _lib.ptr(st_c),
+                                   C.c_void_p((ws.data_ptr() + 255) // 256 * 256), nb, _sync_stream()))
+    assert torch.equal(st, st_c)
