@@ -90,6 +90,9 @@ SYMBOLS = [
     "fabhip_flow_tape_bytes", "fabhip_flow_log_prob_tape", "fabhip_flow_param_grad",
     "fabhip_adam_workspace_bytes", "fabhip_adam_clip_step", "fabhip_topk_workspace_bytes", "fabhip_topk",
     "fabhip_flow_pack_density", "fabhip_abi_sizes", "fabhip_flow_tape_layout",
+    "fabhip_generic_workspace_bytes", "fabhip_hmc_generic_begin", "fabhip_hmc_generic_leap_pre",
+    "fabhip_hmc_generic_leap_post", "fabhip_hmc_generic_accept", "fabhip_anneal_log_prob", "fabhip_log_w_update",
+    "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept",
 ]
 ABI_VERSION = 200          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
@@ -135,6 +138,8 @@ def _declare(lib):
     lib.fabhip_flow_grad_layout.argtypes = [i32, i32, i32, C.POINTER(i64)]
     lib.fabhip_flow_tape_bytes.restype = sz
     lib.fabhip_flow_tape_bytes.argtypes = [i32, i32, i32, i64]
+    lib.fabhip_generic_workspace_bytes.restype = sz
+    lib.fabhip_generic_workspace_bytes.argtypes = [i64, i32]
     lib.fabhip_flow_tape_layout.argtypes = [i32, i32, i32, i64, C.POINTER(i64)]
     lib.fabhip_flow_log_prob_tape.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp, sz, vp]
     lib.fabhip_flow_param_grad.argtypes = [C.POINTER(FlowParams), C.POINTER(Flow), vp, sz, vp, i64, vp, vp]

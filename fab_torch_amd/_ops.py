@@ -88,7 +88,7 @@ def _tape_backward(ctx, g_log_q, g_grad_x, g_tape):
         if not ctx.have_gx:
             raise FabhipError("realnvp_logprob_tape: x requires grad but the forward ran without want_grad_x")
         gx = coef[:, None] * grad_x
-    return flat, gx, None, None, None, None, None, None
+    return flat, gx, None, [None] * ctx.n_params, None, None, None, None      # (Tensor[] slot: a list of that length)
 
 
 def _register_autograd():

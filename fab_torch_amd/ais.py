@@ -13,7 +13,8 @@ from . import _ops
 from .flow import RealNVP
 from .point import Point
 from .targets import _NativeTarget
-from .transition_operators import HamiltonianMonteCarlo, Metropolis, TransitionOperator, create_point, _owner
+from .transition_operators import (HamiltonianMonteCarlo, Metropolis, TransitionOperator, create_point,
+                                   create_point_generic, _owner, _owner_or_none)
 
 
 class LoggingInfo(NamedTuple):
@@ -111,8 +112,65 @@ class AnnealedImportanceSampler:
         point = Point(x, lq, lp, gq if hmc else None, gp if hmc else None)
         return point, log_w, n_valid, stats, base_x, base_lw
 
+    @property
+    def is_native(self) -> bool:
+        return isinstance(self.base_distribution, RealNVP) and \
+            _owner_or_none(self.target_log_prob, _NativeTarget) is not None and self.transition_operator.is_native
+
+    def _sample_generic(self, batch_size: int, logging: bool, noise_a=None, noise_b=None):
+        """ais.py:53-105 for ANY `Distribution` / `LogProbFunc` plug-ins (fab/types_.py:5-27): the reference's loop,
+        stepped from Python; the plug-ins evaluate their own densities, the transitions / log-weight arithmetic /
+        ESS run as fabhip kernels (transition_operators.py: generic path)."""
+        ops = _ops.load()
+        op = self.transition_operator
+        B, M = int(batch_size), self.n_intermediate_distributions
+        alpha = float(self.alpha) if self.alpha is not None else 0.0
+        x, log_q0 = self.base_distribution.sample_and_log_prob((B,))
+        point = create_point_generic(x, self.base_distribution.log_prob, self.target_log_prob,
+                                     with_grad=op.uses_grad_info, log_q_x=log_q0)
+        log_q0 = log_q0.detach().contiguous().float()
+        log_w = ops.anneal_log_prob(point.log_q, point.log_p, float(self.B_space[1]), alpha, bool(self.p_target)) - log_q0
+        point, log_w = self._remove_nan_and_infs(point, log_w, "chain init")
+        ess_base = ops.ess_logz((point.log_p - point.log_q).contiguous(), None, 1.0)
+        hmc = isinstance(op, HamiltonianMonteCarlo)
+        n_inner = op.n_outer if hmc else op.n_updates
+        for j in range(1, M + 1):
+            n = point.x.shape[0]
+            beta, beta_next = float(self.B_space[j]), float(self.B_space[j + 1])
+            lw = log_w if beta_next != beta else None                              # ais.py:93
+            na = noise_a[j - 1][:, :n].contiguous() if noise_a is not None else None
+            nb = noise_b[j - 1][:, :n].contiguous() if noise_b is not None else None
+            if hmc:
+                point = op.transition(point, j, beta, log_w=lw, beta_next=beta_next, noise_p=na, noise_e=nb)
+            else:
+                point = op.transition(point, j, beta, log_w=lw, beta_next=beta_next, noise_x=na, noise_u=nb)
+        point, log_w = self._remove_nan_and_infs(point, log_w, "chain end")
+        if logging:
+            st = torch.cat([ess_base[:1], ops.ess_logz(log_w.contiguous(), None, float(B))[:2]]).tolist()
+            self._logging_info = LoggingInfo(ess_base=st[0], ess_ais=st[1], log_Z=st[2])
+        return point, log_w.detach()
+
+    @staticmethod
+    def _remove_nan_and_infs(point: Point, log_w: torch.Tensor, descriptor: str):
+        """ais.py:190-213 (generic path; the fused path compacts on the device)."""
+        valid = torch.isfinite(point.log_p) & torch.isfinite(point.log_q)
+        n_valid = int(valid.sum())
+        if n_valid == 0:
+            raise Exception(f"No valid points generated in sampling the {descriptor}")
+        if n_valid == valid.shape[0]:
+            return point, log_w
+        print(f"{valid.shape[0] - n_valid} nan/inf samples/log-probs/log-weights encountered at {descriptor}.")
+        keep = valid.nonzero().flatten()
+        g = lambda t: None if t is None else t[keep].contiguous()      # noqa: E731
+        return Point(g(point.x), g(point.log_q), g(point.log_p), g(point.grad_log_q), g(point.grad_log_p)), g(log_w)
+
     def sample_and_log_weights(self, batch_size: int, logging: bool = True, eps0=None, noise_a=None, noise_b=None
                                ) -> Tuple[Point, torch.Tensor]:
+        if not self.is_native:
+            if eps0 is not None:
+                raise _ops.FabhipError("eps0 is the base noise of a fab_torch_amd RealNVP; a generic base_distribution "
+                                       "draws its own samples in sample_and_log_prob")
+            return self._sample_generic(batch_size, logging, noise_a, noise_b)
         point, log_w, n_valid, stats, _, _ = self.run(batch_size, eps0, noise_a, noise_b)
         host = torch.cat([n_valid.float(), stats[:6]]).cpu()          # the single device->host read
         n_init, n_end = int(host[0]), int(host[1])

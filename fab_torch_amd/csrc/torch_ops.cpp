@@ -319,6 +319,109 @@ void metropolis_transition(const Tensor& packed, int64_t dim, int64_t n_layers, 
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// generic plug-in path (any Distribution / LogProbFunc: densities + gradients evaluated by the caller)
+// ------------------------------------------------------------------------------------------------------------------
+Tensor generic_workspace(const Tensor& like, int64_t B, int64_t dim) {
+    return at::empty({(int64_t)(fabhip_generic_workspace_bytes(B, (int32_t)dim) / 4 + 64)}, like.options().dtype(at::kFloat));
+}
+size_t ws_bytes(const Tensor& ws) { return (size_t)ws.numel() * 4; }
+
+void hmc_generic_begin(const Tensor& start_x, const Tensor& start_gq, const Tensor& start_gp, const Tensor& cur_lq,
+                       const Tensor& cur_lp, double beta, double alpha, bool p_target, const Tensor& noise_p,
+                       const Tensor& mass, double max_grad, Tensor ws) {
+    c10::DeviceGuard g(start_x.device());
+    const int64_t B = start_x.size(0), D = start_x.size(1);
+    TORCH_CHECK(noise_p.numel() == B * D && mass.numel() == D, "fabhip: generic HMC shapes");
+    fabhip_point st{const_cast<float*>(fp(start_x, "x")), nullptr, nullptr, const_cast<float*>(fp(start_gq, "grad_log_q")),
+                    const_cast<float*>(fp(start_gp, "grad_log_p"))};
+    fabhip_point cu{nullptr, const_cast<float*>(fp(cur_lq, "log_q")), const_cast<float*>(fp(cur_lp, "log_p")), nullptr,
+                    nullptr};
+    chk(fabhip_hmc_generic_begin(&st, &cu, B, (int32_t)D, coefs(beta, alpha, p_target), fp(noise_p, "noise_p"),
+                                 fp(mass, "mass"), (float)max_grad, fpm(ws, "workspace"), ws_bytes(ws), stream_of(start_x)),
+        "hmc_generic_begin");
+}
+
+Tensor hmc_generic_leap_pre(int64_t B, int64_t dim, const Tensor& eps, const Tensor& ceps, const Tensor& mass,
+                            Tensor ws) {
+    c10::DeviceGuard g(ws.device());
+    Tensor x = fempty({B, dim}, ws);
+    chk(fabhip_hmc_generic_leap_pre(B, (int32_t)dim, fp(eps, "epsilon"), fp(ceps, "common_epsilon"), fp(mass, "mass"),
+                                    x.data_ptr<float>(), fpm(ws, "workspace"), ws_bytes(ws), stream_of(ws)),
+        "hmc_generic_leap_pre");
+    return x;
+}
+
+void hmc_generic_leap_post(const Tensor& gq, const Tensor& gp, double beta, double alpha, bool p_target, double max_grad,
+                           const Tensor& eps, const Tensor& ceps, Tensor ws) {
+    c10::DeviceGuard g(ws.device());
+    const int64_t B = gq.size(0), D = gq.size(1);
+    chk(fabhip_hmc_generic_leap_post(B, (int32_t)D, fp(gq, "grad_log_q"), fp(gp, "grad_log_p"),
+                                     coefs(beta, alpha, p_target), (float)max_grad, fp(eps, "epsilon"),
+                                     fp(ceps, "common_epsilon"), fpm(ws, "workspace"), ws_bytes(ws), stream_of(ws)),
+        "hmc_generic_leap_post");
+}
+
+void hmc_generic_accept(const Tensor& prop_lq, const Tensor& prop_lp, const Tensor& prop_gq, const Tensor& prop_gp,
+                        Tensor x, Tensor log_q, Tensor log_p, Tensor grad_log_q, Tensor grad_log_p,
+                        optional<Tensor> log_w, double beta, double beta_next, double alpha, bool p_target,
+                        const Tensor& noise_e, const Tensor& mass, Tensor eps, Tensor ceps, double target_p_accept,
+                        bool tune, optional<Tensor> p_accept, optional<Tensor> avg_distance, Tensor ws) {
+    c10::DeviceGuard g(x.device());
+    const int64_t B = x.size(0), D = x.size(1);
+    fabhip_point pr{nullptr, const_cast<float*>(fp(prop_lq, "log_q")), const_cast<float*>(fp(prop_lp, "log_p")),
+                    const_cast<float*>(fp(prop_gq, "grad_log_q")), const_cast<float*>(fp(prop_gp, "grad_log_p"))};
+    fabhip_point cu{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), fpm(grad_log_q, "grad_log_q"),
+                    fpm(grad_log_p, "grad_log_p")};
+    chk(fabhip_hmc_generic_accept(&pr, &cu, B, (int32_t)D, coefs(beta, alpha, p_target), coefs(beta_next, alpha, p_target),
+                                  fpm_opt(log_w, "log_w"), fp(noise_e, "noise_e"), fp(mass, "mass"), fpm(eps, "epsilon"),
+                                  fpm(ceps, "common_epsilon"), (float)target_p_accept, tune ? 1 : 0,
+                                  fpm_opt(p_accept, "p_accept"), fpm_opt(avg_distance, "avg_distance"),
+                                  fpm(ws, "workspace"), ws_bytes(ws), stream_of(x)),
+        "hmc_generic_accept");
+}
+
+Tensor anneal_log_prob(const Tensor& log_q, const Tensor& log_p, double beta, double alpha, bool p_target) {
+    c10::DeviceGuard g(log_q.device());
+    Tensor out = at::empty_like(log_q);
+    chk(fabhip_anneal_log_prob(fp(log_q, "log_q"), fp(log_p, "log_p"), log_q.numel(), coefs(beta, alpha, p_target),
+                               out.data_ptr<float>(), stream_of(log_q)),
+        "anneal_log_prob");
+    return out;
+}
+
+void log_w_update(const Tensor& log_q, const Tensor& log_p, double beta, double beta_next, double alpha, bool p_target,
+                  Tensor log_w) {
+    c10::DeviceGuard g(log_q.device());
+    chk(fabhip_log_w_update(fp(log_q, "log_q"), fp(log_p, "log_p"), log_q.numel(), coefs(beta, alpha, p_target),
+                            coefs(beta_next, alpha, p_target), fpm(log_w, "log_w"), stream_of(log_q)),
+        "log_w_update");
+}
+
+Tensor metropolis_generic_propose(const Tensor& x, const Tensor& noise_x, const Tensor& scale) {
+    c10::DeviceGuard g(x.device());
+    Tensor xn = at::empty_like(x);
+    chk(fabhip_metropolis_generic_propose(fp(x, "x"), fp(noise_x, "noise_x"), fp(scale, "noise_scaling"), x.size(0),
+                                          (int32_t)x.size(1), xn.data_ptr<float>(), stream_of(x)),
+        "metropolis_generic_propose");
+    return xn;
+}
+
+void metropolis_generic_accept(const Tensor& x_new, const Tensor& new_lq, const Tensor& new_lp, Tensor x, Tensor log_q,
+                               Tensor log_p, const Tensor& prev_log_prob, const Tensor& noise_u, double beta, double alpha,
+                               bool p_target, Tensor scale, double target_p_accept, bool tune) {
+    c10::DeviceGuard g(x.device());
+    const int64_t B = x.size(0), D = x.size(1);
+    fabhip_point cu{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), nullptr, nullptr};
+    Tensor ws = generic_workspace(x, B, D);
+    chk(fabhip_metropolis_generic_accept(fp(x_new, "x_new"), fp(new_lq, "log_q"), fp(new_lp, "log_p"), &cu,
+                                         fp(prev_log_prob, "prev_log_prob"), fp(noise_u, "noise_u"), B, (int32_t)D,
+                                         coefs(beta, alpha, p_target), fpm(scale, "noise_scaling"),
+                                         (float)target_p_accept, tune ? 1 : 0, fpm(ws, "workspace"), ws_bytes(ws),
+                                         stream_of(x)),
+        "metropolis_generic_accept");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // the whole AIS call (ais.py:53-105): returns
 //   (x, log_q, log_p, grad_log_q, grad_log_p, log_w, n_valid int32[2], stats float[16], base_x, base_log_w)
 // grad_* are empty for Metropolis, base_* are empty unless want_base.
@@ -492,6 +595,24 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
 
+    m.def("generic_workspace(Tensor like, int B, int dim) -> Tensor");
+    m.def("hmc_generic_begin(Tensor start_x, Tensor start_gq, Tensor start_gp, Tensor cur_lq, Tensor cur_lp, float beta, "
+          "float alpha, bool p_target, Tensor noise_p, Tensor mass, float max_grad, Tensor(a!) ws) -> ()");
+    m.def("hmc_generic_leap_pre(int B, int dim, Tensor eps, Tensor ceps, Tensor mass, Tensor(a!) ws) -> Tensor");
+    m.def("hmc_generic_leap_post(Tensor gq, Tensor gp, float beta, float alpha, bool p_target, float max_grad, Tensor eps, "
+          "Tensor ceps, Tensor(a!) ws) -> ()");
+    m.def("hmc_generic_accept(Tensor prop_lq, Tensor prop_lp, Tensor prop_gq, Tensor prop_gp, Tensor(a!) x, "
+          "Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!) grad_log_q, Tensor(e!) grad_log_p, Tensor(f!)? log_w, float beta, "
+          "float beta_next, float alpha, bool p_target, Tensor noise_e, Tensor mass, Tensor(g!) eps, Tensor(h!) ceps, "
+          "float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance, Tensor(k!) ws) -> ()");
+    m.def("anneal_log_prob(Tensor log_q, Tensor log_p, float beta, float alpha, bool p_target) -> Tensor");
+    m.def("log_w_update(Tensor log_q, Tensor log_p, float beta, float beta_next, float alpha, bool p_target, "
+          "Tensor(a!) log_w) -> ()");
+    m.def("metropolis_generic_propose(Tensor x, Tensor noise_x, Tensor scale) -> Tensor");
+    m.def("metropolis_generic_accept(Tensor x_new, Tensor new_lq, Tensor new_lp, Tensor(a!) x, Tensor(b!) log_q, "
+          "Tensor(c!) log_p, Tensor prev_log_prob, Tensor noise_u, float beta, float alpha, bool p_target, "
+          "Tensor(d!) scale, float target_p_accept, bool tune) -> ()");
+
     m.def("ess_logz(Tensor log_w, Tensor? n_ptr, float n_norm) -> Tensor");
     m.def("resample_multinomial(Tensor log_w, Tensor u) -> Tensor");
     m.def("resample_systematic(Tensor log_w, float u0, int n_samples) -> Tensor");
@@ -514,6 +635,15 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("hmc_transition", hmc_transition);
     m.impl("metropolis_transition", metropolis_transition);
     m.impl("ais_run", ais_run);
+    m.impl("generic_workspace", generic_workspace);
+    m.impl("hmc_generic_begin", hmc_generic_begin);
+    m.impl("hmc_generic_leap_pre", hmc_generic_leap_pre);
+    m.impl("hmc_generic_leap_post", hmc_generic_leap_post);
+    m.impl("hmc_generic_accept", hmc_generic_accept);
+    m.impl("anneal_log_prob", anneal_log_prob);
+    m.impl("log_w_update", log_w_update);
+    m.impl("metropolis_generic_propose", metropolis_generic_propose);
+    m.impl("metropolis_generic_accept", metropolis_generic_accept);
     m.impl("ess_logz", ess_logz);
     m.impl("resample_multinomial", resample_multinomial);
     m.impl("resample_systematic", resample_systematic);

@@ -27,9 +27,40 @@ def _owner(fn, cls, what):
     obj = getattr(fn, "__self__", None)
     if not isinstance(obj, cls):
         raise _ops.FabhipError(
-            f"{what} must be the bound `log_prob` of a fab_torch_amd {cls.__name__} for the HIP path "
-            f"(got {fn!r}); there is no CPU / generic-callable fallback")
+            f"{what} must be the bound `log_prob` of a fab_torch_amd {cls.__name__} for the fused HIP path "
+            f"(got {fn!r})")
     return obj
+
+
+def _owner_or_none(fn, cls):
+    obj = getattr(fn, "__self__", None)
+    return obj if isinstance(obj, cls) else None
+
+
+def grad_and_value(x: torch.Tensor, forward_fn):
+    """fab/sampling_methods/base.py:50-56: value and gradient w.r.t. x of a plug-in's log-density (its own code)."""
+    x = x.detach().requires_grad_(True)
+    with torch.enable_grad():
+        y = forward_fn(x)
+        grad = torch.autograd.grad(y, x, grad_outputs=torch.ones_like(y))[0]
+    return grad.detach(), y.detach()
+
+
+def create_point_generic(x: torch.Tensor, log_q_fn, log_p_fn, with_grad: bool,
+                         log_q_x: Optional[torch.Tensor] = None) -> Point:
+    """create_point for ANY plug-in callables (base.py:59-72): the densities are evaluated by the plug-ins themselves
+    (with autograd for the gradients), the result is laid out as the contiguous float32 Point the HIP kernels update."""
+    _ops.require_device(x, "x")
+    c = lambda t: t.detach().contiguous().float()          # noqa: E731
+    x = c(x)
+    if with_grad:
+        gq, lq = grad_and_value(x, log_q_fn)                 # a supplied log_q_x is ignored here, like the reference
+        gp, lp = grad_and_value(x, log_p_fn)
+        return Point(x, c(lq), c(lp), c(gq), c(gp))
+    with torch.no_grad():
+        lq = log_q_x if log_q_x is not None else log_q_fn(x)
+        lp = log_p_fn(x)
+    return Point(x, c(lq), c(lp))
 
 
 class TransitionOperator(torch.nn.Module):
@@ -52,8 +83,17 @@ class TransitionOperator(torch.nn.Module):
     def target(self) -> _NativeTarget:
         return _owner(self.target_log_prob, _NativeTarget, "target_log_prob")
 
+    @property
+    def is_native(self) -> bool:
+        """Both plug-ins are fabhip-native: the fused kernels evaluate the densities themselves.  Otherwise the
+        generic path runs: densities by the plug-ins' own code, the rest of the transition as HIP elementwise kernels."""
+        return (_owner_or_none(self.base_log_prob, RealNVP) is not None
+                and _owner_or_none(self.target_log_prob, _NativeTarget) is not None)
+
     def create_new_point(self, x: torch.Tensor) -> Point:
-        return create_point(x, self.flow, self.target, with_grad=self.uses_grad_info)
+        if self.is_native:
+            return create_point(x, self.flow, self.target, with_grad=self.uses_grad_info)
+        return create_point_generic(x, self.base_log_prob, self.target_log_prob, with_grad=self.uses_grad_info)
 
     @property
     def uses_grad_info(self) -> bool:
@@ -160,12 +200,46 @@ class HamiltonianMonteCarlo(TransitionOperator):
             p_accept, avg_distance = self._p_accept_first, self._dist_first
         elif i == M:
             p_accept, avg_distance = self._p_accept_last, self._dist_last
+        if not self.is_native:
+            return self._transition_generic(point, i, beta, log_w, beta_next, noise_p.contiguous(),
+                                            noise_e.contiguous(), p_accept, avg_distance)
         _ops.load().hmc_transition(
             *self.flow.native(), *self.target.native_target(), point.x, point.log_q, point.log_p, point.grad_log_q,
             point.grad_log_p, log_w, float(beta), float(beta_next if beta_next is not None else beta),
             float(self.alpha if self.alpha is not None else 0.0), bool(self.p_target), noise_p.contiguous(),
             noise_e.contiguous(), self.epsilons[i - 1], self.common_epsilon, self.mass_vector, self.L,
             float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance)
+        return point
+
+
+    def _transition_generic(self, point, i, beta, log_w, beta_next, noise_p, noise_e, p_accept, avg_distance):
+        """hmc.py:129-160 for arbitrary plug-ins: the L x n_outer density evaluations are the plug-ins' own code, the
+        momentum / position updates, the Metropolis test, the in-place commit, the log-weight increment and the
+        step-size adaptation are fabhip elementwise kernels sharing one workspace (include/fabhip.h, generic path)."""
+        ops = _ops.load()
+        assert self.L >= 1
+        B, D = point.x.shape
+        alpha = float(self.alpha if self.alpha is not None else 0.0)
+        beta, beta_next = float(beta), float(beta_next if beta_next is not None else beta)
+        ws = ops.generic_workspace(point.x, B, D)
+        start = point
+        for n in range(self.n_outer):
+            eps_n = self.epsilons[i - 1, n:n + 1]
+            ops.hmc_generic_begin(start.x, start.grad_log_q, start.grad_log_p, point.log_q, point.log_p, beta, alpha,
+                                  bool(self.p_target), noise_p[n], self.mass_vector, float(self.max_grad), ws)
+            prop = None
+            for _ in range(self.L):
+                x_new = ops.hmc_generic_leap_pre(B, D, eps_n, self.common_epsilon, self.mass_vector, ws)
+                prop = self.create_new_point(x_new)
+                ops.hmc_generic_leap_post(prop.grad_log_q, prop.grad_log_p, beta, alpha, bool(self.p_target),
+                                          float(self.max_grad), eps_n, self.common_epsilon, ws)
+            last = n + 1 == self.n_outer
+            ops.hmc_generic_accept(prop.log_q, prop.log_p, prop.grad_log_q, prop.grad_log_p, point.x, point.log_q,
+                                   point.log_p, point.grad_log_q, point.grad_log_p, log_w if last else None, beta,
+                                   beta_next, alpha, bool(self.p_target), noise_e[n], self.mass_vector, eps_n,
+                                   self.common_epsilon, float(self.target_p_accept), not self.eval_mode,
+                                   p_accept[n:n + 1] if p_accept is not None else None, avg_distance, ws)
+            start = prop                       # the reference continues from the PROPOSAL (hmc.py:133-142)
         return point
 
 
@@ -204,9 +278,30 @@ class Metropolis(TransitionOperator):
         if noise_u is None:
             noise_u = torch.rand((self.n_updates, B), dtype=torch.float32, device=dev)
         _check_point(point, False)
+        if not self.is_native:
+            return self._transition_generic(point, i, beta, log_w, beta_next, noise_x.contiguous(), noise_u.contiguous())
         _ops.load().metropolis_transition(
             *self.flow.native(), *self.target.native_target(), point.x, point.log_q, point.log_p, log_w, float(beta),
             float(beta_next if beta_next is not None else beta), float(self.alpha if self.alpha is not None else 0.0),
             bool(self.p_target), noise_x.contiguous(), noise_u.contiguous(), self.noise_scalings[i - 1],
             float(self.target_prob_accept), bool(self.adjust_step_size and not self.eval_mode))
+        return point
+
+    def _transition_generic(self, point, i, beta, log_w, beta_next, noise_x, noise_u):
+        """metropolis.py:51-74 for arbitrary plug-ins (densities by the plug-ins, propose / accept / commit / step
+        adaptation as fabhip elementwise kernels)."""
+        ops = _ops.load()
+        alpha = float(self.alpha if self.alpha is not None else 0.0)
+        beta, beta_next = float(beta), float(beta_next if beta_next is not None else beta)
+        prev = ops.anneal_log_prob(point.log_q, point.log_p, beta, alpha, bool(self.p_target))   # never refreshed (:53)
+        tune = bool(self.adjust_step_size and not self.eval_mode)
+        for n in range(self.n_updates):
+            scale = self.noise_scalings[i - 1, n:n + 1]
+            x_new = ops.metropolis_generic_propose(point.x, noise_x[n], scale)
+            new = self.create_new_point(x_new)
+            ops.metropolis_generic_accept(x_new, new.log_q, new.log_p, point.x, point.log_q, point.log_p, prev,
+                                          noise_u[n], beta, alpha, bool(self.p_target), scale,
+                                          float(self.target_prob_accept), tune)
+        if log_w is not None:
+            ops.log_w_update(point.log_q, point.log_p, beta, beta_next, alpha, bool(self.p_target), log_w)
         return point

@@ -228,6 +228,52 @@ size_t fabhip_metropolis_workspace_bytes(int64_t B, int32_t dim, int32_t n_updat
 int fabhip_metropolis_transition(const fabhip_metropolis_args* args, fabhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Generic plug-in path: transitions for ANY `Distribution` / `LogProbFunc` plug-in (fab/types_.py:5-27,
+ * fab/sampling_methods/ais.py:22-30).  The caller evaluates log q, log p and their gradients with the plug-ins' own
+ * code (create_point, fab/sampling_methods/base.py:50-72); everything else of a transition runs here as
+ * elementwise kernels.  One workspace of fabhip_generic_workspace_bytes(B, dim) carries the trajectory state
+ * (x, p, grad U, -U-K of the current point, acceptance partials) between the calls of one outer step:
+ *
+ *   HMC outer step n (hmc.py:129-160):
+ *     fabhip_hmc_generic_begin(start, cur, ...)        p0 = noise_p * mass, grad U(start), x <- start.x
+ *     L x { fabhip_hmc_generic_leap_pre(... x_out)     p -= eps gradU/2 ; x += eps/mass p ; x_out <- x
+ *           [caller: log q, log p, gradients at x_out]
+ *           fabhip_hmc_generic_leap_post(gq, gp, ...)  gradU <- clamp(-(g_q gq + g_p gp)) ; p -= eps gradU/2 }
+ *     fabhip_hmc_generic_accept(prop, cur, ...)        Metropolis test with noise_e, in-place commit into `cur`,
+ *                                                      log_w increment (if log_w), step-size adaptation, logging
+ *   (`start` = `cur` for n = 0; for n > 0 the reference continues from the previous PROPOSAL, hmc.py:133-142.)
+ *
+ *   Metropolis update n (metropolis.py:51-74): fabhip_metropolis_generic_propose -> [caller: log q, log p at x_new]
+ *     -> fabhip_metropolis_generic_accept (prev_log_prob = fabhip_anneal_log_prob of the point BEFORE the first
+ *     update, never refreshed: the reference's stale x_prev_log_prob).
+ * ---------------------------------------------------------------------------------------- */
+size_t fabhip_generic_workspace_bytes(int64_t B, int32_t dim);
+int fabhip_hmc_generic_begin(const fabhip_point* start, const fabhip_point* cur, int64_t B, int32_t dim,
+                             fabhip_anneal c, const float* noise_p, const float* mass, float max_grad,
+                             void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+int fabhip_hmc_generic_leap_pre(int64_t B, int32_t dim, const float* eps_ptr, const float* ceps_ptr, const float* mass,
+                                float* x_out, void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+int fabhip_hmc_generic_leap_post(int64_t B, int32_t dim, const float* grad_log_q, const float* grad_log_p,
+                                 fabhip_anneal c, float max_grad, const float* eps_ptr, const float* ceps_ptr,
+                                 void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+int fabhip_hmc_generic_accept(const fabhip_point* prop, const fabhip_point* cur, int64_t B, int32_t dim, fabhip_anneal c,
+                              fabhip_anneal next, float* log_w, const float* noise_e, const float* mass,
+                              float* eps_ptr, float* ceps_ptr, float target_p_accept, int32_t tune, float* p_accept,
+                              float* avg_distance, void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+/* out[i] = c_q log_q[i] + c_p log_p[i]  (get_intermediate_log_prob, base.py:76-97) */
+int fabhip_anneal_log_prob(const float* log_q, const float* log_p, int64_t n, fabhip_anneal c, float* out,
+                           fabhip_stream_t stream);
+/* log_w += pi_next(point) - pi_c(point)  (ais.py:93-100) */
+int fabhip_log_w_update(const float* log_q, const float* log_p, int64_t n, fabhip_anneal c, fabhip_anneal next,
+                        float* log_w, fabhip_stream_t stream);
+int fabhip_metropolis_generic_propose(const float* x, const float* noise_x, const float* scale_ptr, int64_t B, int32_t dim,
+                                      float* x_new, fabhip_stream_t stream);
+int fabhip_metropolis_generic_accept(const float* x_new, const float* new_log_q, const float* new_log_p,
+                                     const fabhip_point* cur, const float* prev_log_prob, const float* noise_u,
+                                     int64_t B, int32_t dim, fabhip_anneal c, float* scale_ptr, float target_p_accept,
+                                     int32_t tune, void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Whole AIS call  (fab/sampling_methods/ais.py:53-105): sample the flow, create the point,
  * initial log-weights, NaN/inf filtering (stable compaction, ais.py:190-213), M transitions
  * with log-weight accumulation, final filtering, ESS / log Z statistics — all enqueued by
