@@ -96,11 +96,15 @@ def test_generic_ais_matches_the_oracle_with_the_same_plugins(op_kind, p_target)
             res[where] = (pt, lw, li["ess_ais"], li["log_Z"], op)
     (po, lwo, ess_o, lz_o, oop), (ph, lwh, ess_h, lz_h, hop) = res["cpu"], res[DEV]
     assert ph.x.shape == po.x.shape
-    # low-dimensional, smooth densities: whole chains agree (a chain may flip at an accept threshold)
+    # low-dimensional, smooth densities: whole chains (M x 5 x 5 = 150 leapfrogs at step size ~1) agree; a chain may
+    # flip at an accept threshold.  The two runs evaluate the PLUG-INS with different arithmetic (torch CPU libm vs
+    # torch-ROCm device math), whose 1e-7 differences the dynamics amplify: positions within 1e-3, and the scalars
+    # within what a 1e-3 displacement does to them (|grad| ~ 1): 2e-3 absolute + 1e-4 relative.
     same = (ph.x.cpu() - po.x).abs().max(1).values < 1e-3
     assert int(same.sum()) >= B - 2, f"{int((~same).sum())} chains left the oracle trajectory"
-    assert close(lwh.cpu()[same], lwo[same], RTOL), worst(lwh.cpu()[same], lwo[same])
-    assert close(ph.log_q.cpu()[same], po.log_q[same], RTOL) and close(ph.log_p.cpu()[same], po.log_p[same], RTOL)
+    assert close(lwh.cpu()[same], lwo[same], RTOL, atol=2e-3), worst(lwh.cpu()[same], lwo[same])
+    assert close(ph.log_q.cpu()[same], po.log_q[same], RTOL, atol=2e-3)
+    assert close(ph.log_p.cpu()[same], po.log_p[same], RTOL, atol=2e-3)
     if same.all():
         assert abs(ess_h - ess_o) <= 0.01 * ess_o and abs(lz_h - lz_o) <= 1e-3 * max(1.0, abs(lz_o))
         if hmc:        # identical acceptance statistics => bit-identical adapted step sizes

@@ -46,9 +46,9 @@ def hip_flow_from_oracle(nf):
 
 class Workload:
     def __init__(self, name, D, K, nodes, M, B, target="manywell", op="hmc", L=5, eps=0.12, seed=0, spacing="linear",
-                 n_inner=1, log_scale_shift=0.0):
+                 n_inner=1, log_scale_shift=0.0, std=0.05):
         self.name, self.D, self.M, self.B, self.op, self.L, self.n_inner = name, D, M, B, op, L, n_inner
-        self.nf = seeded_flow(D, K, nodes, 700 + seed)
+        self.nf = seeded_flow(D, K, nodes, 700 + seed, std=std)
         if log_scale_shift:
             with torch.no_grad():
                 self.nf.q0.log_scale += log_scale_shift
@@ -208,7 +208,7 @@ def test_cfg4_sharded_16384_chains_gather_equals_single_run():
     log-weights must be bit-identical to ONE 16384-chain run on the same noise (evaluation-mode step sizes, SURVEY
     8e), so the global ESS / log Z equal the single-device run's."""
     R, per = 8, 2048
-    w = Workload("cfg4", D=32, K=12, nodes=10, M=12, B=R * per, eps=0.12, seed=4)
+    w = Workload("cfg4", D=32, K=12, nodes=10, M=12, B=R * per, eps=0.1, seed=4, std=0.02)
     check_slice_vs_oracle_per_transition(w)
     pt, lw, info = check_full_size_properties(w)
     bufs = []
@@ -255,9 +255,11 @@ def test_cfg3_one_prioritised_buffer_iteration_at_full_size():
     assert idx.shape == (4 * B,) and len(set(idx.tolist())) == 4 * B and int(idx.max()) < 5 * B
     assert not torch.equal(opt.theta.detach(), before)
     touched = torch.zeros(8 * B, dtype=torch.bool, device=DEV); touched[idx] = True
+    touched[4 * B:5 * B] = True                                                  # this iteration's AIS batch (buffer.add)
     assert torch.equal(buf.buffer.log_w[~touched], lw_before[~touched])          # untouched entries keep their weight
     # on a slice of the first minibatch (flow parameters = `before`): adjustment vs the oracle flow
-    sl = idx[:SLICE]
+    first = idx[:B]                                   # first minibatch: evaluated with the parameters `before`
+    sl = first[first < 4 * B][:SLICE]                 # entries that were in the buffer before this iteration
     x_sl = buf.buffer.x[sl].cpu()
     with torch.no_grad():
         lq_new = nf.log_prob(x_sl)
