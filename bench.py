@@ -80,6 +80,84 @@ def cpu_baseline(flow_state, n_calls=2):
             "sec_per_call": dt, "host_cpus": os.cpu_count()}
 
 
+PEAK_HBM_TBPS = 8.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def _event_time(fn, n=20, warm=3):
+    """median seconds per call, HIP events on torch's current stream (the stream the ops enqueue on)."""
+    for _ in range(warm):
+        fn()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    ev[0].record()
+    for i in range(n):
+        fn()
+        ev[i + 1].record()
+    torch.cuda.synchronize()
+    ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))
+    return ms[n // 2] * 1e-3
+
+
+def resample_rooflines(dev, log2n=26):
+    """HBM rooflines of the resample path at N = 2^26 log-weights ~ N(0, 3^2) (seed 0), HIP-event timed in-process:
+    (1) k_scan_fixed_lds alone - the decoupled-look-back fixed-point CDF scan: 4N read + 8N written = 12N algorithmic
+    bytes; (2) the whole fabhip_resample_systematic call (max pass, tile sums, prefix, fused emit): algorithmic bytes
+    4N (log_w in) + 8N (idx out) = 12N, actual traffic 20N (log_w is read three times)."""
+    from fab_torch_amd import _ops
+    ops = _ops.load()
+    N = 1 << log2n
+    g = torch.Generator(device=dev).manual_seed(0)
+    lw = torch.randn(N, device=dev, generator=g) * 3
+    ws = ops.fixed_cdf(lw, None)                                   # max + scan once: leaves the max in the workspace
+    t_scan = _event_time(lambda: ops.fixed_cdf(lw, ws))            # memset of the descriptors (~5 us) + the scan kernel
+    t_sys = _event_time(lambda: ops.resample_systematic(lw, 0.3, N))
+    rows = []
+    for name, t, alg, traffic in (("k_scan_fixed_lds (fixed-point CDF scan, decoupled look-back)", t_scan, 12 * N, 12 * N),
+                                  ("fabhip_resample_systematic end to end (max, tile sums, prefix, fused emit)", t_sys,
+                                   12 * N, 20 * N)):
+        ach = alg / t / 1e12
+        rows.append({"bound": "hbm", "kernel": name, "N": N, "achieved": ach, "peak": PEAK_HBM_TBPS, "unit": "TB/s",
+                     "frac": ach / PEAK_HBM_TBPS, "traffic": traffic, "traffic_TBps": traffic / t / 1e12,
+                     "us_per_call": t * 1e6, "algorithmic_bytes": alg})
+    del lw, ws
+    torch.cuda.empty_cache()
+    return rows
+
+
+def trained_flow_ess(dev):
+    """"Meaningful ESS" row: the committed small TRAINED flow (tests/golden/g13: ManyWell-6, trained with
+    the reference's PrioritisedBufferTrainer) and the reference's own evaluation AIS call on it (1024 chains, target p,
+    frozen step sizes, captured noise): the HIP path on the identical noise must reproduce its ESS (north_star: within 1 %)."""
+    import numpy as np
+    import fab_torch_amd as fa
+    path = os.path.join(ROOT, "tests", "golden", "g13_trained_flow_mw6.npz")
+    if not os.path.exists(path):
+        return None
+    with np.load(path) as z:
+        g = {k: z[k] for k in z.files}
+    D, K, nodes, M, L = int(g["D"]), int(g["K"]), int(g["nodes"]), int(g["M"]), int(g["L"])
+    flow = fa.RealNVP(D, K, nodes)
+    flow._nf_model.load_state_dict({k[len("flow."):]: torch.tensor(v) for k, v in g.items() if k.startswith("flow.")})
+    flow = flow.to(dev).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    out = {"fixture": "tests/golden/g13_trained_flow_mw6.npz", "chains": int(g["B"])}
+    for tag, p_target in (("p", True), ("g", False)):
+        hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=float(g["alpha"]), p_target=p_target,
+                                       epsilon=1.0, L=L, eval_mode=True).to(dev)
+        with torch.no_grad():
+            hmc.epsilons.copy_(torch.tensor(g["epsilons"])); hmc.common_epsilon.copy_(torch.tensor(g["common_epsilon"]))
+        ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target, float(g["alpha"]), M)
+        T = lambda k: torch.tensor(g[k]).to(dev)      # noqa: E731
+        ais.sample_and_log_weights(int(g["B"]), eps0=T(f"{tag}_eps0"), noise_a=T(f"{tag}_noise_p"), noise_b=T(f"{tag}_noise_e"))
+        info = ais.get_logging_info()
+        ref = float(g[f"{tag}_ess_ais"])
+        out["target_" + tag] = {"ess_ais_hip": info["ess_ais"], "ess_ais_reference": ref,
+                                "rel_diff": abs(info["ess_ais"] - ref) / ref, "ess_flow_hip": info["ess_base"],
+                                "ess_flow_reference": float(g[f"{tag}_ess_base"]), "log_Z_hip": info["log_Z"],
+                                "log_Z_reference": float(g[f"{tag}_log_Z"])}
+    out["log_Z_exact"] = float(target.log_Z)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -186,17 +264,25 @@ def main():
                 "workgroups": n_wg, "frac_of_occupied_cus": ach / (PEAK_FP32_MFMA_TFLOPS * min(n_wg, 256) / 256)}
         # HBM traffic per launch: separate rocprofv3 --pmc passes of tools/prof_hmc.py (same kernel, same shape),
         # summarised by tools/pmc_summary.py and committed; not collectable from inside this process.
-        pmc = os.path.join(ROOT, "profiles", "r1", "hmc_step_pmc_summary.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
-            roof["traffic_source"] = "profiles/r1/hmc_step_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+        for rnd in ("r2", "r1"):
+            pmc = os.path.join(ROOT, "profiles", rnd, "hmc_step_pmc_summary.json")
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
+                roof["traffic_source"] = f"profiles/{rnd}/hmc_step_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+                break
         # the headline workload fills 64 of 256 CUs; the same kernel with one workgroup per CU (4096 chains):
         t_full = time_transition(4096)
         ach_full = 4096 * L * 2 * F_FWD / t_full / 1e12
         roof["full_chip"] = {"chains": 4096, "ms_per_launch": t_full * 1e3, "achieved": ach_full,
                              "frac": ach_full / PEAK_FP32_MFMA_TFLOPS}
         hmc.set_eval_mode(False)
+
+    # ---- second roofline: the resample scan + the whole systematic resampler at N = 2^26 (HBM-bound) ----
+    roof_extra, ess_trained = None, None
+    if rank == 0:
+        roof_extra = resample_rooflines(dev)
+        ess_trained = trained_flow_ess(dev)
 
     if rank == 0:
         total = world * B_PER_GPU * args.steps
@@ -213,6 +299,8 @@ def main():
             "ess_ais": info["ess_ais"], "ess_gathered": ess_all, "log_Z": info["log_Z"],
             "p_accept_first": info.get("dist0_p_accept_0"),
             "roofline": roof,
+            "roofline_resample": roof_extra,
+            "ess_trained": ess_trained,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(flow_state)

@@ -92,7 +92,7 @@ SYMBOLS = [
     "fabhip_flow_pack_density", "fabhip_abi_sizes", "fabhip_flow_tape_layout",
     "fabhip_generic_workspace_bytes", "fabhip_hmc_generic_begin", "fabhip_hmc_generic_leap_pre",
     "fabhip_hmc_generic_leap_post", "fabhip_hmc_generic_accept", "fabhip_anneal_log_prob", "fabhip_log_w_update",
-    "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept",
+    "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept", "fabhip_fixed_cdf",
 ]
 ABI_VERSION = 200          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
@@ -131,6 +131,7 @@ def _declare(lib):
     lib.fabhip_resample_workspace_bytes.argtypes = [i64]
     lib.fabhip_resample_multinomial.argtypes = [vp, i64, vp, i64, vp, vp, sz, vp]
     lib.fabhip_resample_systematic.argtypes = [vp, i64, dbl, i64, vp, vp, sz, vp]
+    lib.fabhip_fixed_cdf.argtypes = [vp, i64, i32, vp, vp, sz, vp]
     lib.fabhip_gather_rows.argtypes = [vp, vp, vp, i64, i64, vp]
     lib.fabhip_debug_timeline.argtypes = [vp, i32]
     lib.fabhip_flow_grad_floats.restype = i64

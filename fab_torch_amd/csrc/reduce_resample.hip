@@ -559,6 +559,27 @@ __global__ void k_sample_multinomial(ScanWs ws, long n, long ntiles, const doubl
     }
 }
 
+// stratum map of the systematic resampler (see the fused path below and oracle/numerical.py:systematic_strata)
+struct Strata {            // t_k = (k * S + U) >> F
+    unsigned long long total, S, U;
+    int F;
+};
+
+__device__ __forceinline__ Strata make_strata(unsigned long long total, double u0, long ns) {
+    Strata m;
+    m.total = total;
+    m.F = total ? __clzll((long long)total) - 2 : 0;           // 62 - bit_length(total)
+    m.S = total ? (total << m.F) / (unsigned long long)ns : 0ull;
+    unsigned long long U = (unsigned long long)floor(u0 * (double)m.S);
+    m.U = (m.S && U > m.S - 1ull) ? m.S - 1ull : U;
+    return m;
+}
+__device__ __forceinline__ Strata load_strata(const unsigned long long* p) {
+    Strata m;
+    m.total = p[0]; m.S = p[1]; m.U = p[2]; m.F = (int)p[3];
+    return m;
+}
+
 // Systematic thresholds are sorted, so a chunk of 4096 consecutive samples lands in a short run of CDF
 // tiles: stage each tile (32 KiB) in LDS and binary-search there -> indices are written coalesced and the
 // work is balanced in SAMPLES whatever the weight distribution (a tile-driven variant was 1.75x slower on
@@ -566,32 +587,24 @@ __global__ void k_sample_multinomial(ScanWs ws, long n, long ntiles, const doubl
 // the total number of staged tiles is bounded by ntiles + nchunks.
 constexpr int SYS_CHUNK = 4096, SYS_PER_THREAD = SYS_CHUNK / 256, SYS_MAX_SPAN = 8;
 
-__global__ __launch_bounds__(256) void k_sample_systematic(ScanWs ws, long n, long ntiles, double u0, long ns,
+__global__ __launch_bounds__(256) void k_sample_systematic(ScanWs ws, long n, long ntiles,
+                                                           const unsigned long long* __restrict__ strata_ptr, long ns,
                                                            long long* __restrict__ idx) {
     __shared__ unsigned long long cdf_sh[SCAN_TILE];
     __shared__ long span_sh[2];
     const int tid = threadIdx.x;
-    const unsigned long long total = ws.tile_inc[ntiles - 1];
-    const double step = (double)total / (double)ns;
+    const Strata sm = load_strata(strata_ptr);
+    const unsigned long long total = sm.total;
     const long k0 = (long)blockIdx.x * SYS_CHUNK;
     unsigned long long t[SYS_PER_THREAD];
 #pragma unroll
     for (int m = 0; m < SYS_PER_THREAD; ++m) {
         const long k = k0 + tid + 256 * m;
-        unsigned long long v = 0ull;
-        if (total > 0ull && k < ns) {
-            v = (unsigned long long)floor(((double)k + u0) * step);
-            if (v > total - 1ull) v = total - 1ull;
-        }
-        t[m] = v;
+        t[m] = (total > 0ull && k < ns) ? ((unsigned long long)k * sm.S + sm.U) >> sm.F : 0ull;
     }
     if (tid == 0) {                 // first / last tile touched by this chunk (thresholds are monotone in k)
         const long kl = (k0 + SYS_CHUNK <= ns ? k0 + SYS_CHUNK : ns) - 1;
-        unsigned long long tl = 0ull;
-        if (total > 0ull) {
-            tl = (unsigned long long)floor(((double)kl + u0) * step);
-            if (tl > total - 1ull) tl = total - 1ull;
-        }
+        const unsigned long long tl = total > 0ull ? ((unsigned long long)kl * sm.S + sm.U) >> sm.F : 0ull;
         long lo = 0, hi = ntiles;
         while (lo < hi) { const long mid = (lo + hi) >> 1; if (ws.tile_inc[mid] > t[0]) hi = mid; else lo = mid + 1; }
         span_sh[0] = lo < ntiles ? lo : ntiles - 1;
@@ -636,6 +649,313 @@ __global__ __launch_bounds__(256) void k_sample_systematic(ScanWs ws, long n, lo
             }
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Systematic resampling.  Stratum map (oracle/numerical.py:systematic_strata restates it): pure 64-bit integers
+//     F = 62 - bit_length(total),  S = floor(total 2^F / ns),  U = min(floor(u0 S), S - 1),   t_k = (k S + U) >> F
+// i.e. ns equal strata of width S / 2^F offset by u0 strata.  Its inverse, "the first stratum whose threshold
+// reaches C", is K(C) = ceil(((C << F) - U) / S), evaluated as a float64 estimate + ONE exact integer correction step.
+//
+// Fused path (no CDF in HBM, no per-stratum search):
+//   pass T  k_emit_wave_sums : fixed-point weight sum of every 1024-weight wave tile + of every 8192-weight block
+//           k_emit_prefix    : exclusive prefix over the block sums (one workgroup), total, (F, S, U)      (reads 4N)
+//   pass E  k_emit_systematic: every wave re-derives the CDF of its 1024 weights in registers (coalesced loads, LDS
+//           transpose so that a lane owns 16 consecutive weights, serial sums + one 6-step wave scan).  Weight j owns the
+//           CONTIGUOUS strata [K(C_{j-1}), K(C_j)): the resampled index array is an EXPANSION - weight j repeated
+//           K(C_j) - K(C_{j-1}) times.  Every weight with a non-empty run drops ONE marker (its id) at the first
+//           position of its run in a 2048-entry LDS window; an inclusive max-scan (ids grow with position) fills the
+//           runs - no data-dependent loop, no divergence, a heavy weight costs nothing extra - and the window is
+//           flushed with coalesced 32-byte-per-lane stores.  Runs >= 32768 strata (all the mass on a few particles)
+//           are published and filled by a grid-wide kernel instead of one wave.                 (reads 4N, writes 8 ns)
+// Integer prefix sums and an exact inverse => bit-identical to the scan + search path and to the oracle.
+// HBM traffic 12N + 8 ns bytes instead of 4N + 12N + 16 ns.
+// ------------------------------------------------------------------------------------------------
+constexpr int EM_NW = 8;                                // waves per workgroup
+constexpr int EM_WAVE_ITEMS = 1024;                     // weights per wave: 16 consecutive per lane
+constexpr int EM_BLOCK = EM_WAVE_ITEMS * EM_NW;
+constexpr int EM_FSTRIDE = 20;                          // floats per lane row of the input staging (16 + 4 pad)
+constexpr int EM_WIN = 2048;                            // int32 marker window (entries) per wave: 32 per lane row
+constexpr int EM_WSTRIDE = 36;                          // dwords per lane row of the window (32 + 4 pad: conflict-free b128)
+constexpr int EM_WAVE_LDS = 64 * EM_WSTRIDE * 4;        // bytes per wave (>= 64 * EM_FSTRIDE * 4)
+__device__ __forceinline__ int em_waddr(int e) { return (e >> 5) * EM_WSTRIDE + (e & 31); }
+constexpr int EM_GIANT = 32768;                         // runs at least this long are filled by a grid-wide kernel
+
+__global__ __launch_bounds__(64 * EM_NW) void k_emit_wave_sums(const float* __restrict__ lw, long n,
+                                                               const float* __restrict__ max_val,
+                                                               unsigned long long* __restrict__ wave_sum,
+                                                               unsigned long long* __restrict__ block_sum) {
+    __shared__ unsigned long long wsum[EM_NW];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wt = (long)blockIdx.x * EM_NW + wave;
+    const long wbase = wt * EM_WAVE_ITEMS;
+    const float mx = max_val[0];
+    unsigned long long acc = 0ull;
+    if (wbase + EM_WAVE_ITEMS <= n && (((size_t)lw & 15) == 0)) {
+        float4 x[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x[h] = *reinterpret_cast<const float4*>(lw + wbase + h * 256 + lane * 4);
+#pragma unroll
+        for (int h = 0; h < 4; ++h)
+            acc += fixed_weight(x[h].x, mx) + fixed_weight(x[h].y, mx) + fixed_weight(x[h].z, mx) + fixed_weight(x[h].w, mx);
+    } else {
+        for (int i = lane; i < EM_WAVE_ITEMS; i += 64)
+            if (wbase + i < n) acc += fixed_weight(lw[wbase + i], mx);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += shfl_u64(acc, lane ^ off);
+    if (lane == 0) { wsum[wave] = acc; if (wbase < n) wave_sum[wt] = acc; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long b = 0ull;
+        for (int w = 0; w < EM_NW; ++w) b += wsum[w];
+        block_sum[blockIdx.x] = b;
+    }
+}
+
+// exclusive prefix over the block sums (nb = ceil(N / 8192)): one 1024-thread workgroup, a contiguous chunk per thread;
+// also the stratum map {total, S, U, F} and the reset of the giant-run counter
+__global__ __launch_bounds__(1024) void k_emit_prefix(const unsigned long long* __restrict__ block_sum, long nb,
+                                                      unsigned long long* __restrict__ block_excl, double u0, long ns,
+                                                      unsigned long long* __restrict__ strata_out,
+                                                      unsigned long long* __restrict__ giant_count) {
+    __shared__ unsigned long long part[1024];
+    const int tid = threadIdx.x;
+    if (tid == 0) *giant_count = 0ull;
+    const long chunk = (nb + 1023) / 1024;
+    const long a = (long)tid * chunk, b = a + chunk < nb ? a + chunk : nb;
+    unsigned long long s = 0ull;
+    for (long i = a; i < b; ++i) s += block_sum[i];
+    part[tid] = s;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {               // Hillis-Steele inclusive scan of the chunk sums
+        const unsigned long long v = tid >= off ? part[tid - off] : 0ull;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    unsigned long long run = tid ? part[tid - 1] : 0ull;
+    for (long i = a; i < b; ++i) { block_excl[i] = run; run += block_sum[i]; }
+    if (tid == 1023) {
+        const Strata m = make_strata(part[1023], u0, ns);
+        strata_out[0] = m.total; strata_out[1] = m.S; strata_out[2] = m.U; strata_out[3] = (unsigned long long)m.F;
+    }
+}
+
+// stratum map for the scan + search path (total = last tile prefix)
+__global__ void k_strata_params(const unsigned long long* __restrict__ total_ptr, double u0, long ns,
+                                unsigned long long* __restrict__ strata_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const Strata m = make_strata(*total_ptr, u0, ns);
+    strata_out[0] = m.total; strata_out[1] = m.S; strata_out[2] = m.U; strata_out[3] = (unsigned long long)m.F;
+}
+
+// K(C) - Kref for a CDF value C = c0 + d (d < 2^47), as int32: float64 estimate of ceil(((C << F) - U) / S) with
+// num0 = (double)((c0 << F) - U) (signed) supplied by the caller, then one exact integer correction step
+// (estimate error << 1 stratum: the conversions lose < 2^-26 of a stratum, the reciprocal 2^-27).
+__device__ __forceinline__ int stratum_rel(const Strata& m, unsigned long long c0, unsigned long long d, double num0,
+                                           double pow2F, double invS, long Kref, long ns) {
+    const unsigned long long C = c0 + d;
+    if (C >= m.total) return (int)(ns - Kref);
+    const double y = ((double)d * pow2F + num0) * invS;
+    long k = (long)(int)ceil(y);
+    if (k < 0) k = 0;
+    if (k > ns) k = ns;
+    const unsigned long long B = C << m.F;
+    const unsigned long long v = (unsigned long long)k * m.S + m.U;          // (t_k << F) + fractional bits
+    if (v < B) { if (k < ns) ++k; }                                           // t_k < C: the next stratum is the first
+    else if (k > 0 && v - m.S >= B) --k;                                      // t_{k-1} >= C already
+    return (int)(k - Kref);
+}
+
+__global__ __launch_bounds__(64 * EM_NW) void k_emit_systematic(const float* __restrict__ lw, long n,
+                                                                const float* __restrict__ max_val,
+                                                                const unsigned long long* __restrict__ wave_sum,
+                                                                const unsigned long long* __restrict__ block_excl,
+                                                                const unsigned long long* __restrict__ strata_ptr,
+                                                                long ns, long long* __restrict__ idx,
+                                                                unsigned long long* __restrict__ giant_count,
+                                                                long long* __restrict__ giant_desc, long giant_cap) {
+    __shared__ __attribute__((aligned(16))) unsigned char em_lds[EM_NW * EM_WAVE_LDS];
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long wt = (long)blockIdx.x * EM_NW + wave;
+    const long wbase = wt * EM_WAVE_ITEMS;
+    if (wbase >= n) return;
+    const Strata m = load_strata(strata_ptr);
+    if (m.total == 0ull) {                                 // all weights zero: every stratum maps to the last index
+        if (wt == 0)
+            for (long k = lane; k < ns; k += 64) idx[k] = n - 1;
+        return;
+    }
+    float* wf = reinterpret_cast<float*>(em_lds + (size_t)wave * EM_WAVE_LDS);
+    int* win = reinterpret_cast<int*>(wf);
+    const float mx = max_val[0];
+    unsigned long long c_start = block_excl[blockIdx.x];
+    for (int w = 0; w < wave; ++w) c_start += wave_sum[(long)blockIdx.x * EM_NW + w];
+    // ---- CDF of this wave's 1024 weights: lane owns items [16 lane, 16 lane + 16) ----
+    if (wbase + EM_WAVE_ITEMS <= n && (((size_t)lw & 15) == 0)) {
+        float4 x[4];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) x[h] = *reinterpret_cast<const float4*>(lw + wbase + h * 256 + lane * 4);
+#pragma unroll
+        for (int h = 0; h < 4; ++h)                      // item 256 h + 4 lane -> row 16 h + lane / 4, column 4 (lane % 4)
+            *reinterpret_cast<float4*>(wf + (16 * h + (lane >> 2)) * EM_FSTRIDE + 4 * (lane & 3)) = x[h];
+    } else {
+        for (int i = lane; i < EM_WAVE_ITEMS; i += 64)
+            wf[(i >> 4) * EM_FSTRIDE + (i & 15)] = (wbase + i < n) ? lw[wbase + i] : -INFINITY;
+    }
+    __builtin_amdgcn_wave_barrier();
+    unsigned long long run[16];
+    unsigned long long acc = 0ull;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float4 y = *reinterpret_cast<const float4*>(wf + lane * EM_FSTRIDE + 4 * k);
+        acc += fixed_weight(y.x, mx); run[4 * k + 0] = acc;
+        acc += fixed_weight(y.y, mx); run[4 * k + 1] = acc;
+        acc += fixed_weight(y.z, mx); run[4 * k + 2] = acc;
+        acc += fixed_weight(y.w, mx); run[4 * k + 3] = acc;
+    }
+    unsigned long long incl = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = shfl_up_u64(incl, off);
+        if (lane >= off) incl += o;
+    }
+    const unsigned long long wtot = shfl_u64(incl, 63);
+    if (wtot == 0ull) return;                              // no stratum lands in a zero-weight tile
+    const unsigned long long lane_off = incl - acc;        // CDF offset of this lane's first item inside the wave
+    // ---- stratum ranges relative to K0 = K(c_start): item j owns [ke[j-1], ke[j]) (ke[-1] = previous lane's ke[15]) ----
+    const double pow2F = (double)(1ull << m.F), invS = 1.0 / (double)m.S;
+    const unsigned long long B0 = c_start << m.F;
+    const double num0 = B0 >= m.U ? (double)(B0 - m.U) : -(double)(m.U - B0);
+    const long K0 = (long)stratum_rel(m, c_start, 0ull, num0, pow2F, invS, 0, ns) ;   // wave-uniform (Kref = 0: < 2^31)
+    int ke[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j)
+        ke[j] = (j > 0 && run[j] == run[j - 1]) ? ke[j - 1]
+                                                : stratum_rel(m, c_start, lane_off + run[j], num0, pow2F, invS, K0, ns);
+    int kprev = __shfl_up(ke[15], 1);
+    if (lane == 0) kprev = 0;
+    const int T = __shfl(ke[15], 63);                      // strata owned by this wave: K0 .. K0 + T
+    if (T <= 0) return;
+    __builtin_amdgcn_wave_barrier();                       // every lane is done reading the float staging
+    const long item0 = wbase;
+    // giant runs: publish, the grid-wide fill kernel writes them; this wave skips windows entirely inside one
+    unsigned gmask = 0u;                                   // bit j: item j of this lane is a PUBLISHED giant run
+    if (T >= EM_GIANT) {                                   // wave-uniform
+        int sg = kprev;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (ke[j] - sg >= EM_GIANT) {
+                const unsigned long long slot = atomicAdd(giant_count, 1ull);
+                if ((long)slot < giant_cap) {              // (list full: the run stays with this wave)
+                    long id = item0 + 16 * lane + j;
+                    giant_desc[3 * slot] = K0 + sg; giant_desc[3 * slot + 1] = K0 + ke[j];
+                    giant_desc[3 * slot + 2] = id < n ? id : n - 1;
+                    gmask |= 1u << j;
+                }
+            }
+            sg = ke[j];
+        }
+    }
+    const bool wave_has_giant = __ballot(gmask != 0u) != 0ull;
+    for (int w0 = 0; w0 < T; w0 += EM_WIN) {
+        const int wlen = T - w0 < EM_WIN ? T - w0 : EM_WIN;
+        const int whi = w0 + wlen;
+        if (wave_has_giant) {                              // a window entirely inside ONE published giant run: skip
+            bool cover = false;
+            int sg = kprev;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) { if (((gmask >> j) & 1u) && sg <= w0 && ke[j] >= whi) cover = true; sg = ke[j]; }
+            if (__ballot(cover) != 0ull) continue;
+        }
+        // (a) clear the window, (b) every non-empty run drops its id + 1 at max(run start, window start)
+#pragma unroll
+        for (int i = 0; i < 64 * EM_WSTRIDE / 256; ++i)
+            *reinterpret_cast<int4*>(win + 4 * lane + 256 * i) = make_int4(0, 0, 0, 0);
+        __builtin_amdgcn_wave_barrier();
+        {
+            int sg = kprev;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int e = ke[j];
+                const int pos = sg > w0 ? sg : w0;
+                if (e > pos && pos < whi) win[em_waddr(pos - w0)] = 16 * lane + j + 1;
+                sg = e;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (c) inclusive max-scan: lane owns entries [32 lane, 32 lane + 32)
+        int v[32];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int4 q = *reinterpret_cast<const int4*>(win + EM_WSTRIDE * lane + 4 * i);
+            v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
+        }
+#pragma unroll
+        for (int i = 1; i < 32; ++i) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
+        int mx_in = v[31];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(mx_in, off);
+            if (lane >= off) mx_in = mx_in > o ? mx_in : o;
+        }
+        int carry = __shfl_up(mx_in, 1);
+        if (lane == 0) carry = 0;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            int4 q;
+            q.x = (v[4 * i] > carry ? v[4 * i] : carry) - 1;
+            q.y = (v[4 * i + 1] > carry ? v[4 * i + 1] : carry) - 1;
+            q.z = (v[4 * i + 2] > carry ? v[4 * i + 2] : carry) - 1;
+            q.w = (v[4 * i + 3] > carry ? v[4 * i + 3] : carry) - 1;
+            *reinterpret_cast<int4*>(win + EM_WSTRIDE * lane + 4 * i) = q;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // (d) flush: 4 entries per lane per step -> two 16-byte stores
+        const long obase = K0 + w0;
+        for (int p = 4 * lane; p < wlen; p += 256) {
+            const int4 q = *reinterpret_cast<const int4*>(win + em_waddr(p));
+            long r0 = item0 + q.x, r1 = item0 + q.y, r2 = item0 + q.z, r3 = item0 + q.w;
+            if (r3 >= n) { r0 = r0 < n ? r0 : n - 1; r1 = r1 < n ? r1 : n - 1; r2 = r2 < n ? r2 : n - 1; r3 = n - 1; }
+            if (p + 4 <= wlen) {
+                i64x2* o = reinterpret_cast<i64x2*>(idx + obase + p);
+                o[0] = (i64x2){r0, r1};
+                o[1] = (i64x2){r2, r3};
+            } else {
+                idx[obase + p] = r0;
+                if (p + 1 < wlen) idx[obase + p + 1] = r1;
+                if (p + 2 < wlen) idx[obase + p + 2] = r2;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// constant fill of the published giant runs: workgroup b takes 16384-entry chunks (run r, chunk c) round-robin
+__global__ __launch_bounds__(256) void k_emit_fill_runs(const unsigned long long* __restrict__ giant_count,
+                                                        const long long* __restrict__ giant_desc, long giant_cap,
+                                                        long long* __restrict__ idx) {
+    typedef long long i64x2 __attribute__((ext_vector_type(2)));
+    long cnt = (long)*giant_count;
+    if (cnt > giant_cap) cnt = giant_cap;
+    constexpr long CH = 16384;
+    unsigned work = 0;
+    for (long r = 0; r < cnt; ++r) {
+        const long a = giant_desc[3 * r], b = giant_desc[3 * r + 1], id = giant_desc[3 * r + 2];
+        const long nch = (b - a + CH - 1) / CH;
+        for (long c = 0; c < nch; ++c, ++work) {
+            if (work % gridDim.x != blockIdx.x) continue;
+            const long lo = a + c * CH, hi = lo + CH < b ? lo + CH : b;
+            long p = lo + 2 * threadIdx.x;
+            if ((lo & 1) && threadIdx.x == 0) idx[lo] = id;           // align the 16-byte stores
+            p += (lo & 1);
+            for (; p + 1 < hi; p += 512) *reinterpret_cast<i64x2*>(idx + p) = (i64x2){id, id};
+            if (p < hi) idx[p] = id;
+        }
     }
 }
 
@@ -703,10 +1023,12 @@ static ScanWs carve_scan_ws(void* workspace, long n) {
     return ws;
 }
 
-static int build_fixed_cdf(const float* log_w, long n, const ScanWs& ws, hipStream_t st) {
+static int build_fixed_cdf(const float* log_w, long n, const ScanWs& ws, hipStream_t st, bool reuse_max = false) {
     const int mb = grid_for(n, 256 * 16, 1024);
-    hipLaunchKernelGGL(k_max_partial, dim3(mb), dim3(256), 0, st, log_w, n, ws.max_part);
-    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, ws.max_part, mb, ws.max_val);
+    if (!reuse_max) {
+        hipLaunchKernelGGL(k_max_partial, dim3(mb), dim3(256), 0, st, log_w, n, ws.max_part);
+        hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, ws.max_part, mb, ws.max_val);
+    }
     // zero descriptors + ticket (one contiguous region: desc .. ticket)
     const size_t zbytes = (size_t)((char*)ws.ticket - (char*)ws.desc) + 256;
     if (hipMemsetAsync(ws.desc, 0, zbytes, st) != hipSuccess) return FABHIP_ELAUNCH;
@@ -801,6 +1123,16 @@ size_t fabhip_resample_workspace_bytes(int64_t n) {
     return al256(1024 * 4) + 256 + al256(tiles * 8) + 256 + al256(tiles * 8) + al256((size_t)n * 8) + 256;
 }
 
+int fabhip_fixed_cdf(const float* log_w, int64_t n, int32_t reuse_max, const uint64_t** cdf_out, void* workspace,
+                     size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!log_w || !workspace || n < 1) return FABHIP_EINVAL;
+    if (((size_t)workspace & 255) != 0) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_resample_workspace_bytes(n)) return FABHIP_ENOSPC;
+    const ScanWs ws = carve_scan_ws(workspace, n);
+    if (cdf_out) *cdf_out = (const uint64_t*)ws.cdf;
+    return build_fixed_cdf(log_w, n, ws, (hipStream_t)stream, reuse_max != 0);
+}
+
 int fabhip_resample_multinomial(const float* log_w, int64_t n, const double* u, int64_t n_samples, int64_t* idx,
                                 void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
     if (!log_w || !u || !idx || !workspace || n < 1 || n_samples < 0) return FABHIP_EINVAL;
@@ -822,10 +1154,43 @@ int fabhip_resample_systematic(const float* log_w, int64_t n, double u0, int64_t
     if (workspace_bytes < fabhip_resample_workspace_bytes(n)) return FABHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     const ScanWs ws = carve_scan_ws(workspace, n);
-    FAB_TRY(build_fixed_cdf(log_w, n, ws, st));
-    if (n_samples > 0)
-        hipLaunchKernelGGL(k_sample_systematic, dim3((unsigned)((n_samples + SYS_CHUNK - 1) / SYS_CHUNK)), dim3(256), 0, st, ws, (long)n,
-                           scan_tiles(n), u0, (long)n_samples, (long long*)idx);
+    if (n_samples == 0) return FABHIP_OK;
+    const long nwt = ((long)n + EM_WAVE_ITEMS - 1) / EM_WAVE_ITEMS;
+    const long nbk = ((long)n + EM_BLOCK - 1) / EM_BLOCK;
+    const char* var = getenv("FABHIP_SYSTEMATIC_VARIANT");      // 0 = scan + CDF in HBM + search (A/B reference)
+    if ((var && atoi(var) == 0) || n_samples >= (1ll << 31) - 2) {
+        FAB_TRY(build_fixed_cdf(log_w, n, ws, st));
+        unsigned long long* strata = ws.desc;                    // the descriptors are dead once the scan is done
+        hipLaunchKernelGGL(k_strata_params, dim3(1), dim3(1), 0, st, ws.tile_inc + (scan_tiles(n) - 1), u0,
+                           (long)n_samples, strata);
+        hipLaunchKernelGGL(k_sample_systematic, dim3((unsigned)((n_samples + SYS_CHUNK - 1) / SYS_CHUNK)), dim3(256), 0,
+                           st, ws, (long)n, scan_tiles(n), strata, (long)n_samples, (long long*)idx);
+        return check_launch();
+    }
+    // fused path: max -> wave-tile sums -> block prefix + stratum map -> emit (no CDF in HBM); scratch lives in the
+    // (8 n)-byte `cdf` region of the workspace
+    const int mb = grid_for(n, 256 * 16, 1024);
+    hipLaunchKernelGGL(k_max_partial, dim3(mb), dim3(256), 0, st, log_w, (long)n, ws.max_part);
+    hipLaunchKernelGGL(k_max_final, dim3(1), dim3(256), 0, st, ws.max_part, mb, ws.max_val);
+    unsigned long long* wave_sum = ws.cdf;
+    unsigned long long* block_sum = ws.cdf + nwt;
+    unsigned long long* block_excl = block_sum + nbk;
+    unsigned long long* strata = block_excl + nbk;               // {total, S, U, F}
+    unsigned long long* giant_count = strata + 4;
+    long long* giant_desc = (long long*)(giant_count + 1);
+    // capacity: what is left of the CDF region; at most n_samples / EM_GIANT runs can be giant
+    long giant_cap = ((long)n - (nwt + 2 * nbk + 5)) / 3;
+    if (giant_cap < 0) giant_cap = 0;
+    if (giant_cap > n_samples / EM_GIANT + 1) giant_cap = n_samples / EM_GIANT + 1;
+    const dim3 grid((unsigned)nbk), block(64 * EM_NW);
+    hipLaunchKernelGGL(k_emit_wave_sums, grid, block, 0, st, log_w, (long)n, ws.max_val, wave_sum, block_sum);
+    hipLaunchKernelGGL(k_emit_prefix, dim3(1), dim3(1024), 0, st, block_sum, nbk, block_excl, u0, (long)n_samples, strata,
+                       giant_count);
+    hipLaunchKernelGGL(k_emit_systematic, grid, block, 0, st, log_w, (long)n, ws.max_val, wave_sum, block_excl, strata,
+                       (long)n_samples, (long long*)idx, giant_count, giant_desc, giant_cap);
+    if (giant_cap > 0 && n_samples >= EM_GIANT)
+        hipLaunchKernelGGL(k_emit_fill_runs, dim3(256), dim3(256), 0, st, giant_count, giant_desc, giant_cap,
+                           (long long*)idx);
     return check_launch();
 }
 

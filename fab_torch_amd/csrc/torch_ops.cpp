@@ -503,6 +503,17 @@ Tensor resample_multinomial(const Tensor& log_w, const Tensor& u) {
     return idx;
 }
 
+// scan pass alone (after a first full call): returns the workspace so that a caller can time repeated scans
+Tensor fixed_cdf(const Tensor& log_w, optional<Tensor> workspace) {
+    c10::DeviceGuard g(log_w.device());
+    const int64_t n = log_w.numel();
+    const size_t nb = fabhip_resample_workspace_bytes(n);
+    Tensor ws = workspace.has_value() ? *workspace : scratch(nb, log_w);
+    chk(fabhip_fixed_cdf(fp(log_w, "log_w"), n, workspace.has_value() ? 1 : 0, nullptr, aligned(ws), nb, stream_of(log_w)),
+        "fixed_cdf");
+    return ws;
+}
+
 Tensor resample_systematic(const Tensor& log_w, double u0, int64_t n_samples) {
     c10::DeviceGuard g(log_w.device());
     const int64_t n = log_w.numel();
@@ -614,6 +625,7 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(d!) scale, float target_p_accept, bool tune) -> ()");
 
     m.def("ess_logz(Tensor log_w, Tensor? n_ptr, float n_norm) -> Tensor");
+    m.def("fixed_cdf(Tensor log_w, Tensor(a!)? workspace) -> Tensor(a!)");
     m.def("resample_multinomial(Tensor log_w, Tensor u) -> Tensor");
     m.def("resample_systematic(Tensor log_w, float u0, int n_samples) -> Tensor");
     m.def("multinomial_torch(Tensor probs, Tensor u) -> Tensor");
@@ -645,6 +657,7 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("metropolis_generic_propose", metropolis_generic_propose);
     m.impl("metropolis_generic_accept", metropolis_generic_accept);
     m.impl("ess_logz", ess_logz);
+    m.impl("fixed_cdf", fixed_cdf);
     m.impl("resample_multinomial", resample_multinomial);
     m.impl("resample_systematic", resample_systematic);
     m.impl("multinomial_torch", multinomial_torch);

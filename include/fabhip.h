@@ -344,11 +344,19 @@ int fabhip_multinomial_torch(const float* probs, int64_t n, const double* u, int
                              int64_t* idx, void* workspace, size_t workspace_bytes,
                              fabhip_stream_t stream);
 
-/* Scalable fixed-point CDF resamplers from log-weights (any n): p_i = fl32(exp(w_i - max w)) via
- * float64, q_i = floor(p_i 2^36), C = inclusive integer prefix sum (decoupled look-back scan).
- *   multinomial: idx_k = first j with C_j > floor(u_k * C_total)
- *   systematic : idx_k = first j with C_j > floor((k + u0) * (C_total / n_samples))            */
+/* Scalable fixed-point CDF resamplers from log-weights (any n): p_i = exp_spec(w_i - max w) (a specified fp32
+ * exponential, oracle/numerical.py), q_i = floor(p_i 2^36), C = inclusive integer prefix sum.
+ *   multinomial: idx_k = first j with C_j > floor(u_k * C_total)                (decoupled look-back scan + search)
+ *   systematic : idx_k = first j with C_j > floor((k + u0) * (C_total / n_samples))
+ *                fused: wave-tile sums -> tile prefix -> every tile emits the strata that fall inside its CDF range;
+ *                the CDF never touches HBM (12n + 8 n_samples bytes of traffic).                              */
 size_t fabhip_resample_workspace_bytes(int64_t n);
+/* The fixed-point inclusive CDF C[0..n) (uint64) of log-weights, built in the workspace by ONE decoupled-look-back scan
+ * pass (4n bytes read, 8n written) after a max pass (4n read); *cdf_out (host pointer-to-device-pointer, may be
+ * NULL) receives its device address inside the workspace.  reuse_max != 0 skips the max pass and uses the maximum a
+ * previous call on the same log_w left in this workspace (measurement of the scan pass alone). */
+int fabhip_fixed_cdf(const float* log_w, int64_t n, int32_t reuse_max, const uint64_t** cdf_out, void* workspace,
+                     size_t workspace_bytes, fabhip_stream_t stream);
 int fabhip_resample_multinomial(const float* log_w, int64_t n, const double* u, int64_t n_samples,
                                 int64_t* idx, void* workspace, size_t workspace_bytes,
                                 fabhip_stream_t stream);

@@ -103,13 +103,28 @@ def multinomial_fixed(log_w: np.ndarray, u: np.ndarray) -> np.ndarray:
     return np.searchsorted(C, _thresholds_multinomial(u, total), side="right").astype(np.int64)
 
 
+def systematic_strata(total: int, n_out: int, u0: float):
+    """Integer stratum map of the systematic resampler: t_k = (k * S + U) >> F with
+        F = 62 - bit_length(total)            (total * 2^F in [2^61, 2^62): 64-bit arithmetic never overflows)
+        S = floor(total * 2^F / n_out)         (stratum width in units of 2^-F)
+        U = min(floor(u0 * float(S)), S - 1)   (the single uniform draw, u0 in [0, 1))
+    i.e. n_out equal strata of width S / 2^F = total / n_out (up to a relative 2^-36 truncation, the same order as
+    the 2^-36 quantisation of the weights themselves) offset by u0 strata.  Pure integer arithmetic per stratum:
+    the device evaluates it - and its inverse - exactly."""
+    assert total > 0 and n_out > 0 and 0.0 <= u0 < 1.0
+    F = 62 - int(total).bit_length()
+    S = (int(total) << F) // int(n_out)
+    U = min(int(np.floor(np.float64(u0) * np.float64(S))), S - 1)
+    return F, S, U
+
+
 def systematic_fixed(log_w: np.ndarray, u0: float, n_out: int = None) -> np.ndarray:
-    """Systematic resampling on the fixed-point CDF: t_k = floor((k + u0) * (total / n_out))."""
+    """Systematic resampling on the fixed-point CDF: idx_k = first j with C[j] > t_k, t_k = (k S + U) >> F."""
     C = fixed_point_cdf(log_w)
     total = int(C[-1])
     assert total > 0
     n_out = len(C) if n_out is None else n_out
-    step = np.float64(total) / np.float64(n_out)
-    t = np.floor((np.arange(n_out, dtype=np.float64) + np.float64(u0)) * step).astype(np.uint64)
-    t = np.minimum(t, np.uint64(total - 1))
+    F, S, U = systematic_strata(total, n_out, u0)
+    k = np.arange(n_out, dtype=np.uint64)
+    t = (k * np.uint64(S) + np.uint64(U)) >> np.uint64(F)
     return np.searchsorted(C, t, side="right").astype(np.int64)

@@ -496,8 +496,76 @@ def g12_trainer_traces():
         npz(f"g12_trainer_seed{seed}.npz", **out)
 
 
+def g13_trained_flow():
+    """SURVEY 8(d) "meaningful ESS" fixture: a SMALL trained flow (ManyWell-6, RealNVP 4 x W=30, ~4k parameters) trained
+    here with the reference's own PrioritisedBufferTrainer driving the oracle flow, its tuned HMC step sizes, and ONE
+    evaluation AIS call of the reference (1024 chains, M = 4, p^2/q target, step sizes frozen) with all noise captured:
+    ESS >> 1/B, so "ESS within 1 %" (north_star) is a real check."""
+    import torch.nn as nn
+    from fab.utils.prioritised_replay_buffer import PrioritisedReplayBuffer
+    from fab.train_with_prioritised_buffer import PrioritisedBufferTrainer
+    from fab.utils.logging import ListLogger
+    from fab import FABModel
+
+    class OracleTrainable(nn.Module):
+        def __init__(self, nf):
+            super().__init__()
+            self.nf = nf
+
+        def sample_and_log_prob(self, shape):
+            with torch.no_grad():
+                return self.nf.sample_eps(torch.randn(shape[0], self.nf.q0.shape[0]))
+
+        def sample(self, shape):
+            return self.sample_and_log_prob(shape)[0]
+
+        def log_prob(self, x):
+            return self.nf.log_prob(x)
+
+        @property
+        def event_shape(self):
+            return self.nf.q0.shape
+
+    D, K, nodes, M, L, B, alpha = 6, 4, 5, 4, 5, 128, 2.0
+    torch.manual_seed(7)
+    nf = oflow.make_realnvp(D, K, nodes)              # init_zeros: identity flow, like the reference's experiments
+    flow = OracleTrainable(nf)
+    target = ManyWellEnergy(dim=D, use_gpu=False)
+    hmc = HamiltonianMonteCarlo(n_ais_intermediate_distributions=M, dim=D, base_log_prob=flow.log_prob,
+                                target_log_prob=target.log_prob, alpha=alpha, p_target=False, epsilon=1.0, n_outer=1, L=L)
+    model = FABModel(flow=flow, target_distribution=target, n_intermediate_distributions=M, alpha=alpha,
+                     transition_operator=hmc)
+    ais = model.annealed_importance_sampler
+
+    def initial_sampler():
+        pt, lw = ais.sample_and_log_weights(B, logging=False)
+        return pt.x, lw, pt.log_q
+    buffer = PrioritisedReplayBuffer(dim=D, max_length=B * 100, min_sample_length=B * 10, initial_sampler=initial_sampler)
+    opt = torch.optim.Adam(flow.parameters(), lr=2e-3)
+    trainer = PrioritisedBufferTrainer(model=model, optimizer=opt, buffer=buffer, alpha=alpha,
+                                       n_batches_buffer_sampling=4, logger=ListLogger(), max_gradient_norm=100.0)
+    trainer.run(n_iterations=1500, batch_size=B, save=False)
+    # one evaluation call of the reference: frozen step sizes, captured noise, 1024 chains
+    hmc.set_eval_mode(True)
+    Be = 1024
+    out = dict(D=D, K=K, nodes=nodes, M=M, L=L, alpha=alpha, B=Be, epsilons=hmc.epsilons.clone(),
+               common_epsilon=hmc.common_epsilon.clone())
+    out.update({k: v.detach().clone() for k, v in flow_state(nf).items()})
+    for tag, p_target in (("g", False), ("p", True)):            # practical target p^2/q and target p
+        model.set_ais_target(min_is_target=not p_target)
+        torch.manual_seed(70 + int(p_target))
+        with Capture() as cap:
+            pt, lw = ais.sample_and_log_weights(Be)
+        info = ais.get_logging_info()
+        out.update({f"{tag}_eps0": cap.randn[0], f"{tag}_noise_p": torch.stack(cap.randn_like)[:, None],
+                    f"{tag}_noise_e": torch.stack(cap.expo)[:, None], f"{tag}_log_w": lw, f"{tag}_x": pt.x,
+                    f"{tag}_ess_ais": info["ess_ais"], f"{tag}_ess_base": info["ess_base"], f"{tag}_log_Z": info["log_Z"]})
+        print(tag, "ess_base", info["ess_base"], "ess_ais", info["ess_ais"], "log_Z", info["log_Z"], float(target.log_Z))
+    npz("g13_trained_flow_mw6.npz", **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)      # deterministic reduction order in the fixtures
     g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
     g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval(); g11_gmm_eval()
-    g12_trainer_traces()
+    g12_trainer_traces(); g13_trained_flow()

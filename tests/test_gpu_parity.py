@@ -584,3 +584,49 @@ def test_plain_trainer_fab_alpha_div_loss(optimiser, tmp_path):
     assert (tmp_path / "model_checkpoints" / "iter_12" / "optimizer.pt").exists()
     assert any(float((a - b.detach()).abs().max()) > 0 for a, b in zip(before, flow.parameters()))
     assert model.annealed_importance_sampler.p_target is False
+
+
+@pytest.mark.parametrize("case", ["heavy_tail", "one_survivor", "leading_zeros", "more_samples", "unaligned", "tiny_n"])
+def test_fused_systematic_sampler_edge_cases_bit_exact_vs_oracle(case):
+    """fabhip_resample_systematic (fused: tile sums -> prefix -> per-tile emit, no CDF in HBM) against
+    oracle/numerical.py:systematic_fixed on the shapes that stress the stratum-range inversion: one weight owning
+    most strata, a single non-zero weight, zero-weight tiles in front / at the end, n_samples != n (more and fewer
+    strata than weights), a log_w pointer that is not 16-byte aligned, n smaller than one tile."""
+    rng = np.random.default_rng(hash(case) % 2 ** 31)
+    N, ns, u0 = 70_001, None, 0.613
+    lw = (rng.standard_normal(N) * 2).astype(np.float32)
+    if case == "heavy_tail":
+        lw[12345] = 40.0; lw[66000] = 38.5
+    elif case == "one_survivor":
+        lw[:] = -np.inf; lw[43210] = 0.5
+    elif case == "leading_zeros":
+        lw[:5000] = -np.inf; lw[-9000:] = -np.inf; lw[20000:23000] = np.nan
+    elif case == "more_samples":
+        ns = 3 * N + 17
+    elif case == "tiny_n":
+        N = 37; lw = lw[:N]; ns = 1000
+    lw_d = torch.tensor(lw).to(DEV)
+    if case == "unaligned":
+        buf = torch.empty(N + 1, device=DEV); buf[1:] = lw_d; lw_d = buf[1:]
+        assert lw_d.data_ptr() % 16 != 0
+    for n_out in ([ns] if ns else [None, N // 7]):
+        got = fa.systematic_indices(lw_d, u0=u0, n_samples=n_out).cpu().numpy()
+        np.testing.assert_array_equal(got, onum.systematic_fixed(lw, u0, n_out))
+
+
+def test_fused_systematic_equals_the_scan_and_search_path_at_2_pow_26(monkeypatch):
+    """N = 2^26 (the HBM-roofline size): the fused sampler and the CDF-in-HBM reference path (FABHIP_SYSTEMATIC_VARIANT=0)
+    must give identical indices (both exact integer arithmetic); offspring counts sum to N."""
+    N = 1 << 26
+    g = torch.Generator(device=DEV).manual_seed(1)
+    lw = torch.randn(N, device=DEV, generator=g) * 3
+    a = fa.systematic_indices(lw, u0=0.123)
+    monkeypatch.setenv("FABHIP_SYSTEMATIC_VARIANT", "0")
+    b = fa.systematic_indices(lw, u0=0.123)
+    monkeypatch.delenv("FABHIP_SYSTEMATIC_VARIANT")
+    assert torch.equal(a, b)
+    assert bool((a[1:] >= a[:-1]).all()) and int(a.max()) < N
+    del b
+    counts = torch.bincount(a, minlength=N)
+    w = torch.softmax(lw.double(), 0) * N
+    assert int(counts.sum()) == N and float((counts.double() - w).abs().max()) <= 1.0 + 1e-3 * float(w.max())

@@ -344,3 +344,31 @@ def test_trainer_replays_reference_traces(seed, optimiser):
         if ("final." + k) in g and v.dtype.is_floating_point:
             ref = g["final." + k]
             assert float((v.cpu() - torch.tensor(ref)).abs().max()) <= 2e-5 + 1e-4 * float(np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize("tag,p_target", [("p", True), ("g", False)])
+def test_trained_flow_ess_matches_the_reference_within_one_percent(tag, p_target):
+    """SURVEY 8(d) / north_star "ESS within 1 % of reference" where the ESS is MEANINGFUL: the committed small trained
+    flow (g13: ManyWell-6, trained by the reference's own trainer; flow ESS 0.6, AIS ESS 0.77 towards p) and the
+    reference's evaluation AIS call on it (1024 chains, frozen step sizes, captured noise) replayed through the HIP path."""
+    g = load_golden("g13_trained_flow_mw6.npz")
+    D, M, L, B = int(g["D"]), int(g["M"]), int(g["L"]), int(g["B"])
+    nf = oracle_flow_from_golden(g)
+    hf = hip_flow_from_oracle(nf)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=p_target, epsilon=1.0, L=L,
+                                   eval_mode=True).to(DEV)
+    with torch.no_grad():
+        hmc.epsilons.copy_(torch.tensor(g["epsilons"])); hmc.common_epsilon.copy_(torch.tensor(g["common_epsilon"]))
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, p_target, 2.0, M)
+    T = lambda k: torch.tensor(g[k]).to(DEV)          # noqa: E731
+    pt, lw = ais.sample_and_log_weights(B, eps0=T(f"{tag}_eps0"), noise_a=T(f"{tag}_noise_p"), noise_b=T(f"{tag}_noise_e"))
+    info = ais.get_logging_info()
+    ref_ess, ref_lz = float(g[f"{tag}_ess_ais"]), float(g[f"{tag}_log_Z"])
+    assert ref_ess > 10.0 / B
+    assert abs(info["ess_ais"] - ref_ess) <= 0.01 * ref_ess, (info["ess_ais"], ref_ess)
+    assert abs(info["ess_base"] - float(g[f"{tag}_ess_base"])) <= 0.01 * float(g[f"{tag}_ess_base"])
+    assert abs(info["log_Z"] - ref_lz) <= 1e-3 * max(1.0, abs(ref_lz))
+    same = (pt.x.cpu() - torch.tensor(g[f"{tag}_x"])).abs().max(1).values < 1e-3
+    assert int(same.sum()) >= B - B // 50, f"{int((~same).sum())} of {B} chains left the reference trajectory"
+    assert close(lw.cpu()[same], torch.tensor(g[f"{tag}_log_w"])[same], RTOL, atol=2e-3)
