@@ -15,6 +15,7 @@ from .buffer import PrioritisedReplayBuffer, sample_without_replacement
 from .train import PrioritisedBufferTrainer, Trainer
 from .optim import FlatAdam
 from .wrappers import WrappedTorchDist
+from .spline_flow import CircularCoupledRQSFlow, make_wrapped_normflow_spline
 from .resample import resample, multinomial_indices, systematic_indices, multinomial_torch_compat, gather_rows
 
 __all__ = [
@@ -22,5 +23,5 @@ __all__ = [
     "HamiltonianMonteCarlo", "Metropolis", "create_point", "AnnealedImportanceSampler", "LoggingInfo",
     "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
     "multinomial_torch_compat", "gather_rows", "FABModel", "PrioritisedReplayBuffer",
-    "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam", "WrappedTorchDist",
+    "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam", "WrappedTorchDist", "CircularCoupledRQSFlow", "make_wrapped_normflow_spline",
 ]

@@ -93,6 +93,8 @@ SYMBOLS = [
     "fabhip_generic_workspace_bytes", "fabhip_hmc_generic_begin", "fabhip_hmc_generic_leap_pre",
     "fabhip_hmc_generic_leap_post", "fabhip_hmc_generic_accept", "fabhip_anneal_log_prob", "fabhip_log_w_update",
     "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept", "fabhip_fixed_cdf",
+    "fabhip_spline_packed_floats", "fabhip_spline_pack", "fabhip_spline_workspace_bytes", "fabhip_spline_log_prob",
+    "fabhip_spline_sample",
 ]
 ABI_VERSION = 200          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 

@@ -1,0 +1,805 @@
+// Circular / linear-tail rational-quadratic spline COUPLING flow (R9s): the flow family the reference builds for
+// alanine dipeptide - normflows `CircularCoupledRationalQuadraticSpline` x n_layers (+ PeriodicShift / PeriodicWrap,
+// UniformGaussian base), experiments/make_flow/make_aldp_model.py:57-71,121-134,146-167.  Arithmetic restated in
+// oracle/spline.py (normflows is absent from the reference tree: parity unpinned, oracle = specification).
+//
+// Structure (one C-ABI call enqueues all launches of a density / sampling pass, no host synchronisation):
+//   k_spline_net_fwd   conditioner of one coupling layer for a 16-chain tile: periodic features of the identity
+//                      coordinates -> ResidualNet (Linear, pre-activation residual block, Linear) on the fp32 matrix
+//                      cores (flow_device.h ring GEMMs, weights streamed in MFMA B-operand tiles) -> 3K+1 spline
+//                      parameters per transformed coordinate, written to HBM
+//   k_spline_apply     element-wise: spline evaluation (log_prob direction) or inversion (sampling direction) of the
+//                      transformed coordinates with the conditioner's parameters and of the identity coordinates with
+//                      the layer's unconditional parameters; log-det row sums; periodic shift / wrap of the next stage
+//   k_spline_apply_bwd reverse-mode through the same maps: d log q / d(input) and the cotangents of the 3K+1
+//                      conditioner outputs
+//   k_spline_net_bwd   recomputes the conditioner's activations for the tile and back-propagates the parameter
+//                      cotangents to the identity coordinates (transposed weight tiles on the matrix cores)
+// One wave handles one chain in the element-wise kernels (lane = coordinate, D <= 64).
+#include "flow_device.h"
+#include "launch.h"
+
+#pragma clang fp contract(off)
+
+namespace fab {
+
+constexpr int SP_K = 8;                 // bins
+constexpr int SP_NP = 3 * SP_K + 1;     // parameters per coordinate: K widths, K heights, K + 1 knot derivatives
+constexpr int SP_MD = 64;               // max dim
+constexpr int SP_META_ROWS = 12;        // per-layer metadata rows of 64 floats (see fabhip.h)
+constexpr float SP_MIN_W = 1e-3f, SP_MIN_H = 1e-3f, SP_MIN_D = 1e-3f;
+
+enum { M_IDF = 0, M_TRF = 1, M_CIRC = 2, M_TB = 3, M_PFON = 4, M_PFS = 5, M_PFK = 6, M_PRESH = 7, M_PREON = 8,
+       M_POSTSH = 9, M_POSTON = 10, M_CNT = 11 };
+
+struct SplineDims {
+    int D, L, W, Wp, NTWM, KBW;          // hidden width, padded to 64 * tiles-per-wave
+    int n_tr_max, NCH, NFP;              // chunks of Wp conditioner outputs: NFP = NCH * Wp >= n_tr_max * SP_NP
+    int o_meta, o_unc, o_pfw, o_W0, o_b0, o_Wa, o_ba, o_Wb, o_bb, o_Wf, o_bf, o_WfT, o_WbT, o_WaT, o_W0T;
+    int layer_stride, o_base, total;
+};
+
+FAB_HD SplineDims make_spline_dims(int D, int L, int W) {
+    SplineDims f;
+    f.D = D; f.L = L; f.W = W;
+    f.NTWM = ntw_variant(W); f.Wp = 64 * f.NTWM; f.KBW = f.Wp / 16;
+    f.n_tr_max = (D + 1) / 2;
+    f.NCH = ceil_div(f.n_tr_max * SP_NP, f.Wp);
+    f.NFP = f.NCH * f.Wp;
+    int o = 0;
+    f.o_meta = o; o += SP_META_ROWS * 64;
+    f.o_unc = o; o += SP_MD * SP_NP + 32;                 // [64][25] (+ pad to a multiple of 64 floats below)
+    o = (o + 63) & ~63;
+    f.o_pfw = o; o += 2 * SP_MD;                           // [64][2] periodic-feature weights
+    const int T = f.KBW * 256;                             // floats per column-tile strip of K = Wp
+    f.o_W0 = o; o += 4 * (4 * f.NTWM) * 256;              // K = 64 (identity coordinates, padded), N = Wp
+    f.o_b0 = o; o += f.Wp;
+    f.o_Wa = o; o += (4 * f.NTWM) * T;
+    f.o_ba = o; o += f.Wp;
+    f.o_Wb = o; o += (4 * f.NTWM) * T;
+    f.o_bb = o; o += f.Wp;
+    f.o_Wf = o; o += f.NCH * (4 * f.NTWM) * T;            // NCH chunks of [Wp x Wp]
+    f.o_bf = o; o += f.NFP;
+    f.o_WfT = o; o += (4 * f.NTWM) * (f.NFP / 16) * 256;  // K = NFP, N = Wp
+    f.o_WbT = o; o += (4 * f.NTWM) * T;
+    f.o_WaT = o; o += (4 * f.NTWM) * T;
+    f.o_W0T = o; o += 4 * T;                               // K = Wp, N = 64
+    f.layer_stride = o;
+    f.o_base = L * f.layer_stride;                         // scale[64], circ[64]
+    f.total = f.o_base + 128;
+    return f;
+}
+
+static inline int check_spline_shape(int D, int L, int W) {
+    if (D < 2 || L < 1 || W < 1) return FABHIP_EINVAL;
+    if (D > SP_MD || L > FABHIP_MAX_LAYERS || W > 256) return FABHIP_ENOTSUP;       // NTWM in {1, 2, 4}
+    return FABHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// packing
+// ------------------------------------------------------------------------------------------------
+struct SplineSrc {
+    const float *meta, *w0, *b0, *wa, *ba, *wb, *bb, *wf, *bf, *pfw, *uw, *uh, *ud;
+};
+
+__device__ __forceinline__ void sp_tile_kn(int off, int KB, int& k, int& n) {
+    const int tile = off >> 8, within = off & 255;
+    const int lane = within >> 2, tt = within & 3;
+    const int c = tile / KB, S = tile % KB;
+    k = 16 * S + 4 * (lane >> 4) + tt;
+    n = 16 * c + (lane & 15);
+}
+
+__global__ __launch_bounds__(256) void k_spline_pack_layer(SplineDims f, SplineSrc s, int layer, float* __restrict__ packed) {
+    float* __restrict__ dst = packed + (size_t)layer * f.layer_stride;
+    const int n_id = (int)s.meta[M_CNT * 64 + 0], n_tr = (int)s.meta[M_CNT * 64 + 1], n_pf = (int)s.meta[M_CNT * 64 + 2];
+    const int W = f.W, Wp = f.Wp, KBW = f.KBW, nout = n_tr * SP_NP;
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.layer_stride; off += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        int k, n;
+        if (off < f.o_unc) {
+            v = s.meta[off - f.o_meta];
+        } else if (off < f.o_pfw) {
+            const int e = off - f.o_unc, i = e / SP_NP, p = e % SP_NP;
+            if (i < n_id && e < SP_MD * SP_NP)
+                v = p < SP_K ? s.uw[i * SP_K + p] : (p < 2 * SP_K ? s.uh[i * SP_K + p - SP_K] : s.ud[i * (SP_K + 1) + p - 2 * SP_K]);
+        } else if (off < f.o_W0) {
+            const int e = off - f.o_pfw;
+            if (e < 2 * n_pf) v = s.pfw[e];
+        } else if (off < f.o_b0) {                 // W0: B[k][n] = w0[n][k]   (k identity position, n hidden)
+            sp_tile_kn(off - f.o_W0, 4, k, n);
+            if (k < n_id && n < W) v = s.w0[n * n_id + k];
+        } else if (off < f.o_Wa) {
+            const int j = off - f.o_b0; if (j < W) v = s.b0[j];
+        } else if (off < f.o_ba) {                 // Wa: B[k][n] = wa[n][k]
+            sp_tile_kn(off - f.o_Wa, KBW, k, n);
+            if (k < W && n < W) v = s.wa[n * W + k];
+        } else if (off < f.o_Wb) {
+            const int j = off - f.o_ba; if (j < W) v = s.ba[j];
+        } else if (off < f.o_bb) {
+            sp_tile_kn(off - f.o_Wb, KBW, k, n);
+            if (k < W && n < W) v = s.wb[n * W + k];
+        } else if (off < f.o_Wf) {
+            const int j = off - f.o_bb; if (j < W) v = s.bb[j];
+        } else if (off < f.o_bf) {                 // Wf chunk c: B[k][n] = wf[c Wp + n][k]
+            const int e = off - f.o_Wf, per = 4 * f.NTWM * KBW * 256;
+            const int c = e / per;
+            sp_tile_kn(e % per, KBW, k, n);
+            const int col = c * Wp + n;
+            if (k < W && col < nout) v = s.wf[col * W + k];
+        } else if (off < f.o_WfT) {
+            const int j = off - f.o_bf; if (j < nout) v = s.bf[j];
+        } else if (off < f.o_WbT) {                // WfT: B[k][n] = wf[k][n]   (k conditioner output, n hidden)
+            sp_tile_kn(off - f.o_WfT, f.NFP / 16, k, n);
+            if (k < nout && n < W) v = s.wf[k * W + n];
+        } else if (off < f.o_WaT) {                // WbT: B[k][n] = wb[k][n]
+            sp_tile_kn(off - f.o_WbT, KBW, k, n);
+            if (k < W && n < W) v = s.wb[k * W + n];
+        } else if (off < f.o_W0T) {
+            sp_tile_kn(off - f.o_WaT, KBW, k, n);
+            if (k < W && n < W) v = s.wa[k * W + n];
+        } else {                                    // W0T: B[k][n] = w0[k][n]   (k hidden, n identity position)
+            sp_tile_kn(off - f.o_W0T, KBW, k, n);
+            if (k < W && n < n_id) v = s.w0[k * n_id + n];
+        }
+        dst[off] = v;
+    }
+}
+
+__global__ void k_spline_pack_base(SplineDims f, const float* __restrict__ scale, const float* __restrict__ circ,
+                                   float* __restrict__ packed) {
+    const int j = threadIdx.x;
+    if (j < 64) {
+        packed[f.o_base + j] = j < f.D ? scale[j] : 1.f;
+        packed[f.o_base + 64 + j] = j < f.D ? circ[j] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conditioner (ResidualNet) on a 16-chain tile
+// ------------------------------------------------------------------------------------------------
+struct NetLds {
+    int AS, WS, PS;                       // leading dims: identity inputs (64 + 4), hidden (Wp + 4), dparams (NFP + 4)
+    int o_A0, o_H0, o_T, o_X1, o_X2, o_DP, o_PART, total;
+};
+FAB_HD NetLds make_net_lds(const SplineDims& f, bool bwd) {
+    NetLds l;
+    l.AS = 64 + 4; l.WS = f.Wp + 4; l.PS = f.NFP + 4;
+    int o = 0;
+    l.o_A0 = o; o += ROWS * l.AS;
+    l.o_H0 = o; o += ROWS * l.WS;
+    l.o_T = o; o += ROWS * l.WS;
+    l.o_X1 = o; o += ROWS * l.WS;
+    l.o_X2 = o; o += ROWS * l.WS;
+    l.o_DP = o; if (bwd) o += ROWS * l.PS;
+    l.o_PART = o; if (bwd) o += NWAVE * ROWS * l.AS;
+    l.total = (o + 3) & ~3;
+    return l;
+}
+
+// plain GEMM on the tile: acc[i] = A[16 x 16 KB] @ B[:, tile wave + 4 i] (+ bias)
+template <int NTWM, int DEPTH, bool BIAS>
+__device__ __forceinline__ void sp_gemm(const float* A, int lda, int KB, const float4* Bp, const float* bias, const Tid& t,
+                                        f32x4 (&acc)[NTWM]) {
+    WRing<NTWM, DEPTH> w;
+    if (!BIAS) {
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    ring_issue<NTWM, DEPTH, BIAS>(w, Bp, KB, bias, t);
+    ring_run<NTWM, DEPTH, false, BIAS>(w, A, lda, 0, KB, Bp, t, acc);
+}
+
+// identity coordinates of the tile with their periodic features -> A0 (columns >= n_id zero); returns nothing
+__device__ __forceinline__ void sp_load_identity(const SplineDims& f, const float* __restrict__ Lp, const float* __restrict__ Z,
+                                                 long row0, long B, float* A0, int AS, const Tid& t) {
+    const float* meta = Lp + f.o_meta;
+    const int n_id = (int)meta[M_CNT * 64];
+    for (int e = t.tid; e < ROWS * AS; e += NTHREADS) {
+        const int r = e / AS, i = e % AS;
+        const long g = row0 + r;
+        float v = 0.f;
+        if (i < n_id && g < B) {
+            const int feat = (int)meta[M_IDF * 64 + i];
+            v = Z[g * f.D + feat];
+            if (meta[M_PFON * 64 + i] != 0.f) {
+                const int k = (int)meta[M_PFK * 64 + i];
+                const float s = meta[M_PFS * 64 + i];
+                v = Lp[f.o_pfw + 2 * k] * sinf(s * v) + Lp[f.o_pfw + 2 * k + 1] * cosf(s * v);
+            }
+        }
+        A0[e] = v;
+    }
+}
+
+// h0 = A0 W0 + b0 (kept raw in H0), t = relu(h0) Wa + ba (kept raw in T), h1 = h0 + relu(t) Wb + bb -> X1
+template <int NTWM>
+__device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds& l, const float* __restrict__ Lp, float* lds,
+                                              const Tid& t) {
+    constexpr int DW = depth_w<NTWM>();
+    float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
+    float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2;
+    f32x4 acc[NTWM];
+    sp_gemm<NTWM, 2, true>(A0, l.AS, 4, reinterpret_cast<const float4*>(Lp + f.o_W0), Lp + f.o_b0, t, acc);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
+            H0[o] = acc[i][r];
+            X2[o] = acc[i][r] > 0.f ? acc[i][r] : 0.f;
+        }
+    __syncthreads();
+    sp_gemm<NTWM, DW, true>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wa), Lp + f.o_ba, t, acc);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
+            T[o] = acc[i][r];
+            X1[o] = acc[i][r] > 0.f ? acc[i][r] : 0.f;
+        }
+    __syncthreads();
+    sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wb), Lp + f.o_bb, t, acc);
+    __syncthreads();                                   // everybody is done reading X1 (relu(t)) before it is overwritten
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
+            X1[o] = H0[o] + acc[i][r];
+        }
+    __syncthreads();
+}
+
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_spline_net_fwd(SplineDims f, NetLds l, const float* __restrict__ packed,
+                                                             int layer, const float* __restrict__ Z,
+                                                             float* __restrict__ P, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    constexpr int DW = depth_w<NTWM>();
+    const float* Lp = packed + (size_t)layer * f.layer_stride;
+    const long row0 = (long)blockIdx.x * ROWS;
+    sp_load_identity(f, Lp, Z, row0, B, lds + l.o_A0, l.AS, t);
+    __syncthreads();
+    sp_net_hidden<NTWM>(f, l, Lp, lds, t);
+    const float* X1 = lds + l.o_X1;
+    const int per = 4 * NTWM * f.KBW * 256;
+    for (int c = 0; c < f.NCH; ++c) {
+        f32x4 acc[NTWM];
+        sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wf + (size_t)c * per),
+                                Lp + f.o_bf + c * f.Wp, t, acc);
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long g = row0 + 4 * t.q + r;
+                if (g < B) P[g * f.NFP + c * f.Wp + 16 * (t.wave + 4 * i) + t.n] = acc[i][r];
+            }
+    }
+}
+
+// backward of the conditioner: dP [B][NFP] -> contribution to d log q / d(identity coordinates), ADDED into G [B][D]
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLds l, const float* __restrict__ packed,
+                                                             int layer, const float* __restrict__ Z,
+                                                             const float* __restrict__ dP, float* __restrict__ G, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    constexpr int DW = depth_w<NTWM>();
+    const float* Lp = packed + (size_t)layer * f.layer_stride;
+    const float* meta = Lp + f.o_meta;
+    const long row0 = (long)blockIdx.x * ROWS;
+    float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
+    float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* DP = lds + l.o_DP; float* PART = lds + l.o_PART;
+    sp_load_identity(f, Lp, Z, row0, B, A0, l.AS, t);
+    for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) {
+        const int r = e / l.PS, j = e % l.PS;
+        const long g = row0 + r;
+        DP[e] = (j < f.NFP && g < B) ? dP[g * f.NFP + j] : 0.f;
+    }
+    __syncthreads();
+    sp_net_hidden<NTWM>(f, l, Lp, lds, t);              // recompute h0 (H0) and t (T): the ReLU decisions
+    f32x4 acc[NTWM];
+    // dh1 = dP WfT  -> X1
+    sp_gemm<NTWM, DW, false>(DP, l.PS, f.NFP / 16, reinterpret_cast<const float4*>(Lp + f.o_WfT), nullptr, t, acc);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) X1[(4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n] = acc[i][r];
+    __syncthreads();
+    // d relu(t) = dh1 WbT, masked by t > 0 -> X2
+    sp_gemm<NTWM, DW, false>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WbT), nullptr, t, acc);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
+            X2[o] = T[o] > 0.f ? acc[i][r] : 0.f;
+        }
+    __syncthreads();
+    // dh0 = dh1 + (dt WaT) masked by h0 > 0 -> T
+    sp_gemm<NTWM, DW, false>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WaT), nullptr, t, acc);
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
+            T[o] = X1[o] + (H0[o] > 0.f ? acc[i][r] : 0.f);
+        }
+    __syncthreads();
+    // dA0 = dh0 W0T (N = 64: K-split over the waves)
+    gemm_ksplit<NTWM>(T, l.WS, reinterpret_cast<const float4*>(Lp + f.o_W0T), 4, PART, l.AS, t);
+    __syncthreads();
+    const int n_id = (int)meta[M_CNT * 64];
+    for (int e = t.tid; e < ROWS * 64; e += NTHREADS) {
+        const int r = e >> 6, i = e & 63;
+        const long g = row0 + r;
+        if (i < n_id && g < B) {
+            float d = part_sum(PART, l.AS, r, i);
+            const int feat = (int)meta[M_IDF * 64 + i];
+            if (meta[M_PFON * 64 + i] != 0.f) {
+                const int k = (int)meta[M_PFK * 64 + i];
+                const float s = meta[M_PFS * 64 + i], x = Z[g * f.D + feat];
+                d = d * (s * (Lp[f.o_pfw + 2 * k] * cosf(s * x) - Lp[f.o_pfw + 2 * k + 1] * sinf(s * x)));
+            }
+            G[g * f.D + feat] += d;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// rational-quadratic spline (Durkan et al. 2019, eqs. 4-8; nflows / normflows rational_quadratic_spline)
+// ------------------------------------------------------------------------------------------------
+struct Rqs {
+    float cw[SP_K + 1], ch[SP_K + 1], dv[SP_K + 1];     // knot positions / values / derivatives
+    float pw[SP_K], ph[SP_K];                            // softmax probabilities (backward)
+    float sg[SP_K + 1];                                  // sigmoid(ud) of the free knots (backward), 0 for fixed ones
+};
+
+__device__ __forceinline__ float sp_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+
+// p[0..K) widths, [K..2K) heights (both already divided by sqrt(hidden) when conditional), [2K..3K] derivatives
+__device__ __forceinline__ void rqs_setup(const float* p, bool circ, float tb, Rqs& s) {
+    float mw = p[0], mh = p[SP_K];
+#pragma unroll
+    for (int j = 1; j < SP_K; ++j) { mw = fmaxf(mw, p[j]); mh = fmaxf(mh, p[SP_K + j]); }
+    float sw = 0.f, sh = 0.f;
+#pragma unroll
+    for (int j = 0; j < SP_K; ++j) { s.pw[j] = expf(p[j] - mw); sw += s.pw[j]; s.ph[j] = expf(p[SP_K + j] - mh); sh += s.ph[j]; }
+    float cw = 0.f, chh = 0.f;
+    s.cw[0] = -tb; s.ch[0] = -tb;
+#pragma unroll
+    for (int j = 0; j < SP_K; ++j) {
+        s.pw[j] = s.pw[j] / sw; s.ph[j] = s.ph[j] / sh;
+        cw += SP_MIN_W + (1.f - SP_MIN_W * SP_K) * s.pw[j];
+        chh += SP_MIN_H + (1.f - SP_MIN_H * SP_K) * s.ph[j];
+        s.cw[j + 1] = (2.f * tb) * cw + (-tb);
+        s.ch[j + 1] = (2.f * tb) * chh + (-tb);
+    }
+    s.cw[SP_K] = tb; s.ch[SP_K] = tb;
+    const float cst = logf(expf(1.f - SP_MIN_D) - 1.f);
+#pragma unroll
+    for (int j = 0; j <= SP_K; ++j) {
+        float u = p[2 * SP_K + j];
+        bool fixed = false;
+        if (!circ && (j == 0 || j == SP_K)) { u = cst; fixed = true; }
+        if (circ && j == SP_K) u = p[2 * SP_K];
+        s.dv[j] = SP_MIN_D + sp_softplus(u);
+        s.sg[j] = fixed ? 0.f : 1.f / (1.f + expf(-u));
+    }
+}
+
+__device__ __forceinline__ int rqs_bin(const float* knots, float x) {
+    int b = 0;
+#pragma unroll
+    for (int j = 1; j < SP_K; ++j) b += (x >= knots[j]) ? 1 : 0;
+    return b;                                             // clamp(sum(x >= knots (last + eps)) - 1, 0, K - 1), x in [-B, B]
+}
+
+// y = f(x), logabsdet; identity outside [-tb, tb]
+__device__ __forceinline__ void rqs_forward(const Rqs& s, float x, float tb, float& y, float& ld) {
+    if (!(x >= -tb && x <= tb)) { y = x; ld = 0.f; return; }
+    const int b = rqs_bin(s.cw, x);
+    float xk = 0.f, w = 1.f, yk = 0.f, h = 1.f, d0 = 1.f, d1 = 1.f;
+#pragma unroll
+    for (int j = 0; j < SP_K; ++j)
+        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; d0 = s.dv[j]; d1 = s.dv[j + 1]; }
+    const float th = (x - xk) / w, t1 = th * (1.f - th), dl = h / w;
+    const float num = h * (dl * (th * th) + d0 * t1);
+    const float den = dl + (d0 + d1 - 2.f * dl) * t1;
+    y = yk + num / den;
+    const float dn = (dl * dl) * (d1 * (th * th) + 2.f * dl * t1 + d0 * ((1.f - th) * (1.f - th)));
+    ld = logf(dn) - 2.f * logf(den);
+}
+
+// x = f^-1(y), logabsdet of the INVERSE map
+__device__ __forceinline__ void rqs_inverse(const Rqs& s, float y, float tb, float& x, float& ld) {
+    if (!(y >= -tb && y <= tb)) { x = y; ld = 0.f; return; }
+    const int b = rqs_bin(s.ch, y);
+    float xk = 0.f, w = 1.f, yk = 0.f, h = 1.f, d0 = 1.f, d1 = 1.f;
+#pragma unroll
+    for (int j = 0; j < SP_K; ++j)
+        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; d0 = s.dv[j]; d1 = s.dv[j + 1]; }
+    const float dl = h / w, dy = y - yk, A = d0 + d1 - 2.f * dl;
+    const float a = dy * A + h * (dl - d0);
+    const float bq = h * d0 - dy * A;
+    const float c = -dl * dy;
+    const float disc = bq * bq - 4.f * a * c;
+    const float root = (2.f * c) / (-bq - sqrtf(disc));
+    x = root * w + xk;
+    const float t1 = root * (1.f - root);
+    const float den = dl + A * t1;
+    const float dn = (dl * dl) * (d1 * (root * root) + 2.f * dl * t1 + d0 * ((1.f - root) * (1.f - root)));
+    ld = -(logf(dn) - 2.f * logf(den));
+}
+
+// reverse mode of rqs_forward with cotangents (gy, 1 on logabsdet): returns d/dx and, if dp != nullptr, the cotangents
+// of the 3K+1 unnormalised parameters (scaled by `wh_scale` for widths / heights)
+__device__ __forceinline__ float rqs_backward(const Rqs& s, const float* p, bool circ, float x, float tb, float gy,
+                                              float wh_scale, float* dp) {
+    if (dp) {
+#pragma unroll
+        for (int j = 0; j < SP_NP; ++j) dp[j] = 0.f;
+    }
+    if (!(x >= -tb && x <= tb)) return gy;
+    const int b = rqs_bin(s.cw, x);
+    float xk = 0.f, w = 1.f, h = 1.f, d0 = 1.f, d1 = 1.f;
+#pragma unroll
+    for (int j = 0; j < SP_K; ++j)
+        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; h = s.ch[j + 1] - s.ch[j]; d0 = s.dv[j]; d1 = s.dv[j + 1]; }
+    const float th = (x - xk) / w, t1 = th * (1.f - th), dl = h / w, A = d0 + d1 - 2.f * dl;
+    const float num = h * (dl * (th * th) + d0 * t1);
+    const float den = dl + A * t1;
+    const float e = d1 * (th * th) + 2.f * dl * t1 + d0 * ((1.f - th) * (1.f - th));
+    const float nb = gy / den;                                     // cotangent of num
+    const float db = -gy * num / (den * den) - 2.f / den;          // of den
+    const float eb = 1.f / e;                                      // of e
+    const float sb = 2.f / dl + eb * 2.f * t1 + db * (1.f - 2.f * t1) + nb * h * (th * th);
+    const float t1b = eb * 2.f * dl + db * A + nb * h * d0;
+    const float d0b = eb * ((1.f - th) * (1.f - th)) + db * t1 + nb * h * t1;
+    const float d1b = eb * (th * th) + db * t1;
+    const float thb = eb * (2.f * d1 * th - 2.f * d0 * (1.f - th)) + nb * 2.f * h * dl * th + t1b * (1.f - 2.f * th);
+    const float hb = nb * (num / h) + sb / w;
+    const float wb = -sb * h / (w * w) - thb * th / w;
+    const float xb = thb / w;
+    if (dp) {
+        // knots: W_b += -xb - wb, W_{b+1} += wb ; H_b += gy - hb, H_{b+1} += hb ; D_b += d0b, D_{b+1} += d1b
+        const float cWb = -xb - wb, cW1 = wb, cHb = gy - hb, cH1 = hb;
+        // W_j = -tb + 2 tb (j MIN + (1 - K MIN) P_j), P_j = sum_{i<j} p_i  ->  d uw_m = c p_m sum_j cW_j (1[m < j] - P_j)
+        const float cw_ = 2.f * tb * (1.f - SP_MIN_W * SP_K), chh = 2.f * tb * (1.f - SP_MIN_H * SP_K);
+        float Pw = 0.f, Ph = 0.f, Pwb = 0.f, Pw1 = 0.f, Phb = 0.f, Ph1 = 0.f;
+#pragma unroll
+        for (int j = 0; j <= SP_K; ++j) {
+            if (j == b) { Pwb = Pw; Phb = Ph; }
+            if (j == b + 1) { Pw1 = Pw; Ph1 = Ph; }
+            if (j < SP_K) { Pw += s.pw[j]; Ph += s.ph[j]; }
+        }
+        const bool fb = b >= 1, f1 = b + 1 <= SP_K - 1;           // the end knots W_0, W_K are fixed
+#pragma unroll
+        for (int m = 0; m < SP_K; ++m) {
+            float aw = 0.f, ah = 0.f;
+            if (fb) { aw += cWb * ((m < b ? 1.f : 0.f) - Pwb); ah += cHb * ((m < b ? 1.f : 0.f) - Phb); }
+            if (f1) { aw += cW1 * ((m < b + 1 ? 1.f : 0.f) - Pw1); ah += cH1 * ((m < b + 1 ? 1.f : 0.f) - Ph1); }
+            dp[m] = cw_ * s.pw[m] * aw * wh_scale;
+            dp[SP_K + m] = chh * s.ph[m] * ah * wh_scale;
+        }
+#pragma unroll
+        for (int j = 0; j <= SP_K; ++j) {
+            float g = 0.f;
+            if (j == b) g += d0b;
+            if (j == b + 1) g += d1b;
+            if (circ && j == SP_K) { dp[2 * SP_K] += g * s.sg[0]; g = 0.f; }   // last knot tied to the first
+            dp[2 * SP_K + j] += g * s.sg[j];
+        }
+    }
+    return xb;
+}
+
+__device__ __forceinline__ float sp_wrap(float z, float bound) {       // torch.remainder(z + b, 2 b) - b
+    const float p = 2.f * bound;
+    float r = fmodf(z + bound, p);
+    if (r < 0.f) r += p;
+    return r - bound;
+}
+
+__device__ __forceinline__ float wave_sum64(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// One wave per chain, lane = coordinate.  MODE 0: log_prob direction (evaluate), 1: sampling direction, identity
+// coordinates only (unconditional inverse, before the conditioner runs), 2: sampling direction, transformed
+// coordinates (needs P) + post shift.
+template <int MODE>
+__global__ __launch_bounds__(256) void k_spline_apply(SplineDims f, const float* __restrict__ packed, int layer,
+                                                      const float* __restrict__ Zin, const float* __restrict__ P,
+                                                      float* __restrict__ Zout, float* __restrict__ log_q, float ld_sign,
+                                                      long B) {
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;
+    const float* Lp = packed + (size_t)layer * f.layer_stride;
+    const float* meta = Lp + f.o_meta;
+    const int n_id = (int)meta[M_CNT * 64], n_tr = (int)meta[M_CNT * 64 + 1];
+    const float isq = 1.f / sqrtf((float)f.W);
+    float ld = 0.f;
+    if (lane < f.D) {
+        // role of this coordinate
+        int pos_id = -1, pos_tr = -1;
+        for (int i = 0; i < n_id; ++i) if ((int)meta[M_IDF * 64 + i] == lane) pos_id = i;
+        for (int i = 0; i < n_tr; ++i) if ((int)meta[M_TRF * 64 + i] == lane) pos_tr = i;
+        const bool circ = meta[M_CIRC * 64 + lane] != 0.f;
+        const float tb = meta[M_TB * 64 + lane];
+        float z = Zin[g * f.D + lane], out = z;
+        float p[SP_NP];
+        Rqs s;
+        if (pos_id >= 0 && MODE != 2) {
+#pragma unroll
+            for (int j = 0; j < SP_NP; ++j) p[j] = Lp[f.o_unc + pos_id * SP_NP + j];
+            rqs_setup(p, circ, tb, s);
+            float l1;
+            if (MODE == 0) rqs_forward(s, z, tb, out, l1); else rqs_inverse(s, z, tb, out, l1);
+            ld = l1;
+        } else if (pos_tr >= 0 && MODE != 1) {
+#pragma unroll
+            for (int j = 0; j < SP_NP; ++j) {
+                const float v = P[g * f.NFP + pos_tr * SP_NP + j];
+                p[j] = j < 2 * SP_K ? v * isq : v;
+            }
+            rqs_setup(p, circ, tb, s);
+            float l1;
+            if (MODE == 0) rqs_forward(s, z, tb, out, l1); else rqs_inverse(s, z, tb, out, l1);
+            ld = l1;
+        }
+        // stage boundary: MODE 0 -> the NEXT (lower) layer's pre-shift; MODE 2 -> this layer's post-shift
+        if (MODE == 0 && layer > 0) {
+            const float* mn = packed + (size_t)(layer - 1) * f.layer_stride + f.o_meta;
+            if (mn[M_PREON * 64 + lane] != 0.f) out = sp_wrap(out - mn[M_PRESH * 64 + lane], tb);
+        }
+        if (MODE == 2 && meta[M_POSTON * 64 + lane] != 0.f) out = sp_wrap(out + meta[M_POSTSH * 64 + lane], tb);
+        Zout[g * f.D + lane] = out;
+    }
+    ld = wave_sum64(ld);
+    if (lane == 0) log_q[g] += ld_sign * ld;
+}
+
+// x <- wrap(x - pre_shift of the top layer) : the first stage of the log_prob direction (PeriodicWrap.inverse)
+__global__ void k_spline_first_stage(SplineDims f, const float* __restrict__ packed, const float* __restrict__ x,
+                                     float* __restrict__ Z, float* __restrict__ log_q, long B) {
+    const float* meta = packed + (size_t)(f.L - 1) * f.layer_stride + f.o_meta;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < B * f.D; e += (long)gridDim.x * blockDim.x) {
+        const int j = (int)(e % f.D);
+        float v = x[e];
+        if (meta[M_PREON * 64 + j] != 0.f) v = sp_wrap(v - meta[M_PRESH * 64 + j], meta[M_TB * 64 + j]);
+        Z[e] = v;
+        if (j == 0) log_q[e / f.D] = 0.f;
+    }
+}
+
+// base UniformGaussian: log_q += log p0(z); G = d log p0 / dz (if G)
+__global__ __launch_bounds__(256) void k_spline_base(SplineDims f, const float* __restrict__ packed,
+                                                     const float* __restrict__ Z, float* __restrict__ log_q,
+                                                     float* __restrict__ G, long B) {
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;
+    float lp = 0.f;
+    if (lane < f.D) {
+        const float sc = packed[f.o_base + lane];
+        const bool circ = packed[f.o_base + 64 + lane] != 0.f;
+        const float z = Z[g * f.D + lane];
+        if (circ) { lp = -logf(sc); if (G) G[g * f.D + lane] = 0.f; }
+        else {
+            lp = -0.5f * 1.8378770664093453f - logf(sc) - 0.5f * ((z / sc) * (z / sc));
+            if (G) G[g * f.D + lane] = -(z / sc) / sc;
+        }
+    }
+    lp = wave_sum64(lp);
+    if (lane == 0) log_q[g] += lp;
+}
+
+// sampling: z0 = base sample from (u, eps), log_q = log p0(z0)
+__global__ __launch_bounds__(256) void k_spline_base_sample(SplineDims f, const float* __restrict__ packed,
+                                                            const float* __restrict__ u, const float* __restrict__ eps,
+                                                            float* __restrict__ Z, float* __restrict__ log_q, long B) {
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;
+    float lp = 0.f;
+    if (lane < f.D) {
+        const float sc = packed[f.o_base + lane];
+        const bool circ = packed[f.o_base + 64 + lane] != 0.f;
+        const float z = (circ ? u[g * f.D + lane] - 0.5f : eps[g * f.D + lane]) * sc;
+        Z[g * f.D + lane] = z;
+        lp = circ ? -logf(sc) : -0.5f * 1.8378770664093453f - logf(sc) - 0.5f * ((z / sc) * (z / sc));
+    }
+    lp = wave_sum64(lp);
+    if (lane == 0) log_q[g] = lp;
+}
+
+// reverse mode through k_spline_apply<0> of one layer: Gout (cotangent of the layer's output state, BEFORE the stage
+// boundary shift, which has unit derivative) -> Gin (w.r.t. the layer's input state, conditioner path excluded) and dP
+__global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const float* __restrict__ packed, int layer,
+                                                          const float* __restrict__ Zin, const float* __restrict__ P,
+                                                          const float* __restrict__ Gout, float* __restrict__ Gin,
+                                                          float* __restrict__ dP, long B) {
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;
+    const float* Lp = packed + (size_t)layer * f.layer_stride;
+    const float* meta = Lp + f.o_meta;
+    const int n_id = (int)meta[M_CNT * 64], n_tr = (int)meta[M_CNT * 64 + 1];
+    const float isq = 1.f / sqrtf((float)f.W);
+    // zero the padding columns of this chain's dP row (the conditioner backward reads all NFP of them)
+    for (int j = n_tr * SP_NP + lane; j < f.NFP; j += 64) dP[g * f.NFP + j] = 0.f;
+    if (lane >= f.D) return;
+    int pos_id = -1, pos_tr = -1;
+    for (int i = 0; i < n_id; ++i) if ((int)meta[M_IDF * 64 + i] == lane) pos_id = i;
+    for (int i = 0; i < n_tr; ++i) if ((int)meta[M_TRF * 64 + i] == lane) pos_tr = i;
+    const bool circ = meta[M_CIRC * 64 + lane] != 0.f;
+    const float tb = meta[M_TB * 64 + lane];
+    const float z = Zin[g * f.D + lane], gy = Gout[g * f.D + lane];
+    float p[SP_NP];
+    Rqs s;
+    float gx = gy;
+    if (pos_id >= 0) {
+#pragma unroll
+        for (int j = 0; j < SP_NP; ++j) p[j] = Lp[f.o_unc + pos_id * SP_NP + j];
+        rqs_setup(p, circ, tb, s);
+        gx = rqs_backward(s, p, circ, z, tb, gy, 1.f, nullptr);
+    } else if (pos_tr >= 0) {
+#pragma unroll
+        for (int j = 0; j < SP_NP; ++j) {
+            const float v = P[g * f.NFP + pos_tr * SP_NP + j];
+            p[j] = j < 2 * SP_K ? v * isq : v;
+        }
+        rqs_setup(p, circ, tb, s);
+        float dp[SP_NP];
+        gx = rqs_backward(s, p, circ, z, tb, gy, isq, dp);
+#pragma unroll
+        for (int j = 0; j < SP_NP; ++j) dP[g * f.NFP + pos_tr * SP_NP + j] = dp[j];
+    }
+    Gin[g * f.D + lane] = gx;
+}
+
+template <int NTWM>
+static int launch_net(const SplineDims& f, const float* packed, int layer, const float* Z, float* P, const float* dP,
+                      float* G, long B, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
+    const bool bwd = dP != nullptr;
+    const NetLds l = make_net_lds(f, bwd);
+    const size_t bytes = (size_t)l.total * 4;
+    if (bwd) {
+        FAB_TRY(set_max_lds((const void*)k_spline_net_bwd<NTWM>, bytes));
+        hipLaunchKernelGGL((k_spline_net_bwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, dP, G, B);
+    } else {
+        FAB_TRY(set_max_lds((const void*)k_spline_net_fwd<NTWM>, bytes));
+        hipLaunchKernelGGL((k_spline_net_fwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, P, B);
+    }
+    return check_launch();
+}
+
+static int net(const SplineDims& f, const float* packed, int layer, const float* Z, float* P, const float* dP, float* G,
+               long B, hipStream_t st) {
+    if (f.NTWM == 1) return launch_net<1>(f, packed, layer, Z, P, dP, G, B, st);
+    if (f.NTWM == 2) return launch_net<2>(f, packed, layer, Z, P, dP, G, B, st);
+    if (f.NTWM == 4) return launch_net<4>(f, packed, layer, Z, P, dP, G, B, st);
+    return FABHIP_ENOTSUP;
+}
+
+static inline size_t sp_al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+}  // namespace fab
+
+using namespace fab;
+
+extern "C" {
+
+int64_t fabhip_spline_packed_floats(int32_t dim, int32_t n_layers, int32_t hidden) {
+    if (check_spline_shape(dim, n_layers, hidden) != FABHIP_OK) return -1;
+    return (int64_t)make_spline_dims(dim, n_layers, hidden).total;
+}
+
+int fabhip_spline_pack(const fabhip_spline_params* p, float* packed, fabhip_stream_t stream) {
+    if (!p || !packed || !p->base_scale || !p->base_circ) return FABHIP_EINVAL;
+    FAB_TRY(check_spline_shape(p->dim, p->n_layers, p->hidden));
+    const SplineDims f = make_spline_dims(p->dim, p->n_layers, p->hidden);
+    hipStream_t st = (hipStream_t)stream;
+    for (int l = 0; l < f.L; ++l) {
+        if (!p->meta[l] || !p->w0[l] || !p->b0[l] || !p->wa[l] || !p->ba[l] || !p->wb[l] || !p->bb[l] || !p->wf[l] ||
+            !p->bf[l] || !p->uw[l] || !p->uh[l] || !p->ud[l])
+            return FABHIP_EINVAL;
+        const SplineSrc s{p->meta[l], p->w0[l], p->b0[l], p->wa[l], p->ba[l], p->wb[l], p->bb[l], p->wf[l], p->bf[l],
+                          p->pfw[l], p->uw[l], p->uh[l], p->ud[l]};
+        hipLaunchKernelGGL(k_spline_pack_layer, dim3(ceil_div(f.layer_stride, 256 * 8)), dim3(256), 0, st, f, s, l, packed);
+    }
+    hipLaunchKernelGGL(k_spline_pack_base, dim3(1), dim3(64), 0, st, f, p->base_scale, p->base_circ, packed);
+    return check_launch();
+}
+
+size_t fabhip_spline_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B, int32_t with_grad) {
+    if (check_spline_shape(dim, n_layers, hidden) != FABHIP_OK || B < 0) return 0;
+    const SplineDims f = make_spline_dims(dim, n_layers, hidden);
+    size_t s = sp_al((size_t)(f.L + 1) * B * f.D * 4);                 // layer input states
+    s += sp_al((size_t)(with_grad ? f.L : 1) * B * f.NFP * 4);          // conditioner outputs (kept per layer for the reverse sweep)
+    if (with_grad) s += sp_al((size_t)B * f.NFP * 4) + 2 * sp_al((size_t)B * f.D * 4);
+    return s + 256;
+}
+
+int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                           void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !x || !log_q || !workspace || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_spline_shape(flow->dim, flow->n_layers, flow->hidden));
+    if (B == 0) return FABHIP_OK;
+    if (workspace_bytes < fabhip_spline_workspace_bytes(flow->dim, flow->n_layers, flow->hidden, B, grad_x != nullptr))
+        return FABHIP_ENOSPC;
+    const SplineDims f = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* Z = (float*)ws; ws += sp_al((size_t)(f.L + 1) * B * f.D * 4);       // Z[l+1] = input of layer l, Z[0] = base side
+    float* P = (float*)ws; ws += sp_al((size_t)(grad_x ? f.L : 1) * B * f.NFP * 4);
+    float* dP = nullptr; float* Ga = nullptr; float* Gb = nullptr;
+    if (grad_x) {
+        dP = (float*)ws; ws += sp_al((size_t)B * f.NFP * 4);
+        Ga = (float*)ws; ws += sp_al((size_t)B * f.D * 4);
+        Gb = (float*)ws;
+    }
+    const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
+    const float* pk = flow->packed;
+    const dim3 wgrid((unsigned)((B + 3) / 4)), wblock(256);
+    hipLaunchKernelGGL(k_spline_first_stage, dim3((unsigned)((B * f.D + 255) / 256 > 4096 ? 4096 : (B * f.D + 255) / 256)),
+                       dim3(256), 0, st, f, pk, x, Z + (size_t)f.L * zs, log_q, (long)B);
+    for (int l = f.L - 1; l >= 0; --l) {
+        float* Pl = P + (grad_x ? (size_t)l * ps : 0);
+        FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, Pl, nullptr, nullptr, (long)B, st));
+        hipLaunchKernelGGL(k_spline_apply<0>, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs, Pl, Z + (size_t)l * zs,
+                           log_q, 1.f, (long)B);
+    }
+    hipLaunchKernelGGL(k_spline_base, wgrid, wblock, 0, st, f, pk, Z, log_q, Ga, (long)B);
+    if (grad_x) {
+        float* gin = Ga;                                 // cotangent of Z[0] (the base side): d log p0 / dz
+        for (int l = 0; l < f.L; ++l) {
+            float* out = (l == f.L - 1) ? grad_x : (gin == Ga ? Gb : Ga);
+            hipLaunchKernelGGL(k_spline_apply_bwd, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs,
+                               P + (size_t)l * ps, gin, out, dP, (long)B);
+            FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, dP, out, (long)B, st));
+            gin = out;
+        }
+    }
+    return check_launch();
+}
+
+int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const float* eps, float* x, float* log_q,
+                         int64_t B, void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !u || !eps || !x || !log_q || !workspace || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_spline_shape(flow->dim, flow->n_layers, flow->hidden));
+    if (B == 0) return FABHIP_OK;
+    if (workspace_bytes < fabhip_spline_workspace_bytes(flow->dim, flow->n_layers, flow->hidden, B, 0)) return FABHIP_ENOSPC;
+    const SplineDims f = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* Z = (float*)ws; ws += sp_al((size_t)(f.L + 1) * B * f.D * 4);
+    float* P = (float*)ws;
+    const size_t zs = (size_t)B * f.D;
+    float* za = Z; float* zb = Z + zs; float* zc = Z + 2 * zs;
+    const float* pk = flow->packed;
+    const dim3 wgrid((unsigned)((B + 3) / 4)), wblock(256);
+    hipLaunchKernelGGL(k_spline_base_sample, wgrid, wblock, 0, st, f, pk, u, eps, za, log_q, (long)B);
+    for (int l = 0; l < f.L; ++l) {
+        // identity coordinates through the inverse unconditional spline (zb), conditioner on them, then the rest
+        hipLaunchKernelGGL(k_spline_apply<1>, wgrid, wblock, 0, st, f, pk, l, za, (const float*)nullptr, zb, log_q, -1.f, (long)B);
+        FAB_TRY(net(f, pk, l, zb, P, nullptr, nullptr, (long)B, st));
+        float* out = (l == f.L - 1) ? x : zc;
+        hipLaunchKernelGGL(k_spline_apply<2>, wgrid, wblock, 0, st, f, pk, l, zb, P, out, log_q, -1.f, (long)B);
+        float* tmp = za; za = zc; zc = tmp;
+    }
+    return check_launch();
+}
+
+}  // extern "C"

@@ -122,6 +122,9 @@ std::vector<int64_t> flow_tape_layout(int64_t dim, int64_t n_layers, int64_t wid
     chk(fabhip_flow_tape_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, B, out.data()), "flow_tape_layout");
     return out;
 }
+int64_t spline_packed_floats(int64_t dim, int64_t n_layers, int64_t hidden) {
+    return fabhip_spline_packed_floats((int32_t)dim, (int32_t)n_layers, (int32_t)hidden);
+}
 std::vector<double> anneal_coefs(double beta, double alpha, bool p_target) {
     const fabhip_anneal a = coefs(beta, alpha, p_target);
     return {a.c_q, a.c_p, a.g_q, a.g_p};
@@ -213,6 +216,70 @@ void adam_clip_step(Tensor theta, const Tensor& grad, Tensor m, Tensor v, double
                               (float)beta1, (float)beta2, (float)eps, step_count.data_ptr<int32_t>(), (float)max_norm,
                               fpm(grad_norm, "grad_norm"), aligned(ws), nb, stream_of(theta)),
         "adam_clip_step");
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// RQ-spline coupling flow.  `Tensor[] params`: per layer {meta, w0, b0, wa, ba, wb, bb, wf, bf, pfw, uw, uh, ud}
+// (pfw may be an empty tensor), then {base_scale, base_circ}.
+// ------------------------------------------------------------------------------------------------------------------
+fabhip_spline_flow make_spline(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden) {
+    fabhip_spline_flow f;
+    f.dim = (int32_t)dim; f.n_layers = (int32_t)n_layers; f.hidden = (int32_t)hidden;
+    f.packed = fp(packed, "packed spline image");
+    const int64_t n = fabhip_spline_packed_floats(f.dim, f.n_layers, f.hidden);
+    TORCH_CHECK(n > 0, "fabhip: spline flow shape not supported (dim ", dim, ", hidden ", hidden, ")");
+    TORCH_CHECK(packed.numel() == n, "fabhip: packed spline image has ", packed.numel(), " floats, expected ", n);
+    return f;
+}
+
+void spline_pack(at::TensorList params, int64_t dim, int64_t n_layers, int64_t hidden, Tensor packed) {
+    c10::DeviceGuard g(packed.device());
+    TORCH_CHECK(n_layers >= 1 && n_layers <= FABHIP_MAX_LAYERS, "fabhip: n_layers out of range");
+    TORCH_CHECK((int64_t)params.size() == 13 * n_layers + 2, "fabhip: expected ", 13 * n_layers + 2, " spline tensors");
+    make_spline(packed, dim, n_layers, hidden);
+    fabhip_spline_params p;
+    p.dim = (int32_t)dim; p.n_layers = (int32_t)n_layers; p.hidden = (int32_t)hidden;
+    for (int64_t l = 0; l < n_layers; ++l) {
+        const Tensor* t = &params[13 * l];
+        p.meta[l] = fp(t[0], "meta"); p.w0[l] = fp(t[1], "w0"); p.b0[l] = fp(t[2], "b0"); p.wa[l] = fp(t[3], "wa");
+        p.ba[l] = fp(t[4], "ba"); p.wb[l] = fp(t[5], "wb"); p.bb[l] = fp(t[6], "bb"); p.wf[l] = fp(t[7], "wf");
+        p.bf[l] = fp(t[8], "bf"); p.pfw[l] = t[9].numel() ? fp(t[9], "pfw") : nullptr;
+        p.uw[l] = fp(t[10], "uw"); p.uh[l] = fp(t[11], "uh"); p.ud[l] = fp(t[12], "ud");
+        TORCH_CHECK(t[0].numel() == 12 * 64, "fabhip: spline meta must be [12, 64]");
+    }
+    p.base_scale = fp(params[13 * n_layers], "base_scale");
+    p.base_circ = fp(params[13 * n_layers + 1], "base_circ");
+    chk(fabhip_spline_pack(&p, packed.data_ptr<float>(), stream_of(packed)), "spline_pack");
+}
+
+std::tuple<Tensor, Tensor> spline_logprob_grad(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden,
+                                               const Tensor& x, bool with_grad) {
+    c10::DeviceGuard g(x.device());
+    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0);
+    Tensor log_q = fempty({B}, x), grad = with_grad ? at::empty_like(x) : fempty({0}, x);
+    const size_t nb = fabhip_spline_workspace_bytes(f.dim, f.n_layers, f.hidden, B, with_grad ? 1 : 0);
+    Tensor ws = scratch(nb, x);
+    chk(fabhip_spline_log_prob(&f, fp(x, "x"), log_q.data_ptr<float>(), with_grad ? grad.data_ptr<float>() : nullptr, B,
+                               aligned(ws), nb, stream_of(x)),
+        "spline_log_prob");
+    return {log_q, grad};
+}
+
+std::tuple<Tensor, Tensor> spline_sample(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden,
+                                         const Tensor& u, const Tensor& eps) {
+    c10::DeviceGuard g(u.device());
+    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
+    TORCH_CHECK(u.dim() == 2 && u.size(1) == dim && eps.sizes() == u.sizes(), "fabhip: u, eps must be [B, dim]");
+    const int64_t B = u.size(0);
+    Tensor x = at::empty_like(u), log_q = fempty({B}, u);
+    const size_t nb = fabhip_spline_workspace_bytes(f.dim, f.n_layers, f.hidden, B, 0);
+    Tensor ws = scratch(nb, u);
+    chk(fabhip_spline_sample(&f, fp(u, "u"), fp(eps, "eps"), x.data_ptr<float>(), log_q.data_ptr<float>(), B, aligned(ws),
+                             nb, stream_of(u)),
+        "spline_sample");
+    return {x, log_q};
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -588,6 +655,10 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("adam_clip_step(Tensor(a!) theta, Tensor grad, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, "
           "float eps, Tensor(d!) step_count, float max_norm, Tensor(e!) grad_norm) -> ()");
 
+    m.def("spline_packed_floats(int dim, int n_layers, int hidden) -> int", spline_packed_floats);
+    m.def("spline_pack(Tensor[] params, int dim, int n_layers, int hidden, Tensor(a!) packed) -> ()");
+    m.def("spline_logprob_grad(Tensor packed, int dim, int n_layers, int hidden, Tensor x, bool with_grad) -> (Tensor, Tensor)");
+    m.def("spline_sample(Tensor packed, int dim, int n_layers, int hidden, Tensor u, Tensor eps) -> (Tensor, Tensor)");
     m.def("target_logp_grad(" TGT ", Tensor x, bool with_grad) -> (Tensor, Tensor)");
     m.def("manywell_logp_grad(Tensor x, float a, float b, float c, float log_norm) -> (Tensor, Tensor)");
     m.def("gmm_logp_grad(Tensor x, Tensor locs, Tensor scales) -> (Tensor, Tensor)");
@@ -640,6 +711,9 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("realnvp_logprob_tape", realnvp_logprob_tape);
     m.impl("realnvp_param_grad", realnvp_param_grad);
     m.impl("adam_clip_step", adam_clip_step);
+    m.impl("spline_pack", spline_pack);
+    m.impl("spline_logprob_grad", spline_logprob_grad);
+    m.impl("spline_sample", spline_sample);
     m.impl("target_logp_grad", target_logp_grad);
     m.impl("manywell_logp_grad", manywell_logp_grad);
     m.impl("gmm_logp_grad", gmm_logp_grad);

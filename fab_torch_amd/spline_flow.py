@@ -1,0 +1,291 @@
+"""Circular / linear-tail rational-quadratic spline coupling flow backed by the HIP kernels of csrc/spline_kernels.hip.
+
+Host-side mirror of what the reference builds with normflows for alanine dipeptide
+(experiments/make_flow/make_aldp_model.py:57-71,121-134,146-167, `flow.type = circular-coup-nsf`,
+experiments/aldp/config/fab_buff.yaml:20-36) and wraps in fab/wrappers/normflows.py:8-31: n_layers x
+`CircularCoupledRationalQuadraticSpline(dim, blocks_per_layer=1, hidden_units, ind_circ, tail_bound, num_bins=8,
+init_identity, mask)` with alternating random binary masks, a `PeriodicShift` after every second layer, a final
+`PeriodicWrap`, base `UniformGaussian`.  Same `Distribution` methods (fab/types_.py:8-27) and the same state-dict key
+names as the normflows modules (`_nf_model.flows.{i}.prqct.transform_net.{initial_layer, blocks.0.linear_layers.{0,1},
+final_layer, preprocessing.weights}`, `...prqct.unconditional_transform.unnormalized_{widths,heights,derivatives}`) so
+that a normflows checkpoint of this architecture loads by key (fab/core.py:237-240) - the "checkpoint importer" of
+SURVEY.md section 8f-4.  normflows is absent from the reference tree: the arithmetic is specified by oracle/spline.py
+(parity unpinned by the reference).
+
+`log_prob`, its gradient w.r.t. x and `sample_and_log_prob` run on the GPU through torch.ops.fabhip.spline_*; the
+sampler drives this flow through the generic plug-in path of the transition operators (`log_prob` is differentiable
+w.r.t. x through a custom autograd Function whose backward is the kernels' own reverse sweep).  Parameter gradients
+(training this flow family) are not built."""
+import math
+from typing import Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import _ops
+
+NUM_BINS = 8
+MIN_DERIVATIVE = 1e-3
+
+
+class _PeriodicFeatures(nn.Module):
+    def __init__(self, ind, scale):
+        super().__init__()
+        self.register_buffer("ind", torch.as_tensor(list(ind), dtype=torch.long))
+        self.register_buffer("scale", torch.as_tensor(scale, dtype=torch.float32).reshape(-1))
+        self.weights = nn.Parameter(torch.ones(len(ind), 2))
+
+
+class _ResidualBlock(nn.Module):
+    def __init__(self, features):
+        super().__init__()
+        self.linear_layers = nn.ModuleList([nn.Linear(features, features), nn.Linear(features, features)])
+        nn.init.uniform_(self.linear_layers[-1].weight, -1e-3, 1e-3)
+        nn.init.uniform_(self.linear_layers[-1].bias, -1e-3, 1e-3)
+
+
+class _ResidualNet(nn.Module):
+    def __init__(self, in_features, out_features, hidden, preprocessing):
+        super().__init__()
+        self.hidden_features = hidden
+        self.preprocessing = preprocessing
+        self.initial_layer = nn.Linear(in_features, hidden)
+        self.blocks = nn.ModuleList([_ResidualBlock(hidden)])
+        self.final_layer = nn.Linear(hidden, out_features)
+
+
+class _UnconditionalRQS(nn.Module):
+    def __init__(self, n, circ, tail_bound):
+        super().__init__()
+        self.register_buffer("circ", circ)
+        self.register_buffer("tail_bound", tail_bound)
+        const = math.log(math.exp(1 - MIN_DERIVATIVE) - 1)
+        self.unnormalized_widths = nn.Parameter(torch.zeros(n, NUM_BINS))
+        self.unnormalized_heights = nn.Parameter(torch.zeros(n, NUM_BINS))
+        self.unnormalized_derivatives = nn.Parameter(const * torch.ones(n, NUM_BINS + 1))
+
+
+class _PRQCT(nn.Module):
+    def __init__(self, mask, hidden, circ_all, tail_bound_all, init_identity):
+        super().__init__()
+        feats = torch.arange(mask.shape[0])
+        self.register_buffer("identity_features", feats[mask <= 0])
+        self.register_buffer("transform_features", feats[mask > 0])
+        idf, trf = self.identity_features, self.transform_features
+        circ_id = [i for i, f in enumerate(idf.tolist()) if bool(circ_all[f])]
+        pf = _PeriodicFeatures(circ_id, math.pi / tail_bound_all[idf][circ_id]) if circ_id else None
+        self.transform_net = _ResidualNet(len(idf), len(trf) * (3 * NUM_BINS + 1), hidden, pf)
+        if init_identity:
+            nn.init.constant_(self.transform_net.final_layer.weight, 0.0)
+            nn.init.constant_(self.transform_net.final_layer.bias, math.log(math.exp(1 - MIN_DERIVATIVE) - 1))
+        self.register_buffer("circ_t", circ_all[trf].clone())
+        self.register_buffer("tb_t", tail_bound_all[trf].clone())
+        self.unconditional_transform = _UnconditionalRQS(len(idf), circ_all[idf].clone(), tail_bound_all[idf].clone())
+
+
+class _Coupling(nn.Module):
+    def __init__(self, mask, hidden, circ_all, tail_bound_all, init_identity):
+        super().__init__()
+        self.prqct = _PRQCT(mask, hidden, circ_all, tail_bound_all, init_identity)
+
+
+class _PeriodicShift(nn.Module):
+    def __init__(self, ind, bound, shift):
+        super().__init__()
+        self.register_buffer("ind", torch.as_tensor(list(ind), dtype=torch.long))
+        self.register_buffer("bound", torch.as_tensor(bound, dtype=torch.float32).reshape(-1))
+        self.register_buffer("shift", torch.as_tensor(shift, dtype=torch.float32).reshape(-1))
+
+
+class _PeriodicWrap(nn.Module):
+    def __init__(self, ind, bound):
+        super().__init__()
+        self.register_buffer("ind", torch.as_tensor(list(ind), dtype=torch.long))
+        self.register_buffer("bound", torch.as_tensor(bound, dtype=torch.float32).reshape(-1))
+
+
+class _UniformGaussian(nn.Module):
+    def __init__(self, ndim, ind_circ, scale):
+        super().__init__()
+        self.shape = (ndim,)
+        circ = torch.zeros(ndim, dtype=torch.bool)
+        circ[list(ind_circ)] = True
+        self.register_buffer("circ", circ)
+        self.register_buffer("scale", torch.as_tensor(scale, dtype=torch.float32).reshape(-1))
+
+
+class _NormalizingFlow(nn.Module):
+    def __init__(self, q0, flows):
+        super().__init__()
+        self.q0 = q0
+        self.flows = nn.ModuleList(flows)
+
+
+class _SplineLogProb(torch.autograd.Function):
+    """log q(x) with d log q / dx from the kernels' reverse sweep: what `grad_and_value(x, flow.log_prob)`
+    (fab/sampling_methods/base.py:50-56) differentiates through on the generic transition path."""
+
+    @staticmethod
+    def forward(ctx, flow, x):
+        lq, g = flow.native_log_prob(x, with_grad=True)
+        ctx.save_for_backward(g)
+        return lq
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (g,) = ctx.saved_tensors
+        return None, grad_out[:, None] * g
+
+
+class CircularCoupledRQSFlow(nn.Module):
+    def __init__(self, dim: int, n_layers: int, hidden_units: int, ind_circ: Sequence[int], tail_bound,
+                 num_bins: int = 8, blocks_per_layer: int = 1, seed: int = 0, circ_shift: str = "random",
+                 init_identity: bool = True):
+        super().__init__()
+        if num_bins != NUM_BINS or blocks_per_layer != 1:
+            raise NotImplementedError("the HIP spline kernels are built for 8 bins and one residual block per conditioner "
+                                      "(experiments/aldp/config/fab_buff.yaml:28-32)")
+        self.dim, self.n_layers, self.hidden = dim, n_layers, hidden_units
+        tail_bound = torch.as_tensor(tail_bound, dtype=torch.float32).reshape(-1)
+        if tail_bound.numel() == 1:
+            tail_bound = tail_bound.expand(dim).clone()
+        ind_circ = list(ind_circ)
+        circ = torch.zeros(dim, dtype=torch.bool)
+        circ[ind_circ] = True
+        bound_circ = tail_bound[ind_circ]
+        scale = torch.ones(dim)
+        scale[ind_circ] = 2 * bound_circ
+        layers, mask = [], None
+        for i in range(n_layers):
+            if i % 2 == 0:                                 # nf.utils.masks.create_random_binary_mask(ndim, seed=seed + i)
+                g = torch.Generator().manual_seed(seed + i)
+                mask = torch.zeros(dim)
+                mask[torch.multinomial(torch.ones(dim), dim // 2 + dim % 2, replacement=False, generator=g)] += 1
+            else:
+                mask = 1 - mask
+            layers.append(_Coupling(mask.clone(), hidden_units, circ, tail_bound, init_identity))
+            if i % 2 == 1 and i != n_layers - 1 and circ_shift is not None and ind_circ:
+                if circ_shift == "constant":
+                    layers.append(_PeriodicShift(ind_circ, bound_circ, bound_circ))
+                else:
+                    g = torch.Generator().manual_seed(seed + i)
+                    layers.append(_PeriodicShift(ind_circ, bound_circ, (torch.rand([], generator=g) + 0.5) * bound_circ))
+        if ind_circ:
+            layers.append(_PeriodicWrap(ind_circ, bound_circ))
+        self._nf_model = _NormalizingFlow(_UniformGaussian(dim, ind_circ, scale), layers)
+        self.register_buffer("_circ", circ)
+        self.register_buffer("_tail_bound", tail_bound.clone())
+        self._packed = None
+        self._packed_key = None
+
+    # ---- Distribution interface (fab/types_.py:8-27) ---------------------------------------------------------------
+    @property
+    def event_shape(self) -> Tuple[int, ...]:
+        return self._nf_model.q0.shape
+
+    def sample_and_log_prob(self, shape: Tuple[int, ...], u: torch.Tensor = None, eps: torch.Tensor = None):
+        assert len(shape) == 1
+        dev = self._tail_bound.device
+        if u is None:
+            u = torch.rand((shape[0], self.dim), dtype=torch.float32, device=dev)
+        if eps is None:
+            eps = torch.randn((shape[0], self.dim), dtype=torch.float32, device=dev)
+        _ops.require_device(u, "u")
+        x, log_q = _ops.load().spline_sample(*self.native(), u.contiguous().float(), eps.contiguous().float())
+        return x, log_q
+
+    def sample(self, shape: Tuple) -> torch.Tensor:
+        return self.sample_and_log_prob(shape)[0]
+
+    def log_prob(self, x: torch.Tensor) -> torch.Tensor:
+        _ops.require_device(x, "x")
+        if torch.is_grad_enabled() and x.requires_grad:
+            return _SplineLogProb.apply(self, x)
+        return self.native_log_prob(x)[0]
+
+    def log_prob_and_grad(self, x: torch.Tensor):
+        return self.native_log_prob(x, with_grad=True)
+
+    def native_log_prob(self, x: torch.Tensor, with_grad: bool = False):
+        _ops.require_device(x, "x")
+        lq, g = _ops.load().spline_logprob_grad(*self.native(), x.detach().contiguous().float(), bool(with_grad))
+        return lq, (g if with_grad else None)
+
+    # ---- packing -----------------------------------------------------------------------------------------------------
+    def _structure(self):
+        """[(coupling module, pre_shift or None, pre_wrap, post_shift or None)] in layer order."""
+        out = []
+        flows = list(self._nf_model.flows)
+        couplings = [(i, f) for i, f in enumerate(flows) if isinstance(f, _Coupling)]
+        for n, (i, f) in enumerate(couplings):
+            nxt = flows[i + 1] if i + 1 < len(flows) else None
+            post = nxt if isinstance(nxt, _PeriodicShift) else None       # PeriodicShift right after this coupling
+            is_last = n == len(couplings) - 1
+            wrap = flows[-1] if (is_last and isinstance(flows[-1], _PeriodicWrap)) else None
+            out.append((f, post, wrap))
+        return out
+
+    def _param_list(self):
+        dev = self._tail_bound.device
+        D = self.dim
+        tensors = []
+        for f, post, wrap in self._structure():
+            pr = f.prqct
+            net = pr.transform_net
+            idf, trf = pr.identity_features.tolist(), pr.transform_features.tolist()
+            meta = torch.zeros(12, 64)
+            meta[0, :] = -1; meta[1, :] = -1
+            meta[0, :len(idf)] = torch.tensor(idf, dtype=torch.float32)
+            meta[1, :len(trf)] = torch.tensor(trf, dtype=torch.float32)
+            meta[2, :D] = self._circ.float().cpu()
+            meta[3, :D] = self._tail_bound.cpu()
+            n_pf = 0
+            if net.preprocessing is not None:
+                pf = net.preprocessing
+                for k, i in enumerate(pf.ind.tolist()):
+                    meta[4, i] = 1.0; meta[5, i] = float(pf.scale[k]); meta[6, i] = float(k)
+                n_pf = len(pf.ind)
+            # log_prob direction, BEFORE this layer: the inverse of the PeriodicShift that follows it / the final wrap
+            if post is not None:
+                meta[7, post.ind.cpu()] = post.shift.cpu().expand(len(post.ind)); meta[8, post.ind.cpu()] = 1.0
+                meta[9, post.ind.cpu()] = post.shift.cpu().expand(len(post.ind)); meta[10, post.ind.cpu()] = 1.0
+            if wrap is not None:
+                meta[8, wrap.ind.cpu()] = 1.0                         # shift 0: PeriodicWrap.inverse
+            meta[11, 0], meta[11, 1], meta[11, 2] = len(idf), len(trf), n_pf
+            u = pr.unconditional_transform
+            tensors += [meta.to(dev), net.initial_layer.weight, net.initial_layer.bias,
+                        net.blocks[0].linear_layers[0].weight, net.blocks[0].linear_layers[0].bias,
+                        net.blocks[0].linear_layers[1].weight, net.blocks[0].linear_layers[1].bias,
+                        net.final_layer.weight, net.final_layer.bias,
+                        net.preprocessing.weights if net.preprocessing is not None else torch.zeros(0, device=dev),
+                        u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives]
+        q0 = self._nf_model.q0
+        return tensors + [q0.scale, q0.circ.float()]
+
+    def native(self):
+        """(packed image, dim, n_layers, hidden): the flow arguments of torch.ops.fabhip.spline_*; re-packed whenever a
+        parameter changed."""
+        ops = _ops.load()
+        _ops.require_device(self._tail_bound, "spline flow parameters")
+        params = [p for p in self.parameters()] + [b for b in self.buffers()]
+        key = tuple((t.data_ptr(), t._version) for t in params)
+        if key != self._packed_key:
+            n = ops.spline_packed_floats(self.dim, self.n_layers, self.hidden)
+            if n < 0:
+                raise _ops.FabhipError(f"spline flow shape not supported: dim={self.dim} hidden={self.hidden}")
+            if self._packed is None or self._packed.numel() != n or self._packed.device != self._tail_bound.device:
+                self._packed = torch.empty(n, dtype=torch.float32, device=self._tail_bound.device)
+            with torch.no_grad():
+                ops.spline_pack([t.detach().contiguous().float() for t in self._param_list()], self.dim, self.n_layers,
+                                self.hidden, self._packed)
+            self._packed_key = key
+        return self._packed, self.dim, self.n_layers, self.hidden
+
+
+def make_wrapped_normflow_spline(dim: int, n_layers: int, hidden_units: int, ind_circ: Sequence[int], tail_bound,
+                                 seed: int = 0, circ_shift: str = "random", init_identity: bool = True
+                                 ) -> CircularCoupledRQSFlow:
+    """The 'circular-coup-nsf' branch of experiments/make_flow/make_aldp_model.py:121-134 behind the `Distribution`
+    interface of fab/wrappers/normflows.py."""
+    return CircularCoupledRQSFlow(dim, n_layers, hidden_units, ind_circ, tail_bound, seed=seed, circ_shift=circ_shift,
+                                  init_identity=init_identity)

@@ -94,6 +94,61 @@ int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, 
                          fabhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Circular / linear-tail rational-quadratic spline COUPLING flow (the alanine-dipeptide flow of
+ * experiments/make_flow/make_aldp_model.py:57-71,121-134,146-167: n_layers x normflows
+ * CircularCoupledRationalQuadraticSpline(dim, 1 block, hidden, ind_circ, tail_bound, 8 bins, mask) with PeriodicShift /
+ * PeriodicWrap layers and a UniformGaussian base; replaces NormalizingFlow.log_prob / .sample behind
+ * fab/wrappers/normflows.py:16-31).  dim <= 64, hidden <= 256, 8 bins, one residual block per conditioner.
+ *
+ * Per layer, raw parameters in normflows / nn.Linear layout (weight[out][in]):
+ *   w0 [hidden][n_id], b0 [hidden]            transform_net.initial_layer
+ *   wa, wb [hidden][hidden], ba, bb [hidden]  transform_net.blocks.0.linear_layers.{0,1}
+ *   wf [25 n_tr][hidden], bf [25 n_tr]        transform_net.final_layer (per transformed coordinate: 8 widths, 8 heights,
+ *                                             9 knot derivatives)
+ *   pfw [n_pf][2] (may be NULL)               transform_net.preprocessing.weights (periodic features)
+ *   uw, uh [n_id][8], ud [n_id][9]            unconditional_transform.unnormalized_{widths,heights,derivatives}
+ *   meta [12][64] floats: row 0 identity coordinate indices (n_id valid), 1 transformed coordinate indices (n_tr valid),
+ *     2 circular flag per coordinate, 3 tail bound per coordinate, 4 periodic-feature flag per identity position,
+ *     5 its scale pi / bound, 6 its row in pfw, 7/8 shift and on-flag applied BEFORE this layer in the log_prob direction
+ *     (z <- wrap(z - shift): PeriodicShift.inverse / PeriodicWrap.inverse), 9/10 shift and on-flag applied AFTER this layer
+ *     in the sampling direction (PeriodicShift.forward), 11: {n_id, n_tr, n_pf}.
+ * base_scale [dim], base_circ [dim] (0/1): UniformGaussian (uniform on [-scale/2, scale/2] for circular coordinates).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t dim, n_layers, hidden;
+    const float* meta[FABHIP_MAX_LAYERS];
+    const float* w0[FABHIP_MAX_LAYERS];
+    const float* b0[FABHIP_MAX_LAYERS];
+    const float* wa[FABHIP_MAX_LAYERS];
+    const float* ba[FABHIP_MAX_LAYERS];
+    const float* wb[FABHIP_MAX_LAYERS];
+    const float* bb[FABHIP_MAX_LAYERS];
+    const float* wf[FABHIP_MAX_LAYERS];
+    const float* bf[FABHIP_MAX_LAYERS];
+    const float* pfw[FABHIP_MAX_LAYERS];
+    const float* uw[FABHIP_MAX_LAYERS];
+    const float* uh[FABHIP_MAX_LAYERS];
+    const float* ud[FABHIP_MAX_LAYERS];
+    const float* base_scale;
+    const float* base_circ;
+} fabhip_spline_params;
+
+typedef struct {
+    int32_t dim, n_layers, hidden;
+    const float* packed; /* fabhip_spline_pack output */
+} fabhip_spline_flow;
+
+int64_t fabhip_spline_packed_floats(int32_t dim, int32_t n_layers, int32_t hidden);
+int fabhip_spline_pack(const fabhip_spline_params* params, float* packed, fabhip_stream_t stream);
+size_t fabhip_spline_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B, int32_t with_grad);
+/* log_q[B] = flow.log_prob(x[B][dim]) and, if grad_x != NULL, d log_q / dx [B][dim] (reverse sweep through all layers). */
+int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                           void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+/* x, log_q = flow.sample given u[B][dim] ~ U(0,1) (circular coordinates) and eps[B][dim] ~ N(0,1) (the others). */
+int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const float* eps, float* x, float* log_q,
+                         int64_t B, void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Flow training path — the backward of `flow.log_prob(x)` w.r.t. the parameters, i.e. what
  * `loss.backward()` does in fab/train_with_prioritised_buffer.py:162-177 (loss = -mean(w_adjust * log_q_x))
  * and for fab/core.py:112-118 (fab_alpha_div_inner).  Two calls:

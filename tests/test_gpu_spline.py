@@ -1,0 +1,116 @@
+"""RQ-spline coupling flow (R9s): HIP kernels (torch.ops.fabhip.spline_*) against oracle/spline.py on the same
+parameters and noise - log q, d log q / dx, samples; the alanine-dipeptide shape (60-D, 12 layers, hidden 256, 8 bins,
+12 circular coordinates); HMC transitions on a 60-D target through the generic plug-in path, per transition vs the
+oracle.  (normflows is absent from the reference: the oracle is the specification, parity with the reference unpinned.)"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import close, worst, RTOL
+
+pytestmark = pytest.mark.gpu
+
+fa = pytest.importorskip("fab_torch_amd")
+from oracle import ais as oais            # noqa: E402
+from oracle import spline as osp          # noqa: E402
+from oracle import targets as otgt        # noqa: E402
+
+DEV = "cuda"
+
+
+def make_pair(D, L, hidden, circ, seed, std=0.4):
+    tb = torch.full((D,), 5.0)
+    g = torch.Generator().manual_seed(seed)
+    tb[list(circ)] = math.pi / (0.5 + torch.rand(len(circ), generator=g))
+    of = osp.make_circular_coupled_flow(D, L, hidden, circ, tb, seed=seed)
+    osp.randomize(of, std, seed + 1)
+    hf = fa.CircularCoupledRQSFlow(D, L, hidden, circ, tb, seed=seed)
+    missing = hf._nf_model.load_state_dict(of.state_dict(), strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return of, hf.to(DEV).requires_grad_(False)
+
+
+CASES = [(8, 4, 64, (1, 4, 6), 100), (6, 3, 32, (), 64), (7, 5, 128, (0, 6), 33),
+         (60, 12, 256, (3, 7, 8, 12, 20, 21, 22, 30, 41, 45, 52, 59), 48)]
+
+
+@pytest.mark.parametrize("D,L,hidden,circ,B", CASES)
+def test_spline_flow_log_prob_grad_and_sample_vs_oracle(D, L, hidden, circ, B):
+    of, hf = make_pair(D, L, hidden, circ, seed=D + L)
+    g = torch.Generator().manual_seed(5)
+    u, eps = torch.rand(B, D, generator=g), torch.randn(B, D, generator=g)
+    with torch.no_grad():
+        x_o, lq_s_o = of.sample_eps(u, eps)
+    x_h, lq_s_h = hf.sample_and_log_prob((B,), u=u.to(DEV), eps=eps.to(DEV))
+    assert close(x_h, x_o, RTOL), f"sample x: {worst(x_h, x_o):.2f}x tol"
+    assert close(lq_s_h, lq_s_o, RTOL), f"sample log q: {worst(lq_s_h, lq_s_o):.2f}x tol"
+    # density + gradient at perturbed points (incl. points outside the tail bound and beyond the period)
+    x = x_o + 0.3 * torch.randn(B, D, generator=g)
+    x[0] = 7.0
+    if len(circ):
+        x[1, list(circ)] += 4 * math.pi
+    xg = x.clone().requires_grad_(True)
+    lq_o = of.log_prob(xg)
+    (g_o,) = torch.autograd.grad(lq_o.sum(), xg)
+    lq_h, g_h = hf.log_prob_and_grad(x.to(DEV))
+    assert close(lq_h, lq_o.detach(), RTOL), f"log q: {worst(lq_h, lq_o.detach()):.2f}x tol"
+    assert close(g_h, g_o, RTOL, atol_scale=10), f"grad: {worst(g_h, g_o):.2f}x tol"
+    # log_prob of the flow's own samples returns the sampling log q; autograd w.r.t. x goes through the kernels
+    assert close(hf.log_prob(x_h), lq_s_h, RTOL)
+    xd = x.to(DEV).requires_grad_(True)
+    (ga,) = torch.autograd.grad(hf.log_prob(xd).sum(), xd)
+    assert torch.equal(ga, g_h)
+    # deterministic
+    lq2, g2 = hf.log_prob_and_grad(x.to(DEV))
+    assert torch.equal(lq2, lq_h) and torch.equal(g2, g_h)
+
+
+def test_identity_initialised_spline_flow_is_the_base_distribution():
+    D, circ = 10, (2, 5)
+    tb = torch.full((D,), 5.0); tb[list(circ)] = math.pi
+    hf = fa.make_wrapped_normflow_spline(D, 4, 64, circ, tb, circ_shift=None).to(DEV)
+    x, lq = hf.sample_and_log_prob((256,))
+    assert hf.event_shape == (D,) and x.shape == (256, D)
+    base = -0.5 * math.log(2 * math.pi) * (D - 2) - 0.5 * (x[:, [i for i in range(D) if i not in circ]] ** 2).sum(1) \
+        - 2 * math.log(2 * math.pi)
+    assert close(lq, base, RTOL) and close(hf.log_prob(x), lq, RTOL)
+    assert float(x[:, list(circ)].abs().max()) <= math.pi + 1e-5
+
+
+def test_hmc_transitions_with_the_spline_flow_on_a_60d_target_vs_oracle():
+    """BASELINE cfg 5's shape with the flow family it names: 60-D, spline flow 12 layers / hidden 256 / 8 bins / 12
+    circular coordinates, HMC with 10 leapfrogs (OpenMM's alanine-dipeptide energy is unobtainable offline: the target
+    is the 60-D ManyWell stand-in).  The flow is a non-RealNVP plug-in -> the transitions run through the generic
+    path (HIP elementwise kernels + the spline kernels for the density / gradient)."""
+    D, L, hidden, M, B, LF = 60, 12, 256, 4, 32, 10
+    circ = (3, 7, 8, 12, 20, 21, 22, 30, 41, 45, 52, 59)
+    of, hf = make_pair(D, L, hidden, circ, seed=9, std=0.2)
+    target, otarget = fa.ManyWellEnergy(D), otgt.ManyWell(D)
+    hop = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05, L=LF,
+                                   eval_mode=True).to(DEV)
+    assert not hop.is_native
+    oop = oais.HMC(M, D, of.log_prob, otarget.log_prob, alpha=2.0, p_target=False, epsilon=0.05, L=LF, eval_mode=True)
+    g = torch.Generator().manual_seed(3)
+    u, eps = torch.rand(B, D, generator=g), torch.randn(B, D, generator=g)
+    noise_p = torch.randn(M, 1, B, D, generator=g); noise_e = torch.empty(M, 1, B).exponential_(generator=g)
+    with torch.no_grad():
+        x0, _ = of.sample_eps(u, eps)
+    pt = oais.create_point(x0, of.log_prob, otarget.log_prob, with_grad=True)
+    betas = oais.beta_schedule(M, "linear")
+    for j in range(1, M + 1):
+        hp = fa.Point(pt.x.clone().to(DEV), pt.log_q.clone().to(DEV), pt.log_p.clone().to(DEV),
+                      pt.grad_log_q.clone().to(DEV), pt.grad_log_p.clone().to(DEV))
+        lw_h = torch.zeros(B, device=DEV)
+        hop.transition(hp, j, float(betas[j]), log_w=lw_h, beta_next=float(betas[j + 1]), noise_p=noise_p[j - 1].to(DEV),
+                       noise_e=noise_e[j - 1].to(DEV))
+        ref = oop.transition(pt.clone(), j, betas[j], noise_p[j - 1], noise_e[j - 1])
+        scale = max(1.0, float(ref.x.abs().max()))
+        err = (hp.x.cpu() - ref.x).abs().max(1).values / scale
+        ok = err <= 1e-4
+        assert int((~ok).sum()) <= 2, f"transition {j}: {int((~ok).sum())} chains differ (max {float(err.max()):.2e})"
+        assert close(hp.log_q.cpu()[ok], ref.log_q[ok], RTOL) and close(hp.log_p.cpu()[ok], ref.log_p[ok], RTOL)
+        lw_ref = (oais.intermediate_log_prob(ref, betas[j + 1], 2.0, False) - oais.intermediate_log_prob(ref, betas[j], 2.0, False))
+        assert close(lw_h.cpu()[ok], lw_ref[ok].detach(), RTOL, atol=1e-3)
+        pt = ref
