@@ -143,6 +143,8 @@ def _declare(lib):
     lib.fabhip_flow_tape_bytes.argtypes = [i32, i32, i32, i64]
     lib.fabhip_generic_workspace_bytes.restype = sz
     lib.fabhip_generic_workspace_bytes.argtypes = [i64, i32]
+    lib.fabhip_spline_packed_floats.restype = i64
+    lib.fabhip_spline_packed_floats.argtypes = [i32, i32, i32]
     lib.fabhip_flow_tape_layout.argtypes = [i32, i32, i32, i64, C.POINTER(i64)]
     lib.fabhip_flow_log_prob_tape.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp, sz, vp]
     lib.fabhip_flow_param_grad.argtypes = [C.POINTER(FlowParams), C.POINTER(Flow), vp, sz, vp, i64, vp, vp]

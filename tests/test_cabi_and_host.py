@@ -135,3 +135,21 @@ def test_state_dict_is_normflows_compatible_and_cpu_calls_fail_loudly():
                  lambda: flow.sample_and_log_prob((16,), eps=torch.randn(16, 6))):
         with pytest.raises(FabhipError):              # parameters on the CPU / x on the CPU: no ATen fallback
             call()
+
+
+def test_spline_flow_module_has_normflows_keys_and_fails_loudly_on_the_cpu():
+    import math
+    from oracle import spline as osp
+    tb = torch.full((10,), 5.0); tb[[2, 7]] = math.pi
+    of = osp.make_circular_coupled_flow(10, 4, 32, (2, 7), tb, seed=3)
+    hf = fa.CircularCoupledRQSFlow(10, 4, 32, (2, 7), tb, seed=3)
+    assert set(hf._nf_model.state_dict()) == set(of.state_dict())
+    hf._nf_model.load_state_dict(of.state_dict())
+    assert hf.event_shape == (10,)
+    lib = _lib.load()
+    assert lib.fabhip_spline_packed_floats(60, 12, 256) > 12 * 2 * (30 * 256 + 2 * 256 * 256 + 256 * 750)
+    assert lib.fabhip_spline_packed_floats(65, 2, 64) == -1 and lib.fabhip_spline_packed_floats(60, 2, 257) == -1
+    with pytest.raises(_lib.FabhipError):
+        hf.log_prob(torch.randn(4, 10))
+    with pytest.raises(NotImplementedError):
+        fa.CircularCoupledRQSFlow(10, 4, 32, (2, 7), tb, num_bins=4)
