@@ -262,7 +262,7 @@ def test_ess_logz_vs_golden():
 
 def test_multinomial_torch_compat_bit_exact_vs_reference():
     g = load_golden("g5_multinomial.npz")
-    for N in (64, 1024, 4096):
+    for N in (64, 1024, 4096, 16384):                     # 16384 = BASELINE cfg 4's gathered particle count
         idx = fa.multinomial_torch_compat(torch.tensor(g[f"probs_{N}"]).to(DEV), torch.tensor(g[f"u_{N}"]).to(DEV))
         np.testing.assert_array_equal(idx.cpu().numpy(), g[f"idx_{N}"])
 

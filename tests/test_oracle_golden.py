@@ -75,7 +75,7 @@ def test_g4_ess_logz():
 
 def test_g5_multinomial_bit_exact_vs_reference_resample():
     g = load_golden("g5_multinomial.npz")
-    for N in (64, 1024, 4096):
+    for N in (64, 1024, 4096, 16384):
         probs = onum.categorical_probs(torch.tensor(g[f"lw_{N}"])).numpy()
         np.testing.assert_array_equal(probs, g[f"probs_{N}"])
         idx = onum.multinomial_torch_compat(g[f"probs_{N}"], g[f"u_{N}"])
