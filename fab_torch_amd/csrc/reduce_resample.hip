@@ -53,13 +53,52 @@ __device__ __forceinline__ Msum msum_block_reduce(Msum v, Msum* sh) {
 constexpr int ESS_THREADS = 256;
 constexpr int ESS_MAX_BLOCKS = 1024;
 
+// chunk of values -> (max, sum exp(x - max), sum exp(2 (x - max))) with ONE rescale per chunk: the max is taken in fp32
+// first, the exponentials are fp32 (1e-7 relative) and summed in fp32 over the <= 16 values of the chunk, the running
+// totals are float64.  Same special values as torch's softmax: NaN or +inf anywhere -> NaN, -inf -> weight 0.
+template <int NV>
+__device__ __forceinline__ Msum msum_push_chunk(const Msum& a, const float (&x)[NV]) {
+    float m = -INFINITY;
+    bool bad = false;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { bad |= (x[i] != x[i]) | (x[i] == INFINITY); m = fmaxf(m, x[i]); }
+    if (bad || a.m != a.m) return Msum{NAN, NAN, NAN};
+    if (m == -INFINITY) return a;                       // every weight of the chunk is zero
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const float e = expf(x[i] - m); s1 += e; s2 += e * e; }
+    const double md = (double)m;
+    if (md <= a.m) {
+        const double r = (double)expf((float)(md - a.m));
+        return Msum{a.m, a.s1 + r * (double)s1, a.s2 + r * r * (double)s2};
+    }
+    const double r = (double)expf((float)(a.m - md));   // a.m == -inf -> 0
+    return Msum{md, a.s1 * r + (double)s1, a.s2 * r * r + (double)s2};
+}
+
 __global__ __launch_bounds__(ESS_THREADS) void k_ess_partial(const float* __restrict__ lw, long n_cap, const int* n_ptr,
                                                              Msum* __restrict__ part) {
     __shared__ Msum sh[ESS_THREADS];
     const long n = n_ptr ? (long)*n_ptr : n_cap;
     Msum v = msum_id();
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
-        v = msum_push(v, (double)lw[i]);
+    const long stride = (long)gridDim.x * blockDim.x;
+    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long done = 0;
+    if ((((size_t)lw) & 15) == 0) {                     // 16 values per thread per step: four coalesced 16-byte loads
+        const long n16 = n / (16 * stride) * (16 * stride);
+        const float4* p4 = reinterpret_cast<const float4*>(lw);
+        for (long base = 0; base < n16; base += 16 * stride) {
+            float x[16];
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const float4 q = p4[(base >> 2) + h * stride + tid];
+                x[4 * h] = q.x; x[4 * h + 1] = q.y; x[4 * h + 2] = q.z; x[4 * h + 3] = q.w;
+            }
+            v = msum_push_chunk<16>(v, x);
+        }
+        done = n16;
+    }
+    for (long i = done + tid; i < n; i += stride) v = msum_push(v, (double)lw[i]);
     v = msum_block_reduce(v, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = v;
 }
