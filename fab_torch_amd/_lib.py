@@ -94,9 +94,9 @@ SYMBOLS = [
     "fabhip_hmc_generic_leap_post", "fabhip_hmc_generic_accept", "fabhip_anneal_log_prob", "fabhip_log_w_update",
     "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept", "fabhip_fixed_cdf",
     "fabhip_spline_packed_floats", "fabhip_spline_pack", "fabhip_spline_workspace_bytes", "fabhip_spline_log_prob",
-    "fabhip_spline_sample",
+    "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
 ]
-ABI_VERSION = 200          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 201          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):
@@ -145,6 +145,7 @@ def _declare(lib):
     lib.fabhip_generic_workspace_bytes.argtypes = [i64, i32]
     lib.fabhip_spline_packed_floats.restype = i64
     lib.fabhip_spline_packed_floats.argtypes = [i32, i32, i32]
+    lib.fabhip_spline_tape_layout.argtypes = [i32, i32, i32, i64, C.POINTER(i64)]
     lib.fabhip_flow_tape_layout.argtypes = [i32, i32, i32, i64, C.POINTER(i64)]
     lib.fabhip_flow_log_prob_tape.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp, sz, vp]
     lib.fabhip_flow_param_grad.argtypes = [C.POINTER(FlowParams), C.POINTER(Flow), vp, sz, vp, i64, vp, vp]

@@ -76,6 +76,33 @@ static inline int check_spline_shape(int D, int L, int W) {
     return FABHIP_OK;
 }
 
+// Training tape of one log_prob call (fabhip_spline_log_prob_tape): per coupling layer, row-major [B][width] matrices
+// of the conditioner's activations and of the reverse sweep's cotangents (seed 1 per sample).  The weight gradients
+// are sum_b c_b (cotangent row)^T (activation row): GEMMs over these matrices, done by the caller (rocBLAS through
+// torch.mm in fab_torch_amd/spline_flow.py) with the per-sample coefficient c_b folded into the cotangent rows.
+struct SplineTape {
+    float* base;                          // nullptr: no tape
+    long o_XI, o_A0, o_dA0;               // [B][64]: raw identity coordinates, after the periodic features, cotangent of A0
+    long o_R0, o_R1, o_H1;                // [B][Wp]: relu(h0), relu(t), h1
+    long o_dH1, o_dT, o_dH0;              // [B][Wp]: cotangents of h1, of t (masked), of h0
+    long o_dP;                            // [B][NFP]: cotangent of the conditioner output
+    long o_dU;                            // [B][64 * 25]: cotangent of the unconditional parameters per identity position
+    long layer_stride;
+};
+
+static inline SplineTape make_spline_tape(const SplineDims& f, long B, float* base) {
+    SplineTape t;
+    t.base = base;
+    long o = 0;
+    t.o_XI = o; o += B * 64; t.o_A0 = o; o += B * 64; t.o_dA0 = o; o += B * 64;
+    t.o_R0 = o; o += B * f.Wp; t.o_R1 = o; o += B * f.Wp; t.o_H1 = o; o += B * f.Wp;
+    t.o_dH1 = o; o += B * f.Wp; t.o_dT = o; o += B * f.Wp; t.o_dH0 = o; o += B * f.Wp;
+    t.o_dP = o; o += B * f.NFP;
+    t.o_dU = o; o += B * (long)(SP_MD * SP_NP);
+    t.layer_stride = o;
+    return t;
+}
+
 // ------------------------------------------------------------------------------------------------
 // packing
 // ------------------------------------------------------------------------------------------------
@@ -213,6 +240,15 @@ __device__ __forceinline__ void sp_load_identity(const SplineDims& f, const floa
     }
 }
 
+// tape: rows of an LDS tile [16][ld] (first `width` columns) -> dst [B][width]
+__device__ __forceinline__ void sp_tape_rows(float* __restrict__ dst, int width, const float* src, int ld, long row0, long B,
+                                             const Tid& t) {
+    for (int e = t.tid; e < ROWS * width; e += NTHREADS) {
+        const int r = e / width, c = e % width;
+        if (row0 + r < B) dst[(row0 + r) * width + c] = src[r * ld + c];
+    }
+}
+
 // h0 = A0 W0 + b0 (kept raw in H0), t = relu(h0) Wa + ba (kept raw in T), h1 = h0 + relu(t) Wb + bb -> X1
 template <int NTWM>
 __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds& l, const float* __restrict__ Lp, float* lds,
@@ -285,13 +321,15 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_fwd(SplineDims f, NetLd
 template <int NTWM>
 __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLds l, const float* __restrict__ packed,
                                                              int layer, const float* __restrict__ Z,
-                                                             const float* __restrict__ dP, float* __restrict__ G, long B) {
+                                                             const float* __restrict__ dP, float* __restrict__ G, long B,
+                                                             SplineTape tp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid t;
     constexpr int DW = depth_w<NTWM>();
     const float* Lp = packed + (size_t)layer * f.layer_stride;
     const float* meta = Lp + f.o_meta;
     const long row0 = (long)blockIdx.x * ROWS;
+    float* tl = tp.base ? tp.base + (size_t)layer * tp.layer_stride : nullptr;
     float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
     float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* DP = lds + l.o_DP; float* PART = lds + l.o_PART;
     sp_load_identity(f, Lp, Z, row0, B, A0, l.AS, t);
@@ -302,6 +340,16 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
     }
     __syncthreads();
     sp_net_hidden<NTWM>(f, l, Lp, lds, t);              // recompute h0 (H0) and t (T): the ReLU decisions
+    if (tl) {
+        sp_tape_rows(tl + tp.o_A0, 64, A0, l.AS, row0, B, t);
+        sp_tape_rows(tl + tp.o_R0, f.Wp, X2, l.WS, row0, B, t);
+        sp_tape_rows(tl + tp.o_H1, f.Wp, X1, l.WS, row0, B, t);
+        for (int e = t.tid; e < ROWS * f.Wp; e += NTHREADS) {
+            const int r = e / f.Wp, c = e % f.Wp;
+            if (row0 + r < B) { const float v = T[r * l.WS + c]; tl[tp.o_R1 + (row0 + r) * f.Wp + c] = v > 0.f ? v : 0.f; }
+        }
+        __syncthreads();
+    }
     f32x4 acc[NTWM];
     // dh1 = dP WfT  -> X1
     sp_gemm<NTWM, DW, false>(DP, l.PS, f.NFP / 16, reinterpret_cast<const float4*>(Lp + f.o_WfT), nullptr, t, acc);
@@ -311,6 +359,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
 #pragma unroll
         for (int r = 0; r < 4; ++r) X1[(4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n] = acc[i][r];
     __syncthreads();
+    if (tl) sp_tape_rows(tl + tp.o_dH1, f.Wp, X1, l.WS, row0, B, t);
     // d relu(t) = dh1 WbT, masked by t > 0 -> X2
     sp_gemm<NTWM, DW, false>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WbT), nullptr, t, acc);
 #pragma unroll
@@ -321,6 +370,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
             X2[o] = T[o] > 0.f ? acc[i][r] : 0.f;
         }
     __syncthreads();
+    if (tl) sp_tape_rows(tl + tp.o_dT, f.Wp, X2, l.WS, row0, B, t);
     // dh0 = dh1 + (dt WaT) masked by h0 > 0 -> T
     sp_gemm<NTWM, DW, false>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WaT), nullptr, t, acc);
     __syncthreads();
@@ -332,6 +382,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
             T[o] = X1[o] + (H0[o] > 0.f ? acc[i][r] : 0.f);
         }
     __syncthreads();
+    if (tl) sp_tape_rows(tl + tp.o_dH0, f.Wp, T, l.WS, row0, B, t);
     // dA0 = dh0 W0T (N = 64: K-split over the waves)
     gemm_ksplit<NTWM>(T, l.WS, reinterpret_cast<const float4*>(Lp + f.o_W0T), 4, PART, l.AS, t);
     __syncthreads();
@@ -339,9 +390,11 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
     for (int e = t.tid; e < ROWS * 64; e += NTHREADS) {
         const int r = e >> 6, i = e & 63;
         const long g = row0 + r;
+        if (tl && g < B && i >= n_id) { tl[tp.o_XI + g * 64 + i] = 0.f; tl[tp.o_dA0 + g * 64 + i] = 0.f; }
         if (i < n_id && g < B) {
             float d = part_sum(PART, l.AS, r, i);
             const int feat = (int)meta[M_IDF * 64 + i];
+            if (tl) { tl[tp.o_XI + g * 64 + i] = Z[g * f.D + feat]; tl[tp.o_dA0 + g * 64 + i] = d; }
             if (meta[M_PFON * 64 + i] != 0.f) {
                 const int k = (int)meta[M_PFK * 64 + i];
                 const float s = meta[M_PFS * 64 + i], x = Z[g * f.D + feat];
@@ -628,7 +681,7 @@ __global__ __launch_bounds__(256) void k_spline_base_sample(SplineDims f, const 
 __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const float* __restrict__ packed, int layer,
                                                           const float* __restrict__ Zin, const float* __restrict__ P,
                                                           const float* __restrict__ Gout, float* __restrict__ Gin,
-                                                          float* __restrict__ dP, long B) {
+                                                          float* __restrict__ dP, long B, float* __restrict__ dU) {
     const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= B) return;
@@ -652,7 +705,14 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
 #pragma unroll
         for (int j = 0; j < SP_NP; ++j) p[j] = Lp[f.o_unc + pos_id * SP_NP + j];
         rqs_setup(p, circ, tb, s);
-        gx = rqs_backward(s, p, circ, z, tb, gy, 1.f, nullptr);
+        if (dU) {
+            float dp[SP_NP];
+            gx = rqs_backward(s, p, circ, z, tb, gy, 1.f, dp);
+#pragma unroll
+            for (int j = 0; j < SP_NP; ++j) dU[g * (SP_MD * SP_NP) + pos_id * SP_NP + j] = dp[j];
+        } else {
+            gx = rqs_backward(s, p, circ, z, tb, gy, 1.f, nullptr);
+        }
     } else if (pos_tr >= 0) {
 #pragma unroll
         for (int j = 0; j < SP_NP; ++j) {
@@ -670,14 +730,14 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
 
 template <int NTWM>
 static int launch_net(const SplineDims& f, const float* packed, int layer, const float* Z, float* P, const float* dP,
-                      float* G, long B, hipStream_t st) {
+                      float* G, long B, hipStream_t st, const SplineTape& tp) {
     const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
     const bool bwd = dP != nullptr;
     const NetLds l = make_net_lds(f, bwd);
     const size_t bytes = (size_t)l.total * 4;
     if (bwd) {
         FAB_TRY(set_max_lds((const void*)k_spline_net_bwd<NTWM>, bytes));
-        hipLaunchKernelGGL((k_spline_net_bwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, dP, G, B);
+        hipLaunchKernelGGL((k_spline_net_bwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, dP, G, B, tp);
     } else {
         FAB_TRY(set_max_lds((const void*)k_spline_net_fwd<NTWM>, bytes));
         hipLaunchKernelGGL((k_spline_net_fwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, P, B);
@@ -686,10 +746,10 @@ static int launch_net(const SplineDims& f, const float* packed, int layer, const
 }
 
 static int net(const SplineDims& f, const float* packed, int layer, const float* Z, float* P, const float* dP, float* G,
-               long B, hipStream_t st) {
-    if (f.NTWM == 1) return launch_net<1>(f, packed, layer, Z, P, dP, G, B, st);
-    if (f.NTWM == 2) return launch_net<2>(f, packed, layer, Z, P, dP, G, B, st);
-    if (f.NTWM == 4) return launch_net<4>(f, packed, layer, Z, P, dP, G, B, st);
+               long B, hipStream_t st, const SplineTape& tp = SplineTape{}) {
+    if (f.NTWM == 1) return launch_net<1>(f, packed, layer, Z, P, dP, G, B, st, tp);
+    if (f.NTWM == 2) return launch_net<2>(f, packed, layer, Z, P, dP, G, B, st, tp);
+    if (f.NTWM == 4) return launch_net<4>(f, packed, layer, Z, P, dP, G, B, st, tp);
     return FABHIP_ENOTSUP;
 }
 
@@ -732,8 +792,8 @@ size_t fabhip_spline_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidd
     return s + 256;
 }
 
-int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
-                           void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                                float* tape, void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
     if (!flow || !flow->packed || !x || !log_q || !workspace || B < 0) return FABHIP_EINVAL;
     FAB_TRY(check_spline_shape(flow->dim, flow->n_layers, flow->hidden));
     if (B == 0) return FABHIP_OK;
@@ -752,6 +812,7 @@ int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float
     }
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
+    const SplineTape tp = make_spline_tape(f, (long)B, tape);
     const dim3 wgrid((unsigned)((B + 3) / 4)), wblock(256);
     hipLaunchKernelGGL(k_spline_first_stage, dim3((unsigned)((B * f.D + 255) / 256 > 4096 ? 4096 : (B * f.D + 255) / 256)),
                        dim3(256), 0, st, f, pk, x, Z + (size_t)f.L * zs, log_q, (long)B);
@@ -766,13 +827,41 @@ int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float
         float* gin = Ga;                                 // cotangent of Z[0] (the base side): d log p0 / dz
         for (int l = 0; l < f.L; ++l) {
             float* out = (l == f.L - 1) ? grad_x : (gin == Ga ? Gb : Ga);
+            float* dPl = tape ? tape + (size_t)l * tp.layer_stride + tp.o_dP : dP;      // kept per layer on the tape
+            float* dUl = tape ? tape + (size_t)l * tp.layer_stride + tp.o_dU : nullptr;
             hipLaunchKernelGGL(k_spline_apply_bwd, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs,
-                               P + (size_t)l * ps, gin, out, dP, (long)B);
-            FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, dP, out, (long)B, st));
+                               P + (size_t)l * ps, gin, out, dPl, (long)B, dUl);
+            FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, dPl, out, (long)B, st, tp));
             gin = out;
         }
     }
     return check_launch();
+}
+
+int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                           void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    return spline_log_prob_impl(flow, x, log_q, grad_x, B, nullptr, workspace, workspace_bytes, stream);
+}
+
+int fabhip_spline_tape_layout(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B, int64_t out16[16]) {
+    if (!out16 || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_spline_shape(dim, n_layers, hidden));
+    const SplineDims f = make_spline_dims(dim, n_layers, hidden);
+    const SplineTape t = make_spline_tape(f, (long)B, nullptr);
+    const int64_t v[16] = {(int64_t)t.layer_stride * n_layers, t.layer_stride, t.o_XI, t.o_A0, t.o_dA0, t.o_R0, t.o_R1, t.o_H1,
+                           t.o_dH1, t.o_dT, t.o_dH0, t.o_dP, t.o_dU, f.Wp, f.NFP, SP_MD * SP_NP};
+    for (int i = 0; i < 16; ++i) out16[i] = v[i];
+    return FABHIP_OK;
+}
+
+int fabhip_spline_log_prob_tape(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                                float* tape, int64_t tape_floats, void* workspace, size_t workspace_bytes,
+                                fabhip_stream_t stream) {
+    if (!flow || !tape || !grad_x) return FABHIP_EINVAL;
+    int64_t lay[16];
+    FAB_TRY(fabhip_spline_tape_layout(flow->dim, flow->n_layers, flow->hidden, B, lay));
+    if (tape_floats < lay[0]) return FABHIP_ENOSPC;
+    return spline_log_prob_impl(flow, x, log_q, grad_x, B, tape, workspace, workspace_bytes, stream);
 }
 
 int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const float* eps, float* x, float* log_q,

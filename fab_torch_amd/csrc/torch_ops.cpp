@@ -267,6 +267,31 @@ std::tuple<Tensor, Tensor> spline_logprob_grad(const Tensor& packed, int64_t dim
     return {log_q, grad};
 }
 
+std::vector<int64_t> spline_tape_layout(int64_t dim, int64_t n_layers, int64_t hidden, int64_t B) {
+    std::vector<int64_t> out(16);
+    chk(fabhip_spline_tape_layout((int32_t)dim, (int32_t)n_layers, (int32_t)hidden, B, out.data()), "spline_tape_layout");
+    return out;
+}
+
+// log_q, d log_q / dx and the training tape (see fabhip_spline_tape_layout); the parameter gradients are GEMMs over
+// tape slices done in fab_torch_amd/spline_flow.py
+std::tuple<Tensor, Tensor, Tensor> spline_logprob_tape(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden,
+                                                       const Tensor& x) {
+    c10::DeviceGuard g(x.device());
+    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0);
+    int64_t lay[16];
+    chk(fabhip_spline_tape_layout(f.dim, f.n_layers, f.hidden, B, lay), "spline_tape_layout");
+    Tensor log_q = fempty({B}, x), grad = at::empty_like(x), tape = fempty({lay[0]}, x);
+    const size_t nb = fabhip_spline_workspace_bytes(f.dim, f.n_layers, f.hidden, B, 1);
+    Tensor ws = scratch(nb, x);
+    chk(fabhip_spline_log_prob_tape(&f, fp(x, "x"), log_q.data_ptr<float>(), grad.data_ptr<float>(), B,
+                                    tape.data_ptr<float>(), lay[0], aligned(ws), nb, stream_of(x)),
+        "spline_log_prob_tape");
+    return {log_q, grad, tape};
+}
+
 std::tuple<Tensor, Tensor> spline_sample(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden,
                                          const Tensor& u, const Tensor& eps) {
     c10::DeviceGuard g(u.device());
@@ -658,6 +683,8 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("spline_packed_floats(int dim, int n_layers, int hidden) -> int", spline_packed_floats);
     m.def("spline_pack(Tensor[] params, int dim, int n_layers, int hidden, Tensor(a!) packed) -> ()");
     m.def("spline_logprob_grad(Tensor packed, int dim, int n_layers, int hidden, Tensor x, bool with_grad) -> (Tensor, Tensor)");
+    m.def("spline_tape_layout(int dim, int n_layers, int hidden, int B) -> int[]", spline_tape_layout);
+    m.def("spline_logprob_tape(Tensor packed, int dim, int n_layers, int hidden, Tensor x) -> (Tensor, Tensor, Tensor)");
     m.def("spline_sample(Tensor packed, int dim, int n_layers, int hidden, Tensor u, Tensor eps) -> (Tensor, Tensor)");
     m.def("target_logp_grad(" TGT ", Tensor x, bool with_grad) -> (Tensor, Tensor)");
     m.def("manywell_logp_grad(Tensor x, float a, float b, float c, float log_norm) -> (Tensor, Tensor)");
@@ -713,6 +740,7 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("adam_clip_step", adam_clip_step);
     m.impl("spline_pack", spline_pack);
     m.impl("spline_logprob_grad", spline_logprob_grad);
+    m.impl("spline_logprob_tape", spline_logprob_tape);
     m.impl("spline_sample", spline_sample);
     m.impl("target_logp_grad", target_logp_grad);
     m.impl("manywell_logp_grad", manywell_logp_grad);

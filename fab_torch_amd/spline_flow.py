@@ -14,8 +14,15 @@ SURVEY.md section 8f-4.  normflows is absent from the reference tree: the arithm
 
 `log_prob`, its gradient w.r.t. x and `sample_and_log_prob` run on the GPU through torch.ops.fabhip.spline_*; the
 sampler drives this flow through the generic plug-in path of the transition operators (`log_prob` is differentiable
-w.r.t. x through a custom autograd Function whose backward is the kernels' own reverse sweep).  Parameter gradients
-(training this flow family) are not built."""
+w.r.t. x through a custom autograd Function whose backward is the kernels' own reverse sweep).
+
+Training (`loss.backward()` through `log_prob`, the forward-KL term of the FAB loss, fab/core.py:114-127 /
+fab/train_with_prioritised_buffer.py:160-171): when a parameter requires grad, `log_prob` runs
+`fabhip::spline_logprob_tape`, which also writes the conditioner activations and the reverse sweep's cotangents of every
+layer to a tape; the backward turns them into the parameter gradients with one rocBLAS GEMM per Linear (torch.mm over
+tape slices, the upstream coefficient folded into the cotangent rows) - no ATen re-implementation of the flow exists.
+The sampling direction is not differentiable w.r.t. the parameters (the reverse-KL style baseline losses are built for
+the RealNVP family only)."""
 import math
 from typing import Sequence, Tuple
 
@@ -137,6 +144,26 @@ class _SplineLogProb(torch.autograd.Function):
         return None, grad_out[:, None] * g
 
 
+class _SplineLogProbTape(torch.autograd.Function):
+    """log q(x) with gradients w.r.t. x AND the flow parameters (`params` = flow._train_params(), passed only so that
+    autograd routes the gradients to them)."""
+
+    @staticmethod
+    def forward(ctx, flow, x, *params):
+        xd = x.detach().contiguous().float()
+        lq, gx, tape = _ops.load().spline_logprob_tape(*flow.native(), xd)
+        ctx.flow, ctx.B = flow, xd.shape[0]
+        ctx.save_for_backward(gx, tape)
+        return lq
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        gx, tape = ctx.saved_tensors
+        c = grad_out.detach().float().contiguous()
+        grads = ctx.flow._param_grads_from_tape(tape, c, ctx.B)
+        return (None, c[:, None] * gx if ctx.needs_input_grad[1] else None, *grads)
+
+
 class CircularCoupledRQSFlow(nn.Module):
     def __init__(self, dim: int, n_layers: int, hidden_units: int, ind_circ: Sequence[int], tail_bound,
                  num_bins: int = 8, blocks_per_layer: int = 1, seed: int = 0, circ_shift: str = "random",
@@ -199,9 +226,56 @@ class CircularCoupledRQSFlow(nn.Module):
 
     def log_prob(self, x: torch.Tensor) -> torch.Tensor:
         _ops.require_device(x, "x")
-        if torch.is_grad_enabled() and x.requires_grad:
-            return _SplineLogProb.apply(self, x)
+        if torch.is_grad_enabled():
+            params = self._train_params()
+            if any(p.requires_grad for p in params):
+                return _SplineLogProbTape.apply(self, x, *params)
+            if x.requires_grad:
+                return _SplineLogProb.apply(self, x)
         return self.native_log_prob(x)[0]
+
+    # ---- training: parameter gradients from the kernels' tape ---------------------------------------------------------
+    def _train_params(self):
+        """The trainable tensors in the order `_param_grads_from_tape` returns their gradients."""
+        out = []
+        for f, _, _ in self._structure():
+            net, u = f.prqct.transform_net, f.prqct.unconditional_transform
+            out += [net.initial_layer.weight, net.initial_layer.bias,
+                    net.blocks[0].linear_layers[0].weight, net.blocks[0].linear_layers[0].bias,
+                    net.blocks[0].linear_layers[1].weight, net.blocks[0].linear_layers[1].bias,
+                    net.final_layer.weight, net.final_layer.bias]
+            if net.preprocessing is not None:
+                out.append(net.preprocessing.weights)
+            out += [u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives]
+        return out
+
+    def _param_grads_from_tape(self, tape: torch.Tensor, c: torch.Tensor, B: int):
+        """d (sum_b c_b log q(x_b)) / d parameter for every tensor of `_train_params()` (tape layout: include/fabhip.h,
+        fabhip_spline_tape_layout)."""
+        lay = _ops.load().spline_tape_layout(self.dim, self.n_layers, self.hidden, B)
+        stride, (o_xi, o_a0, o_da0, o_r0, o_r1, o_h1, o_dh1, o_dt, o_dh0, o_dp, o_du), Wp, NFP, UW = \
+            lay[1], lay[2:13], lay[13], lay[14], lay[15]
+        W, NP = self.hidden, 3 * NUM_BINS + 1
+        cc = c[:, None]
+        grads = []
+        for l, (f, _, _) in enumerate(self._structure()):
+            pr, net = f.prqct, f.prqct.transform_net
+            n_id, n_tr = len(pr.identity_features), len(pr.transform_features)
+
+            def mat(off, width, cols):
+                return tape[l * stride + off: l * stride + off + B * width].view(B, width)[:, :cols]
+            a0, r0, r1, h1 = mat(o_a0, 64, n_id), mat(o_r0, Wp, W), mat(o_r1, Wp, W), mat(o_h1, Wp, W)
+            dh0, dt, dh1 = cc * mat(o_dh0, Wp, W), cc * mat(o_dt, Wp, W), cc * mat(o_dh1, Wp, W)
+            dp = cc * mat(o_dp, NFP, n_tr * NP)
+            grads += [dh0.t() @ a0, dh0.sum(0), dt.t() @ r0, dt.sum(0), dh1.t() @ r1, dh1.sum(0), dp.t() @ h1, dp.sum(0)]
+            if net.preprocessing is not None:
+                pf = net.preprocessing
+                xs = mat(o_xi, 64, n_id)[:, pf.ind] * pf.scale
+                da = (cc * mat(o_da0, 64, n_id))[:, pf.ind]
+                grads.append(torch.stack([(da * torch.sin(xs)).sum(0), (da * torch.cos(xs)).sum(0)], dim=1))
+            du = (cc * mat(o_du, UW, n_id * NP)).sum(0).view(n_id, NP)
+            grads += [du[:, :NUM_BINS], du[:, NUM_BINS:2 * NUM_BINS], du[:, 2 * NUM_BINS:]]
+        return grads
 
     def log_prob_and_grad(self, x: torch.Tensor):
         return self.native_log_prob(x, with_grad=True)

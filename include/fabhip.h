@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 200
+#define FABHIP_ABI_VERSION 201
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -144,6 +144,22 @@ size_t fabhip_spline_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidd
 /* log_q[B] = flow.log_prob(x[B][dim]) and, if grad_x != NULL, d log_q / dx [B][dim] (reverse sweep through all layers). */
 int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
                            void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+/* Training tape of the spline flow (the backward of `flow.log_prob(x)` w.r.t. the flow parameters in the forward-KL
+ * term of the FAB loss, fab/core.py:114-127, for the normflows spline family).  One call computes log_q, d log_q / dx
+ * (required) and writes, per coupling layer l at tape + l * out16[1], row-major [B][width] matrices at offsets
+ *   out16[2] XI  [B][64]   raw identity coordinates         out16[3] A0  [B][64]  after the periodic features
+ *   out16[4] dA0 [B][64]   cotangent of A0                  out16[5] R0  [B][Wp]  relu(h0)
+ *   out16[6] R1  [B][Wp]   relu(t)                          out16[7] H1  [B][Wp]  h1 (input of the final layer)
+ *   out16[8] dH1 out16[9] dT out16[10] dH0 [B][Wp]          cotangents of h1, t (ReLU-masked), h0
+ *   out16[11] dP [B][NFP]  cotangent of the conditioner output (columns >= 25 n_transform are 0)
+ *   out16[12] dU [B][out16[15]] cotangent of the unconditional parameters, [identity position][25]
+ * with out16[0] = total floats, out16[13] = Wp, out16[14] = NFP.  All cotangents are for seed 1 per sample: the
+ * gradient of sum_b c_b log q(x_b) w.r.t. a Linear's weight is (c * cotangent)^T @ activation - plain GEMMs over the
+ * tape, left to the caller's BLAS (rocBLAS; fab_torch_amd/spline_flow.py uses torch.mm). */
+int fabhip_spline_tape_layout(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B, int64_t out16[16]);
+int fabhip_spline_log_prob_tape(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                                float* tape, int64_t tape_floats, void* workspace, size_t workspace_bytes,
+                                fabhip_stream_t stream);
 /* x, log_q = flow.sample given u[B][dim] ~ U(0,1) (circular coordinates) and eps[B][dim] ~ N(0,1) (the others). */
 int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const float* eps, float* x, float* log_q,
                          int64_t B, void* workspace, size_t workspace_bytes, fabhip_stream_t stream);

@@ -149,6 +149,14 @@ def test_spline_flow_module_has_normflows_keys_and_fails_loudly_on_the_cpu():
     lib = _lib.load()
     assert lib.fabhip_spline_packed_floats(60, 12, 256) > 12 * 2 * (30 * 256 + 2 * 256 * 256 + 256 * 750)
     assert lib.fabhip_spline_packed_floats(65, 2, 64) == -1 and lib.fabhip_spline_packed_floats(60, 2, 257) == -1
+    # training tape layout (host-only arithmetic): 3 [B][64] + 6 [B][Wp] + [B][NFP] + [B][64 * 25] per layer
+    import ctypes
+    lay = (ctypes.c_int64 * 16)()
+    assert lib.fabhip_spline_tape_layout(60, 12, 256, 1024, lay) == 0
+    Wp, NFP = lay[13], lay[14]
+    assert (Wp, NFP, lay[15]) == (256, 768, 1600) and lay[1] == 1024 * (3 * 64 + 6 * Wp + NFP + 1600)
+    assert lay[0] == 12 * lay[1] and list(lay[2:13]) == sorted(lay[2:13])
+    assert lib.fabhip_spline_tape_layout(65, 2, 64, 8, lay) != 0
     with pytest.raises(_lib.FabhipError):
         hf.log_prob(torch.randn(4, 10))
     with pytest.raises(NotImplementedError):

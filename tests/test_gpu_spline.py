@@ -71,17 +71,25 @@ def test_spline_flow_log_prob_grad_and_sample_vs_oracle(D, L, hidden, circ, B):
     (g_o,) = torch.autograd.grad(lq_o.sum(), xg)
     lq_h, g_h = hf.log_prob_and_grad(x.to(DEV))
     assert close(lq_h, lq_o.detach(), RTOL), f"log q: {worst(lq_h, lq_o.detach()):.2f}x tol"
-    # d log q / dx is DISCONTINUOUS in x: log|dy/dx| of a C1 spline has a kink at every knot and the conditioner has ReLU
-    # kinks, so an intermediate coordinate that sits within fp32 rounding of a knot / kink gives a different (equally
-    # valid) one-sided derivative under a different summation order.  Small flows: every sample must match; the 12-layer
-    # 60-D flow (~10^4 knots + kinks per sample): at least 85 % of the samples match to tolerance, the others to 2 %.
-    per_sample_ok = torch.tensor([close(g_h[b], g_o[b], RTOL, atol_scale=10) for b in range(B)])
+    # Small flows: every sample's gradient matches the fp32 CPU oracle to tolerance.  The randomised 12-layer 60-D flow
+    # is stiff (|d log q / dx| up to ~3e3, log|dy/dx| kinked at every knot, ReLU kinks in the conditioner): there fp32
+    # itself is only good to 1e-5 .. 3e-3 (relative L2 per sample, measured for the CPU oracle against its float64
+    # twin; tools/diag_spline_grad.py prints both columns), so float64 arbitrates - the HIP error distribution over the
+    # samples may not be worse than the fp32 CPU oracle's own by more than 2x (median) / 3x (90th percentile).
     if D < 60:
-        assert per_sample_ok.all(), f"grad: {worst(g_h, g_o):.2f}x tol"
+        assert close(g_h, g_o, RTOL, atol_scale=10), f"grad: {worst(g_h, g_o):.2f}x tol"
     else:
-        assert per_sample_ok.float().mean() >= 0.85, f"only {int(per_sample_ok.sum())} of {B} gradients match"
-        rel = (g_h.cpu() - g_o).norm(dim=1) / g_o.norm(dim=1)
-        assert float(rel.max()) < 2e-2, f"a gradient is {float(rel.max()):.2e} off (relative L2)"
+        x64 = x.double().requires_grad_(True)
+        (g64,) = torch.autograd.grad(of64.log_prob(x64).sum(), x64)
+        n64 = g64.norm(dim=1)
+        rh = ((g_h.cpu().double() - g64).norm(dim=1) / n64).sort().values
+        ro = ((g_o.double() - g64).norm(dim=1) / n64).sort().values
+        # (the maximum is one near-singular sample, |dlogq/dx_j| ~ 2e3, whose fp32 error differs 10x between two hosts'
+        # BLAS for the CPU oracle itself: bounded absolutely below)
+        for name, i, fac in (("median", B // 2, 2.0), ("90th percentile", (9 * B) // 10, 3.0)):
+            assert float(rh[i]) <= fac * float(ro[i]) + 1e-4, \
+                f"grad {name}: HIP {float(rh[i]):.2e} from float64, the fp32 CPU oracle {float(ro[i]):.2e}"
+        assert float(rh[-1]) < 2e-2
     # log_prob of the flow's own samples returns the sampling log q; autograd w.r.t. x goes through the kernels
     assert close(hf.log_prob(x_h), lq_s_h, RTOL)
     xd = x.to(DEV).requires_grad_(True)
@@ -157,3 +165,72 @@ def test_full_ais_call_with_the_spline_flow_as_base_distribution():
     info = ais.get_logging_info()
     assert pt.x.shape == (B, D) and torch.isfinite(lw).all()
     assert info["ess_ais"] > info["ess_base"] and 0.2 < info["dist0_p_accept_0"] < 0.99
+
+
+@pytest.mark.parametrize("D,L,hidden,circ,B", [(8, 4, 64, (1, 4, 6), 100), (7, 5, 128, (0, 6), 33), (6, 3, 32, (), 64),
+                                               (60, 12, 256, (3, 7, 8, 12, 20, 21, 22, 30, 41, 45, 52, 59), 64)])
+def test_spline_flow_parameter_gradients_vs_oracle(D, L, hidden, circ, B):
+    """Training path: d (sum_b c_b log q(x_b)) / d theta from the kernels' tape (+ one GEMM per Linear) against autograd
+    through the CPU oracle, tensor by tensor under the normflows state-dict names."""
+    import copy
+    of, hf = make_pair(D, L, hidden, circ, seed=3 * D + L)
+    hf.requires_grad_(True)
+    g = torch.Generator().manual_seed(11)
+    u, eps = torch.rand(B, D, generator=g), torch.randn(B, D, generator=g)
+    with torch.no_grad():
+        x, _ = of.sample_eps(u, eps)
+    x = x + 0.2 * torch.randn(B, D, generator=g)
+    c = torch.randn(B, generator=g)
+    of64 = copy.deepcopy(of).double()
+    for f, xx, cc in ((of, x, c), (of64, x.double(), c.double())):
+        for p in f.parameters():
+            p.grad = None
+        (cc * f.log_prob(xx)).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    lq = hf.log_prob(xd)
+    (c.to(DEV) * lq).sum().backward()
+    lq0, gx0 = hf.log_prob_and_grad(x.to(DEV))
+    assert torch.equal(lq.detach(), lq0) and close(xd.grad, c.to(DEV)[:, None] * gx0, 1e-6)
+    ref32, ref64 = dict(of.named_parameters()), dict(of64.named_parameters())
+    names = [n for n, _ in hf._nf_model.named_parameters()]
+    assert set(names) == set(ref32) and len(names) == len(hf._train_params())
+    worst_ratio = 0.0
+    for n, p in hf._nf_model.named_parameters():
+        assert p.grad is not None, n
+        g64 = ref64[n].grad
+        scale = float(g64.norm()) + 1e-30
+        eh = float((p.grad.cpu().double() - g64).norm()) / scale
+        eo = float((ref32[n].grad.double() - g64).norm()) / scale
+        # fp32 summation over the batch and the stiff 12-layer chain: float64 arbitrates; HIP within 1e-4 relative L2 of
+        # it, or no worse than 3x the fp32 CPU oracle's own distance
+        assert eh <= max(1e-4, 3.0 * eo), f"{n}: HIP {eh:.2e} from float64 (fp32 CPU oracle {eo:.2e})"
+        worst_ratio = max(worst_ratio, eh)
+    # a second backward through a fresh forward accumulates like autograd does
+    before = {n: p.grad.clone() for n, p in hf._nf_model.named_parameters()}
+    (c.to(DEV) * hf.log_prob(x.to(DEV))).sum().backward()
+    for n, p in hf._nf_model.named_parameters():
+        assert close(p.grad, 2 * before[n], 1e-5), n
+
+
+def test_spline_flow_trains_by_maximum_likelihood_on_the_gpu():
+    """forward-KL training of the spline flow with torch.optim.Adam through the HIP tape: the loss must fall (the
+    reference trains this family with the same optimiser, experiments/aldp/train.py)."""
+    D, circ = 6, (1, 4)
+    tb = torch.full((D,), 4.0); tb[list(circ)] = math.pi
+    torch.manual_seed(0)
+    hf = fa.make_wrapped_normflow_spline(D, 4, 64, circ, tb).to(DEV)
+    g = torch.Generator().manual_seed(1)
+    data = torch.randn(4096, D, generator=g) * 0.5 + 0.7
+    data[:, list(circ)] = (torch.rand(4096, len(circ), generator=g) ** 2 - 0.5) * 2 * math.pi * 0.99
+    data = data.to(DEV)
+    opt = torch.optim.Adam(hf.parameters(), lr=3e-3)
+    losses = []
+    for it in range(60):
+        xb = data[torch.randint(0, 4096, (512,), generator=g)]
+        opt.zero_grad()
+        loss = -hf.log_prob(xb).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in losses)
+    assert losses[-1] < losses[0] - 1.0, f"{losses[0]:.3f} -> {losses[-1]:.3f}"
