@@ -38,7 +38,14 @@ def _owner_or_none(fn, cls):
 
 
 def grad_and_value(x: torch.Tensor, forward_fn):
-    """fab/sampling_methods/base.py:50-56: value and gradient w.r.t. x of a plug-in's log-density (its own code)."""
+    """fab/sampling_methods/base.py:50-56: value and gradient w.r.t. x of a plug-in's log-density (its own code).
+    A `log_prob` bound to one of this package's HIP-backed distributions returns both from one kernel sweep
+    (`log_prob_and_grad`) without building an autograd graph (nor, for a flow being trained, a parameter tape)."""
+    owner = getattr(forward_fn, "__self__", None)
+    if owner is not None and getattr(forward_fn, "__name__", "") == "log_prob" and \
+            getattr(type(owner), "__module__", "").startswith(__package__ + ".") and hasattr(owner, "log_prob_and_grad"):
+        y, grad = owner.log_prob_and_grad(x.detach())
+        return grad, y
     x = x.detach().requires_grad_(True)
     with torch.enable_grad():
         y = forward_fn(x)
