@@ -22,7 +22,8 @@ class FlowParams(C.Structure):
     _fields_ = [("dim", C.c_int32), ("n_layers", C.c_int32), ("width", C.c_int32)] + \
                [(n, C.c_void_p * MAX_LAYERS) for n in
                 ("w1", "b1", "w2", "b2", "w3", "b3", "lu_L", "lu_U", "log_S", "sign_S", "perm_P")] + \
-               [("loc", C.c_void_p), ("log_scale", C.c_void_p)]
+               [("loc", C.c_void_p), ("log_scale", C.c_void_p)] + \
+               [("an_s", C.c_void_p * MAX_LAYERS), ("an_t", C.c_void_p * MAX_LAYERS)]
 
 
 class Flow(C.Structure):
@@ -96,7 +97,7 @@ SYMBOLS = [
     "fabhip_spline_packed_floats", "fabhip_spline_pack", "fabhip_spline_workspace_bytes", "fabhip_spline_log_prob",
     "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
 ]
-ABI_VERSION = 201          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 202          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):

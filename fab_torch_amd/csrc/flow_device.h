@@ -665,11 +665,13 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
 }
 
 // OUT[16 x 16*NT] = A[16 x K] @ B   (NT <= 4: one column tile per wave), used for the D x D affine maps.
+// `add` (nullable): per-column additive term [16 * NT] (the ActNorm shift folded into the affine map).
 __device__ __forceinline__ void dense_small(const float* A, int lda, int kmax, int KB, const float4* Bp, int NT,
-                                            float* OUT, int ldo, const Tid& t) {
+                                            float* OUT, int ldo, const Tid& t, const float* __restrict__ add = nullptr) {
     if (t.wave < NT) {
         f32x4 acc[1];
-        acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        const float av = add ? add[16 * t.wave + t.n] : 0.f;
+        acc[0] = (f32x4){av, av, av, av};
         WRing<1, 2> w;
         ring_issue<1, 2, false>(w, Bp, KB, nullptr, t);
         ring_run<1, 2, true, false>(w, A, lda, kmax, KB, Bp, t, acc);
@@ -714,7 +716,8 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
     {
         const float* Lp = packed + (size_t)(f.K - 1) * f.layer_stride;
         smallw_load<NTWM, 2, true>(w1r, reinterpret_cast<const float4*>(Lp + f.o_W1), Lp + f.o_b1, t);
-        if (kbd2) smallw_load<1, 2, false>(awr, reinterpret_cast<const float4*>(Lp + f.o_AW), nullptr, t);
+        // (its bias slot carries the ActNorm term `ac` of the layer, zero without ActNorm)
+        if (kbd2) smallw_load<1, 2, true>(awr, reinterpret_cast<const float4*>(Lp + f.o_AW), Lp + f.o_ac, t);
     }
     for (int layer = f.K - 1; layer >= 0; --layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
@@ -728,7 +731,7 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         // ---- InvertibleAffine.inverse: z <- z @ (P L U), log_det = +sum(log_S) --------------------------
         if (kbd2) dense_small_pre(awr, lds + cur, l.DS, f.D, f.NTD, lds + nxt, l.DS, t);
         else dense_small(lds + cur, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AW), f.NTD, lds + nxt,
-                         l.DS, t);
+                         l.DS, t, Lp + f.o_ac);
         logq += Lp[f.o_logS];
         if (tl) FAB_TL(f, 1);
         __syncthreads();
@@ -774,8 +777,10 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
                 if (nxt_layer) w1r.bv[i] = Ln[f.o_b1 + 16 * (t.wave + 4 * i) + t.n];
             } else if constexpr (j < 4 * N + 2) {
                 constexpr int S = j - 4 * N;
-                if (nxt_layer && kbd2)
+                if (nxt_layer && kbd2) {
                     awr.b[S][0] = reinterpret_cast<const float4*>(Ln + f.o_AW)[((size_t)t.wave * 2 + S) * 64 + t.lane];
+                    if (S == 0) awr.bv[0] = Ln[f.o_ac + 16 * t.wave + t.n];     // (64 floats, zero beyond D)
+                }
             } else if constexpr (j < 4 * N + 6) {
                 constexpr int it = (j - 4 * N - 2) & 1, sc = (j - 4 * N - 2) >> 1;
                 const int col = t.c + 16 * it;
@@ -980,7 +985,7 @@ __device__ float flow_sample_tile(const FlowDims& f, const FlowLds& l, const flo
         logq -= row16_sum(ssum);
         __syncthreads();
         // InvertibleAffine.forward: z <- z @ W^-1, log_det = -sum(log_S)
-        dense_small(Z, l.DS, f.D, f.KBD, AWI, f.NTD, lds + nxt, l.DS, t);
+        dense_small(Z, l.DS, f.D, f.KBD, AWI, f.NTD, lds + nxt, l.DS, t, Lp + f.o_at);
         logq -= -Lp[f.o_logS];
         __syncthreads();
         const int tmp = cur; cur = nxt; nxt = tmp;

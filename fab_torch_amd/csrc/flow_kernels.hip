@@ -14,6 +14,7 @@ namespace fab {
 constexpr int LBATCH = 16;      // layers per launch (pointer tables travel as kernel arguments)
 struct AffineTab {
     const float *L[LBATCH], *U[LBATCH], *logS[LBATCH], *signS[LBATCH], *P[LBATCH];
+    const float *an_s[LBATCH], *an_t[LBATCH];              // ActNorm after the affine map (nullptr: none)
 };
 struct MlpTab {
     const float *w1[LBATCH], *b1[LBATCH], *w2[LBATCH], *b2[LBATCH], *w3[LBATCH], *b3[LBATCH];
@@ -28,6 +29,9 @@ __global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab t
     const float* __restrict__ logS = tab.logS[blockIdx.x];
     const float* __restrict__ signS = tab.signS[blockIdx.x];
     const float* __restrict__ P = tab.P[blockIdx.x];
+    const float* __restrict__ an_s = tab.an_s[blockIdx.x];
+    const float* __restrict__ an_t = tab.an_t[blockIdx.x];
+    float* __restrict__ Lblock = packed + (size_t)layer * f.layer_stride;
     float* __restrict__ Wout = packed + f.o_scratch + (size_t)layer * 2 * D * D;
     float* __restrict__ Winvout = Wout + D * D;
     float* __restrict__ logS_sum = packed + (size_t)layer * f.layer_stride + f.o_logS;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab t
         const int i = e / D, j = e % D;
         float s = 0.f;
         for (int k = 0; k < D; ++k) s = fmaf(T[i * D + k], Ps[j * D + k], s);
-        Winvout[e] = s;
+        Winvout[e] = an_s ? s * expf(an_s[j]) : s;            // ActNorm.forward after the map: W^-1 diag(e^s)
     }
     __syncthreads();
     }
@@ -104,11 +108,21 @@ __global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab t
         const int i = e / D, j = e % D;
         float s = 0.f;
         for (int k = 0; k < D; ++k) s = fmaf(Li[i * D + k], Um(k, j), s);
-        Wout[e] = s;
+        Wout[e] = an_s ? expf(-an_s[i]) * s : s;              // ActNorm.inverse before the map: diag(e^-s) W
+    }
+    __syncthreads();
+    if (tid < 64) {                                           // additive terms (zero without ActNorm / beyond D)
+        float ac = 0.f, at = 0.f;
+        if (an_s && tid < D) {
+            for (int i = 0; i < D; ++i) ac = fmaf(-an_t[i], Wout[i * D + tid], ac);    // -(t e^-s) @ W = -t @ W'
+            at = an_t[tid];
+        }
+        Lblock[f.o_ac + tid] = ac;
+        Lblock[f.o_at + tid] = at;
     }
     if (tid == 0) {
         float s = 0.f;
-        for (int k = 0; k < D; ++k) s += logS[k];
+        for (int k = 0; k < D; ++k) s += logS[k] - (an_s ? an_s[k] : 0.f);
         *logS_sum = s;
     }
 }
@@ -306,7 +320,7 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
     FAB_TRY(set_max_lds((const void*)k_affine_assemble, smem));
     for (int k = 0; k < f.K; ++k)
         if (!p->w1[k] || !p->b1[k] || !p->w2[k] || !p->b2[k] || !p->w3[k] || !p->b3[k] || !p->lu_L[k] ||
-            !p->lu_U[k] || !p->log_S[k] || !p->sign_S[k] || !p->perm_P[k])
+            !p->lu_U[k] || !p->log_S[k] || !p->sign_S[k] || !p->perm_P[k] || (!p->an_s[k] != !p->an_t[k]))
             return FABHIP_EINVAL;
     for (int k0 = 0; k0 < f.K; k0 += LBATCH) {             // all layers of a batch in one launch each
         const int nl = f.K - k0 < LBATCH ? f.K - k0 : LBATCH;
@@ -316,6 +330,7 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
             const int k = k0 + (y < nl ? y : 0);
             at.L[y] = p->lu_L[k]; at.U[y] = p->lu_U[k]; at.logS[y] = p->log_S[k]; at.signS[y] = p->sign_S[k];
             at.P[y] = p->perm_P[k];
+            at.an_s[y] = p->an_s[k]; at.an_t[y] = p->an_t[k];
             mt.w1[y] = p->w1[k]; mt.b1[y] = p->b1[k]; mt.w2[y] = p->w2[k]; mt.b2[y] = p->b2[k];
             mt.w3[y] = p->w3[k]; mt.b3[y] = p->b3[k];
         }

@@ -12,7 +12,8 @@
 //    torch.library.register_autograd (fab_torch_amd/_ops.py); its backward is fabhip::realnvp_param_grad.
 //
 // Flow parameters travel as `Tensor[] params` in the order of fabhip_flow_params: per layer
-// {w1, b1, w2, b2, w3, b3, L, U, log_S, sign_S, P}, then {loc, log_scale}.  Targets travel as
+// {w1, b1, w2, b2, w3, b3, L, U, log_S, sign_S, P}, then {loc, log_scale}, then (act_norm flows only) one
+// {ActNorm.s, ActNorm.t} pair per layer.  Targets travel as
 // (int kind, float[] {a, b, c, log_norm}, Tensor? locs, Tensor? scales).
 #include <ATen/ATen.h>
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
@@ -67,8 +68,10 @@ fabhip_flow make_flow(const Tensor& packed, int64_t dim, int64_t n_layers, int64
 
 void fill_params(fabhip_flow_params& p, at::TensorList params, int64_t dim, int64_t n_layers, int64_t width) {
     TORCH_CHECK(n_layers >= 1 && n_layers <= FABHIP_MAX_LAYERS, "fabhip: n_layers out of range");
-    TORCH_CHECK((int64_t)params.size() == 11 * n_layers + 2, "fabhip: expected ", 11 * n_layers + 2,
-                " parameter tensors (11 per layer + loc + log_scale), got ", params.size());
+    const bool act_norm = (int64_t)params.size() == 13 * n_layers + 2;
+    TORCH_CHECK(act_norm || (int64_t)params.size() == 11 * n_layers + 2, "fabhip: expected ", 11 * n_layers + 2,
+                " parameter tensors (11 per layer + loc + log_scale), or ", 13 * n_layers + 2,
+                " with one ActNorm {s, t} pair per layer appended, got ", params.size());
     p.dim = (int32_t)dim; p.n_layers = (int32_t)n_layers; p.width = (int32_t)width;
     for (int64_t k = 0; k < n_layers; ++k) {
         const Tensor* t = &params[11 * k];
@@ -78,6 +81,13 @@ void fill_params(fabhip_flow_params& p, at::TensorList params, int64_t dim, int6
     }
     p.loc = fp(params[11 * n_layers], "loc");
     p.log_scale = fp(params[11 * n_layers + 1], "log_scale");
+    for (int64_t k = 0; k < FABHIP_MAX_LAYERS; ++k) { p.an_s[k] = nullptr; p.an_t[k] = nullptr; }
+    if (act_norm)
+        for (int64_t k = 0; k < n_layers; ++k) {
+            const Tensor &s = params[11 * n_layers + 2 + 2 * k], &t = params[11 * n_layers + 3 + 2 * k];
+            TORCH_CHECK(s.numel() == dim && t.numel() == dim, "fabhip: ActNorm s / t must have dim entries");
+            p.an_s[k] = fp(s, "ActNorm.s"); p.an_t[k] = fp(t, "ActNorm.t");
+        }
 }
 
 fabhip_target make_target(int64_t kind, at::ArrayRef<double> prm, const optional<Tensor>& locs,
@@ -113,7 +123,7 @@ int64_t flow_grad_floats(int64_t dim, int64_t n_layers, int64_t width) {
     return fabhip_flow_grad_floats((int32_t)dim, (int32_t)n_layers, (int32_t)width);
 }
 std::vector<int64_t> flow_grad_layout(int64_t dim, int64_t n_layers, int64_t width) {
-    std::vector<int64_t> out(13);
+    std::vector<int64_t> out(15);
     chk(fabhip_flow_grad_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, out.data()), "flow_grad_layout");
     return out;
 }
@@ -197,7 +207,9 @@ Tensor realnvp_param_grad(at::TensorList params, const Tensor& packed, int64_t d
     const int64_t B = coef.size(0);
     const size_t nbytes = fabhip_flow_tape_bytes(f.dim, f.n_layers, f.width, B);
     TORCH_CHECK((size_t)tape.numel() * 4 >= nbytes, "fabhip: tape too small for ", B, " rows");
-    Tensor flat = fempty({fabhip_flow_grad_floats(f.dim, f.n_layers, f.width)}, coef);
+    int64_t lay[15];
+    chk(fabhip_flow_grad_layout(f.dim, f.n_layers, f.width, lay), "flow_grad_layout");
+    Tensor flat = fempty({p.an_s[0] ? lay[14] : lay[12]}, coef);     // ActNorm flows: + [an_s | an_t] per layer
     chk(fabhip_flow_param_grad(&p, &f, fp(tape, "tape"), nbytes, fp(coef, "coef"), B, flat.data_ptr<float>(),
                                stream_of(coef)),
         "flow_param_grad");

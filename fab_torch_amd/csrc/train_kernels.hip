@@ -15,9 +15,10 @@
 
 namespace fab {
 
-// ---- flat gradient image: per layer [w1 | b1 | w2 | b2 | w3 | b3 | L | U | log_S], then loc, log_scale ----------
+// ---- flat gradient image: per layer [w1 | b1 | w2 | b2 | w3 | b3 | L | U | log_S], then loc, log_scale; flows with
+// ActNorm layers: then per layer [an_s | an_t] from `an_base` (= total without ActNorm) on
 struct GradLayout {
-    long layer_stride, w1, b1, w2, b2, w3, b3, L, U, logS, loc, log_scale, total;
+    long layer_stride, w1, b1, w2, b2, w3, b3, L, U, logS, loc, log_scale, total, an_base, total_an;
 };
 
 FAB_HD GradLayout make_grad_layout(const FlowDims& f) {
@@ -36,6 +37,8 @@ FAB_HD GradLayout make_grad_layout(const FlowDims& f) {
     g.loc = (long)f.K * o;
     g.log_scale = g.loc + f.D;
     g.total = g.log_scale + f.D;
+    g.an_base = g.total;
+    g.total_an = g.total + (long)f.K * 2 * f.D;
     return g;
 }
 
@@ -214,30 +217,48 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
 // ------------------------------------------------------------------------------------------------
 constexpr int LBATCH = 16;
 struct AffineSrc {
-    const float *L, *U, *logS, *signS, *P;
+    const float *L, *U, *logS, *signS, *P, *an_s, *an_t;
 };
 struct AffineSrcTab {
-    const float *L[LBATCH], *U[LBATCH], *logS[LBATCH], *signS[LBATCH], *P[LBATCH];
+    const float *L[LBATCH], *U[LBATCH], *logS[LBATCH], *signS[LBATCH], *P[LBATCH], *an_s[LBATCH], *an_t[LBATCH];
 };
 
-// one workgroup per InvertibleAffine layer: (dL, dU, dlog_S) from dW = ga_ws[layer]; everything staged in LDS
+// one workgroup per InvertibleAffine layer: (dL, dU, dlog_S) from dW = ga_ws[layer]; everything staged in LDS.
+// With an ActNorm after the map (density direction z = a @ W, a = (x - t) e^-s, log_det -= sum(s)) ga_ws holds
+// dW' = sum_b c_b x_b^T g_b for the FOLDED map W' = diag(e^-s) W.  With dc = sum_b c_b g_b (reduced here from the
+// tape's GZ rows):  dW = diag(e^-s) (dW' - t (x) dc),  ds_i = -sum_j W_ij dW_ij - sum_b c_b,  dt_i = -e^-s_i (W dc)_i.
 __global__ __launch_bounds__(256) void k_affine_grads(FlowDims f, TapeDims td, GradLayout gl, AffineSrcTab tab,
                                                       int k0, const float* __restrict__ ga_ws,
-                                                      float* __restrict__ grads) {
+                                                      float* __restrict__ grads, const float* __restrict__ tape,
+                                                      const float* __restrict__ coef, long B) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int tid = threadIdx.x, D = f.D, DD = D * D;
     const int y = blockIdx.x, layer = k0 + y;
-    const AffineSrc src{tab.L[y], tab.U[y], tab.logS[y], tab.signS[y], tab.P[y]};
+    const AffineSrc src{tab.L[y], tab.U[y], tab.logS[y], tab.signS[y], tab.P[y], tab.an_s[y], tab.an_t[y]};
     float* dW = sm;                 // [D][D] each
     float* Lm = dW + DD;
     float* Um = Lm + DD;
     float* Ps = Um + DD;
     float* PL = Ps + DD;            // P @ Lm
     float* T = PL + DD;             // dW @ Um^T
+    float* dc = T + DD;             // [4][64] partial column sums of c_b g_b, then [64] (ActNorm only)
     const float csum = ga_ws[(size_t)f.K * td.wz * td.wz];          // sum_b coef_b (k_param_grad, base block)
+    const bool an = src.an_s != nullptr;
+    if (an) {
+        const float* GZ = tape + (size_t)layer * td.layer_stride + td.o_GZ;
+        const int j = tid & 63, r = tid >> 6;
+        float s = 0.f;
+        if (j < D)
+            for (long b = r; b < B; b += 4) s = fmaf(coef[b], GZ[b * td.wz + j], s);
+        dc[r * 64 + j] = s;
+        __syncthreads();
+        if (tid < 64) dc[tid] = (dc[tid] + dc[64 + tid]) + (dc[128 + tid] + dc[192 + tid]);
+        __syncthreads();
+    }
     for (int e = tid; e < DD; e += 256) {
         const int i = e / D, j = e - i * D;
-        dW[e] = ga_ws[((size_t)layer * td.wz + i) * td.wz + j];
+        const float raw = ga_ws[((size_t)layer * td.wz + i) * td.wz + j];
+        dW[e] = an ? expf(-src.an_s[i]) * (raw - src.an_t[i] * dc[j]) : raw;
         Lm[e] = i == j ? 1.f : (i > j ? src.L[e] : 0.f);
         Um[e] = i == j ? src.signS[i] * expf(src.logS[i]) : (i < j ? src.U[e] : 0.f);
         Ps[e] = src.P[e];
@@ -255,6 +276,18 @@ __global__ __launch_bounds__(256) void k_affine_grads(FlowDims f, TapeDims td, G
     }
     __syncthreads();
     float* G = grads + (size_t)layer * gl.layer_stride;
+    if (an && tid < D) {                                             // ActNorm gradients
+        float gs = 0.f, gt = 0.f;
+        const int i = tid;
+        for (int j = 0; j < D; ++j) {
+            float w = 0.f;
+            for (int k = 0; k < D; ++k) w = fmaf(PL[i * D + k], Um[k * D + j], w);          // W_ij = (P Lm Um)_ij
+            gs = fmaf(-w, dW[i * D + j], gs);
+            gt = fmaf(w, dc[j], gt);
+        }
+        grads[gl.an_base + (long)layer * 2 * D + i] = gs - csum;
+        grads[gl.an_base + (long)layer * 2 * D + D + i] = -expf(-src.an_s[i]) * gt;
+    }
     for (int e = tid; e < DD; e += 256) {
         const int i = e / D, j = e - i * D;
         float su = 0.f, sl = 0.f;
@@ -294,13 +327,13 @@ int64_t fabhip_flow_grad_floats(int32_t dim, int32_t n_layers, int32_t width) {
     return (int64_t)make_grad_layout(make_flow_dims(dim, n_layers, width)).total;
 }
 
-int fabhip_flow_grad_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t* out13) {
-    if (!out13) return FABHIP_EINVAL;
+int fabhip_flow_grad_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t* out15) {
+    if (!out15) return FABHIP_EINVAL;
     FAB_TRY(check_flow_shape(dim, n_layers, width));
     const GradLayout g = make_grad_layout(make_flow_dims(dim, n_layers, width));
-    const long v[13] = {g.layer_stride, g.w1, g.b1, g.w2, g.b2, g.w3, g.b3, g.L, g.U, g.logS, g.loc, g.log_scale,
-                        g.total};
-    for (int i = 0; i < 13; ++i) out13[i] = v[i];
+    const long v[15] = {g.layer_stride, g.w1, g.b1, g.w2, g.b2, g.w3, g.b3, g.L, g.U, g.logS, g.loc, g.log_scale,
+                        g.total, g.an_base, g.total_an};
+    for (int i = 0; i < 15; ++i) out15[i] = v[i];
     return FABHIP_OK;
 }
 
@@ -349,10 +382,11 @@ int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* 
     const int nbase = ceil_div(td.wb, 64) * gb.q1;               // base-distribution blocks after the K layers
     hipLaunchKernelGGL(k_param_grad, dim3((unsigned)(f.K * gb.per_layer + nbase)), dim3(256), 0, st, f, td, gb, gl,
                        tp, coef, (long)B, grads, ga);
-    const size_t smem = (size_t)6 * f.D * f.D * 4;
+    const size_t smem = ((size_t)6 * f.D * f.D + 256) * 4;
     FAB_TRY(set_max_lds((const void*)k_affine_grads, smem));
     for (int k = 0; k < f.K; ++k)
-        if (!params->lu_L[k] || !params->lu_U[k] || !params->log_S[k] || !params->sign_S[k] || !params->perm_P[k])
+        if (!params->lu_L[k] || !params->lu_U[k] || !params->log_S[k] || !params->sign_S[k] || !params->perm_P[k] ||
+            (!params->an_s[k] != !params->an_t[k]))
             return FABHIP_EINVAL;
     for (int k0 = 0; k0 < f.K; k0 += LBATCH) {
         const int nl = f.K - k0 < LBATCH ? f.K - k0 : LBATCH;
@@ -361,8 +395,9 @@ int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* 
             const int k = k0 + (y < nl ? y : 0);
             tab.L[y] = params->lu_L[k]; tab.U[y] = params->lu_U[k]; tab.logS[y] = params->log_S[k];
             tab.signS[y] = params->sign_S[k]; tab.P[y] = params->perm_P[k];
+            tab.an_s[y] = params->an_s[k]; tab.an_t[y] = params->an_t[k];
         }
-        hipLaunchKernelGGL(k_affine_grads, dim3(nl), dim3(256), smem, st, f, td, gl, tab, k0, ga, grads);
+        hipLaunchKernelGGL(k_affine_grads, dim3(nl), dim3(256), smem, st, f, td, gl, tab, k0, ga, grads, tp, coef, (long)B);
     }
     return check_launch();
 }

@@ -77,6 +77,18 @@ class _InvertibleAffine(nn.Module):
         return self.P @ L @ U
 
 
+class _ActNorm(nn.Module):
+    """normflows ActNorm(dim) (AffineConstFlow with data-dependent initialisation): sampling direction
+    z <- z * exp(s) + t, log_det = sum(s); `s`, `t` of shape [1, dim] and the `data_dep_init_done` buffer under the
+    normflows names."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.s = nn.Parameter(torch.zeros(1, dim))
+        self.t = nn.Parameter(torch.zeros(1, dim))
+        self.register_buffer("data_dep_init_done", torch.tensor(0.0))
+
+
 class _DiagGaussian(nn.Module):
     def __init__(self, dim):
         super().__init__()
@@ -86,7 +98,7 @@ class _DiagGaussian(nn.Module):
 
 
 class _NormalizingFlow(nn.Module):
-    def __init__(self, dim, n_layers, width):
+    def __init__(self, dim, n_layers, width, act_norm=False):
         super().__init__()
         self.q0 = _DiagGaussian(dim)
         d = int((dim / 2) + 0.5)
@@ -94,20 +106,25 @@ class _NormalizingFlow(nn.Module):
         for _ in range(n_layers):
             flows.append(_AffineCouplingBlock(_MLP([d, width, width, 2 * (dim - d)], init_zeros=True)))
             flows.append(_InvertibleAffine(dim))
+            if act_norm:                                   # make_normflow_model.py:27-29
+                flows.append(_ActNorm(dim))
         self.flows = nn.ModuleList(flows)
 
 
 class RealNVP(nn.Module):
-    """`make_wrapped_normflow_realnvp(dim, n_flow_layers, layer_nodes_per_dim, act_norm=False)`."""
+    """`make_wrapped_normflow_realnvp(dim, n_flow_layers, layer_nodes_per_dim, act_norm)`.  With `act_norm` an
+    ActNorm follows every InvertibleAffine (make_normflow_model.py:27-29); the kernels see it folded into the affine
+    map (W' = diag(e^-s) W, W'^-1 = W^-1 diag(e^s), additive terms, log-det), its gradients come out of the
+    LU chain-rule kernel.  Like the reference builder (make_normflow_model.py:94-95) call `init_act_norm()` (one
+    500-sample draw per layer on the GPU) - or load a checkpoint - before use: `make_wrapped_normflow_realnvp` does."""
 
     def __init__(self, dim: int, n_flow_layers: int = 5, layer_nodes_per_dim: int = 10, act_norm: bool = False):
         super().__init__()
-        if act_norm:
-            raise NotImplementedError("ActNorm layers are not part of the MI355X hot path (all shipped "
-                                      "reference configs set act_norm=false)")
         self.dim, self.n_layers, self.width = dim, n_flow_layers, dim * layer_nodes_per_dim
         self.d = int((dim / 2) + 0.5)
-        self._nf_model = _NormalizingFlow(dim, n_flow_layers, self.width)
+        self.act_norm = bool(act_norm)
+        self._act_norm_ready = False
+        self._nf_model = _NormalizingFlow(dim, n_flow_layers, self.width, self.act_norm)
         self._packed = None
         self._packed_key = None
         self._grad_layout = None
@@ -125,6 +142,7 @@ class RealNVP(nn.Module):
         if eps is None:
             eps = torch.randn((shape[0], self.dim), dtype=torch.float32, device=dev)
         if torch.is_grad_enabled() and self._params_need_grad():
+            self._ensure_act_norm()
             return self._aten_sample(eps)
         return self.native_sample(eps)
 
@@ -152,13 +170,16 @@ class RealNVP(nn.Module):
         for l1, l2, l3, aff in self._layers():
             out += [l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, aff.L, aff.U, aff.log_S]
         q0 = self._nf_model.q0
-        return out + [q0.loc, q0.log_scale]
+        out += [q0.loc, q0.log_scale]
+        for an in self._act_norms():
+            out += [an.s, an.t]
+        return out
 
     def _grad_views(self, flat: torch.Tensor):
         """Views of the flat gradient image, one per tensor of `_grad_tensors()`."""
         if self._grad_layout is None:
             self._grad_layout = [int(v) for v in _ops.load().flow_grad_layout(self.dim, self.n_layers, self.width)]
-        stride, w1, b1, w2, b2, w3, b3, oL, oU, oS, loc, lsc, _ = self._grad_layout
+        stride, w1, b1, w2, b2, w3, b3, oL, oU, oS, loc, lsc, _, an_base, _ = self._grad_layout
         D, d, W = self.dim, self.d, self.width
         shapes = [(w1, (W, d)), (b1, (W,)), (w2, (W, W)), (b2, (W,)), (w3, (2 * (D - d), W)), (b3, (2 * (D - d),)),
                   (oL, (D, D)), (oU, (D, D)), (oS, (D,))]
@@ -172,26 +193,77 @@ class RealNVP(nn.Module):
                 views.append(flat[base + off: base + off + n].view(shp))
         views.append(flat[loc: loc + D].view(1, D))
         views.append(flat[lsc: lsc + D].view(1, D))
+        if self.act_norm:
+            for k in range(self.n_layers):
+                o = an_base + 2 * D * k
+                views += [flat[o: o + D].view(1, D), flat[o + D: o + 2 * D].view(1, D)]
         return views
+
+    def grad_floats(self) -> int:
+        """Length of the flat gradient / parameter image (fabhip_flow_grad_layout)."""
+        if self._grad_layout is None:
+            self._grad_layout = [int(v) for v in _ops.load().flow_grad_layout(self.dim, self.n_layers, self.width)]
+        return self._grad_layout[14] if self.act_norm else self._grad_layout[12]
 
     # ---- native (HIP) entry points: torch.ops.fabhip.* --------------------------------------------------------------
     def _params_need_grad(self):
         return any(p.requires_grad for p in self.parameters())
 
     def _layers(self):
-        fl = self._nf_model.flows
+        fl, st = self._nf_model.flows, (3 if self.act_norm else 2)
         for i in range(self.n_layers):
-            net = fl[2 * i].flows[1].param_map.net
-            yield net[0], net[2], net[4], fl[2 * i + 1]
+            net = fl[st * i].flows[1].param_map.net
+            yield net[0], net[2], net[4], fl[st * i + 1]
 
-    def _param_list(self):
-        """`Tensor[] params` of the ops: per layer {w1, b1, w2, b2, w3, b3, L, U, log_S, sign_S, P}, then loc, log_scale."""
+    def _act_norms(self):
+        return [self._nf_model.flows[3 * i + 2] for i in range(self.n_layers)] if self.act_norm else []
+
+    def _ensure_act_norm(self):
+        if self.act_norm and not self._act_norm_ready:
+            if any(float(an.data_dep_init_done) <= 0 for an in self._act_norms()):
+                self.init_act_norm()
+            self._act_norm_ready = True                  # (checked once: the flags only ever go 0 -> 1)
+
+    @torch.no_grad()
+    def init_act_norm(self, n_samples: int = 500, eps: torch.Tensor = None):
+        """Data-dependent initialisation of the ActNorm layers, what the reference's builder triggers with
+        `wrapped_dist.sample((500,))` (make_normflow_model.py:94-95 -> ActNorm.forward on its first batch): layer by
+        layer, s = -log(std(z) + 1e-6), t = -mean(z) exp(s) of the batch that reaches the layer (unbiased std, like
+        torch.std).  Every partial flow is sampled by the HIP kernel (layers above the one being initialised are
+        skipped by sampling a flow truncated to the first k + 1 layers)."""
+        if not self.act_norm:
+            return
+        dev = self._nf_model.q0.loc.device
+        if eps is None:
+            eps = torch.randn(n_samples, self.dim, device=dev)
+        ops = _ops.load()
+        for k, an in enumerate(self._act_norms()):
+            if float(an.data_dep_init_done) > 0:
+                continue
+            an.s.zero_(); an.t.zero_()
+            K = k + 1
+            tensors = self._param_list(n_layers=K)
+            packed = torch.empty(ops.flow_packed_floats(self.dim, K, self.width), dtype=torch.float32, device=dev)
+            ops.realnvp_pack([t.detach().contiguous().float() for t in tensors], self.dim, K, self.width, True, packed)
+            z, _ = ops.realnvp_sample(packed, self.dim, K, self.width, eps.contiguous().float())
+            s = -torch.log(z.std(dim=0, keepdim=True) + 1e-6)
+            an.s.copy_(s)
+            an.t.copy_(-z.mean(dim=0, keepdim=True) * torch.exp(s))
+            an.data_dep_init_done.fill_(1.0)
+
+    def _param_list(self, n_layers: int = None):
+        """`Tensor[] params` of the ops: per layer {w1, b1, w2, b2, w3, b3, L, U, log_S, sign_S, P}, then loc, log_scale,
+        then (act_norm) one {s, t} pair per layer.  n_layers: only the first layers (init_act_norm)."""
+        K = self.n_layers if n_layers is None else n_layers
         tensors = []
-        for l1, l2, l3, aff in self._layers():
+        for l1, l2, l3, aff in list(self._layers())[:K]:
             tensors += [l1.weight, l1.bias, l2.weight, l2.bias, l3.weight, l3.bias, aff.L, aff.U, aff.log_S,
                         aff.sign_S, aff.P]
         q0 = self._nf_model.q0
-        return tensors + [q0.loc, q0.log_scale]
+        tensors += [q0.loc, q0.log_scale]
+        for an in self._act_norms()[:K]:
+            tensors += [an.s.reshape(-1), an.t.reshape(-1)]
+        return tensors
 
     def native(self, need_inverse: bool = True):
         """(packed image, dim, n_layers, width) - the flow arguments of the ops; the image is re-tiled by the pack
@@ -200,6 +272,7 @@ class RealNVP(nn.Module):
         ops = _ops.load()
         q0 = self._nf_model.q0
         _ops.require_device(q0.loc, "RealNVP parameters")
+        self._ensure_act_norm()
         tensors = self._param_list()
         key = tuple((t.data_ptr(), t._version) for t in tensors)
         if key != self._packed_key or (need_inverse and not self._packed_has_inverse):
@@ -262,7 +335,8 @@ class RealNVP(nn.Module):
         z = q0.loc + torch.exp(q0.log_scale) * eps
         log_q = -0.5 * self.dim * math.log(2 * math.pi) - torch.sum(q0.log_scale + 0.5 * torch.pow(eps, 2), 1)
         relu = torch.nn.functional.relu
-        for l1, l2, l3, aff in self._layers():
+        ans = self._act_norms()
+        for k, (l1, l2, l3, aff) in enumerate(self._layers()):
             z1, z2 = z[:, :self.d], z[:, self.d:]
             prm = l3(relu(l2(relu(l1(z1)))))
             shift, scale = prm[:, 0::2], prm[:, 1::2]
@@ -270,10 +344,16 @@ class RealNVP(nn.Module):
             log_q = log_q - torch.sum(scale, dim=1)
             z = torch.cat([z1, z2], 1) @ aff.assemble(inverse=True)
             log_q = log_q + torch.sum(aff.log_S)
+            if self.act_norm:
+                an = ans[k]
+                z = z * torch.exp(an.s) + an.t
+                log_q = log_q - torch.sum(an.s)
         return z, log_q
 
 
 def make_wrapped_normflow_realnvp(dim: int, n_flow_layers: int = 5, layer_nodes_per_dim: int = 10,
                                   act_norm: bool = True) -> RealNVP:
-    """Same name/arguments as experiments/make_flow/make_normflow_model.py:82-96."""
+    """Same name/arguments as experiments/make_flow/make_normflow_model.py:82-96.  With act_norm the reference draws 500
+    samples at construction to initialise the ActNorm layers (:94-95); here that happens the first time the flow's
+    parameters are on the GPU (`RealNVP.init_act_norm`, called lazily by `native()`), the kernels having no CPU path."""
     return RealNVP(dim, n_flow_layers, layer_nodes_per_dim, act_norm)

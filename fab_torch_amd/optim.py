@@ -21,7 +21,7 @@ class FlatAdam(torch.optim.Optimizer):
         for p in self._params:
             _ops.require_device(p, "RealNVP parameters (move the flow to the GPU before building FlatAdam)")
         super().__init__(self._params, dict(lr=lr, betas=betas, eps=eps))
-        self.n = int(_ops.load().flow_grad_floats(flow.dim, flow.n_layers, flow.width))
+        self.n = flow.grad_floats()                  # (+ the ActNorm pairs for an act_norm flow)
         dev = self._params[0].device
         self.theta = torch.empty(self.n, dtype=torch.float32, device=dev)
         views = flow._grad_views(self.theta)

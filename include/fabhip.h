@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 201
+#define FABHIP_ABI_VERSION 202
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -65,6 +65,10 @@ typedef struct {
     const float* perm_P[FABHIP_MAX_LAYERS]; /* [dim][dim] permutation matrix                  */
     const float* loc;                       /* [dim] DiagGaussian.loc                         */
     const float* log_scale;                 /* [dim] DiagGaussian.log_scale                   */
+    /* normflows ActNorm(dim) after layer k's InvertibleAffine (make_normflow_model.py:27-29, act_norm=True):
+     * sampling direction z <- z * exp(s) + t, log_det += sum(s).  NULL (both) = no ActNorm after that layer. */
+    const float* an_s[FABHIP_MAX_LAYERS];   /* [dim] ActNorm.s                                */
+    const float* an_t[FABHIP_MAX_LAYERS];   /* [dim] ActNorm.t                                */
 } fabhip_flow_params;
 
 /* Number of floats of the MFMA-tiled parameter image for a (dim, n_layers, width) flow. */
@@ -173,12 +177,15 @@ int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const f
  *   fabhip_flow_param_grad    : grads[theta] = sum_b coef[b] * d log_q(x_b) / d theta for every parameter,
  *                               coef = d loss / d log_q (autograd's grad_output), written into one flat image:
  *                               per layer [w1 | b1 | w2 | b2 | w3 | b3 | L | U | log_S] (each in the shape of
- *                               the fabhip_flow_params tensor of that name), then loc, log_scale.
+ *                               the fabhip_flow_params tensor of that name), then loc, log_scale; when
+ *                               params->an_s is set (ActNorm flows) then per layer [an_s | an_t] - `grads` must
+ *                               then hold out15[14] floats instead of out15[12].
  * fabhip_flow_grad_layout fills {layer_stride, w1, b1, w2, b2, w3, b3, L, U, log_S (offsets inside a layer
- * block), loc, log_scale (absolute offsets), total}, all in floats.
+ * block), loc, log_scale (absolute offsets), total, an_base (absolute offset of layer 0's [an_s | an_t] pair, the
+ * pairs are 2 dim floats apart), total with ActNorm}, all in floats.
  * ---------------------------------------------------------------------------------------- */
 int64_t fabhip_flow_grad_floats(int32_t dim, int32_t n_layers, int32_t width);
-int fabhip_flow_grad_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t* out13);
+int fabhip_flow_grad_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t* out15);
 size_t fabhip_flow_tape_bytes(int32_t dim, int32_t n_layers, int32_t width, int64_t B);
 /* Layout of the tape (floats): row-major [Bp x width] matrices per layer block, then the base block TB.
  * out18 = {Bp, wz, w1, wh, wp, we, wb (row widths of ZA/GZ, Z1, H1/H2, DP, E1/E2, TB),

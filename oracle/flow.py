@@ -152,6 +152,35 @@ class InvertibleAffine(nn.Module):
         return z @ W, torch.sum(self.log_S)
 
 
+class ActNorm(nn.Module):
+    """normflows ActNorm (flows/normalization.py; AffineConstFlow of flows/affine/coupling.py with scale and shift):
+    forward z * exp(s) + t with log_det sum(s), inverse (z - t) * exp(-s) with log_det -sum(s); the first batch
+    through either direction initialises s, t from its statistics (torch.std: unbiased).  normflows is absent from the
+    reference tree (requirements.txt:3, version unpinned): restated from its published definition, parity unpinned."""
+
+    def __init__(self, dim: int):
+        super().__init__()
+        self.s = nn.Parameter(torch.zeros(1, dim))
+        self.t = nn.Parameter(torch.zeros(1, dim))
+        self.register_buffer("data_dep_init_done", torch.tensor(0.0))
+
+    def forward(self, z):
+        if not self.data_dep_init_done > 0.0:
+            s_init = -torch.log(z.std(dim=0, keepdim=True) + 1e-6)
+            self.s.data = s_init.data
+            self.t.data = (-z.mean(dim=0, keepdim=True) * torch.exp(self.s)).data
+            self.data_dep_init_done = torch.tensor(1.0)
+        return z * torch.exp(self.s) + self.t, torch.sum(self.s)
+
+    def inverse(self, z):
+        if not self.data_dep_init_done > 0.0:
+            s_init = torch.log(z.std(dim=0, keepdim=True) + 1e-6)
+            self.s.data = s_init.data
+            self.t.data = z.mean(dim=0, keepdim=True).data
+            self.data_dep_init_done = torch.tensor(1.0)
+        return (z - self.t) * torch.exp(-self.s), -torch.sum(self.s)
+
+
 class DiagGaussian(nn.Module):
     def __init__(self, shape: int):
         super().__init__()
@@ -203,8 +232,8 @@ class NormalizingFlow(nn.Module):
         return log_q
 
 
-def make_realnvp(dim: int, n_flow_layers: int, layer_nodes_per_dim: int) -> NormalizingFlow:
-    """experiments/make_flow/make_normflow_model.py:11-30 with act_norm=False."""
+def make_realnvp(dim: int, n_flow_layers: int, layer_nodes_per_dim: int, act_norm: bool = False) -> NormalizingFlow:
+    """experiments/make_flow/make_normflow_model.py:11-30."""
     flows = []
     width = dim * layer_nodes_per_dim
     for _ in range(n_flow_layers):
@@ -212,6 +241,8 @@ def make_realnvp(dim: int, n_flow_layers: int, layer_nodes_per_dim: int) -> Norm
         param_map = MLP([d, width, width, 2 * (dim - d)], init_zeros=True)
         flows.append(AffineCouplingBlock(param_map))
         flows.append(InvertibleAffine(dim))
+        if act_norm:
+            flows.append(ActNorm(dim))
     return NormalizingFlow(DiagGaussian(dim), flows)
 
 
