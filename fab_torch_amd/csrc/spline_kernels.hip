@@ -30,7 +30,9 @@ constexpr int SP_META_ROWS = 12;        // per-layer metadata rows of 64 floats 
 constexpr float SP_MIN_W = 1e-3f, SP_MIN_H = 1e-3f, SP_MIN_D = 1e-3f;
 
 enum { M_IDF = 0, M_TRF = 1, M_CIRC = 2, M_TB = 3, M_PFON = 4, M_PFS = 5, M_PFK = 6, M_PRESH = 7, M_PREON = 8,
-       M_POSTSH = 9, M_POSTON = 10, M_CNT = 11 };
+       M_POSTSH = 9, M_POSTON = 10, M_CNT = 11,
+       M_POSID = 12, M_POSTR = 13 };      // derived at pack time: position of coordinate j among the identity / transformed
+                                          // features of the layer (-1: not one), so the element-wise kernels need no search
 
 struct SplineDims {
     int D, L, W, Wp, NTWM, KBW;          // hidden width, padded to 64 * tiles-per-wave
@@ -47,7 +49,7 @@ FAB_HD SplineDims make_spline_dims(int D, int L, int W) {
     f.NCH = ceil_div(f.n_tr_max * SP_NP, f.Wp);
     f.NFP = f.NCH * f.Wp;
     int o = 0;
-    f.o_meta = o; o += SP_META_ROWS * 64;
+    f.o_meta = o; o += (SP_META_ROWS + 2) * 64;
     f.o_unc = o; o += SP_MD * SP_NP + 32;                 // [64][25] (+ pad to a multiple of 64 floats below)
     o = (o + 63) & ~63;
     f.o_pfw = o; o += 2 * SP_MD;                           // [64][2] periodic-feature weights
@@ -125,8 +127,16 @@ __global__ __launch_bounds__(256) void k_spline_pack_layer(SplineDims f, SplineS
     for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.layer_stride; off += gridDim.x * blockDim.x) {
         float v = 0.f;
         int k, n;
-        if (off < f.o_unc) {
+        if (off < f.o_meta + SP_META_ROWS * 64) {
             v = s.meta[off - f.o_meta];
+        } else if (off < f.o_meta + (SP_META_ROWS + 2) * 64) {
+            const int e = off - f.o_meta - SP_META_ROWS * 64, row = e >> 6, j = e & 63;
+            const int cnt = row == 0 ? n_id : n_tr;
+            const float* feats = s.meta + (row == 0 ? M_IDF : M_TRF) * 64;
+            v = -1.f;
+            for (int i = 0; i < cnt; ++i) if ((int)feats[i] == j) v = (float)i;
+        } else if (off < f.o_unc) {
+            v = 0.f;
         } else if (off < f.o_pfw) {
             const int e = off - f.o_unc, i = e / SP_NP, p = e % SP_NP;
             if (i < n_id && e < SP_MD * SP_NP)
@@ -250,9 +260,11 @@ __device__ __forceinline__ void sp_tape_rows(float* __restrict__ dst, int width,
 }
 
 // h0 = A0 W0 + b0 (kept raw in H0), t = relu(h0) Wa + ba (kept raw in T), h1 = h0 + relu(t) Wb + bb -> X1
+// `act` (nullable): relu(h0) | relu(t) of the tile's rows are kept ([B][2 Wp], rows row0..) for k_spline_net_bwd, which
+// then only needs their signs (the ReLU decisions) and skips this recomputation.
 template <int NTWM>
 __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds& l, const float* __restrict__ Lp, float* lds,
-                                              const Tid& t) {
+                                              const Tid& t, float* __restrict__ act = nullptr, long row0 = 0, long B = 0) {
     constexpr int DW = depth_w<NTWM>();
     float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
     float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2;
@@ -265,6 +277,8 @@ __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds&
             const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
             H0[o] = acc[i][r];
             X2[o] = acc[i][r] > 0.f ? acc[i][r] : 0.f;
+            if (act && row0 + 4 * t.q + r < B)
+                act[(row0 + 4 * t.q + r) * (2 * f.Wp) + 16 * (t.wave + 4 * i) + t.n] = X2[o];
         }
     __syncthreads();
     sp_gemm<NTWM, DW, true>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wa), Lp + f.o_ba, t, acc);
@@ -275,6 +289,8 @@ __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds&
             const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
             T[o] = acc[i][r];
             X1[o] = acc[i][r] > 0.f ? acc[i][r] : 0.f;
+            if (act && row0 + 4 * t.q + r < B)
+                act[(row0 + 4 * t.q + r) * (2 * f.Wp) + f.Wp + 16 * (t.wave + 4 * i) + t.n] = X1[o];
         }
     __syncthreads();
     sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wb), Lp + f.o_bb, t, acc);
@@ -292,7 +308,7 @@ __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds&
 template <int NTWM>
 __global__ __launch_bounds__(NTHREADS) void k_spline_net_fwd(SplineDims f, NetLds l, const float* __restrict__ packed,
                                                              int layer, const float* __restrict__ Z,
-                                                             float* __restrict__ P, long B) {
+                                                             float* __restrict__ P, long B, float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid t;
     constexpr int DW = depth_w<NTWM>();
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_fwd(SplineDims f, NetLd
     const long row0 = (long)blockIdx.x * ROWS;
     sp_load_identity(f, Lp, Z, row0, B, lds + l.o_A0, l.AS, t);
     __syncthreads();
-    sp_net_hidden<NTWM>(f, l, Lp, lds, t);
+    sp_net_hidden<NTWM>(f, l, Lp, lds, t, act, row0, B);
     const float* X1 = lds + l.o_X1;
     const int per = 4 * NTWM * f.KBW * 256;
     for (int c = 0; c < f.NCH; ++c) {
@@ -322,7 +338,7 @@ template <int NTWM>
 __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLds l, const float* __restrict__ packed,
                                                              int layer, const float* __restrict__ Z,
                                                              const float* __restrict__ dP, float* __restrict__ G, long B,
-                                                             SplineTape tp) {
+                                                             SplineTape tp, const float* __restrict__ act) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid t;
     constexpr int DW = depth_w<NTWM>();
@@ -332,14 +348,22 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
     float* tl = tp.base ? tp.base + (size_t)layer * tp.layer_stride : nullptr;
     float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
     float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* DP = lds + l.o_DP; float* PART = lds + l.o_PART;
-    sp_load_identity(f, Lp, Z, row0, B, A0, l.AS, t);
+    if (!act) sp_load_identity(f, Lp, Z, row0, B, A0, l.AS, t);
     for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) {
         const int r = e / l.PS, j = e % l.PS;
         const long g = row0 + r;
         DP[e] = (j < f.NFP && g < B) ? dP[g * f.NFP + j] : 0.f;
     }
+    if (act) {                                          // the forward kept relu(h0) | relu(t): only their signs matter here
+        for (int e = t.tid; e < ROWS * f.Wp; e += NTHREADS) {
+            const int r = e / f.Wp, c = e % f.Wp;
+            const long g = row0 + r;
+            H0[r * l.WS + c] = g < B ? act[g * (2 * f.Wp) + c] : 0.f;
+            T[r * l.WS + c] = g < B ? act[g * (2 * f.Wp) + f.Wp + c] : 0.f;
+        }
+    }
     __syncthreads();
-    sp_net_hidden<NTWM>(f, l, Lp, lds, t);              // recompute h0 (H0) and t (T): the ReLU decisions
+    if (!act) sp_net_hidden<NTWM>(f, l, Lp, lds, t);    // recompute h0 (H0) and t (T): the ReLU decisions
     if (tl) {
         sp_tape_rows(tl + tp.o_A0, 64, A0, l.AS, row0, B, t);
         sp_tape_rows(tl + tp.o_R0, f.Wp, X2, l.WS, row0, B, t);
@@ -584,9 +608,7 @@ __global__ __launch_bounds__(256) void k_spline_apply(SplineDims f, const float*
     float ld = 0.f;
     if (lane < f.D) {
         // role of this coordinate
-        int pos_id = -1, pos_tr = -1;
-        for (int i = 0; i < n_id; ++i) if ((int)meta[M_IDF * 64 + i] == lane) pos_id = i;
-        for (int i = 0; i < n_tr; ++i) if ((int)meta[M_TRF * 64 + i] == lane) pos_tr = i;
+        const int pos_id = (int)meta[M_POSID * 64 + lane], pos_tr = (int)meta[M_POSTR * 64 + lane];
         const bool circ = meta[M_CIRC * 64 + lane] != 0.f;
         const float tb = meta[M_TB * 64 + lane];
         float z = Zin[g * f.D + lane], out = z;
@@ -692,9 +714,7 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
     // zero the padding columns of this chain's dP row (the conditioner backward reads all NFP of them)
     for (int j = n_tr * SP_NP + lane; j < f.NFP; j += 64) dP[g * f.NFP + j] = 0.f;
     if (lane >= f.D) return;
-    int pos_id = -1, pos_tr = -1;
-    for (int i = 0; i < n_id; ++i) if ((int)meta[M_IDF * 64 + i] == lane) pos_id = i;
-    for (int i = 0; i < n_tr; ++i) if ((int)meta[M_TRF * 64 + i] == lane) pos_tr = i;
+    const int pos_id = (int)meta[M_POSID * 64 + lane], pos_tr = (int)meta[M_POSTR * 64 + lane];
     const bool circ = meta[M_CIRC * 64 + lane] != 0.f;
     const float tb = meta[M_TB * 64 + lane];
     const float z = Zin[g * f.D + lane], gy = Gout[g * f.D + lane];
@@ -730,26 +750,27 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
 
 template <int NTWM>
 static int launch_net(const SplineDims& f, const float* packed, int layer, const float* Z, float* P, const float* dP,
-                      float* G, long B, hipStream_t st, const SplineTape& tp) {
+                      float* G, long B, hipStream_t st, const SplineTape& tp, float* act) {
     const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
     const bool bwd = dP != nullptr;
     const NetLds l = make_net_lds(f, bwd);
     const size_t bytes = (size_t)l.total * 4;
     if (bwd) {
         FAB_TRY(set_max_lds((const void*)k_spline_net_bwd<NTWM>, bytes));
-        hipLaunchKernelGGL((k_spline_net_bwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, dP, G, B, tp);
+        hipLaunchKernelGGL((k_spline_net_bwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, dP, G, B, tp,
+                           tp.base ? nullptr : act);
     } else {
         FAB_TRY(set_max_lds((const void*)k_spline_net_fwd<NTWM>, bytes));
-        hipLaunchKernelGGL((k_spline_net_fwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, P, B);
+        hipLaunchKernelGGL((k_spline_net_fwd<NTWM>), grid, block, bytes, st, f, l, packed, layer, Z, P, B, act);
     }
     return check_launch();
 }
 
 static int net(const SplineDims& f, const float* packed, int layer, const float* Z, float* P, const float* dP, float* G,
-               long B, hipStream_t st, const SplineTape& tp = SplineTape{}) {
-    if (f.NTWM == 1) return launch_net<1>(f, packed, layer, Z, P, dP, G, B, st, tp);
-    if (f.NTWM == 2) return launch_net<2>(f, packed, layer, Z, P, dP, G, B, st, tp);
-    if (f.NTWM == 4) return launch_net<4>(f, packed, layer, Z, P, dP, G, B, st, tp);
+               long B, hipStream_t st, const SplineTape& tp = SplineTape{}, float* act = nullptr) {
+    if (f.NTWM == 1) return launch_net<1>(f, packed, layer, Z, P, dP, G, B, st, tp, act);
+    if (f.NTWM == 2) return launch_net<2>(f, packed, layer, Z, P, dP, G, B, st, tp, act);
+    if (f.NTWM == 4) return launch_net<4>(f, packed, layer, Z, P, dP, G, B, st, tp, act);
     return FABHIP_ENOTSUP;
 }
 
@@ -789,6 +810,7 @@ size_t fabhip_spline_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidd
     size_t s = sp_al((size_t)(f.L + 1) * B * f.D * 4);                 // layer input states
     s += sp_al((size_t)(with_grad ? f.L : 1) * B * f.NFP * 4);          // conditioner outputs (kept per layer for the reverse sweep)
     if (with_grad) s += sp_al((size_t)B * f.NFP * 4) + 2 * sp_al((size_t)B * f.D * 4);
+    if (with_grad) s += sp_al((size_t)f.L * B * 2 * f.Wp * 4);          // relu(h0) | relu(t) per layer (ReLU decisions)
     return s + 256;
 }
 
@@ -808,8 +830,10 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     if (grad_x) {
         dP = (float*)ws; ws += sp_al((size_t)B * f.NFP * 4);
         Ga = (float*)ws; ws += sp_al((size_t)B * f.D * 4);
-        Gb = (float*)ws;
+        Gb = (float*)ws; ws += sp_al((size_t)B * f.D * 4);
     }
+    float* act = (grad_x && !tape) ? (float*)ws : nullptr;               // (the tape path recomputes: it needs h1 too)
+    const size_t as = (size_t)B * 2 * f.Wp;
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
     const SplineTape tp = make_spline_tape(f, (long)B, tape);
@@ -818,7 +842,8 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
                        dim3(256), 0, st, f, pk, x, Z + (size_t)f.L * zs, log_q, (long)B);
     for (int l = f.L - 1; l >= 0; --l) {
         float* Pl = P + (grad_x ? (size_t)l * ps : 0);
-        FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, Pl, nullptr, nullptr, (long)B, st));
+        FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, Pl, nullptr, nullptr, (long)B, st, SplineTape{},
+                    act ? act + (size_t)l * as : nullptr));
         hipLaunchKernelGGL(k_spline_apply<0>, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs, Pl, Z + (size_t)l * zs,
                            log_q, 1.f, (long)B);
     }
@@ -831,7 +856,8 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
             float* dUl = tape ? tape + (size_t)l * tp.layer_stride + tp.o_dU : nullptr;
             hipLaunchKernelGGL(k_spline_apply_bwd, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs,
                                P + (size_t)l * ps, gin, out, dPl, (long)B, dUl);
-            FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, dPl, out, (long)B, st, tp));
+            FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, dPl, out, (long)B, st, tp,
+                        act ? act + (size_t)l * as : nullptr));
             gin = out;
         }
     }

@@ -274,3 +274,42 @@ def test_fab_buffer_trainer_with_the_spline_flow():
     if x_eval is not None:                                  # forward KL to exact target samples improves
         ll1 = float(hf.log_prob(x_eval).mean().detach())
         assert ll1 > ll0, f"test-set log-likelihood {ll0:.3f} -> {ll1:.3f}"
+
+
+def test_cfg3_with_the_spline_flow_at_full_size():
+    """BASELINE cfg 3 as BASELINE.json words it: ManyWell-32, SPLINE flow 12 layers (hidden 256, 8 bins), 2048 chains, 12
+    intermediate distributions, HMC(5), prioritised replay buffer - one trainer iteration at full size through the
+    generic plug-in path; the flow's densities of a 64-chain slice of the AIS batch against the CPU oracle."""
+    D, L, hidden, M, B, SL = 32, 12, 256, 12, 2048, 64
+    torch.manual_seed(0)
+    of = osp.make_circular_coupled_flow(D, L, hidden, (), torch.full((D,), 5.0), seed=0)
+    osp.randomize(of, 0.1, 1)
+    hf = fa.make_wrapped_normflow_spline(D, L, hidden, (), 5.0, seed=0)
+    hf._nf_model.load_state_dict(of.state_dict(), strict=True)
+    hf = hf.to(DEV)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1, L=5).to(DEV)
+    model = fa.FABModel(hf, target, M, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
+    ais = model.annealed_importance_sampler
+
+    def initial_sampler():
+        pt, lw = ais.sample_and_log_weights(B, logging=False)
+        return pt.x, lw, pt.log_q
+    buf = fa.PrioritisedReplayBuffer(D, 6 * B, 2 * B, initial_sampler, device=DEV)
+    opt = torch.optim.Adam(hf.parameters(), lr=1e-4)
+    trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=2.0, n_batches_buffer_sampling=2)
+    # the AIS batch of a fresh call: point fields consistent with the oracle flow / target on a slice
+    pt, lw = ais.sample_and_log_weights(B)
+    assert pt.x.shape == (B, D) and torch.isfinite(lw).all() and torch.isfinite(pt.x).all()
+    xs = pt.x[:SL].cpu()
+    with torch.no_grad():
+        lq_o = of.log_prob(xs)
+    assert close(pt.log_q[:SL], lq_o, RTOL), f"log q of the AIS points: {worst(pt.log_q[:SL], lq_o):.2f}x tol"
+    assert close(pt.log_p[:SL], otgt.ManyWell(D).log_prob(xs), RTOL)
+    before = [p.detach().clone() for p in hf.parameters()]
+    info = trainer.step(0, B)
+    assert math.isfinite(info["loss"]) and math.isfinite(info["grad_norm"]) and 0 < info["ess_ais"] <= 1
+    idx = trainer.last_indices
+    assert idx.shape == (2 * B,) and len(set(idx.tolist())) == 2 * B
+    assert any(not torch.equal(a, p.detach()) for a, p in zip(before, hf.parameters()))
+    assert all(torch.isfinite(p).all() for p in hf.parameters())
