@@ -123,7 +123,7 @@ def resample_rooflines(dev, log2n=26):
     return rows
 
 
-def trained_flow_ess(dev):
+def trained_flow_ess(dev, fast=False):
     """"Meaningful ESS" row: the committed small TRAINED flow (tests/golden/g13: ManyWell-6, trained with
     the reference's PrioritisedBufferTrainer) and the reference's own evaluation AIS call on it (1024 chains, target p,
     frozen step sizes, captured noise): the HIP path on the identical noise must reproduce its ESS (north_star: within 1 %)."""
@@ -147,7 +147,9 @@ def trained_flow_ess(dev):
             hmc.epsilons.copy_(torch.tensor(g["epsilons"])); hmc.common_epsilon.copy_(torch.tensor(g["common_epsilon"]))
         ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target, float(g["alpha"]), M)
         T = lambda k: torch.tensor(g[k]).to(dev)      # noqa: E731
-        ais.sample_and_log_weights(int(g["B"]), eps0=T(f"{tag}_eps0"), noise_a=T(f"{tag}_noise_p"), noise_b=T(f"{tag}_noise_e"))
+        with fa.fast_mode(fast):
+            ais.sample_and_log_weights(int(g["B"]), eps0=T(f"{tag}_eps0"), noise_a=T(f"{tag}_noise_p"),
+                                       noise_b=T(f"{tag}_noise_e"))
         info = ais.get_logging_info()
         ref = float(g[f"{tag}_ess_ais"])
         out["target_" + tag] = {"ess_ais_hip": info["ess_ais"], "ess_ais_reference": ref,
@@ -233,6 +235,24 @@ def main():
         tt = torch.tensor([elapsed_eval], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed_eval = float(tt.item())
+    # third row: FAST MODE (bf16 W x W GEMMs in the transition kernels; NOT the parity path, never `value`) on the same
+    # workload, step-size tuning on ("an fp32 parity mode and a fast mode, report both")
+    saved = {k: v.clone() for k, v in hmc.state_dict().items()}
+    with fa.fast_mode():
+        for _ in range(10):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed_fast = time.perf_counter() - t0
+        info_fast = ais.get_logging_info()
+    hmc.load_state_dict(saved)
+    if distributed:
+        tt = torch.tensor([elapsed_fast], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed_fast = float(tt.item())
 
     # ---- roofline of the dominant kernel (k_hmc_step): live HIP-event timing on the launch stream -----
     roof = None
@@ -279,10 +299,11 @@ def main():
         hmc.set_eval_mode(False)
 
     # ---- second roofline: the resample scan + the whole systematic resampler at N = 2^26 (HBM-bound) ----
-    roof_extra, ess_trained = None, None
+    roof_extra, ess_trained, ess_trained_fast = None, None, None
     if rank == 0:
         roof_extra = resample_rooflines(dev)
         ess_trained = trained_flow_ess(dev)
+        ess_trained_fast = trained_flow_ess(dev, fast=True)
 
     if rank == 0:
         total = world * B_PER_GPU * args.steps
@@ -301,6 +322,16 @@ def main():
             "roofline": roof,
             "roofline_resample": roof_extra,
             "ess_trained": ess_trained,
+            "fast_mode": {
+                "what": "NOT the parity path: the two 320x320 GEMMs of every coupling layer on the bf16 matrix cores "
+                        "(v_mfma_f32_16x16x32_bf16, fp32 accumulation) inside the transition kernels; log q deviates "
+                        "1e-3 .. 1e-2 from the fp32 kernels",
+                "value": total / elapsed_fast, "unit": "AIS samples/s", "ms_per_step": elapsed_fast / args.steps * 1e3,
+                "speedup_vs_value": elapsed / elapsed_fast, "ess_ais": info_fast["ess_ais"], "log_Z": info_fast["log_Z"],
+                "ess_trained": None if ess_trained_fast is None else
+                {t: {k: ess_trained_fast[t][k] for k in ("ess_ais_hip", "ess_ais_reference", "rel_diff", "log_Z_hip")}
+                 for t in ("target_p", "target_g")},
+            },
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(flow_state)

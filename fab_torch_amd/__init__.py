@@ -18,10 +18,30 @@ from .wrappers import WrappedTorchDist
 from .spline_flow import CircularCoupledRQSFlow, make_wrapped_normflow_spline
 from .resample import resample, multinomial_indices, systematic_indices, multinomial_torch_compat, gather_rows
 
+
+
+class fast_mode:
+    """`fab_torch_amd.fast_mode(True)` / `with fab_torch_amd.fast_mode():` - the HMC transition / AIS kernels run the
+    width x width GEMMs of the RealNVP conditioners on the bf16 matrix cores (include/fabhip.h, fabhip_set_fast_mode).
+    NOT the parity path: log q differs from the fp32 kernels at the 1e-3 .. 1e-2 level.  Process-wide switch."""
+
+    def __init__(self, on: bool = True):
+        from . import _ops
+        self._ops = _ops.load()
+        self.prev = bool(self._ops.set_fast_mode(bool(on)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self._ops.set_fast_mode(self.prev)
+        return False
+
+
 __all__ = [
     "Point", "RealNVP", "make_wrapped_normflow_realnvp", "ManyWellEnergy", "GMM", "TransitionOperator",
     "HamiltonianMonteCarlo", "Metropolis", "create_point", "AnnealedImportanceSampler", "LoggingInfo",
     "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
     "multinomial_torch_compat", "gather_rows", "FABModel", "PrioritisedReplayBuffer",
-    "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam", "WrappedTorchDist", "CircularCoupledRQSFlow", "make_wrapped_normflow_spline",
+    "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam", "WrappedTorchDist", "CircularCoupledRQSFlow", "make_wrapped_normflow_spline", "fast_mode",
 ]

@@ -54,10 +54,10 @@ __device__ __forceinline__ float clamp_nan0(float g, float mg) {
 // ------------------------------------------------------------------------------------------------
 // create_point: log q (+grad), log p (+grad) at point.x      (fab/sampling_methods/base.py:59-72)
 // ------------------------------------------------------------------------------------------------
-template <int NTWM, bool GRAD>
-__global__ __launch_bounds__(NTHREADS) void k_create_point(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
-                                                           TargetDev tg, PointDev pt, long B) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int NTWM, bool GRAD, bool FAST>
+__device__ __forceinline__ void create_point_body(const FlowDims& f, const FlowLds& l, const ExtraLds& x,
+                                                  const float* __restrict__ packed, const TargetDev& tg, const PointDev& pt,
+                                                  long B, float* lds) {
     Tid t;
     const int D = f.D;
     const long row0 = (long)blockIdx.x * ROWS;
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(NTHREADS) void k_create_point(FlowDims f, FlowLds l
     load_state_to_u0(l, D, lds, XP, t);
     __syncthreads();
     int goff = 0;
-    const float lq = flow_log_prob_tile<NTWM, GRAD>(f, l, packed, lds, t, &goff);
+    const float lq = flow_log_prob_tile<NTWM, GRAD, false, FAST>(f, l, packed, lds, t, &goff);
     const float lp = target_tile<GRAD>(tg, XP, D, GP, D, t);
     const long g = row0 + t.row;
     if (g < B) {
@@ -86,17 +86,31 @@ __global__ __launch_bounds__(NTHREADS) void k_create_point(FlowDims f, FlowLds l
     }
 }
 
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_create_point(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
+                                                           TargetDev tg, PointDev pt, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    create_point_body<NTWM, GRAD, false>(f, l, x, packed, tg, pt, B, lds);
+}
+// fast mode (bf16 W x W GEMMs, flow_device.h): same kernel, not the parity path
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_create_point_fast(FlowDims f, FlowLds l, ExtraLds x,
+                                                                const float* __restrict__ packed, TargetDev tg, PointDev pt,
+                                                                long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    create_point_body<NTWM, GRAD, true>(f, l, x, packed, tg, pt, B, lds);
+}
+
 // ------------------------------------------------------------------------------------------------
 // AIS chain initialisation (ais.py:55-64): x, log_q0 = flow.sample(eps0); point = create_point(x);
 // log_w = pi_beta1(point) - log_q0.   With GRAD (HMC) log q is re-evaluated through log_prob, as the
 // reference does (base.py:65-68 ignores the supplied log_q_x).
 // ------------------------------------------------------------------------------------------------
-template <int NTWM, bool GRAD>
-__global__ __launch_bounds__(NTHREADS) void k_ais_init(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
-                                                       TargetDev tg, const float* __restrict__ eps0, PointDev pt,
-                                                       float* __restrict__ log_w, float* __restrict__ base_log_w,
-                                                       fabhip_anneal an, long B) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int NTWM, bool GRAD, bool FAST>
+__device__ __forceinline__ void ais_init_body(const FlowDims& f, const FlowLds& l, const ExtraLds& x,
+                                              const float* __restrict__ packed, const TargetDev& tg,
+                                              const float* __restrict__ eps0, const PointDev& pt, float* __restrict__ log_w,
+                                              float* __restrict__ base_log_w, const fabhip_anneal& an, long B, float* lds) {
     Tid t;
     const int D = f.D;
     const long row0 = (long)blockIdx.x * ROWS;
@@ -118,7 +132,7 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init(FlowDims f, FlowLds l, Ex
     if (GRAD) {
         load_state_to_u0(l, D, lds, XP, t);
         __syncthreads();
-        lq = flow_log_prob_tile<NTWM, true>(f, l, packed, lds, t, &goff);
+        lq = flow_log_prob_tile<NTWM, true, false, FAST>(f, l, packed, lds, t, &goff);
     }
     const float lp = target_tile<GRAD>(tg, XP, D, GP, D, t);
     const long g = row0 + t.row;
@@ -137,6 +151,25 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init(FlowDims f, FlowLds l, Ex
             if (base_log_w) base_log_w[g] = lp - lq0;          // ais.py:160 (log q of the sampling pass)
         }
     }
+}
+
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_ais_init(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
+                                                       TargetDev tg, const float* __restrict__ eps0, PointDev pt,
+                                                       float* __restrict__ log_w, float* __restrict__ base_log_w,
+                                                       fabhip_anneal an, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ais_init_body<NTWM, GRAD, false>(f, l, x, packed, tg, eps0, pt, log_w, base_log_w, an, B, lds);
+}
+// fast mode: the sampling pass stays fp32; the density the transitions continue from is the bf16-GEMM one
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_ais_init_fast(FlowDims f, FlowLds l, ExtraLds x,
+                                                            const float* __restrict__ packed, TargetDev tg,
+                                                            const float* __restrict__ eps0, PointDev pt,
+                                                            float* __restrict__ log_w, float* __restrict__ base_log_w,
+                                                            fabhip_anneal an, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    ais_init_body<NTWM, true, true>(f, l, x, packed, tg, eps0, pt, log_w, base_log_w, an, B, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -159,10 +192,10 @@ struct HmcK {
     float* part_dist;                // [nblk] sum of the store_info distance
 };
 
-template <int NTWM>
-__global__ __launch_bounds__(NTHREADS) void k_hmc_step(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
-                                                       TargetDev tg, HmcK a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int NTWM, bool FAST>
+__device__ __forceinline__ void hmc_step_body(const FlowDims& f, const FlowLds& l, const ExtraLds& x,
+                                              const float* __restrict__ packed, const TargetDev& tg, const HmcK& a,
+                                              float* lds) {
     Tid t;
     const int D = f.D;
     const long nv = a.n_valid ? (long)*a.n_valid : a.B;
@@ -209,7 +242,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step(FlowDims f, FlowLds l, Ex
         __syncthreads();
         load_state_to_u0(l, D, lds, XP, t);
         __syncthreads();
-        lq = flow_log_prob_tile<NTWM, true>(f, l, packed, lds, t, &goff);
+        lq = flow_log_prob_tile<NTWM, true, false, FAST>(f, l, packed, lds, t, &goff);
         lp = target_tile<true>(tg, XP, D, GP, D, t);
         for (int j = t.c; j < D; j += 16) {
             const float gr = -(a.c.g_q * lds[goff + t.row * l.DS + j] + a.c.g_p * GP[t.row * D + j]);
@@ -268,6 +301,20 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step(FlowDims f, FlowLds l, Ex
         a.part_acc[blockIdx.x] = s;
         a.part_dist[blockIdx.x] = d;
     }
+}
+
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_hmc_step(FlowDims f, FlowLds l, ExtraLds x, const float* __restrict__ packed,
+                                                       TargetDev tg, HmcK a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    hmc_step_body<NTWM, false>(f, l, x, packed, tg, a, lds);
+}
+// fast mode (fabhip_set_fast_mode): the W x W GEMMs of every coupling layer on the bf16 matrix cores
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_hmc_step_fast(FlowDims f, FlowLds l, ExtraLds x,
+                                                            const float* __restrict__ packed, TargetDev tg, HmcK a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    hmc_step_body<NTWM, true>(f, l, x, packed, tg, a, lds);
 }
 
 // step-size adaptation from the block partials (hmc.py:122-123,162-170), fixed summation order
@@ -487,6 +534,11 @@ static int launch_create_point(const FlowDims& f, const float* packed, const Tar
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid(nblk_of(B)), block(NTHREADS);
     if (with_grad) {
+        if (fast_mode()) {
+            FAB_TRY(set_max_lds((const void*)k_create_point_fast<NTWM, true>, bytes));
+            hipLaunchKernelGGL((k_create_point_fast<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, pt, B);
+            return check_launch();
+        }
         FAB_TRY(set_max_lds((const void*)k_create_point<NTWM, true>, bytes));
         hipLaunchKernelGGL((k_create_point<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, pt, B);
     } else {
@@ -505,6 +557,11 @@ static int launch_ais_init(const FlowDims& f, const float* packed, const TargetD
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid(nblk_of(B)), block(NTHREADS);
     if (with_grad) {
+        if (fast_mode()) {
+            FAB_TRY(set_max_lds((const void*)k_ais_init_fast<NTWM>, bytes));
+            hipLaunchKernelGGL((k_ais_init_fast<NTWM>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, base_log_w, an, B);
+            return check_launch();
+        }
         FAB_TRY(set_max_lds((const void*)k_ais_init<NTWM, true>, bytes));
         hipLaunchKernelGGL((k_ais_init<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, base_log_w, an, B);
     } else {
@@ -519,6 +576,11 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
     const FlowLds l = make_flow_lds(f, true);
     const ExtraLds x = make_extra_lds(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
+    if (fast_mode()) {
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_fast<NTWM>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_fast<NTWM>), dim3(nblk_of(a.B)), dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);
+        return check_launch();
+    }
     FAB_TRY(set_max_lds((const void*)k_hmc_step<NTWM>, bytes));
     hipLaunchKernelGGL((k_hmc_step<NTWM>), dim3(nblk_of(a.B)), dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);
     return check_launch();

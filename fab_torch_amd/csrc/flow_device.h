@@ -664,6 +664,173 @@ __device__ __forceinline__ void dense_masked(const float* A, int lda, int KB, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// FAST MODE (fabhip_set_fast_mode(1); NOT the parity path): the two W x W GEMMs of a coupling layer - 87 % of its
+// flops - on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation).  Weights come from a second, bf16
+// image of W2 / W2^T (FlowDims::o_W2h / o_W2Th, packed by k_pack_bf16); activations stay fp32 in LDS and are rounded
+// to bf16 (v_cvt_pk_bf16_f32, round to nearest even) as they are fetched.  Everything else (first / last conditioner
+// layer, affine maps, coupling arithmetic, accumulation, the reverse sweep's structure) is unchanged.
+// Packed bf16 B-operand tile (c, S) of a K x N matrix: 64 lanes x 16 bytes, lane l = (g = l>>4, n = l&15) holds
+// B[32S + 8g + j][16c + n], j = 0..7; the A fragment of lane (g, row) is A[row][32S + 8g + j]: the same (g, j) -> k
+// map on both sides, which is all the instruction's dot product needs.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+__device__ __forceinline__ f32x4 mfma_bf16(const float4& a0, const float4& a1, const uint4& b, f32x4 c) {
+    union { unsigned u[4]; bf16x8 v; } ua, ub;
+    ua.u[0] = cvt_pk_bf16(a0.x, a0.y); ua.u[1] = cvt_pk_bf16(a0.z, a0.w);
+    ua.u[2] = cvt_pk_bf16(a1.x, a1.y); ua.u[3] = cvt_pk_bf16(a1.z, a1.w);
+    ub.u[0] = b.x; ub.u[1] = b.y; ub.u[2] = b.z; ub.u[3] = b.w;
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, c, 0, 0, 0);
+}
+
+// acc[i] += A[16 x 64 NTWM] (fp32, LDS) @ B[:, tile wave + 4 i] (bf16 image), K = 64 NTWM = 2 NTWM blocks of 32.
+// Plain compiler-tracked loads in straight-line code, two chunks of CH k-blocks in flight (CH NTWM <= 25 loads each:
+// the vector-memory counter is 6 bits - with more than 63 loads outstanding waits release early, measured).  `mid`
+// runs once chunk 0 has been multiplied: the requests of the stages after this GEMM go out there (they stay in flight
+// behind chunk 1), not in front of it.  Never more than 63 loads in flight.
+template <int NTWM, int CH, int C, class Mid>
+__device__ __forceinline__ void gemm_bf16_chunk(uint4 (&b0)[CH][NTWM], uint4 (&b1)[CH][NTWM], const float* __restrict__ arow,
+                                                const uint4* __restrict__ bw, f32x4 (&acc)[NTWM], Mid& mid) {
+    constexpr int KB2 = 2 * NTWM, NCH = (KB2 + CH - 1) / CH;
+    if constexpr (C < NCH) {
+        uint4 (&b)[CH][NTWM] = (C & 1) ? b1 : b0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int S = C * CH + c;
+            if (S < KB2) {
+                const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * S);
+                const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * S + 4);
+                union { unsigned u[4]; bf16x8 v; } ua;
+                ua.u[0] = cvt_pk_bf16(a0.x, a0.y); ua.u[1] = cvt_pk_bf16(a0.z, a0.w);
+                ua.u[2] = cvt_pk_bf16(a1.x, a1.y); ua.u[3] = cvt_pk_bf16(a1.z, a1.w);
+#pragma unroll
+                for (int i = 0; i < NTWM; ++i) {
+                    union { uint4 q; bf16x8 v; } ub;
+                    ub.q = b[c][i];
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        // two chunks (NTWM <= 5): behind chunk 0, at most 25 + 46 - ... <= 56 loads in flight; more chunks (NTWM = 8, up
+        // to 46 requests): only after the last chunk, when nothing else is in flight
+        if constexpr (C == (NCH == 2 ? 0 : NCH - 1)) mid();
+        if constexpr (C + 2 < NCH) {                          // refill this buffer with chunk C + 2
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+#pragma unroll
+                for (int i = 0; i < NTWM; ++i)
+                    if ((C + 2) * CH + c < KB2) b[c][i] = bw[((size_t)i * 4 * KB2 + (C + 2) * CH + c) * 64];
+        }
+        gemm_bf16_chunk<NTWM, CH, C + 1>(b0, b1, arow, bw, acc, mid);
+    }
+}
+
+template <int NTWM>
+__host__ __device__ constexpr int bf16_chunk() { return NTWM <= 5 ? NTWM : 24 / NTWM; }     // NTWM = 8: 3 k-blocks x 8 tiles
+
+// chunk 0 (+ the bias of the wave's columns) of a bf16 GEMM, requested one short stage early with plain loads
+template <int NTWM>
+struct Bf16Pre {
+    uint4 b[bf16_chunk<NTWM>()][NTWM];
+    float bv[NTWM];
+};
+
+template <int NTWM, bool BIAS>
+__device__ __forceinline__ void bf16pre_load(Bf16Pre<NTWM>& p, const uint4* __restrict__ Bh, const float* __restrict__ bias,
+                                             const Tid& t) {
+    constexpr int KB2 = 2 * NTWM, CH = bf16_chunk<NTWM>();
+    const uint4* bw = Bh + ((size_t)t.wave * KB2) * 64 + t.lane;
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) p.bv[i] = BIAS ? bias[16 * (t.wave + 4 * i) + t.n] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) p.b[c][i] = bw[((size_t)i * 4 * KB2 + c) * 64];
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int NTWM, class Mid>
+__device__ __forceinline__ void gemm_bf16(const float* __restrict__ A, int lda, const uint4* __restrict__ Bh, const Tid& t,
+                                          f32x4 (&acc)[NTWM], Mid& mid, const Bf16Pre<NTWM>& pre) {
+    constexpr int KB2 = 2 * NTWM;
+    constexpr int CH = bf16_chunk<NTWM>();
+    const float* arow = A + t.n * lda + 8 * t.q;
+    const uint4* bw = Bh + ((size_t)t.wave * KB2) * 64 + t.lane;
+    uint4 b0[CH][NTWM], b1[CH][NTWM];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) b0[c][i] = pre.b[c][i];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i)
+            if (CH + c < KB2) b1[c][i] = bw[((size_t)i * 4 * KB2 + CH + c) * 64];
+    gemm_bf16_chunk<NTWM, CH, 0>(b0, b1, arow, bw, acc, mid);
+}
+
+// fast-mode twin of dense_relu (K = N = 64 NTWM): OUT = relu(A @ B + bias), ReLU sign words as there
+template <int NTWM, bool MASK, bool TAPE, class Mid>
+__device__ __forceinline__ void dense_relu_bf16(const float* A, int lda, const uint4* Bh, const float* __restrict__ bias,
+                                                float* OUT, int ldo, unsigned* mask, const Tid& t, Mid& mid,
+                                                const Bf16Pre<NTWM>& pre, float* __restrict__ gout = nullptr, int ldg = 0) {
+    f32x4 acc[NTWM];
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){pre.bv[i], pre.bv[i], pre.bv[i], pre.bv[i]};
+    gemm_bf16<NTWM>(A, lda, Bh, t, acc, mid, pre);
+    unsigned m = 0u;
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const int c = t.wave + 4 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float v = acc[i][r];
+            const float o = MASK ? relu_bit(v, m) : (v > 0.f ? v : 0.f);
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
+            if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
+        }
+    }
+    if (MASK) mask[t.tid] = m << (32 - 4 * NTWM);
+}
+
+// fast-mode twin of dense_masked (K = N = 64 NTWM): OUT = (A @ B) * mask
+template <int NTWM, bool TAPE, class Mid>
+__device__ __forceinline__ void dense_masked_bf16(const float* A, int lda, const uint4* Bh, float* OUT, int ldo,
+                                                  const unsigned* mask, const Tid& t, Mid& mid, const Bf16Pre<NTWM>& pre,
+                                                  float* __restrict__ gout = nullptr, int ldg = 0) {
+    f32x4 acc[NTWM];
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    unsigned m = mask[t.tid];
+    gemm_bf16<NTWM>(A, lda, Bh, t, acc, mid, pre);
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const int c = t.wave + 4 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float o = mask_bit(acc[i][r], m);
+            OUT[(4 * t.q + r) * ldo + 16 * c + t.n] = o;
+            if (TAPE) gout[(long)(4 * t.q + r) * ldg + 16 * c + t.n] = o;
+        }
+    }
+}
+
+// the requests a fp32 W x W main loop issues behind its MFMAs (`inj(IC<j>)`, j < N), all at once
+template <int J, int N, class Inject>
+__device__ __forceinline__ void inject_all(Inject& inj) {
+    if constexpr (J < N) {
+        inj(IC<J>());
+        inject_all<J + 1, N>(inj);
+    }
+}
+
 // OUT[16 x 16*NT] = A[16 x K] @ B   (NT <= 4: one column tile per wave), used for the D x D affine maps.
 // `add` (nullable): per-column additive term [16 * NT] (the ActNorm shift folded into the affine map).
 __device__ __forceinline__ void dense_small(const float* A, int lda, int kmax, int KB, const float4* Bp, int NT,
@@ -696,7 +863,7 @@ __device__ __forceinline__ void tape_copy(float* __restrict__ dst, int w, const 
 
 // With TAPE (requires GRAD) the quantities the parameter-gradient GEMMs need are also written to `tape`
 // (TapeDims layout, rows row0 .. row0+15): see fabhip_common.h.
-template <int NTWM, bool GRAD, bool TAPE = false>
+template <int NTWM, bool GRAD, bool TAPE = false, bool FAST = false>
 __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const float* __restrict__ packed,
                                     float* lds, const Tid& t, int* grad_off, const TapeDims* td = nullptr,
                                     float* __restrict__ tape = nullptr, long row0 = 0) {
@@ -751,7 +918,9 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         }
         // ---- conditioner MLP: relu(relu(z1 W1 + b1) W2 + b2) W3' ----------------------------------------
         RingPre<NTWM> rp;                                 // block 0 + bias of the W x W GEMM below: lands during this stage
-        ringpre_load<NTWM, true>(rp, W2, f.KBW, Lp + f.o_b2, t);
+        Bf16Pre<NTWM> bp;                                 // fast mode: chunk 0 + bias of the bf16 W x W GEMM instead
+        if constexpr (FAST) bf16pre_load<NTWM, true>(bp, reinterpret_cast<const uint4*>(Lp + f.o_W2h), Lp + f.o_b2, t);
+        else ringpre_load<NTWM, true>(rp, W2, f.KBW, Lp + f.o_b2, t);
         dense_relu_small<NTWM, 2, GRAD, TAPE>(w1r, Z, l.DS, f.d, HA, l.WS, mk, t,
                                               TAPE ? tl_layer + td->o_H1 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
         if (tl) FAB_TL(f, 3);
@@ -791,10 +960,17 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
                 kp.b1[sidx] = W3[((size_t)4 * N + t.wave + 4 * sidx) * 64 + t.lane];
             }
         };
-        dense_relu<NTWM, DW, false, GRAD, TAPE, NoPost, true, 5 * NTWM + 6, decltype(inj_fwd)>(
-            HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
-            TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, NoPost(), &rp,
-            (tl && blockIdx.x == 0) ? f.timeline : nullptr, inj_fwd);
+        if constexpr (FAST) {
+            auto mid = [&]() { inject_all<0, 5 * NTWM + 6>(inj_fwd); };
+            dense_relu_bf16<NTWM, GRAD, TAPE>(HA, l.WS, reinterpret_cast<const uint4*>(Lp + f.o_W2h), Lp + f.o_b2, HB, l.WS,
+                                              mk + NTHREADS, t, mid, bp,
+                                              TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
+        } else {
+            dense_relu<NTWM, DW, false, GRAD, TAPE, NoPost, true, 5 * NTWM + 6, decltype(inj_fwd)>(
+                HA, l.WS, f.Wp, f.KBW, W2, Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
+                TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0, NoPost(), &rp,
+                (tl && blockIdx.x == 0) ? f.timeline : nullptr, inj_fwd);
+        }
         if (tl) FAB_TL(f, 5);
         // no workgroup barrier: the K-split GEMM reads only this wave's own columns of HB (LDS is in-order per wave)
         __builtin_amdgcn_wave_barrier();
@@ -879,7 +1055,9 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         float* tl_layer = TAPE ? tape + (size_t)layer * td->layer_stride : nullptr;
         if (TAPE) tape_copy(tl_layer + td->o_DP + row0 * td->wp, td->wp, DP, l.PS, t);
         RingPre<NTWM> rpb;                                // block 0 of the W x W GEMM below: lands during this stage
-        ringpre_load<NTWM, false>(rpb, W2T, f.KBW, nullptr, t);
+        Bf16Pre<NTWM> bpb;
+        if constexpr (FAST) bf16pre_load<NTWM, false>(bpb, reinterpret_cast<const uint4*>(Lp + f.o_W2Th), nullptr, t);
+        else ringpre_load<NTWM, false>(rpb, W2T, f.KBW, nullptr, t);
         if (kbo2)
             dense_masked_small<NTWM, 2, TAPE>(w3a, DP, l.PS, HA, l.WS, mk + NTHREADS, t,
                                               TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0);
@@ -909,9 +1087,15 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
                 if (kbd2) awtr.b[S][0] = AWT[((size_t)t.wave * 2 + S) * 64 + t.lane];
             }
         };
-        dense_masked<NTWM, DW, TAPE, NoPost, true, 3 * NTWM + 2, decltype(inj_bwd)>(
-            HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t, TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr,
-            TAPE ? td->we : 0, NoPost(), &rpb, inj_bwd);
+        if constexpr (FAST) {
+            auto mid = [&]() { inject_all<0, 3 * NTWM + 2>(inj_bwd); };
+            dense_masked_bf16<NTWM, TAPE>(HA, l.WS, reinterpret_cast<const uint4*>(Lp + f.o_W2Th), HB, l.WS, mk, t, mid, bpb,
+                                          TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0);
+        } else {
+            dense_masked<NTWM, DW, TAPE, NoPost, true, 3 * NTWM + 2, decltype(inj_bwd)>(
+                HA, l.WS, f.KBW, W2T, HB, l.WS, mk, t, TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr,
+                TAPE ? td->we : 0, NoPost(), &rpb, inj_bwd);
+        }
         if (tl) FAB_TL(f, 21);
         __builtin_amdgcn_wave_barrier();              // as in the forward sweep: own columns only, no barrier
         if (tl) FAB_TL(f, 22);

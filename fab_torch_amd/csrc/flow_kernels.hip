@@ -200,6 +200,34 @@ __global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, MlpTab tab, int 
     }
 }
 
+// fast mode: bf16 images of W2 (B[k][n] = w2[n][k]) and W2^T (B[k][n] = w2[k][n]) in v_mfma_f32_16x16x32_bf16 B-operand
+// tiles (flow_device.h): float slot `off` of an image holds the bf16 pair (j, j + 1), j = 2 (off & 3), of lane
+// (off >> 2) & 63 of tile off >> 8 = c * KB2 + S.  Round to nearest even, like v_cvt_pk_bf16_f32 on the activations.
+__device__ __forceinline__ unsigned bf16_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;        // NaN stays NaN
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256) void k_pack_bf16(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed) {
+    const int y = blockIdx.y, layer = k0 + y, W = f.W, half = f.Wp * f.Wp / 2, KB2 = f.Wp / 32;
+    const float* __restrict__ w2 = tab.w2[y];
+    unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(packed + (size_t)layer * f.layer_stride + f.o_W2h);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 2 * half; e += gridDim.x * blockDim.x) {
+        const bool tr = e >= half;
+        const int off = tr ? e - half : e;
+        const int tile = off >> 8, lane = (off >> 2) & 63, j = 2 * (off & 3);
+        const int c = tile / KB2, S = tile % KB2;
+        const int k = 32 * S + 8 * (lane >> 4) + j, n = 16 * c + (lane & 15);
+        float v0 = 0.f, v1 = 0.f;
+        if (n < W) {
+            if (k < W) v0 = tr ? w2[k * W + n] : w2[n * W + k];
+            if (k + 1 < W) v1 = tr ? w2[(k + 1) * W + n] : w2[n * W + k + 1];
+        }
+        dst[e] = bf16_rne(v0) | (bf16_rne(v1) << 16);
+    }
+}
+
 __global__ void k_pack_base(FlowDims f, const float* __restrict__ loc, const float* __restrict__ log_scale,
                             float* __restrict__ dst) {
     const int j = threadIdx.x;
@@ -212,11 +240,10 @@ __global__ void k_pack_base(FlowDims f, const float* __restrict__ loc, const flo
 // ------------------------------------------------------------------------------------------------
 // tile helpers shared with the transition kernels
 // ------------------------------------------------------------------------------------------------
-template <int NTWM, bool GRAD>
-__global__ __launch_bounds__(NTHREADS) void k_flow_log_prob(FlowDims f, FlowLds l, const float* __restrict__ packed,
-                                                            const float* __restrict__ x, float* __restrict__ log_q,
-                                                            float* __restrict__ grad, long B) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int NTWM, bool GRAD, bool FAST>
+__device__ __forceinline__ void flow_log_prob_body(const FlowDims& f, const FlowLds& l, const float* __restrict__ packed,
+                                                   const float* __restrict__ x, float* __restrict__ log_q,
+                                                   float* __restrict__ grad, long B, float* lds) {
     Tid t;
     const long row0 = (long)blockIdx.x * ROWS;
     for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) lds[l.o_DP + e] = 0.f;
@@ -227,7 +254,7 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob(FlowDims f, FlowLds 
     }
     __syncthreads();
     int goff = 0;
-    const float lq = flow_log_prob_tile<NTWM, GRAD>(f, l, packed, lds, t, &goff);
+    const float lq = flow_log_prob_tile<NTWM, GRAD, false, FAST>(f, l, packed, lds, t, &goff);
     if (t.c == 0 && row0 + t.row < B) log_q[row0 + t.row] = lq;
     if (GRAD) {
         for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
@@ -236,6 +263,22 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob(FlowDims f, FlowLds 
             if (g < B) grad[g * f.D + j] = lds[goff + r * l.DS + j];
         }
     }
+}
+
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_flow_log_prob(FlowDims f, FlowLds l, const float* __restrict__ packed,
+                                                            const float* __restrict__ x, float* __restrict__ log_q,
+                                                            float* __restrict__ grad, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    flow_log_prob_body<NTWM, GRAD, false>(f, l, packed, x, log_q, grad, B, lds);
+}
+// fast mode (bf16 W x W GEMMs): with the gradient only - a plain density evaluation stays fp32
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_fast(FlowDims f, FlowLds l, const float* __restrict__ packed,
+                                                                 const float* __restrict__ x, float* __restrict__ log_q,
+                                                                 float* __restrict__ grad, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    flow_log_prob_body<NTWM, true, true>(f, l, packed, x, log_q, grad, B, lds);
 }
 
 template <int NTWM>
@@ -268,6 +311,11 @@ static int launch_log_prob(const FlowDims& f, const float* packed, const float* 
     if (grad) {
         const FlowLds l = make_flow_lds(f, true);
         const size_t bytes = (size_t)l.total * 4;
+        if (fast_mode()) {
+            FAB_TRY(set_max_lds((const void*)k_flow_log_prob_fast<NTWM>, bytes));
+            hipLaunchKernelGGL((k_flow_log_prob_fast<NTWM>), grid, block, bytes, st, f, l, packed, x, log_q, grad, B);
+            return check_launch();
+        }
         FAB_TRY(set_max_lds((const void*)k_flow_log_prob<NTWM, true>, bytes));
         hipLaunchKernelGGL((k_flow_log_prob<NTWM, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad, B);
     } else {
@@ -297,7 +345,20 @@ using namespace fab;
 // dev-only stage timeline (FABHIP_TIMELINE=1): 64 s_memtime stamps written by workgroup 0 of fabhip_flow_log_prob
 static long long* g_timeline = nullptr;
 
+namespace fab {
+static int g_fast_mode = 0;
+int fast_mode() { return g_fast_mode; }
+}  // namespace fab
+
 extern "C" {
+
+int fabhip_set_fast_mode(int on) {
+    const int prev = fab::g_fast_mode;
+    fab::g_fast_mode = on ? 1 : 0;
+    return prev;
+}
+
+int fabhip_get_fast_mode(void) { return fab::g_fast_mode; }
 
 int fabhip_debug_timeline(int64_t* host_out, int32_t n) {
     if (!g_timeline || !host_out || n < 1 || n > 64) return FABHIP_EINVAL;
@@ -337,6 +398,7 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
         hipLaunchKernelGGL(k_affine_assemble, dim3(nl), dim3(256), smem, st, f, at, k0, packed, with_inverse);
         const int nblk = ceil_div(f.o_logS, 256 * 4);
         hipLaunchKernelGGL(k_pack_layer, dim3(nblk, nl), dim3(256), 0, st, f, mt, k0, packed);
+        hipLaunchKernelGGL(k_pack_bf16, dim3(ceil_div(f.Wp * f.Wp, 256 * 4), nl), dim3(256), 0, st, f, mt, k0, packed);
     }
     hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();

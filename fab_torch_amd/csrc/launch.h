@@ -10,6 +10,9 @@ namespace fab {
         if (_e != FABHIP_OK) return _e;   \
     } while (0)
 
+// process-wide fast-mode switch (fabhip_set_fast_mode, flow_kernels.hip)
+int fast_mode();
+
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
 
 // Allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU).

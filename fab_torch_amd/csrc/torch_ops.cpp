@@ -127,6 +127,8 @@ std::vector<int64_t> flow_grad_layout(int64_t dim, int64_t n_layers, int64_t wid
     chk(fabhip_flow_grad_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, out.data()), "flow_grad_layout");
     return out;
 }
+int64_t set_fast_mode(bool on) { return fabhip_set_fast_mode(on ? 1 : 0); }
+int64_t get_fast_mode() { return fabhip_get_fast_mode(); }
 std::vector<int64_t> flow_tape_layout(int64_t dim, int64_t n_layers, int64_t width, int64_t B) {
     std::vector<int64_t> out(18);
     chk(fabhip_flow_tape_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, B, out.data()), "flow_tape_layout");
@@ -681,6 +683,8 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("flow_grad_floats(int dim, int n_layers, int width) -> int", flow_grad_floats);
     m.def("flow_grad_layout(int dim, int n_layers, int width) -> int[]", flow_grad_layout);
     m.def("flow_tape_layout(int dim, int n_layers, int width, int B) -> int[]", flow_tape_layout);
+    m.def("set_fast_mode(bool on) -> int", set_fast_mode);
+    m.def("get_fast_mode() -> int", get_fast_mode);
     m.def("anneal_coefs(float beta, float alpha, bool p_target) -> float[]", anneal_coefs);
 
     m.def("realnvp_pack(Tensor[] params, int dim, int n_layers, int width, bool with_inverse, Tensor(a!) packed) -> ()");

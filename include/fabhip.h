@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 202
+#define FABHIP_ABI_VERSION 203
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -70,6 +70,16 @@ typedef struct {
     const float* an_s[FABHIP_MAX_LAYERS];   /* [dim] ActNorm.s                                */
     const float* an_t[FABHIP_MAX_LAYERS];   /* [dim] ActNorm.t                                */
 } fabhip_flow_params;
+
+/* FAST MODE (off by default; NOT the parity path).  When on, the transition kernels (fabhip_hmc_transition,
+ * fabhip_ais_run with HMC, fabhip_create_point and fabhip_flow_log_prob when they return gradients) run the two width x width GEMMs of every coupling
+ * layer - 87 % of the flow's flops - on the bf16 matrix cores (v_mfma_f32_16x16x32_bf16, fp32 accumulation, weights
+ * from a bf16 image every fabhip_flow_pack also writes, activations rounded to bf16 as they are fetched).  log q then
+ * differs from the fp32 path at the 1e-3 .. 1e-2 level (the sampler stays a valid HMC-AIS sampler for that slightly
+ * different density; fabhip_flow_sample, gradient-free density evaluations, the training path and Metropolis stay fp32).
+ * Process-wide switch, returns the previous value.  SURVEY section 7's "fp32 parity mode and a fast mode". */
+int fabhip_set_fast_mode(int on);
+int fabhip_get_fast_mode(void);
 
 /* Number of floats of the MFMA-tiled parameter image for a (dim, n_layers, width) flow. */
 int64_t fabhip_flow_packed_floats(int32_t dim, int32_t n_layers, int32_t width);

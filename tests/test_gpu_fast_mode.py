@@ -1,0 +1,114 @@
+"""Fast mode (fabhip_set_fast_mode / fab_torch_amd.fast_mode): the W x W GEMMs of the RealNVP conditioners on the bf16
+matrix cores inside the transition kernels.  NOT the parity path - these tests pin what it IS: the flow with bf16-rounded
+W2 weights and bf16-rounded inputs of that Linear (fp32 accumulation), deterministic, off by default, leaving the fp32
+path bit-for-bit alone, and a sampler whose ESS on the trained-flow fixture stays within 1 % of the fp32 path's."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_golden, close, RTOL
+
+pytestmark = pytest.mark.gpu
+
+fa = pytest.importorskip("fab_torch_amd")
+from oracle import flow as oflow          # noqa: E402
+
+DEV = "cuda"
+
+
+class _Bf16Linear(torch.nn.Module):
+    def __init__(self, lin):
+        super().__init__()
+        self.w = lin.weight.detach().float().bfloat16().double()
+        self.b = lin.bias.detach().double()
+
+    def forward(self, x):
+        return x.float().bfloat16().double() @ self.w.t() + self.b
+
+
+def emulation(nf):
+    nf64 = copy.deepcopy(nf).double()
+    for f in nf64.flows:
+        if isinstance(f, oflow.AffineCouplingBlock):
+            net = f.flows[1].param_map.net
+            net[2] = _Bf16Linear(net[2])
+    return nf64
+
+
+@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 128), (6, 8, 40, 64), (2, 4, 40, 100), (32, 2, 16, 40), (64, 2, 8, 24),
+                                         (6, 3, 5, 50)])
+def test_fast_mode_is_the_flow_with_bf16_rounded_inner_gemm_operands(D, K, nodes, B):
+    torch.manual_seed(D + K)
+    nf = oflow.make_realnvp(D, K, nodes)
+    oflow.randomize_last_layers(nf, 0.02, 5)
+    hf = fa.RealNVP(D, K, nodes)
+    hf._nf_model.load_state_dict(nf.state_dict())
+    hf = hf.to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    x, _ = hf.sample_and_log_prob((B,))
+    assert int(fa._ops.load().get_fast_mode()) == 0                      # off by default
+    p32 = fa.create_point(x, hf, target, with_grad=True)
+    with fa.fast_mode():
+        assert int(fa._ops.load().get_fast_mode()) == 1
+        pf = fa.create_point(x, hf, target, with_grad=True)
+        pf2 = fa.create_point(x, hf, target, with_grad=True)
+        lq_f, g_f = hf.log_prob_and_grad(x)                                # the gradient-returning density op follows the mode
+        lq_plain = hf.log_prob(x)                                          # a plain density evaluation stays fp32
+    assert int(fa._ops.load().get_fast_mode()) == 0
+    p32b = fa.create_point(x, hf, target, with_grad=True)
+    assert torch.equal(p32.log_q, p32b.log_q) and torch.equal(p32.grad_log_q, p32b.grad_log_q)   # fp32 path untouched
+    assert torch.equal(pf.log_q, pf2.log_q) and torch.equal(pf.grad_log_q, pf2.grad_log_q)       # deterministic
+    assert torch.equal(lq_f, pf.log_q) and torch.equal(g_f, pf.grad_log_q)
+    assert close(lq_plain, p32.log_q, RTOL)
+    assert torch.equal(pf.log_p, p32.log_p) and torch.equal(pf.grad_log_p, p32.grad_log_p)       # the target is not touched
+    em = emulation(nf)
+    xg = x.cpu().double().requires_grad_(True)
+    lq_e = em.log_prob(xg)
+    (g_e,) = torch.autograd.grad(lq_e.sum(), xg)
+    lq_e = lq_e.detach()
+    dev_em = float((pf.log_q.cpu().double() - lq_e).abs().max())
+    dev_32 = float((pf.log_q.cpu().double() - p32.log_q.cpu().double()).abs().max())
+    # the kernels against the emulation: fp32 accumulation order + activations within rounding of a bf16 tie; against
+    # the fp32 path: the bf16 approximation itself (a few 1e-3 of |log q| ~ 10 .. 50)
+    assert dev_em <= 2e-3, f"fast mode vs its emulation: {dev_em:.2e}"
+    assert 0 < dev_32 <= 5e-2, f"fast mode vs fp32: {dev_32:.2e}"
+    rel = (pf.grad_log_q.cpu().double() - g_e).norm(dim=1) / g_e.norm(dim=1)
+    assert float(rel.median()) <= 2e-3 and float(rel.max()) <= 5e-2, f"grad vs emulation: {float(rel.max()):.2e}"
+
+
+def test_fast_mode_ais_on_the_trained_flow_keeps_the_ess_within_one_percent():
+    """g13: the committed trained ManyWell-6 flow and the reference's evaluation AIS call on it (captured noise).  The
+    fp32 path reproduces the reference ESS to 1e-6 (test_gpu_workloads); the fast mode must stay within 1 % of it."""
+    g = load_golden("g13_trained_flow_mw6.npz")
+    D, K, nodes, M, L, B = int(g["D"]), int(g["K"]), int(g["nodes"]), int(g["M"]), int(g["L"]), int(g["B"])
+    flow = fa.RealNVP(D, K, nodes)
+    flow._nf_model.load_state_dict({k[len("flow."):]: torch.tensor(v) for k, v in g.items() if k.startswith("flow.")})
+    flow = flow.to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    for tag, p_target in (("p", True), ("g", False)):
+        res = {}
+        for fast in (False, True):
+            hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=float(g["alpha"]), p_target=p_target,
+                                           epsilon=1.0, L=L, eval_mode=True).to(DEV)
+            with torch.no_grad():
+                hmc.epsilons.copy_(torch.tensor(g["epsilons"])); hmc.common_epsilon.copy_(torch.tensor(g["common_epsilon"]))
+            ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target, float(g["alpha"]), M)
+            T = lambda k: torch.tensor(g[k]).to(DEV)      # noqa: E731
+            with fa.fast_mode(fast):
+                pt, lw = ais.sample_and_log_weights(B, eps0=T(f"{tag}_eps0"), noise_a=T(f"{tag}_noise_p"),
+                                                    noise_b=T(f"{tag}_noise_e"))
+            res[fast] = (ais.get_logging_info(), pt.x.clone(), lw.clone())
+        ref = float(g[f"{tag}_ess_ais"])
+        assert abs(res[False][0]["ess_ais"] - ref) / ref < 1e-3
+        assert not torch.equal(res[True][2], res[False][2]) and torch.isfinite(res[True][2]).all()
+        if p_target:
+            rel = abs(res[True][0]["ess_ais"] - ref) / ref
+            assert rel < 1e-2, f"target p: fast-mode ESS {res[True][0]['ess_ais']:.5f} vs reference {ref:.5f}"
+            assert abs(res[True][0]["log_Z"] - res[False][0]["log_Z"]) < 2e-2
+        else:
+            # target p^2/q: the reference's own ESS is 0.02 (a handful of chains carry the weight) and HMC at the tuned step
+            # size is chaotic - half of the chains leave the fp32 trajectory after 8 x 5 leapfrogs under a 1e-3
+            # perturbation of log q - so this ESS is a different draw of a heavy-tailed statistic, not a parity quantity
+            assert 0 < res[True][0]["ess_ais"] <= 1 and abs(res[True][0]["log_Z"] - res[False][0]["log_Z"]) < 1.0

@@ -10,6 +10,8 @@ nodes = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 torch.manual_seed(0)
 flow = fa.RealNVP(32, 10, nodes).to(dev).requires_grad_(False)
 x = torch.randn(1024, 32, device=dev)
+if os.environ.get("FAST") == "1":
+    fa.fast_mode(True)
 for _ in range(5):
     flow.native_log_prob(x, with_grad=True)
 torch.cuda.synchronize()
