@@ -18,6 +18,7 @@
 // One wave handles one chain in the element-wise kernels (lane = coordinate, D <= 64).
 #include "flow_device.h"
 #include "launch.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -199,8 +200,11 @@ __global__ void k_spline_pack_base(SplineDims f, const float* __restrict__ scale
 struct NetLds {
     int AS, WS, PS;                       // leading dims: identity inputs (64 + 4), hidden (Wp + 4), dparams (NFP + 4)
     int o_A0, o_H0, o_T, o_X1, o_X2, o_DP, o_PART, total;
+    int o_ZT, o_GT;                       // persistent kernel: state tile and cotangent tile [16][64]
 };
-FAB_HD NetLds make_net_lds(const SplineDims& f, bool bwd) {
+// persist: the one-launch density kernel (k_spline_logprob): + state / cotangent tiles; its conditioner output P lives
+// in the DP region (the reverse sweep turns it into dP in place)
+FAB_HD NetLds make_net_lds(const SplineDims& f, bool bwd, bool persist = false) {
     NetLds l;
     l.AS = 64 + 4; l.WS = f.Wp + 4; l.PS = f.NFP + 4;
     int o = 0;
@@ -209,8 +213,10 @@ FAB_HD NetLds make_net_lds(const SplineDims& f, bool bwd) {
     l.o_T = o; o += ROWS * l.WS;
     l.o_X1 = o; o += ROWS * l.WS;
     l.o_X2 = o; o += ROWS * l.WS;
-    l.o_DP = o; if (bwd) o += ROWS * l.PS;
+    l.o_DP = o; if (bwd || persist) o += ROWS * l.PS;
     l.o_PART = o; if (bwd) o += NWAVE * ROWS * l.AS;
+    l.o_ZT = o; if (persist) o += ROWS * 64;
+    l.o_GT = o; if (persist) o += ROWS * 64;
     l.total = (o + 3) & ~3;
     return l;
 }
@@ -433,10 +439,27 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
 // rational-quadratic spline (Durkan et al. 2019, eqs. 4-8; nflows / normflows rational_quadratic_spline)
 // ------------------------------------------------------------------------------------------------
 struct Rqs {
-    float cw[SP_K + 1], ch[SP_K + 1], dv[SP_K + 1];     // knot positions / values / derivatives
+    float cw[SP_K + 1], ch[SP_K + 1];                    // knot positions / values
+    float ud[SP_K + 1];                                  // effective unnormalised knot derivatives (end knots fixed / tied)
     float pw[SP_K], ph[SP_K];                            // softmax probabilities (backward)
-    float sg[SP_K + 1];                                  // sigmoid(ud) of the free knots (backward), 0 for fixed ones
+    bool circ;
 };
+// derivative min + softplus(u) of knot j and (backward) its d/du = sigmoid(u), 0 for a fixed end knot - evaluated only
+// for the two knots of the bin that holds x (9 softplus + 9 sigmoid per coordinate otherwise)
+__device__ __forceinline__ float sp_softplus(float x);
+__device__ __forceinline__ void rqs_knot_pair(const Rqs& s, int b, float& d0, float& d1, float* sg0, float* sg1) {
+    float u0 = s.ud[0], u1 = s.ud[1];
+#pragma unroll
+    for (int j = 1; j < SP_K; ++j)
+        if (j == b) { u0 = s.ud[j]; u1 = s.ud[j + 1]; }
+    d0 = SP_MIN_D + sp_softplus(u0);
+    d1 = SP_MIN_D + sp_softplus(u1);
+    if (sg0) {
+        const bool f0 = !s.circ && b == 0, f1 = !s.circ && b == SP_K - 1;
+        *sg0 = f0 ? 0.f : 1.f / (1.f + expf(-u0));
+        *sg1 = f1 ? 0.f : 1.f / (1.f + expf(-u1));
+    }
+}
 
 __device__ __forceinline__ float sp_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 
@@ -460,14 +483,13 @@ __device__ __forceinline__ void rqs_setup(const float* p, bool circ, float tb, R
     }
     s.cw[SP_K] = tb; s.ch[SP_K] = tb;
     const float cst = logf(expf(1.f - SP_MIN_D) - 1.f);
+    s.circ = circ;
 #pragma unroll
     for (int j = 0; j <= SP_K; ++j) {
         float u = p[2 * SP_K + j];
-        bool fixed = false;
-        if (!circ && (j == 0 || j == SP_K)) { u = cst; fixed = true; }
+        if (!circ && (j == 0 || j == SP_K)) u = cst;
         if (circ && j == SP_K) u = p[2 * SP_K];
-        s.dv[j] = SP_MIN_D + sp_softplus(u);
-        s.sg[j] = fixed ? 0.f : 1.f / (1.f + expf(-u));
+        s.ud[j] = u;
     }
 }
 
@@ -482,10 +504,11 @@ __device__ __forceinline__ int rqs_bin(const float* knots, float x) {
 __device__ __forceinline__ void rqs_forward(const Rqs& s, float x, float tb, float& y, float& ld) {
     if (!(x >= -tb && x <= tb)) { y = x; ld = 0.f; return; }
     const int b = rqs_bin(s.cw, x);
-    float xk = 0.f, w = 1.f, yk = 0.f, h = 1.f, d0 = 1.f, d1 = 1.f;
+    float xk = 0.f, w = 1.f, yk = 0.f, h = 1.f, d0, d1;
 #pragma unroll
     for (int j = 0; j < SP_K; ++j)
-        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; d0 = s.dv[j]; d1 = s.dv[j + 1]; }
+        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; }
+    rqs_knot_pair(s, b, d0, d1, nullptr, nullptr);
     const float th = (x - xk) / w, t1 = th * (1.f - th), dl = h / w;
     const float num = h * (dl * (th * th) + d0 * t1);
     const float den = dl + (d0 + d1 - 2.f * dl) * t1;
@@ -498,10 +521,11 @@ __device__ __forceinline__ void rqs_forward(const Rqs& s, float x, float tb, flo
 __device__ __forceinline__ void rqs_inverse(const Rqs& s, float y, float tb, float& x, float& ld) {
     if (!(y >= -tb && y <= tb)) { x = y; ld = 0.f; return; }
     const int b = rqs_bin(s.ch, y);
-    float xk = 0.f, w = 1.f, yk = 0.f, h = 1.f, d0 = 1.f, d1 = 1.f;
+    float xk = 0.f, w = 1.f, yk = 0.f, h = 1.f, d0, d1;
 #pragma unroll
     for (int j = 0; j < SP_K; ++j)
-        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; d0 = s.dv[j]; d1 = s.dv[j + 1]; }
+        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; }
+    rqs_knot_pair(s, b, d0, d1, nullptr, nullptr);
     const float dl = h / w, dy = y - yk, A = d0 + d1 - 2.f * dl;
     const float a = dy * A + h * (dl - d0);
     const float bq = h * d0 - dy * A;
@@ -525,10 +549,11 @@ __device__ __forceinline__ float rqs_backward(const Rqs& s, const float* p, bool
     }
     if (!(x >= -tb && x <= tb)) return gy;
     const int b = rqs_bin(s.cw, x);
-    float xk = 0.f, w = 1.f, h = 1.f, d0 = 1.f, d1 = 1.f;
+    float xk = 0.f, w = 1.f, h = 1.f, d0, d1, sg0 = 0.f, sg1 = 0.f;
 #pragma unroll
     for (int j = 0; j < SP_K; ++j)
-        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; h = s.ch[j + 1] - s.ch[j]; d0 = s.dv[j]; d1 = s.dv[j + 1]; }
+        if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; h = s.ch[j + 1] - s.ch[j]; }
+    rqs_knot_pair(s, b, d0, d1, dp ? &sg0 : nullptr, dp ? &sg1 : nullptr);
     const float th = (x - xk) / w, t1 = th * (1.f - th), dl = h / w, A = d0 + d1 - 2.f * dl;
     const float num = h * (dl * (th * th) + d0 * t1);
     const float den = dl + A * t1;
@@ -568,10 +593,10 @@ __device__ __forceinline__ float rqs_backward(const Rqs& s, const float* p, bool
 #pragma unroll
         for (int j = 0; j <= SP_K; ++j) {
             float g = 0.f;
-            if (j == b) g += d0b;
-            if (j == b + 1) g += d1b;
-            if (circ && j == SP_K) { dp[2 * SP_K] += g * s.sg[0]; g = 0.f; }   // last knot tied to the first
-            dp[2 * SP_K + j] += g * s.sg[j];
+            if (j == b) g += d0b * sg0;
+            if (j == b + 1) g += d1b * sg1;
+            if (circ && j == SP_K) { dp[2 * SP_K] += g; g = 0.f; }            // last knot tied to the first (same u)
+            dp[2 * SP_K + j] += g;
         }
     }
     return xb;
@@ -748,6 +773,257 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
     Gin[g * f.D + lane] = gx;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// ONE launch for log q (+ d log q / dx): a workgroup carries its 16 chains through all layers - conditioner on the
+// matrix cores, its 3K+1 parameters per coordinate kept in LDS, the splines evaluated by the same workgroup (thread =
+// (chain, coordinate mod 16)), the state tile never leaving LDS - then, with GRAD, back again (layer inputs, conditioner
+// outputs and ReLU decisions of the forward sweep are parked in the workspace, per tile: L2-resident).  Replaces 4 L + 2
+// launches of the per-stage kernels above (kept for the training tape and the sampling direction).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void sp_identity_from_tile(const SplineDims& f, const float* __restrict__ Lp, const float* ZT,
+                                                      float* A0, int AS, const Tid& t) {
+    const float* meta = Lp + f.o_meta;
+    const int n_id = (int)meta[M_CNT * 64];
+    for (int e = t.tid; e < ROWS * AS; e += NTHREADS) {
+        const int r = e / AS, i = e % AS;
+        float v = 0.f;
+        if (i < n_id) {
+            v = ZT[r * 64 + (int)meta[M_IDF * 64 + i]];
+            if (meta[M_PFON * 64 + i] != 0.f) {
+                const int k = (int)meta[M_PFK * 64 + i];
+                const float sc = meta[M_PFS * 64 + i];
+                v = Lp[f.o_pfw + 2 * k] * sinf(sc * v) + Lp[f.o_pfw + 2 * k + 1] * cosf(sc * v);
+            }
+        }
+        A0[e] = v;
+    }
+}
+
+// parameters of coordinate j of chain row r in this layer: returns 0 (untouched), 1 (identity: unconditional), 2 (transformed)
+__device__ __forceinline__ int sp_coord_params(const SplineDims& f, const float* __restrict__ Lp, const float* meta,
+                                               const float* PT, int PS, int r, int j, float isq, float (&p)[SP_NP],
+                                               int& pos) {
+    const int pos_id = (int)meta[M_POSID * 64 + j], pos_tr = (int)meta[M_POSTR * 64 + j];
+    if (pos_id >= 0) {
+#pragma unroll
+        for (int k = 0; k < SP_NP; ++k) p[k] = Lp[f.o_unc + pos_id * SP_NP + k];
+        pos = pos_id;
+        return 1;
+    }
+    if (pos_tr >= 0) {
+#pragma unroll
+        for (int k = 0; k < SP_NP; ++k) {
+            const float v = PT[r * PS + pos_tr * SP_NP + k];
+            p[k] = k < 2 * SP_K ? v * isq : v;
+        }
+        pos = pos_tr;
+        return 2;
+    }
+    pos = -1;
+    return 0;
+}
+
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLds l, const float* __restrict__ packed,
+                                                             const float* __restrict__ x, float* __restrict__ log_q,
+                                                             float* __restrict__ grad_x, long B,
+                                                             float* __restrict__ Zsave, float* __restrict__ Psave,
+                                                             float* __restrict__ actsave) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid t;
+    constexpr int DW = depth_w<NTWM>();
+    const long row0 = (long)blockIdx.x * ROWS;
+    float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
+    float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* PT = lds + l.o_DP; float* PART = lds + l.o_PART;
+    float* ZT = lds + l.o_ZT; float* GT = lds + l.o_GT;
+    const float isq = 1.f / sqrtf((float)f.W);
+    const int per = 4 * NTWM * f.KBW * 256;
+    const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP, as = (size_t)B * 2 * f.Wp;
+    // x <- wrap(x - pre-shift of the top layer)   (PeriodicWrap.inverse / the last PeriodicShift.inverse)
+    {
+        const float* mt = packed + (size_t)(f.L - 1) * f.layer_stride + f.o_meta;
+        for (int e = t.tid; e < ROWS * 64; e += NTHREADS) {
+            const int r = e >> 6, j = e & 63;
+            const long g = row0 + r;
+            float v = 0.f;
+            if (j < f.D && g < B) {
+                v = x[g * f.D + j];
+                if (mt[M_PREON * 64 + j] != 0.f) v = sp_wrap(v - mt[M_PRESH * 64 + j], mt[M_TB * 64 + j]);
+            }
+            ZT[e] = v;
+        }
+    }
+    __syncthreads();
+    float ld_acc = 0.f;
+    for (int layer = f.L - 1; layer >= 0; --layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        const float* meta = Lp + f.o_meta;
+        if (GRAD) {                                        // this layer's input state, for the reverse sweep
+            for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
+                const int r = e / f.D, j = e % f.D;
+                if (row0 + r < B) Zsave[(size_t)layer * zs + (row0 + r) * f.D + j] = ZT[r * 64 + j];
+            }
+        }
+        sp_identity_from_tile(f, Lp, ZT, A0, l.AS, t);
+        __syncthreads();
+        sp_net_hidden<NTWM>(f, l, Lp, lds, t, GRAD ? actsave + (size_t)layer * as : nullptr, row0, B);
+        for (int c = 0; c < f.NCH; ++c) {
+            f32x4 acc[NTWM];
+            sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wf + (size_t)c * per),
+                                    Lp + f.o_bf + c * f.Wp, t, acc);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = c * f.Wp + 16 * (t.wave + 4 * i) + t.n;
+                    PT[(4 * t.q + r) * l.PS + col] = acc[i][r];
+                    if (GRAD && row0 + 4 * t.q + r < B) Psave[(size_t)layer * ps + (row0 + 4 * t.q + r) * f.NFP + col] = acc[i][r];
+                }
+        }
+        __syncthreads();
+        const float* mn = layer > 0 ? packed + (size_t)(layer - 1) * f.layer_stride + f.o_meta : nullptr;
+        for (int j = t.c; j < f.D; j += 16) {
+            float p[SP_NP];
+            int pos;
+            const int kind = sp_coord_params(f, Lp, meta, PT, l.PS, t.row, j, isq, p, pos);
+            const float tb = meta[M_TB * 64 + j];
+            float out = ZT[t.row * 64 + j];
+            if (kind) {
+                Rqs sp;
+                rqs_setup(p, meta[M_CIRC * 64 + j] != 0.f, tb, sp);
+                float l1;
+                rqs_forward(sp, out, tb, out, l1);
+                ld_acc += l1;
+            }
+            if (mn && mn[M_PREON * 64 + j] != 0.f) out = sp_wrap(out - mn[M_PRESH * 64 + j], tb);   // next stage's shift
+            ZT[t.row * 64 + j] = out;
+        }
+        __syncthreads();
+    }
+    // base UniformGaussian
+    for (int j = t.c; j < f.D; j += 16) {
+        const float sc = packed[f.o_base + j];
+        const float z = ZT[t.row * 64 + j];
+        if (packed[f.o_base + 64 + j] != 0.f) { ld_acc += -logf(sc); if (GRAD) GT[t.row * 64 + j] = 0.f; }
+        else {
+            ld_acc += -0.5f * 1.8378770664093453f - logf(sc) - 0.5f * ((z / sc) * (z / sc));
+            if (GRAD) GT[t.row * 64 + j] = -(z / sc) / sc;
+        }
+    }
+    const float lq = row16_sum(ld_acc);
+    if (t.c == 0 && row0 + t.row < B) log_q[row0 + t.row] = lq;
+    if (!GRAD) return;
+    __syncthreads();
+    // ---- reverse sweep: GT = d log q / d(state), layers 0 .. L-1 ---------------------------------------------------
+    for (int layer = 0; layer < f.L; ++layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        const float* meta = Lp + f.o_meta;
+        const int n_id = (int)meta[M_CNT * 64], n_tr = (int)meta[M_CNT * 64 + 1];
+        for (int e = t.tid; e < ROWS * 64; e += NTHREADS) {           // layer input state
+            const int r = e >> 6, j = e & 63;
+            ZT[e] = (j < f.D && row0 + r < B) ? Zsave[(size_t)layer * zs + (row0 + r) * f.D + j] : 0.f;
+        }
+        for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) {         // conditioner output (-> dP in place below)
+            const int r = e / l.PS, c = e % l.PS;
+            PT[e] = (c < f.NFP && row0 + r < B) ? Psave[(size_t)layer * ps + (row0 + r) * f.NFP + c] : 0.f;
+        }
+        for (int e = t.tid; e < ROWS * f.Wp; e += NTHREADS) {         // ReLU decisions of the forward sweep
+            const int r = e / f.Wp, c = e % f.Wp;
+            const long g = row0 + r;
+            H0[r * l.WS + c] = g < B ? actsave[(size_t)layer * as + g * (2 * f.Wp) + c] : 0.f;
+            T[r * l.WS + c] = g < B ? actsave[(size_t)layer * as + g * (2 * f.Wp) + f.Wp + c] : 0.f;
+        }
+        __syncthreads();
+        for (int j = t.c; j < f.D; j += 16) {
+            float p[SP_NP];
+            int pos;
+            const int kind = sp_coord_params(f, Lp, meta, PT, l.PS, t.row, j, isq, p, pos);
+            if (kind) {
+                const float tb = meta[M_TB * 64 + j];
+                const bool circ = meta[M_CIRC * 64 + j] != 0.f;
+                Rqs sp;
+                rqs_setup(p, circ, tb, sp);
+                const float z = ZT[t.row * 64 + j], gy = GT[t.row * 64 + j];
+                if (kind == 2) {
+                    float dp[SP_NP];
+                    GT[t.row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, isq, dp);
+#pragma unroll
+                    for (int k = 0; k < SP_NP; ++k) PT[t.row * l.PS + pos * SP_NP + k] = dp[k];
+                } else {
+                    GT[t.row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, 1.f, nullptr);
+                }
+            }
+        }
+        for (int c = n_tr * SP_NP + t.c; c < l.PS; c += 16) PT[t.row * l.PS + c] = 0.f;    // padding columns of dP
+        __syncthreads();
+        f32x4 acc[NTWM];
+        sp_gemm<NTWM, DW, false>(PT, l.PS, f.NFP / 16, reinterpret_cast<const float4*>(Lp + f.o_WfT), nullptr, t, acc);
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) X1[(4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n] = acc[i][r];
+        __syncthreads();
+        sp_gemm<NTWM, DW, false>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WbT), nullptr, t, acc);
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
+                X2[o] = T[o] > 0.f ? acc[i][r] : 0.f;
+            }
+        __syncthreads();
+        sp_gemm<NTWM, DW, false>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WaT), nullptr, t, acc);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
+                T[o] = X1[o] + (H0[o] > 0.f ? acc[i][r] : 0.f);
+            }
+        __syncthreads();
+        gemm_ksplit<NTWM>(T, l.WS, reinterpret_cast<const float4*>(Lp + f.o_W0T), 4, PART, l.AS, t);
+        __syncthreads();
+        for (int e = t.tid; e < ROWS * 64; e += NTHREADS) {
+            const int r = e >> 6, i = e & 63;
+            if (i < n_id) {
+                float d = part_sum(PART, l.AS, r, i);
+                const int feat = (int)meta[M_IDF * 64 + i];
+                if (meta[M_PFON * 64 + i] != 0.f) {
+                    const int k = (int)meta[M_PFK * 64 + i];
+                    const float sc = meta[M_PFS * 64 + i], zz = ZT[r * 64 + feat];
+                    d = d * (sc * (Lp[f.o_pfw + 2 * k] * cosf(sc * zz) - Lp[f.o_pfw + 2 * k + 1] * sinf(sc * zz)));
+                }
+                GT[r * 64 + feat] += d;
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
+        const int r = e / f.D, j = e % f.D;
+        if (row0 + r < B) grad_x[(row0 + r) * f.D + j] = GT[r * 64 + j];
+    }
+}
+
+template <int NTWM>
+static int launch_logprob(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
+                          float* Zsave, float* Psave, float* actsave, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
+    const NetLds l = make_net_lds(f, grad_x != nullptr, true);
+    const size_t bytes = (size_t)l.total * 4;
+    if (grad_x) {
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, true>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob<NTWM, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+                           Psave, actsave);
+    } else {
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, false>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob<NTWM, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+                           Psave, actsave);
+    }
+    return check_launch();
+}
+
 template <int NTWM>
 static int launch_net(const SplineDims& f, const float* packed, int layer, const float* Z, float* P, const float* dP,
                       float* G, long B, hipStream_t st, const SplineTape& tp, float* act) {
@@ -836,6 +1112,12 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     const size_t as = (size_t)B * 2 * f.Wp;
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
+    if (!tape && !getenv("FABHIP_SPLINE_STAGED")) {           // one launch (the staged kernels below: tape, debugging)
+        if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, act, (hipStream_t)stream);
+        if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, act, (hipStream_t)stream);
+        if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, act, (hipStream_t)stream);
+        return FABHIP_ENOTSUP;
+    }
     const SplineTape tp = make_spline_tape(f, (long)B, tape);
     const dim3 wgrid((unsigned)((B + 3) / 4)), wblock(256);
     hipLaunchKernelGGL(k_spline_first_stage, dim3((unsigned)((B * f.D + 255) / 256 > 4096 ? 4096 : (B * f.D + 255) / 256)),

@@ -197,7 +197,9 @@ def test_spline_flow_parameter_gradients_vs_oracle(D, L, hidden, circ, B):
     lq = hf.log_prob(xd)
     (c.to(DEV) * lq).sum().backward()
     lq0, gx0 = hf.log_prob_and_grad(x.to(DEV))
-    assert torch.equal(lq.detach(), lq0) and close(xd.grad, c.to(DEV)[:, None] * gx0, 1e-6)
+    # (the training forward runs the staged kernels with the tape, log_prob_and_grad the one-launch kernel: same
+    # arithmetic per coordinate, different order of the log-det row sums)
+    assert close(lq.detach(), lq0, 1e-6) and close(xd.grad, c.to(DEV)[:, None] * gx0, 1e-5)
     ref32, ref64 = dict(of.named_parameters()), dict(of64.named_parameters())
     names = [n for n, _ in hf._nf_model.named_parameters()]
     assert set(names) == set(ref32) and len(names) == len(hf._train_params())
