@@ -37,6 +37,8 @@ def main():
         d["hbm_bytes_per_launch"] = d["hbm_read_bytes_per_launch"] + d["hbm_write_bytes_per_launch"]
     if g("SQ_INSTS_VALU_MFMA_MOPS_F32") is not None:
         d["mfma_flops_per_launch"] = g("SQ_INSTS_VALU_MFMA_MOPS_F32") * 512   # 1 MOP = 512 flops
+    if g("SQ_INSTS_VALU_MFMA_MOPS_BF16") is not None:
+        d["mfma_bf16_flops_per_launch"] = g("SQ_INSTS_VALU_MFMA_MOPS_BF16") * 512
     if g("TCC_HIT_sum") is not None and g("TCC_MISS_sum") is not None:
         d["l2_hit_rate"] = g("TCC_HIT_sum") / (g("TCC_HIT_sum") + g("TCC_MISS_sum"))
     if g("SQ_WAIT_ANY") is not None and g("SQ_WAVE_CYCLES"):

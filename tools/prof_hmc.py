@@ -17,6 +17,8 @@ flow = bench.build_flow_state(0).to(dev).requires_grad_(False)
 target = fa.ManyWellEnergy(bench.D)
 hmc = fa.HamiltonianMonteCarlo(bench.M, bench.D, flow.log_prob, target.log_prob, alpha=bench.ALPHA, p_target=False,
                                epsilon=bench.EPS_INIT, n_outer=1, L=bench.L, eval_mode=True).to(dev)
+if os.environ.get("FAST") == "1":                       # profile k_hmc_step_fast (bf16 W x W GEMMs) instead
+    fa.fast_mode(True)
 x0, _ = flow.native_sample(torch.randn(B, bench.D, device=dev))
 pt = create_point(x0, flow, target, with_grad=True)
 for _ in range(n):
