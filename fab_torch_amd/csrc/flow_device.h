@@ -695,9 +695,10 @@ __device__ __forceinline__ f32x4 mfma_bf16(const float4& a0, const float4& a1, c
 // the vector-memory counter is 6 bits - with more than 63 loads outstanding waits release early, measured).  `mid`
 // runs once chunk 0 has been multiplied: the requests of the stages after this GEMM go out there (they stay in flight
 // behind chunk 1), not in front of it.  Never more than 63 loads in flight.
+// KB2T: k-blocks per column-tile strip of the packed matrix (its K / 32); a call multiplies 2 NTWM of them (K = 64 NTWM).
 template <int NTWM, int CH, int C, class Mid>
 __device__ __forceinline__ void gemm_bf16_chunk(uint4 (&b0)[CH][NTWM], uint4 (&b1)[CH][NTWM], const float* __restrict__ arow,
-                                                const uint4* __restrict__ bw, f32x4 (&acc)[NTWM], Mid& mid) {
+                                                const uint4* __restrict__ bw, f32x4 (&acc)[NTWM], Mid& mid, int KB2T) {
     constexpr int KB2 = 2 * NTWM, NCH = (KB2 + CH - 1) / CH;
     if constexpr (C < NCH) {
         uint4 (&b)[CH][NTWM] = (C & 1) ? b1 : b0;
@@ -726,9 +727,9 @@ __device__ __forceinline__ void gemm_bf16_chunk(uint4 (&b0)[CH][NTWM], uint4 (&b
             for (int c = 0; c < CH; ++c)
 #pragma unroll
                 for (int i = 0; i < NTWM; ++i)
-                    if ((C + 2) * CH + c < KB2) b[c][i] = bw[((size_t)i * 4 * KB2 + (C + 2) * CH + c) * 64];
+                    if ((C + 2) * CH + c < KB2) b[c][i] = bw[((size_t)i * 4 * KB2T + (C + 2) * CH + c) * 64];
         }
-        gemm_bf16_chunk<NTWM, CH, C + 1>(b0, b1, arow, bw, acc, mid);
+        gemm_bf16_chunk<NTWM, CH, C + 1>(b0, b1, arow, bw, acc, mid, KB2T);
     }
 }
 
@@ -773,7 +774,33 @@ __device__ __forceinline__ void gemm_bf16(const float* __restrict__ A, int lda, 
 #pragma unroll
         for (int i = 0; i < NTWM; ++i)
             if (CH + c < KB2) b1[c][i] = bw[((size_t)i * 4 * KB2 + CH + c) * 64];
-    gemm_bf16_chunk<NTWM, CH, 0>(b0, b1, arow, bw, acc, mid);
+    gemm_bf16_chunk<NTWM, CH, 0>(b0, b1, arow, bw, acc, mid, KB2);
+}
+
+// the same without an early chunk 0, for a K = 64 NTWM slice (k-blocks S0 .. S0 + 2 NTWM - 1) of a matrix with KB2T
+// k-blocks per strip (the spline conditioner's K = NFP reverse GEMM is NCH such slices): acc += A[:, slice] @ B[slice, :]
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+template <int NTWM>
+__device__ __forceinline__ void gemm_bf16_slice(const float* __restrict__ A, int lda, const uint4* __restrict__ Bh, int KB2T,
+                                                int S0, const Tid& t, f32x4 (&acc)[NTWM]) {
+    constexpr int KB2 = 2 * NTWM;
+    constexpr int CH = bf16_chunk<NTWM>();
+    const float* arow = A + t.n * lda + 8 * t.q + 32 * S0;
+    const uint4* bw = Bh + ((size_t)t.wave * KB2T + S0) * 64 + t.lane;
+    uint4 b0[CH][NTWM], b1[CH][NTWM];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i) b0[c][i] = bw[((size_t)i * 4 * KB2T + c) * 64];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int i = 0; i < NTWM; ++i)
+            if (CH + c < KB2) b1[c][i] = bw[((size_t)i * 4 * KB2T + CH + c) * 64];
+    NoMid mid;
+    gemm_bf16_chunk<NTWM, CH, 0>(b0, b1, arow, bw, acc, mid, KB2T);
 }
 
 // fast-mode twin of dense_relu (K = N = 64 NTWM): OUT = relu(A @ B + bias), ReLU sign words as there

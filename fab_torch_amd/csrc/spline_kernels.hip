@@ -39,6 +39,7 @@ struct SplineDims {
     int D, L, W, Wp, NTWM, KBW;          // hidden width, padded to 64 * tiles-per-wave
     int n_tr_max, NCH, NFP;              // chunks of Wp conditioner outputs: NFP = NCH * Wp >= n_tr_max * SP_NP
     int o_meta, o_unc, o_pfw, o_W0, o_b0, o_Wa, o_ba, o_Wb, o_bb, o_Wf, o_bf, o_WfT, o_WbT, o_WaT, o_W0T;
+    int o_h;                             // fast mode: bf16 images [Wa | Wb | Wf (NCH chunks) | WfT | WbT | WaT], Wp^2/2 floats per Wp x Wp
     int layer_stride, o_base, total;
 };
 
@@ -67,6 +68,7 @@ FAB_HD SplineDims make_spline_dims(int D, int L, int W) {
     f.o_WbT = o; o += (4 * f.NTWM) * T;
     f.o_WaT = o; o += (4 * f.NTWM) * T;
     f.o_W0T = o; o += 4 * T;                               // K = Wp, N = 64
+    f.o_h = o; o += (4 + 2 * f.NCH) * (f.Wp * f.Wp / 2);
     f.layer_stride = o;
     f.o_base = L * f.layer_stride;                         // scale[64], circ[64]
     f.total = f.o_base + 128;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256) void k_spline_pack_layer(SplineDims f, SplineS
     float* __restrict__ dst = packed + (size_t)layer * f.layer_stride;
     const int n_id = (int)s.meta[M_CNT * 64 + 0], n_tr = (int)s.meta[M_CNT * 64 + 1], n_pf = (int)s.meta[M_CNT * 64 + 2];
     const int W = f.W, Wp = f.Wp, KBW = f.KBW, nout = n_tr * SP_NP;
-    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.layer_stride; off += gridDim.x * blockDim.x) {
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.o_h; off += gridDim.x * blockDim.x) {
         float v = 0.f;
         int k, n;
         if (off < f.o_meta + SP_META_ROWS * 64) {
@@ -194,6 +196,42 @@ __global__ void k_spline_pack_base(SplineDims f, const float* __restrict__ scale
     }
 }
 
+// fast mode: bf16 images of the conditioner's Wp x Wp GEMM operands in v_mfma_f32_16x16x32_bf16 B-operand tiles
+// (flow_device.h).  Image m of a layer, HALF = Wp^2/2 floats each, K x N:
+//   0 Wa (Wp x Wp)   1 Wb   2 .. 2+NCH-1 Wf chunk c   then WfT (K = NFP: NCH HALFs, KB2T = NFP/32)   WbT   WaT
+__device__ __forceinline__ unsigned sp_bf16_rne(float v) {
+    unsigned u = __float_as_uint(v);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (u >> 16) | 0x40u;
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+
+__global__ __launch_bounds__(256) void k_spline_pack_bf16(SplineDims f, SplineSrc s, int layer, float* __restrict__ packed) {
+    const int W = f.W, Wp = f.Wp, HALF = Wp * Wp / 2, n_tr = (int)s.meta[M_CNT * 64 + 1], nout = n_tr * SP_NP;
+    const int total = (4 + 2 * f.NCH) * HALF;
+    unsigned* __restrict__ dst = reinterpret_cast<unsigned*>(packed + (size_t)layer * f.layer_stride + f.o_h);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        int m = e / HALF, off = e % HALF;
+        int KB2T = Wp / 32;
+        const bool wft = m >= 2 + f.NCH && m < 2 + 2 * f.NCH;
+        if (wft) { off = e - (2 + f.NCH) * HALF; KB2T = f.NFP / 32; }      // one K = NFP image spanning NCH HALFs
+        const int tile = off >> 8, lane = (off >> 2) & 63, j = 2 * (off & 3);
+        const int c = tile / KB2T, S = tile % KB2T;
+        const int k = 32 * S + 8 * (lane >> 4) + j, n = 16 * c + (lane & 15);
+        float v[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int kk = k + q;
+            if (m == 0) { if (kk < W && n < W) v[q] = s.wa[n * W + kk]; }
+            else if (m == 1) { if (kk < W && n < W) v[q] = s.wb[n * W + kk]; }
+            else if (m < 2 + f.NCH) { const int col = (m - 2) * Wp + n; if (kk < W && col < nout) v[q] = s.wf[col * W + kk]; }
+            else if (wft) { if (kk < nout && n < W) v[q] = s.wf[kk * W + n]; }
+            else if (m == 2 + 2 * f.NCH) { if (kk < W && n < W) v[q] = s.wb[kk * W + n]; }
+            else { if (kk < W && n < W) v[q] = s.wa[kk * W + n]; }
+        }
+        dst[e] = sp_bf16_rne(v[0]) | (sp_bf16_rne(v[1]) << 16);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // conditioner (ResidualNet) on a 16-chain tile
 // ------------------------------------------------------------------------------------------------
@@ -234,6 +272,19 @@ __device__ __forceinline__ void sp_gemm(const float* A, int lda, int KB, const f
     ring_run<NTWM, DEPTH, false, BIAS>(w, A, lda, 0, KB, Bp, t, acc);
 }
 
+// fast-mode twin of sp_gemm for the Wp x Wp operands: image `m` of the layer's bf16 block (see k_spline_pack_bf16)
+template <int NTWM, bool BIAS>
+__device__ __forceinline__ void sp_gemm_bf16(const SplineDims& f, const float* A, int lda, const float* __restrict__ Lp, int m,
+                                             const float* bias, const Tid& t, f32x4 (&acc)[NTWM]) {
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) {
+        const float bv = BIAS ? bias[16 * (t.wave + 4 * i) + t.n] : 0.f;
+        acc[i] = (f32x4){bv, bv, bv, bv};
+    }
+    const uint4* Bh = reinterpret_cast<const uint4*>(Lp + f.o_h + (size_t)m * (f.Wp * f.Wp / 2));
+    gemm_bf16_slice<NTWM>(A, lda, Bh, f.Wp / 32, 0, t, acc);
+}
+
 // identity coordinates of the tile with their periodic features -> A0 (columns >= n_id zero); returns nothing
 __device__ __forceinline__ void sp_load_identity(const SplineDims& f, const float* __restrict__ Lp, const float* __restrict__ Z,
                                                  long row0, long B, float* A0, int AS, const Tid& t) {
@@ -268,7 +319,7 @@ __device__ __forceinline__ void sp_tape_rows(float* __restrict__ dst, int width,
 // h0 = A0 W0 + b0 (kept raw in H0), t = relu(h0) Wa + ba (kept raw in T), h1 = h0 + relu(t) Wb + bb -> X1
 // `act` (nullable): relu(h0) | relu(t) of the tile's rows are kept ([B][2 Wp], rows row0..) for k_spline_net_bwd, which
 // then only needs their signs (the ReLU decisions) and skips this recomputation.
-template <int NTWM>
+template <int NTWM, bool FAST = false>
 __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds& l, const float* __restrict__ Lp, float* lds,
                                               const Tid& t, float* __restrict__ act = nullptr, long row0 = 0, long B = 0) {
     constexpr int DW = depth_w<NTWM>();
@@ -287,7 +338,8 @@ __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds&
                 act[(row0 + 4 * t.q + r) * (2 * f.Wp) + 16 * (t.wave + 4 * i) + t.n] = X2[o];
         }
     __syncthreads();
-    sp_gemm<NTWM, DW, true>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wa), Lp + f.o_ba, t, acc);
+    if constexpr (FAST) sp_gemm_bf16<NTWM, true>(f, X2, l.WS, Lp, 0, Lp + f.o_ba, t, acc);
+    else sp_gemm<NTWM, DW, true>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wa), Lp + f.o_ba, t, acc);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i)
 #pragma unroll
@@ -299,7 +351,8 @@ __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds&
                 act[(row0 + 4 * t.q + r) * (2 * f.Wp) + f.Wp + 16 * (t.wave + 4 * i) + t.n] = X1[o];
         }
     __syncthreads();
-    sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wb), Lp + f.o_bb, t, acc);
+    if constexpr (FAST) sp_gemm_bf16<NTWM, true>(f, X1, l.WS, Lp, 1, Lp + f.o_bb, t, acc);
+    else sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wb), Lp + f.o_bb, t, acc);
     __syncthreads();                                   // everybody is done reading X1 (relu(t)) before it is overwritten
 #pragma unroll
     for (int i = 0; i < NTWM; ++i)
@@ -824,13 +877,11 @@ __device__ __forceinline__ int sp_coord_params(const SplineDims& f, const float*
     return 0;
 }
 
-template <int NTWM, bool GRAD>
-__global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLds l, const float* __restrict__ packed,
-                                                             const float* __restrict__ x, float* __restrict__ log_q,
-                                                             float* __restrict__ grad_x, long B,
-                                                             float* __restrict__ Zsave, float* __restrict__ Psave,
-                                                             float* __restrict__ actsave) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
+template <int NTWM, bool GRAD, bool FAST>
+__device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const NetLds& l, const float* __restrict__ packed,
+                                                    const float* __restrict__ x, float* __restrict__ log_q,
+                                                    float* __restrict__ grad_x, long B, float* __restrict__ Zsave,
+                                                    float* __restrict__ Psave, float* __restrict__ actsave, float* lds) {
     Tid t;
     constexpr int DW = depth_w<NTWM>();
     const long row0 = (long)blockIdx.x * ROWS;
@@ -867,11 +918,12 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLd
         }
         sp_identity_from_tile(f, Lp, ZT, A0, l.AS, t);
         __syncthreads();
-        sp_net_hidden<NTWM>(f, l, Lp, lds, t, GRAD ? actsave + (size_t)layer * as : nullptr, row0, B);
+        sp_net_hidden<NTWM, FAST>(f, l, Lp, lds, t, GRAD ? actsave + (size_t)layer * as : nullptr, row0, B);
         for (int c = 0; c < f.NCH; ++c) {
             f32x4 acc[NTWM];
-            sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wf + (size_t)c * per),
-                                    Lp + f.o_bf + c * f.Wp, t, acc);
+            if constexpr (FAST) sp_gemm_bf16<NTWM, true>(f, X1, l.WS, Lp, 2 + c, Lp + f.o_bf + c * f.Wp, t, acc);
+            else sp_gemm<NTWM, DW, true>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_Wf + (size_t)c * per),
+                                         Lp + f.o_bf + c * f.Wp, t, acc);
 #pragma unroll
             for (int i = 0; i < NTWM; ++i)
 #pragma unroll
@@ -958,13 +1010,21 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLd
         for (int c = n_tr * SP_NP + t.c; c < l.PS; c += 16) PT[t.row * l.PS + c] = 0.f;    // padding columns of dP
         __syncthreads();
         f32x4 acc[NTWM];
-        sp_gemm<NTWM, DW, false>(PT, l.PS, f.NFP / 16, reinterpret_cast<const float4*>(Lp + f.o_WfT), nullptr, t, acc);
+        if constexpr (FAST) {                              // K = NFP: NCH slices of K = Wp of the WfT image
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const uint4* Bh = reinterpret_cast<const uint4*>(Lp + f.o_h + (size_t)(2 + f.NCH) * (f.Wp * f.Wp / 2));
+            for (int c = 0; c < f.NCH; ++c) gemm_bf16_slice<NTWM>(PT, l.PS, Bh, f.NFP / 32, c * (f.Wp / 32), t, acc);
+        } else {
+            sp_gemm<NTWM, DW, false>(PT, l.PS, f.NFP / 16, reinterpret_cast<const float4*>(Lp + f.o_WfT), nullptr, t, acc);
+        }
 #pragma unroll
         for (int i = 0; i < NTWM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) X1[(4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n] = acc[i][r];
         __syncthreads();
-        sp_gemm<NTWM, DW, false>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WbT), nullptr, t, acc);
+        if constexpr (FAST) sp_gemm_bf16<NTWM, false>(f, X1, l.WS, Lp, 2 + 2 * f.NCH, nullptr, t, acc);
+        else sp_gemm<NTWM, DW, false>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WbT), nullptr, t, acc);
 #pragma unroll
         for (int i = 0; i < NTWM; ++i)
 #pragma unroll
@@ -973,7 +1033,8 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLd
                 X2[o] = T[o] > 0.f ? acc[i][r] : 0.f;
             }
         __syncthreads();
-        sp_gemm<NTWM, DW, false>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WaT), nullptr, t, acc);
+        if constexpr (FAST) sp_gemm_bf16<NTWM, false>(f, X2, l.WS, Lp, 3 + 2 * f.NCH, nullptr, t, acc);
+        else sp_gemm<NTWM, DW, false>(X2, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WaT), nullptr, t, acc);
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < NTWM; ++i)
@@ -1006,13 +1067,37 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLd
     }
 }
 
+template <int NTWM, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLds l, const float* __restrict__ packed,
+                                                             const float* __restrict__ x, float* __restrict__ log_q,
+                                                             float* __restrict__ grad_x, long B,
+                                                             float* __restrict__ Zsave, float* __restrict__ Psave,
+                                                             float* __restrict__ actsave) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    spline_logprob_body<NTWM, GRAD, false>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds);
+}
+// fast mode (fabhip_set_fast_mode): the conditioner's Wp x Wp GEMMs on the bf16 matrix cores; gradient evaluations only
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_spline_logprob_fast(SplineDims f, NetLds l, const float* __restrict__ packed,
+                                                                  const float* __restrict__ x, float* __restrict__ log_q,
+                                                                  float* __restrict__ grad_x, long B,
+                                                                  float* __restrict__ Zsave, float* __restrict__ Psave,
+                                                                  float* __restrict__ actsave) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    spline_logprob_body<NTWM, true, true>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds);
+}
+
 template <int NTWM>
 static int launch_logprob(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
                           float* Zsave, float* Psave, float* actsave, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
     const NetLds l = make_net_lds(f, grad_x != nullptr, true);
     const size_t bytes = (size_t)l.total * 4;
-    if (grad_x) {
+    if (grad_x && fast_mode()) {
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob_fast<NTWM>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob_fast<NTWM>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+                           Psave, actsave);
+    } else if (grad_x) {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, true>, bytes));
         hipLaunchKernelGGL((k_spline_logprob<NTWM, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
                            Psave, actsave);
@@ -1074,7 +1159,9 @@ int fabhip_spline_pack(const fabhip_spline_params* p, float* packed, fabhip_stre
             return FABHIP_EINVAL;
         const SplineSrc s{p->meta[l], p->w0[l], p->b0[l], p->wa[l], p->ba[l], p->wb[l], p->bb[l], p->wf[l], p->bf[l],
                           p->pfw[l], p->uw[l], p->uh[l], p->ud[l]};
-        hipLaunchKernelGGL(k_spline_pack_layer, dim3(ceil_div(f.layer_stride, 256 * 8)), dim3(256), 0, st, f, s, l, packed);
+        hipLaunchKernelGGL(k_spline_pack_layer, dim3(ceil_div(f.o_h, 256 * 8)), dim3(256), 0, st, f, s, l, packed);
+        hipLaunchKernelGGL(k_spline_pack_bf16, dim3(ceil_div((4 + 2 * f.NCH) * (f.Wp * f.Wp / 2), 256 * 8)), dim3(256), 0, st,
+                           f, s, l, packed);
     }
     hipLaunchKernelGGL(k_spline_pack_base, dim3(1), dim3(64), 0, st, f, p->base_scale, p->base_circ, packed);
     return check_launch();

@@ -77,6 +77,7 @@ typedef struct {
  * from a bf16 image every fabhip_flow_pack also writes, activations rounded to bf16 as they are fetched).  log q then
  * differs from the fp32 path at the 1e-3 .. 1e-2 level (the sampler stays a valid HMC-AIS sampler for that slightly
  * different density; fabhip_flow_sample, gradient-free density evaluations, the training path and Metropolis stay fp32).
+ * fabhip_spline_log_prob with gradients does the same for the spline conditioner's hidden x hidden GEMMs.
  * Process-wide switch, returns the previous value.  SURVEY section 7's "fp32 parity mode and a fast mode". */
 int fabhip_set_fast_mode(int on);
 int fabhip_get_fast_mode(void);

@@ -112,3 +112,48 @@ def test_fast_mode_ais_on_the_trained_flow_keeps_the_ess_within_one_percent():
             # size is chaotic - half of the chains leave the fp32 trajectory after 8 x 5 leapfrogs under a 1e-3
             # perturbation of log q - so this ESS is a different draw of a heavy-tailed statistic, not a parity quantity
             assert 0 < res[True][0]["ess_ais"] <= 1 and abs(res[True][0]["log_Z"] - res[False][0]["log_Z"]) < 1.0
+
+
+@pytest.mark.parametrize("D,L,hidden,circ,B", [(8, 4, 64, (1, 4, 6), 64), (32, 6, 256, (), 48), (60, 4, 256, (3, 7, 20, 41), 32),
+                                               (7, 3, 128, (0, 6), 33)])
+def test_fast_mode_of_the_spline_flow_is_the_conditioner_with_bf16_rounded_inner_gemm_operands(D, L, hidden, circ, B):
+    """The spline family's fast mode: blocks.0.linear_layers.{0,1} and final_layer of every conditioner on the bf16 matrix
+    cores in the one-launch density + gradient kernel (gradient evaluations only)."""
+    import math
+    from oracle import spline as osp
+    tb = torch.full((D,), 5.0); tb[list(circ)] = math.pi
+    torch.manual_seed(D + L)
+    of = osp.make_circular_coupled_flow(D, L, hidden, circ, tb, seed=3)
+    osp.randomize(of, 0.2, 4)
+    hf = fa.CircularCoupledRQSFlow(D, L, hidden, circ, tb, seed=3)
+    hf._nf_model.load_state_dict(of.state_dict(), strict=True)
+    hf = hf.to(DEV).requires_grad_(False)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        x, _ = of.sample_eps(torch.rand(B, D, generator=g), torch.randn(B, D, generator=g))
+    x = x + 0.2 * torch.randn(B, D, generator=g)
+    lq32, g32 = hf.log_prob_and_grad(x.to(DEV))
+    with fa.fast_mode():
+        lqf, gf = hf.log_prob_and_grad(x.to(DEV))
+        lqf2, gf2 = hf.log_prob_and_grad(x.to(DEV))
+        lq_plain = hf.log_prob(x.to(DEV))
+    lq32b, g32b = hf.log_prob_and_grad(x.to(DEV))
+    assert torch.equal(lq32, lq32b) and torch.equal(g32, g32b) and torch.equal(lqf, lqf2) and torch.equal(gf, gf2)
+    assert close(lq_plain, lq32, 1e-5)
+    em = copy.deepcopy(of).double()
+    for f in em.flows:
+        if isinstance(f, osp.CircularCoupledRationalQuadraticSpline):
+            net = f.prqct.transform_net
+            net.blocks[0].linear_layers[0] = _Bf16Linear(net.blocks[0].linear_layers[0])
+            net.blocks[0].linear_layers[1] = _Bf16Linear(net.blocks[0].linear_layers[1])
+            net.final_layer = _Bf16Linear(net.final_layer)
+    xg = x.double().requires_grad_(True)
+    lq_e = em.log_prob(xg)
+    (g_e,) = torch.autograd.grad(lq_e.sum(), xg)
+    lq_e = lq_e.detach()
+    dev_em = float((lqf.cpu().double() - lq_e).abs().max())
+    dev_32 = float((lqf.cpu().double() - lq32.cpu().double()).abs().max())
+    assert dev_em <= 5e-3, f"fast mode vs its emulation: {dev_em:.2e}"
+    assert 0 < dev_32 <= 0.2, f"fast mode vs fp32: {dev_32:.2e}"
+    rel = (gf.cpu().double() - g_e).norm(dim=1) / g_e.norm(dim=1)
+    assert float(rel.median()) <= 1e-2 and float(rel.max()) <= 0.2, f"grad vs emulation: {float(rel.median()):.2e} / {float(rel.max()):.2e}"

@@ -39,4 +39,9 @@ t = timeit(lambda: ais.sample_and_log_weights(B), int(os.environ.get("N", 5)), w
 out["ais_call_ms"] = 1e3 * t
 out["ais_samples_per_s"] = B / t
 out["n_flow_grad_evals_per_call"] = M * 6 + 1
+with fa.fast_mode():                                   # bf16 conditioner GEMMs (not the parity path)
+    out["fast_log_prob_and_grad_ms"] = 1e3 * timeit(lambda: flow.log_prob_and_grad(x), 50)
+    t = timeit(lambda: ais.sample_and_log_weights(B), int(os.environ.get("N", 5)), warm=2)
+    out["fast_ais_call_ms"] = 1e3 * t
+    out["fast_ais_samples_per_s"] = B / t
 print(json.dumps(out))
