@@ -491,6 +491,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
 // ------------------------------------------------------------------------------------------------
 // rational-quadratic spline (Durkan et al. 2019, eqs. 4-8; nflows / normflows rational_quadratic_spline)
 // ------------------------------------------------------------------------------------------------
+// The spline arithmetic below uses the hardware transcendental forms (__expf = v_exp_f32 on a scaled argument, __logf =
+// v_log_f32 scaled: ~1-2 ulp) - the dependent exp / log chains of a coordinate are what bounds the element-wise part
+// of the kernels, and 2e-7 relative is far inside the 1e-4 parity bar (softplus keeps log1pf where exp(u) is tiny).
 struct Rqs {
     float cw[SP_K + 1], ch[SP_K + 1];                    // knot positions / values
     float ud[SP_K + 1];                                  // effective unnormalised knot derivatives (end knots fixed / tied)
@@ -509,12 +512,12 @@ __device__ __forceinline__ void rqs_knot_pair(const Rqs& s, int b, float& d0, fl
     d1 = SP_MIN_D + sp_softplus(u1);
     if (sg0) {
         const bool f0 = !s.circ && b == 0, f1 = !s.circ && b == SP_K - 1;
-        *sg0 = f0 ? 0.f : 1.f / (1.f + expf(-u0));
-        *sg1 = f1 ? 0.f : 1.f / (1.f + expf(-u1));
+        *sg0 = f0 ? 0.f : 1.f / (1.f + __expf(-u0));
+        *sg1 = f1 ? 0.f : 1.f / (1.f + __expf(-u1));
     }
 }
 
-__device__ __forceinline__ float sp_softplus(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sp_softplus(float x) { return x > 20.f ? x : (x < -5.f ? log1pf(expf(x)) : __logf(1.f + __expf(x))); }
 
 // p[0..K) widths, [K..2K) heights (both already divided by sqrt(hidden) when conditional), [2K..3K] derivatives
 __device__ __forceinline__ void rqs_setup(const float* p, bool circ, float tb, Rqs& s) {
@@ -523,7 +526,7 @@ __device__ __forceinline__ void rqs_setup(const float* p, bool circ, float tb, R
     for (int j = 1; j < SP_K; ++j) { mw = fmaxf(mw, p[j]); mh = fmaxf(mh, p[SP_K + j]); }
     float sw = 0.f, sh = 0.f;
 #pragma unroll
-    for (int j = 0; j < SP_K; ++j) { s.pw[j] = expf(p[j] - mw); sw += s.pw[j]; s.ph[j] = expf(p[SP_K + j] - mh); sh += s.ph[j]; }
+    for (int j = 0; j < SP_K; ++j) { s.pw[j] = __expf(p[j] - mw); sw += s.pw[j]; s.ph[j] = __expf(p[SP_K + j] - mh); sh += s.ph[j]; }
     float cw = 0.f, chh = 0.f;
     s.cw[0] = -tb; s.ch[0] = -tb;
 #pragma unroll
@@ -535,7 +538,7 @@ __device__ __forceinline__ void rqs_setup(const float* p, bool circ, float tb, R
         s.ch[j + 1] = (2.f * tb) * chh + (-tb);
     }
     s.cw[SP_K] = tb; s.ch[SP_K] = tb;
-    const float cst = logf(expf(1.f - SP_MIN_D) - 1.f);
+    const float cst = __logf(__expf(1.f - SP_MIN_D) - 1.f);
     s.circ = circ;
 #pragma unroll
     for (int j = 0; j <= SP_K; ++j) {
@@ -567,7 +570,7 @@ __device__ __forceinline__ void rqs_forward(const Rqs& s, float x, float tb, flo
     const float den = dl + (d0 + d1 - 2.f * dl) * t1;
     y = yk + num / den;
     const float dn = (dl * dl) * (d1 * (th * th) + 2.f * dl * t1 + d0 * ((1.f - th) * (1.f - th)));
-    ld = logf(dn) - 2.f * logf(den);
+    ld = __logf(dn) - 2.f * __logf(den);
 }
 
 // x = f^-1(y), logabsdet of the INVERSE map
@@ -589,7 +592,7 @@ __device__ __forceinline__ void rqs_inverse(const Rqs& s, float y, float tb, flo
     const float t1 = root * (1.f - root);
     const float den = dl + A * t1;
     const float dn = (dl * dl) * (d1 * (root * root) + 2.f * dl * t1 + d0 * ((1.f - root) * (1.f - root)));
-    ld = -(logf(dn) - 2.f * logf(den));
+    ld = -(__logf(dn) - 2.f * __logf(den));
 }
 
 // reverse mode of rqs_forward with cotangents (gy, 1 on logabsdet): returns d/dx and, if dp != nullptr, the cotangents
@@ -834,6 +837,21 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
 // outputs and ReLU decisions of the forward sweep are parked in the workspace, per tile: L2-resident).  Replaces 4 L + 2
 // launches of the per-stage kernels above (kept for the training tape and the sampling direction).
 // ------------------------------------------------------------------------------------------------
+// rows row0 .. row0+15 of a row-major [B][width] matrix (width % 4 == 0, 16-byte aligned rows) -> LDS tile [16][ldd]:
+// one wave per row (4 rows each), float4 per lane, no index division (the element-wise version of this load cost 27 %
+// of the reverse sweep)
+__device__ __forceinline__ void sp_tile_load4(float* dst, int ldd, const float* __restrict__ src, long lds_src, int width,
+                                              long row0, long B, const Tid& t) {
+    for (int r = t.wave; r < ROWS; r += NWAVE) {
+        const long g = row0 + r;
+        for (int c4 = t.lane; 4 * c4 < width; c4 += 64) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < B) v = *reinterpret_cast<const float4*>(src + g * lds_src + 4 * c4);
+            *reinterpret_cast<float4*>(dst + r * ldd + 4 * c4) = v;
+        }
+    }
+}
+
 __device__ __forceinline__ void sp_identity_from_tile(const SplineDims& f, const float* __restrict__ Lp, const float* ZT,
                                                       float* A0, int AS, const Tid& t) {
     const float* meta = Lp + f.o_meta;
@@ -881,8 +899,10 @@ template <int NTWM, bool GRAD, bool FAST>
 __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const NetLds& l, const float* __restrict__ packed,
                                                     const float* __restrict__ x, float* __restrict__ log_q,
                                                     float* __restrict__ grad_x, long B, float* __restrict__ Zsave,
-                                                    float* __restrict__ Psave, float* __restrict__ actsave, float* lds) {
+                                                    float* __restrict__ Psave, float* __restrict__ actsave, float* lds,
+                                                    long long* tlp = nullptr) {
     Tid t;
+#define SP_TL(idx) do { if (tlp && blockIdx.x == 0 && threadIdx.x == 0) tlp[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     constexpr int DW = depth_w<NTWM>();
     const long row0 = (long)blockIdx.x * ROWS;
     float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
@@ -910,6 +930,8 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
     for (int layer = f.L - 1; layer >= 0; --layer) {
         const float* Lp = packed + (size_t)layer * f.layer_stride;
         const float* meta = Lp + f.o_meta;
+        const bool tl = layer == 1;
+        if (tl) SP_TL(0);
         if (GRAD) {                                        // this layer's input state, for the reverse sweep
             for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
                 const int r = e / f.D, j = e % f.D;
@@ -918,7 +940,9 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
         }
         sp_identity_from_tile(f, Lp, ZT, A0, l.AS, t);
         __syncthreads();
+        if (tl) SP_TL(1);
         sp_net_hidden<NTWM, FAST>(f, l, Lp, lds, t, GRAD ? actsave + (size_t)layer * as : nullptr, row0, B);
+        if (tl) SP_TL(2);
         for (int c = 0; c < f.NCH; ++c) {
             f32x4 acc[NTWM];
             if constexpr (FAST) sp_gemm_bf16<NTWM, true>(f, X1, l.WS, Lp, 2 + c, Lp + f.o_bf + c * f.Wp, t, acc);
@@ -934,6 +958,7 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
                 }
         }
         __syncthreads();
+        if (tl) SP_TL(3);
         const float* mn = layer > 0 ? packed + (size_t)(layer - 1) * f.layer_stride + f.o_meta : nullptr;
         for (int j = t.c; j < f.D; j += 16) {
             float p[SP_NP];
@@ -952,6 +977,7 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
             ZT[t.row * 64 + j] = out;
         }
         __syncthreads();
+        if (tl) SP_TL(4);
     }
     // base UniformGaussian
     for (int j = t.c; j < f.D; j += 16) {
@@ -972,21 +998,18 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
         const float* Lp = packed + (size_t)layer * f.layer_stride;
         const float* meta = Lp + f.o_meta;
         const int n_id = (int)meta[M_CNT * 64], n_tr = (int)meta[M_CNT * 64 + 1];
+        const bool tl = layer == 1;
+        if (tl) SP_TL(8);
         for (int e = t.tid; e < ROWS * 64; e += NTHREADS) {           // layer input state
             const int r = e >> 6, j = e & 63;
             ZT[e] = (j < f.D && row0 + r < B) ? Zsave[(size_t)layer * zs + (row0 + r) * f.D + j] : 0.f;
         }
-        for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) {         // conditioner output (-> dP in place below)
-            const int r = e / l.PS, c = e % l.PS;
-            PT[e] = (c < f.NFP && row0 + r < B) ? Psave[(size_t)layer * ps + (row0 + r) * f.NFP + c] : 0.f;
-        }
-        for (int e = t.tid; e < ROWS * f.Wp; e += NTHREADS) {         // ReLU decisions of the forward sweep
-            const int r = e / f.Wp, c = e % f.Wp;
-            const long g = row0 + r;
-            H0[r * l.WS + c] = g < B ? actsave[(size_t)layer * as + g * (2 * f.Wp) + c] : 0.f;
-            T[r * l.WS + c] = g < B ? actsave[(size_t)layer * as + g * (2 * f.Wp) + f.Wp + c] : 0.f;
-        }
+        // conditioner output (-> dP in place below) and the ReLU decisions of the forward sweep
+        sp_tile_load4(PT, l.PS, Psave + (size_t)layer * ps, f.NFP, f.NFP, row0, B, t);
+        sp_tile_load4(H0, l.WS, actsave + (size_t)layer * as, 2 * f.Wp, f.Wp, row0, B, t);
+        sp_tile_load4(T, l.WS, actsave + (size_t)layer * as + f.Wp, 2 * f.Wp, f.Wp, row0, B, t);
         __syncthreads();
+        if (tl) SP_TL(9);
         for (int j = t.c; j < f.D; j += 16) {
             float p[SP_NP];
             int pos;
@@ -1009,6 +1032,7 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
         }
         for (int c = n_tr * SP_NP + t.c; c < l.PS; c += 16) PT[t.row * l.PS + c] = 0.f;    // padding columns of dP
         __syncthreads();
+        if (tl) SP_TL(10);
         f32x4 acc[NTWM];
         if constexpr (FAST) {                              // K = NFP: NCH slices of K = Wp of the WfT image
 #pragma unroll
@@ -1023,6 +1047,7 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
 #pragma unroll
             for (int r = 0; r < 4; ++r) X1[(4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n] = acc[i][r];
         __syncthreads();
+        if (tl) SP_TL(11);
         if constexpr (FAST) sp_gemm_bf16<NTWM, false>(f, X1, l.WS, Lp, 2 + 2 * f.NCH, nullptr, t, acc);
         else sp_gemm<NTWM, DW, false>(X1, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_WbT), nullptr, t, acc);
 #pragma unroll
@@ -1044,8 +1069,10 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
                 T[o] = X1[o] + (H0[o] > 0.f ? acc[i][r] : 0.f);
             }
         __syncthreads();
+        if (tl) SP_TL(12);
         gemm_ksplit<NTWM>(T, l.WS, reinterpret_cast<const float4*>(Lp + f.o_W0T), 4, PART, l.AS, t);
         __syncthreads();
+        if (tl) SP_TL(13);
         for (int e = t.tid; e < ROWS * 64; e += NTHREADS) {
             const int r = e >> 6, i = e & 63;
             if (i < n_id) {
@@ -1060,11 +1087,13 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
             }
         }
         __syncthreads();
+        if (tl) SP_TL(14);
     }
     for (int e = t.tid; e < ROWS * f.D; e += NTHREADS) {
         const int r = e / f.D, j = e % f.D;
         if (row0 + r < B) grad_x[(row0 + r) * f.D + j] = GT[r * 64 + j];
     }
+#undef SP_TL
 }
 
 template <int NTWM, bool GRAD>
@@ -1072,9 +1101,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLd
                                                              const float* __restrict__ x, float* __restrict__ log_q,
                                                              float* __restrict__ grad_x, long B,
                                                              float* __restrict__ Zsave, float* __restrict__ Psave,
-                                                             float* __restrict__ actsave) {
+                                                             float* __restrict__ actsave, long long* tlp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    spline_logprob_body<NTWM, GRAD, false>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds);
+    spline_logprob_body<NTWM, GRAD, false>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds, tlp);
 }
 // fast mode (fabhip_set_fast_mode): the conditioner's Wp x Wp GEMMs on the bf16 matrix cores; gradient evaluations only
 template <int NTWM>
@@ -1082,9 +1111,18 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_fast(SplineDims f, 
                                                                   const float* __restrict__ x, float* __restrict__ log_q,
                                                                   float* __restrict__ grad_x, long B,
                                                                   float* __restrict__ Zsave, float* __restrict__ Psave,
-                                                                  float* __restrict__ actsave) {
+                                                                  float* __restrict__ actsave, long long* tlp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    spline_logprob_body<NTWM, true, true>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds);
+    spline_logprob_body<NTWM, true, true>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds, tlp);
+}
+
+// dev-only stage timeline (FABHIP_TIMELINE=1): s_memtime stamps of workgroup 0 in layer 1 of k_spline_logprob
+static long long* g_sp_timeline = nullptr;
+static long long* sp_timeline(hipStream_t st) {
+    if (!getenv("FABHIP_TIMELINE")) return nullptr;
+    if (!g_sp_timeline && hipMalloc((void**)&g_sp_timeline, 32 * 8) != hipSuccess) return nullptr;
+    hipMemsetAsync(g_sp_timeline, 0, 32 * 8, st);
+    return g_sp_timeline;
 }
 
 template <int NTWM>
@@ -1096,15 +1134,15 @@ static int launch_logprob(const SplineDims& f, const float* packed, const float*
     if (grad_x && fast_mode()) {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob_fast<NTWM>, bytes));
         hipLaunchKernelGGL((k_spline_logprob_fast<NTWM>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, actsave);
+                           Psave, actsave, sp_timeline(st));
     } else if (grad_x) {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, true>, bytes));
         hipLaunchKernelGGL((k_spline_logprob<NTWM, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, actsave);
+                           Psave, actsave, sp_timeline(st));
     } else {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, false>, bytes));
         hipLaunchKernelGGL((k_spline_logprob<NTWM, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, actsave);
+                           Psave, actsave, sp_timeline(st));
     }
     return check_launch();
 }
@@ -1142,6 +1180,11 @@ static inline size_t sp_al(size_t v) { return (v + 255) & ~(size_t)255; }
 using namespace fab;
 
 extern "C" {
+
+int fabhip_debug_spline_timeline(int64_t* host_out, int32_t n) {
+    if (!g_sp_timeline || !host_out || n < 1 || n > 32) return FABHIP_EINVAL;
+    return hipMemcpy(host_out, g_sp_timeline, (size_t)n * 8, hipMemcpyDeviceToHost) == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH;
+}
 
 int64_t fabhip_spline_packed_floats(int32_t dim, int32_t n_layers, int32_t hidden) {
     if (check_spline_shape(dim, n_layers, hidden) != FABHIP_OK) return -1;

@@ -154,6 +154,8 @@ typedef struct {
 } fabhip_spline_flow;
 
 int64_t fabhip_spline_packed_floats(int32_t dim, int32_t n_layers, int32_t hidden);
+/* development aid (FABHIP_TIMELINE=1): s_memtime stamps of one layer of the one-launch density kernel */
+int fabhip_debug_spline_timeline(int64_t* host_out, int32_t n);
 int fabhip_spline_pack(const fabhip_spline_params* params, float* packed, fabhip_stream_t stream);
 size_t fabhip_spline_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B, int32_t with_grad);
 /* log_q[B] = flow.log_prob(x[B][dim]) and, if grad_x != NULL, d log_q / dx [B][dim] (reverse sweep through all layers). */
