@@ -307,6 +307,21 @@ __device__ __forceinline__ void sp_load_identity(const SplineDims& f, const floa
     }
 }
 
+// rows row0 .. row0+15 of a row-major [B][width] matrix (width % 4 == 0, 16-byte aligned rows) -> LDS tile [16][ldd]:
+// one wave per row (4 rows each), float4 per lane, no index division (the element-wise version of this load cost 27 %
+// of the reverse sweep)
+__device__ __forceinline__ void sp_tile_load4(float* dst, int ldd, const float* __restrict__ src, long lds_src, int width,
+                                              long row0, long B, const Tid& t) {
+    for (int r = t.wave; r < ROWS; r += NWAVE) {
+        const long g = row0 + r;
+        for (int c4 = t.lane; 4 * c4 < width; c4 += 64) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g < B) v = *reinterpret_cast<const float4*>(src + g * lds_src + 4 * c4);
+            *reinterpret_cast<float4*>(dst + r * ldd + 4 * c4) = v;
+        }
+    }
+}
+
 // tape: rows of an LDS tile [16][ld] (first `width` columns) -> dst [B][width]
 __device__ __forceinline__ void sp_tape_rows(float* __restrict__ dst, int width, const float* src, int ld, long row0, long B,
                                              const Tid& t) {
@@ -408,18 +423,10 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
     float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
     float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* DP = lds + l.o_DP; float* PART = lds + l.o_PART;
     if (!act) sp_load_identity(f, Lp, Z, row0, B, A0, l.AS, t);
-    for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) {
-        const int r = e / l.PS, j = e % l.PS;
-        const long g = row0 + r;
-        DP[e] = (j < f.NFP && g < B) ? dP[g * f.NFP + j] : 0.f;
-    }
+    sp_tile_load4(DP, l.PS, dP, f.NFP, f.NFP, row0, B, t);
     if (act) {                                          // the forward kept relu(h0) | relu(t): only their signs matter here
-        for (int e = t.tid; e < ROWS * f.Wp; e += NTHREADS) {
-            const int r = e / f.Wp, c = e % f.Wp;
-            const long g = row0 + r;
-            H0[r * l.WS + c] = g < B ? act[g * (2 * f.Wp) + c] : 0.f;
-            T[r * l.WS + c] = g < B ? act[g * (2 * f.Wp) + f.Wp + c] : 0.f;
-        }
+        sp_tile_load4(H0, l.WS, act, 2 * f.Wp, f.Wp, row0, B, t);
+        sp_tile_load4(T, l.WS, act + f.Wp, 2 * f.Wp, f.Wp, row0, B, t);
     }
     __syncthreads();
     if (!act) sp_net_hidden<NTWM>(f, l, Lp, lds, t);    // recompute h0 (H0) and t (T): the ReLU decisions
@@ -837,21 +844,6 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
 // outputs and ReLU decisions of the forward sweep are parked in the workspace, per tile: L2-resident).  Replaces 4 L + 2
 // launches of the per-stage kernels above (kept for the training tape and the sampling direction).
 // ------------------------------------------------------------------------------------------------
-// rows row0 .. row0+15 of a row-major [B][width] matrix (width % 4 == 0, 16-byte aligned rows) -> LDS tile [16][ldd]:
-// one wave per row (4 rows each), float4 per lane, no index division (the element-wise version of this load cost 27 %
-// of the reverse sweep)
-__device__ __forceinline__ void sp_tile_load4(float* dst, int ldd, const float* __restrict__ src, long lds_src, int width,
-                                              long row0, long B, const Tid& t) {
-    for (int r = t.wave; r < ROWS; r += NWAVE) {
-        const long g = row0 + r;
-        for (int c4 = t.lane; 4 * c4 < width; c4 += 64) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (g < B) v = *reinterpret_cast<const float4*>(src + g * lds_src + 4 * c4);
-            *reinterpret_cast<float4*>(dst + r * ldd + 4 * c4) = v;
-        }
-    }
-}
-
 __device__ __forceinline__ void sp_identity_from_tile(const SplineDims& f, const float* __restrict__ Lp, const float* ZT,
                                                       float* A0, int AS, const Tid& t) {
     const float* meta = Lp + f.o_meta;
