@@ -73,7 +73,13 @@ class ShardedAIS:
         sizes = shard_sizes(total_batch, world)
         x, log_w, log_q = self.local_sampler(sizes[rank])
         if self.sync_step_size and self.step_state is not None and world > 1:
-            for t in self.step_state():
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
-                t.div_(world)
+            # ONE tiny all-reduce for all step-size tensors (epsilons [M, n_outer] + common_epsilon [1]: latency-bound)
+            ts = list(self.step_state())
+            flat = torch.cat([t.reshape(-1).to(torch.float32) for t in ts])
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            flat.div_(world)
+            o = 0
+            for t in ts:
+                t.copy_(flat[o:o + t.numel()].view_as(t))
+                o += t.numel()
         return gather_particles(x, log_w, log_q, max(sizes), self.group)

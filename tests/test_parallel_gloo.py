@@ -76,3 +76,26 @@ def test_two_rank_gloo_gather_equals_concatenated_shards(tmp_path):
     assert got["x"].shape[0] == total - 1                 # the NaN chain of rank 1 was removed, no padding leaked
     np.testing.assert_array_equal(got["x"].numpy(), x_ref.numpy())
     np.testing.assert_array_equal(got["lw"].numpy(), lw_ref.numpy())
+
+
+def _worker_sync(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eps = torch.full((3, 1), 0.1 * (rank + 1))             # per-rank adapted step sizes: 0.1 / 0.2
+    ceps = torch.tensor([0.01 * (rank + 1)])
+
+    def sampler(b):
+        return torch.zeros(b, 2), torch.zeros(b), torch.zeros(b)
+    sh = parallel.ShardedAIS(sampler, step_state=lambda: [eps, ceps], sync_step_size=True)
+    sh.sample_and_log_weights(8)
+    torch.save({"eps": eps, "ceps": ceps}, out + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_size_averaging_is_one_collective_and_identical_on_all_ranks(tmp_path):
+    out = str(tmp_path / "s")
+    mp.spawn(_worker_sync, args=(2, _free_port(), out), nprocs=2, join=True)
+    a, b = torch.load(out + "0"), torch.load(out + "1")
+    assert torch.equal(a["eps"], b["eps"]) and torch.equal(a["ceps"], b["ceps"])
+    assert torch.allclose(a["eps"], torch.full((3, 1), 0.15)) and torch.allclose(a["ceps"], torch.tensor([0.015]))
