@@ -117,7 +117,8 @@ class AnnealedImportanceSampler:
         return isinstance(self.base_distribution, RealNVP) and \
             _owner_or_none(self.target_log_prob, _NativeTarget) is not None and self.transition_operator.is_native
 
-    def _sample_generic(self, batch_size: int, logging: bool, noise_a=None, noise_b=None):
+    def _sample_generic(self, batch_size: int, logging: bool, noise_a=None, noise_b=None, want_base: bool = False,
+                        raise_at_end: bool = True):
         """ais.py:53-105 for ANY `Distribution` / `LogProbFunc` plug-ins (fab/types_.py:5-27): the reference's loop,
         stepped from Python; the plug-ins evaluate their own densities, the transitions / log-weight arithmetic /
         ESS run as fabhip kernels (transition_operators.py: generic path)."""
@@ -130,6 +131,10 @@ class AnnealedImportanceSampler:
                                      with_grad=op.uses_grad_info, log_q_x=log_q0)
         log_q0 = log_q0.detach().contiguous().float()
         log_w = ops.anneal_log_prob(point.log_q, point.log_p, float(self.B_space[1]), alpha, bool(self.p_target)) - log_q0
+        base = None
+        if want_base:                                      # generate_eval_data (ais.py:152-166): log p - log q of the sampling pass
+            valid = torch.isfinite(point.log_p) & torch.isfinite(point.log_q)
+            base = (point.x[valid].clone(), (point.log_p - log_q0)[valid])
         point, log_w = self._remove_nan_and_infs(point, log_w, "chain init")
         ess_base = ops.ess_logz((point.log_p - point.log_q).contiguous(), None, 1.0)
         hmc = isinstance(op, HamiltonianMonteCarlo)
@@ -144,19 +149,24 @@ class AnnealedImportanceSampler:
                 point = op.transition(point, j, beta, log_w=lw, beta_next=beta_next, noise_p=na, noise_e=nb)
             else:
                 point = op.transition(point, j, beta, log_w=lw, beta_next=beta_next, noise_x=na, noise_u=nb)
-        point, log_w = self._remove_nan_and_infs(point, log_w, "chain end")
+        point, log_w = self._remove_nan_and_infs(point, log_w, "chain end", raise_exception=raise_at_end)
         if logging:
             st = torch.cat([ess_base[:1], ops.ess_logz(log_w.contiguous(), None, float(B))[:2]]).tolist()
             self._logging_info = LoggingInfo(ess_base=st[0], ess_ais=st[1], log_Z=st[2])
+        if want_base:
+            return point, log_w.detach(), base
         return point, log_w.detach()
 
     @staticmethod
-    def _remove_nan_and_infs(point: Point, log_w: torch.Tensor, descriptor: str):
+    def _remove_nan_and_infs(point: Point, log_w: torch.Tensor, descriptor: str, raise_exception: bool = True):
         """ais.py:190-213 (generic path; the fused path compacts on the device)."""
         valid = torch.isfinite(point.log_p) & torch.isfinite(point.log_q)
         n_valid = int(valid.sum())
         if n_valid == 0:
-            raise Exception(f"No valid points generated in sampling the {descriptor}")
+            if raise_exception:
+                raise Exception(f"No valid points generated in sampling the {descriptor}")
+            print(f"No valid points generated in sampling the {descriptor}")       # ais.py:206-207 (evaluation)
+            return point, log_w
         if n_valid == valid.shape[0]:
             return point, log_w
         print(f"{valid.shape[0] - n_valid} nan/inf samples/log-probs/log-weights encountered at {descriptor}.")
@@ -190,11 +200,18 @@ class AnnealedImportanceSampler:
         """ais.py:132-188 — evaluation batches: the chains' starting points (flow samples) with log p - log q, and
         the AIS samples with their log-weights.  Everything stays on the device: the batches are enqueued back to
         back and the row counts of all of them are read with ONE device->host copy at the end (the reference
-        concatenates on the CPU after a `.cpu()` per batch); the returned tensors live on the GPU."""
-        flow, _ = self._native_parts()
+        concatenates on the CPU after a `.cpu()` per batch); the returned tensors live on the GPU.  Generic plug-ins
+        (e.g. the spline flow): the reference's loop per batch through `_sample_generic`."""
         assert outer_batch_size % inner_batch_size == 0
         n_batches = outer_batch_size // inner_batch_size
         B = inner_batch_size
+        if not self.is_native:
+            bx, blw, ax, alw = [], [], [], []
+            for _ in range(n_batches):
+                point, log_w, base = self._sample_generic(B, logging=False, want_base=True, raise_at_end=False)
+                bx.append(base[0]); blw.append(base[1]); ax.append(point.x.detach()); alw.append(log_w)
+            return torch.cat(bx), torch.cat(blw), torch.cat(ax), torch.cat(alw)
+        flow, _ = self._native_parts()
         base_x, base_lw, ais_x, ais_lw, counts = [], [], [], [], []
         for i in range(n_batches):
             point, log_w, n_valid, _, bx, blw = self.run(B, want_base=True)

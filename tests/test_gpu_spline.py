@@ -315,3 +315,24 @@ def test_cfg3_with_the_spline_flow_at_full_size():
     assert idx.shape == (2 * B,) and len(set(idx.tolist())) == 2 * B
     assert any(not torch.equal(a, p.detach()) for a, p in zip(before, hf.parameters()))
     assert all(torch.isfinite(p).all() for p in hf.parameters())
+
+
+def test_eval_info_with_the_spline_flow():
+    """FABModel.get_eval_info / AnnealedImportanceSampler.generate_eval_data (ais.py:132-188, core.py:191-220) through the
+    generic path: base samples carry log p - log q of the sampling pass, AIS towards p, ManyWell metrics on both."""
+    D, L, hidden, M = 6, 3, 64, 3
+    torch.manual_seed(0)
+    hf = fa.make_wrapped_normflow_spline(D, L, hidden, (), 5.0).to(DEV)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
+    model = fa.FABModel(hf, target, M, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
+    bx, blw, ax, alw = model.annealed_importance_sampler.generate_eval_data(512, 256)
+    assert bx.shape == (512, D) and ax.shape == (512, D) and blw.shape == (512,) and alw.shape == (512,)
+    with torch.no_grad():
+        assert close(blw, target.log_prob(bx) - hf.log_prob(bx), 1e-4)            # log p - log q at the base samples
+    info = model.get_eval_info(outer_batch_size=512, inner_batch_size=256)
+    for k in ("eval_ess_flow", "eval_ess_ais", "flow_forward_kl", "flow_test_set_exact_mean_log_prob",
+              "ais_abs_MSE_log_Z_estimate"):
+        assert k in info and math.isfinite(info[k]), k
+    assert 0 < info["eval_ess_flow"] <= 1 and 0 < info["eval_ess_ais"] <= 1
+    assert model.annealed_importance_sampler.p_target is False                      # toggled back (core.py:219)

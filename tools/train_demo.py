@@ -24,17 +24,22 @@ def main():
     ap.add_argument("--M", type=int, default=4)
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--evals", type=int, default=10)
+    ap.add_argument("--flow", choices=("realnvp", "spline"), default="realnvp")
+    ap.add_argument("--hidden", type=int, default=256)
     args = ap.parse_args()
     torch.manual_seed(0)
     D = args.dim
-    flow = fa.make_wrapped_normflow_realnvp(D, n_flow_layers=args.layers, layer_nodes_per_dim=40 if D <= 8 else 10,
-                                            act_norm=False).to(DEV)
+    if args.flow == "spline":       # the alanine-dipeptide flow family on the ManyWell target (BASELINE cfg 3), torch Adam
+        flow = fa.make_wrapped_normflow_spline(D, args.layers, args.hidden, (), 5.0).to(DEV)
+    else:
+        flow = fa.make_wrapped_normflow_realnvp(D, n_flow_layers=args.layers, layer_nodes_per_dim=40 if D <= 8 else 10,
+                                                act_norm=False).to(DEV)
     target = fa.ManyWellEnergy(D)
     hmc = fa.HamiltonianMonteCarlo(args.M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=1.0,
                                    n_outer=1, L=5).to(DEV)
     model = fa.FABModel(flow, target, args.M, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
     ais = model.annealed_importance_sampler
-    opt = fa.FlatAdam(flow, lr=args.lr)
+    opt = fa.FlatAdam(flow, lr=args.lr) if args.flow == "realnvp" else torch.optim.Adam(flow.parameters(), lr=args.lr)
 
     def init_sampler():
         pt, lw = ais.sample_and_log_weights(args.batch, logging=False)
