@@ -255,26 +255,35 @@ class CircularCoupledRQSFlow(nn.Module):
         lay = _ops.load().spline_tape_layout(self.dim, self.n_layers, self.hidden, B)
         stride, (o_xi, o_a0, o_da0, o_r0, o_r1, o_h1, o_dh1, o_dt, o_dh0, o_dp, o_du), Wp, NFP, UW = \
             lay[1], lay[2:13], lay[13], lay[14], lay[15]
-        W, NP = self.hidden, 3 * NUM_BINS + 1
-        cc = c[:, None]
+        W, NP, L = self.hidden, 3 * NUM_BINS + 1, self.n_layers
+        # all layers at once: the tape holds the same matrices at the same offsets for every layer (padding columns of
+        # the activations / cotangents are zero), so each Linear's weight gradient is ONE batched GEMM over the layers
+        T = tape[:L * stride].view(L, stride)
+
+        def m3(off, width):
+            return T[:, off: off + B * width].view(L, B, width)
+        cc = c.view(1, B, 1)
+        a0, r0, r1, h1 = m3(o_a0, 64), m3(o_r0, Wp)[..., :W], m3(o_r1, Wp)[..., :W], m3(o_h1, Wp)[..., :W]
+        dh0, dt, dh1 = cc * m3(o_dh0, Wp)[..., :W], cc * m3(o_dt, Wp)[..., :W], cc * m3(o_dh1, Wp)[..., :W]
+        dp = cc * m3(o_dp, NFP)
+        gw0, gb0 = torch.bmm(dh0.transpose(1, 2), a0), dh0.sum(1)                 # [L, W, 64], [L, W]
+        gwa, gba = torch.bmm(dt.transpose(1, 2), r0), dt.sum(1)
+        gwb, gbb = torch.bmm(dh1.transpose(1, 2), r1), dh1.sum(1)
+        gwf, gbf = torch.bmm(dp.transpose(1, 2), h1), dp.sum(1)                   # [L, NFP, W], [L, NFP]
+        du = (cc * m3(o_du, UW)).sum(1)                                            # [L, 64 * 25] (rows >= n_id: unwritten)
         grads = []
         for l, (f, _, _) in enumerate(self._structure()):
             pr, net = f.prqct, f.prqct.transform_net
             n_id, n_tr = len(pr.identity_features), len(pr.transform_features)
-
-            def mat(off, width, cols):
-                return tape[l * stride + off: l * stride + off + B * width].view(B, width)[:, :cols]
-            a0, r0, r1, h1 = mat(o_a0, 64, n_id), mat(o_r0, Wp, W), mat(o_r1, Wp, W), mat(o_h1, Wp, W)
-            dh0, dt, dh1 = cc * mat(o_dh0, Wp, W), cc * mat(o_dt, Wp, W), cc * mat(o_dh1, Wp, W)
-            dp = cc * mat(o_dp, NFP, n_tr * NP)
-            grads += [dh0.t() @ a0, dh0.sum(0), dt.t() @ r0, dt.sum(0), dh1.t() @ r1, dh1.sum(0), dp.t() @ h1, dp.sum(0)]
+            nout = n_tr * NP
+            grads += [gw0[l, :, :n_id], gb0[l], gwa[l], gba[l], gwb[l], gbb[l], gwf[l, :nout], gbf[l, :nout]]
             if net.preprocessing is not None:
                 pf = net.preprocessing
-                xs = mat(o_xi, 64, n_id)[:, pf.ind] * pf.scale
-                da = (cc * mat(o_da0, 64, n_id))[:, pf.ind]
+                xs = m3(o_xi, 64)[l][:, pf.ind] * pf.scale
+                da = (c[:, None] * m3(o_da0, 64)[l])[:, pf.ind]
                 grads.append(torch.stack([(da * torch.sin(xs)).sum(0), (da * torch.cos(xs)).sum(0)], dim=1))
-            du = (cc * mat(o_du, UW, n_id * NP)).sum(0).view(n_id, NP)
-            grads += [du[:, :NUM_BINS], du[:, NUM_BINS:2 * NUM_BINS], du[:, 2 * NUM_BINS:]]
+            dul = du[l, :n_id * NP].view(n_id, NP)
+            grads += [dul[:, :NUM_BINS], dul[:, NUM_BINS:2 * NUM_BINS], dul[:, 2 * NUM_BINS:]]
         return grads
 
     def log_prob_and_grad(self, x: torch.Tensor):
@@ -303,9 +312,20 @@ class CircularCoupledRQSFlow(nn.Module):
         dev = self._tail_bound.device
         D = self.dim
         tensors = []
-        for f, post, wrap in self._structure():
+        cache = self.__dict__.setdefault("_meta_cache", {})          # static structure: built once per device
+        for li, (f, post, wrap) in enumerate(self._structure()):
             pr = f.prqct
             net = pr.transform_net
+            key = (li, str(dev))
+            if key in cache:
+                pr, net, u = f.prqct, f.prqct.transform_net, f.prqct.unconditional_transform
+                tensors += [cache[key], net.initial_layer.weight, net.initial_layer.bias,
+                            net.blocks[0].linear_layers[0].weight, net.blocks[0].linear_layers[0].bias,
+                            net.blocks[0].linear_layers[1].weight, net.blocks[0].linear_layers[1].bias,
+                            net.final_layer.weight, net.final_layer.bias,
+                            net.preprocessing.weights if net.preprocessing is not None else cache[("empty", str(dev))],
+                            u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives]
+                continue
             idf, trf = pr.identity_features.tolist(), pr.transform_features.tolist()
             meta = torch.zeros(12, 64)
             meta[0, :] = -1; meta[1, :] = -1
@@ -327,11 +347,13 @@ class CircularCoupledRQSFlow(nn.Module):
                 meta[8, wrap.ind.cpu()] = 1.0                         # shift 0: PeriodicWrap.inverse
             meta[11, 0], meta[11, 1], meta[11, 2] = len(idf), len(trf), n_pf
             u = pr.unconditional_transform
-            tensors += [meta.to(dev), net.initial_layer.weight, net.initial_layer.bias,
+            cache[key] = meta.to(dev)
+            cache.setdefault(("empty", str(dev)), torch.zeros(0, device=dev))
+            tensors += [cache[key], net.initial_layer.weight, net.initial_layer.bias,
                         net.blocks[0].linear_layers[0].weight, net.blocks[0].linear_layers[0].bias,
                         net.blocks[0].linear_layers[1].weight, net.blocks[0].linear_layers[1].bias,
                         net.final_layer.weight, net.final_layer.bias,
-                        net.preprocessing.weights if net.preprocessing is not None else torch.zeros(0, device=dev),
+                        net.preprocessing.weights if net.preprocessing is not None else cache[("empty", str(dev))],
                         u.unnormalized_widths, u.unnormalized_heights, u.unnormalized_derivatives]
         q0 = self._nf_model.q0
         return tensors + [q0.scale, q0.circ.float()]
@@ -341,8 +363,11 @@ class CircularCoupledRQSFlow(nn.Module):
         parameter changed."""
         ops = _ops.load()
         _ops.require_device(self._tail_bound, "spline flow parameters")
-        params = [p for p in self.parameters()] + [b for b in self.buffers()]
-        key = tuple((t.data_ptr(), t._version) for t in params)
+        bkey = tuple((b.data_ptr(), b._version) for b in self.buffers())
+        if bkey != self.__dict__.get("_bkey"):                 # masks / shifts / bounds changed (e.g. load_state_dict)
+            self.__dict__["_meta_cache"] = {}
+            self.__dict__["_bkey"] = bkey
+        key = tuple((t.data_ptr(), t._version) for t in self.parameters()) + bkey
         if key != self._packed_key:
             n = ops.spline_packed_floats(self.dim, self.n_layers, self.hidden)
             if n < 0:
