@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--evals", type=int, default=10)
     ap.add_argument("--flow", choices=("realnvp", "spline"), default="realnvp")
     ap.add_argument("--hidden", type=int, default=256)
+    ap.add_argument("--fast", action="store_true", help="AIS transitions in fast mode (bf16 W x W GEMMs) during training; "
+                                                          "evaluation always runs the fp32 parity path")
     args = ap.parse_args()
     torch.manual_seed(0)
     D = args.dim
@@ -56,7 +58,8 @@ def main():
         n = min(chunk, args.iters - done)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        hist = trainer.run(done + n, args.batch, start_iter=done)
+        with fa.fast_mode(args.fast):
+            hist = trainer.run(done + n, args.batch, start_iter=done)
         torch.cuda.synchronize()
         t_train += time.perf_counter() - t0
         done += n
