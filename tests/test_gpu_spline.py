@@ -336,3 +336,39 @@ def test_eval_info_with_the_spline_flow():
         assert k in info and math.isfinite(info[k]), k
     assert 0 < info["eval_ess_flow"] <= 1 and 0 < info["eval_ess_ais"] <= 1
     assert model.annealed_importance_sampler.p_target is False                      # toggled back (core.py:219)
+
+
+def test_plain_trainer_forward_kl_and_checkpoint_roundtrip_with_the_spline_flow(tmp_path):
+    """fab/train.py's Trainer (model.loss -> backward -> clip -> step) with the spline flow for both losses it can take
+    through the HIP tape (`fab_alpha_div`, `target_forward_kl`), and FABModel.save / load (core.py:222-251) incl. a raw
+    `_nf_model` state dict as a normflows checkpoint would be."""
+    D, L, hidden, M, B = 6, 3, 64, 3, 128
+    torch.manual_seed(0)
+    hf = fa.make_wrapped_normflow_spline(D, L, hidden, (1,), torch.tensor([5.0, math.pi, 5.0, 5.0, 5.0, 5.0])).to(DEV)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
+    for loss_type in ("fab_alpha_div", "target_forward_kl"):
+        model = fa.FABModel(hf, target, M, alpha=2.0, transition_operator=hmc, loss_type=loss_type)
+        opt = torch.optim.Adam(hf.parameters(), lr=1e-3)
+        trainer = fa.Trainer(model, opt, save_path=str(tmp_path))
+        before = [p.detach().clone() for p in hf.parameters()]
+        infos = [trainer.step(i, B) for i in range(3)]
+        assert all(math.isfinite(i["loss"]) and math.isfinite(i["grad_norm"]) for i in infos), loss_type
+        assert any(not torch.equal(a, p.detach()) for a, p in zip(before, hf.parameters())), loss_type
+    path = str(tmp_path / "model.pt")
+    model.save(path)
+    x = target.sample((64,))
+    ref = hf.log_prob(x).detach()
+    hf2 = fa.make_wrapped_normflow_spline(D, L, hidden, (1,), torch.tensor([5.0, math.pi, 5.0, 5.0, 5.0, 5.0])).to(DEV)
+    hmc2 = fa.HamiltonianMonteCarlo(M, D, hf2.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
+    model2 = fa.FABModel(hf2, target, M, alpha=2.0, transition_operator=hmc2, loss_type="fab_alpha_div")
+    assert not torch.equal(hf2.log_prob(x).detach(), ref)
+    model2.load(path, map_location=DEV)
+    assert torch.equal(hf2.log_prob(x).detach(), ref)
+    assert torch.equal(hmc2.epsilons, hmc.epsilons) and torch.equal(hmc2.common_epsilon, hmc.common_epsilon)
+    raw = {"flow": hf._nf_model.state_dict(), "trans_op": hmc.state_dict()}     # keys as normflows itself would save them
+    torch.save(raw, str(tmp_path / "raw.pt"))
+    hf3 = fa.make_wrapped_normflow_spline(D, L, hidden, (1,), torch.tensor([5.0, math.pi, 5.0, 5.0, 5.0, 5.0])).to(DEV)
+    hmc3 = fa.HamiltonianMonteCarlo(M, D, hf3.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
+    fa.FABModel(hf3, target, M, alpha=2.0, transition_operator=hmc3, loss_type="fab_alpha_div").load(str(tmp_path / "raw.pt"), DEV)
+    assert torch.equal(hf3.log_prob(x).detach(), ref)
