@@ -332,11 +332,14 @@ __device__ __forceinline__ void sp_tape_rows(float* __restrict__ dst, int width,
 }
 
 // h0 = A0 W0 + b0 (kept raw in H0), t = relu(h0) Wa + ba (kept raw in T), h1 = h0 + relu(t) Wb + bb -> X1
+// `bits` (nullable, the one-launch kernel): the ReLU decisions of h0 and t as one 64-bit ballot per (wave, tile, r) -
+// 2 * 4 * NTWM * 4 words per 16-chain tile - for the reverse sweep (which then needs no activations at all).
 // `act` (nullable): relu(h0) | relu(t) of the tile's rows are kept ([B][2 Wp], rows row0..) for k_spline_net_bwd, which
 // then only needs their signs (the ReLU decisions) and skips this recomputation.
 template <int NTWM, bool FAST = false>
 __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds& l, const float* __restrict__ Lp, float* lds,
-                                              const Tid& t, float* __restrict__ act = nullptr, long row0 = 0, long B = 0) {
+                                              const Tid& t, float* __restrict__ act = nullptr, long row0 = 0, long B = 0,
+                                              unsigned long long* __restrict__ bits = nullptr) {
     constexpr int DW = depth_w<NTWM>();
     float* A0 = lds + l.o_A0; float* H0 = lds + l.o_H0; float* T = lds + l.o_T;
     float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2;
@@ -351,6 +354,10 @@ __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds&
             X2[o] = acc[i][r] > 0.f ? acc[i][r] : 0.f;
             if (act && row0 + 4 * t.q + r < B)
                 act[(row0 + 4 * t.q + r) * (2 * f.Wp) + 16 * (t.wave + 4 * i) + t.n] = X2[o];
+            if (bits) {                                  // ReLU decisions of (rows 4q + r, tile wave + 4 i): one word per wave
+                const unsigned long long m = __ballot(acc[i][r] > 0.f);
+                if (t.lane == 0) bits[((0 * NWAVE + t.wave) * NTWM + i) * 4 + r] = m;
+            }
         }
     __syncthreads();
     if constexpr (FAST) sp_gemm_bf16<NTWM, true>(f, X2, l.WS, Lp, 0, Lp + f.o_ba, t, acc);
@@ -364,6 +371,10 @@ __device__ __forceinline__ void sp_net_hidden(const SplineDims& f, const NetLds&
             X1[o] = acc[i][r] > 0.f ? acc[i][r] : 0.f;
             if (act && row0 + 4 * t.q + r < B)
                 act[(row0 + 4 * t.q + r) * (2 * f.Wp) + f.Wp + 16 * (t.wave + 4 * i) + t.n] = X1[o];
+            if (bits) {
+                const unsigned long long m = __ballot(acc[i][r] > 0.f);
+                if (t.lane == 0) bits[((1 * NWAVE + t.wave) * NTWM + i) * 4 + r] = m;
+            }
         }
     __syncthreads();
     if constexpr (FAST) sp_gemm_bf16<NTWM, true>(f, X1, l.WS, Lp, 1, Lp + f.o_bb, t, acc);
@@ -891,7 +902,7 @@ template <int NTWM, bool GRAD, bool FAST>
 __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const NetLds& l, const float* __restrict__ packed,
                                                     const float* __restrict__ x, float* __restrict__ log_q,
                                                     float* __restrict__ grad_x, long B, float* __restrict__ Zsave,
-                                                    float* __restrict__ Psave, float* __restrict__ actsave, float* lds,
+                                                    float* __restrict__ Psave, unsigned long long* __restrict__ bitsave, float* lds,
                                                     long long* tlp = nullptr) {
     Tid t;
 #define SP_TL(idx) do { if (tlp && blockIdx.x == 0 && threadIdx.x == 0) tlp[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -902,7 +913,7 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
     float* ZT = lds + l.o_ZT; float* GT = lds + l.o_GT;
     const float isq = 1.f / sqrtf((float)f.W);
     const int per = 4 * NTWM * f.KBW * 256;
-    const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP, as = (size_t)B * 2 * f.Wp;
+    const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     // x <- wrap(x - pre-shift of the top layer)   (PeriodicWrap.inverse / the last PeriodicShift.inverse)
     {
         const float* mt = packed + (size_t)(f.L - 1) * f.layer_stride + f.o_meta;
@@ -933,7 +944,8 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
         sp_identity_from_tile(f, Lp, ZT, A0, l.AS, t);
         __syncthreads();
         if (tl) SP_TL(1);
-        sp_net_hidden<NTWM, FAST>(f, l, Lp, lds, t, GRAD ? actsave + (size_t)layer * as : nullptr, row0, B);
+        sp_net_hidden<NTWM, FAST>(f, l, Lp, lds, t, nullptr, row0, B,
+                                  GRAD ? bitsave + ((size_t)layer * gridDim.x + blockIdx.x) * (2 * NWAVE * NTWM * 4) : nullptr);
         if (tl) SP_TL(2);
         for (int c = 0; c < f.NCH; ++c) {
             f32x4 acc[NTWM];
@@ -998,8 +1010,17 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
         }
         // conditioner output (-> dP in place below) and the ReLU decisions of the forward sweep
         sp_tile_load4(PT, l.PS, Psave + (size_t)layer * ps, f.NFP, f.NFP, row0, B, t);
-        sp_tile_load4(H0, l.WS, actsave + (size_t)layer * as, 2 * f.Wp, f.Wp, row0, B, t);
-        sp_tile_load4(T, l.WS, actsave + (size_t)layer * as + f.Wp, 2 * f.Wp, f.Wp, row0, B, t);
+        unsigned long long m0[NTWM][4], m1[NTWM][4];                       // this thread's ReLU decisions (wave-uniform words)
+        {
+            const unsigned long long* bw = bitsave + ((size_t)layer * gridDim.x + blockIdx.x) * (2 * NWAVE * NTWM * 4);
+#pragma unroll
+            for (int i = 0; i < NTWM; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    m0[i][r] = bw[((0 * NWAVE + t.wave) * NTWM + i) * 4 + r];
+                    m1[i][r] = bw[((1 * NWAVE + t.wave) * NTWM + i) * 4 + r];
+                }
+        }
         __syncthreads();
         if (tl) SP_TL(9);
         for (int j = t.c; j < f.D; j += 16) {
@@ -1047,7 +1068,7 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
-                X2[o] = T[o] > 0.f ? acc[i][r] : 0.f;
+                X2[o] = ((m1[i][r] >> t.lane) & 1ull) ? acc[i][r] : 0.f;
             }
         __syncthreads();
         if constexpr (FAST) sp_gemm_bf16<NTWM, false>(f, X2, l.WS, Lp, 3 + 2 * f.NCH, nullptr, t, acc);
@@ -1058,7 +1079,7 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int o = (4 * t.q + r) * l.WS + 16 * (t.wave + 4 * i) + t.n;
-                T[o] = X1[o] + (H0[o] > 0.f ? acc[i][r] : 0.f);
+                T[o] = X1[o] + (((m0[i][r] >> t.lane) & 1ull) ? acc[i][r] : 0.f);
             }
         __syncthreads();
         if (tl) SP_TL(12);
@@ -1093,9 +1114,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLd
                                                              const float* __restrict__ x, float* __restrict__ log_q,
                                                              float* __restrict__ grad_x, long B,
                                                              float* __restrict__ Zsave, float* __restrict__ Psave,
-                                                             float* __restrict__ actsave, long long* tlp) {
+                                                             unsigned long long* __restrict__ bitsave, long long* tlp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    spline_logprob_body<NTWM, GRAD, false>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds, tlp);
+    spline_logprob_body<NTWM, GRAD, false>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, bitsave, lds, tlp);
 }
 // fast mode (fabhip_set_fast_mode): the conditioner's Wp x Wp GEMMs on the bf16 matrix cores; gradient evaluations only
 template <int NTWM>
@@ -1103,9 +1124,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_fast(SplineDims f, 
                                                                   const float* __restrict__ x, float* __restrict__ log_q,
                                                                   float* __restrict__ grad_x, long B,
                                                                   float* __restrict__ Zsave, float* __restrict__ Psave,
-                                                                  float* __restrict__ actsave, long long* tlp) {
+                                                                  unsigned long long* __restrict__ bitsave, long long* tlp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    spline_logprob_body<NTWM, true, true>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, actsave, lds, tlp);
+    spline_logprob_body<NTWM, true, true>(f, l, packed, x, log_q, grad_x, B, Zsave, Psave, bitsave, lds, tlp);
 }
 
 // dev-only stage timeline (FABHIP_TIMELINE=1): s_memtime stamps of workgroup 0 in layer 1 of k_spline_logprob
@@ -1119,22 +1140,22 @@ static long long* sp_timeline(hipStream_t st) {
 
 template <int NTWM>
 static int launch_logprob(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
-                          float* Zsave, float* Psave, float* actsave, hipStream_t st) {
+                          float* Zsave, float* Psave, unsigned long long* bitsave, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
     const NetLds l = make_net_lds(f, grad_x != nullptr, true);
     const size_t bytes = (size_t)l.total * 4;
     if (grad_x && fast_mode()) {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob_fast<NTWM>, bytes));
         hipLaunchKernelGGL((k_spline_logprob_fast<NTWM>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, actsave, sp_timeline(st));
+                           Psave, bitsave, sp_timeline(st));
     } else if (grad_x) {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, true>, bytes));
         hipLaunchKernelGGL((k_spline_logprob<NTWM, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, actsave, sp_timeline(st));
+                           Psave, bitsave, sp_timeline(st));
     } else {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, false>, bytes));
         hipLaunchKernelGGL((k_spline_logprob<NTWM, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, actsave, sp_timeline(st));
+                           Psave, bitsave, sp_timeline(st));
     }
     return check_launch();
 }
@@ -1208,7 +1229,7 @@ size_t fabhip_spline_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidd
     size_t s = sp_al((size_t)(f.L + 1) * B * f.D * 4);                 // layer input states
     s += sp_al((size_t)(with_grad ? f.L : 1) * B * f.NFP * 4);          // conditioner outputs (kept per layer for the reverse sweep)
     if (with_grad) s += sp_al((size_t)B * f.NFP * 4) + 2 * sp_al((size_t)B * f.D * 4);
-    if (with_grad) s += sp_al((size_t)f.L * B * 2 * f.Wp * 4);          // relu(h0) | relu(t) per layer (ReLU decisions)
+    if (with_grad) s += sp_al((size_t)f.L * ceil_div((int)B, ROWS) * (2 * NWAVE * f.NTWM * 4) * 8);   // ReLU decision words
     return s + 256;
 }
 
@@ -1230,14 +1251,13 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
         Ga = (float*)ws; ws += sp_al((size_t)B * f.D * 4);
         Gb = (float*)ws; ws += sp_al((size_t)B * f.D * 4);
     }
-    float* act = (grad_x && !tape) ? (float*)ws : nullptr;               // (the tape path recomputes: it needs h1 too)
-    const size_t as = (size_t)B * 2 * f.Wp;
+    unsigned long long* bits = grad_x ? (unsigned long long*)ws : nullptr;   // ReLU decisions (one-launch kernel)
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
     if (!tape && !getenv("FABHIP_SPLINE_STAGED")) {           // one launch (the staged kernels below: tape, debugging)
-        if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, act, (hipStream_t)stream);
-        if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, act, (hipStream_t)stream);
-        if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, act, (hipStream_t)stream);
+        if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
+        if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
+        if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
         return FABHIP_ENOTSUP;
     }
     const SplineTape tp = make_spline_tape(f, (long)B, tape);
@@ -1246,8 +1266,7 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
                        dim3(256), 0, st, f, pk, x, Z + (size_t)f.L * zs, log_q, (long)B);
     for (int l = f.L - 1; l >= 0; --l) {
         float* Pl = P + (grad_x ? (size_t)l * ps : 0);
-        FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, Pl, nullptr, nullptr, (long)B, st, SplineTape{},
-                    act ? act + (size_t)l * as : nullptr));
+        FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, Pl, nullptr, nullptr, (long)B, st));
         hipLaunchKernelGGL(k_spline_apply<0>, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs, Pl, Z + (size_t)l * zs,
                            log_q, 1.f, (long)B);
     }
@@ -1260,8 +1279,7 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
             float* dUl = tape ? tape + (size_t)l * tp.layer_stride + tp.o_dU : nullptr;
             hipLaunchKernelGGL(k_spline_apply_bwd, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs,
                                P + (size_t)l * ps, gin, out, dPl, (long)B, dUl);
-            FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, dPl, out, (long)B, st, tp,
-                        act ? act + (size_t)l * as : nullptr));
+            FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, dPl, out, (long)B, st, tp));
             gin = out;
         }
     }
