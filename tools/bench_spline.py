@@ -44,7 +44,7 @@ out["sample_ms"] = 1e3 * timeit(lambda: flow.sample_and_log_prob((B,)), 50)
 t = timeit(lambda: ais.sample_and_log_weights(B), int(os.environ.get("N", 5)), warm=2)
 out["ais_call_ms"] = 1e3 * t
 out["ais_samples_per_s"] = B / t
-out["n_flow_grad_evals_per_call"] = M * (LF + 1) + 1
+out["n_flow_grad_evals_per_call"] = M * LF + 1            # one per leapfrog + the chain initialisation
 with fa.fast_mode():                                   # bf16 conditioner GEMMs (not the parity path)
     out["fast_log_prob_and_grad_ms"] = 1e3 * timeit(lambda: flow.log_prob_and_grad(x), 50)
     t = timeit(lambda: ais.sample_and_log_weights(B), int(os.environ.get("N", 5)), warm=2)
