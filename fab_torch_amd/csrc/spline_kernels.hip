@@ -322,6 +322,17 @@ __device__ __forceinline__ void sp_tile_load4(float* dst, int ldd, const float* 
     }
 }
 
+// the reverse: LDS tile [16][lds_src] -> rows row0 .. of a row-major [B][ldd] matrix, float4 per lane
+__device__ __forceinline__ void sp_tile_store4(float* __restrict__ dst, long ldd, const float* src, int lds_src, int width,
+                                               long row0, long B, const Tid& t) {
+    for (int r = t.wave; r < ROWS; r += NWAVE) {
+        const long g = row0 + r;
+        if (g < B)
+            for (int c4 = t.lane; 4 * c4 < width; c4 += 64)
+                *reinterpret_cast<float4*>(dst + g * ldd + 4 * c4) = *reinterpret_cast<const float4*>(src + r * lds_src + 4 * c4);
+    }
+}
+
 // tape: rows of an LDS tile [16][ld] (first `width` columns) -> dst [B][width]
 __device__ __forceinline__ void sp_tape_rows(float* __restrict__ dst, int width, const float* src, int ld, long row0, long B,
                                              const Tid& t) {
@@ -958,10 +969,10 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
                 for (int r = 0; r < 4; ++r) {
                     const int col = c * f.Wp + 16 * (t.wave + 4 * i) + t.n;
                     PT[(4 * t.q + r) * l.PS + col] = acc[i][r];
-                    if (GRAD && row0 + 4 * t.q + r < B) Psave[(size_t)layer * ps + (row0 + 4 * t.q + r) * f.NFP + col] = acc[i][r];
                 }
         }
         __syncthreads();
+        if (GRAD) sp_tile_store4(Psave + (size_t)layer * ps, f.NFP, PT, l.PS, f.NFP, row0, B, t);   // for the reverse sweep
         if (tl) SP_TL(3);
         const float* mn = layer > 0 ? packed + (size_t)(layer - 1) * f.layer_stride + f.o_meta : nullptr;
         for (int j = t.c; j < f.D; j += 16) {
