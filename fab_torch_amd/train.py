@@ -12,11 +12,25 @@ from .core import FABModel
 from .optim import FlatAdam
 
 
+def _log(logger, info: Dict):
+    """`logger` is the reference's `Logger` (fab/utils/logging.py:12-30: `.write(dict)`, `.close()`) or a plain callable."""
+    if logger is None:
+        return
+    write = getattr(logger, "write", None)
+    (write if callable(write) else logger)(info)
+
+
+def _close(logger):
+    close = getattr(logger, "close", None)
+    if callable(close):
+        close()                                            # train_with_prioritised_buffer.py:255, train.py:135
+
+
 class PrioritisedBufferTrainer:
     def __init__(self, model: FABModel, optimizer: torch.optim.Optimizer, buffer: PrioritisedReplayBuffer,
                  alpha: float, n_batches_buffer_sampling: int = 2, optim_schedular=None,
                  max_gradient_norm: Optional[float] = 5.0, w_adjust_max_clip: Optional[float] = 10.0,
-                 w_adjust_in_buffer_after_update: bool = False, logger: Optional[Callable[[Dict], None]] = None,
+                 w_adjust_in_buffer_after_update: bool = False, logger=None,
                  save_path: str = ""):
         self.model, self.optimizer, self.buffer, self.alpha = model, optimizer, buffer, alpha
         self.save_dir = save_path
@@ -140,15 +154,14 @@ class PrioritisedBufferTrainer:
         for i in range(start_iter + 1, n_iterations + 1):
             info = self.step(i, batch_size)
             self.history.append(info)
-            if self.logger:
-                self.logger(info)
+            _log(self.logger, info)
             if i in eval_iter:
                 ev = self.perform_eval(i, eval_batch_size, batch_size)
                 self.history.append(ev)
-                if self.logger:
-                    self.logger(ev)
+                _log(self.logger, ev)
             if i in ckpt_iter:
                 self.save_checkpoint(i)
+        _close(self.logger)
         return self.history
 
 
@@ -159,7 +172,7 @@ class Trainer:
     Plotting / tqdm / time limits are left to the caller."""
 
     def __init__(self, model: FABModel, optimizer: torch.optim.Optimizer, optim_schedular=None,
-                 logger: Optional[Callable[[Dict], None]] = None, max_gradient_norm: Optional[float] = 5.0,
+                 logger=None, max_gradient_norm: Optional[float] = 5.0,
                  save_path: str = ""):
         self.model, self.optimizer, self.optim_schedular, self.logger = model, optimizer, optim_schedular, logger
         self.max_gradient_norm = max_gradient_norm if max_gradient_norm else float("inf")
@@ -240,8 +253,8 @@ class Trainer:
             if i in eval_iter:
                 info.update(self.model.get_eval_info(outer_batch_size=eval_batch_size, inner_batch_size=batch_size))
             self.history.append(info)
-            if self.logger:
-                self.logger(info)
+            _log(self.logger, info)
             if i in ckpt_iter:
                 self.save_checkpoint(i)
+        _close(self.logger)
         return self.history

@@ -123,3 +123,25 @@ def test_gmm_eval_helpers_match_reference_golden():
     assert abs(info["bias_normed"] - float(g["bias_normed"])) < 1e-5
     assert abs(info["bias_no_correction"] - float(g["bias_no_correction"])) < 1e-5
     assert abs(float(effective_sample_size_over_p(0.5 * log_w)) - float(g["ess_over_p"])) < 1e-6
+
+
+def test_trainers_accept_the_reference_logger_objects_and_plain_callables():
+    """fab/utils/logging.py:12-30: the reference's trainers call `logger.write(info)` / `logger.close()`; a plain callable
+    (this repo's own convention) keeps working."""
+    from fab_torch_amd.train import _log, _close
+
+    class ListLogger:                                      # the reference's default logger, reduced to its interface
+        def __init__(self):
+            self.history, self.closed = [], False
+
+        def write(self, data):
+            self.history.append(data)
+
+        def close(self):
+            self.closed = True
+    lg = ListLogger()
+    _log(lg, {"loss": 1.0}); _close(lg)
+    assert lg.history == [{"loss": 1.0}] and lg.closed
+    seen = []
+    _log(seen.append, {"loss": 2.0}); _close(seen.append); _log(None, {}); _close(None)
+    assert seen == [{"loss": 2.0}]
