@@ -20,6 +20,29 @@ def _log(logger, info: Dict):
     (write if callable(write) else logger)(info)
 
 
+def _make_and_save_plots(trainer, i: int, save: bool):
+    """train.py:47-54 / train_with_prioritised_buffer.py:70-77: `plot(model)` returns figures; saved under plots/ or
+    shown.  (Plotting itself is the caller's code - this repo ships no plotter.)"""
+    import os
+    figures = trainer.plot(trainer.model)
+    for j, figure in enumerate(figures):
+        if save:
+            os.makedirs(os.path.join(trainer.save_dir, "plots"), exist_ok=True)
+            figure.savefig(os.path.join(trainer.save_dir, "plots", f"{j}_iter_{i}.png"))
+        close = getattr(figure, "close", None)
+        if callable(close):
+            close()
+
+
+def _time_is_up(tlimit, start_time, max_it_time) -> Optional[float]:
+    """train.py:121-131: hours past if the next iteration would cross the limit, else None."""
+    if tlimit is None:
+        return None
+    from time import time
+    past = (time() - start_time) / 3600
+    return past if past + max_it_time / 3600 > tlimit else None
+
+
 def _close(logger):
     close = getattr(logger, "close", None)
     if callable(close):
@@ -28,11 +51,12 @@ def _close(logger):
 
 class PrioritisedBufferTrainer:
     def __init__(self, model: FABModel, optimizer: torch.optim.Optimizer, buffer: PrioritisedReplayBuffer,
-                 alpha: float, n_batches_buffer_sampling: int = 2, optim_schedular=None,
+                 alpha: float, n_batches_buffer_sampling: int = 2, optim_schedular=None, logger=None, plot=None,
                  max_gradient_norm: Optional[float] = 5.0, w_adjust_max_clip: Optional[float] = 10.0,
-                 w_adjust_in_buffer_after_update: bool = False, logger=None,
-                 save_path: str = ""):
+                 w_adjust_in_buffer_after_update: bool = False, save_path: str = ""):
+        # (argument order of train_with_prioritised_buffer.py:23-36)
         self.model, self.optimizer, self.buffer, self.alpha = model, optimizer, buffer, alpha
+        self.plot = plot
         self.save_dir = save_path
         self.model.annealed_importance_sampler.p_target = False          # AIS targets p^alpha q^(1-alpha)
         self.model.annealed_importance_sampler.transition_operator.p_target = False
@@ -143,15 +167,26 @@ class PrioritisedBufferTrainer:
         return out
 
     def run(self, n_iterations: int, batch_size: int, eval_batch_size: Optional[int] = None,
-            n_eval: Optional[int] = None, n_checkpoints: Optional[int] = None, start_iter: int = 0) -> List[Dict]:
+            n_eval: Optional[int] = None, n_plot: Optional[int] = None, n_checkpoints: Optional[int] = None,
+            save: bool = True, tlimit: Optional[float] = None, start_time: Optional[float] = None,
+            start_iter: int = 0) -> List[Dict]:
+        """train_with_prioritised_buffer.py:106-255, same arguments (`tlimit` in hours: stop + checkpoint before the next
+        iteration would cross it; `n_plot` / `save` drive the caller's `plot(model)`)."""
         import numpy as np
+        from time import time
         if start_iter >= n_iterations:
             raise Exception("Not running training as start_iter >= total training iterations")
         eval_iter = list(np.linspace(1, n_iterations, n_eval, dtype="int")) if n_eval is not None else []
+        plot_iter = list(np.linspace(1, n_iterations, n_plot, dtype="int")) if n_plot is not None and self.plot else []
         ckpt_iter = list(np.linspace(1, n_iterations, n_checkpoints, dtype="int")) if n_checkpoints else []
         if n_eval is not None:
             assert eval_batch_size is not None
+        if tlimit is not None:
+            assert n_checkpoints is not None, "Time limited specified but not checkpoints are being saved."
+        start_time = time()                                 # (the reference overwrites a supplied start_time too, :129-130)
+        max_it_time = 0.0
         for i in range(start_iter + 1, n_iterations + 1):
+            it_start = time()
             info = self.step(i, batch_size)
             self.history.append(info)
             _log(self.logger, info)
@@ -159,8 +194,19 @@ class PrioritisedBufferTrainer:
                 ev = self.perform_eval(i, eval_batch_size, batch_size)
                 self.history.append(ev)
                 _log(self.logger, ev)
+            if i in plot_iter:
+                _make_and_save_plots(self, i, save)
             if i in ckpt_iter:
                 self.save_checkpoint(i)
+            max_it_time = max(max_it_time, time() - it_start)
+            past = _time_is_up(tlimit, start_time, max_it_time)
+            if past is not None:
+                if i not in ckpt_iter:
+                    self.save_checkpoint(i)
+                _close(self.logger)
+                print(f"\nEnding training at iteration {i}, after training for {past:.2f} hours as timelimit "
+                      f"{tlimit:.2f} hours has been reached.\n")
+                return self.history
         _close(self.logger)
         return self.history
 
@@ -172,9 +218,10 @@ class Trainer:
     Plotting / tqdm / time limits are left to the caller."""
 
     def __init__(self, model: FABModel, optimizer: torch.optim.Optimizer, optim_schedular=None,
-                 logger=None, max_gradient_norm: Optional[float] = 5.0,
+                 logger=None, plot=None, max_gradient_norm: Optional[float] = 5.0,
                  save_path: str = ""):
         self.model, self.optimizer, self.optim_schedular, self.logger = model, optimizer, optim_schedular, logger
+        self.plot = plot
         self.max_gradient_norm = max_gradient_norm if max_gradient_norm else float("inf")
         self.save_dir = save_path
         self.history: List[Dict] = []
@@ -240,21 +287,42 @@ class Trainer:
         return info
 
     def run(self, n_iterations: int, batch_size: int, eval_batch_size: Optional[int] = None,
-            n_eval: Optional[int] = None, n_checkpoints: Optional[int] = None, start_iter: int = 0) -> List[Dict]:
+            n_eval: Optional[int] = None, n_plot: Optional[int] = None, n_checkpoints: Optional[int] = None,
+            save: bool = True, tlimit: Optional[float] = None, start_time: Optional[float] = None,
+            start_iter: int = 0) -> List[Dict]:
+        """fab/train.py:63-136, same arguments."""
         import numpy as np
+        from time import time
         if start_iter >= n_iterations:
             raise Exception("Not running training as start_iter >= total training iterations")
         eval_iter = list(np.linspace(1, n_iterations, n_eval, dtype="int")) if n_eval is not None else []
+        plot_iter = list(np.linspace(1, n_iterations, n_plot, dtype="int")) if n_plot is not None and self.plot else []
         ckpt_iter = list(np.linspace(1, n_iterations, n_checkpoints, dtype="int")) if n_checkpoints else []
         if n_eval is not None:
             assert eval_batch_size is not None
+        if tlimit is not None:
+            assert n_checkpoints is not None, "Time limited specified but not checkpoints are being saved."
+        start_time = time()
+        max_it_time = 0.0
         for i in range(start_iter + 1, n_iterations + 1):
+            it_start = time()
             info = self.step(i, batch_size)
             if i in eval_iter:
                 info.update(self.model.get_eval_info(outer_batch_size=eval_batch_size, inner_batch_size=batch_size))
             self.history.append(info)
             _log(self.logger, info)
+            if i in plot_iter:
+                _make_and_save_plots(self, i, save)
             if i in ckpt_iter:
                 self.save_checkpoint(i)
+            max_it_time = max(max_it_time, time() - it_start)
+            past = _time_is_up(tlimit, start_time, max_it_time)
+            if past is not None:
+                if i not in ckpt_iter:
+                    self.save_checkpoint(i)
+                _close(self.logger)
+                print(f"\nEnding training at iteration {i}, after training for {past:.2f} hours as timelimit "
+                      f"{tlimit:.2f} hours has been reached.\n")
+                return self.history
         _close(self.logger)
         return self.history

@@ -101,3 +101,52 @@ def test_fused_fab_alpha_div_step_equals_the_autograd_step():
         assert torch.equal(va, vb), k
     # like core.py:123-128, the sampler is left on the p target (evaluation) after the loss
     assert model_b.annealed_importance_sampler.p_target is model_a.annealed_importance_sampler.p_target is True
+
+
+@pytest.mark.parametrize("kind", ["buffer", "plain"])
+def test_run_takes_the_reference_arguments_time_limit_plots_logger(kind, tmp_path):
+    """`run(n_iterations, batch_size, eval_batch_size, n_eval, n_plot, n_checkpoints, save, tlimit, start_time,
+    start_iter)` as in fab/train.py:63-136 / train_with_prioritised_buffer.py:106-255: the caller's `plot(model)` is
+    driven at the plot iterations, a `Logger` object gets write() / close(), and a time limit stops the run with a
+    checkpoint of the iteration it stopped at."""
+    import os
+
+    class Fig:
+        saved = []
+
+        def savefig(self, path):
+            Fig.saved.append(os.path.basename(path))
+
+    class ListLogger:
+        def __init__(self):
+            self.rows, self.closed = [], False
+
+        def write(self, d):
+            self.rows.append(d)
+
+        def close(self):
+            self.closed = True
+    flow, hmc, model, opt = make(0, "torch_adam")
+    lg, calls = ListLogger(), []
+
+    def plot(m):
+        calls.append(m)
+        return [Fig(), Fig()]
+    if kind == "buffer":
+        trainer = fa.PrioritisedBufferTrainer(model, opt, make_buffer(model), 2.0, 2, None, lg, plot, 100.0, 10.0, False,
+                                              str(tmp_path))          # positional, in the reference's order
+    else:
+        trainer = fa.Trainer(model, opt, None, lg, plot, 100.0, str(tmp_path))
+    trainer.run(n_iterations=4, batch_size=B, eval_batch_size=2 * B, n_eval=2, n_plot=2, n_checkpoints=2, save=True,
+                tlimit=None, start_time=None, start_iter=0)
+    assert len(calls) == 2 and calls[0] is model and sorted(set(Fig.saved)) == ["0_iter_1.png", "0_iter_4.png", "1_iter_1.png",
+                                                                               "1_iter_4.png"]
+    assert lg.closed and len(lg.rows) >= 4 and any("eval_ess_ais" in r or "eval_ess_ais_p_target" in r for r in lg.rows)
+    assert sorted(os.listdir(tmp_path / "model_checkpoints")) == ["iter_1", "iter_4"]
+    # a time limit of ~0 hours: one iteration, then a checkpoint of that iteration and a closed logger
+    lg2 = ListLogger()
+    trainer.logger = lg2
+    hist_before = len(trainer.history)
+    trainer.run(n_iterations=50, batch_size=B, n_checkpoints=2, tlimit=1e-9, start_iter=10)
+    assert lg2.closed and len(trainer.history) == hist_before + 1
+    assert "iter_11" in os.listdir(tmp_path / "model_checkpoints")
