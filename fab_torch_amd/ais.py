@@ -112,6 +112,15 @@ class AnnealedImportanceSampler:
         point = Point(x, lq, lp, gq if hmc else None, gp if hmc else None)
         return point, log_w, n_valid, stats, base_x, base_lw
 
+    def perform_transition(self, x_new: Point, log_w: torch.Tensor, j: int):
+        """ais.py:90-105: one MCMC transition towards the j-th intermediate distribution + the log-weight increment
+        (skipped when beta does not change).  The fused call does the same for all j inside `fabhip_ais_run`."""
+        beta, beta_next = float(self.B_space[j]), float(self.B_space[j + 1])
+        log_w = log_w.detach().clone().contiguous()
+        x_new = self.transition_operator.transition(x_new, j, beta, log_w=log_w if beta_next != beta else None,
+                                                    beta_next=beta_next)
+        return x_new, log_w
+
     @property
     def is_native(self) -> bool:
         return isinstance(self.base_distribution, RealNVP) and \

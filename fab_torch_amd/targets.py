@@ -122,6 +122,32 @@ class ManyWellEnergy(_NativeTarget):
         x[:, 1::2] = torch.randn(n, self.n_wells, device=dev)
         return x
 
+    def _well(self):
+        w = self.__dict__.get("_well2d")
+        if w is None:
+            w = self.__dict__["_well2d"] = ManyWellEnergy(2, a=self._a, b=self._b, c=self._c)
+        return w
+
+    def log_prob_2D(self, x):
+        """many_well.py:92-94: the double-well density of one coordinate pair (plotting helper), HIP like log_prob."""
+        return self._well().log_prob(x)
+
+    def energy(self, x, temperature=None):
+        """double_well.py:19-23 (2-D, shape [..., 1])."""
+        assert x.shape[-1] == 2, "`x` does not match `dim`"
+        return -self._well().log_prob(x)[..., None] / (1.0 if temperature is None else temperature)
+
+    def force(self, x, temperature=None):
+        """double_well.py:25-28: -d energy / dx."""
+        assert x.shape[-1] == 2, "`x` does not match `dim`"
+        _, g = self._well().log_prob_and_grad(x.detach().contiguous().float())
+        return g / (1.0 if temperature is None else temperature)
+
+    def sample_first_dimension(self, shape):
+        """double_well.py:60-82: exact samples of the quartic coordinate of one well (rejection sampling)."""
+        assert len(shape) == 1
+        return self._well().sample(shape)[:, 0]
+
     def get_modes_test_set_iterator(self, batch_size: int):
         """Points placed at the modes (x_even = +-1.7, x_odd = 0): all 2^(dim/2) of them below 40 dims, 10^4 random
         ones above (many_well.py:24-36, 68-79)."""

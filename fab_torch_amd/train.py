@@ -151,6 +151,9 @@ class PrioritisedBufferTrainer:
         if self.optim_schedular:
             torch.save(self.optim_schedular.state_dict(), os.path.join(ckpt_dir, "scheduler.pt"))
 
+    def make_and_save_plots(self, i: int, save: bool):
+        _make_and_save_plots(self, i, save)
+
     def perform_eval(self, i: int, eval_batch_size: int, batch_size: int) -> Dict:
         """train_with_prioritised_buffer.py:79-101: frozen step sizes; p as the AIS target, then the practical target."""
         ais = self.model.annealed_importance_sampler
@@ -236,6 +239,16 @@ class Trainer:
         if self.optim_schedular:
             torch.save(self.optim_schedular.state_dict(),
                        os.path.join(self.save_dir, "model_checkpoints", "scheduler.pt"))
+
+    def make_and_save_plots(self, i: int, save: bool):
+        _make_and_save_plots(self, i, save)
+
+    def perform_eval(self, i: int, eval_batch_size: int, batch_size: int) -> Dict:
+        """fab/train.py:56-60."""
+        ev = self.model.get_eval_info(outer_batch_size=eval_batch_size, inner_batch_size=batch_size)
+        ev.update(step=i)
+        _log(self.logger, ev)
+        return ev
 
     def step(self, i: int, batch_size: int) -> Dict:
         self.optimizer.zero_grad()

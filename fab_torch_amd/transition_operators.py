@@ -97,6 +97,17 @@ class TransitionOperator(torch.nn.Module):
         return (_owner_or_none(self.base_log_prob, RealNVP) is not None
                 and _owner_or_none(self.target_log_prob, _NativeTarget) is not None)
 
+    def intermediate_target_log_prob(self, point: Point, beta: float) -> torch.Tensor:
+        """transition_operators/base.py:37-43 (fabhip_anneal_log_prob: the coefficients of base.py:76-97)."""
+        a = float(self.alpha if self.alpha is not None else 0.0)
+        return _ops.load().anneal_log_prob(point.log_q.contiguous(), point.log_p.contiguous(), float(beta), a,
+                                           bool(self.p_target))
+
+    def grad_intermediate_target_log_prob(self, point: Point, beta: float) -> torch.Tensor:
+        """transition_operators/base.py:45-54, incl. the reference's 2 beta on grad log p (base.py:116)."""
+        c_q, c_p, g_q, g_p = anneal_coefs(beta, self.alpha, self.p_target)
+        return g_q * point.grad_log_q + g_p * point.grad_log_p
+
     def create_new_point(self, x: torch.Tensor) -> Point:
         if self.is_native:
             return create_point(x, self.flow, self.target, with_grad=self.uses_grad_info)
@@ -218,6 +229,22 @@ class HamiltonianMonteCarlo(TransitionOperator):
             float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance)
         return point
 
+
+    def save_model(self, save_path, epoch=None):
+        """hmc.py:204-214 (state dict under HMC_model[_epoch{n}] + a text description)."""
+        import os
+        tag = "" if epoch is None else f"_epoch{epoch}"
+        with open(os.path.join(str(save_path), f"HMC_model_info{tag}.txt"), "w") as g:
+            g.write(str(dict(n_distributions=self.n_ais_intermediate_distributions, n_outer=self.n_outer, L=self.L,
+                             dim=self.dim, target_p_accept=self.target_p_accept, tune_period=self.tune_period)))
+        torch.save(self.state_dict(), os.path.join(str(save_path), f"HMC_model{tag}"))
+
+    def load_model(self, save_path, epoch=None, device="cpu"):
+        """hmc.py:216-222."""
+        import os
+        tag = "" if epoch is None else f"_epoch{epoch}"
+        self.load_state_dict(torch.load(os.path.join(str(save_path), f"HMC_model{tag}"), map_location=torch.device(device)))
+        print("loaded HMC model")
 
     def _transition_generic(self, point, i, beta, log_w, beta_next, noise_p, noise_e, p_accept, avg_distance):
         """hmc.py:129-160 for arbitrary plug-ins: the L x n_outer density evaluations are the plug-ins' own code, the

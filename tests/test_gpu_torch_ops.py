@@ -198,3 +198,53 @@ def test_fused_ais_call_is_capturable_in_a_hip_graph():
     assert not torch.equal(eps_before, hmc.epsilons)                              # step sizes keep adapting on the device
     ref = fa.effective_sample_size(log_w)
     assert 0 < float(ref) <= 1
+
+
+def test_reference_helper_methods_of_the_operators_sampler_and_target(tmp_path):
+    """Small public methods of the reference a caller may use next to the hot path: TransitionOperator.
+    (grad_)intermediate_target_log_prob (transition_operators/base.py:37-54), AnnealedImportanceSampler.perform_transition
+    (ais.py:90-105), HamiltonianMonteCarlo.save_model / load_model (hmc.py:204-222), ManyWellEnergy.log_prob_2D / energy /
+    force / sample_first_dimension (many_well.py:92-94, double_well.py:19-28,60-82)."""
+    D, M, B = 6, 3, 64
+    torch.manual_seed(0)
+    flow = fa.RealNVP(D, 2, 6).to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
+    ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, False, 2.0, M)
+    x, _ = flow.sample_and_log_prob((B,))
+    pt = hmc.create_new_point(x)
+    beta, alpha = 0.3, 2.0
+    ref = ((1 - beta) + beta * (1 - alpha)) * pt.log_q + beta * alpha * pt.log_p
+    assert torch.allclose(hmc.intermediate_target_log_prob(pt, beta), ref, rtol=1e-5, atol=1e-5)
+    gref = ((1 - beta) + beta * (1 - alpha)) * pt.grad_log_q + 2 * beta * pt.grad_log_p          # the reference's 2 beta
+    assert torch.allclose(hmc.grad_intermediate_target_log_prob(pt, beta), gref, rtol=1e-5, atol=1e-5)
+    hmc.p_target = True
+    assert torch.allclose(hmc.intermediate_target_log_prob(pt, beta), (1 - beta) * pt.log_q + beta * pt.log_p, rtol=1e-5, atol=1e-5)
+    hmc.p_target = False
+    # perform_transition = transition + log-weight increment, input log_w untouched
+    lw0 = torch.zeros(B, device=DEV)
+    torch.manual_seed(5)
+    p1 = fa.Point(pt.x.clone(), pt.log_q.clone(), pt.log_p.clone(), pt.grad_log_q.clone(), pt.grad_log_p.clone())
+    p1, lw1 = ais.perform_transition(p1, lw0, 1)
+    torch.manual_seed(5)
+    p2 = fa.Point(pt.x.clone(), pt.log_q.clone(), pt.log_p.clone(), pt.grad_log_q.clone(), pt.grad_log_p.clone())
+    hmc.epsilons.copy_(torch.ones_like(hmc.epsilons) * 0.2 * 0.9); hmc.common_epsilon.fill_(0.02)
+    assert torch.equal(lw0, torch.zeros(B, device=DEV)) and torch.isfinite(lw1).all() and not torch.equal(lw1, lw0)
+    b1, b2 = float(ais.B_space[1]), float(ais.B_space[2])
+    inc = hmc.intermediate_target_log_prob(p1, b2) - hmc.intermediate_target_log_prob(p1, b1)
+    assert torch.allclose(lw1, inc, rtol=1e-4, atol=1e-4)
+    # HMC save / load
+    hmc.save_model(tmp_path, epoch=3)
+    other = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=1.0, L=3).to(DEV)
+    other.load_model(tmp_path, epoch=3, device=DEV)
+    assert torch.equal(other.epsilons, hmc.epsilons) and torch.equal(other.common_epsilon, hmc.common_epsilon)
+    # the 2-D helpers of the target
+    x2 = torch.randn(32, 2, device=DEV)
+    full = torch.zeros(32, D, device=DEV); full[:, :2] = x2
+    rest = target.log_prob(torch.zeros(1, D, device=DEV))[0] * (D // 2 - 1) / (D // 2)        # the other wells at the origin
+    assert torch.allclose(target.log_prob_2D(x2), target.log_prob(full) - rest, rtol=1e-5, atol=1e-5)
+    assert target.energy(x2).shape == (32, 1) and torch.allclose(target.energy(x2)[:, 0], -target.log_prob_2D(x2))
+    f = target.force(x2)
+    assert torch.allclose(f[:, 0], 0.5 + 12 * x2[:, 0] - 4 * x2[:, 0] ** 3, rtol=1e-4, atol=1e-4) and torch.allclose(f[:, 1], -x2[:, 1])
+    s = target.sample_first_dimension((4096,))
+    assert s.shape == (4096,) and 0.6 < float((s > 0).float().mean()) < 0.97            # the deep well is at +1.7
