@@ -17,17 +17,19 @@ from .point import Point
 from .transition_operators import TransitionOperator
 
 ALPHA_DIV_TARGET_LOSSES = ["fab_alpha_div"]
-LOSSES_USING_AIS = ["fab_alpha_div", None]
+LOSSES_USING_AIS = ["fab_alpha_div", "fab_ub_alpha_2_div", None]
+EXPERIMENTAL_LOSSES = ["flow_alpha_2_div_unbiased", "flow_alpha_2_div", "fab_ub_alpha_2_div"]     # core.py:15
 SUPPORTED_LOSSES = [None, "fab_alpha_div", "forward_kl", "flow_reverse_kl", "flow_alpha_2_div_nis",
-                    "target_forward_kl"]
+                    "target_forward_kl"] + EXPERIMENTAL_LOSSES
 
 
 class FABModel:
     def __init__(self, flow, target_distribution, n_intermediate_distributions: int, alpha: float = 2.,
                  transition_operator: Optional[TransitionOperator] = None, ais_distribution_spacing: str = "linear",
                  loss_type: Optional[str] = None, use_ais: bool = True):
-        if loss_type not in SUPPORTED_LOSSES:
-            raise Exception(f"loss_type {loss_type!r} is not supported (experimental reference losses are omitted)")
+        assert loss_type in SUPPORTED_LOSSES
+        if loss_type in EXPERIMENTAL_LOSSES:               # same refusal as the reference (core.py:50-51)
+            raise Exception("Running using experiment loss not used within the main FAB paper.")
         if loss_type in ALPHA_DIV_TARGET_LOSSES:
             assert alpha is not None, "Alpha must be specified if using the alpha div loss."
         self.alpha, self.loss_type = alpha, loss_type
@@ -81,11 +83,33 @@ class FABModel:
     def inner_loss(self, point: Point, log_w_ais) -> torch.Tensor:
         if self.loss_type == "fab_alpha_div":
             return self.fab_alpha_div_inner(point, log_w_ais)
+        if self.loss_type == "fab_ub_alpha_2_div":
+            return self.fab_ub_alpha_div_loss_inner(point, log_w_ais)
         raise NotImplementedError
 
     def flow_reverse_kl(self, batch_size: int) -> torch.Tensor:
         x, log_q = self.flow.sample_and_log_prob((batch_size,))
         return torch.mean(log_q) - torch.mean(self.target_distribution.log_prob(x))
+
+    # the reference's experimental losses (core.py:134-170): refused by the constructor there and here, callable directly
+    def flow_alpha_2_div(self, batch_size: int) -> torch.Tensor:
+        x, log_q = self.flow.sample_and_log_prob((batch_size,))
+        return torch.logsumexp(2 * (self.target_distribution.log_prob(x) - log_q), 0)
+
+    def flow_alpha_2_div_unbiased(self, batch_size: int) -> torch.Tensor:
+        x, log_q_x = self.flow.sample_and_log_prob((batch_size,))
+        log_p_x = self.target_distribution.log_prob(x)
+        return torch.mean(torch.exp(2 * (log_p_x - log_q_x)) * log_q_x)
+
+    def fab_ub_alpha_div_loss_inner(self, point: Point, log_w_ais: torch.Tensor) -> torch.Tensor:
+        log_q_x = self.flow.log_prob(point.x)
+        return torch.logsumexp(log_w_ais + (point.log_p - log_q_x), dim=0)
+
+    def fab_ub_alpha_div_loss(self, batch_size: int) -> torch.Tensor:
+        # (the reference passes three arguments to the two-argument inner function here, core.py:166-168; the evident
+        # intent is the call below)
+        point_ais, log_w_ais = self.annealed_importance_sampler.sample_and_log_weights(batch_size)
+        return self.fab_ub_alpha_div_loss_inner(point_ais, log_w_ais)
 
     def flow_alpha_2_div_nis(self, batch_size: int) -> torch.Tensor:
         x, log_q_x = self.flow.sample_and_log_prob((batch_size,))

@@ -248,3 +248,25 @@ def test_reference_helper_methods_of_the_operators_sampler_and_target(tmp_path):
     assert torch.allclose(f[:, 0], 0.5 + 12 * x2[:, 0] - 4 * x2[:, 0] ** 3, rtol=1e-4, atol=1e-4) and torch.allclose(f[:, 1], -x2[:, 1])
     s = target.sample_first_dimension((4096,))
     assert s.shape == (4096,) and 0.6 < float((s > 0).float().mean()) < 0.97            # the deep well is at +1.7
+
+
+def test_experimental_losses_are_refused_like_the_reference_but_callable():
+    """core.py:13-15,50-51: FABModel refuses the three experimental loss types with the reference's message; the loss
+    functions themselves (core.py:134-170) exist and differentiate through the HIP ops."""
+    D, M, B = 6, 2, 64
+    torch.manual_seed(0)
+    flow = fa.RealNVP(D, 2, 6).to(DEV)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
+    for lt in ("flow_alpha_2_div", "flow_alpha_2_div_unbiased", "fab_ub_alpha_2_div"):
+        with pytest.raises(Exception, match="experiment loss"):
+            fa.FABModel(flow, target, M, alpha=2.0, transition_operator=hmc, loss_type=lt)
+    model = fa.FABModel(flow, target, M, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
+    for fn in (model.flow_alpha_2_div, model.flow_alpha_2_div_unbiased, model.fab_ub_alpha_div_loss, model.flow_alpha_2_div_nis,
+               model.flow_reverse_kl):
+        for p in flow.parameters():
+            p.grad = None
+        loss = fn(B)
+        assert loss.dim() == 0 and torch.isfinite(loss)
+        loss.backward()
+        assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in flow.parameters()), fn.__name__
