@@ -23,6 +23,18 @@ def anneal_coefs(beta, alpha, p_target):
     return tuple(_ops.load().anneal_coefs(float(beta), float(alpha if alpha is not None else 0.0), bool(p_target)))
 
 
+def get_intermediate_log_prob(x: Point, beta: float, alpha: Optional[float], p_target: bool) -> torch.Tensor:
+    """fab/sampling_methods/base.py:76-97: log of the annealed density at a Point (fabhip_anneal_log_prob)."""
+    return _ops.load().anneal_log_prob(x.log_q.contiguous(), x.log_p.contiguous(), float(beta),
+                                       float(alpha if alpha is not None else 0.0), bool(p_target))
+
+
+def get_grad_intermediate_log_prob(x: Point, beta: float, alpha: Optional[float], p_target: bool) -> torch.Tensor:
+    """fab/sampling_methods/base.py:100-118, incl. its hard-coded 2 beta on grad log p."""
+    _, _, g_q, g_p = anneal_coefs(beta, alpha, p_target)
+    return g_q * x.grad_log_q + g_p * x.grad_log_p
+
+
 def _owner(fn, cls, what):
     obj = getattr(fn, "__self__", None)
     if not isinstance(obj, cls):

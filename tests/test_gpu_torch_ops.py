@@ -221,6 +221,8 @@ def test_reference_helper_methods_of_the_operators_sampler_and_target(tmp_path):
     hmc.p_target = True
     assert torch.allclose(hmc.intermediate_target_log_prob(pt, beta), (1 - beta) * pt.log_q + beta * pt.log_p, rtol=1e-5, atol=1e-5)
     hmc.p_target = False
+    assert torch.equal(fa.get_intermediate_log_prob(pt, beta, alpha, False), hmc.intermediate_target_log_prob(pt, beta))
+    assert torch.equal(fa.get_grad_intermediate_log_prob(pt, beta, alpha, False), hmc.grad_intermediate_target_log_prob(pt, beta))
     # perform_transition = transition + log-weight increment, input log_w untouched
     lw0 = torch.zeros(B, device=DEV)
     torch.manual_seed(5)
