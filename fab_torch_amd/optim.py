@@ -15,16 +15,26 @@ from .flow import RealNVP
 
 
 class FlatAdam(torch.optim.Optimizer):
-    def __init__(self, flow: RealNVP, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
+    """`flow`: a fab_torch_amd RealNVP (flat image = the layout of its parameter-gradient kernels, one autograd leaf), or
+    any other nn.Module (e.g. the spline flow: parameters in `.parameters()` order, gradients concatenated per step)."""
+
+    def __init__(self, flow: torch.nn.Module, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8):
         self.flow = flow
-        self._params = flow._grad_tensors()
+        self.native = isinstance(flow, RealNVP)
+        self._params = flow._grad_tensors() if self.native else [p for p in flow.parameters()]
         for p in self._params:
-            _ops.require_device(p, "RealNVP parameters (move the flow to the GPU before building FlatAdam)")
+            _ops.require_device(p, "flow parameters (move the flow to the GPU before building FlatAdam)")
         super().__init__(self._params, dict(lr=lr, betas=betas, eps=eps))
-        self.n = flow.grad_floats()                  # (+ the ActNorm pairs for an act_norm flow)
+        self.n = flow.grad_floats() if self.native else sum(p.numel() for p in self._params)
         dev = self._params[0].device
         self.theta = torch.empty(self.n, dtype=torch.float32, device=dev)
-        views = flow._grad_views(self.theta)
+        if self.native:                              # (+ the ActNorm pairs for an act_norm flow)
+            views = flow._grad_views(self.theta)
+        else:
+            views, o = [], 0
+            for p in self._params:
+                views.append(self.theta[o:o + p.numel()].view(p.shape))
+                o += p.numel()
         with torch.no_grad():
             for p, v in zip(self._params, views):
                 v.copy_(p.detach())
@@ -35,10 +45,11 @@ class FlatAdam(torch.optim.Optimizer):
         self.steps = torch.zeros(1, dtype=torch.int32, device=dev)     # applied steps (device: skips happen there)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
         flow._packed_key = None
-        # one autograd leaf for the whole flow: flow.log_prob(x).backward() then delivers ONE flat gradient
-        # (theta.grad) instead of 112 per-parameter views (the per-parameter .grad stay None in this mode)
-        self.theta.requires_grad_(True)
-        flow._flat_leaf = self.theta
+        if self.native:
+            # one autograd leaf for the whole flow: flow.log_prob(x).backward() then delivers ONE flat gradient
+            # (theta.grad) instead of 112 per-parameter views (the per-parameter .grad stay None in this mode)
+            self.theta.requires_grad_(True)
+            flow._flat_leaf = self.theta
 
     def zero_grad(self, set_to_none: bool = True):
         super().zero_grad(set_to_none=True)

@@ -67,7 +67,8 @@ class PrioritisedBufferTrainer:
         self.w_adjust_in_buffer_after_update = w_adjust_in_buffer_after_update
         self.logger = logger
         self.history: List[Dict] = []
-        self._fused = isinstance(optimizer, FlatAdam)
+        self._fused = isinstance(optimizer, FlatAdam) and optimizer.native      # tape + flat-image kernels: RealNVP
+        self._flat = isinstance(optimizer, FlatAdam)                            # fused clip + Adam for any flow
 
     def step(self, i: int, batch_size: int, noise: Optional[Dict] = None) -> Dict:
         """One iteration of train_with_prioritised_buffer.py:138-198.  `noise` (optional, parity replays): the random
@@ -114,7 +115,12 @@ class PrioritisedBufferTrainer:
             w_adjust = (torch.clip(w_adjust_pre_clip, max=self.max_adjust_w_clip)
                         if self.max_adjust_w_clip is not None else w_adjust_pre_clip)
             loss = - torch.mean(w_adjust * log_q_x)
-            if torch.isfinite(loss):
+            if self._flat:
+                # FlatAdam on a non-RealNVP flow: autograd for the gradients, then ONE fused clip + Adam launch whose
+                # on-device finite-norm check skips the update (a non-finite loss poisons the gradient: reference :172-181)
+                (loss * torch.where(torch.isfinite(loss.detach()), 1.0, float("nan"))).backward()
+                grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm)
+            elif torch.isfinite(loss):
                 loss.backward()
                 grad_norm = torch.nn.utils.clip_grad_norm_(model.parameters(), self.max_gradient_norm)
                 if torch.isfinite(grad_norm):
@@ -228,7 +234,8 @@ class Trainer:
         self.max_gradient_norm = max_gradient_norm if max_gradient_norm else float("inf")
         self.save_dir = save_path
         self.history: List[Dict] = []
-        self._fused = isinstance(optimizer, FlatAdam)
+        self._fused = isinstance(optimizer, FlatAdam) and optimizer.native      # tape + flat-image kernels: RealNVP
+        self._flat = isinstance(optimizer, FlatAdam)                            # fused clip + Adam for any flow
 
     def save_checkpoint(self, i: int):
         import os
@@ -276,12 +283,12 @@ class Trainer:
             info.update(loss=loss.item(), step=i, grad_norm=float(grad_norm))
             return info
         loss = self.model.loss(batch_size)
-        if self._fused and bool(torch.isfinite(loss)):
+        if self._flat and bool(torch.isfinite(loss)):
             loss.backward()
             grad_norm = self.optimizer.step(max_grad_norm=self.max_gradient_norm)
             if self.optim_schedular:
                 self.optim_schedular.step()
-        elif self._fused:
+        elif self._flat:
             print("nan loss encountered")
         elif not torch.isnan(loss) and not torch.isinf(loss):
             loss.backward()

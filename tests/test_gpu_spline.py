@@ -372,3 +372,35 @@ def test_plain_trainer_forward_kl_and_checkpoint_roundtrip_with_the_spline_flow(
     hmc3 = fa.HamiltonianMonteCarlo(M, D, hf3.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
     fa.FABModel(hf3, target, M, alpha=2.0, transition_operator=hmc3, loss_type="fab_alpha_div").load(str(tmp_path / "raw.pt"), DEV)
     assert torch.equal(hf3.log_prob(x).detach(), ref)
+
+
+def test_flat_adam_on_the_spline_flow_matches_clip_grad_norm_and_torch_adam():
+    """FlatAdam generalised to any module (parameters re-pointed into one flat buffer, gradients concatenated, ONE fused
+    clip + Adam launch): the buffer trainer with it follows the torch.optim.Adam + clip_grad_norm_ run step for step."""
+    D, L, hidden, M, B = 6, 3, 64, 3, 128
+    tb = torch.tensor([5.0, math.pi, 5.0, 5.0, 5.0, 5.0])
+    runs = {}
+    for kind in ("torch", "flat"):
+        torch.manual_seed(0)
+        hf = fa.make_wrapped_normflow_spline(D, L, hidden, (1,), tb).to(DEV)
+        target = fa.ManyWellEnergy(D)
+        hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=3).to(DEV)
+        model = fa.FABModel(hf, target, M, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
+        ais = model.annealed_importance_sampler
+
+        def initial_sampler():
+            pt, lw = ais.sample_and_log_weights(B, logging=False)
+            return pt.x, lw, pt.log_q
+        torch.manual_seed(1)
+        buf = fa.PrioritisedReplayBuffer(D, 8 * B, 2 * B, initial_sampler, device=DEV)
+        opt = fa.FlatAdam(hf, lr=1e-3) if kind == "flat" else torch.optim.Adam(hf.parameters(), lr=1e-3)
+        if kind == "flat":
+            assert not opt.native and opt.theta.numel() == sum(p.numel() for p in hf.parameters())
+        trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=2.0, n_batches_buffer_sampling=2, max_gradient_norm=1.0)
+        torch.manual_seed(2)
+        infos = [trainer.step(i, B) for i in range(3)]
+        runs[kind] = ({k: v.detach().clone() for k, v in hf.state_dict().items()}, infos)
+    for k, v in runs["torch"][0].items():
+        assert close(runs["flat"][0][k], v, 1e-4, atol_scale=50), k
+    for a, b in zip(runs["torch"][1], runs["flat"][1]):
+        assert abs(a["loss"] - b["loss"]) <= 1e-4 * max(1.0, abs(a["loss"])) and abs(a["grad_norm"] - b["grad_norm"]) <= 1e-3 * a["grad_norm"]

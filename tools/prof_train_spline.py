@@ -43,6 +43,16 @@ def full():
 
 
 out["fwd_bwd_clip_adam_ms"] = t(full)
+fopt = fa.FlatAdam(flow, lr=1e-4)
+
+
+def full_flat():
+    fopt.zero_grad()
+    (-flow.log_prob(x).mean()).backward()
+    fopt.step(max_grad_norm=100.0)
+
+
+out["fwd_bwd_flat_adam_ms"] = t(full_flat)
 p0 = next(flow.parameters())
 with torch.no_grad():
     out["pack_ms"] = t(lambda: (p0.add_(0.0), flow.native()))                  # re-pack after an optimiser step

@@ -41,7 +41,7 @@ def main():
                                    n_outer=1, L=5).to(DEV)
     model = fa.FABModel(flow, target, args.M, alpha=2.0, transition_operator=hmc, loss_type="fab_alpha_div")
     ais = model.annealed_importance_sampler
-    opt = fa.FlatAdam(flow, lr=args.lr) if args.flow == "realnvp" else torch.optim.Adam(flow.parameters(), lr=args.lr)
+    opt = fa.FlatAdam(flow, lr=args.lr)          # RealNVP: tape + flat-image kernels; spline: autograd + fused clip / Adam
 
     def init_sampler():
         pt, lw = ais.sample_and_log_weights(args.batch, logging=False)
