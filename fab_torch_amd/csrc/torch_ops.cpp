@@ -486,6 +486,59 @@ void hmc_generic_accept(const Tensor& prop_lq, const Tensor& prop_lp, const Tens
         "hmc_generic_accept");
 }
 
+// One HMC transition (hmc.py:129-160, all n_outer x L leapfrogs) for the SPLINE flow + a native target, enqueued from
+// C++: per leapfrog the generic element-wise kernels, the one-launch spline density + gradient kernel and the target
+// kernel - what transition_operators.py::_transition_generic does step by step from Python, without the ~40 op calls
+// per transition in between (they cost as much as the kernels at batch sizes <= 1024).
+void spline_hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden, int64_t kind,
+                           at::ArrayRef<double> prm, const optional<Tensor>& locs, const optional<Tensor>& scales, Tensor x,
+                           Tensor log_q, Tensor log_p, Tensor grad_log_q, Tensor grad_log_p, optional<Tensor> log_w,
+                           double beta, double beta_next, double alpha, bool p_target, const Tensor& noise_p,
+                           const Tensor& noise_e, Tensor eps_row, Tensor ceps, const Tensor& mass, int64_t n_outer,
+                           int64_t n_leap, double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept,
+                           optional<Tensor> avg_distance) {
+    c10::DeviceGuard g(x.device());
+    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
+    const fabhip_target tg = make_target(kind, prm, locs, scales, dim);
+    const int64_t B = x.size(0), D = x.size(1);
+    TORCH_CHECK(D == dim && n_outer >= 1 && n_leap >= 1, "fabhip: spline_hmc_transition shapes");
+    TORCH_CHECK(noise_p.numel() == n_outer * B * D && noise_e.numel() == n_outer * B && eps_row.numel() == n_outer &&
+                mass.numel() == D, "fabhip: spline_hmc_transition noise / step-size shapes");
+    if (B == 0) return;
+    const fabhip_stream_t st = stream_of(x);
+    Tensor ws = generic_workspace(x, B, D);
+    const size_t sb = fabhip_spline_workspace_bytes(f.dim, f.n_layers, f.hidden, B, 1);
+    Tensor sws = scratch(sb, x);
+    Tensor xn = at::empty_like(x), gq = at::empty_like(x), gp = at::empty_like(x), lq = fempty({B}, x), lp = fempty({B}, x);
+    const fabhip_anneal c = coefs(beta, alpha, p_target), cn = coefs(beta_next, alpha, p_target);
+    fabhip_point cur{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), fpm(grad_log_q, "grad_log_q"),
+                     fpm(grad_log_p, "grad_log_p")};
+    fabhip_point start = cur;
+    fabhip_point prop{xn.data_ptr<float>(), lq.data_ptr<float>(), lp.data_ptr<float>(), gq.data_ptr<float>(),
+                      gp.data_ptr<float>()};
+    float* eps = fpm(eps_row, "epsilons"); float* ce = fpm(ceps, "common_epsilon");
+    const float* ms = fp(mass, "mass");
+    for (int64_t n = 0; n < n_outer; ++n) {
+        chk(fabhip_hmc_generic_begin(&start, &cur, B, (int32_t)D, c, fp(noise_p, "noise_p") + n * B * D, ms,
+                                     (float)max_grad, fpm(ws, "workspace"), ws_bytes(ws), st), "hmc_generic_begin");
+        for (int64_t l = 0; l < n_leap; ++l) {
+            chk(fabhip_hmc_generic_leap_pre(B, (int32_t)D, eps + n, ce, ms, prop.x, fpm(ws, "workspace"), ws_bytes(ws), st),
+                "hmc_generic_leap_pre");
+            chk(fabhip_spline_log_prob(&f, prop.x, prop.log_q, prop.grad_log_q, B, aligned(sws), sb, st), "spline_log_prob");
+            chk(fabhip_target_log_prob(&tg, prop.x, prop.log_p, prop.grad_log_p, B, st), "target_log_prob");
+            chk(fabhip_hmc_generic_leap_post(B, (int32_t)D, prop.grad_log_q, prop.grad_log_p, c, (float)max_grad, eps + n, ce,
+                                             fpm(ws, "workspace"), ws_bytes(ws), st), "hmc_generic_leap_post");
+        }
+        const bool last = n + 1 == n_outer;
+        chk(fabhip_hmc_generic_accept(&prop, &cur, B, (int32_t)D, c, cn, last ? fpm_opt(log_w, "log_w") : nullptr,
+                                      fp(noise_e, "noise_e") + n * B, ms, eps + n, ce, (float)target_p_accept, tune ? 1 : 0,
+                                      p_accept.has_value() ? fpm(*p_accept, "p_accept") + n : nullptr,
+                                      fpm_opt(avg_distance, "avg_distance"), fpm(ws, "workspace"), ws_bytes(ws), st),
+            "hmc_generic_accept");
+        start = prop;                                  // the reference continues from the PROPOSAL (hmc.py:133-142)
+    }
+}
+
 Tensor anneal_log_prob(const Tensor& log_q, const Tensor& log_p, double beta, double alpha, bool p_target) {
     c10::DeviceGuard g(log_q.device());
     Tensor out = at::empty_like(log_q);
@@ -730,6 +783,11 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!) grad_log_q, Tensor(e!) grad_log_p, Tensor(f!)? log_w, float beta, "
           "float beta_next, float alpha, bool p_target, Tensor noise_e, Tensor mass, Tensor(g!) eps, Tensor(h!) ceps, "
           "float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance, Tensor(k!) ws) -> ()");
+    m.def("spline_hmc_transition(Tensor packed, int dim, int n_layers, int hidden, int target_kind, float[] target_params, "
+          "Tensor? locs, Tensor? scales, Tensor(a!) x, Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!) grad_log_q, "
+          "Tensor(e!) grad_log_p, Tensor(f!)? log_w, float beta, float beta_next, float alpha, bool p_target, Tensor noise_p, "
+          "Tensor noise_e, Tensor(g!) eps_row, Tensor(h!) ceps, Tensor mass, int n_outer, int n_leap, float max_grad, "
+          "float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance) -> ()");
     m.def("anneal_log_prob(Tensor log_q, Tensor log_p, float beta, float alpha, bool p_target) -> Tensor");
     m.def("log_w_update(Tensor log_q, Tensor log_p, float beta, float beta_next, float alpha, bool p_target, "
           "Tensor(a!) log_w) -> ()");
@@ -770,6 +828,7 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("hmc_generic_leap_pre", hmc_generic_leap_pre);
     m.impl("hmc_generic_leap_post", hmc_generic_leap_post);
     m.impl("hmc_generic_accept", hmc_generic_accept);
+    m.impl("spline_hmc_transition", spline_hmc_transition);
     m.impl("anneal_log_prob", anneal_log_prob);
     m.impl("log_w_update", log_w_update);
     m.impl("metropolis_generic_propose", metropolis_generic_propose);

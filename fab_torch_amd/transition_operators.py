@@ -8,6 +8,7 @@ A transition is ONE custom-op call (torch.ops.fabhip.hmc_transition / metropolis
 flow + target evaluations, accept/reject, commit and step-size adaptation run on the GPU; the step-size
 state lives in the registered device buffers and is updated in place (no host synchronisation).
 """
+import os
 from typing import Dict, Optional, Union
 
 import torch
@@ -231,6 +232,16 @@ class HamiltonianMonteCarlo(TransitionOperator):
         elif i == M:
             p_accept, avg_distance = self._p_accept_last, self._dist_last
         if not self.is_native:
+            spline = self._spline_parts()
+            if spline is not None:                     # spline flow + native target: the same steps, enqueued by one op
+                flow, target = spline
+                _ops.load().spline_hmc_transition(
+                    *flow.native(), *target.native_target(), point.x, point.log_q, point.log_p, point.grad_log_q,
+                    point.grad_log_p, log_w, float(beta), float(beta_next if beta_next is not None else beta),
+                    float(self.alpha if self.alpha is not None else 0.0), bool(self.p_target), noise_p.contiguous(),
+                    noise_e.contiguous(), self.epsilons[i - 1], self.common_epsilon, self.mass_vector, self.n_outer, self.L,
+                    float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance)
+                return point
             return self._transition_generic(point, i, beta, log_w, beta_next, noise_p.contiguous(),
                                             noise_e.contiguous(), p_accept, avg_distance)
         _ops.load().hmc_transition(
@@ -241,6 +252,16 @@ class HamiltonianMonteCarlo(TransitionOperator):
             float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance)
         return point
 
+
+    def _spline_parts(self):
+        """(spline flow, native target) when the base distribution is this package's spline flow and the target is
+        native - the host-fused transition op applies; else None (step-by-step generic path)."""
+        if os.environ.get("FABHIP_SPLINE_STEPWISE"):   # debugging: force the step-by-step path
+            return None
+        from .spline_flow import CircularCoupledRQSFlow
+        flow = _owner_or_none(self.base_log_prob, CircularCoupledRQSFlow)
+        target = _owner_or_none(self.target_log_prob, _NativeTarget)
+        return (flow, target) if flow is not None and target is not None else None
 
     def save_model(self, save_path, epoch=None):
         """hmc.py:204-214 (state dict under HMC_model[_epoch{n}] + a text description)."""

@@ -404,3 +404,37 @@ def test_flat_adam_on_the_spline_flow_matches_clip_grad_norm_and_torch_adam():
         assert close(runs["flat"][0][k], v, 1e-4, atol_scale=50), k
     for a, b in zip(runs["torch"][1], runs["flat"][1]):
         assert abs(a["loss"] - b["loss"]) <= 1e-4 * max(1.0, abs(a["loss"])) and abs(a["grad_norm"] - b["grad_norm"]) <= 1e-3 * a["grad_norm"]
+
+
+@pytest.mark.parametrize("n_outer", [1, 2])
+def test_host_fused_spline_transition_equals_the_step_by_step_generic_path(monkeypatch, n_outer):
+    """`fabhip::spline_hmc_transition` enqueues exactly the launches the Python loop of `_transition_generic` issues (one op
+    call per transition instead of ~40): same state, weights, step sizes and logging slots, bit for bit."""
+    D, L, hidden, M, B, LF = 8, 3, 64, 3, 200, 4
+    tb = torch.full((D,), 5.0); tb[[1, 6]] = math.pi
+    torch.manual_seed(0)
+    hf = fa.make_wrapped_normflow_spline(D, L, hidden, (1, 6), tb).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    res = {}
+    for mode in ("fused", "stepwise"):
+        if mode == "stepwise":
+            monkeypatch.setenv("FABHIP_SPLINE_STEPWISE", "1")
+        hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.15, L=LF,
+                                       n_outer=n_outer).to(DEV)
+        g = torch.Generator(device=DEV).manual_seed(3)
+        x = torch.randn(B, D, device=DEV, generator=g)
+        pt = hmc.create_new_point(x)
+        lw = torch.zeros(B, device=DEV)
+        for j in (1, 2, 3):
+            npz = torch.randn(n_outer, B, D, device=DEV, generator=g)
+            nez = torch.empty(n_outer, B, device=DEV).exponential_(generator=g)
+            hmc.transition(pt, j, 0.25 * j, log_w=lw, beta_next=0.25 * (j + 1), noise_p=npz, noise_e=nez)
+        res[mode] = (pt.x.clone(), pt.log_q.clone(), pt.grad_log_p.clone(), lw.clone(), hmc.epsilons.clone(),
+                     hmc.common_epsilon.clone(), hmc.get_logging_info())
+    for a, b in zip(res["fused"][:6], res["stepwise"][:6]):
+        assert torch.equal(a, b)
+    assert res["fused"][6] == res["stepwise"][6]
+    assert not torch.equal(res["fused"][3], torch.zeros(B, device=DEV))
