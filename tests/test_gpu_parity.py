@@ -573,6 +573,7 @@ def test_plain_trainer_fab_alpha_div_loss(optimiser, tmp_path):
     pt, lw = model.annealed_importance_sampler.sample_and_log_weights(B)
     loss_hip = model.fab_alpha_div_inner(pt, lw)
     loss_ref = -torch.mean(torch.softmax(lw, dim=-1) * aten_reference.log_prob(flow, pt.x))
+    loss_hip, loss_ref = loss_hip.detach(), loss_ref.detach()
     assert abs(float(loss_hip) - float(loss_ref)) <= 1e-5 * max(1.0, abs(float(loss_ref)))
     opt = torch.optim.Adam(flow.parameters(), lr=1e-3) if optimiser == "torch_adam" else fa.FlatAdam(flow, lr=1e-3)
     trainer = fa.Trainer(model, opt, max_gradient_norm=100.0, save_path=str(tmp_path))
