@@ -18,6 +18,7 @@
 // across any code; they are issued a few at a time behind the MFMAs of the previous W x W main loop, never as a
 // burst (the CU's vector-memory path takes ~16 cycles per 1-KiB wave load).
 #pragma once
+#include <type_traits>
 #include "fabhip_common.h"
 
 namespace fab {
@@ -273,6 +274,14 @@ struct IC {
     static constexpr int value = V;
 };
 
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(IC<I>());
+        static_for<I + 1, N>(f);
+    }
+}
+
 // one k-block.  MODE 1: first block (data present, no wait; issues the prologue of slots 1 .. DEPTH-1);
 // MODE 0: steady state (wait slot D, refill slot D-1 with block S-1+DEPTH, NJ injected requests from index JB)
 template <int NTWM, int DEPTH, int D, int MODE, int NJ, int JB, class Inject>
@@ -527,13 +536,45 @@ __device__ __forceinline__ void smallw_mul(const SmallW<NTWM, KB>& w, const floa
     }
 }
 
+// smallw_mul with ONE injected request behind each of its 4 KB NTWM MFMAs (`inj(IC<m>)`, m = running MFMA index):
+// fast mode streams the bf16 weight slice of the W x W GEMM that FOLLOWS this short stage this way - a burst of 50
+// loads blocks the issuing wave for ~3 k cycles (measured: the stage grew from 2.9 k to 6.2 k), one load per MFMA
+// issues in the shadow of the matrix pipe.
+
+template <int NTWM, int KB, bool MASKK, class Inject>
+__device__ __forceinline__ void smallw_mul_inj(const SmallW<NTWM, KB>& w, const float* __restrict__ A, int lda, int kmax,
+                                               const Tid& t, f32x4 (&acc)[NTWM], Inject& inj) {
+    const float* arow = A + t.n * lda + 4 * t.q;
+#pragma unroll
+    for (int i = 0; i < NTWM; ++i) acc[i] = (f32x4){w.bv[i], w.bv[i], w.bv[i], w.bv[i]};
+    float a[KB][4];
+#pragma unroll
+    for (int S = 0; S < KB; ++S) {
+        const float4 v = *reinterpret_cast<const float4*>(arow + 16 * S);
+        const int k0 = 16 * S + 4 * t.q;
+        a[S][0] = (!MASKK || k0 + 0 < kmax) ? v.x : 0.f;
+        a[S][1] = (!MASKK || k0 + 1 < kmax) ? v.y : 0.f;
+        a[S][2] = (!MASKK || k0 + 2 < kmax) ? v.z : 0.f;
+        a[S][3] = (!MASKK || k0 + 3 < kmax) ? v.w : 0.f;
+    }
+    static_for<0, 4 * KB * NTWM>([&](auto mc) {
+        constexpr int m = decltype(mc)::value, S = m / (4 * NTWM), sub = (m / NTWM) % 4, i = m % NTWM;
+        const float bb = sub == 0 ? w.b[S][i].x : (sub == 1 ? w.b[S][i].y : (sub == 2 ? w.b[S][i].z : w.b[S][i].w));
+        acc[i] = mfma4(a[S][sub], bb, acc[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        inj(mc);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
 // OUT = relu(A @ B + bias) with pre-loaded weights (same epilogue as dense_relu)
-template <int NTWM, int KB, bool MASK, bool TAPE>
+template <int NTWM, int KB, bool MASK, bool TAPE, class Inject = NoInject>
 __device__ __forceinline__ void dense_relu_small(const SmallW<NTWM, KB>& w, const float* A, int lda, int kmax,
                                                  float* OUT, int ldo, unsigned* mask, const Tid& t,
-                                                 float* __restrict__ gout, int ldg) {
+                                                 float* __restrict__ gout, int ldg, Inject inj = Inject()) {
     f32x4 acc[NTWM];
-    smallw_mul<NTWM, KB, true>(w, A, lda, kmax, t, acc);
+    if constexpr (std::is_same<Inject, NoInject>::value) smallw_mul<NTWM, KB, true>(w, A, lda, kmax, t, acc);
+    else smallw_mul_inj<NTWM, KB, true>(w, A, lda, kmax, t, acc, inj);
     unsigned m = 0u;
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
@@ -550,13 +591,14 @@ __device__ __forceinline__ void dense_relu_small(const SmallW<NTWM, KB>& w, cons
 }
 
 // OUT = (A @ B) * mask with pre-loaded weights (same epilogue as dense_masked)
-template <int NTWM, int KB, bool TAPE>
+template <int NTWM, int KB, bool TAPE, class Inject = NoInject>
 __device__ __forceinline__ void dense_masked_small(const SmallW<NTWM, KB>& w, const float* A, int lda, float* OUT,
                                                    int ldo, const unsigned* mask, const Tid& t,
-                                                   float* __restrict__ gout, int ldg) {
+                                                   float* __restrict__ gout, int ldg, Inject inj = Inject()) {
     f32x4 acc[NTWM];
     unsigned m = mask[t.tid];
-    smallw_mul<NTWM, KB, false>(w, A, lda, 0, t, acc);
+    if constexpr (std::is_same<Inject, NoInject>::value) smallw_mul<NTWM, KB, false>(w, A, lda, 0, t, acc);
+    else smallw_mul_inj<NTWM, KB, false>(w, A, lda, 0, t, acc, inj);
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) {
         const int c = t.wave + 4 * i;
@@ -736,26 +778,57 @@ __device__ __forceinline__ void gemm_bf16_chunk(uint4 (&b0)[CH][NTWM], uint4 (&b
 template <int NTWM>
 __host__ __device__ constexpr int bf16_chunk() { return NTWM <= 5 ? NTWM : 24 / NTWM; }     // NTWM = 8: 3 k-blocks x 8 tiles
 
-// chunk 0 (+ the bias of the wave's columns) of a bf16 GEMM, requested one short stage early with plain loads
+// blocks requested one short stage EARLY with plain loads: for NTWM <= 5 the wave's whole weight slice (2 NTWM^2 <= 50
+// loads, 200 registers - a wave runs alone on its SIMD) so that the stream overlaps the short stage in front of the
+// GEMM (a pure stream reaches 45 - 60 B/clk per CU, tools/ubench/stream.hip; issued at the GEMM's own start the same
+// bytes cost their latency + transfer on top of its MFMAs); for NTWM = 8 chunk 0 only (the rest is streamed in chunks).
+template <int NTWM>
+__host__ __device__ constexpr int bf16_pre_blocks() { return NTWM <= 5 ? 2 * NTWM : bf16_chunk<NTWM>(); }
+
 template <int NTWM>
 struct Bf16Pre {
-    uint4 b[bf16_chunk<NTWM>()][NTWM];
+    uint4 b[bf16_pre_blocks<NTWM>()][NTWM];
     float bv[NTWM];
 };
 
 template <int NTWM, bool BIAS>
 __device__ __forceinline__ void bf16pre_load(Bf16Pre<NTWM>& p, const uint4* __restrict__ Bh, const float* __restrict__ bias,
                                              const Tid& t) {
-    constexpr int KB2 = 2 * NTWM, CH = bf16_chunk<NTWM>();
+    constexpr int KB2 = 2 * NTWM, PB = bf16_pre_blocks<NTWM>();
     const uint4* bw = Bh + ((size_t)t.wave * KB2) * 64 + t.lane;
 #pragma unroll
     for (int i = 0; i < NTWM; ++i) p.bv[i] = BIAS ? bias[16 * (t.wave + 4 * i) + t.n] : 0.f;
 #pragma unroll
-    for (int c = 0; c < CH; ++c)
+    for (int c = 0; c < PB; ++c)
 #pragma unroll
         for (int i = 0; i < NTWM; ++i) p.b[c][i] = bw[((size_t)i * 4 * KB2 + c) * 64];
     __builtin_amdgcn_sched_barrier(0);
 }
+
+// request m of the preload (m < NTWM: bias of tile m, then block (m - NTWM) / NTWM, tile (m - NTWM) % NTWM), one per call
+template <int NTWM, bool BIAS>
+struct Bf16Injector {
+    Bf16Pre<NTWM>& p;
+    const uint4* Bh;
+    const float* bias;
+    const Tid& t;
+    static constexpr int KB2 = 2 * NTWM, PB = bf16_pre_blocks<NTWM>(), TOTAL = NTWM + PB * NTWM;
+    template <class M>
+    __device__ __forceinline__ void operator()(M) const {
+        constexpr int m = M::value;
+        if constexpr (m < NTWM) {
+            p.bv[m] = BIAS ? bias[16 * (t.wave + 4 * m) + t.n] : 0.f;
+        } else if constexpr (m < TOTAL) {
+            constexpr int c = (m - NTWM) / NTWM, i = (m - NTWM) % NTWM;
+            p.b[c][i] = Bh[((size_t)t.wave * KB2 + (size_t)i * 4 * KB2 + c) * 64 + t.lane];
+        }
+    }
+    template <int DONE>
+    __device__ __forceinline__ void rest() const {            // the requests with index >= DONE
+        static_for<DONE, (TOTAL > DONE ? TOTAL : DONE)>(*this);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
 
 template <int NTWM, class Mid>
 __device__ __forceinline__ void gemm_bf16(const float* __restrict__ A, int lda, const uint4* __restrict__ Bh, const Tid& t,
@@ -763,6 +836,25 @@ __device__ __forceinline__ void gemm_bf16(const float* __restrict__ A, int lda, 
     constexpr int KB2 = 2 * NTWM;
     constexpr int CH = bf16_chunk<NTWM>();
     const float* arow = A + t.n * lda + 8 * t.q;
+    if constexpr (bf16_pre_blocks<NTWM>() == KB2) {          // everything is already on its way / here
+        static_for<0, KB2>([&](auto Sc) {
+            constexpr int S = decltype(Sc)::value;
+            const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * S);
+            const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * S + 4);
+            union { unsigned u[4]; bf16x8 v; } ua;
+            ua.u[0] = cvt_pk_bf16(a0.x, a0.y); ua.u[1] = cvt_pk_bf16(a0.z, a0.w);
+            ua.u[2] = cvt_pk_bf16(a1.x, a1.y); ua.u[3] = cvt_pk_bf16(a1.z, a1.w);
+            static_for<0, NTWM>([&](auto ic) {
+                constexpr int i = decltype(ic)::value;
+                union { uint4 q; bf16x8 v; } ub;
+                ub.q = pre.b[S][i];
+                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
+                mid.template step<S * NTWM + i>();            // one of the later stages' requests behind each MFMA
+            });
+        });
+        mid.template rest<KB2 * NTWM>();
+        return;
+    }
     const uint4* bw = Bh + ((size_t)t.wave * KB2) * 64 + t.lane;
     uint4 b0[CH][NTWM], b1[CH][NTWM];
 #pragma unroll
@@ -781,6 +873,8 @@ __device__ __forceinline__ void gemm_bf16(const float* __restrict__ A, int lda, 
 // k-blocks per strip (the spline conditioner's K = NFP reverse GEMM is NCH such slices): acc += A[:, slice] @ B[slice, :]
 struct NoMid {
     __device__ __forceinline__ void operator()() const {}
+    template <int M> __device__ __forceinline__ void step() const {}
+    template <int DONE> __device__ __forceinline__ void rest() const {}
 };
 template <int NTWM>
 __device__ __forceinline__ void gemm_bf16_slice(const float* __restrict__ A, int lda, const uint4* __restrict__ Bh, int KB2T,
@@ -857,6 +951,22 @@ __device__ __forceinline__ void inject_all(Inject& inj) {
         inject_all<J + 1, N>(inj);
     }
 }
+
+// hook of the bf16 GEMMs: `step(m)` behind MFMA m (a runtime index into a compile-time switch: the loops around it are
+// fully unrolled, so it folds), `rest(done)` for the requests the MFMAs did not carry, `operator()` = all at once
+template <int NI, class Inject>
+struct MidInject {
+    Inject& inj;
+    template <int M>
+    __device__ __forceinline__ void step() const {
+        if constexpr (M < NI) { __builtin_amdgcn_sched_barrier(0); inj(IC<M>()); __builtin_amdgcn_sched_barrier(0); }
+    }
+    template <int DONE>
+    __device__ __forceinline__ void rest() const {
+        if constexpr (DONE < NI) inject_all<DONE, NI>(inj);
+    }
+    __device__ __forceinline__ void operator()() const { inject_all<0, NI>(inj); }
+};
 
 // OUT[16 x 16*NT] = A[16 x K] @ B   (NT <= 4: one column tile per wave), used for the D x D affine maps.
 // `add` (nullable): per-column additive term [16 * NT] (the ActNorm shift folded into the affine map).
@@ -945,11 +1055,18 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         }
         // ---- conditioner MLP: relu(relu(z1 W1 + b1) W2 + b2) W3' ----------------------------------------
         RingPre<NTWM> rp;                                 // block 0 + bias of the W x W GEMM below: lands during this stage
-        Bf16Pre<NTWM> bp;                                 // fast mode: chunk 0 + bias of the bf16 W x W GEMM instead
-        if constexpr (FAST) bf16pre_load<NTWM, true>(bp, reinterpret_cast<const uint4*>(Lp + f.o_W2h), Lp + f.o_b2, t);
-        else ringpre_load<NTWM, true>(rp, W2, f.KBW, Lp + f.o_b2, t);
-        dense_relu_small<NTWM, 2, GRAD, TAPE>(w1r, Z, l.DS, f.d, HA, l.WS, mk, t,
-                                              TAPE ? tl_layer + td->o_H1 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
+        Bf16Pre<NTWM> bp;                                 // fast mode: the bf16 slice of the W x W GEMM (+ bias) instead,
+        if constexpr (!FAST) ringpre_load<NTWM, true>(rp, W2, f.KBW, Lp + f.o_b2, t);      // requested behind the MFMAs below
+        auto inj_w2h = Bf16Injector<NTWM, true>{bp, reinterpret_cast<const uint4*>(Lp + f.o_W2h), Lp + f.o_b2, t};
+        if constexpr (FAST) {
+            dense_relu_small<NTWM, 2, GRAD, TAPE>(w1r, Z, l.DS, f.d, HA, l.WS, mk, t,
+                                                  TAPE ? tl_layer + td->o_H1 + row0 * td->wh : nullptr, TAPE ? td->wh : 0,
+                                                  inj_w2h);
+            inj_w2h.template rest<8 * NTWM>();                     // what the 8 NTWM MFMAs did not carry
+        } else {
+            dense_relu_small<NTWM, 2, GRAD, TAPE>(w1r, Z, l.DS, f.d, HA, l.WS, mk, t,
+                                                  TAPE ? tl_layer + td->o_H1 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
+        }
         if (tl) FAB_TL(f, 3);
         __syncthreads();
         if (tl) FAB_TL(f, 4);
@@ -988,7 +1105,7 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
             }
         };
         if constexpr (FAST) {
-            auto mid = [&]() { inject_all<0, 5 * NTWM + 6>(inj_fwd); };
+            MidInject<5 * NTWM + 6, decltype(inj_fwd)> mid{inj_fwd};
             dense_relu_bf16<NTWM, GRAD, TAPE>(HA, l.WS, reinterpret_cast<const uint4*>(Lp + f.o_W2h), Lp + f.o_b2, HB, l.WS,
                                               mk + NTHREADS, t, mid, bp,
                                               TAPE ? tl_layer + td->o_H2 + row0 * td->wh : nullptr, TAPE ? td->wh : 0);
@@ -1083,15 +1200,24 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
         if (TAPE) tape_copy(tl_layer + td->o_DP + row0 * td->wp, td->wp, DP, l.PS, t);
         RingPre<NTWM> rpb;                                // block 0 of the W x W GEMM below: lands during this stage
         Bf16Pre<NTWM> bpb;
-        if constexpr (FAST) bf16pre_load<NTWM, false>(bpb, reinterpret_cast<const uint4*>(Lp + f.o_W2Th), nullptr, t);
-        else ringpre_load<NTWM, false>(rpb, W2T, f.KBW, nullptr, t);
-        if (kbo2)
-            dense_masked_small<NTWM, 2, TAPE>(w3a, DP, l.PS, HA, l.WS, mk + NTHREADS, t,
-                                              TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0);
-        else
+        if constexpr (!FAST) ringpre_load<NTWM, false>(rpb, W2T, f.KBW, nullptr, t);
+        auto inj_w2th = Bf16Injector<NTWM, false>{bpb, reinterpret_cast<const uint4*>(Lp + f.o_W2Th), nullptr, t};
+        if (kbo2) {
+            if constexpr (FAST) {
+                dense_masked_small<NTWM, 2, TAPE>(w3a, DP, l.PS, HA, l.WS, mk + NTHREADS, t,
+                                                  TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0,
+                                                  inj_w2th);
+                inj_w2th.template rest<8 * NTWM>();
+            } else {
+                dense_masked_small<NTWM, 2, TAPE>(w3a, DP, l.PS, HA, l.WS, mk + NTHREADS, t,
+                                                  TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr, TAPE ? td->we : 0);
+            }
+        } else {
+            if constexpr (FAST) bf16pre_load<NTWM, false>(bpb, reinterpret_cast<const uint4*>(Lp + f.o_W2Th), nullptr, t);
             dense_masked<NTWM, 2, TAPE>(DP, l.PS, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), HA, l.WS,
                                         mk + NTHREADS, t, TAPE ? tl_layer + td->o_E2 + row0 * td->we : nullptr,
                                         TAPE ? td->we : 0);
+        }
         if (tl) FAB_TL(f, 19);
         __syncthreads();
         if (tl) FAB_TL(f, 20);
@@ -1115,7 +1241,7 @@ __device__ float flow_log_prob_tile(const FlowDims& f, const FlowLds& l, const f
             }
         };
         if constexpr (FAST) {
-            auto mid = [&]() { inject_all<0, 3 * NTWM + 2>(inj_bwd); };
+            MidInject<3 * NTWM + 2, decltype(inj_bwd)> mid{inj_bwd};
             dense_masked_bf16<NTWM, TAPE>(HA, l.WS, reinterpret_cast<const uint4*>(Lp + f.o_W2Th), HB, l.WS, mk, t, mid, bpb,
                                           TAPE ? tl_layer + td->o_E1 + row0 * td->we : nullptr, TAPE ? td->we : 0);
         } else {
