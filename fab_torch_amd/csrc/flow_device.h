@@ -738,39 +738,39 @@ __device__ __forceinline__ f32x4 mfma_bf16(const float4& a0, const float4& a1, c
 // runs once chunk 0 has been multiplied: the requests of the stages after this GEMM go out there (they stay in flight
 // behind chunk 1), not in front of it.  Never more than 63 loads in flight.
 // KB2T: k-blocks per column-tile strip of the packed matrix (its K / 32); a call multiplies 2 NTWM of them (K = 64 NTWM).
+// Chunk C is multiplied out of buffer C & 1 while the loads of chunk C + 1 go out into the other buffer ONE BEHIND EACH
+// MFMA (a burst of loads blocks the issuing wave: see Bf16Injector); at most one chunk (<= 25 loads) + the later stages'
+// requests in flight.  b0 holds chunk 0 on entry.
 template <int NTWM, int CH, int C, class Mid>
 __device__ __forceinline__ void gemm_bf16_chunk(uint4 (&b0)[CH][NTWM], uint4 (&b1)[CH][NTWM], const float* __restrict__ arow,
                                                 const uint4* __restrict__ bw, f32x4 (&acc)[NTWM], Mid& mid, int KB2T) {
     constexpr int KB2 = 2 * NTWM, NCH = (KB2 + CH - 1) / CH;
     if constexpr (C < NCH) {
         uint4 (&b)[CH][NTWM] = (C & 1) ? b1 : b0;
-#pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            const int S = C * CH + c;
-            if (S < KB2) {
+        uint4 (&bn)[CH][NTWM] = (C & 1) ? b0 : b1;
+        static_for<0, CH>([&](auto cc) {
+            constexpr int c = decltype(cc)::value, S = C * CH + c;
+            if constexpr (S < KB2) {
                 const float4 a0 = *reinterpret_cast<const float4*>(arow + 32 * S);
                 const float4 a1 = *reinterpret_cast<const float4*>(arow + 32 * S + 4);
                 union { unsigned u[4]; bf16x8 v; } ua;
                 ua.u[0] = cvt_pk_bf16(a0.x, a0.y); ua.u[1] = cvt_pk_bf16(a0.z, a0.w);
                 ua.u[2] = cvt_pk_bf16(a1.x, a1.y); ua.u[3] = cvt_pk_bf16(a1.z, a1.w);
-#pragma unroll
-                for (int i = 0; i < NTWM; ++i) {
+                static_for<0, NTWM>([&](auto ic) {
+                    constexpr int i = decltype(ic)::value;
                     union { uint4 q; bf16x8 v; } ub;
                     ub.q = b[c][i];
                     acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
-                }
+                    // block (C + 1) CH + c, tile i of the next chunk.  (No sched_barrier pins around this load: pinned, the
+                    // spline kernel's reverse sweep gave run-to-run different gradients at NTWM = 4 - hipcc's own
+                    // placement is deterministic over 30 x 4096-chain repeats and as fast.)
+                    if constexpr ((C + 1) * CH + c < KB2) bn[c][i] = bw[((size_t)i * 4 * KB2T + (C + 1) * CH + c) * 64];
+                });
             }
-        }
-        // two chunks (NTWM <= 5): behind chunk 0, at most 25 + 46 - ... <= 56 loads in flight; more chunks (NTWM = 8, up
-        // to 46 requests): only after the last chunk, when nothing else is in flight
+        });
+        // the later stages' requests: two chunks (NTWM <= 5) - behind chunk 0; more chunks (NTWM = 8, up to 46 requests) -
+        // only after the last chunk, when nothing else is in flight (never more than 63 loads outstanding)
         if constexpr (C == (NCH == 2 ? 0 : NCH - 1)) mid();
-        if constexpr (C + 2 < NCH) {                          // refill this buffer with chunk C + 2
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-#pragma unroll
-                for (int i = 0; i < NTWM; ++i)
-                    if ((C + 2) * CH + c < KB2) b[c][i] = bw[((size_t)i * 4 * KB2T + (C + 2) * CH + c) * 64];
-        }
         gemm_bf16_chunk<NTWM, CH, C + 1>(b0, b1, arow, bw, acc, mid, KB2T);
     }
 }
@@ -861,11 +861,6 @@ __device__ __forceinline__ void gemm_bf16(const float* __restrict__ A, int lda, 
     for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int i = 0; i < NTWM; ++i) b0[c][i] = pre.b[c][i];
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-        for (int i = 0; i < NTWM; ++i)
-            if (CH + c < KB2) b1[c][i] = bw[((size_t)i * 4 * KB2 + CH + c) * 64];
     gemm_bf16_chunk<NTWM, CH, 0>(b0, b1, arow, bw, acc, mid, KB2);
 }
 
@@ -888,11 +883,6 @@ __device__ __forceinline__ void gemm_bf16_slice(const float* __restrict__ A, int
     for (int c = 0; c < CH; ++c)
 #pragma unroll
         for (int i = 0; i < NTWM; ++i) b0[c][i] = bw[((size_t)i * 4 * KB2T + c) * 64];
-#pragma unroll
-    for (int c = 0; c < CH; ++c)
-#pragma unroll
-        for (int i = 0; i < NTWM; ++i)
-            if (CH + c < KB2) b1[c][i] = bw[((size_t)i * 4 * KB2T + CH + c) * 64];
     NoMid mid;
     gemm_bf16_chunk<NTWM, CH, 0>(b0, b1, arow, bw, acc, mid, KB2T);
 }
