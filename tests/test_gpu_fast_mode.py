@@ -157,3 +157,37 @@ def test_fast_mode_of_the_spline_flow_is_the_conditioner_with_bf16_rounded_inner
     assert 0 < dev_32 <= 0.2, f"fast mode vs fp32: {dev_32:.2e}"
     rel = (gf.cpu().double() - g_e).norm(dim=1) / g_e.norm(dim=1)
     assert float(rel.median()) <= 1e-2 and float(rel.max()) <= 0.2, f"grad vs emulation: {float(rel.median()):.2e} / {float(rel.max()):.2e}"
+
+
+def test_fast_mode_with_actnorm_layers_matches_its_emulation():
+    """The folded ActNorm terms (fp32 affine stages) and the bf16 W x W GEMMs together: fast mode of an act_norm=True flow
+    against the float64 emulation, and a fused fast-mode AIS call on it."""
+    D, K, nodes, B = 32, 4, 10, 64
+    torch.manual_seed(3)
+    nf = oflow.make_realnvp(D, K, nodes, act_norm=True)
+    oflow.randomize_last_layers(nf, 0.02, 5)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for f in nf.flows:
+            if isinstance(f, oflow.ActNorm):
+                f.s.copy_(0.1 * torch.randn(1, D, generator=g)); f.t.copy_(0.2 * torch.randn(1, D, generator=g))
+                f.data_dep_init_done.fill_(1.0)
+    hf = fa.RealNVP(D, K, nodes, act_norm=True)
+    hf._nf_model.load_state_dict(nf.state_dict(), strict=True)
+    hf = hf.to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    x, _ = hf.sample_and_log_prob((B,))
+    with fa.fast_mode():
+        pf = fa.create_point(x, hf, target, with_grad=True)
+    em = emulation(nf)
+    xg = x.cpu().double().requires_grad_(True)
+    lq_e = em.log_prob(xg)
+    (g_e,) = torch.autograd.grad(lq_e.sum(), xg)
+    assert float((pf.log_q.cpu().double() - lq_e.detach()).abs().max()) <= 2e-3
+    rel = (pf.grad_log_q.cpu().double() - g_e).norm(dim=1) / g_e.norm(dim=1)
+    assert float(rel.median()) <= 2e-3 and float(rel.max()) <= 5e-2
+    hmc = fa.HamiltonianMonteCarlo(3, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1, L=3).to(DEV)
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, 3)
+    with fa.fast_mode():
+        pt, lw = ais.sample_and_log_weights(256)
+    assert pt.x.shape == (256, D) and torch.isfinite(lw).all()
