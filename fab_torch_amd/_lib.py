@@ -88,7 +88,7 @@ SYMBOLS = [
     "fabhip_ess_logz", "fabhip_multinomial_torch_workspace_bytes", "fabhip_multinomial_torch",
     "fabhip_resample_workspace_bytes", "fabhip_resample_multinomial", "fabhip_resample_systematic",
     "fabhip_gather_rows", "fabhip_debug_timeline", "fabhip_flow_grad_floats", "fabhip_flow_grad_layout",
-    "fabhip_flow_tape_bytes", "fabhip_flow_log_prob_tape", "fabhip_flow_param_grad",
+    "fabhip_flow_tape_bytes", "fabhip_flow_log_prob_tape", "fabhip_flow_param_grad", "fabhip_flow_sample_grad_tape",
     "fabhip_adam_workspace_bytes", "fabhip_adam_clip_step", "fabhip_topk_workspace_bytes", "fabhip_topk",
     "fabhip_flow_pack_density", "fabhip_abi_sizes", "fabhip_flow_tape_layout",
     "fabhip_generic_workspace_bytes", "fabhip_hmc_generic_begin", "fabhip_hmc_generic_leap_pre",
@@ -98,7 +98,7 @@ SYMBOLS = [
     "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
     "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_debug_spline_timeline",
 ]
-ABI_VERSION = 203          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 204          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):
@@ -151,6 +151,7 @@ def _declare(lib):
     lib.fabhip_flow_tape_layout.argtypes = [i32, i32, i32, i64, C.POINTER(i64)]
     lib.fabhip_flow_log_prob_tape.argtypes = [C.POINTER(Flow), vp, vp, vp, i64, vp, sz, vp]
     lib.fabhip_flow_param_grad.argtypes = [C.POINTER(FlowParams), C.POINTER(Flow), vp, sz, vp, i64, vp, vp]
+    lib.fabhip_flow_sample_grad_tape.argtypes = [C.POINTER(Flow), vp, vp, vp, vp, i64, vp, sz, vp]
     lib.fabhip_adam_workspace_bytes.restype = sz
     lib.fabhip_adam_workspace_bytes.argtypes = [i64]
     f32 = C.c_float

@@ -14,7 +14,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 203          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+ABI_VERSION = 204          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
 TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
@@ -91,9 +91,34 @@ def _tape_backward(ctx, g_log_q, g_grad_x, g_tape):
     return flat, gx, None, [None] * ctx.n_params, None, None, None, None      # (Tensor[] slot: a list of that length)
 
 
+# ---- autograd of the sampling op (reparameterised baseline losses) -------------------------------------------------
+def _sample_setup_context(ctx, inputs, output):
+    theta, eps, packed, params, dim, n_layers, width = inputs
+    x, log_q = output
+    ctx.dims = (dim, n_layers, width)
+    ctx.n_params = len(params)
+    ctx.save_for_backward(packed, x, *params)
+
+
+def _sample_backward(ctx, g_x, g_log_q):
+    """One sweep x -> eps (fabhip_flow_sample_grad_tape) writes the density path's tape with the sampling direction's
+    cotangents; the parameter gradients are then the same GEMMs + LU chain rule with unit coefficients."""
+    packed, x = ctx.saved_tensors[:2]
+    params = list(ctx.saved_tensors[2:])
+    gx = torch.zeros_like(x) if g_x is None else g_x.detach().contiguous().float()
+    gl = x.new_zeros(x.shape[0]) if g_log_q is None else g_log_q.detach().contiguous().float()
+    tape, g_eps = torch.ops.fabhip.realnvp_sample_grad_tape(packed, *ctx.dims, x, gx, gl)
+    flat = None
+    if ctx.needs_input_grad[0]:
+        flat = torch.ops.fabhip.realnvp_param_grad(params, packed, *ctx.dims, tape, x.new_ones(x.shape[0]))
+    return flat, (g_eps if ctx.needs_input_grad[1] else None), None, [None] * ctx.n_params, None, None, None
+
+
 def _register_autograd():
     torch.library.register_autograd("fabhip::realnvp_logprob_tape", _tape_backward,
                                     setup_context=_tape_setup_context)
+    torch.library.register_autograd("fabhip::realnvp_sample_tape", _sample_backward,
+                                    setup_context=_sample_setup_context)
 
 
 # ---- shape functions (torch.compile / fake tensors) for the tensor-in / tensor-out density ops ---------------------

@@ -35,6 +35,7 @@ struct FlowDims {
     int o_AW, o_AWT, o_AWI, o_W1, o_W2, o_W3, o_W3T, o_W2T, o_W1T, o_b1, o_b2, o_b3, o_logS;
     int o_ac, o_at;             // ActNorm folded into the affine maps: additive terms of the density / sampling direction
     int o_W2h, o_W2Th;          // fast mode: bf16 images of W2 / W2^T (v_mfma_f32_16x16x32_bf16 B-operand tiles), Wp^2/2 floats each
+    int o_AWIT;                 // (W'^-1)^T tiles: backward of the sampling direction (fabhip_flow_sample_grad_tape)
     int layer_stride;           // floats per layer block
     int o_base;                 // offset of base block: loc[Dp], log_scale[Dp]
     int o_scratch;              // offset of affine scratch: per layer W[D*D], Winv[D*D]
@@ -73,6 +74,7 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     f.o_at = o; o += 64;        // sampling direction: z <- x @ W'^-1 + at, W'^-1 = W^-1 diag(e^s), at = t
     f.o_W2h = o; o += f.Wp * f.Wp / 2;
     f.o_W2Th = o; o += f.Wp * f.Wp / 2;
+    f.o_AWIT = mat(f.KBD, f.NTD);
     f.layer_stride = o;
     f.o_base = K * f.layer_stride;
     f.o_scratch = f.o_base + 2 * f.Dp;

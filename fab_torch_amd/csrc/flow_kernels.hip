@@ -198,6 +198,12 @@ __global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, MlpTab tab, int 
         }
         dst[off] = v;
     }
+    // (W'^-1)^T, appended after the bf16 images: B[k][n] = Winv[n][k]
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.KBD * f.NTD * 256; off += gridDim.x * blockDim.x) {
+        int k, n;
+        tile_kn(off, f.KBD, k, n);
+        dst[f.o_AWIT + off] = (k < D && n < D) ? s.Winv[n * D + k] : 0.f;
+    }
 }
 
 // fast mode: bf16 images of W2 (B[k][n] = w2[n][k]) and W2^T (B[k][n] = w2[k][n]) in v_mfma_f32_16x16x32_bf16 B-operand

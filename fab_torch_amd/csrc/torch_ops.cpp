@@ -218,6 +218,31 @@ Tensor realnvp_param_grad(at::TensorList params, const Tensor& packed, int64_t d
     return flat;
 }
 
+// the differentiable sampling op (reparameterised baseline losses, fab/core.py:130-152): forward = fabhip_flow_sample;
+// autograd is registered from Python (_ops.py), its backward = realnvp_sample_grad_tape + realnvp_param_grad(coef = 1).
+// `theta` is the autograd handle of the parameters, as in realnvp_logprob_tape.
+std::tuple<Tensor, Tensor> realnvp_sample_tape(const Tensor& theta, const Tensor& eps, const Tensor& packed,
+                                               at::TensorList params, int64_t dim, int64_t n_layers, int64_t width) {
+    (void)theta; (void)params;
+    return realnvp_sample(packed, dim, n_layers, width, eps);
+}
+
+std::tuple<Tensor, Tensor> realnvp_sample_grad_tape(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width,
+                                                    const Tensor& x, const Tensor& grad_x, const Tensor& grad_log_q) {
+    c10::DeviceGuard g(x.device());
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0);
+    TORCH_CHECK(grad_x.dim() == 2 && grad_x.size(0) == B && grad_x.size(1) == dim && grad_log_q.numel() == B,
+                "fabhip: grad_x must be [B, dim] and grad_log_q [B]");
+    const size_t nbytes = fabhip_flow_tape_bytes(f.dim, f.n_layers, f.width, B);
+    Tensor tape = fempty({(int64_t)(nbytes / 4 + 1)}, x), g_eps = at::empty_like(x);
+    chk(fabhip_flow_sample_grad_tape(&f, fp(x, "x"), fp(grad_x, "grad_x"), fp(grad_log_q, "grad_log_q"),
+                                     g_eps.data_ptr<float>(), B, tape.data_ptr<float>(), nbytes, stream_of(x)),
+        "flow_sample_grad_tape");
+    return {tape, g_eps};
+}
+
 void adam_clip_step(Tensor theta, const Tensor& grad, Tensor m, Tensor v, double lr, double beta1, double beta2,
                     double eps, Tensor step_count, double max_norm, Tensor grad_norm) {
     c10::DeviceGuard g(theta.device());
@@ -746,6 +771,9 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("realnvp_logprob_tape(Tensor theta, Tensor x, Tensor packed, Tensor[] params, int dim, int n_layers, "
           "int width, bool want_grad_x) -> (Tensor, Tensor, Tensor)");
     m.def("realnvp_param_grad(Tensor[] params, " FLW ", Tensor tape, Tensor coef) -> Tensor");
+    m.def("realnvp_sample_tape(Tensor theta, Tensor eps, Tensor packed, Tensor[] params, int dim, int n_layers, "
+          "int width) -> (Tensor, Tensor)");
+    m.def("realnvp_sample_grad_tape(" FLW ", Tensor x, Tensor grad_x, Tensor grad_log_q) -> (Tensor, Tensor)");
     m.def("adam_clip_step(Tensor(a!) theta, Tensor grad, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, "
           "float eps, Tensor(d!) step_count, float max_norm, Tensor(e!) grad_norm) -> ()");
 
@@ -811,6 +839,8 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("realnvp_logprob_grad", realnvp_logprob_grad);
     m.impl("realnvp_logprob_tape", realnvp_logprob_tape);
     m.impl("realnvp_param_grad", realnvp_param_grad);
+    m.impl("realnvp_sample_tape", realnvp_sample_tape);
+    m.impl("realnvp_sample_grad_tape", realnvp_sample_grad_tape);
     m.impl("adam_clip_step", adam_clip_step);
     m.impl("spline_pack", spline_pack);
     m.impl("spline_logprob_grad", spline_logprob_grad);

@@ -72,6 +72,128 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape(FlowDims f, Flo
 }
 
 // ------------------------------------------------------------------------------------------------
+// Backward of the SAMPLING direction (x, log q = flow.sample(eps); the reparameterised losses flow_reverse_kl /
+// flow_alpha_2_div_nis of fab/core.py:130-152): given x = T(eps), gx = d loss / dx and gl = d loss / d log q, one sweep
+// x -> eps re-evaluates each layer from its output (the conditioner sees the same z1 in both directions) and at the same
+// time propagates the cotangent through the layer's transposed maps, writing the SAME tape the density path writes:
+//   Z1 | H1 | H2   the conditioner's input / hidden activations           DP | E2 | E1   the true cotangents of
+//   (shift, s) and of the two pre-activations      ZA = the affine map's x-side value, GZ = -(cotangent of its z-side
+//   value u): x = (u - ac) W'^-1  =>  d loss / dW' = -x^T (g_x W'^-T) = ZA^T GZ (implicit-function form, so the LU /
+//   ActNorm chain rule of k_affine_grads applies unchanged)         TB = [g_z0 | g_z0 (z0 - loc) - gl | gl]
+// => fabhip_flow_param_grad(tape, coef = 1) returns d loss / d theta (its sum(coef) column is sum(gl): the log-det terms).
+// Stages issue their own prologues (not a hot path: one call per optimiser step of a baseline loss).
+// ------------------------------------------------------------------------------------------------
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_flow_sample_bwd(FlowDims f, FlowLds l, TapeDims td,
+                                                              const float* __restrict__ packed,
+                                                              const float* __restrict__ x, const float* __restrict__ gx,
+                                                              const float* __restrict__ gl, float* __restrict__ g_eps,
+                                                              float* __restrict__ tape, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int DW = depth_w<NTWM>();
+    Tid t;
+    const long row0 = (long)blockIdx.x * ROWS;
+    const int o_U2 = l.total, o_MK = o_U2 + ROWS * l.DS;
+    for (int e = t.tid; e < ROWS * l.PS; e += NTHREADS) lds[l.o_DP + e] = 0.f;
+    for (int e = t.tid; e < ROWS * l.DS; e += NTHREADS) {
+        const int r = e / l.DS, j = e % l.DS;
+        const long g = row0 + r;
+        const bool in = j < f.D && g < B;
+        lds[l.o_U0 + e] = in ? x[g * f.D + j] : 0.f;
+        lds[l.o_U1 + e] = in ? gx[g * f.D + j] : 0.f;
+        lds[o_U2 + e] = 0.f;
+    }
+    const float glr = row0 + t.row < B ? gl[row0 + t.row] : 0.f;
+    __syncthreads();
+    int bx = l.o_U0, bg = l.o_U1, bf = o_U2;              // state (x side), its cotangent, free buffer
+    float* PART = lds + l.o_PART;
+    float* HA = lds + l.o_HA;
+    float* HB = lds + l.o_HB;
+    float* DP = lds + l.o_DP;
+    unsigned* mk = reinterpret_cast<unsigned*>(lds + o_MK);
+    for (int layer = f.K - 1; layer >= 0; --layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        float* tl_layer = tape + (size_t)layer * td.layer_stride;
+        tape_copy(tl_layer + td.o_ZA + row0 * td.wz, td.wz, lds + bx, l.DS, t);
+        // u = x @ W' + ac (the density direction's affine map = the inverse of the sampling direction's)
+        dense_small(lds + bx, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AW), f.NTD, lds + bf, l.DS, t,
+                    Lp + f.o_ac);
+        __syncthreads();
+        // g_u = g_x @ (W'^-1)^T, into the buffer x just left
+        dense_small(lds + bg, l.DS, f.D, f.KBD, reinterpret_cast<const float4*>(Lp + f.o_AWIT), f.NTD, lds + bx, l.DS, t);
+        __syncthreads();
+        { const int tmp = bg; bg = bx; bx = bf; bf = tmp; }
+        float* U = lds + bx;
+        float* G = lds + bg;
+        {
+            float* GZ = tl_layer + td.o_GZ + row0 * td.wz;
+            const int wz = td.wz;
+            for (int e = t.tid; e < ROWS * wz; e += NTHREADS) {
+                const int r = e / wz, j = e - r * wz;
+                GZ[(long)r * wz + j] = -G[r * l.DS + j];
+            }
+            float* Z1 = tl_layer + td.o_Z1 + row0 * td.w1;
+            const int w1 = td.w1, c1 = w1 - 16;
+            for (int e = t.tid; e < ROWS * w1; e += NTHREADS) {
+                const int r = e / w1, j = e - r * w1;
+                Z1[(long)r * w1 + j] = j < f.d ? U[r * l.DS + j] : (j == c1 ? 1.f : 0.f);
+            }
+            const int r = t.tid >> 4, j = t.tid & 15;
+            const float one = j == 0 ? 1.f : 0.f;
+            tl_layer[td.o_H1 + (row0 + r) * td.wh + f.Wp + j] = one;
+            tl_layer[td.o_H2 + (row0 + r) * td.wh + f.Wp + j] = one;
+        }
+        // conditioner, forward: the ReLU sign words stay in LDS for the transposed pass below
+        dense_relu<NTWM, 2, true, true, true>(U, l.DS, f.d, f.KBd, reinterpret_cast<const float4*>(Lp + f.o_W1),
+                                              Lp + f.o_b1, HA, l.WS, mk, t, tl_layer + td.o_H1 + row0 * td.wh, td.wh);
+        __syncthreads();
+        dense_relu<NTWM, DW, false, true, true>(HA, l.WS, f.Wp, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2),
+                                                Lp + f.o_b2, HB, l.WS, mk + NTHREADS, t,
+                                                tl_layer + td.o_H2 + row0 * td.wh, td.wh);
+        __syncthreads();
+        gemm_ksplit<NTWM>(HB, l.WS, reinterpret_cast<const float4*>(Lp + f.o_W3), f.NTO, PART, l.PN, t);
+        __syncthreads();
+        // coupling: sampling direction b2 = a2 e^s + t (log q -= sum s), here u2 = b2 is known and a2 is recovered
+        for (int j = t.c; j < f.DO; j += 16) {
+            const float shift = part_sum(PART, l.PN, t.row, j) + Lp[f.o_b3 + j];
+            const float s = part_sum(PART, l.PN, t.row, f.DOp + j) + Lp[f.o_b3 + f.DOp + j];
+            const float u2 = U[t.row * l.DS + f.d + j], g2 = G[t.row * l.DS + f.d + j];
+            U[t.row * l.DS + f.d + j] = (u2 - shift) * expf(-s);           // a2
+            DP[t.row * l.PS + j] = g2;                                     // d/d shift
+            DP[t.row * l.PS + f.DOp + j] = g2 * (u2 - shift) - glr;        // d/d s  (a2 e^s = u2 - shift; -gl: log-det)
+            G[t.row * l.DS + f.d + j] = g2 * expf(s);                      // d/d a2
+        }
+        __syncthreads();
+        tape_copy(tl_layer + td.o_DP + row0 * td.wp, td.wp, DP, l.PS, t);
+        dense_masked<NTWM, 2, true>(DP, l.PS, f.KBO, reinterpret_cast<const float4*>(Lp + f.o_W3T), HA, l.WS,
+                                    mk + NTHREADS, t, tl_layer + td.o_E2 + row0 * td.we, td.we);
+        __syncthreads();
+        dense_masked<NTWM, DW, true>(HA, l.WS, f.KBW, reinterpret_cast<const float4*>(Lp + f.o_W2T), HB, l.WS, mk, t,
+                                     tl_layer + td.o_E1 + row0 * td.we, td.we);
+        __syncthreads();
+        gemm_ksplit<NTWM>(HB, l.WS, reinterpret_cast<const float4*>(Lp + f.o_W1T), f.NTd, PART, l.PN, t);
+        __syncthreads();
+        for (int j = t.c; j < f.d; j += 16) G[t.row * l.DS + j] += part_sum(PART, l.PN, t.row, j);
+        __syncthreads();
+    }
+    // base distribution: z0 = loc + e^{log_scale} eps, log q has -sum(log_scale)
+    const float* base = packed + f.o_base;
+    const float* Z = lds + bx;
+    const float* G = lds + bg;
+    float* TB = tape + td.o_TB + (row0 + t.row) * td.wb;
+    for (int j = t.c; j < f.D; j += 16) {
+        const float g = G[t.row * l.DS + j], dz = Z[t.row * l.DS + j] - base[j];
+        TB[j] = g;
+        TB[td.wz + j] = g * dz - glr;
+        if (g_eps && row0 + t.row < B) {                 // eps = dz / sc; log q has -eps^2 / 2
+            const float sc = expf(base[f.Dp + j]);
+            g_eps[(row0 + t.row) * f.D + j] = g * sc - glr * (dz / sc);
+        }
+    }
+    TB[2 * td.wz + t.c] = t.c == 0 ? glr : 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------
 // batch-reduction GEMMs.  One workgroup = one 64 x 64 block of one (layer, matrix); wave w owns rows
 // [16 w, 16 w + 16) of the block and all four 16-column tiles.
 // ------------------------------------------------------------------------------------------------
@@ -312,6 +434,17 @@ static int launch_log_prob_tape(const FlowDims& f, const TapeDims& td, const flo
     return check_launch();
 }
 
+template <int NTWM>
+static int launch_sample_bwd(const FlowDims& f, const TapeDims& td, const float* packed, const float* x,
+                             const float* gx, const float* gl, float* g_eps, float* tape, long B, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
+    const FlowLds l = make_flow_lds(f, false);
+    const size_t bytes = ((size_t)l.total + ROWS * l.DS + 2 * NTHREADS) * 4;
+    FAB_TRY(set_max_lds((const void*)k_flow_sample_bwd<NTWM>, bytes));
+    hipLaunchKernelGGL((k_flow_sample_bwd<NTWM>), grid, block, bytes, st, f, l, td, packed, x, gx, gl, g_eps, tape, B);
+    return check_launch();
+}
+
 static size_t tape_floats(const FlowDims& f, const TapeDims& td) {
     return (size_t)td.total + (size_t)f.K * td.wz * td.wz + 16;     // + per-layer affine dW scratch + sum(coef)
 }
@@ -362,6 +495,18 @@ int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* lo
     const TapeDims td = make_tape_dims(f, (long)B);
     if (tape_bytes < tape_floats(f, td) * sizeof(float)) return FABHIP_ENOSPC;
     FAB_DISPATCH_NTW(f, launch_log_prob_tape, f, td, flow->packed, x, log_q, grad_x, (float*)tape, (long)B,
+                     (hipStream_t)stream);
+}
+
+int fabhip_flow_sample_grad_tape(const fabhip_flow* flow, const float* x, const float* grad_x, const float* grad_log_q,
+                                 float* grad_eps, int64_t B, void* tape, size_t tape_bytes, fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !x || !grad_x || !grad_log_q || !tape || B < 0) return FABHIP_EINVAL;
+    FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
+    if (B == 0) return FABHIP_OK;
+    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    const TapeDims td = make_tape_dims(f, (long)B);
+    if (tape_bytes < tape_floats(f, td) * sizeof(float)) return FABHIP_ENOSPC;
+    FAB_DISPATCH_NTW(f, launch_sample_bwd, f, td, flow->packed, x, grad_x, grad_log_q, grad_eps, (float*)tape, (long)B,
                      (hipStream_t)stream);
 }
 

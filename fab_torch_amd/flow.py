@@ -11,10 +11,11 @@ Hot path (no autograd graph requested): `sample_and_log_prob`, `log_prob`, `log_
 fp32-MFMA kernels of csrc/flow_kernels.hip through the C ABI.  When autograd is recording w.r.t. the
 parameters (the trainer's `flow.log_prob(x)` + `loss.backward()`, fab/train_with_prioritised_buffer.py:162-173)
 `log_prob` runs the HIP forward with a tape and `backward` the parameter-gradient GEMM kernels of
-csrc/train_kernels.hip (the custom op `fabhip::realnvp_logprob_tape` and its registered autograd, _ops.py).  There is no CPU path and no stock-PyTorch density path: every entry
-raises `FabhipError` for tensors that are not on the GPU.  The one exception is documented at `_aten_sample`:
-the REPARAMETERISED sampling gradient needed only by the non-FAB baseline losses (`flow_reverse_kl`,
-`flow_alpha_2_div_nis`, fab/core.py:130-152) is expressed with ATen ops on the GPU.
+csrc/train_kernels.hip (the custom op `fabhip::realnvp_logprob_tape` and its registered autograd, _ops.py); the
+REPARAMETERISED sampling gradient of the non-FAB baseline losses (`flow_reverse_kl`, `flow_alpha_2_div_nis`,
+fab/core.py:130-152) is the custom op `fabhip::realnvp_sample_tape` (HIP sampler forward, `k_flow_sample_bwd` + the same
+parameter-gradient kernels backward).  There is no CPU path and no stock-PyTorch path: every entry raises `FabhipError`
+for tensors that are not on the GPU.
 """
 import math
 from typing import Tuple
@@ -141,9 +142,15 @@ class RealNVP(nn.Module):
         dev = self._nf_model.q0.loc.device
         if eps is None:
             eps = torch.randn((shape[0], self.dim), dtype=torch.float32, device=dev)
-        if torch.is_grad_enabled() and self._params_need_grad():
-            self._ensure_act_norm()
-            return self._aten_sample(eps)
+        if torch.is_grad_enabled() and (eps.requires_grad or self._params_need_grad()):
+            # the differentiable sampling op (reparameterised baseline losses, fab/core.py:130-152): forward = the HIP
+            # sampler, backward (registered in _ops.py) = fabhip::realnvp_sample_grad_tape + fabhip::realnvp_param_grad
+            _ops.require_device(eps, "eps")
+            ops = _ops.load()
+            packed, D, K, W = self.native()
+            theta = self._flat_leaf if self._flat_leaf is not None else \
+                torch.cat([p.reshape(-1) for p in self._grad_tensors()])
+            return ops.realnvp_sample_tape(theta, eps.contiguous().float(), packed, self._param_list(), D, K, W)
         return self.native_sample(eps)
 
     def sample(self, shape: Tuple) -> torch.Tensor:
@@ -325,30 +332,6 @@ class RealNVP(nn.Module):
     def log_prob_and_grad(self, x: torch.Tensor):
         """(log q(x), d log q / dx) - what `grad_and_value(x, flow.log_prob)` computes (base.py:50-56)."""
         return self.native_log_prob(x, with_grad=True)
-
-    # ---- reparameterised sampling gradient (baseline losses only, NOT on the FAB path) ------------------------------
-    def _aten_sample(self, eps):
-        """x, log q = flow.sample with an autograd graph w.r.t. the parameters, for `flow_reverse_kl` /
-        `flow_alpha_2_div_nis` (fab/core.py:130-152), the paper's non-FAB baselines.  GPU only (no CPU path)."""
-        _ops.require_device(eps, "eps")
-        q0 = self._nf_model.q0
-        z = q0.loc + torch.exp(q0.log_scale) * eps
-        log_q = -0.5 * self.dim * math.log(2 * math.pi) - torch.sum(q0.log_scale + 0.5 * torch.pow(eps, 2), 1)
-        relu = torch.nn.functional.relu
-        ans = self._act_norms()
-        for k, (l1, l2, l3, aff) in enumerate(self._layers()):
-            z1, z2 = z[:, :self.d], z[:, self.d:]
-            prm = l3(relu(l2(relu(l1(z1)))))
-            shift, scale = prm[:, 0::2], prm[:, 1::2]
-            z2 = z2 * torch.exp(scale) + shift
-            log_q = log_q - torch.sum(scale, dim=1)
-            z = torch.cat([z1, z2], 1) @ aff.assemble(inverse=True)
-            log_q = log_q + torch.sum(aff.log_S)
-            if self.act_norm:
-                an = ans[k]
-                z = z * torch.exp(an.s) + an.t
-                log_q = log_q - torch.sum(an.s)
-        return z, log_q
 
 
 def make_wrapped_normflow_realnvp(dim: int, n_flow_layers: int = 5, layer_nodes_per_dim: int = 10,

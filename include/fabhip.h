@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 203
+#define FABHIP_ABI_VERSION 204
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -210,6 +210,14 @@ int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* lo
                               void* tape, size_t tape_bytes, fabhip_stream_t stream);
 int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* flow, const void* tape,
                            size_t tape_bytes, const float* coef, int64_t B, float* grads, fabhip_stream_t stream);
+/* Backward of the SAMPLING direction - `loss.backward()` through `flow.sample_and_log_prob` for the reparameterised
+ * baseline losses flow_reverse_kl / flow_alpha_2_div_nis (fab/core.py:130-152).  Given x = the samples fabhip_flow_sample
+ * returned, grad_x = d loss / dx [B][dim] and grad_log_q = d loss / d log_q [B], one sweep x -> eps writes the same tape
+ * as fabhip_flow_log_prob_tape (same size and layout) with the sampling direction's cotangents, such that
+ * fabhip_flow_param_grad(params, flow, tape, coef = ones[B], B, grads) returns d loss / d theta.  grad_eps (nullable)
+ * receives d loss / d eps.  `flow->packed` must come from fabhip_flow_pack (with the inverses). */
+int fabhip_flow_sample_grad_tape(const fabhip_flow* flow, const float* x, const float* grad_x, const float* grad_log_q,
+                                 float* grad_eps, int64_t B, void* tape, size_t tape_bytes, fabhip_stream_t stream);
 
 /* One optimiser step on a flat parameter image (the layout of fabhip_flow_grad_layout): global-norm clipping
  * (torch.nn.utils.clip_grad_norm_(params, max_norm), fab/train_with_prioritised_buffer.py:174; max_norm <= 0 = off)
