@@ -210,6 +210,8 @@ struct ScanWs {          // workspace layout (all 256-byte aligned)
     unsigned int* ticket;        // [1] dynamic tile id
     unsigned long long* tile_inc;// [ntiles] inclusive prefix at the end of each tile
     unsigned long long* cdf;     // [n]
+    unsigned long long* cdf16;   // [ceil(n / 16)] cdf16[g] = cdf[min(16 g + 15, n - 1)] (LDS scan only)
+    unsigned long long* cdf256;  // [ceil(n / 256)] the same, every 256th value
     int variant;                 // store-pattern variant (A/B experiments)
 };
 
@@ -550,6 +552,12 @@ __global__ __launch_bounds__(64 * SCAN_NW) void k_scan_fixed_lds(const float* __
     if (lane == 63 && (wave & 1) && wbase - SCAN_WAVE_ITEMS < n)
         ws.tile_inc[((long)blk * SCAN_BLOCK + (long)(wave - 1) * SCAN_WAVE_ITEMS) / SCAN_TILE] = off0 + wtot;
     const unsigned long long base = off0 + lane_excl;
+    {                                                    // sub-sampled CDF: the last value of each 16-group (padding weighs 0)
+        const long g0 = (wbase + 32 * lane) >> 4;
+        if ((g0 << 4) < n) ws.cdf16[g0] = base + run[15];
+        if (((g0 + 1) << 4) < n) ws.cdf16[g0 + 1] = base + run[31];
+        if ((lane & 7) == 7 && wbase + 32 * (lane - 7) < n) ws.cdf256[(wbase + 32 * lane) >> 8] = base + run[31];
+    }
 #pragma unroll
     for (int h = 0; h < 2; ++h) {                        // values 16 h .. 16 h + 15 of every lane
 #pragma unroll
@@ -585,16 +593,99 @@ __device__ __forceinline__ long search_cdf(const ScanWs& ws, long n, long ntiles
     return a < n ? a : n - 1;
 }
 
-__global__ void k_sample_multinomial(ScanWs ws, long n, long ntiles, const double* __restrict__ u, long ns,
-                                     long long* __restrict__ idx) {
+// Multinomial sampler: the thresholds are unordered, so every draw walks the CDF on its own.  A bisection of a 4096-entry
+// tile of the full CDF touches 9 distinct cache lines of an 8N-byte array per draw, and - with thousands of searches in
+// flight per CU - even the last steps inside one line miss the 32 KB L1 again (measured: splitting the tile search over
+// sub-sampled tables cut the time only from 9.6 to 5.1 ms at N = 2^26, more searches in flight per thread made it slower).
+// So below the tile the search is 16-ary over three tables the LDS scan writes - cdf256 (every 256th value, N/32 bytes,
+// L2-resident), cdf16 (N/2 bytes, MALL), the CDF itself - and each 16-entry node is ONE 128-byte line fetched ONCE by a
+// group of 8 lanes (16 bytes each, coalesced); the position inside the node is a ballot + popcount.  A wave serves its
+// 64 draws in 8 rounds (group g, round r: the draw of lane 8 g + r), all 8 rounds of a level in flight together.
+// The tile prefixes are one more 16-ary level; above it the last prefix of every `cs`-th 16-tile node (<= 4096 entries,
+// cs = 1 up to N = 2^28) is bisected in LDS.
+constexpr int MN_COARSE = 4096;
+
+__device__ __forceinline__ long shfl_i64(long v, int src) { return (long)shfl_u64((unsigned long long)v, src); }
+
+// one 16-ary level for the wave's 8 rounds: p[r] (node start, multiple of 16) += entries <= t among the node's 16
+__device__ __forceinline__ void node16_level(const unsigned long long* __restrict__ table, long len, long (&p)[8],
+                                             const unsigned long long (&t)[8], int sub, int gbase) {
+    ulonglong2 v[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = *reinterpret_cast<const ulonglong2*>(table + p[r] + 2 * sub);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const long i0 = p[r] + 2 * sub;
+        const unsigned long long bx = __ballot(i0 < len && v[r].x <= t[r]);
+        const unsigned long long by = __ballot(i0 + 1 < len && v[r].y <= t[r]);
+        p[r] += __popc((unsigned)((bx >> gbase) & 0xffull)) + __popc((unsigned)((by >> gbase) & 0xffull));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sample_multinomial(ScanWs ws, long n, long ntiles, const double* __restrict__ u,
+                                                            long ns, long long* __restrict__ idx) {
+    __shared__ unsigned long long coarse[MN_COARSE];
     const unsigned long long total = ws.tile_inc[ntiles - 1];
-    for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (long)gridDim.x * blockDim.x) {
+    if (ws.variant != 3) {                           // only the LDS scan writes the sub-sampled tables
+        for (long k = (long)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (long)gridDim.x * blockDim.x) {
+            unsigned long long t = 0ull;
+            if (total > 0ull) {
+                t = (unsigned long long)floor(u[k] * (double)total);
+                if (t > total - 1ull) t = total - 1ull;
+            }
+            idx[k] = search_cdf(ws, n, ntiles, t);
+        }
+        return;
+    }
+    // LDS: the inclusive prefix at the end of every `cs`-th 16-tile node (cs = 1 up to N = 2^28)
+    const long nnodes = (ntiles + 15) >> 4;
+    const long cs = (nnodes + MN_COARSE - 1) / MN_COARSE, nc = (nnodes + cs - 1) / cs;
+    for (long i = threadIdx.x; i < nc; i += blockDim.x) {
+        const long j = 16 * (i + 1) * cs - 1;
+        coarse[i] = ws.tile_inc[j < ntiles ? j : ntiles - 1];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, sub = lane & 7, gbase = lane & ~7;
+    const long n256 = (n + 255) >> 8, n16 = (n + 15) >> 4;
+    const long stride = (long)gridDim.x * blockDim.x;
+    for (long w0 = (long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); w0 < ns; w0 += stride) {   // wave-uniform trip count
+        const long k = w0 + lane;
         unsigned long long t = 0ull;
-        if (total > 0ull) {
+        if (k < ns && total > 0ull) {
             t = (unsigned long long)floor(u[k] * (double)total);
             if (t > total - 1ull) t = total - 1ull;
         }
-        idx[k] = search_cdf(ws, n, ntiles, t);
+        // this lane's 16-tile node: first node whose last inclusive prefix exceeds t
+        long lo = 0, hi = nc;
+        while (lo < hi) { const long mid = (lo + hi) >> 1; if (coarse[mid] > t) hi = mid; else lo = mid + 1; }
+        lo *= cs; hi = lo + cs;
+        if (hi > nnodes) hi = nnodes;
+        while (lo < hi) {
+            const long mid = (lo + hi) >> 1, j = 16 * mid + 15;
+            if (ws.tile_inc[j < ntiles ? j : ntiles - 1] > t) hi = mid; else lo = mid + 1;
+        }
+        if (lo > nnodes - 1) lo = nnodes - 1;        // (only when total == 0)
+        long p[8];
+        unsigned long long tr[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            tr[r] = shfl_u64(t, gbase + r);
+            p[r] = shfl_i64(lo, gbase + r) << 4;
+        }
+        node16_level(ws.tile_inc, ntiles, p, tr, sub, gbase);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[r] = (p[r] < ntiles ? p[r] : ntiles - 1) * (SCAN_TILE / 256);
+        node16_level(ws.cdf256, n256, p, tr, sub, gbase);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[r] = (p[r] < n256 ? p[r] : n256 - 1) << 4;
+        node16_level(ws.cdf16, n16, p, tr, sub, gbase);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) p[r] = (p[r] < n16 ? p[r] : n16 - 1) << 4;
+        node16_level(ws.cdf, n, p, tr, sub, gbase);
+        long res = 0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) res = sub == r ? p[r] : res;
+        if (k < ns) idx[k] = (total > 0ull && res < n) ? res : n - 1;
     }
 }
 
@@ -1057,7 +1148,9 @@ static ScanWs carve_scan_ws(void* workspace, long n) {
     ws.desc = (unsigned long long*)p; p += al256((size_t)scan_tiles(n) * 8);
     ws.ticket = (unsigned int*)p; p += 256;
     ws.tile_inc = (unsigned long long*)p; p += al256((size_t)scan_tiles(n) * 8);
-    ws.cdf = (unsigned long long*)p;
+    ws.cdf = (unsigned long long*)p; p += al256((size_t)n * 8);
+    ws.cdf16 = (unsigned long long*)p; p += al256(((size_t)n / 16 + 1) * 8);
+    ws.cdf256 = (unsigned long long*)p;
     { const char* e = getenv("FABHIP_SCAN_VARIANT"); ws.variant = e ? atoi(e) : 3; }   // 3 = LDS-transposed scan; 0-2 = register/shuffle variants (A/B)
     return ws;
 }
@@ -1159,7 +1252,8 @@ int fabhip_multinomial_torch(const float* probs, int64_t n, const double* u, int
 
 size_t fabhip_resample_workspace_bytes(int64_t n) {
     const size_t tiles = (size_t)scan_tiles(n);
-    return al256(1024 * 4) + 256 + al256(tiles * 8) + 256 + al256(tiles * 8) + al256((size_t)n * 8) + 256;
+    return al256(1024 * 4) + 256 + al256(tiles * 8) + 256 + al256(tiles * 8) + al256((size_t)n * 8) +
+           al256(((size_t)n / 16 + 1) * 8) + al256(((size_t)n / 256 + 1) * 8) + 256;
 }
 
 int fabhip_fixed_cdf(const float* log_w, int64_t n, int32_t reuse_max, const uint64_t** cdf_out, void* workspace,

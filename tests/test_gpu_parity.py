@@ -631,3 +631,41 @@ def test_fused_systematic_equals_the_scan_and_search_path_at_2_pow_26(monkeypatc
     counts = torch.bincount(a, minlength=N)
     w = torch.softmax(lw.double(), 0) * N
     assert int(counts.sum()) == N and float((counts.double() - w).abs().max()) <= 1.0 + 1e-3 * float(w.max())
+
+
+@pytest.mark.parametrize("N", [1, 2, 15, 16, 17, 255, 256, 257, 4095, 4096, 4097, 65535, 65536, 65537, 300_001])
+def test_multinomial_16ary_search_edge_sizes_bit_exact_vs_oracle(N):
+    """fabhip_resample_multinomial walks tile prefixes -> cdf256 -> cdf16 -> CDF as 16-entry nodes served by 8-lane groups
+    (k_sample_multinomial): sizes around every node / tile boundary, more and fewer draws than weights, thresholds at the
+    extremes (u = 0 and u -> 1), zero-weight runs at both ends, all weights zero."""
+    rng = np.random.default_rng(1000 + N)
+    lw = (rng.standard_normal(N) * 2.5).astype(np.float32)
+    if N > 40:
+        lw[: N // 9] = -np.inf
+        lw[-(N // 11):] = -np.inf
+    lw_d = torch.tensor(lw).to(DEV)
+    for ns in (N, 3 * N + 5, max(1, N // 3), 1, 63, 64, 65):
+        u = rng.random(ns)
+        u[0] = 0.0
+        u[-1] = np.nextafter(1.0, 0.0)
+        got = fa.multinomial_indices(lw_d, u=torch.tensor(u).to(DEV)).cpu().numpy()
+        np.testing.assert_array_equal(got, onum.multinomial_fixed(lw, u))
+    dead = torch.full((N,), float("-inf"), device=DEV)
+    got = fa.multinomial_indices(dead, u=torch.tensor(rng.random(77)).to(DEV)).cpu().numpy()
+    assert (got == N - 1).all()                        # (outside the oracle's domain: total = 0 maps every draw to n - 1)
+
+
+def test_multinomial_16ary_search_equals_plain_bisection_at_2_pow_26(monkeypatch):
+    """N = 2^26: the node search and the plain two-level bisection (register scan variant, FABHIP_SCAN_VARIANT=2, which
+    writes no sub-sampled tables) return identical indices for a heavy-tailed and a flat weight vector."""
+    N = 1 << 26
+    g = torch.Generator(device=DEV).manual_seed(4)
+    u = torch.rand(N, dtype=torch.float64, device=DEV, generator=g)
+    for sigma in (3.0, 0.0):
+        lw = torch.randn(N, device=DEV, generator=g) * sigma
+        a = fa.multinomial_indices(lw, u=u)
+        monkeypatch.setenv("FABHIP_SCAN_VARIANT", "2")
+        b = fa.multinomial_indices(lw, u=u)
+        monkeypatch.delenv("FABHIP_SCAN_VARIANT")
+        assert torch.equal(a, b)
+        del a, b
