@@ -213,6 +213,7 @@ struct ScanWs {          // workspace layout (all 256-byte aligned)
     unsigned long long* cdf16;   // [ceil(n / 16)] cdf16[g] = cdf[min(16 g + 15, n - 1)] (LDS scan only)
     unsigned long long* cdf256;  // [ceil(n / 256)] the same, every 256th value
     int variant;                 // store-pattern variant (A/B experiments)
+    int want_sub;                // write cdf16 / cdf256 (only the multinomial sampler reads them)
 };
 
 __global__ __launch_bounds__(256) void k_max_partial(const float* __restrict__ lw, long n, float* __restrict__ part) {
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(64 * SCAN_NW) void k_scan_fixed_lds(const float* __
     if (lane == 63 && (wave & 1) && wbase - SCAN_WAVE_ITEMS < n)
         ws.tile_inc[((long)blk * SCAN_BLOCK + (long)(wave - 1) * SCAN_WAVE_ITEMS) / SCAN_TILE] = off0 + wtot;
     const unsigned long long base = off0 + lane_excl;
-    {                                                    // sub-sampled CDF: the last value of each 16-group (padding weighs 0)
+    if (ws.want_sub) {                                   // sub-sampled CDF: the last value of each 16-group (padding weighs 0)
         const long g0 = (wbase + 32 * lane) >> 4;
         if ((g0 << 4) < n) ws.cdf16[g0] = base + run[15];
         if (((g0 + 1) << 4) < n) ws.cdf16[g0 + 1] = base + run[31];
@@ -1151,6 +1152,7 @@ static ScanWs carve_scan_ws(void* workspace, long n) {
     ws.cdf = (unsigned long long*)p; p += al256((size_t)n * 8);
     ws.cdf16 = (unsigned long long*)p; p += al256(((size_t)n / 16 + 1) * 8);
     ws.cdf256 = (unsigned long long*)p;
+    ws.want_sub = 0;
     { const char* e = getenv("FABHIP_SCAN_VARIANT"); ws.variant = e ? atoi(e) : 3; }   // 3 = LDS-transposed scan; 0-2 = register/shuffle variants (A/B)
     return ws;
 }
@@ -1272,7 +1274,8 @@ int fabhip_resample_multinomial(const float* log_w, int64_t n, const double* u, 
     if (((size_t)workspace & 255) != 0) return FABHIP_EINVAL;
     if (workspace_bytes < fabhip_resample_workspace_bytes(n)) return FABHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
-    const ScanWs ws = carve_scan_ws(workspace, n);
+    ScanWs ws = carve_scan_ws(workspace, n);
+    ws.want_sub = 1;
     FAB_TRY(build_fixed_cdf(log_w, n, ws, st));
     if (n_samples > 0)
         hipLaunchKernelGGL(k_sample_multinomial, dim3(grid_for(n_samples, 256, 4096)), dim3(256), 0, st, ws, (long)n,
