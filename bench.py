@@ -277,8 +277,11 @@ def main():
         t_kernel = time_transition(B_PER_GPU)
         flop = B_PER_GPU * L * 2 * F_FWD                  # flow fwd + d/dx per leapfrog (target flops ignored)
         ach = flop / t_kernel / 1e12
-        n_wg = (B_PER_GPU + 15) // 16                     # 16 chains per workgroup, one workgroup per CU
-        roof = {"bound": "mfma", "kernel": "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)", "achieved": ach,
+        r4 = B_PER_GPU <= 1152 and os.environ.get("FABHIP_R4", "") != "0"     # 4-chain tiles (flow_r4.h) below 1153 chains
+        n_wg = (B_PER_GPU + 3) // 4 if r4 else (B_PER_GPU + 15) // 16
+        kname = "k_hmc_step_r4<5> (4 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r4 else \
+            "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)"
+        roof = {"bound": "mfma", "kernel": kname, "achieved": ach,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": None, "ms_per_launch": t_kernel * 1e3, "flop_per_launch": flop,
                 "workgroups": n_wg, "frac_of_occupied_cus": ach / (PEAK_FP32_MFMA_TFLOPS * min(n_wg, 256) / 256)}
@@ -291,7 +294,7 @@ def main():
                     roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
                 roof["traffic_source"] = f"profiles/{rnd}/hmc_step_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
                 break
-        # the headline workload fills 64 of 256 CUs; the same kernel with one workgroup per CU (4096 chains):
+        # 16-chain tiles (k_hmc_step<5>) with one workgroup per CU (4096 chains):
         t_full = time_transition(4096)
         ach_full = 4096 * L * 2 * F_FWD / t_full / 1e12
         roof["full_chip"] = {"chains": 4096, "ms_per_launch": t_full * 1e3, "achieved": ach_full,

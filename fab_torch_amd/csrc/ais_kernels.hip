@@ -9,6 +9,7 @@
 // in a fixed order (deterministic).
 #include "flow_device.h"
 #include "target_device.h"
+#include "flow_r4.h"
 #include "launch.h"
 
 #pragma clang fp contract(off)   // keep a*b+c un-fused in the elementwise code, like the eager CPU reference
@@ -190,6 +191,8 @@ struct HmcK {
     float max_grad;
     float* part_acc;                 // [nblk] sum of min(1, acceptance prob)
     float* part_dist;                // [nblk] sum of the store_info distance
+    float* row_acc;                  // 4-chain tiles: the same two quantities per chain [16 nblk]; k_hmc_adapt adds them
+    float* row_dist;                 //   in the 16-chain kernel's order (16 rows, then blocks)
 };
 
 template <int NTWM, bool FAST>
@@ -317,10 +320,155 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_fast(FlowDims f, FlowLds 
     hmc_step_body<NTWM, true>(f, l, x, packed, tg, a, lds);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same HMC outer step for FOUR chains per workgroup (flow_r4.h): used when 16-chain tiles would leave most of
+// the chip idle (B <= 1152: 1024 chains = 256 workgroups instead of 64).  Element-wise work runs on wave 0 with the
+// 16-chain code's (row = tid >> 4, c = tid & 15) mapping; acceptance / distance contributions go out per chain.
+// ------------------------------------------------------------------------------------------------
+struct ExtraLds4 {
+    int o_XP, o_P, o_GU, o_GP, total;
+};
+static inline ExtraLds4 make_extra_lds4(const R4Lds& l, int D) {
+    ExtraLds4 e;
+    int o = l.total;
+    e.o_XP = o; o += R4 * D;
+    e.o_P = o; o += R4 * D;
+    e.o_GU = o; o += R4 * D;
+    e.o_GP = o; o += R4 * D;
+    e.total = (o + 3) & ~3;
+    return e;
+}
+
+template <int NTWM, bool BIGD>
+__global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
+                                                          const float* __restrict__ packed, TargetDev tg, HmcK a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid4 t4;
+    Tid t;                                           // (row, c) of the element-wise mapping; valid rows: tid < 64
+    const int D = f.D;
+    const long nv = a.n_valid ? (long)*a.n_valid : a.B;
+    const long row0 = (long)blockIdx.x * R4;
+    const bool ew = t.tid < 64;
+    const long g = row0 + t.row;
+    if (row0 >= nv) {
+        if (ew && t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = 0.f; a.row_dist[g] = 0.f; }
+        return;
+    }
+    float* XP = lds + x.o_XP;
+    float* P = lds + x.o_P;
+    float* GU = lds + x.o_GU;
+    float* GP = lds + x.o_GP;
+    const bool active = ew && g < nv;
+    const float eps = *a.eps_ptr + *a.ceps_ptr;
+    for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
+    float k0 = 0.f;
+    if (ew) {
+        for (int j = t.c; j < D; j += 16) {
+            const float m = a.mass[j];
+            float xs = 0.f, p = 0.f, gu = 0.f;
+            if (active) {
+                xs = a.start.x[g * D + j];
+                p = a.noise_p[g * D + j] * m;
+                const float gr = -(a.c.g_q * a.start.gq[g * D + j] + a.c.g_p * a.start.gp[g * D + j]);
+                gu = clamp_nan0(gr, a.max_grad);
+            }
+            XP[t.row * D + j] = xs; P[t.row * D + j] = p; GU[t.row * D + j] = gu;
+            k0 += p * p / m;
+        }
+        k0 = row16_sum(k0) / 2.f;
+    }
+    float lq_c = 0.f, lp_c = 0.f;
+    if (active) { lq_c = a.cur.lq[g]; lp_c = a.cur.lp[g]; }
+    const float logp_cur = (a.c.c_q * lq_c + a.c.c_p * lp_c) - k0;
+    float lq = 0.f, lp = 0.f;
+    int goff = 0;
+    for (int step = 0; step < a.L; ++step) {
+        if (ew) {
+            for (int j = t.c; j < D; j += 16) {
+                const float m = a.mass[j];
+                float p = P[t.row * D + j] - eps * GU[t.row * D + j] / 2.f;
+                const float xn = XP[t.row * D + j] + eps / m * p;
+                P[t.row * D + j] = p; XP[t.row * D + j] = xn;
+            }
+        }
+        __syncthreads();
+        for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) {
+            const int r = e / R4_DS, j = e % R4_DS;
+            lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
+        }
+        __syncthreads();
+        lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2>(f, rd, l, packed, lds, t4, &goff);
+        if (ew) {
+            lp = target_tile<true>(tg, XP, D, GP, D, t);
+            for (int j = t.c; j < D; j += 16) {
+                const float gr = -(a.c.g_q * lds[goff + t.row * R4_DS + j] + a.c.g_p * GP[t.row * D + j]);
+                const float gu = clamp_nan0(gr, a.max_grad);
+                GU[t.row * D + j] = gu;
+                P[t.row * D + j] = P[t.row * D + j] - eps * gu / 2.f;
+            }
+        }
+    }
+    if (!ew) return;
+    // Metropolis test (hmc.py:105-124)
+    float k1 = 0.f, dist2 = 0.f;
+    for (int j = t.c; j < D; j += 16) {
+        const float p = P[t.row * D + j];
+        k1 += p * p / a.mass[j];
+        if (active) { const float dx = a.cur.x[g * D + j] - XP[t.row * D + j]; dist2 += dx * dx; }
+    }
+    k1 = row16_sum(k1) / 2.f;
+    dist2 = row16_sum(dist2);
+    const float logp_prop = (a.c.c_q * lq + a.c.c_p * lp) - k1;
+    const float delta = logp_prop - logp_cur;
+    const bool valid = isfinite(delta);
+    const float dd = valid ? delta : -INFINITY;
+    bool accept = false;
+    float contrib = 0.f, dist = 0.f;
+    if (active) {
+        accept = valid && (dd > -a.noise_e[g]);
+        contrib = expf(fminf(dd, 0.f));
+        dist = accept ? 0.f : sqrtf(dist2);
+    }
+    if (a.prop_out.x && active) {
+        for (int j = t.c; j < D; j += 16) {
+            a.prop_out.x[g * D + j] = XP[t.row * D + j];
+            a.prop_out.gq[g * D + j] = lds[goff + t.row * R4_DS + j];
+            a.prop_out.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) { a.prop_out.lq[g] = lq; a.prop_out.lp[g] = lp; }
+    }
+    if (accept) {
+        for (int j = t.c; j < D; j += 16) {
+            a.cur.x[g * D + j] = XP[t.row * D + j];
+            a.cur.gq[g * D + j] = lds[goff + t.row * R4_DS + j];
+            a.cur.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) { a.cur.lq[g] = lq; a.cur.lp[g] = lp; }
+    }
+    if (a.log_w && active && t.c == 0) {
+        const float lqf = accept ? lq : lq_c, lpf = accept ? lp : lp_c;
+        const float num = a.nx.c_q * lqf + a.nx.c_p * lpf;
+        const float den = a.c.c_q * lqf + a.c.c_p * lpf;
+        a.log_w[g] = a.log_w[g] + (num - den);
+    }
+    if (t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = contrib; a.row_dist[g] = dist; }
+}
+
 // step-size adaptation from the block partials (hmc.py:122-123,162-170), fixed summation order
-__global__ void k_hmc_adapt(const float* __restrict__ part_acc, const float* __restrict__ part_dist, int nblk,
+// (4-chain tiles hand over per-chain values: the 64 threads first add each block's 16 rows in row order, which is
+// what a 16-chain workgroup writes, so both tile shapes give the step-size rule bit-identical sums)
+__global__ void k_hmc_adapt(float* __restrict__ part_acc, float* __restrict__ part_dist, int nblk,
                             const int* n_valid, long B, float* eps_ptr, float* ceps_ptr, float target_p_accept,
-                            int tune, float* p_accept_out, float* dist_out) {
+                            int tune, float* p_accept_out, float* dist_out, const float* __restrict__ row_acc,
+                            const float* __restrict__ row_dist) {
+    if (row_acc) {
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
+            float s = 0.f, d = 0.f;
+            for (int r = 0; r < ROWS; ++r) { s += row_acc[(long)b * ROWS + r]; d += row_dist[(long)b * ROWS + r]; }
+            part_acc[b] = s; part_dist[b] = d;
+        }
+        __syncthreads();
+    }
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long nv = n_valid ? (long)*n_valid : B;
     if (nv <= 0) return;
@@ -586,6 +734,37 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
     return check_launch();
 }
 
+// 4-chain tiles pay when 16-chain tiles cannot fill the chip: up to 288 workgroups of 4 chains (B <= 1152); off in fast
+// mode (no bf16 variant of the 4-chain kernel).  FABHIP_R4=0 / 1 forces the choice (tests exercise both shapes).
+static bool use_r4_tiles(long B) {
+    if (fast_mode()) return false;
+    const char* e = getenv("FABHIP_R4");
+    if (e && e[0] == '0') return false;
+    if (e && e[0] == '1') return true;
+    return B <= 1152;
+}
+
+long long* debug_timeline(hipStream_t st);           // flow_kernels.hip (dev-only stage stamps)
+
+template <int NTWM>
+static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const TargetDev& tg, const HmcK& a, hipStream_t st) {
+    FlowDims f = f0;
+    f.timeline = debug_timeline(st);
+    const R4Dims rd = make_r4_dims(f);
+    const R4Lds l = make_r4_lds(f);
+    const ExtraLds4 x = make_extra_lds4(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    const dim3 grid((unsigned)((a.B + R4 - 1) / R4));
+    if (f.D > 32) {
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, true>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+    } else {
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, false>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+    }
+    return check_launch();
+}
+
 template <int NTWM>
 static int launch_metropolis(const FlowDims& f, const float* packed, const TargetDev& tg, const MetK& a, hipStream_t st) {
     const FlowLds l = make_flow_lds(f, false);
@@ -605,6 +784,9 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
     char* ws = (char*)a->workspace;
     float* part_acc = (float*)ws; ws += align256((size_t)nblk * 4);
     float* part_dist = (float*)ws; ws += align256((size_t)nblk * 4);
+    float* row_acc = (float*)ws; ws += align256((size_t)nblk * ROWS * 4);
+    float* row_dist = (float*)ws; ws += align256((size_t)nblk * ROWS * 4);
+    const bool r4 = use_r4_tiles(a->B);
     PointDev prop{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (a->n_outer > 1) {
         float* pb = (float*)ws;
@@ -623,10 +805,13 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
         k.noise_e = a->noise_e + (size_t)n * a->B;
         k.eps_ptr = a->epsilons + n; k.ceps_ptr = a->common_epsilon; k.mass = a->mass;
         k.L = a->L; k.max_grad = a->max_grad; k.part_acc = part_acc; k.part_dist = part_dist;
-        FAB_DISPATCH_NTW_NORET(f, launch_hmc_step, f, a->flow.packed, tg, k, st);
+        k.row_acc = row_acc; k.row_dist = row_dist;
+        if (r4) FAB_DISPATCH_NTW_NORET(f, launch_hmc_step_r4, f, a->flow.packed, tg, k, st);
+        else FAB_DISPATCH_NTW_NORET(f, launch_hmc_step, f, a->flow.packed, tg, k, st);
         hipLaunchKernelGGL(k_hmc_adapt, dim3(1), dim3(64), 0, st, part_acc, part_dist, nblk, a->n_valid, (long)a->B,
                            a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
-                           a->p_accept ? a->p_accept + n : nullptr, a->avg_distance);
+                           a->p_accept ? a->p_accept + n : nullptr, a->avg_distance,
+                           r4 ? row_acc : (const float*)nullptr, r4 ? row_dist : (const float*)nullptr);
         FAB_TRY(check_launch());
     }
     return FABHIP_OK;
@@ -688,7 +873,7 @@ int fabhip_create_point(const fabhip_flow* flow, const fabhip_target* target, co
 
 size_t fabhip_hmc_workspace_bytes(int64_t B, int32_t dim, int32_t n_outer) {
     const size_t nblk = (size_t)nblk_of(B);
-    size_t s = 2 * align256(nblk * 4);
+    size_t s = 2 * align256(nblk * 4) + 2 * align256(nblk * ROWS * 4);      // block partials + per-chain values (4-chain tiles)
     if (n_outer > 1) s += align256((size_t)B * (3 * dim + 2) * 4);
     return s + 256;
 }

@@ -39,6 +39,7 @@ struct FlowDims {
     int layer_stride;           // floats per layer block
     int o_base;                 // offset of base block: loc[Dp], log_scale[Dp]
     int o_scratch;              // offset of affine scratch: per layer W[D*D], Winv[D*D]
+    int o_r4;                   // 4-chain-tile weight image (flow_r4.h: R4Dims), K layer blocks
     int total;                  // total floats
     long long* timeline;        // dev-only: s_memtime stamps of workgroup 0 (nullptr in production)
 };
@@ -78,7 +79,9 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     f.layer_stride = o;
     f.o_base = K * f.layer_stride;
     f.o_scratch = f.o_base + 2 * f.Dp;
-    f.total = f.o_scratch + K * 2 * D * D;
+    f.o_r4 = f.o_scratch + K * 2 * D * D;
+    // per layer: AW, AWT [pad16(D) x 64], W1 [pad16(d) x Wp], W2, W2T [Wp x Wp], W3, W1T [Wp x 64], W3T [pad16(2 DOp) x Wp]
+    f.total = f.o_r4 + K * (2 * pad16(D) * 64 + pad16(f.d) * f.Wp + 2 * f.Wp * f.Wp + 2 * f.Wp * 64 + pad16(2 * f.DOp) * f.Wp);
     f.timeline = nullptr;
     return f;
 }

@@ -1,5 +1,6 @@
 // RealNVP flow: parameter packing, log_prob (+ d/dx) and sampling kernels + their C ABI.
 #include "flow_device.h"
+#include "flow_r4.h"
 #include "launch.h"
 #include <stdlib.h>
 
@@ -333,6 +334,40 @@ static int launch_log_prob(const FlowDims& f, const float* packed, const float* 
     return check_launch();
 }
 
+// 4-chain-tile image (flow_r4.h): float4 tile (q, g) of a matrix B[K][N], lane l = { B[4 q + kk][64 g + l] } kk < 4,
+// tiles q-major.  One workgroup column per layer (blockIdx.y), grid-stride over the layer block.
+__global__ __launch_bounds__(256) void k_pack_r4(FlowDims f, R4Dims rd, MlpTab tab, int k0, float* __restrict__ packed) {
+    const int D = f.D, d = f.d, DO = f.DO, W = f.W;
+    const int y = blockIdx.y, layer = k0 + y;
+    float* __restrict__ dst = packed + f.o_r4 + (size_t)layer * rd.layer_stride;
+    const float* Wm = packed + f.o_scratch + (size_t)layer * 2 * D * D;       // W' (assembled, ActNorm folded)
+    const float *w1 = tab.w1[y], *w2 = tab.w2[y], *w3 = tab.w3[y];
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < rd.layer_stride; off += gridDim.x * blockDim.x) {
+        int base, G;
+        if (off < rd.o_AWT) { base = rd.o_AW; G = 1; }
+        else if (off < rd.o_W1) { base = rd.o_AWT; G = 1; }
+        else if (off < rd.o_W2) { base = rd.o_W1; G = rd.G; }
+        else if (off < rd.o_W3) { base = rd.o_W2; G = rd.G; }
+        else if (off < rd.o_W3T) { base = rd.o_W3; G = 1; }
+        else if (off < rd.o_W2T) { base = rd.o_W3T; G = rd.G; }
+        else if (off < rd.o_W1T) { base = rd.o_W2T; G = rd.G; }
+        else { base = rd.o_W1T; G = 1; }
+        const int e = off - base, kk = e & 3, l = (e >> 2) & 63, tile = e >> 8;
+        const int g = tile % G, q = tile / G;
+        const int k = 4 * q + kk, n = 64 * g + l;
+        float v = 0.f;
+        if (base == rd.o_AW) { if (k < D && n < D) v = Wm[k * D + n]; }
+        else if (base == rd.o_AWT) { if (k < D && n < D) v = Wm[n * D + k]; }
+        else if (base == rd.o_W1) { if (k < d && n < W) v = w1[n * d + k]; }
+        else if (base == rd.o_W2) { if (k < W && n < W) v = w2[n * W + k]; }
+        else if (base == rd.o_W3) { const int o = prm_orig(n, DO, f.DOp); if (k < W && n < 2 * f.DOp && o >= 0) v = w3[o * W + k]; }
+        else if (base == rd.o_W3T) { const int o = prm_orig(k, DO, f.DOp); if (k < 2 * f.DOp && o >= 0 && n < W) v = w3[o * W + n]; }
+        else if (base == rd.o_W2T) { if (k < W && n < W) v = w2[k * W + n]; }
+        else { if (k < W && n < d) v = w1[k * d + n]; }
+        dst[off] = v;
+    }
+}
+
 template <int NTWM>
 static int launch_sample(const FlowDims& f, const float* packed, const float* eps, float* x, float* log_q, long B,
                          hipStream_t st) {
@@ -350,6 +385,15 @@ using namespace fab;
 
 // dev-only stage timeline (FABHIP_TIMELINE=1): 64 s_memtime stamps written by workgroup 0 of fabhip_flow_log_prob
 static long long* g_timeline = nullptr;
+namespace fab {
+// dev-only (FABHIP_TIMELINE=1): the 64-stamp buffer, zeroed on `st`; nullptr when the switch is off
+long long* debug_timeline(hipStream_t st) {
+    if (!getenv("FABHIP_TIMELINE")) return nullptr;
+    if (!g_timeline && hipMalloc((void**)&g_timeline, 64 * 8) != hipSuccess) return nullptr;
+    (void)hipMemsetAsync(g_timeline, 0, 64 * 8, st);
+    return g_timeline;
+}
+}  // namespace fab
 
 namespace fab {
 static int g_fast_mode = 0;
@@ -405,6 +449,8 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
         const int nblk = ceil_div(f.o_logS, 256 * 4);
         hipLaunchKernelGGL(k_pack_layer, dim3(nblk, nl), dim3(256), 0, st, f, mt, k0, packed);
         hipLaunchKernelGGL(k_pack_bf16, dim3(ceil_div(f.Wp * f.Wp, 256 * 4), nl), dim3(256), 0, st, f, mt, k0, packed);
+        const R4Dims rd = make_r4_dims(f);
+        hipLaunchKernelGGL(k_pack_r4, dim3(ceil_div(rd.layer_stride, 256 * 8), nl), dim3(256), 0, st, f, rd, mt, k0, packed);
     }
     hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();

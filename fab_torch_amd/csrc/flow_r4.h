@@ -1,0 +1,466 @@
+// 4-chain tiles (R4): the flow density + d/dx for FOUR chains per workgroup on v_mfma_f32_4x4x1_16b_f32.
+//
+// Why a second tile shape: the 16-chain tile code (flow_device.h) gives B / 16 workgroups - 64 of 256 CUs at the
+// headline batch of 1024 chains, and its time per launch is flat from 16 to 4096 chains (per-workgroup dependent
+// chain).  With 4 chains per workgroup 1024 chains fill the chip; a workgroup then does a quarter of the MFMA work but
+// still streams ALL the weights, so the stages are bound by the L2 -> VGPR weight stream (tools/ubench/stream.hip:
+// 56 B/clk per CU with 256 workgroups reading the same 10 MB in lockstep) instead of by the matrix pipe.
+//
+// GEMM shape: OUT[4][N] = ACT[4][K] @ B[K][N].  v_mfma_f32_4x4x1_16b computes 16 independent 4x4 outer products:
+// lane l = 4 b + j supplies A[b][i = l % 4] and B[b][j], and holds D[b][i = VGPR r][j].  Block b of column group g is
+// columns 64 g + 4 b .. + 3, so lane l owns column 64 g + l of the group: ONE instruction = 4 chains x 64 columns x 1 k.
+// K is split over the 4 waves (wave w: k-quads [w Q/4, (w+1) Q/4), Q = Kp / 4); the four partial [4][N] products go
+// through LDS and are added in a fixed order by the epilogue (bias, ReLU + sign bits / sign-bit mask), which every
+// thread runs for N / 64 of the 4 N outputs.
+// Packed image of a matrix (k_pack_r4): float4 tile (q, g), lane l = { B[4 q + kk][64 g + l] } kk < 4, tiles ordered
+// q-major: every load instruction of a wave is one contiguous 1-KiB block, a wave's K range is one contiguous stream.
+#pragma once
+#include "flow_device.h"
+#include "target_device.h"
+
+namespace fab {
+
+constexpr int R4 = 4;                  // chains per workgroup
+constexpr int R4_DS = MAX_DIM + 4;     // leading dim of the state / parameter buffers (D <= 64)
+
+// geometry of the r4 weight image of one layer (floats), appended to the packed flow image at FlowDims::o_r4
+struct R4Dims {
+    int Kd, Ko, KD;                    // padded K extents: conditioner input d, coupling parameters 2 DOp, state D (Kw = Wp)
+    int G;                             // hidden column groups: Wp / 64
+    int o_AW, o_AWT, o_W1, o_W2, o_W3, o_W3T, o_W2T, o_W1T, layer_stride;
+};
+
+FAB_HD R4Dims make_r4_dims(const FlowDims& f) {
+    R4Dims r;
+    r.Kd = pad16(f.d); r.Ko = pad16(2 * f.DOp); r.KD = pad16(f.D);
+    r.G = f.Wp / 64;
+    int o = 0;
+    r.o_AW = o; o += r.KD * 64;        // [D -> D]   (N padded to 64)
+    r.o_AWT = o; o += r.KD * 64;
+    r.o_W1 = o; o += r.Kd * f.Wp;      // [d -> W]
+    r.o_W2 = o; o += f.Wp * f.Wp;      // [W -> W]
+    r.o_W3 = o; o += f.Wp * 64;        // [W -> shift | scale]
+    r.o_W3T = o; o += r.Ko * f.Wp;     // [shift | scale -> W]
+    r.o_W2T = o; o += f.Wp * f.Wp;
+    r.o_W1T = o; o += f.Wp * 64;       // [W -> d]
+    r.layer_stride = o;
+    return r;
+}
+
+// LDS plan of an r4 workgroup (floats)
+struct R4Lds {
+    int WS, PN;                        // leading dims: hidden activations, partial products
+    int o_X0, o_X1, o_HA, o_HB, o_PRM, o_DP, o_PART, o_ES, o_V2, o_MASK, total;
+};
+
+FAB_HD R4Lds make_r4_lds(const FlowDims& f) {
+    R4Lds l;
+    l.WS = f.Wp + 4;                   // (Wp + 4) * 4 bytes = 16 mod 128: the 4 rows' 16-byte A reads hit 4 different bank groups
+    l.PN = f.Wp;
+    int o = 0;
+    l.o_X0 = o; o += R4 * R4_DS;
+    l.o_X1 = o; o += R4 * R4_DS;
+    l.o_HA = o; o += R4 * l.WS;
+    l.o_HB = o; o += R4 * l.WS;
+    l.o_PRM = o; o += R4 * R4_DS;
+    l.o_DP = o; o += R4 * R4_DS;
+    l.o_PART = o; o += NWAVE * R4 * l.PN;
+    l.o_ES = o; o += f.K * R4 * f.DOp;
+    l.o_V2 = o; o += f.K * R4 * f.DOp;
+    l.o_MASK = o; o += f.K * 2 * NTHREADS;
+    l.total = (o + 3) & ~3;
+    return l;
+}
+
+__device__ __forceinline__ f32x4 mfma44(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0);
+}
+
+// thread roles: GEMMs use all 4 waves; the element-wise stages run on wave 0 as 4 rows x 16 lanes (row = tid >> 4,
+// c = tid & 15: the 16-chain code's mapping restricted to its first 4 rows, so row16_sum / target_tile apply as they are)
+struct Tid4 {
+    int tid, wave, lane, arow;
+    __device__ __forceinline__ Tid4() {
+        tid = threadIdx.x;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lane = tid & 63;
+        arow = lane & 3;               // the chain whose activations this lane feeds to the MFMA
+    }
+};
+
+// ---- weight tiles requested one stage ahead --------------------------------------------------------------------
+// hipcc puts s_waitcnt vmcnt(0) in front of every workgroup barrier, so a request issued inside a short stage is
+// waited for at that stage's own barrier (measured: every short stage then lasts one L2 / MALL latency, 2 - 3 k cycles).
+// Weights are therefore requested only from inside the long W x W stages (see flow_log_prob_r4).
+template <int NQ, int G>
+struct R4Pre {
+    float4 b[NQ][G];                   // tiles (q, g) of the first NQ k-quads of this wave's K range
+};
+
+// nq_valid <= NQ quads starting at this wave's quad `qbase`
+template <int NQ, int G>
+__device__ __forceinline__ void r4_preload(R4Pre<NQ, G>& p, const float4* __restrict__ Bm, int qbase, int nq_valid,
+                                           const Tid4& t) {
+    const float4* bw = Bm + ((size_t)qbase * G) * 64 + t.lane;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+            if (q < nq_valid) p.b[q][g] = bw[(size_t)(q * G + g) * 64];
+}
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() carries an all-address-space fence, for which hipcc
+// emits s_waitcnt vmcnt(0) - every weight request in flight would be waited for at every barrier.  The stages exchange
+// data through LDS only, so lgkmcnt(0) + s_barrier is sufficient; the "memory" clobber keeps the compiler from moving
+// LDS accesses across it, and the registers of pending (compiler-tracked) global loads are still waited for at first use.
+__device__ __forceinline__ void r4_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// quads [Q0, Q1) of a preload (the ring of the next W x W GEMM is requested a few quads per short stage: a burst of
+// requests blocks the issuing wave until the memory pipe has taken it, ~16 cycles per KiB and CU)
+template <int Q0, int Q1, int NQ, int G>
+__device__ __forceinline__ void r4_preload_part(R4Pre<NQ, G>& p, const float4* __restrict__ Bm, int qbase, const Tid4& t) {
+    const float4* bw = Bm + ((size_t)qbase * G) * 64 + t.lane;
+#pragma unroll
+    for (int q = Q0; q < Q1 && q < NQ; ++q)
+#pragma unroll
+        for (int g = 0; g < G; ++g) p.b[q][g] = bw[(size_t)(q * G + g) * 64];
+}
+
+struct R4NoNext {
+    __device__ __forceinline__ void operator()() const {}
+};
+
+template <int G>
+__device__ __forceinline__ void r4_quad(const float4& a, const float4 (&b)[G], f32x4 (&acc)[G]) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma44(a.x, b[g].x, acc[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma44(a.y, b[g].y, acc[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma44(a.z, b[g].z, acc[g]);
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = mfma44(a.w, b[g].w, acc[g]);
+}
+
+// ---- wide-K product (K = Wp), G >= 2 column groups: this wave's 4 NTWM k-quads stream through a ring of RD quads
+// (G tiles each): the first RD quads come preloaded (requested during the short stages before this one, so the weight
+// stream does not stop there), quad q + RD is requested as soon as quad q is multiplied.  Straight-line code: hipcc
+// counts vmcnt exactly.
+template <int NTWM>
+struct R4Ring {
+    static constexpr int NQ = 4 * NTWM, RD = NQ < 6 ? NQ : 6;
+};
+
+template <int NTWM, int G, class Next>
+__device__ __forceinline__ void r4_mma_wide(const float* __restrict__ act, int lda, const float4* __restrict__ Bm,
+                                            const R4Pre<R4Ring<NTWM>::RD, G>& pre, const Tid4& t, f32x4 (&acc)[G], Next next) {
+    constexpr int NQ = R4Ring<NTWM>::NQ, RD = R4Ring<NTWM>::RD;
+    const float* arow = act + t.arow * lda + 16 * NTWM * t.wave;                  // this wave's K range starts at 16 NTWM w
+    const float4* bw = Bm + ((size_t)(4 * NTWM * t.wave) * G) * 64 + t.lane;      // tile (q, g) at (q G + g) * 64
+    float4 b[RD][G];
+#pragma unroll
+    for (int q = 0; q < RD; ++q)
+#pragma unroll
+        for (int g = 0; g < G; ++g) b[q][g] = pre.b[q][g];
+    next();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+        r4_quad<G>(a, b[q % RD], acc);
+        if (q + RD < NQ) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) b[q % RD][g] = bw[(size_t)((q + RD) * G + g) * 64];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// this wave's partial [4][64 G] product -> PART[wave][row][col]
+template <int G>
+__device__ __forceinline__ void r4_store_part(const f32x4 (&acc)[G], float* __restrict__ part, int PN, const Tid4& t) {
+    float* pw = part + (size_t)t.wave * R4 * PN + t.lane;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[r * PN + 64 * g] = acc[g][r];
+}
+
+// bias of this thread's G outputs (output o = 256 i + tid -> col o % (64 G)), requested at the start of the stage
+template <int G>
+__device__ __forceinline__ void r4_bias_load(float (&bv)[G], const float* __restrict__ bias, const Tid4& t) {
+    constexpr int N = 64 * G;
+#pragma unroll
+    for (int i = 0; i < G; ++i) bv[i] = bias ? bias[(256 * i + t.tid) % N] : 0.f;
+}
+
+// epilogue: OUT[row][col] = f(bias[col] + ((P0 + P1) + (P2 + P3))) for this thread's G of the 4 x 64 G outputs
+// (row o / (64 G), col o % (64 G)).  EP 0: plain, 1: ReLU, sign bit i kept in *mask, 2: multiplied by sign bit i.
+template <int G, int EP>
+__device__ __forceinline__ void r4_epilogue(const float* __restrict__ part, int PN, const float (&bv)[G],
+                                            float* __restrict__ out, int ldo, unsigned* mask, const Tid4& t) {
+    constexpr int N = 64 * G;
+    unsigned m = EP == 2 ? mask[t.tid] : 0u;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int o = 256 * i + t.tid, row = o / N, col = o - row * N;
+        const float* p = part + row * PN + col;
+        float v = ((p[0] + p[R4 * PN]) + (p[2 * R4 * PN] + p[3 * R4 * PN])) + bv[i];
+        if (EP == 1) { const bool pos = v > 0.f; m |= (pos ? 1u : 0u) << i; v = pos ? v : 0.f; }
+        if (EP == 2) v = ((m >> i) & 1u) ? v : 0.f;
+        out[row * ldo + col] = v;
+    }
+    if (EP == 1) mask[t.tid] = m;
+}
+
+// OUT[4][64 G] = epilogue(ACT[4][Wp] @ B)   (two workgroup barriers: partials visible / outputs visible).
+// `bv`: the bias of this thread's outputs, already in registers (r4_bias_load one W x W stage earlier).
+template <int NTWM, int G, int EP, class Next = R4NoNext>
+__device__ __forceinline__ void r4_dense_wide(const float* act, int lda, const float4* Bm,
+                                              const R4Pre<R4Ring<NTWM>::RD, G>& pre,
+                                              const float (&bv)[G], float* out, int ldo, unsigned* mask, float* part, int PN,
+                                              const Tid4& t, Next next = Next()) {
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    r4_mma_wide<NTWM, G>(act, lda, Bm, pre, t, acc, next);
+    r4_store_part<G>(acc, part, PN, t);
+    r4_barrier();
+    r4_epilogue<G, EP>(part, PN, bv, out, ldo, mask, t);
+    r4_barrier();
+}
+
+// one column group, ALL 4 NTWM tiles of the wave preloaded
+template <int NTWM, class Next = R4NoNext>
+__device__ __forceinline__ void r4_dense_wide1(const float* act, int lda, const R4Pre<4 * NTWM, 1>& pre, float* out, int ldo,
+                                               float* part, int PN, const Tid4& t, Next next = Next()) {
+    f32x4 acc[1], acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};                             // two chains: no back-to-back dependence
+    const float bv[1] = {0.f};
+    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* arow = act + t.arow * lda + 16 * NTWM * t.wave;
+#pragma unroll
+    for (int q = 0; q < 4 * NTWM; ++q) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+        const float4 w = pre.b[q][0];
+        acc[0] = mfma44(a.x, w.x, acc[0]);
+        acc2 = mfma44(a.y, w.y, acc2);
+        acc[0] = mfma44(a.z, w.z, acc[0]);
+        acc2 = mfma44(a.w, w.w, acc2);
+    }
+    next();
+    acc[0] += acc2;
+    r4_store_part<1>(acc, part, PN, t);
+    r4_barrier();
+    r4_epilogue<1, 0>(part, PN, bv, out, ldo, nullptr, t);
+    r4_barrier();
+}
+
+// short K (nqw <= NQ quads per wave), all tiles preloaded
+template <int NQ, int G, int EP, class Next = R4NoNext>
+__device__ __forceinline__ void r4_dense_short(const float* act, int lda, int kmax, int nqw, const R4Pre<NQ, G>& pre,
+                                               const float (&bv)[G], float* out, int ldo, unsigned* mask, float* part, int PN,
+                                               const Tid4& t, Next next = Next()) {
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int q0 = nqw * t.wave;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+        if (q < nqw) {
+            const int k0 = 4 * (q0 + q);
+            float4 a = *reinterpret_cast<const float4*>(act + t.arow * lda + k0);
+            if (k0 + 0 >= kmax) a.x = 0.f;
+            if (k0 + 1 >= kmax) a.y = 0.f;
+            if (k0 + 2 >= kmax) a.z = 0.f;
+            if (k0 + 3 >= kmax) a.w = 0.f;
+            r4_quad<G>(a, pre.b[q], acc);
+        }
+    }
+    next();
+    r4_store_part<G>(acc, part, PN, t);
+    r4_barrier();
+    r4_epilogue<G, EP>(part, PN, bv, out, ldo, mask, t);
+    r4_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------
+// log q(x) and d log q / dx for the 4 rows in X0 (columns >= D zero); the gradient is left in the state buffer whose
+// offset is returned through *grad_off.  Same arithmetic as flow_log_prob_tile<GRAD = true> (flow_device.h) up to the
+// summation order inside the GEMMs.  Returns log q of row `tid >> 4` on wave 0 (other waves: undefined).
+// ------------------------------------------------------------------------------------------------
+// All weights of the stages between two W x W GEMMs are requested at the START of the preceding W x W stage (its ~8 k
+// cycles of streaming hide them, and hipcc's vmcnt(0) in front of every workgroup barrier then finds nothing pending in
+// the short stages): forward W2(layer) -> { W3(layer), AW / W1 / first W2 chunk of layer - 1 }, reverse W2T(layer) ->
+// { W1T, AWT of the layer, W3T / first W2T chunk of layer + 1 }.  NQS / NQA: k-quads per wave of the short GEMMs into
+// the hidden width / of the D x D maps (2 for D <= 32, 4 above).
+template <int NTWM, int NQS, int NQA>
+__device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4Lds& l, const float* __restrict__ packed,
+                                  float* lds, const Tid4& t, int* grad_off) {
+    constexpr int G = NTWM;
+    const float* r4base = packed + f.o_r4;
+    int cur = l.o_X0, nxt = l.o_X1;
+    float* HA = lds + l.o_HA;
+    float* HB = lds + l.o_HB;
+    float* PRM = lds + l.o_PRM;
+    float* DP = lds + l.o_DP;
+    float* PART = lds + l.o_PART;
+    const bool ew = t.tid < 64;                       // element-wise stages: wave 0
+    const int row = t.tid >> 4, c = t.tid & 15;
+    const int nqD = rd.KD / 16, nqd = rd.Kd / 16, nqo = rd.Ko / 16;     // quads per wave of the short GEMMs
+    const int qW = 4 * NTWM * t.wave;                                    // this wave's first quad of a K = Wp GEMM
+    R4Pre<NQA, 1> preA;                // affine maps (AW, AWT)
+    R4Pre<4 * NTWM, 1> preN;           // the one-group wide GEMMs (W3, W1T), whole K range of the wave
+    R4Pre<NQS, G> preS;                // short GEMMs into the hidden width (W1, W3T)
+    constexpr int RD = R4Ring<NTWM>::RD;
+    R4Pre<RD, G> preW;                 // first RD quads of the W x W GEMMs (W2, W2T), requested at the top of the layer
+    float bvA[1], bv1[G], bv2[G], bv0[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bv0[g] = 0.f;
+    float logq = 0.f;
+    {                                  // the first layer's pre-W2 stages: requested here (one exposed latency per call)
+        const float* Lp = packed + (size_t)(f.K - 1) * f.layer_stride;
+        const float* Rp = r4base + (size_t)(f.K - 1) * rd.layer_stride;
+        r4_preload<NQA, 1>(preA, reinterpret_cast<const float4*>(Rp + rd.o_AW), nqD * t.wave, nqD, t);
+        r4_preload<NQS, G>(preS, reinterpret_cast<const float4*>(Rp + rd.o_W1), nqd * t.wave, nqd, t);
+        r4_bias_load<1>(bvA, Lp + f.o_ac, t);
+        r4_bias_load<G>(bv1, Lp + f.o_b1, t);
+        r4_preload_part<0, 3>(preW, reinterpret_cast<const float4*>(Rp + rd.o_W2), qW, t);
+    }
+    for (int layer = f.K - 1; layer >= 0; --layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        const float* Rp = r4base + (size_t)layer * rd.layer_stride;
+        unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
+        const bool tl = layer == f.K - 2;
+        if (tl) FAB_TL(f, 0);
+        // InvertibleAffine.inverse (+ folded ActNorm): z <- z @ W' + ac   (+ quads 3, 4 of this layer's W2 ring)
+        r4_dense_short<NQA, 1, 0>(lds + cur, R4_DS, f.D, nqD, preA, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t, [&] {
+            r4_preload_part<3, 5>(preW, reinterpret_cast<const float4*>(Rp + rd.o_W2), qW, t);
+        });
+        logq += Lp[f.o_logS];
+        float* Z = lds + nxt;
+        if (tl) FAB_TL(f, 1);
+        // conditioner
+        r4_dense_short<NQS, G, 1>(Z, R4_DS, f.d, nqd, preS, bv1, HA, l.WS, mk, PART, l.PN, t, [&] {
+            r4_preload_part<5, RD>(preW, reinterpret_cast<const float4*>(Rp + rd.o_W2), qW, t);
+        });
+        if (tl) FAB_TL(f, 2);
+        float b3s[2] = {0.f, 0.f}, b3c[2] = {0.f, 0.f};      // coupling biases of this thread's columns (D - d <= 32)
+        r4_bias_load<G>(bv2, Lp + f.o_b2, t);
+        r4_dense_wide<NTWM, G, 1>(HA, l.WS, reinterpret_cast<const float4*>(Rp + rd.o_W2), preW, bv2, HB, l.WS,
+                                  mk + NTHREADS, PART, l.PN, t, [&] {
+            r4_preload<4 * NTWM, 1>(preN, reinterpret_cast<const float4*>(Rp + rd.o_W3), qW, 4 * NTWM, t);
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int j = c + 16 * it;
+                if (ew && j < f.DO) { b3s[it] = Lp[f.o_b3 + j]; b3c[it] = Lp[f.o_b3 + f.DOp + j]; }
+            }
+            if (layer > 0) {
+                const float* Ln = Lp - f.layer_stride;
+                const float* Rn = Rp - rd.layer_stride;
+                r4_preload<NQA, 1>(preA, reinterpret_cast<const float4*>(Rn + rd.o_AW), nqD * t.wave, nqD, t);
+                r4_preload<NQS, G>(preS, reinterpret_cast<const float4*>(Rn + rd.o_W1), nqd * t.wave, nqd, t);
+                r4_bias_load<1>(bvA, Ln + f.o_ac, t);
+                r4_bias_load<G>(bv1, Ln + f.o_b1, t);
+            } else {                   // the reverse sweep starts at layer 0 with the (shift | scale) -> hidden GEMM
+                r4_preload<NQS, G>(preS, reinterpret_cast<const float4*>(Rp + rd.o_W3T), nqo * t.wave, nqo, t);
+            }
+        });
+        if (tl) FAB_TL(f, 3);
+        const float4* Wnext = reinterpret_cast<const float4*>(layer > 0 ? Rp - rd.layer_stride + rd.o_W2 : Rp + rd.o_W2T);
+        r4_dense_wide1<NTWM>(HB, l.WS, preN, PRM, R4_DS, PART, l.PN, t, [&] { r4_preload_part<0, 2>(preW, Wnext, qW, t); });
+        if (tl) FAB_TL(f, 4);
+        r4_preload_part<2, 3>(preW, Wnext, qW, t);
+        // AffineCoupling.inverse: z2 <- (z2 - shift) exp(-s), log_det = -sum(s)
+        if (ew) {
+            float ssum = 0.f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int j = c + 16 * it;
+                if (j < f.DO) {
+                    const float shift = PRM[row * R4_DS + j] + b3s[it];
+                    const float s = PRM[row * R4_DS + f.DOp + j] + b3c[it];
+                    const float es = expf(-s);
+                    const float v2 = (Z[row * R4_DS + f.d + j] - shift) * es;
+                    Z[row * R4_DS + f.d + j] = v2;
+                    lds[l.o_ES + ((size_t)layer * R4 + row) * f.DOp + j] = es;
+                    lds[l.o_V2 + ((size_t)layer * R4 + row) * f.DOp + j] = v2;
+                    ssum += s;
+                }
+            }
+            logq += -row16_sum(ssum);
+        }
+        r4_barrier();
+        if (tl) FAB_TL(f, 5);
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // DiagGaussian.log_prob, and the seed of the reverse sweep
+    if (ew) {
+        const float* base = packed + f.o_base;
+        float* Zc = lds + cur;
+        float bsum = 0.f;
+        for (int j = c; j < f.D; j += 16) {
+            const float ls = base[f.Dp + j];
+            const float sc = expf(ls);
+            const float zn = (Zc[row * R4_DS + j] - base[j]) / sc;
+            bsum += ls + 0.5f * (zn * zn);
+            Zc[row * R4_DS + j] = -(zn / sc);
+        }
+        logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
+    }
+    r4_barrier();
+    // reverse sweep: g = d log q / d(state), layers 0 .. K-1
+    bvA[0] = 0.f;
+    for (int layer = 0; layer < f.K; ++layer) {
+        const float* Rp = r4base + (size_t)layer * rd.layer_stride;
+        unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
+        float* Gs = lds + cur;
+        const bool tl = layer == 1;
+        if (tl) FAB_TL(f, 16);
+        r4_preload_part<3, 5>(preW, reinterpret_cast<const float4*>(Rp + rd.o_W2T), qW, t);
+        if (ew) {
+            for (int j = c; j < f.DO; j += 16) {
+                const float g2 = Gs[row * R4_DS + f.d + j];
+                const float es = lds[l.o_ES + ((size_t)layer * R4 + row) * f.DOp + j];
+                const float v2 = lds[l.o_V2 + ((size_t)layer * R4 + row) * f.DOp + j];
+                DP[row * R4_DS + j] = -(g2 * es);
+                DP[row * R4_DS + f.DOp + j] = -(g2 * v2) - 1.f;
+                Gs[row * R4_DS + f.d + j] = g2 * es;
+            }
+        }
+        r4_barrier();
+        if (tl) FAB_TL(f, 17);
+        r4_dense_short<NQS, G, 2>(DP, R4_DS, 2 * f.DOp, nqo, preS, bv0, HA, l.WS, mk + NTHREADS, PART, l.PN, t, [&] {
+            r4_preload_part<5, RD>(preW, reinterpret_cast<const float4*>(Rp + rd.o_W2T), qW, t);
+        });
+        if (tl) FAB_TL(f, 18);
+        r4_dense_wide<NTWM, G, 2>(HA, l.WS, reinterpret_cast<const float4*>(Rp + rd.o_W2T), preW, bv0, HB, l.WS, mk, PART,
+                                  l.PN, t, [&] {
+            r4_preload<4 * NTWM, 1>(preN, reinterpret_cast<const float4*>(Rp + rd.o_W1T), qW, 4 * NTWM, t);
+            r4_preload<NQA, 1>(preA, reinterpret_cast<const float4*>(Rp + rd.o_AWT), nqD * t.wave, nqD, t);
+            if (layer + 1 < f.K) {
+                const float* Rn = Rp + rd.layer_stride;
+                r4_preload<NQS, G>(preS, reinterpret_cast<const float4*>(Rn + rd.o_W3T), nqo * t.wave, nqo, t);
+            }
+        });
+        if (tl) FAB_TL(f, 19);
+        const float4* Wnext = reinterpret_cast<const float4*>(Rp + rd.layer_stride + rd.o_W2T);
+        const bool more = layer + 1 < f.K;
+        r4_dense_wide1<NTWM>(HB, l.WS, preN, PRM, R4_DS, PART, l.PN, t, [&] {
+            if (more) r4_preload_part<0, 2>(preW, Wnext, qW, t);
+        });
+        if (tl) FAB_TL(f, 20);
+        if (ew)
+            for (int j = c; j < f.d; j += 16) Gs[row * R4_DS + j] += PRM[row * R4_DS + j];
+        r4_barrier();
+        if (tl) FAB_TL(f, 21);
+        r4_dense_short<NQA, 1, 0>(Gs, R4_DS, f.D, nqD, preA, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t, [&] {
+            if (more) r4_preload_part<2, 3>(preW, Wnext, qW, t);
+        });
+        if (tl) FAB_TL(f, 22);
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *grad_off = cur;
+    return logq;
+}
+
+}  // namespace fab

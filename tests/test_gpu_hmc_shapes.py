@@ -85,3 +85,41 @@ def test_hmc_transition_is_bitwise_deterministic_over_repeated_launches(D, K, no
     op = ohmc.transition(op, 1, 1.0 / 3, noise_p[:, idx].cpu(), noise_e[:, idx].cpu())
     err = (outs[0][0][idx].cpu() - op.x).abs().max(1).values / max(1.0, float(op.x.abs().max()))
     assert (err > 1e-4).sum() <= 1, f"{int((err > 1e-4).sum())} of {len(idx)} sampled chains differ from the oracle"
+
+
+@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 1024), (6, 3, 8, 70), (60, 4, 4, 200), (2, 2, 40, 33), (16, 3, 16, 257)])
+def test_four_chain_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B):
+    """k_hmc_step_r4 (4 chains per workgroup on v_mfma_f32_4x4x1, used for B <= 1152) against k_hmc_step (16 chains per
+    workgroup): the same transition from the same point and noise.  The two differ only in the summation order inside
+    the GEMMs, so per-chain results agree to fp32 rounding except where an accept / reject decision flips; the
+    acceptance sums feeding the step-size rule are added in the same order by construction (bit-equal epsilons
+    whenever no decision flipped)."""
+    torch.manual_seed(D * 100 + K)
+    flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.05 * torch.randn_like(p))
+    target = fa.GMM(D, n_mixes=5, loc_scaling=2.0, seed=1, true_expectation_estimation_n_samples=1000) if D == 2 else \
+        (fa.ManyWellEnergy(D) if D % 2 == 0 else None)
+    if target is None:
+        pytest.skip("ManyWell needs an even dimension")
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FABHIP_R4", mode)
+        hmc = fa.HamiltonianMonteCarlo(4, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
+                                       n_outer=2, L=3).to(DEV)
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x0, _ = flow.native_sample(torch.randn(B, D, device=DEV, generator=g))
+        pt = fa.create_point(x0, flow, target, with_grad=True)
+        torch.manual_seed(77)
+        out = hmc.transition(pt, 2, 0.4)
+        res[mode] = (out.x.clone(), out.log_q.clone(), out.log_p.clone(), hmc.epsilons.clone(), hmc.common_epsilon.clone())
+    monkeypatch.delenv("FABHIP_R4")
+    xa, lqa, lpa, ea, ca = res["0"]
+    xb, lqb, lpb, eb, cb = res["1"]
+    same = (xa - xb).abs().amax(dim=1) <= 1e-4 * (1 + xa.abs().amax(dim=1))
+    assert float(same.float().mean()) >= 0.98                         # a flipped decision moves a whole chain
+    assert float((lqa[same] - lqb[same]).abs().max()) <= 2e-3 * (1 + float(lqa[same].abs().max()))
+    assert torch.allclose(ea, eb, rtol=0, atol=0) or float(same.float().mean()) < 1.0
+    assert torch.allclose(ca, cb, rtol=1e-6)
