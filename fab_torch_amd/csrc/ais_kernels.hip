@@ -397,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
             lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
         }
         __syncthreads();
-        lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2>(f, rd, l, packed, lds, t4, &goff);
+        lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 2 : 1>(f, rd, l, packed, lds, t4, &goff);
         if (ew) {
             lp = target_tile<true>(tg, XP, D, GP, D, t);
             for (int j = t.c; j < D; j += 16) {

@@ -80,8 +80,10 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     f.o_base = K * f.layer_stride;
     f.o_scratch = f.o_base + 2 * f.Dp;
     f.o_r4 = f.o_scratch + K * 2 * D * D;
-    // per layer: AW, AWT [pad16(D) x 64], W1 [pad16(d) x Wp], W2, W2T [Wp x Wp], W3, W1T [Wp x 64], W3T [pad16(2 DOp) x Wp]
-    f.total = f.o_r4 + K * (2 * pad16(D) * 64 + pad16(f.d) * f.Wp + 2 * f.Wp * f.Wp + 2 * f.Wp * 64 + pad16(2 * f.DOp) * f.Wp);
+    // per layer: AW, AWT [pad16(D) x 64], W1 [pad16(d) x Wp], W2, W2T [Wp x Wp], W3 [Wp x 2 DOp], W1T [Wp x pad16(d)],
+    // W3T [pad16(2 DOp) x Wp]
+    f.total = f.o_r4 + K * (2 * pad16(D) * 64 + pad16(f.d) * f.Wp + 2 * f.Wp * f.Wp + f.Wp * 2 * f.DOp + f.Wp * pad16(f.d) +
+                            pad16(2 * f.DOp) * f.Wp);
     f.timeline = nullptr;
     return f;
 }

@@ -353,8 +353,15 @@ __global__ __launch_bounds__(256) void k_pack_r4(FlowDims f, R4Dims rd, MlpTab t
         else if (off < rd.o_W1T) { base = rd.o_W2T; G = rd.G; }
         else { base = rd.o_W1T; G = 1; }
         const int e = off - base, kk = e & 3, l = (e >> 2) & 63, tile = e >> 8;
-        const int g = tile % G, q = tile / G;
-        const int k = 4 * q + kk, n = 64 * g + l;
+        int k, n;
+        if (base == rd.o_W3 || base == rd.o_W1T) {           // 16-column tiles of the 16x16x4 path (r4_dense_n16)
+            const int NT = (base == rd.o_W3 ? 2 * f.DOp : pad16(d)) / 16;
+            const int ct = tile % NT, Q = tile / NT;
+            k = 16 * Q + 4 * (l >> 4) + kk; n = 16 * ct + (l & 15);
+        } else {
+            const int g = tile % G, q = tile / G;
+            k = 4 * q + kk; n = 64 * g + l;
+        }
         float v = 0.f;
         if (base == rd.o_AW) { if (k < D && n < D) v = Wm[k * D + n]; }
         else if (base == rd.o_AWT) { if (k < D && n < D) v = Wm[n * D + k]; }

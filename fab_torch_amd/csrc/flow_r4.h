@@ -39,10 +39,10 @@ FAB_HD R4Dims make_r4_dims(const FlowDims& f) {
     r.o_AWT = o; o += r.KD * 64;
     r.o_W1 = o; o += r.Kd * f.Wp;      // [d -> W]
     r.o_W2 = o; o += f.Wp * f.Wp;      // [W -> W]
-    r.o_W3 = o; o += f.Wp * 64;        // [W -> shift | scale]
+    r.o_W3 = o; o += f.Wp * 2 * f.DOp; // [W -> shift | scale]   (16-column tiles, see r4_dense_n16)
     r.o_W3T = o; o += r.Ko * f.Wp;     // [shift | scale -> W]
     r.o_W2T = o; o += f.Wp * f.Wp;
-    r.o_W1T = o; o += f.Wp * 64;       // [W -> d]
+    r.o_W1T = o; o += f.Wp * pad16(f.d); // [W -> d]            (16-column tiles)
     r.layer_stride = o;
     return r;
 }
@@ -230,28 +230,58 @@ __device__ __forceinline__ void r4_dense_wide(const float* act, int lda, const f
     r4_barrier();
 }
 
-// one column group, ALL 4 NTWM tiles of the wave preloaded
-template <int NTWM, class Next = R4NoNext>
-__device__ __forceinline__ void r4_dense_wide1(const float* act, int lda, const R4Pre<4 * NTWM, 1>& pre, float* out, int ldo,
-                                               float* part, int PN, const Tid4& t, Next next = Next()) {
-    f32x4 acc[1], acc2 = (f32x4){0.f, 0.f, 0.f, 0.f};                             // two chains: no back-to-back dependence
-    const float bv[1] = {0.f};
-    acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const float* arow = act + t.arow * lda + 16 * NTWM * t.wave;
+// ---- narrow outputs (the coupling parameters, N = 2 DOp; the d-wide input gradient, N = pad16(d)) of a K = Wp
+// product: with 64-column groups half to three quarters of every weight tile would be padding, and these stages are
+// bound by the bytes they stream.  They use v_mfma_f32_16x16x4_f32 instead, with the 4 chains in rows 0 .. 3 of its
+// 16-row A operand (rows 4 .. 15 zero): the B operand is a dense [4 k][16 columns] block.  Tile (Q, ct) of the image:
+// lane l = { B[16 Q + 4 (l >> 4) + j][16 ct + (l & 15)] } j < 4; wave w owns k-tiles [NTWM w, NTWM (w + 1)).
+template <int NTWM, int NT>
+struct R4PreT {
+    float4 b[NTWM][NT];
+};
+
+template <int NTWM, int NT>
+__device__ __forceinline__ void r4_preload_n16(R4PreT<NTWM, NT>& p, const float4* __restrict__ Bm, const Tid4& t) {
+    const float4* bw = Bm + ((size_t)(NTWM * t.wave) * NT) * 64 + t.lane;
 #pragma unroll
-    for (int q = 0; q < 4 * NTWM; ++q) {
-        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
-        const float4 w = pre.b[q][0];
-        acc[0] = mfma44(a.x, w.x, acc[0]);
-        acc2 = mfma44(a.y, w.y, acc2);
-        acc[0] = mfma44(a.z, w.z, acc[0]);
-        acc2 = mfma44(a.w, w.w, acc2);
+    for (int Q = 0; Q < NTWM; ++Q)
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) p.b[Q][ct] = bw[(size_t)(Q * NT + ct) * 64];
+}
+
+template <int NTWM, int NT, class Next = R4NoNext>
+__device__ __forceinline__ void r4_dense_n16(const float* act, int lda, const R4PreT<NTWM, NT>& pre, float* out, int ldo,
+                                             float* part, int PN, const Tid4& t, Next next = Next()) {
+    f32x4 acc[NT];
+#pragma unroll
+    for (int ct = 0; ct < NT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int r16 = t.lane & 15, kq = t.lane >> 4;
+    const bool live = r16 < 4;
+    const float* ap = act + (r16 & 3) * lda + 16 * NTWM * t.wave + 4 * kq;
+#pragma unroll
+    for (int Q = 0; Q < NTWM; ++Q) {
+        float4 a = *reinterpret_cast<const float4*>(ap + 16 * Q);
+        if (!live) a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.x, pre.b[Q][ct].x, acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.y, pre.b[Q][ct].y, acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.z, pre.b[Q][ct].z, acc[ct]);
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.w, pre.b[Q][ct].w, acc[ct]);
     }
     next();
-    acc[0] += acc2;
-    r4_store_part<1>(acc, part, PN, t);
+    if (kq == 0) {                                   // lanes 0 .. 15 hold rows 0 .. 3 (VGPR r) of column 16 ct + lane
+        float* pw = part + (size_t)t.wave * R4 * PN + r16;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pw[r * PN + 16 * ct] = acc[ct][r];
+    }
     r4_barrier();
-    r4_epilogue<1, 0>(part, PN, bv, out, ldo, nullptr, t);
+    const float bv[1] = {0.f};
+    r4_epilogue<1, 0>(part, PN, bv, out, ldo, nullptr, t);     // (columns >= 16 NT of `out` receive stale partials: unused)
     r4_barrier();
 }
 
@@ -293,7 +323,7 @@ __device__ __forceinline__ void r4_dense_short(const float* act, int lda, int km
 // the short stages): forward W2(layer) -> { W3(layer), AW / W1 / first W2 chunk of layer - 1 }, reverse W2T(layer) ->
 // { W1T, AWT of the layer, W3T / first W2T chunk of layer + 1 }.  NQS / NQA: k-quads per wave of the short GEMMs into
 // the hidden width / of the D x D maps (2 for D <= 32, 4 above).
-template <int NTWM, int NQS, int NQA>
+template <int NTWM, int NQS, int NQA, int NT3, int NT1>
 __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4Lds& l, const float* __restrict__ packed,
                                   float* lds, const Tid4& t, int* grad_off) {
     constexpr int G = NTWM;
@@ -309,7 +339,8 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
     const int nqD = rd.KD / 16, nqd = rd.Kd / 16, nqo = rd.Ko / 16;     // quads per wave of the short GEMMs
     const int qW = 4 * NTWM * t.wave;                                    // this wave's first quad of a K = Wp GEMM
     R4Pre<NQA, 1> preA;                // affine maps (AW, AWT)
-    R4Pre<4 * NTWM, 1> preN;           // the one-group wide GEMMs (W3, W1T), whole K range of the wave
+    R4PreT<NTWM, NT3> preN3;           // W3 (16-column tiles), whole K range of the wave
+    R4PreT<NTWM, NT1> preN1;           // W1T
     R4Pre<NQS, G> preS;                // short GEMMs into the hidden width (W1, W3T)
     constexpr int RD = R4Ring<NTWM>::RD;
     R4Pre<RD, G> preW;                 // first RD quads of the W x W GEMMs (W2, W2T), requested at the top of the layer
@@ -348,7 +379,7 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
         r4_bias_load<G>(bv2, Lp + f.o_b2, t);
         r4_dense_wide<NTWM, G, 1>(HA, l.WS, reinterpret_cast<const float4*>(Rp + rd.o_W2), preW, bv2, HB, l.WS,
                                   mk + NTHREADS, PART, l.PN, t, [&] {
-            r4_preload<4 * NTWM, 1>(preN, reinterpret_cast<const float4*>(Rp + rd.o_W3), qW, 4 * NTWM, t);
+            r4_preload_n16<NTWM, NT3>(preN3, reinterpret_cast<const float4*>(Rp + rd.o_W3), t);
 #pragma unroll
             for (int it = 0; it < 2; ++it) {
                 const int j = c + 16 * it;
@@ -367,7 +398,7 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
         });
         if (tl) FAB_TL(f, 3);
         const float4* Wnext = reinterpret_cast<const float4*>(layer > 0 ? Rp - rd.layer_stride + rd.o_W2 : Rp + rd.o_W2T);
-        r4_dense_wide1<NTWM>(HB, l.WS, preN, PRM, R4_DS, PART, l.PN, t, [&] { r4_preload_part<0, 2>(preW, Wnext, qW, t); });
+        r4_dense_n16<NTWM, NT3>(HB, l.WS, preN3, PRM, R4_DS, PART, l.PN, t, [&] { r4_preload_part<0, 2>(preW, Wnext, qW, t); });
         if (tl) FAB_TL(f, 4);
         r4_preload_part<2, 3>(preW, Wnext, qW, t);
         // AffineCoupling.inverse: z2 <- (z2 - shift) exp(-s), log_det = -sum(s)
@@ -435,7 +466,7 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
         if (tl) FAB_TL(f, 18);
         r4_dense_wide<NTWM, G, 2>(HA, l.WS, reinterpret_cast<const float4*>(Rp + rd.o_W2T), preW, bv0, HB, l.WS, mk, PART,
                                   l.PN, t, [&] {
-            r4_preload<4 * NTWM, 1>(preN, reinterpret_cast<const float4*>(Rp + rd.o_W1T), qW, 4 * NTWM, t);
+            r4_preload_n16<NTWM, NT1>(preN1, reinterpret_cast<const float4*>(Rp + rd.o_W1T), t);
             r4_preload<NQA, 1>(preA, reinterpret_cast<const float4*>(Rp + rd.o_AWT), nqD * t.wave, nqD, t);
             if (layer + 1 < f.K) {
                 const float* Rn = Rp + rd.layer_stride;
@@ -445,7 +476,7 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
         if (tl) FAB_TL(f, 19);
         const float4* Wnext = reinterpret_cast<const float4*>(Rp + rd.layer_stride + rd.o_W2T);
         const bool more = layer + 1 < f.K;
-        r4_dense_wide1<NTWM>(HB, l.WS, preN, PRM, R4_DS, PART, l.PN, t, [&] {
+        r4_dense_n16<NTWM, NT1>(HB, l.WS, preN1, PRM, R4_DS, PART, l.PN, t, [&] {
             if (more) r4_preload_part<0, 2>(preW, Wnext, qW, t);
         });
         if (tl) FAB_TL(f, 20);
