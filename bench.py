@@ -287,13 +287,22 @@ def main():
                 "workgroups": n_wg, "frac_of_occupied_cus": ach / (PEAK_FP32_MFMA_TFLOPS * min(n_wg, 256) / 256)}
         # HBM traffic per launch: separate rocprofv3 --pmc passes of tools/prof_hmc.py (same kernel, same shape),
         # summarised by tools/pmc_summary.py and committed; not collectable from inside this process.
-        for rnd in ("r2", "r1"):
-            pmc = os.path.join(ROOT, "profiles", rnd, "hmc_step_pmc_summary.json")
+        if r4:      # no FETCH_SIZE figure for this kernel (the pass does not finish under rocprofv3 on this pool): traffic = null
+            pmc = os.path.join(ROOT, "profiles", "r2", "hmc_step_r4_pmc_summary.json")
             if os.path.exists(pmc):
                 with open(pmc) as f:
-                    roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
-                roof["traffic_source"] = f"profiles/{rnd}/hmc_step_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
-                break
+                    der = json.load(f).get("_derived", {})
+                roof["traffic_note"] = ("FETCH_SIZE unavailable; L2 misses x 128 B = %.0f MB per launch, L2 hit rate %.3f "
+                                        "(profiles/r2/hmc_step_r4_pmc_summary.json)" %
+                                        (der.get("tcc_miss_bytes_per_launch", 0) / 1e6, der.get("l2_hit_rate", 0)))
+        else:
+            for rnd in ("r2", "r1"):
+                pmc = os.path.join(ROOT, "profiles", rnd, "hmc_step_pmc_summary.json")
+                if os.path.exists(pmc):
+                    with open(pmc) as f:
+                        roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = f"profiles/{rnd}/hmc_step_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
+                    break
         # 16-chain tiles (k_hmc_step<5>) with one workgroup per CU (4096 chains):
         t_full = time_transition(4096)
         ach_full = 4096 * L * 2 * F_FWD / t_full / 1e12
