@@ -123,3 +123,23 @@ def test_four_chain_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B)
     assert float((lqa[same] - lqb[same]).abs().max()) <= 2e-3 * (1 + float(lqa[same].abs().max()))
     assert torch.allclose(ea, eb, rtol=0, atol=0) or float(same.float().mean()) < 1.0
     assert torch.allclose(ca, cb, rtol=1e-6)
+
+
+def test_four_chain_tiles_are_bitwise_reproducible():
+    """Race screen for k_hmc_step_r4 (LDS-only barriers written in inline asm, weight requests in flight across them):
+    the same AIS call on the same noise, five times at 1024 chains (256 workgroups) and at a ragged 1027: identical bits."""
+    D, K, nodes, M = 32, 10, 10, 4
+    torch.manual_seed(1)
+    flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    for B in (1024, 1027):
+        outs = []
+        for rep in range(5):
+            hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1,
+                                           n_outer=1, L=5).to(DEV)
+            ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, False, 2.0, M)
+            torch.manual_seed(123)
+            pt, lw = ais.sample_and_log_weights(B)
+            outs.append((pt.x.clone(), lw.clone(), hmc.epsilons.clone()))
+        for o in outs[1:]:
+            assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
