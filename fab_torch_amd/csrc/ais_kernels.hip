@@ -339,7 +339,7 @@ static inline ExtraLds4 make_extra_lds4(const R4Lds& l, int D) {
     return e;
 }
 
-template <int NTWM, bool BIGD>
+template <int NTWM, bool BIGD, bool STREAM>
 __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
                                                           const float* __restrict__ packed, TargetDev tg, HmcK a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -397,7 +397,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
             lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
         }
         __syncthreads();
-        lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 2 : 1>(f, rd, l, packed, lds, t4, &goff);
+        if constexpr (STREAM) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
+        else lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 2 : 1>(f, rd, l, packed, lds, t4, &goff);
         if (ew) {
             lp = target_tile<true>(tg, XP, D, GP, D, t);
             for (int j = t.c; j < D; j += 16) {
@@ -755,12 +756,17 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
     const ExtraLds4 x = make_extra_lds4(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid((unsigned)((a.B + R4 - 1) / R4));
+    const char* es = getenv("FABHIP_R4_STREAM");          // "0": per-stage request groups also where the stream image exists
     if (f.D > 32) {
-        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, true>, bytes));
-        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, true, false>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, true, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+    } else if (NTWM >= 2 && f.o_r4s >= 0 && !(es && es[0] == '0')) {
+        constexpr int NS = NTWM >= 2 ? NTWM : 2;           // (never instantiates the stream code for NTWM = 1)
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, true>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NS, false, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
     } else {
-        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, false>, bytes));
-        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, false, false>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, false, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
     }
     return check_launch();
 }

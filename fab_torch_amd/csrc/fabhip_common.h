@@ -40,6 +40,7 @@ struct FlowDims {
     int o_base;                 // offset of base block: loc[Dp], log_scale[Dp]
     int o_scratch;              // offset of affine scratch: per layer W[D*D], Winv[D*D]
     int o_r4;                   // 4-chain-tile weight image (flow_r4.h: R4Dims), K layer blocks
+    int o_r4s;                  // the same tiles in per-wave consumption order (flow_r4.h: R4Stream; D <= 32, Wp >= 128), else -1
     int total;                  // total floats
     long long* timeline;        // dev-only: s_memtime stamps of workgroup 0 (nullptr in production)
 };
@@ -79,11 +80,18 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     f.layer_stride = o;
     f.o_base = K * f.layer_stride;
     f.o_scratch = f.o_base + 2 * f.Dp;
-    f.o_r4 = f.o_scratch + K * 2 * D * D;
+    f.o_r4 = (f.o_scratch + K * 2 * D * D + 63) & ~63;          // 256-byte aligned: read as float4 tiles
     // per layer: AW, AWT [pad16(D) x 64], W1 [pad16(d) x Wp], W2, W2T [Wp x Wp], W3 [Wp x 2 DOp], W1T [Wp x pad16(d)],
     // W3T [pad16(2 DOp) x Wp]
     f.total = f.o_r4 + K * (2 * pad16(D) * 64 + pad16(f.d) * f.Wp + 2 * f.Wp * f.Wp + f.Wp * 2 * f.DOp + f.Wp * pad16(f.d) +
                             pad16(2 * f.DOp) * f.Wp);
+    // stream image: (4 NTW + 4) items per layer and direction, each 4 waves x NTW tiles of 1 KiB, + 8 items of padding
+    f.o_r4s = -1;
+    if (D <= 32 && f.Wp >= 128) {
+        const int ntw = f.Wp / 64;
+        f.o_r4s = f.total;
+        f.total += (2 * K * (4 * ntw + 4) + 8) * 4 * ntw * 256;
+    }
     f.timeline = nullptr;
     return f;
 }

@@ -375,6 +375,48 @@ __global__ __launch_bounds__(256) void k_pack_r4(FlowDims f, R4Dims rd, MlpTab t
     }
 }
 
+// Stream image (flow_r4.h: R4Stream): the r4 tiles copied into the order a wave consumes them.  float4 index of a
+// stream element = ((item * 4 + wave) * G + g) * 64 + lane, item = global item number (forward layers K-1 .. 0, then
+// reverse layers 0 .. K-1, C = 4 G + 4 items each).  Source tiles come from the r4 image k_pack_r4 has just written.
+__global__ __launch_bounds__(256) void k_pack_r4s(FlowDims f, R4Dims rd, float* __restrict__ packed) {
+    const int G = rd.G, C = 4 * G + 4, K = f.K;
+    const int nqD = rd.KD / 16;
+    const long total4 = (long)(2 * K * C + 8) * 4 * G * 64;                  // float4 elements incl. the padding items
+    const float4* r4 = reinterpret_cast<const float4*>(packed + f.o_r4);
+    float4* dst = reinterpret_cast<float4*>(packed + f.o_r4s);
+    const long LS4 = rd.layer_stride / 4;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        long r = e >> 6;
+        const int g = (int)(r % G); r /= G;
+        const int w = (int)(r & 3);
+        const long item = r >> 2;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (item < 2L * K * C) {
+            const bool fwd = item < (long)K * C;
+            const long li = fwd ? item : item - (long)K * C;
+            const int layer = fwd ? K - 1 - (int)(li / C) : (int)(li / C);
+            const int i = (int)(li % C);
+            const float4* L = r4 + (long)layer * LS4;
+            long src = -1;                                                    // float4 index inside the layer's r4 block
+            if (fwd) {
+                if (i == 0) { if (g < nqD) src = rd.o_AW / 4 + (long)(nqD * w + g) * 64 + lane; }
+                else if (i == 1) src = rd.o_W1 / 4 + ((long)(1 * w) * G + g) * 64 + lane;            // Kd = 16: one quad per wave
+                else if (i < 2 + 4 * G) src = rd.o_W2 / 4 + ((long)(4 * G * w + (i - 2)) * G + g) * 64 + lane;
+                else { const int fi = (i - 2 - 4 * G) * G + g, Q = fi / 2, ct = fi % 2;              // W3: G k-tiles x 2 column tiles
+                       src = rd.o_W3 / 4 + ((long)(G * w + Q) * 2 + ct) * 64 + lane; }
+            } else {
+                if (i < 2) src = rd.o_W3T / 4 + ((long)(2 * w + i) * G + g) * 64 + lane;             // Ko = 32: two quads per wave
+                else if (i < 2 + 4 * G) src = rd.o_W2T / 4 + ((long)(4 * G * w + (i - 2)) * G + g) * 64 + lane;
+                else if (i == 2 + 4 * G) src = rd.o_W1T / 4 + ((long)(G * w + g) * 1) * 64 + lane;  // W1T: k-tile Q = g, one column tile
+                else { if (g < nqD) src = rd.o_AWT / 4 + (long)(nqD * w + g) * 64 + lane; }
+            }
+            if (src >= 0) v = L[src];
+        }
+        dst[e] = v;
+    }
+}
+
 template <int NTWM>
 static int launch_sample(const FlowDims& f, const float* packed, const float* eps, float* x, float* log_q, long B,
                          hipStream_t st) {
@@ -459,6 +501,8 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
         const R4Dims rd = make_r4_dims(f);
         hipLaunchKernelGGL(k_pack_r4, dim3(ceil_div(rd.layer_stride, 256 * 8), nl), dim3(256), 0, st, f, rd, mt, k0, packed);
     }
+    if (f.o_r4s >= 0)
+        hipLaunchKernelGGL(k_pack_r4s, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed);
     hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();
 }

@@ -494,4 +494,224 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
     return logq;
 }
 
+
+// ================================================================================================
+// One continuous weight stream per wave (shapes with D <= 32 and Wp >= 128).
+// The per-stage request groups above leave the memory pipe idle in the short stages.  Here the tiles of ALL matrices
+// are laid out once more in the order a wave consumes them (k_pack_r4s: "items" of G float4 per lane = one k-quad of a
+// 64 G-wide matrix, or G tiles of a narrow one; forward layers K-1 .. 0, then reverse layers 0 .. K-1), and every wave
+// keeps a ring of RD items: whenever an item has been consumed, the item RD places further down the stream is requested
+// into its slot - across stage and layer boundaries - so RD - 1 items (25 KB per wave) are in flight at all times.
+// Per layer and direction the stream has C = 4 NTWM + 4 items (forward: AW | W1 | 4 NTWM quads of W2 | 2 of W3;
+// reverse: 2 of W3T | 4 NTWM quads of W2T | W1T | AWT); RD divides C, so the slot of every item is a compile-time
+// constant inside the layer body.
+// ================================================================================================
+template <int NTWM>
+struct R4Stream {
+    static constexpr int G = NTWM;
+    static constexpr int C = 4 * NTWM + 4;
+    static constexpr int RD = C % 6 == 0 ? 6 : (C % 8 == 0 ? 8 : 5);
+    static constexpr int IS = 4 * G * 64;                  // float4 between consecutive items of one wave
+    // forward items                                          reverse items
+    static constexpr int IA = 0, IW1 = 1, IW2 = 2, IW3 = 2 + 4 * NTWM;
+    static constexpr int IW3T = 0, IW2T = 2, IW1T = 2 + 4 * NTWM, IAT = 3 + 4 * NTWM;
+    static_assert(C % RD == 0, "ring size must divide the items per layer");
+};
+
+// W x W stage on the shared ring: quad qq of the stage is item I0 + qq
+template <int NTWM, int EP, int I0, class Ring, class Refill>
+__device__ __forceinline__ void r4s_dense_wide(const float* act, int lda, Ring& ring, Refill refill,
+                                               const float (&bv)[NTWM], float* out, int ldo, unsigned* mask, float* part,
+                                               int PN, const Tid4& t) {
+    constexpr int G = NTWM, NQ = 4 * NTWM, RD = R4Stream<NTWM>::RD;
+    f32x4 acc[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float* arow = act + t.arow * lda + 16 * NTWM * t.wave;
+    static_for<0, NQ>([&](auto qc) {
+        constexpr int q = decltype(qc)::value;
+        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
+        r4_quad<G>(a, ring[(I0 + q) % RD], acc);
+        refill(IC<I0 + q>{});
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    r4_store_part<G>(acc, part, PN, t);
+    r4_barrier();
+    r4_epilogue<G, EP>(part, PN, bv, out, ldo, mask, t);
+    r4_barrier();
+}
+
+template <int NTWM>
+__device__ float flow_log_prob_r4s(const FlowDims& f, const R4Dims& rd, const R4Lds& l, const float* __restrict__ packed,
+                                   float* lds, const Tid4& t, int* grad_off) {
+    using S = R4Stream<NTWM>;
+    constexpr int G = NTWM, RD = S::RD, IS = S::IS;
+    int cur = l.o_X0, nxt = l.o_X1;
+    float* HA = lds + l.o_HA;
+    float* HB = lds + l.o_HB;
+    float* PRM = lds + l.o_PRM;
+    float* DP = lds + l.o_DP;
+    float* PART = lds + l.o_PART;
+    const bool ew = t.tid < 64;
+    const int row = t.tid >> 4, c = t.tid & 15;
+    const int nqD = rd.KD / 16;                        // 1 or 2 k-quads per wave in the D x D maps (D <= 32)
+    const float4* sp = reinterpret_cast<const float4*>(packed + f.o_r4s) + ((size_t)t.wave * G) * 64 + t.lane;
+    float4 ring[RD][G];
+#pragma unroll
+    for (int i = 0; i < RD; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) ring[i][g] = sp[(size_t)i * IS + g * 64];
+    auto refill = [&](auto ic) {                       // item I of the current layer was consumed: request item I + RD
+        constexpr int I = decltype(ic)::value;
+#pragma unroll
+        for (int g = 0; g < G; ++g) ring[I % RD][g] = sp[(size_t)(I + RD) * IS + g * 64];
+    };
+    float bvA[1], bv1[G], bv2[G], bv0[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) bv0[g] = 0.f;
+    float logq = 0.f;
+    {
+        const float* Lp = packed + (size_t)(f.K - 1) * f.layer_stride;
+        r4_bias_load<1>(bvA, Lp + f.o_ac, t);
+        r4_bias_load<G>(bv1, Lp + f.o_b1, t);
+    }
+    for (int layer = f.K - 1; layer >= 0; --layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
+        const bool tl = layer == f.K - 2;
+        if (tl) FAB_TL(f, 0);
+        {   // InvertibleAffine.inverse (+ folded ActNorm): z <- z @ W' + ac
+            R4Pre<2, 1> pa;
+            pa.b[0][0] = ring[S::IA % RD][0]; pa.b[1][0] = ring[S::IA % RD][1];
+            refill(IC<S::IA>{});
+            r4_dense_short<2, 1, 0>(lds + cur, R4_DS, f.D, nqD, pa, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t);
+        }
+        logq += Lp[f.o_logS];
+        float* Z = lds + nxt;
+        if (tl) FAB_TL(f, 1);
+        {   // conditioner, first layer (K = 16: one k-quad per wave)
+            R4Pre<1, G> p1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) p1.b[0][g] = ring[S::IW1 % RD][g];
+            refill(IC<S::IW1>{});
+            r4_dense_short<1, G, 1>(Z, R4_DS, f.d, 1, p1, bv1, HA, l.WS, mk, PART, l.PN, t);
+        }
+        if (tl) FAB_TL(f, 2);
+        float b3s[2] = {0.f, 0.f}, b3c[2] = {0.f, 0.f};
+        r4_bias_load<G>(bv2, Lp + f.o_b2, t);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int j = c + 16 * it;
+            if (ew && j < f.DO) { b3s[it] = Lp[f.o_b3 + j]; b3c[it] = Lp[f.o_b3 + f.DOp + j]; }
+        }
+        if (layer > 0) {
+            const float* Ln = Lp - f.layer_stride;
+            r4_bias_load<1>(bvA, Ln + f.o_ac, t);
+            r4_bias_load<G>(bv1, Ln + f.o_b1, t);
+        }
+        r4s_dense_wide<NTWM, 1, S::IW2>(HA, l.WS, ring, refill, bv2, HB, l.WS, mk + NTHREADS, PART, l.PN, t);
+        if (tl) FAB_TL(f, 3);
+        {   // coupling parameters: N NTWM k-tiles x 2 column tiles = the 2 items after W2
+            R4PreT<NTWM, 2> p3;
+#pragma unroll
+            for (int Q = 0; Q < NTWM; ++Q)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) p3.b[Q][ct] = ring[(S::IW3 + (2 * Q + ct) / G) % RD][(2 * Q + ct) % G];
+            refill(IC<S::IW3>{});
+            refill(IC<S::IW3 + 1>{});
+            r4_dense_n16<NTWM, 2>(HB, l.WS, p3, PRM, R4_DS, PART, l.PN, t);
+        }
+        if (tl) FAB_TL(f, 4);
+        if (ew) {
+            float ssum = 0.f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int j = c + 16 * it;
+                if (j < f.DO) {
+                    const float shift = PRM[row * R4_DS + j] + b3s[it];
+                    const float s = PRM[row * R4_DS + f.DOp + j] + b3c[it];
+                    const float es = expf(-s);
+                    const float v2 = (Z[row * R4_DS + f.d + j] - shift) * es;
+                    Z[row * R4_DS + f.d + j] = v2;
+                    lds[l.o_ES + ((size_t)layer * R4 + row) * f.DOp + j] = es;
+                    lds[l.o_V2 + ((size_t)layer * R4 + row) * f.DOp + j] = v2;
+                    ssum += s;
+                }
+            }
+            logq += -row16_sum(ssum);
+        }
+        r4_barrier();
+        if (tl) FAB_TL(f, 5);
+        sp += (size_t)S::C * IS;
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    if (ew) {
+        const float* base = packed + f.o_base;
+        float* Zc = lds + cur;
+        float bsum = 0.f;
+        for (int j = c; j < f.D; j += 16) {
+            const float ls = base[f.Dp + j];
+            const float sc = expf(ls);
+            const float zn = (Zc[row * R4_DS + j] - base[j]) / sc;
+            bsum += ls + 0.5f * (zn * zn);
+            Zc[row * R4_DS + j] = -(zn / sc);
+        }
+        logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
+    }
+    r4_barrier();
+    bvA[0] = 0.f;
+    for (int layer = 0; layer < f.K; ++layer) {
+        unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
+        float* Gs = lds + cur;
+        const bool tl = layer == 1;
+        if (tl) FAB_TL(f, 16);
+        if (ew) {
+            for (int j = c; j < f.DO; j += 16) {
+                const float g2 = Gs[row * R4_DS + f.d + j];
+                const float es = lds[l.o_ES + ((size_t)layer * R4 + row) * f.DOp + j];
+                const float v2 = lds[l.o_V2 + ((size_t)layer * R4 + row) * f.DOp + j];
+                DP[row * R4_DS + j] = -(g2 * es);
+                DP[row * R4_DS + f.DOp + j] = -(g2 * v2) - 1.f;
+                Gs[row * R4_DS + f.d + j] = g2 * es;
+            }
+        }
+        r4_barrier();
+        if (tl) FAB_TL(f, 17);
+        {   // (shift | scale) -> hidden: K = 32, two k-quads per wave = items 0, 1
+            R4Pre<2, G> ps;
+#pragma unroll
+            for (int g = 0; g < G; ++g) { ps.b[0][g] = ring[S::IW3T % RD][g]; ps.b[1][g] = ring[(S::IW3T + 1) % RD][g]; }
+            refill(IC<S::IW3T>{});
+            refill(IC<S::IW3T + 1>{});
+            r4_dense_short<2, G, 2>(DP, R4_DS, 2 * f.DOp, 2, ps, bv0, HA, l.WS, mk + NTHREADS, PART, l.PN, t);
+        }
+        if (tl) FAB_TL(f, 18);
+        r4s_dense_wide<NTWM, 2, S::IW2T>(HA, l.WS, ring, refill, bv0, HB, l.WS, mk, PART, l.PN, t);
+        if (tl) FAB_TL(f, 19);
+        {   // hidden -> d: NTWM k-tiles x 1 column tile = one item
+            R4PreT<NTWM, 1> p1t;
+#pragma unroll
+            for (int Q = 0; Q < NTWM; ++Q) p1t.b[Q][0] = ring[S::IW1T % RD][Q];
+            refill(IC<S::IW1T>{});
+            r4_dense_n16<NTWM, 1>(HB, l.WS, p1t, PRM, R4_DS, PART, l.PN, t);
+        }
+        if (tl) FAB_TL(f, 20);
+        if (ew)
+            for (int j = c; j < f.d; j += 16) Gs[row * R4_DS + j] += PRM[row * R4_DS + j];
+        r4_barrier();
+        if (tl) FAB_TL(f, 21);
+        {
+            R4Pre<2, 1> pa;
+            pa.b[0][0] = ring[S::IAT % RD][0]; pa.b[1][0] = ring[S::IAT % RD][1];
+            refill(IC<S::IAT>{});
+            r4_dense_short<2, 1, 0>(Gs, R4_DS, f.D, nqD, pa, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t);
+        }
+        if (tl) FAB_TL(f, 22);
+        sp += (size_t)S::C * IS;
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *grad_off = cur;
+    return logq;
+}
+
 }  // namespace fab
