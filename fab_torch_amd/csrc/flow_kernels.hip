@@ -354,10 +354,9 @@ __global__ __launch_bounds__(256) void k_pack_r4(FlowDims f, R4Dims rd, MlpTab t
         else { base = rd.o_W1T; G = 1; }
         const int e = off - base, kk = e & 3, l = (e >> 2) & 63, tile = e >> 8;
         int k, n;
-        if (base == rd.o_W3 || base == rd.o_W1T) {           // 16-column tiles of the 16x16x4 path (r4_dense_n16)
-            const int NT = (base == rd.o_W3 ? 2 * f.DOp : pad16(d)) / 16;
-            const int ct = tile % NT, Q = tile / NT;
-            k = 16 * Q + 4 * (l >> 4) + kk; n = 16 * ct + (l & 15);
+        if (base == rd.o_W3 || base == rd.o_W1T) {           // dense narrow tiles (r4_dense_n16): NSUB k-quads side by side
+            const int CW = base == rd.o_W3 ? 2 * f.DOp : pad16(d), NSUB = 64 / CW;
+            k = 4 * (NSUB * tile + l / CW) + kk; n = l % CW;   // (tiles are wave-major, 4 NTW / NSUB per wave: quads stay in order)
         } else {
             const int g = tile % G, q = tile / G;
             k = 4 * q + kk; n = 64 * g + l;

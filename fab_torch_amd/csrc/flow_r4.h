@@ -39,7 +39,7 @@ FAB_HD R4Dims make_r4_dims(const FlowDims& f) {
     r.o_AWT = o; o += r.KD * 64;
     r.o_W1 = o; o += r.Kd * f.Wp;      // [d -> W]
     r.o_W2 = o; o += f.Wp * f.Wp;      // [W -> W]
-    r.o_W3 = o; o += f.Wp * 2 * f.DOp; // [W -> shift | scale]   (16-column tiles, see r4_dense_n16)
+    r.o_W3 = o; o += f.Wp * 2 * f.DOp; // [W -> shift | scale]   (dense tiles, see r4_dense_n16)
     r.o_W3T = o; o += r.Ko * f.Wp;     // [shift | scale -> W]
     r.o_W2T = o; o += f.Wp * f.Wp;
     r.o_W1T = o; o += f.Wp * pad16(f.d); // [W -> d]            (16-column tiles)
@@ -232,9 +232,11 @@ __device__ __forceinline__ void r4_dense_wide(const float* act, int lda, const f
 
 // ---- narrow outputs (the coupling parameters, N = 2 DOp; the d-wide input gradient, N = pad16(d)) of a K = Wp
 // product: with 64-column groups half to three quarters of every weight tile would be padding, and these stages are
-// bound by the bytes they stream.  They use v_mfma_f32_16x16x4_f32 instead, with the 4 chains in rows 0 .. 3 of its
-// 16-row A operand (rows 4 .. 15 zero): the B operand is a dense [4 k][16 columns] block.  Tile (Q, ct) of the image:
-// lane l = { B[16 Q + 4 (l >> 4) + j][16 ct + (l & 15)] } j < 4; wave w owns k-tiles [NTWM w, NTWM (w + 1)).
+// bound by the bytes they stream.  Their tiles are dense instead: with CW = 16 NT output columns (NT = 1, 2, 4) a tile
+// holds NSUB = 64 / CW consecutive k-quads side by side - lanes [s CW, (s + 1) CW) carry quad NSUB T + s - so the 16
+// blocks of one v_mfma_f32_4x4x1 work on NSUB different k's at once and every lane sub-range accumulates its own partial
+// product (4 NSUB partials per workgroup, added in a fixed order by the epilogue).  Tile T of wave w, lane l:
+// { B[4 (4 NTWM w + NSUB T + l / CW) + j][l % CW] } j < 4; the wave owns NTWM NT tiles (kept as b[T / NT][T % NT]).
 template <int NTWM, int NT>
 struct R4PreT {
     float4 b[NTWM][NT];
@@ -252,36 +254,39 @@ __device__ __forceinline__ void r4_preload_n16(R4PreT<NTWM, NT>& p, const float4
 template <int NTWM, int NT, class Next = R4NoNext>
 __device__ __forceinline__ void r4_dense_n16(const float* act, int lda, const R4PreT<NTWM, NT>& pre, float* out, int ldo,
                                              float* part, int PN, const Tid4& t, Next next = Next()) {
-    f32x4 acc[NT];
+    constexpr int NSUB = 4 / NT, CW = 16 * NT, NTILE = NTWM * NT;
+    static_assert(NT == 1 || NT == 2 || NT == 4, "16, 32 or 64 output columns");
+    const int sblk = t.lane / CW, col = t.lane % CW;
+    const float* arow = act + t.arow * lda + 16 * NTWM * t.wave + 4 * sblk;
+    f32x4 acc0 = (f32x4){0.f, 0.f, 0.f, 0.f}, acc1 = acc0;                        // two chains: no back-to-back dependence
 #pragma unroll
-    for (int ct = 0; ct < NT; ++ct) acc[ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int r16 = t.lane & 15, kq = t.lane >> 4;
-    const bool live = r16 < 4;
-    const float* ap = act + (r16 & 3) * lda + 16 * NTWM * t.wave + 4 * kq;
-#pragma unroll
-    for (int Q = 0; Q < NTWM; ++Q) {
-        float4 a = *reinterpret_cast<const float4*>(ap + 16 * Q);
-        if (!live) a = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.x, pre.b[Q][ct].x, acc[ct]);
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.y, pre.b[Q][ct].y, acc[ct]);
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.z, pre.b[Q][ct].z, acc[ct]);
-#pragma unroll
-        for (int ct = 0; ct < NT; ++ct) acc[ct] = mfma4(a.w, pre.b[Q][ct].w, acc[ct]);
+    for (int T = 0; T < NTILE; ++T) {
+        const float4 a = *reinterpret_cast<const float4*>(arow + 4 * NSUB * T);
+        const float4 w = pre.b[T / NT][T % NT];
+        acc0 = mfma44(a.x, w.x, acc0);
+        acc1 = mfma44(a.y, w.y, acc1);
+        acc0 = mfma44(a.z, w.z, acc0);
+        acc1 = mfma44(a.w, w.w, acc1);
     }
     next();
-    if (kq == 0) {                                   // lanes 0 .. 15 hold rows 0 .. 3 (VGPR r) of column 16 ct + lane
-        float* pw = part + (size_t)t.wave * R4 * PN + r16;
+    acc0 += acc1;
+    (void)PN;
+    float* pw = part + ((size_t)(t.wave * NSUB + sblk) * R4) * CW + col;            // partial p = wave NSUB + sblk: [p][row][CW]
 #pragma unroll
-        for (int ct = 0; ct < NT; ++ct)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) pw[r * PN + 16 * ct] = acc[ct][r];
-    }
+    for (int r = 0; r < 4; ++r) pw[r * CW] = acc0[r];
     r4_barrier();
-    const float bv[1] = {0.f};
-    r4_epilogue<1, 0>(part, PN, bv, out, ldo, nullptr, t);     // (columns >= 16 NT of `out` receive stale partials: unused)
+    if (t.tid < R4 * CW) {
+        const int row = t.tid / CW, c = t.tid - row * CW;
+        const float* p = part + row * CW + c;
+        float v[4 * NSUB];
+#pragma unroll
+        for (int i = 0; i < 4 * NSUB; ++i) v[i] = p[(size_t)i * R4 * CW];
+#pragma unroll
+        for (int n = 4 * NSUB; n > 1; n >>= 1)                                      // fixed pairwise tree
+#pragma unroll
+            for (int i = 0; i < n / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
+        out[row * ldo + c] = v[0];
+    }
     r4_barrier();
 }
 
