@@ -143,3 +143,27 @@ def test_four_chain_tiles_are_bitwise_reproducible():
             outs.append((pt.x.clone(), lw.clone(), hmc.epsilons.clone()))
         for o in outs[1:]:
             assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
+
+
+@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 1024), (6, 3, 40, 70), (16, 3, 8, 257)])
+def test_stream_and_staged_four_chain_kernels_are_bit_identical(monkeypatch, D, K, nodes, B):
+    """The 4-chain kernel exists in two request schedules - one continuous weight stream per wave (D <= 32, hidden width
+    >= 128) and per-stage request groups (everything else; FABHIP_R4_STREAM=0 forces it) - with the same arithmetic in the
+    same order: identical bits."""
+    torch.manual_seed(D + K)
+    flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FABHIP_R4_STREAM", mode)
+        hmc = fa.HamiltonianMonteCarlo(3, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
+                                       n_outer=2, L=4).to(DEV)
+        g = torch.Generator(device=DEV).manual_seed(5)
+        x0, _ = flow.native_sample(torch.randn(B, D, device=DEV, generator=g))
+        pt = fa.create_point(x0, flow, target, with_grad=True)
+        torch.manual_seed(7)
+        out = hmc.transition(pt, 1, 0.3)
+        res.append((out.x.clone(), out.log_q.clone(), out.grad_log_q.clone(), hmc.epsilons.clone()))
+    monkeypatch.delenv("FABHIP_R4_STREAM")
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
