@@ -287,6 +287,15 @@ def main():
                 "workgroups": n_wg, "frac_of_occupied_cus": ach / (PEAK_FP32_MFMA_TFLOPS * min(n_wg, 256) / 256)}
         # HBM traffic per launch: separate rocprofv3 --pmc passes of tools/prof_hmc.py (same kernel, same shape),
         # summarised by tools/pmc_summary.py and committed; not collectable from inside this process.
+        if r4:
+            # the binding resource of the 4-chain kernel is not the matrix pipe but each CU's L2 -> VGPR weight stream: every
+            # workgroup reads the whole r4 image once per flow evaluation (forward + reverse sweep)
+            wp = 64 * ((D * NODES + 63) // 64)
+            per_pair = 4 * (2 * 32 * 64 + 16 * wp + 2 * wp * wp + wp * 32 + wp * 16 + 32 * wp)     # bytes per layer pair (D = 32)
+            stream = per_pair * K_LAYERS * L
+            roof["weight_stream"] = {"bytes_per_workgroup_per_launch": stream, "GBps_per_cu": stream / t_kernel / 1e9,
+                                     "note": "tools/ubench/stream.hip: 48 B/clk per CU for a pure stream of an image this size "
+                                             "(~100 GB/s at the ~2.1 GHz the kernel runs at); DESIGN.md section 4"}
         if r4:      # no FETCH_SIZE figure for this kernel (the pass does not finish under rocprofv3 on this pool): traffic = null
             pmc = os.path.join(ROOT, "profiles", "r2", "hmc_step_r4_pmc_summary.json")
             if os.path.exists(pmc):
