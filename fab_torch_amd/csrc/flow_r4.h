@@ -251,7 +251,8 @@ __device__ __forceinline__ void r4_preload_n16(R4PreT<NTWM, NT>& p, const float4
         for (int ct = 0; ct < NT; ++ct) p.b[Q][ct] = bw[(size_t)(Q * NT + ct) * 64];
 }
 
-template <int NTWM, int NT, class Next = R4NoNext>
+// ACC: the result is added to `out` (the d-wide input gradient joins the cotangent it belongs to: no separate stage)
+template <int NTWM, int NT, bool ACC = false, class Next = R4NoNext>
 __device__ __forceinline__ void r4_dense_n16(const float* act, int lda, const R4PreT<NTWM, NT>& pre, float* out, int ldo,
                                              float* part, int PN, const Tid4& t, Next next = Next()) {
     constexpr int NSUB = 4 / NT, CW = 16 * NT, NTILE = NTWM * NT;
@@ -285,7 +286,8 @@ __device__ __forceinline__ void r4_dense_n16(const float* act, int lda, const R4
         for (int n = 4 * NSUB; n > 1; n >>= 1)                                      // fixed pairwise tree
 #pragma unroll
             for (int i = 0; i < n / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
-        out[row * ldo + c] = v[0];
+        if (ACC) out[row * ldo + c] += v[0];
+        else out[row * ldo + c] = v[0];
     }
     r4_barrier();
 }
@@ -481,13 +483,10 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
         if (tl) FAB_TL(f, 19);
         const float4* Wnext = reinterpret_cast<const float4*>(Rp + rd.layer_stride + rd.o_W2T);
         const bool more = layer + 1 < f.K;
-        r4_dense_n16<NTWM, NT1>(HB, l.WS, preN1, PRM, R4_DS, PART, l.PN, t, [&] {
+        r4_dense_n16<NTWM, NT1, true>(HB, l.WS, preN1, Gs, R4_DS, PART, l.PN, t, [&] {
             if (more) r4_preload_part<0, 2>(preW, Wnext, qW, t);
-        });
+        });                                           // g[:, :d] += (conditioner input gradient)
         if (tl) FAB_TL(f, 20);
-        if (ew)
-            for (int j = c; j < f.d; j += 16) Gs[row * R4_DS + j] += PRM[row * R4_DS + j];
-        r4_barrier();
         if (tl) FAB_TL(f, 21);
         r4_dense_short<NQA, 1, 0>(Gs, R4_DS, f.D, nqD, preA, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t, [&] {
             if (more) r4_preload_part<2, 3>(preW, Wnext, qW, t);
@@ -698,12 +697,9 @@ __device__ float flow_log_prob_r4s(const FlowDims& f, const R4Dims& rd, const R4
 #pragma unroll
             for (int Q = 0; Q < NTWM; ++Q) p1t.b[Q][0] = ring[S::IW1T % RD][Q];
             refill(IC<S::IW1T>{});
-            r4_dense_n16<NTWM, 1>(HB, l.WS, p1t, PRM, R4_DS, PART, l.PN, t);
+            r4_dense_n16<NTWM, 1, true>(HB, l.WS, p1t, Gs, R4_DS, PART, l.PN, t);     // g[:, :d] += (conditioner input gradient)
         }
         if (tl) FAB_TL(f, 20);
-        if (ew)
-            for (int j = c; j < f.d; j += 16) Gs[row * R4_DS + j] += PRM[row * R4_DS + j];
-        r4_barrier();
         if (tl) FAB_TL(f, 21);
         {
             R4Pre<2, 1> pa;
