@@ -196,9 +196,16 @@ __device__ __forceinline__ void r4_bias_load(float (&bv)[G], const float* __rest
 
 // epilogue: OUT[row][col] = f(bias[col] + ((P0 + P1) + (P2 + P3))) for this thread's G of the 4 x 64 G outputs
 // (row o / (64 G), col o % (64 G)).  EP 0: plain, 1: ReLU, sign bit i kept in *mask, 2: multiplied by sign bit i.
-template <int G, int EP>
+struct R4NoPost {
+    __device__ __forceinline__ float operator()(int, int, float v) const { return v; }
+};
+
+// `post(row, col, v)` maps the finished value before it is stored (the D x D map of the reverse sweep hands its result
+// straight to the next layer's coupling cotangents)
+template <int G, int EP, class Post = R4NoPost>
 __device__ __forceinline__ void r4_epilogue(const float* __restrict__ part, int PN, const float (&bv)[G],
-                                            float* __restrict__ out, int ldo, unsigned* mask, const Tid4& t) {
+                                            float* __restrict__ out, int ldo, unsigned* mask, const Tid4& t,
+                                            Post post = Post()) {
     constexpr int N = 64 * G;
     unsigned m = EP == 2 ? mask[t.tid] : 0u;
 #pragma unroll
@@ -208,7 +215,7 @@ __device__ __forceinline__ void r4_epilogue(const float* __restrict__ part, int 
         float v = ((p[0] + p[R4 * PN]) + (p[2 * R4 * PN] + p[3 * R4 * PN])) + bv[i];
         if (EP == 1) { const bool pos = v > 0.f; m |= (pos ? 1u : 0u) << i; v = pos ? v : 0.f; }
         if (EP == 2) v = ((m >> i) & 1u) ? v : 0.f;
-        out[row * ldo + col] = v;
+        out[row * ldo + col] = post(row, col, v);
     }
     if (EP == 1) mask[t.tid] = m;
 }
@@ -293,10 +300,10 @@ __device__ __forceinline__ void r4_dense_n16(const float* act, int lda, const R4
 }
 
 // short K (nqw <= NQ quads per wave), all tiles preloaded
-template <int NQ, int G, int EP, class Next = R4NoNext>
+template <int NQ, int G, int EP, class Next = R4NoNext, class Post = R4NoPost>
 __device__ __forceinline__ void r4_dense_short(const float* act, int lda, int kmax, int nqw, const R4Pre<NQ, G>& pre,
                                                const float (&bv)[G], float* out, int ldo, unsigned* mask, float* part, int PN,
-                                               const Tid4& t, Next next = Next()) {
+                                               const Tid4& t, Next next = Next(), Post post = Post()) {
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -316,7 +323,7 @@ __device__ __forceinline__ void r4_dense_short(const float* act, int lda, int km
     next();
     r4_store_part<G>(acc, part, PN, t);
     r4_barrier();
-    r4_epilogue<G, EP>(part, PN, bv, out, ldo, mask, t);
+    r4_epilogue<G, EP>(part, PN, bv, out, ldo, mask, t, post);
     r4_barrier();
 }
 
@@ -455,17 +462,31 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
         const bool tl = layer == 1;
         if (tl) FAB_TL(f, 16);
         r4_preload_part<3, 5>(preW, reinterpret_cast<const float4*>(Rp + rd.o_W2T), qW, t);
-        if (ew) {
-            for (int j = c; j < f.DO; j += 16) {
-                const float g2 = Gs[row * R4_DS + f.d + j];
-                const float es = lds[l.o_ES + ((size_t)layer * R4 + row) * f.DOp + j];
-                const float v2 = lds[l.o_V2 + ((size_t)layer * R4 + row) * f.DOp + j];
-                DP[row * R4_DS + j] = -(g2 * es);
-                DP[row * R4_DS + f.DOp + j] = -(g2 * v2) - 1.f;
-                Gs[row * R4_DS + f.d + j] = g2 * es;
+        if (layer == 0) {                             // (layers > 0: done by the previous layer's D x D epilogue, `couple` below)
+            if (ew) {
+                for (int j = c; j < f.DO; j += 16) {
+                    const float g2 = Gs[row * R4_DS + f.d + j];
+                    const float es = lds[l.o_ES + (size_t)row * f.DOp + j];
+                    const float v2 = lds[l.o_V2 + (size_t)row * f.DOp + j];
+                    DP[row * R4_DS + j] = -(g2 * es);
+                    DP[row * R4_DS + f.DOp + j] = -(g2 * v2) - 1.f;
+                    Gs[row * R4_DS + f.d + j] = g2 * es;
+                }
             }
+            r4_barrier();
         }
-        r4_barrier();
+        // cotangents of the NEXT layer's coupling parameters, formed where its input gradient is produced
+        auto couple = [&](int r, int col, float v) -> float {
+            if (layer + 1 < f.K && col >= f.d && col < f.d + f.DO) {
+                const int j = col - f.d;
+                const float es = lds[l.o_ES + ((size_t)(layer + 1) * R4 + r) * f.DOp + j];
+                const float v2 = lds[l.o_V2 + ((size_t)(layer + 1) * R4 + r) * f.DOp + j];
+                DP[r * R4_DS + j] = -(v * es);
+                DP[r * R4_DS + f.DOp + j] = -(v * v2) - 1.f;
+                return v * es;
+            }
+            return v;
+        };
         if (tl) FAB_TL(f, 17);
         r4_dense_short<NQS, G, 2>(DP, R4_DS, 2 * f.DOp, nqo, preS, bv0, HA, l.WS, mk + NTHREADS, PART, l.PN, t, [&] {
             r4_preload_part<5, RD>(preW, reinterpret_cast<const float4*>(Rp + rd.o_W2T), qW, t);
@@ -490,7 +511,7 @@ __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4L
         if (tl) FAB_TL(f, 21);
         r4_dense_short<NQA, 1, 0>(Gs, R4_DS, f.D, nqD, preA, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t, [&] {
             if (more) r4_preload_part<2, 3>(preW, Wnext, qW, t);
-        });
+        }, couple);
         if (tl) FAB_TL(f, 22);
         const int tmp = cur; cur = nxt; nxt = tmp;
     }
@@ -669,17 +690,31 @@ __device__ float flow_log_prob_r4s(const FlowDims& f, const R4Dims& rd, const R4
         float* Gs = lds + cur;
         const bool tl = layer == 1;
         if (tl) FAB_TL(f, 16);
-        if (ew) {
-            for (int j = c; j < f.DO; j += 16) {
-                const float g2 = Gs[row * R4_DS + f.d + j];
-                const float es = lds[l.o_ES + ((size_t)layer * R4 + row) * f.DOp + j];
-                const float v2 = lds[l.o_V2 + ((size_t)layer * R4 + row) * f.DOp + j];
-                DP[row * R4_DS + j] = -(g2 * es);
-                DP[row * R4_DS + f.DOp + j] = -(g2 * v2) - 1.f;
-                Gs[row * R4_DS + f.d + j] = g2 * es;
+        if (layer == 0) {                             // (layers > 0: done by the previous layer's D x D epilogue, `couple` below)
+            if (ew) {
+                for (int j = c; j < f.DO; j += 16) {
+                    const float g2 = Gs[row * R4_DS + f.d + j];
+                    const float es = lds[l.o_ES + (size_t)row * f.DOp + j];
+                    const float v2 = lds[l.o_V2 + (size_t)row * f.DOp + j];
+                    DP[row * R4_DS + j] = -(g2 * es);
+                    DP[row * R4_DS + f.DOp + j] = -(g2 * v2) - 1.f;
+                    Gs[row * R4_DS + f.d + j] = g2 * es;
+                }
             }
+            r4_barrier();
         }
-        r4_barrier();
+        // cotangents of the NEXT layer's coupling parameters, formed where its input gradient is produced
+        auto couple = [&](int r, int col, float v) -> float {
+            if (layer + 1 < f.K && col >= f.d && col < f.d + f.DO) {
+                const int j = col - f.d;
+                const float es = lds[l.o_ES + ((size_t)(layer + 1) * R4 + r) * f.DOp + j];
+                const float v2 = lds[l.o_V2 + ((size_t)(layer + 1) * R4 + r) * f.DOp + j];
+                DP[r * R4_DS + j] = -(v * es);
+                DP[r * R4_DS + f.DOp + j] = -(v * v2) - 1.f;
+                return v * es;
+            }
+            return v;
+        };
         if (tl) FAB_TL(f, 17);
         {   // (shift | scale) -> hidden: K = 32, two k-quads per wave = items 0, 1
             R4Pre<2, G> ps;
@@ -705,7 +740,7 @@ __device__ float flow_log_prob_r4s(const FlowDims& f, const R4Dims& rd, const R4
             R4Pre<2, 1> pa;
             pa.b[0][0] = ring[S::IAT % RD][0]; pa.b[1][0] = ring[S::IAT % RD][1];
             refill(IC<S::IAT>{});
-            r4_dense_short<2, 1, 0>(Gs, R4_DS, f.D, nqD, pa, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t);
+            r4_dense_short<2, 1, 0>(Gs, R4_DS, f.D, nqD, pa, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t, R4NoNext(), couple);
         }
         if (tl) FAB_TL(f, 22);
         sp += (size_t)S::C * IS;
