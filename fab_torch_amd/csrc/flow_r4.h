@@ -88,10 +88,9 @@ struct Tid4 {
     }
 };
 
-// ---- weight tiles requested one stage ahead --------------------------------------------------------------------
-// hipcc puts s_waitcnt vmcnt(0) in front of every workgroup barrier, so a request issued inside a short stage is
-// waited for at that stage's own barrier (measured: every short stage then lasts one L2 / MALL latency, 2 - 3 k cycles).
-// Weights are therefore requested only from inside the long W x W stages (see flow_log_prob_r4).
+// ---- weight tiles requested ahead of their stage (per-stage schedule: flow_log_prob_r4) -------------------------------
+// A stage that requests its own weights starts with a cold L2 / MALL access (2 - 3 k cycles, 8 stages per layer pair), so
+// tiles are requested earlier and parked in registers (R4Pre / R4PreT) until their stage runs.
 template <int NQ, int G>
 struct R4Pre {
     float4 b[NQ][G];                   // tiles (q, g) of the first NQ k-quads of this wave's K range
@@ -332,11 +331,11 @@ __device__ __forceinline__ void r4_dense_short(const float* act, int lda, int km
 // offset is returned through *grad_off.  Same arithmetic as flow_log_prob_tile<GRAD = true> (flow_device.h) up to the
 // summation order inside the GEMMs.  Returns log q of row `tid >> 4` on wave 0 (other waves: undefined).
 // ------------------------------------------------------------------------------------------------
-// All weights of the stages between two W x W GEMMs are requested at the START of the preceding W x W stage (its ~8 k
-// cycles of streaming hide them, and hipcc's vmcnt(0) in front of every workgroup barrier then finds nothing pending in
-// the short stages): forward W2(layer) -> { W3(layer), AW / W1 / first W2 chunk of layer - 1 }, reverse W2T(layer) ->
-// { W1T, AWT of the layer, W3T / first W2T chunk of layer + 1 }.  NQS / NQA: k-quads per wave of the short GEMMs into
-// the hidden width / of the D x D maps (2 for D <= 32, 4 above).
+// Per-stage request schedule (used for D > 32 or a hidden width of 64; the stream variant below covers the rest): the
+// weights of the stages between two W x W GEMMs are requested at the START of the preceding W x W stage - forward W2(layer)
+// -> { W3(layer), AW / W1 of layer - 1 }, reverse W2T(layer) -> { W1T, AWT of the layer, W3T of layer + 1 } - and the first
+// RD quads of every W x W GEMM a few per short stage before it.  NQS / NQA: k-quads per wave of the short GEMMs into the
+// hidden width / of the D x D maps (2 for D <= 32, 4 above); NT3 / NT1: 16-column units of the narrow outputs.
 template <int NTWM, int NQS, int NQA, int NT3, int NT1>
 __device__ float flow_log_prob_r4(const FlowDims& f, const R4Dims& rd, const R4Lds& l, const float* __restrict__ packed,
                                   float* lds, const Tid4& t, int* grad_off) {
