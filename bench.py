@@ -197,7 +197,7 @@ def main():
     def step():
         pt, log_w = ais.sample_and_log_weights(B_PER_GPU)
         if distributed:
-            return parallel.gather_particles(pt.x, log_w, pt.log_q, B_PER_GPU)
+            return parallel.gather_particles(pt.x, log_w, pt.log_q, B_PER_GPU, compact=False)   # (dropped chains: log_w = -inf rows)
         return pt.x, log_w, pt.log_q
 
     def barrier():

@@ -43,15 +43,21 @@ def unpack_particles(buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, tor
     return flat[:, :D], flat[:, D], flat[:, D + 1]
 
 
-def gather_particles(x, log_w, log_q, capacity: int, group=None):
-    """All-gather fixed-size shards (invalid rows stay in place with log_w = -inf, compaction after)."""
+def gather_particles(x, log_w, log_q, capacity: int, group=None, compact: bool = True):
+    """All-gather fixed-size shards (invalid rows stay in place with log_w = -inf, compaction after).
+    compact=False skips the compaction - and with it the host synchronisation of the boolean-mask indexing: the result
+    keeps `world * capacity` rows, dropped chains appear as rows with log_w = -inf (weight 0 for ESS / log Z /
+    resampling) and x = 0."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     buf = pack_particles(x, log_w, log_q, capacity)
-    if world == 1:
+    if world > 1:
+        out = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
+        dist.all_gather_into_tensor(out, buf, group=group)
+        buf = out
+    if compact:
         return unpack_particles(buf)
-    out = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
-    return unpack_particles(out)
+    D = buf.shape[-1] - 3
+    return buf[:, :D], buf[:, D], buf[:, D + 1]
 
 
 class ShardedAIS:
