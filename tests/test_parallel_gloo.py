@@ -99,3 +99,36 @@ def test_two_rank_step_size_averaging_is_one_collective_and_identical_on_all_ran
     a, b = torch.load(out + "0"), torch.load(out + "1")
     assert torch.equal(a["eps"], b["eps"]) and torch.equal(a["ceps"], b["ceps"])
     assert torch.allclose(a["eps"], torch.full((3, 1), 0.15)) and torch.allclose(a["ceps"], torch.tensor([0.015]))
+
+
+def _worker_nocompact(rank, world, port, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    sizes = parallel.shard_sizes(total, world)
+    x, lw, lq = _local_sampler_factory(rank)(sizes[rank])
+    xg, lwg, lqg = parallel.gather_particles(x, lw, lq, max(sizes), compact=False)
+    if rank == 0:
+        torch.save({"x": xg.clone(), "lw": lwg.clone(), "lq": lqg.clone()}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_without_compaction_keeps_fixed_size_and_marks_dropped_chains(tmp_path):
+    """compact=False (what bench.py times on N > 1: no boolean-mask indexing, no host synchronisation): world * capacity
+    rows, dropped / padding rows carry log_w = -inf and x = 0, and the finite rows are exactly the compacted result."""
+    world, total = 2, 21
+    out = str(tmp_path / "r0.pt")
+    mp.spawn(_worker_nocompact, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    got = torch.load(out)
+    cap = max(parallel.shard_sizes(total, world))
+    assert got["x"].shape[0] == world * cap and got["lw"].shape[0] == world * cap
+    keep = torch.isfinite(got["lw"])
+    assert int((~keep).sum()) == world * cap - (total - 1)          # one NaN chain on rank 1 + one padding row
+    assert bool((got["x"][~keep] == 0).all())
+    xs, lws = [], []
+    for r, b in enumerate(parallel.shard_sizes(total, world)):
+        x, lw, lq = _local_sampler_factory(r)(b)
+        xs.append(x); lws.append(lw)
+    np.testing.assert_array_equal(got["x"][keep].numpy(), torch.cat(xs).numpy())
+    np.testing.assert_array_equal(got["lw"][keep].numpy(), torch.cat(lws).numpy())
