@@ -96,9 +96,9 @@ SYMBOLS = [
     "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept", "fabhip_fixed_cdf",
     "fabhip_spline_packed_floats", "fabhip_spline_pack", "fabhip_spline_workspace_bytes", "fabhip_spline_log_prob",
     "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
-    "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_debug_spline_timeline",
+    "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_set_option", "fabhip_get_option", "fabhip_debug_spline_timeline",
 ]
-ABI_VERSION = 204          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 205          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):

@@ -14,10 +14,12 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 204          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+ABI_VERSION = 205          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
 TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
+# developer / test switches of include/fabhip.h (fabhip_set_option)
+OPT_TILE_SHAPE, OPT_R4_STREAM, OPT_SCAN_VARIANT, OPT_SYSTEMATIC_VARIANT, OPT_SPLINE_STAGED, OPT_TIMELINE = range(6)
 
 
 class FabhipError(RuntimeError):
@@ -26,6 +28,21 @@ class FabhipError(RuntimeError):
 
 _ops = None
 _lock = threading.Lock()
+
+
+class option:
+    """`with _ops.option(_ops.OPT_TILE_SHAPE, 16): ...` - set one developer switch of the library (tests, tools; A/B
+    variants of one computation) and restore it on exit.  Nothing in the product path uses this."""
+
+    def __init__(self, key: int, value: int):
+        self.key, self.prev = key, int(load().set_option(int(key), int(value)))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        load().set_option(self.key, self.prev)
+        return False
 
 
 def load():

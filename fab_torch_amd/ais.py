@@ -130,7 +130,9 @@ class AnnealedImportanceSampler:
                         raise_at_end: bool = True):
         """ais.py:53-105 for ANY `Distribution` / `LogProbFunc` plug-ins (fab/types_.py:5-27): the reference's loop,
         stepped from Python; the plug-ins evaluate their own densities, the transitions / log-weight arithmetic /
-        ESS run as fabhip kernels (transition_operators.py: generic path)."""
+        ESS run as fabhip kernels (transition_operators.py: generic path).  Explicit noise (parity replays): after the
+        chain-init filter has dropped rows, noise row i belongs to the i-th SURVIVING chain - the reference draws
+        `randn_like(point.x)` of the filtered shape (hmc.py:134), and the fused path indexes its noise the same way."""
         ops = _ops.load()
         op = self.transition_operator
         B, M = int(batch_size), self.n_intermediate_distributions

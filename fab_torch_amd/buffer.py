@@ -50,6 +50,13 @@ class PrioritisedReplayBuffer:
                  initial_sampler: Callable[[], Tuple[torch.Tensor, torch.Tensor, torch.Tensor]], device: str = "cpu",
                  sample_with_replacement: bool = False, fill_buffer_during_init: bool = True):
         assert min_sample_length < max_length
+        # the reference defaults to a host buffer and samples it with torch.topk / Categorical on the CPU; here sample()
+        # always runs the HIP top-k / multinomial kernels.  add() / adjust() are plain tensor code and work anywhere (the
+        # CPU tests pin them against the reference's buffer), so a host buffer is allowed but announced up front
+        if torch.device(device).type != "cuda":
+            import warnings
+            warnings.warn(f"PrioritisedReplayBuffer(device={device!r}): sample() needs the buffer on the GPU (there is no "
+                          "CPU sampling path in this package) - pass device='cuda' / the flow's device", stacklevel=2)
         self.dim, self.max_length, self.min_sample_length = dim, max_length, min_sample_length
         self.buffer = ReplayData(x=torch.zeros(max_length, dim, device=device),
                                  log_w=torch.zeros(max_length, device=device),

@@ -736,12 +736,12 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
 }
 
 // 4-chain tiles pay when 16-chain tiles cannot fill the chip: up to 288 workgroups of 4 chains (B <= 1152); off in fast
-// mode (no bf16 variant of the 4-chain kernel).  FABHIP_R4=0 / 1 forces the choice (tests exercise both shapes).
+// mode (no bf16 variant of the 4-chain kernel).  FABHIP_OPT_TILE_SHAPE = 16 / 4 forces the choice (tests exercise both).
 static bool use_r4_tiles(long B) {
     if (fast_mode()) return false;
-    const char* e = getenv("FABHIP_R4");
-    if (e && e[0] == '0') return false;
-    if (e && e[0] == '1') return true;
+    const int shape = option(FABHIP_OPT_TILE_SHAPE);
+    if (shape == 16) return false;
+    if (shape == 4) return true;
     return B <= 1152;
 }
 
@@ -755,12 +755,14 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
     const R4Lds l = make_r4_lds(f);
     const ExtraLds4 x = make_extra_lds4(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
-    const dim3 grid((unsigned)((a.B + R4 - 1) / R4));
-    const char* es = getenv("FABHIP_R4_STREAM");          // "0": per-stage request groups also where the stream image exists
+    // every row of the ceil(B / 16) sixteen-row blocks k_hmc_adapt sums is written by some workgroup (workgroups past
+    // the last chain take the early-return branch and write zeros): the scratch is never read uninitialised
+    const dim3 grid((unsigned)(nblk_of(a.B) * (ROWS / R4)));
+    const bool stream = option(FABHIP_OPT_R4_STREAM) != 0;  // 0: per-stage request groups also where the stream image exists
     if (f.D > 32) {
         FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, true, false>, bytes));
         hipLaunchKernelGGL((k_hmc_step_r4<NTWM, true, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
-    } else if (NTWM >= 2 && f.o_r4s >= 0 && !(es && es[0] == '0')) {
+    } else if (NTWM >= 2 && f.o_r4s >= 0 && stream) {
         constexpr int NS = NTWM >= 2 ? NTWM : 2;           // (never instantiates the stream code for NTWM = 1)
         FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, true>, bytes));
         hipLaunchKernelGGL((k_hmc_step_r4<NS, false, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);

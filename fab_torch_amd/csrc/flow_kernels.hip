@@ -436,7 +436,7 @@ static long long* g_timeline = nullptr;
 namespace fab {
 // dev-only (FABHIP_TIMELINE=1): the 64-stamp buffer, zeroed on `st`; nullptr when the switch is off
 long long* debug_timeline(hipStream_t st) {
-    if (!getenv("FABHIP_TIMELINE")) return nullptr;
+    if (!option(FABHIP_OPT_TIMELINE)) return nullptr;
     if (!g_timeline && hipMalloc((void**)&g_timeline, 64 * 8) != hipSuccess) return nullptr;
     (void)hipMemsetAsync(g_timeline, 0, 64 * 8, st);
     return g_timeline;
@@ -446,6 +446,23 @@ long long* debug_timeline(hipStream_t st) {
 namespace fab {
 static int g_fast_mode = 0;
 int fast_mode() { return g_fast_mode; }
+
+// developer switches: defaults, overridden once from the environment when the library is loaded
+struct Options {
+    int v[FABHIP_OPT_COUNT];
+    Options() {
+        static const struct { int key; const char* env; int dflt; } tab[FABHIP_OPT_COUNT] = {
+            {FABHIP_OPT_TILE_SHAPE, "FABHIP_TILE", 0},           {FABHIP_OPT_R4_STREAM, "FABHIP_R4_STREAM", 1},
+            {FABHIP_OPT_SCAN_VARIANT, "FABHIP_SCAN_VARIANT", 3}, {FABHIP_OPT_SYSTEMATIC_VARIANT, "FABHIP_SYSTEMATIC_VARIANT", 1},
+            {FABHIP_OPT_SPLINE_STAGED, "FABHIP_SPLINE_STAGED", 0}, {FABHIP_OPT_TIMELINE, "FABHIP_TIMELINE", 0}};
+        for (const auto& t : tab) {
+            const char* e = getenv(t.env);
+            v[t.key] = (e && e[0]) ? atoi(e) : t.dflt;
+        }
+    }
+};
+static Options g_options;
+int option(int key) { return g_options.v[key]; }
 }  // namespace fab
 
 extern "C" {
@@ -457,6 +474,15 @@ int fabhip_set_fast_mode(int on) {
 }
 
 int fabhip_get_fast_mode(void) { return fab::g_fast_mode; }
+
+int fabhip_set_option(int key, int value) {
+    if (key < 0 || key >= FABHIP_OPT_COUNT) return FABHIP_EINVAL;
+    const int prev = fab::g_options.v[key];
+    fab::g_options.v[key] = value;
+    return prev;
+}
+
+int fabhip_get_option(int key) { return (key < 0 || key >= FABHIP_OPT_COUNT) ? FABHIP_EINVAL : fab::g_options.v[key]; }
 
 int fabhip_debug_timeline(int64_t* host_out, int32_t n) {
     if (!g_timeline || !host_out || n < 1 || n > 64) return FABHIP_EINVAL;
@@ -520,7 +546,7 @@ int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, 
     FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
     if (B == 0) return FABHIP_OK;
     FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
-    if (getenv("FABHIP_TIMELINE")) {          // diagnostics only: never set in production (allocates once)
+    if (option(FABHIP_OPT_TIMELINE)) {        // diagnostics only: never set in production (allocates once)
         if (!g_timeline && hipMalloc((void**)&g_timeline, 64 * 8) != hipSuccess) return FABHIP_ELAUNCH;
         hipMemsetAsync(g_timeline, 0, 64 * 8, (hipStream_t)stream);
         f.timeline = g_timeline;

@@ -12,6 +12,8 @@ namespace fab {
 
 // process-wide fast-mode switch (fabhip_set_fast_mode, flow_kernels.hip)
 int fast_mode();
+// developer switches (fabhip_set_option; flow_kernels.hip): one int load, initialised from the environment at load time
+int option(int key);
 
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
 

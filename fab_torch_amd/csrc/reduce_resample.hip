@@ -1153,7 +1153,7 @@ static ScanWs carve_scan_ws(void* workspace, long n) {
     ws.cdf16 = (unsigned long long*)p; p += al256(((size_t)n / 16 + 1) * 8);
     ws.cdf256 = (unsigned long long*)p;
     ws.want_sub = 0;
-    { const char* e = getenv("FABHIP_SCAN_VARIANT"); ws.variant = e ? atoi(e) : 3; }   // 3 = LDS-transposed scan; 0-2 = register/shuffle variants (A/B)
+    ws.variant = option(FABHIP_OPT_SCAN_VARIANT);   // 3 = LDS-transposed scan; 0-2 = register/shuffle variants (A/B)
     return ws;
 }
 
@@ -1293,8 +1293,8 @@ int fabhip_resample_systematic(const float* log_w, int64_t n, double u0, int64_t
     if (n_samples == 0) return FABHIP_OK;
     const long nwt = ((long)n + EM_WAVE_ITEMS - 1) / EM_WAVE_ITEMS;
     const long nbk = ((long)n + EM_BLOCK - 1) / EM_BLOCK;
-    const char* var = getenv("FABHIP_SYSTEMATIC_VARIANT");      // 0 = scan + CDF in HBM + search (A/B reference)
-    if ((var && atoi(var) == 0) || n_samples >= (1ll << 31) - 2) {
+    // FABHIP_OPT_SYSTEMATIC_VARIANT 0 = scan + CDF in HBM + search (A/B reference)
+    if (option(FABHIP_OPT_SYSTEMATIC_VARIANT) == 0 || n_samples >= (1ll << 31) - 2) {
         FAB_TRY(build_fixed_cdf(log_w, n, ws, st));
         unsigned long long* strata = ws.desc;                    // the descriptors are dead once the scan is done
         hipLaunchKernelGGL(k_strata_params, dim3(1), dim3(1), 0, st, ws.tile_inc + (scan_tiles(n) - 1), u0,

@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_fast(SplineDims f, 
 // dev-only stage timeline (FABHIP_TIMELINE=1): s_memtime stamps of workgroup 0 in layer 1 of k_spline_logprob
 static long long* g_sp_timeline = nullptr;
 static long long* sp_timeline(hipStream_t st) {
-    if (!getenv("FABHIP_TIMELINE")) return nullptr;
+    if (!option(FABHIP_OPT_TIMELINE)) return nullptr;
     if (!g_sp_timeline && hipMalloc((void**)&g_sp_timeline, 32 * 8) != hipSuccess) return nullptr;
     hipMemsetAsync(g_sp_timeline, 0, 32 * 8, st);
     return g_sp_timeline;
@@ -1265,7 +1265,7 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     unsigned long long* bits = grad_x ? (unsigned long long*)ws : nullptr;   // ReLU decisions (one-launch kernel)
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
-    if (!tape && !getenv("FABHIP_SPLINE_STAGED")) {           // one launch (the staged kernels below: tape, debugging)
+    if (!tape && !option(FABHIP_OPT_SPLINE_STAGED)) {           // one launch (the staged kernels below: tape, debugging)
         if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
         if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
         if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);

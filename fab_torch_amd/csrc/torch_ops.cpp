@@ -47,6 +47,22 @@ float* fpm(const Tensor& t, const char* name) { need(t, at::kFloat, name); retur
 float* fpm_opt(const optional<Tensor>& t, const char* name) { return t.has_value() ? fpm(*t, name) : nullptr; }
 const float* fp_opt(const optional<Tensor>& t, const char* name) { return t.has_value() ? fp(*t, name) : nullptr; }
 
+// The kernels index raw pointers: every tensor whose pointer goes into an argument struct is checked for its element
+// count and for living on the device of the tensor the launch is enqueued for (`ref`).  `at_least`: n is a lower bound.
+void need_n(const Tensor& t, int64_t n, const Tensor& ref, const char* name, bool at_least = false) {
+    TORCH_CHECK(t.device() == ref.device(), "fabhip: ", name, " is on ", t.device(), ", expected ", ref.device());
+    TORCH_CHECK(at_least ? t.numel() >= n : t.numel() == n, "fabhip: ", name, " has ", t.numel(), " elements, expected ",
+                at_least ? "at least " : "", n);
+}
+const float* fpn(const Tensor& t, int64_t n, const Tensor& ref, const char* name) { need_n(t, n, ref, name); return fp(t, name); }
+float* fpmn(const Tensor& t, int64_t n, const Tensor& ref, const char* name, bool at_least = false) {
+    need_n(t, n, ref, name, at_least);
+    return fpm(t, name);
+}
+float* fpmn_opt(const optional<Tensor>& t, int64_t n, const Tensor& ref, const char* name, bool at_least = false) {
+    return t.has_value() ? fpmn(*t, n, ref, name, at_least) : nullptr;
+}
+
 Tensor fempty(at::IntArrayRef shape, const Tensor& like) { return at::empty(shape, like.options().dtype(at::kFloat)); }
 Tensor scratch(size_t bytes, const Tensor& like) {
     return at::empty({(int64_t)(bytes + 256)}, like.options().dtype(at::kByte));
@@ -73,19 +89,24 @@ void fill_params(fabhip_flow_params& p, at::TensorList params, int64_t dim, int6
                 " parameter tensors (11 per layer + loc + log_scale), or ", 13 * n_layers + 2,
                 " with one ActNorm {s, t} pair per layer appended, got ", params.size());
     p.dim = (int32_t)dim; p.n_layers = (int32_t)n_layers; p.width = (int32_t)width;
+    const int64_t d = (dim + 1) / 2, DO = dim - d;     // make_normflow_model.py:17 `int(dim / 2 + 0.5)`
+    const int64_t want[11] = {width * d, width, width * width, width, 2 * DO * width, 2 * DO, dim * dim, dim * dim, dim, dim,
+                              dim * dim};
+    static const char* names[11] = {"w1", "b1", "w2", "b2", "w3", "b3", "L", "U", "log_S", "sign_S", "P"};
     for (int64_t k = 0; k < n_layers; ++k) {
         const Tensor* t = &params[11 * k];
+        for (int i = 0; i < 11; ++i) need_n(t[i], want[i], params[0], names[i]);
         p.w1[k] = fp(t[0], "w1"); p.b1[k] = fp(t[1], "b1"); p.w2[k] = fp(t[2], "w2"); p.b2[k] = fp(t[3], "b2");
         p.w3[k] = fp(t[4], "w3"); p.b3[k] = fp(t[5], "b3"); p.lu_L[k] = fp(t[6], "L"); p.lu_U[k] = fp(t[7], "U");
         p.log_S[k] = fp(t[8], "log_S"); p.sign_S[k] = fp(t[9], "sign_S"); p.perm_P[k] = fp(t[10], "P");
     }
-    p.loc = fp(params[11 * n_layers], "loc");
-    p.log_scale = fp(params[11 * n_layers + 1], "log_scale");
+    p.loc = fpn(params[11 * n_layers], dim, params[0], "loc");
+    p.log_scale = fpn(params[11 * n_layers + 1], dim, params[0], "log_scale");
     for (int64_t k = 0; k < FABHIP_MAX_LAYERS; ++k) { p.an_s[k] = nullptr; p.an_t[k] = nullptr; }
     if (act_norm)
         for (int64_t k = 0; k < n_layers; ++k) {
             const Tensor &s = params[11 * n_layers + 2 + 2 * k], &t = params[11 * n_layers + 3 + 2 * k];
-            TORCH_CHECK(s.numel() == dim && t.numel() == dim, "fabhip: ActNorm s / t must have dim entries");
+            need_n(s, dim, params[0], "ActNorm.s"); need_n(t, dim, params[0], "ActNorm.t");
             p.an_s[k] = fp(s, "ActNorm.s"); p.an_t[k] = fp(t, "ActNorm.t");
         }
 }
@@ -129,6 +150,15 @@ std::vector<int64_t> flow_grad_layout(int64_t dim, int64_t n_layers, int64_t wid
 }
 int64_t set_fast_mode(bool on) { return fabhip_set_fast_mode(on ? 1 : 0); }
 int64_t get_fast_mode() { return fabhip_get_fast_mode(); }
+int64_t set_option(int64_t key, int64_t value) {
+    const int prev = fabhip_set_option((int)key, (int)value);
+    TORCH_CHECK(!(prev < 0 && (key < 0 || key >= FABHIP_OPT_COUNT)), "fabhip: unknown option key ", key);
+    return prev;
+}
+int64_t get_option(int64_t key) {
+    TORCH_CHECK(key >= 0 && key < FABHIP_OPT_COUNT, "fabhip: unknown option key ", key);
+    return fabhip_get_option((int)key);
+}
 std::vector<int64_t> flow_tape_layout(int64_t dim, int64_t n_layers, int64_t width, int64_t B) {
     std::vector<int64_t> out(18);
     chk(fabhip_flow_tape_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, B, out.data()), "flow_tape_layout");
@@ -406,17 +436,20 @@ void hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t
     TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0), n_outer = epsilons_row.numel();
     TORCH_CHECK(noise_p.numel() == n_outer * B * dim && noise_e.numel() == n_outer * B, "fabhip: HMC noise shapes");
-    a.point = fabhip_point{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), fpm(grad_log_q, "grad_log_q"),
-                           fpm(grad_log_p, "grad_log_p")};
+    TORCH_CHECK(n_outer >= 1, "fabhip: epsilons row must hold one step size per outer loop");
+    a.point = fabhip_point{fpm(x, "x"), fpmn(log_q, B, x, "log_q"), fpmn(log_p, B, x, "log_p"),
+                           fpmn(grad_log_q, B * dim, x, "grad_log_q"), fpmn(grad_log_p, B * dim, x, "grad_log_p")};
     a.B = B; a.n_valid = nullptr;
     a.cur = coefs(beta, alpha, p_target); a.next = coefs(beta_next, alpha, p_target);
-    a.log_w = fpm_opt(log_w, "log_w");
-    a.noise_p = fp(noise_p, "noise_p"); a.noise_e = fp(noise_e, "noise_e");
-    a.epsilons = fpm(epsilons_row, "epsilons"); a.common_epsilon = fpm(common_epsilon, "common_epsilon");
-    a.mass = fp(mass, "mass");
+    a.log_w = fpmn_opt(log_w, B, x, "log_w");
+    a.noise_p = fpn(noise_p, n_outer * B * dim, x, "noise_p"); a.noise_e = fpn(noise_e, n_outer * B, x, "noise_e");
+    a.epsilons = fpmn(epsilons_row, n_outer, x, "epsilons");
+    a.common_epsilon = fpmn(common_epsilon, 1, x, "common_epsilon", true);
+    a.mass = fpn(mass, dim, x, "mass");
     a.n_outer = (int32_t)n_outer; a.L = (int32_t)L; a.max_grad = (float)max_grad;
     a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
-    a.p_accept = fpm_opt(p_accept, "p_accept"); a.avg_distance = fpm_opt(avg_distance, "avg_distance");
+    a.p_accept = fpmn_opt(p_accept, n_outer, x, "p_accept", true);
+    a.avg_distance = fpmn_opt(avg_distance, 1, x, "avg_distance", true);
     const size_t nb = fabhip_hmc_workspace_bytes(B, (int32_t)dim, (int32_t)n_outer);
     Tensor ws = scratch(nb, x);
     a.workspace = aligned(ws); a.workspace_bytes = nb;
@@ -436,12 +469,13 @@ void metropolis_transition(const Tensor& packed, int64_t dim, int64_t n_layers, 
     const int64_t B = x.size(0), n_updates = noise_scalings_row.numel();
     TORCH_CHECK(noise_x.numel() == n_updates * B * dim && noise_u.numel() == n_updates * B,
                 "fabhip: Metropolis noise shapes");
-    a.point = fabhip_point{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), nullptr, nullptr};
+    TORCH_CHECK(n_updates >= 1, "fabhip: noise_scalings row must hold one scale per update");
+    a.point = fabhip_point{fpm(x, "x"), fpmn(log_q, B, x, "log_q"), fpmn(log_p, B, x, "log_p"), nullptr, nullptr};
     a.B = B; a.n_valid = nullptr;
     a.cur = coefs(beta, alpha, p_target); a.next = coefs(beta_next, alpha, p_target);
-    a.log_w = fpm_opt(log_w, "log_w");
-    a.noise_x = fp(noise_x, "noise_x"); a.noise_u = fp(noise_u, "noise_u");
-    a.noise_scalings = fpm(noise_scalings_row, "noise_scalings");
+    a.log_w = fpmn_opt(log_w, B, x, "log_w");
+    a.noise_x = fpn(noise_x, n_updates * B * dim, x, "noise_x"); a.noise_u = fpn(noise_u, n_updates * B, x, "noise_u");
+    a.noise_scalings = fpmn(noise_scalings_row, n_updates, x, "noise_scalings");
     a.n_updates = (int32_t)n_updates; a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
     const size_t nb = fabhip_metropolis_workspace_bytes(B, (int32_t)dim, (int32_t)n_updates);
     Tensor ws = scratch(nb, x);
@@ -461,14 +495,17 @@ void hmc_generic_begin(const Tensor& start_x, const Tensor& start_gq, const Tens
                        const Tensor& cur_lp, double beta, double alpha, bool p_target, const Tensor& noise_p,
                        const Tensor& mass, double max_grad, Tensor ws) {
     c10::DeviceGuard g(start_x.device());
+    TORCH_CHECK(start_x.dim() == 2, "fabhip: x must be [B, dim]");
     const int64_t B = start_x.size(0), D = start_x.size(1);
-    TORCH_CHECK(noise_p.numel() == B * D && mass.numel() == D, "fabhip: generic HMC shapes");
-    fabhip_point st{const_cast<float*>(fp(start_x, "x")), nullptr, nullptr, const_cast<float*>(fp(start_gq, "grad_log_q")),
-                    const_cast<float*>(fp(start_gp, "grad_log_p"))};
-    fabhip_point cu{nullptr, const_cast<float*>(fp(cur_lq, "log_q")), const_cast<float*>(fp(cur_lp, "log_p")), nullptr,
-                    nullptr};
-    chk(fabhip_hmc_generic_begin(&st, &cu, B, (int32_t)D, coefs(beta, alpha, p_target), fp(noise_p, "noise_p"),
-                                 fp(mass, "mass"), (float)max_grad, fpm(ws, "workspace"), ws_bytes(ws), stream_of(start_x)),
+    const Tensor& r = start_x;
+    fabhip_point st{const_cast<float*>(fp(start_x, "x")), nullptr, nullptr,
+                    const_cast<float*>(fpn(start_gq, B * D, r, "grad_log_q")),
+                    const_cast<float*>(fpn(start_gp, B * D, r, "grad_log_p"))};
+    fabhip_point cu{nullptr, const_cast<float*>(fpn(cur_lq, B, r, "log_q")), const_cast<float*>(fpn(cur_lp, B, r, "log_p")),
+                    nullptr, nullptr};
+    need_n(ws, 0, r, "workspace", true);
+    chk(fabhip_hmc_generic_begin(&st, &cu, B, (int32_t)D, coefs(beta, alpha, p_target), fpn(noise_p, B * D, r, "noise_p"),
+                                 fpn(mass, D, r, "mass"), (float)max_grad, fpm(ws, "workspace"), ws_bytes(ws), stream_of(start_x)),
         "hmc_generic_begin");
 }
 
@@ -476,6 +513,7 @@ Tensor hmc_generic_leap_pre(int64_t B, int64_t dim, const Tensor& eps, const Ten
                             Tensor ws) {
     c10::DeviceGuard g(ws.device());
     Tensor x = fempty({B, dim}, ws);
+    need_n(eps, 1, ws, "epsilon", true); need_n(ceps, 1, ws, "common_epsilon", true); need_n(mass, dim, ws, "mass");
     chk(fabhip_hmc_generic_leap_pre(B, (int32_t)dim, fp(eps, "epsilon"), fp(ceps, "common_epsilon"), fp(mass, "mass"),
                                     x.data_ptr<float>(), fpm(ws, "workspace"), ws_bytes(ws), stream_of(ws)),
         "hmc_generic_leap_pre");
@@ -485,7 +523,10 @@ Tensor hmc_generic_leap_pre(int64_t B, int64_t dim, const Tensor& eps, const Ten
 void hmc_generic_leap_post(const Tensor& gq, const Tensor& gp, double beta, double alpha, bool p_target, double max_grad,
                            const Tensor& eps, const Tensor& ceps, Tensor ws) {
     c10::DeviceGuard g(ws.device());
+    TORCH_CHECK(gq.dim() == 2, "fabhip: grad_log_q must be [B, dim]");
     const int64_t B = gq.size(0), D = gq.size(1);
+    need_n(gq, B * D, ws, "grad_log_q"); need_n(gp, B * D, ws, "grad_log_p");
+    need_n(eps, 1, ws, "epsilon", true); need_n(ceps, 1, ws, "common_epsilon", true);
     chk(fabhip_hmc_generic_leap_post(B, (int32_t)D, fp(gq, "grad_log_q"), fp(gp, "grad_log_p"),
                                      coefs(beta, alpha, p_target), (float)max_grad, fp(eps, "epsilon"),
                                      fp(ceps, "common_epsilon"), fpm(ws, "workspace"), ws_bytes(ws), stream_of(ws)),
@@ -498,15 +539,19 @@ void hmc_generic_accept(const Tensor& prop_lq, const Tensor& prop_lp, const Tens
                         const Tensor& noise_e, const Tensor& mass, Tensor eps, Tensor ceps, double target_p_accept,
                         bool tune, optional<Tensor> p_accept, optional<Tensor> avg_distance, Tensor ws) {
     c10::DeviceGuard g(x.device());
+    TORCH_CHECK(x.dim() == 2, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0), D = x.size(1);
-    fabhip_point pr{nullptr, const_cast<float*>(fp(prop_lq, "log_q")), const_cast<float*>(fp(prop_lp, "log_p")),
-                    const_cast<float*>(fp(prop_gq, "grad_log_q")), const_cast<float*>(fp(prop_gp, "grad_log_p"))};
-    fabhip_point cu{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), fpm(grad_log_q, "grad_log_q"),
-                    fpm(grad_log_p, "grad_log_p")};
+    fabhip_point pr{nullptr, const_cast<float*>(fpn(prop_lq, B, x, "log_q")), const_cast<float*>(fpn(prop_lp, B, x, "log_p")),
+                    const_cast<float*>(fpn(prop_gq, B * D, x, "grad_log_q")),
+                    const_cast<float*>(fpn(prop_gp, B * D, x, "grad_log_p"))};
+    fabhip_point cu{fpm(x, "x"), fpmn(log_q, B, x, "log_q"), fpmn(log_p, B, x, "log_p"),
+                    fpmn(grad_log_q, B * D, x, "grad_log_q"), fpmn(grad_log_p, B * D, x, "grad_log_p")};
+    need_n(ws, 0, x, "workspace", true);
     chk(fabhip_hmc_generic_accept(&pr, &cu, B, (int32_t)D, coefs(beta, alpha, p_target), coefs(beta_next, alpha, p_target),
-                                  fpm_opt(log_w, "log_w"), fp(noise_e, "noise_e"), fp(mass, "mass"), fpm(eps, "epsilon"),
-                                  fpm(ceps, "common_epsilon"), (float)target_p_accept, tune ? 1 : 0,
-                                  fpm_opt(p_accept, "p_accept"), fpm_opt(avg_distance, "avg_distance"),
+                                  fpmn_opt(log_w, B, x, "log_w"), fpn(noise_e, B, x, "noise_e"), fpn(mass, D, x, "mass"),
+                                  fpmn(eps, 1, x, "epsilon", true), fpmn(ceps, 1, x, "common_epsilon", true),
+                                  (float)target_p_accept, tune ? 1 : 0, fpmn_opt(p_accept, 1, x, "p_accept", true),
+                                  fpmn_opt(avg_distance, 1, x, "avg_distance", true),
                                   fpm(ws, "workspace"), ws_bytes(ws), stream_of(x)),
         "hmc_generic_accept");
 }
@@ -525,10 +570,16 @@ void spline_hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, 
     c10::DeviceGuard g(x.device());
     const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
     const fabhip_target tg = make_target(kind, prm, locs, scales, dim);
+    TORCH_CHECK(x.dim() == 2, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0), D = x.size(1);
     TORCH_CHECK(D == dim && n_outer >= 1 && n_leap >= 1, "fabhip: spline_hmc_transition shapes");
-    TORCH_CHECK(noise_p.numel() == n_outer * B * D && noise_e.numel() == n_outer * B && eps_row.numel() == n_outer &&
-                mass.numel() == D, "fabhip: spline_hmc_transition noise / step-size shapes");
+    need_n(log_q, B, x, "log_q"); need_n(log_p, B, x, "log_p");
+    need_n(grad_log_q, B * D, x, "grad_log_q"); need_n(grad_log_p, B * D, x, "grad_log_p");
+    if (log_w.has_value()) need_n(*log_w, B, x, "log_w");
+    need_n(noise_p, n_outer * B * D, x, "noise_p"); need_n(noise_e, n_outer * B, x, "noise_e");
+    need_n(eps_row, n_outer, x, "epsilons"); need_n(ceps, 1, x, "common_epsilon", true); need_n(mass, D, x, "mass");
+    if (p_accept.has_value()) need_n(*p_accept, n_outer, x, "p_accept", true);
+    if (avg_distance.has_value()) need_n(*avg_distance, 1, x, "avg_distance", true);
     if (B == 0) return;
     const fabhip_stream_t st = stream_of(x);
     Tensor ws = generic_workspace(x, B, D);
@@ -567,6 +618,7 @@ void spline_hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, 
 Tensor anneal_log_prob(const Tensor& log_q, const Tensor& log_p, double beta, double alpha, bool p_target) {
     c10::DeviceGuard g(log_q.device());
     Tensor out = at::empty_like(log_q);
+    need_n(log_p, log_q.numel(), log_q, "log_p");
     chk(fabhip_anneal_log_prob(fp(log_q, "log_q"), fp(log_p, "log_p"), log_q.numel(), coefs(beta, alpha, p_target),
                                out.data_ptr<float>(), stream_of(log_q)),
         "anneal_log_prob");
@@ -576,6 +628,7 @@ Tensor anneal_log_prob(const Tensor& log_q, const Tensor& log_p, double beta, do
 void log_w_update(const Tensor& log_q, const Tensor& log_p, double beta, double beta_next, double alpha, bool p_target,
                   Tensor log_w) {
     c10::DeviceGuard g(log_q.device());
+    need_n(log_p, log_q.numel(), log_q, "log_p"); need_n(log_w, log_q.numel(), log_q, "log_w");
     chk(fabhip_log_w_update(fp(log_q, "log_q"), fp(log_p, "log_p"), log_q.numel(), coefs(beta, alpha, p_target),
                             coefs(beta_next, alpha, p_target), fpm(log_w, "log_w"), stream_of(log_q)),
         "log_w_update");
@@ -584,6 +637,8 @@ void log_w_update(const Tensor& log_q, const Tensor& log_p, double beta, double 
 Tensor metropolis_generic_propose(const Tensor& x, const Tensor& noise_x, const Tensor& scale) {
     c10::DeviceGuard g(x.device());
     Tensor xn = at::empty_like(x);
+    TORCH_CHECK(x.dim() == 2, "fabhip: x must be [B, dim]");
+    need_n(noise_x, x.numel(), x, "noise_x"); need_n(scale, 1, x, "noise_scaling", true);
     chk(fabhip_metropolis_generic_propose(fp(x, "x"), fp(noise_x, "noise_x"), fp(scale, "noise_scaling"), x.size(0),
                                           (int32_t)x.size(1), xn.data_ptr<float>(), stream_of(x)),
         "metropolis_generic_propose");
@@ -594,8 +649,11 @@ void metropolis_generic_accept(const Tensor& x_new, const Tensor& new_lq, const 
                                Tensor log_p, const Tensor& prev_log_prob, const Tensor& noise_u, double beta, double alpha,
                                bool p_target, Tensor scale, double target_p_accept, bool tune) {
     c10::DeviceGuard g(x.device());
+    TORCH_CHECK(x.dim() == 2, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0), D = x.size(1);
-    fabhip_point cu{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), nullptr, nullptr};
+    fabhip_point cu{fpm(x, "x"), fpmn(log_q, B, x, "log_q"), fpmn(log_p, B, x, "log_p"), nullptr, nullptr};
+    need_n(x_new, B * D, x, "x_new"); need_n(new_lq, B, x, "new log_q"); need_n(new_lp, B, x, "new log_p");
+    need_n(prev_log_prob, B, x, "prev_log_prob"); need_n(noise_u, B, x, "noise_u"); need_n(scale, 1, x, "noise_scaling", true);
     Tensor ws = generic_workspace(x, B, D);
     chk(fabhip_metropolis_generic_accept(fp(x_new, "x_new"), fp(new_lq, "log_q"), fp(new_lp, "log_p"), &cu,
                                          fp(prev_log_prob, "prev_log_prob"), fp(noise_u, "noise_u"), B, (int32_t)D,
@@ -631,10 +689,15 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     std::vector<double> bt(betas.begin(), betas.end());
     a.betas = bt.data();
     a.alpha = alpha; a.p_target = p_target ? 1 : 0; a.transition = (int32_t)transition;
-    a.eps0 = fp(eps0, "eps0"); a.noise_a = fp(noise_a, "noise_a"); a.noise_b = fp(noise_b, "noise_b");
-    a.step_state = fpm(step_state, "step_state");
-    a.common_epsilon = fpm_opt(common_epsilon, "common_epsilon");
-    a.mass = fp_opt(mass, "mass");
+    TORCH_CHECK(n_inner >= 1, "fabhip: n_inner (HMC outer loops / Metropolis updates per transition) must be >= 1");
+    TORCH_CHECK(hmc || transition == FABHIP_TRANSITION_METROPOLIS, "fabhip: unknown transition kind ", transition);
+    TORCH_CHECK(!hmc || (common_epsilon.has_value() && mass.has_value()),
+                "fabhip: an HMC AIS run needs common_epsilon and the mass vector");
+    a.eps0 = fp(eps0, "eps0");
+    a.noise_a = fpn(noise_a, M * n_inner * B * dim, eps0, "noise_a"); a.noise_b = fpn(noise_b, M * n_inner * B, eps0, "noise_b");
+    a.step_state = fpmn(step_state, M * n_inner, eps0, "step_state");
+    a.common_epsilon = fpmn_opt(common_epsilon, 1, eps0, "common_epsilon", true);
+    a.mass = mass.has_value() ? fpn(*mass, dim, eps0, "mass") : nullptr;
     a.n_inner = (int32_t)n_inner; a.L = (int32_t)L; a.max_grad = (float)max_grad;
     a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
     Tensor x = fempty({B, dim}, eps0), lq = fempty({B}, eps0), lp = fempty({B}, eps0), log_w = fempty({B}, eps0);
@@ -645,10 +708,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     a.point = fabhip_point{x.data_ptr<float>(), lq.data_ptr<float>(), lp.data_ptr<float>(),
                            hmc ? gq.data_ptr<float>() : nullptr, hmc ? gp.data_ptr<float>() : nullptr};
     a.log_w = log_w.data_ptr<float>(); a.n_valid = n_valid.data_ptr<int32_t>(); a.stats = stats.data_ptr<float>();
-    a.p_accept_first = fpm_opt(p_accept_first, "p_accept_first");
-    a.p_accept_last = fpm_opt(p_accept_last, "p_accept_last");
-    a.avg_distance_first = fpm_opt(avg_distance_first, "avg_distance_first");
-    a.avg_distance_last = fpm_opt(avg_distance_last, "avg_distance_last");
+    a.p_accept_first = fpmn_opt(p_accept_first, n_inner, eps0, "p_accept_first", true);
+    a.p_accept_last = fpmn_opt(p_accept_last, n_inner, eps0, "p_accept_last", true);
+    a.avg_distance_first = fpmn_opt(avg_distance_first, 1, eps0, "avg_distance_first", true);
+    a.avg_distance_last = fpmn_opt(avg_distance_last, 1, eps0, "avg_distance_last", true);
     a.base_x = want_base ? base_x.data_ptr<float>() : nullptr;
     a.base_log_w = want_base ? base_lw.data_ptr<float>() : nullptr;
     const size_t nb = fabhip_ais_workspace_bytes(B, (int32_t)dim, (int32_t)n_inner);
@@ -763,6 +826,8 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("flow_tape_layout(int dim, int n_layers, int width, int B) -> int[]", flow_tape_layout);
     m.def("set_fast_mode(bool on) -> int", set_fast_mode);
     m.def("get_fast_mode() -> int", get_fast_mode);
+    m.def("set_option(int key, int value) -> int", set_option);
+    m.def("get_option(int key) -> int", get_option);
     m.def("anneal_coefs(float beta, float alpha, bool p_target) -> float[]", anneal_coefs);
 
     m.def("realnvp_pack(Tensor[] params, int dim, int n_layers, int width, bool with_inverse, Tensor(a!) packed) -> ()");

@@ -29,9 +29,31 @@ def _make_and_save_plots(trainer, i: int, save: bool):
         if save:
             os.makedirs(os.path.join(trainer.save_dir, "plots"), exist_ok=True)
             figure.savefig(os.path.join(trainer.save_dir, "plots", f"{j}_iter_{i}.png"))
-        close = getattr(figure, "close", None)
-        if callable(close):
-            close()
+        else:
+            _pyplot_call("show")                           # train.py:52-53: plt.show() when not saving
+        if not _is_matplotlib_figure(figure) or not _pyplot_call("close", figure):     # train.py:54: plt.close(figure)
+            close = getattr(figure, "close", None)         # (a caller's non-matplotlib figure object)
+            if callable(close):
+                close()
+
+
+def _is_matplotlib_figure(figure) -> bool:
+    try:
+        from matplotlib.figure import Figure
+    except ImportError:
+        return False
+    return isinstance(figure, Figure)
+
+
+def _pyplot_call(name: str, *args) -> bool:
+    """Call matplotlib.pyplot.<name>(*args) if matplotlib is importable (the caller's `plot` made the figures with
+    it); False otherwise."""
+    try:
+        import matplotlib.pyplot as plt
+    except ImportError:
+        return False
+    getattr(plt, name)(*args)
+    return True
 
 
 def _time_is_up(tlimit, start_time, max_it_time) -> Optional[float]:

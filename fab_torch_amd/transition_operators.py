@@ -160,6 +160,8 @@ def _check_point(point: Point, with_grad: bool):
 
 
 class HamiltonianMonteCarlo(TransitionOperator):
+    force_stepwise = False      # tests only: run the spline flow through the step-by-step generic path
+
     def __init__(self, n_ais_intermediate_distributions: int, dim: int, base_log_prob, target_log_prob,
                  alpha: float = None, p_target: bool = False, epsilon: float = 1.0, n_outer: int = 1, L: int = 5,
                  mass_init: Union[float, torch.Tensor] = 1.0, target_p_accept: float = 0.65,
@@ -256,7 +258,7 @@ class HamiltonianMonteCarlo(TransitionOperator):
     def _spline_parts(self):
         """(spline flow, native target) when the base distribution is this package's spline flow and the target is
         native - the host-fused transition op applies; else None (step-by-step generic path)."""
-        if os.environ.get("FABHIP_SPLINE_STEPWISE"):   # debugging: force the step-by-step path
+        if self.force_stepwise:                         # tests: force the step-by-step generic path
             return None
         from .spline_flow import CircularCoupledRQSFlow
         flow = _owner_or_none(self.base_log_prob, CircularCoupledRQSFlow)

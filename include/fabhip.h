@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 204
+#define FABHIP_ABI_VERSION 205
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -81,6 +81,23 @@ typedef struct {
  * Process-wide switch, returns the previous value.  SURVEY section 7's "fp32 parity mode and a fast mode". */
 int fabhip_set_fast_mode(int on);
 int fabhip_get_fast_mode(void);
+
+/* Developer / test switches (A/B variants of one computation, diagnostics).  A plain table of ints inside the library:
+ * initialised ONCE, when the library is loaded, from the environment variables named below, read by the launchers with
+ * one load (nothing on a launch path calls getenv), changed at run time only through fabhip_set_option (returns the
+ * previous value, or a negative FABHIP_E* code for an unknown key).  No reference counterpart (the reference has no
+ * kernel variants); production code never sets them. */
+#define FABHIP_OPT_TILE_SHAPE 0          /* FABHIP_TILE: chains per workgroup of the fused RealNVP transitions: 0 = by batch
+                                            size (default), 4 / 8 = flow_r4.h tiles, 16 = flow_device.h tiles */
+#define FABHIP_OPT_R4_STREAM 1           /* FABHIP_R4_STREAM: 1 = continuous weight stream where its image exists (default),
+                                            0 = per-stage request groups */
+#define FABHIP_OPT_SCAN_VARIANT 2        /* FABHIP_SCAN_VARIANT: fixed-point CDF scan, 3 = LDS-transposed (default), 0-2 = A/B */
+#define FABHIP_OPT_SYSTEMATIC_VARIANT 3  /* FABHIP_SYSTEMATIC_VARIANT: 1 = fused systematic sampler (default), 0 = CDF in HBM */
+#define FABHIP_OPT_SPLINE_STAGED 4       /* FABHIP_SPLINE_STAGED: 1 = per-layer spline kernels instead of the one-launch kernel */
+#define FABHIP_OPT_TIMELINE 5            /* FABHIP_TIMELINE: 1 = workgroup 0 writes s_memtime stage stamps (fabhip_debug_timeline) */
+#define FABHIP_OPT_COUNT 6
+int fabhip_set_option(int key, int value);
+int fabhip_get_option(int key);
 
 /* Number of floats of the MFMA-tiled parameter image for a (dim, n_layers, width) flow. */
 int64_t fabhip_flow_packed_floats(int32_t dim, int32_t n_layers, int32_t width);

@@ -11,6 +11,7 @@ from test_gpu_parity import seeded_flow, hip_flow_from_oracle, DEV
 pytestmark = pytest.mark.gpu
 
 fa = pytest.importorskip("fab_torch_amd")
+from fab_torch_amd import _ops            # noqa: E402
 from oracle import ais as oais            # noqa: E402
 from oracle import targets as otgt        # noqa: E402
 
@@ -106,7 +107,7 @@ def test_four_chain_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B)
         pytest.skip("ManyWell needs an even dimension")
     res = {}
     for mode in ("0", "1"):
-        monkeypatch.setenv("FABHIP_R4", mode)
+        _ops.load().set_option(_ops.OPT_TILE_SHAPE, 4 if mode == "1" else 16)
         hmc = fa.HamiltonianMonteCarlo(4, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
                                        n_outer=2, L=3).to(DEV)
         g = torch.Generator(device=DEV).manual_seed(5)
@@ -115,7 +116,7 @@ def test_four_chain_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B)
         torch.manual_seed(77)
         out = hmc.transition(pt, 2, 0.4)
         res[mode] = (out.x.clone(), out.log_q.clone(), out.log_p.clone(), hmc.epsilons.clone(), hmc.common_epsilon.clone())
-    monkeypatch.delenv("FABHIP_R4")
+    _ops.load().set_option(_ops.OPT_TILE_SHAPE, 0)
     xa, lqa, lpa, ea, ca = res["0"]
     xb, lqb, lpb, eb, cb = res["1"]
     same = (xa - xb).abs().amax(dim=1) <= 1e-4 * (1 + xa.abs().amax(dim=1))
@@ -148,14 +149,14 @@ def test_four_chain_tiles_are_bitwise_reproducible():
 @pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 1024), (6, 3, 40, 70), (16, 3, 8, 257)])
 def test_stream_and_staged_four_chain_kernels_are_bit_identical(monkeypatch, D, K, nodes, B):
     """The 4-chain kernel exists in two request schedules - one continuous weight stream per wave (D <= 32, hidden width
-    >= 128) and per-stage request groups (everything else; FABHIP_R4_STREAM=0 forces it) - with the same arithmetic in the
+    >= 128) and per-stage request groups (everything else; FABHIP_OPT_R4_STREAM = 0 forces it) - with the same arithmetic in the
     same order: identical bits."""
     torch.manual_seed(D + K)
     flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
     target = fa.ManyWellEnergy(D)
     res = []
     for mode in ("1", "0"):
-        monkeypatch.setenv("FABHIP_R4_STREAM", mode)
+        _ops.load().set_option(_ops.OPT_R4_STREAM, int(mode))
         hmc = fa.HamiltonianMonteCarlo(3, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
                                        n_outer=2, L=4).to(DEV)
         g = torch.Generator(device=DEV).manual_seed(5)
@@ -164,6 +165,6 @@ def test_stream_and_staged_four_chain_kernels_are_bit_identical(monkeypatch, D, 
         torch.manual_seed(7)
         out = hmc.transition(pt, 1, 0.3)
         res.append((out.x.clone(), out.log_q.clone(), out.grad_log_q.clone(), hmc.epsilons.clone()))
-    monkeypatch.delenv("FABHIP_R4_STREAM")
+    _ops.load().set_option(_ops.OPT_R4_STREAM, 1)
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)

@@ -12,6 +12,7 @@ import aten_reference
 pytestmark = pytest.mark.gpu
 
 fa = pytest.importorskip("fab_torch_amd")
+from fab_torch_amd import _ops            # noqa: E402
 from oracle import ais as oais            # noqa: E402
 from oracle import flow as oflow          # noqa: E402
 from oracle import numerical as onum      # noqa: E402
@@ -616,15 +617,14 @@ def test_fused_systematic_sampler_edge_cases_bit_exact_vs_oracle(case):
 
 
 def test_fused_systematic_equals_the_scan_and_search_path_at_2_pow_26(monkeypatch):
-    """N = 2^26 (the HBM-roofline size): the fused sampler and the CDF-in-HBM reference path (FABHIP_SYSTEMATIC_VARIANT=0)
+    """N = 2^26 (the HBM-roofline size): the fused sampler and the CDF-in-HBM reference path (FABHIP_OPT_SYSTEMATIC_VARIANT = 0)
     must give identical indices (both exact integer arithmetic); offspring counts sum to N."""
     N = 1 << 26
     g = torch.Generator(device=DEV).manual_seed(1)
     lw = torch.randn(N, device=DEV, generator=g) * 3
     a = fa.systematic_indices(lw, u0=0.123)
-    monkeypatch.setenv("FABHIP_SYSTEMATIC_VARIANT", "0")
-    b = fa.systematic_indices(lw, u0=0.123)
-    monkeypatch.delenv("FABHIP_SYSTEMATIC_VARIANT")
+    with _ops.option(_ops.OPT_SYSTEMATIC_VARIANT, 0):
+        b = fa.systematic_indices(lw, u0=0.123)
     assert torch.equal(a, b)
     assert bool((a[1:] >= a[:-1]).all()) and int(a.max()) < N
     del b
@@ -656,7 +656,7 @@ def test_multinomial_16ary_search_edge_sizes_bit_exact_vs_oracle(N):
 
 
 def test_multinomial_16ary_search_equals_plain_bisection_at_2_pow_26(monkeypatch):
-    """N = 2^26: the node search and the plain two-level bisection (register scan variant, FABHIP_SCAN_VARIANT=2, which
+    """N = 2^26: the node search and the plain two-level bisection (register scan variant, FABHIP_OPT_SCAN_VARIANT = 2, which
     writes no sub-sampled tables) return identical indices for a heavy-tailed and a flat weight vector."""
     N = 1 << 26
     g = torch.Generator(device=DEV).manual_seed(4)
@@ -664,8 +664,7 @@ def test_multinomial_16ary_search_equals_plain_bisection_at_2_pow_26(monkeypatch
     for sigma in (3.0, 0.0):
         lw = torch.randn(N, device=DEV, generator=g) * sigma
         a = fa.multinomial_indices(lw, u=u)
-        monkeypatch.setenv("FABHIP_SCAN_VARIANT", "2")
-        b = fa.multinomial_indices(lw, u=u)
-        monkeypatch.delenv("FABHIP_SCAN_VARIANT")
+        with _ops.option(_ops.OPT_SCAN_VARIANT, 2):
+            b = fa.multinomial_indices(lw, u=u)
         assert torch.equal(a, b)
         del a, b

@@ -421,7 +421,7 @@ def test_host_fused_spline_transition_equals_the_step_by_step_generic_path(monke
     res = {}
     for mode in ("fused", "stepwise"):
         if mode == "stepwise":
-            monkeypatch.setenv("FABHIP_SPLINE_STEPWISE", "1")
+            monkeypatch.setattr(fa.HamiltonianMonteCarlo, "force_stepwise", True)
         hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.15, L=LF,
                                        n_outer=n_outer).to(DEV)
         g = torch.Generator(device=DEV).manual_seed(3)

@@ -272,3 +272,103 @@ def test_experimental_losses_are_refused_like_the_reference_but_callable():
         assert loss.dim() == 0 and torch.isfinite(loss)
         loss.backward()
         assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in flow.parameters()), fn.__name__
+
+
+@pytest.mark.parametrize("B", [100, 33, 1000])
+def test_four_chain_tiles_never_read_uninitialised_scratch(B):
+    """with 4 chains per workgroup, k_hmc_adapt sums all 16 rows of every 16-row block, so every row up
+    to ceil16(B) has to be written by SOME workgroup.  The C ABI's caller-owned workspace is pre-filled with NaN bytes:
+    acceptance logging and the adapted step sizes must be finite and identical to a run on a zeroed workspace."""
+    lib = _lib.load()
+    D, K, nodes, M, L = 6, 3, 5, 3, 3
+    flow = _flow(D, K, nodes, 5)
+    target = fa.ManyWellEnergy(D)
+    f, packed = _cabi_flow(flow)
+    kind, prm, _, _ = target.native_target()
+    tgt = _lib.Target(kind, D, prm[0], prm[1], prm[2], prm[3], 0, None, None)
+    g = torch.Generator(device=DEV).manual_seed(B)
+    x0, _ = flow.native_sample(torch.randn(B, D, device=DEV, generator=g))
+    noise_p = torch.randn(1, B, D, device=DEV, generator=g)
+    noise_e = torch.empty(1, B, device=DEV).exponential_(generator=g)
+    mass = torch.ones(D, device=DEV)
+    res = []
+    with _ops.option(_ops.OPT_TILE_SHAPE, 4):
+        for fill in (0xFF, 0x00):
+            pt = fa.create_point(x0.clone(), flow, target, with_grad=True)
+            lw = torch.zeros(B, device=DEV)
+            eps, ceps = torch.full((1,), 0.1, device=DEV), torch.full((1,), 0.01, device=DEV)
+            pacc, dist = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+            nbytes = lib.fabhip_hmc_workspace_bytes(B, D, 1)
+            ws = torch.full((nbytes + 256,), fill, dtype=torch.uint8, device=DEV)
+            a = _lib.HmcArgs()
+            a.flow, a.target = f, tgt
+            a.point = _lib.Point(pt.x.data_ptr(), pt.log_q.data_ptr(), pt.log_p.data_ptr(), pt.grad_log_q.data_ptr(),
+                                 pt.grad_log_p.data_ptr())
+            a.B, a.n_valid = B, None
+            lib.fabhip_anneal_coefs(0.3, 2.0, 0, C.byref(a.cur)); lib.fabhip_anneal_coefs(0.6, 2.0, 0, C.byref(a.next))
+            a.log_w, a.noise_p, a.noise_e = lw.data_ptr(), noise_p.data_ptr(), noise_e.data_ptr()
+            a.epsilons, a.common_epsilon, a.mass = eps.data_ptr(), ceps.data_ptr(), mass.data_ptr()
+            a.n_outer, a.L, a.max_grad, a.target_p_accept, a.tune = 1, L, 1e3, 0.65, 1
+            a.p_accept, a.avg_distance = pacc.data_ptr(), dist.data_ptr()
+            a.workspace, a.workspace_bytes = (ws.data_ptr() + 255) // 256 * 256, nbytes
+            _lib.check(lib.fabhip_hmc_transition(C.byref(a), _sync_stream()), "hmc_transition")
+            torch.cuda.synchronize()
+            res.append((pacc.clone(), dist.clone(), eps.clone(), ceps.clone(), lw.clone()))
+    for t in res[0]:
+        assert torch.isfinite(t).all()
+    for got, ref in zip(res[0], res[1]):
+        assert torch.equal(got, ref)
+    assert 0.0 < float(res[0][0]) <= 1.0
+
+
+def test_ops_reject_tensors_of_the_wrong_size_or_device():
+    """every tensor whose pointer reaches a kernel is checked (element count, device) in the op layer -
+    a wrong length is an error, never an out-of-bounds access; an HMC AIS run without common_epsilon / mass is refused."""
+    ops = _ops.load()
+    D, K, nodes, B, M = 6, 2, 5, 32, 2
+    flow = _flow(D, K, nodes, 1)
+    target = fa.ManyWellEnergy(D)
+    fl, tg = flow.native(), target.native_target()
+    x = torch.randn(B, D, device=DEV)
+    lq, lp, gq, gp = ops.create_point(*fl, *tg, x, True)
+    noise_p, noise_e = torch.randn(1, B, D, device=DEV), torch.rand(1, B, device=DEV)
+    eps, ceps, mass = torch.full((1,), 0.1, device=DEV), torch.full((1,), 0.01, device=DEV), torch.ones(D, device=DEV)
+
+    def hmc(**kw):
+        a = dict(x=x.clone(), lq=lq.clone(), lp=lp.clone(), gq=gq.clone(), gp=gp.clone(), lw=torch.zeros(B, device=DEV),
+                 noise_p=noise_p, noise_e=noise_e, eps=eps.clone(), ceps=ceps.clone(), mass=mass)
+        a.update(kw)
+        ops.hmc_transition(*fl, *tg, a["x"], a["lq"], a["lp"], a["gq"], a["gp"], a["lw"], 0.3, 0.6, 2.0, False,
+                           a["noise_p"], a["noise_e"], a["eps"], a["ceps"], a["mass"], 3, 1e3, 0.65, True, None, None)
+
+    hmc()                                                   # the well-formed call passes
+    for bad in (dict(lw=torch.zeros(B - 1, device=DEV)), dict(lq=lq[:-1].clone()), dict(gq=gq[:, :-1].contiguous()),
+                dict(mass=torch.ones(D + 1, device=DEV)), dict(ceps=torch.zeros(0, device=DEV)),
+                dict(noise_e=noise_e[:, :-1].contiguous()), dict(mass=torch.ones(D))):
+        with pytest.raises((RuntimeError, NotImplementedError), match="fabhip|CPU"):
+            hmc(**bad)
+    betas = [0.0, 0.3, 0.6, 1.0]
+    eps0 = torch.randn(B, D, device=DEV)
+    na, nb = torch.randn(M, 1, B, D, device=DEV), torch.rand(M, 1, B, device=DEV)
+    step = torch.full((M, 1), 0.1, device=DEV)
+    with pytest.raises(RuntimeError, match="common_epsilon and the mass"):
+        ops.ais_run(*fl, *tg, betas, 2.0, False, _ops.TRANSITION_HMC, eps0, na, nb, step, None, None, 1, 3, 1e3, 0.65, True,
+                    None, None, None, None, False)
+    with pytest.raises(RuntimeError, match="mass"):
+        ops.ais_run(*fl, *tg, betas, 2.0, False, _ops.TRANSITION_HMC, eps0, na, nb, step, ceps, torch.ones(D - 1, device=DEV),
+                    1, 3, 1e3, 0.65, True, None, None, None, None, False)
+    with pytest.raises(RuntimeError, match="w2"):           # a weight tensor of the wrong shape never reaches the pack kernel
+        prm = [p.detach() for p in flow._param_list()]
+        prm[2] = prm[2][:, :-1].contiguous()
+        ops.realnvp_pack(prm, D, K, flow.width, True, torch.empty_like(fl[0]))
+
+
+def test_option_table_is_read_without_the_environment():
+    ops, lib = _ops.load(), _lib.load()
+    assert ops.get_option(_ops.OPT_TILE_SHAPE) == 0 and ops.get_option(_ops.OPT_SCAN_VARIANT) == 3
+    with _ops.option(_ops.OPT_TILE_SHAPE, 16):
+        assert lib.fabhip_get_option(_ops.OPT_TILE_SHAPE) == 16
+    assert ops.get_option(_ops.OPT_TILE_SHAPE) == 0
+    assert lib.fabhip_set_option(99, 1) < 0
+    with pytest.raises(RuntimeError, match="unknown option"):
+        ops.set_option(99, 1)

@@ -167,15 +167,9 @@ def same_tile_shape_as(B):
     """Chains are bit-independent of the batch they run in WITHIN a tile shape; the HMC kernel picks 4-chain tiles for
     B <= 1152 and 16-chain tiles above (different summation order inside the GEMMs), so the small comparison runs are
     pinned to the shape the B-chain run used."""
-    old = os.environ.get("FABHIP_R4")
-    os.environ["FABHIP_R4"] = "1" if B <= 1152 else "0"
-    try:
+    from fab_torch_amd import _ops
+    with _ops.option(_ops.OPT_TILE_SHAPE, 4 if B <= 1152 else 16):
         yield
-    finally:
-        if old is None:
-            os.environ.pop("FABHIP_R4", None)
-        else:
-            os.environ["FABHIP_R4"] = old
 
 
 def check_full_size_properties(w: Workload):

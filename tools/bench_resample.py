@@ -31,9 +31,9 @@ def main():
     t = timeit(lambda: ops.resample_systematic(lw, 0.3, N))
     out["systematic_fused_e2e"] = {"s": t, "alg_bytes": 12 * N, "TBps": 12 * N / t / 1e12, "traffic_bytes": 20 * N,
                                    "traffic_TBps": 20 * N / t / 1e12}
-    os.environ["FABHIP_SYSTEMATIC_VARIANT"] = "0"
+    _opt = _ops.option(_ops.OPT_SYSTEMATIC_VARIANT, 0)
     t = timeit(lambda: ops.resample_systematic(lw, 0.3, N))
-    del os.environ["FABHIP_SYSTEMATIC_VARIANT"]
+    _opt.__exit__()
     out["systematic_cdf_in_hbm_e2e"] = {"s": t, "alg_bytes": 12 * N, "TBps": 12 * N / t / 1e12}
     t = timeit(lambda: ops.ess_logz(lw, None, float(N)))
     out["ess_logz"] = {"s": t, "alg_bytes": 4 * N, "TBps": 4 * N / t / 1e12}
