@@ -160,26 +160,132 @@ def trained_flow_ess(dev, fast=False):
     return out
 
 
+WORKLOADS = {
+    # name: (chains per GPU, coupling layers, intermediate distributions)
+    "headline": (1024, 10, 8),      # BASELINE.json metric / north_star: ManyWell-32, 1024 chains, M = 8
+    "cfg4": (2048, 12, 12),         # BASELINE cfg 4's per-GPU shape: 16384 chains over 8 GPUs, 12 layers, M = 12
+}
+
+
+def _relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` started directly (no torchrun environment): start N ranks of this same script, one per
+    GPU, under torch.distributed.run on 127.0.0.1 and hand its exit code back.  (The driver's own torchrun command line
+    arrives here with WORLD_SIZE set and skips this.)"""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+class _StubSampler:
+    """Launcher self-test (`--stub-step`, tests/test_bench_launcher.py): a CPU stand-in for the rank-local AIS call, so
+    that the re-exec under torch.distributed.run, the rendezvous, the barrier / max-over-ranks timing, the particle
+    all-gather and the JSON line can run on a box without GPUs.  Never a measurement: the line says so in `data`."""
+
+    def __init__(self, dev):
+        self.dev = dev
+
+    def sample_and_log_weights(self, total, compact=False):
+        from fab_torch_amd import parallel
+        b = total // parallel._world()
+        g = torch.Generator().manual_seed(parallel._rank())
+        x = torch.randn(b, D, generator=g).to(self.dev)
+        lw = torch.randn(b, generator=g).to(self.dev)
+        return parallel.gather_particles(x, lw, lw.clone(), b, compact=compact)
+
+
 def main():
+    global B_PER_GPU, K_LAYERS, M, F_FWD
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="headline")
+    ap.add_argument("--chains-per-gpu", type=int, default=None)
+    ap.add_argument("--layers", type=int, default=None)
+    ap.add_argument("--M", type=int, default=None)
+    ap.add_argument("--stub-step", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _relaunch_under_torchrun(args)
+
+    B_PER_GPU, K_LAYERS, M = WORKLOADS[args.workload]
+    B_PER_GPU = args.chains_per_gpu or B_PER_GPU
+    K_LAYERS = args.layers or K_LAYERS
+    M = args.M or M
+    F_FWD = K_LAYERS * 2 * (16 * 320 + 320 * 320 + 2 * 320 * 16) + 2 * K_LAYERS * D * D
+    custom = (B_PER_GPU, K_LAYERS, M) != WORKLOADS[args.workload]
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     distributed = world > 1
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the fab_torch_amd hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # FABHIP_BENCH_BACKEND=gloo: ranks may share a GPU (2-process check on a 1-GPU box; payloads staged through the host)
+    backend = os.environ.get("FABHIP_BENCH_BACKEND", "nccl")
+    if args.stub_step:
+        backend, dev = "gloo", torch.device("cpu")
+    else:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the fab_torch_amd hot path has no CPU fallback")
+        n_dev = torch.cuda.device_count()
+        if distributed and backend == "nccl" and world > n_dev:
+            raise SystemExit(f"bench.py --gpus {world}: this node has {n_dev} GPU(s) (RCCL needs one GPU per rank)")
+        dev = torch.device("cuda", local_rank % n_dev)
+        torch.cuda.set_device(dev)
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize()
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        sync()
+
+    def max_over_ranks(t):
+        if not distributed:
+            return t
+        tt = torch.tensor([t], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    if args.stub_step:
+        sh = _StubSampler(dev)
+        step = lambda: sh.sample_and_log_weights(world * B_PER_GPU, compact=False)      # noqa: E731
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        if rank == 0:
+            print(json.dumps({"metric": "AIS samples/sec (+ESS), ManyWell-32, 8 intermediate dists",
+                              "value": world * B_PER_GPU * args.steps / elapsed, "unit": "AIS samples/s", "n_gpus": world,
+                              "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                              "data": "stub (launcher self-test on CPU ranks, not a measurement)",
+                              "config": {"workload": "launcher self-test", "chains_per_gpu": B_PER_GPU,
+                                         "global_chains": world * B_PER_GPU},
+                              "ranks": world, "backend": backend, "gathered_rows": int(out[0].shape[0])}))
+        if distributed:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     import fab_torch_amd as fa
     from fab_torch_amd import parallel
@@ -192,22 +298,20 @@ def main():
                                    epsilon=EPS_INIT, n_outer=1, L=L).to(dev)
     ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target=False, alpha=ALPHA,
                                        n_intermediate_distributions=M)
+    # N > 1: chains sharded over the ranks with the SINGLE-DEVICE step-size rule (one acceptance-slab all-gather per
+    # transition while tuning is on) + one all-gather of the particles; fixed-size result, no host synchronisation
+    sharded = parallel.ShardedAnnealedImportanceSampler(ais) if distributed else None
     torch.manual_seed(1234 + rank)          # per-rank noise streams
 
     def step():
-        pt, log_w = ais.sample_and_log_weights(B_PER_GPU)
         if distributed:
-            return parallel.gather_particles(pt.x, log_w, pt.log_q, B_PER_GPU, compact=False)   # (dropped chains: log_w = -inf rows)
+            return sharded.sample_and_log_weights(world * B_PER_GPU, compact=False)   # (dropped chains: log_w = -inf rows)
+        pt, log_w = ais.sample_and_log_weights(B_PER_GPU)
         return pt.x, log_w, pt.log_q
 
-    def barrier():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(30):                         # untimed, same count on every rank (step() holds a collective): a fresh
+    for _ in range(30):                         # untimed, same count on every rank (step() holds collectives): a fresh
         step()                                  # box needs ~0.2 s of work to reach steady clocks (measured 105.7k vs
-    torch.cuda.synchronize()                    # 113.4k samples/s for a cold first process)
+    sync()                                      # 113.4k samples/s for a cold first process)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -215,13 +319,12 @@ def main():
     for _ in range(args.steps):
         out = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
+    info = ais.get_logging_info()                   # (N > 1: this rank's chains; `ess_gathered` below is the whole set)
     if distributed:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    info = ais.get_logging_info()
+        info["log_Z"] = float(sharded.logging_info["log_Z"])
     ess_all = float(fa.effective_sample_size(out[1]).item())
+    slab_gathers = sharded.n_slab_gathers if distributed else 0
     # second row of SURVEY.md section 8d: the same K steps with step-size tuning frozen (evaluation mode)
     hmc.set_eval_mode(True)
     barrier()
@@ -229,12 +332,13 @@ def main():
     for _ in range(args.steps):
         step()
     barrier()
-    elapsed_eval = time.perf_counter() - t0
+    elapsed_eval = max_over_ranks(time.perf_counter() - t0)
     hmc.set_eval_mode(False)
+    # the particle all-gather alone (the one data-path collective), HIP events on the collective's stream
+    gather_us = None
     if distributed:
-        tt = torch.tensor([elapsed_eval], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_eval = float(tt.item())
+        px, plw, plq = out[0][:B_PER_GPU].contiguous(), out[1][:B_PER_GPU].contiguous(), out[2][:B_PER_GPU].contiguous()
+        gather_us = _event_time(lambda: parallel.gather_particles(px, plw, plq, B_PER_GPU, compact=False)) * 1e6
     # third row: FAST MODE (bf16 W x W GEMMs in the transition kernels; NOT the parity path, never `value`) on the same
     # workload, step-size tuning on ("an fp32 parity mode and a fast mode, report both")
     saved = {k: v.clone() for k, v in hmc.state_dict().items()}
@@ -246,13 +350,9 @@ def main():
         for _ in range(args.steps):
             step()
         barrier()
-        elapsed_fast = time.perf_counter() - t0
+        elapsed_fast = max_over_ranks(time.perf_counter() - t0)
         info_fast = ais.get_logging_info()
     hmc.load_state_dict(saved)
-    if distributed:
-        tt = torch.tensor([elapsed_fast], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed_fast = float(tt.item())
 
     # ---- roofline of the dominant kernel (k_hmc_step): live HIP-event timing on the launch stream -----
     roof = None
@@ -277,7 +377,9 @@ def main():
         t_kernel = time_transition(B_PER_GPU)
         flop = B_PER_GPU * L * 2 * F_FWD                  # flow fwd + d/dx per leapfrog (target flops ignored)
         ach = flop / t_kernel / 1e12
-        r4 = B_PER_GPU <= 1152 and os.environ.get("FABHIP_R4", "") != "0"     # 4-chain tiles (flow_r4.h) below 1153 chains
+        from fab_torch_amd import _ops
+        shape = int(_ops.load().get_option(_ops.OPT_TILE_SHAPE))
+        r4 = shape == 4 or (shape == 0 and B_PER_GPU <= 1152)               # 4-chain tiles (flow_r4.h) below 1153 chains
         n_wg = (B_PER_GPU + 3) // 4 if r4 else (B_PER_GPU + 15) // 16
         kname = "k_hmc_step_r4<5> (4 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r4 else \
             "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)"
@@ -296,22 +398,15 @@ def main():
             roof["weight_stream"] = {"bytes_per_workgroup_per_launch": stream, "GBps_per_cu": stream / t_kernel / 1e9,
                                      "note": "tools/ubench/stream.hip: 48 B/clk per CU for a pure stream of an image this size "
                                              "(~100 GB/s at the ~2.1 GHz the kernel runs at); DESIGN.md section 4"}
-        if r4:      # no FETCH_SIZE figure for this kernel (the pass does not finish under rocprofv3 on this pool): traffic = null
-            pmc = os.path.join(ROOT, "profiles", "r2", "hmc_step_r4_pmc_summary.json")
-            if os.path.exists(pmc):
-                with open(pmc) as f:
-                    der = json.load(f).get("_derived", {})
-                roof["traffic_note"] = ("FETCH_SIZE unavailable; L2 misses x 128 B = %.0f MB per launch, L2 hit rate %.3f "
-                                        "(profiles/r2/hmc_step_r4_pmc_summary.json)" %
-                                        (der.get("tcc_miss_bytes_per_launch", 0) / 1e6, der.get("l2_hit_rate", 0)))
-        else:
-            for rnd in ("r2", "r1"):
-                pmc = os.path.join(ROOT, "profiles", rnd, "hmc_step_pmc_summary.json")
-                if os.path.exists(pmc):
-                    with open(pmc) as f:
-                        roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
-                    roof["traffic_source"] = f"profiles/{rnd}/hmc_step_pmc_summary.json (rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE)"
-                    break
+        # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes restricted to this kernel
+        # (tools/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed summary
+        for path in ((os.path.join("profiles", "r3", "hmc_step_r4_traffic_pmc_summary.json"),) if r4 else
+                     tuple(os.path.join("profiles", rnd, "hmc_step_pmc_summary.json") for rnd in ("r3", "r2", "r1"))):
+            if os.path.exists(os.path.join(ROOT, path)) and args.workload == "headline" and not custom:
+                with open(os.path.join(ROOT, path)) as f:
+                    roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
+                roof["traffic_source"] = path + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
+                break
         # 16-chain tiles (k_hmc_step<5>) with one workgroup per CU (4096 chains):
         t_full = time_transition(4096)
         ach_full = 4096 * L * 2 * F_FWD / t_full / 1e12
@@ -329,14 +424,19 @@ def main():
     if rank == 0:
         total = world * B_PER_GPU * args.steps
         line = {
-            "metric": "AIS samples/sec (+ESS), ManyWell-32, 8 intermediate dists",
+            "metric": "AIS samples/sec (+ESS), ManyWell-32, %d intermediate dists" % M,
             "value": total / elapsed, "unit": "AIS samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "ManyWell-32 AIS: RealNVP 10x(16-320-320-32)+InvAffine, HMC L=5 n_outer=1, "
-                                   "M=8 linear beta, alpha=2 (target p^2/q), step-size tuning on",
+            "config": {"workload": "%s%s: ManyWell-32 AIS, RealNVP %dx(16-320-320-32)+InvAffine, HMC L=5 n_outer=1, "
+                                   "M=%d linear beta, alpha=2 (target p^2/q), step-size tuning on" %
+                                   (args.workload, " (modified)" if custom else "", K_LAYERS, M),
                        "chains_per_gpu": B_PER_GPU, "global_chains": world * B_PER_GPU,
-                       "parallelism": f"chains sharded x{world}, one all-gather" if world > 1 else "single GPU"},
+                       "parallelism": (f"chains sharded x{world}: single-device step-size rule ({slab_gathers} acceptance-slab "
+                                       "all-gathers per step) + one particle all-gather" if world > 1 else "single GPU")},
+            "ranks": world, "backend": ("rccl" if backend == "nccl" else backend) if distributed else None,
+            "gathered_rows": int(out[0].shape[0]), "particle_all_gather_us": gather_us,
+            "slab_all_gathers_per_step": slab_gathers,
             "value_eval_mode": total / elapsed_eval,
             "ess_ais": info["ess_ais"], "ess_gathered": ess_all, "log_Z": info["log_Z"],
             "p_accept_first": info.get("dist0_p_accept_0"),

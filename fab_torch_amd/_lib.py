@@ -50,7 +50,8 @@ class HmcArgs(C.Structure):
                 ("noise_e", C.c_void_p), ("epsilons", C.c_void_p), ("common_epsilon", C.c_void_p),
                 ("mass", C.c_void_p), ("n_outer", C.c_int32), ("L", C.c_int32), ("max_grad", C.c_float),
                 ("target_p_accept", C.c_float), ("tune", C.c_int32), ("p_accept", C.c_void_p),
-                ("avg_distance", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("avg_distance", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("partials", C.c_void_p)]
 
 
 class MetropolisArgs(C.Structure):
@@ -96,7 +97,8 @@ SYMBOLS = [
     "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept", "fabhip_fixed_cdf",
     "fabhip_spline_packed_floats", "fabhip_spline_pack", "fabhip_spline_workspace_bytes", "fabhip_spline_log_prob",
     "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
-    "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_set_option", "fabhip_get_option", "fabhip_debug_spline_timeline",
+    "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_set_option", "fabhip_get_option", "fabhip_ais_phase", "fabhip_hmc_partials_floats",
+    "fabhip_hmc_adapt_gathered", "fabhip_debug_spline_timeline",
 ]
 ABI_VERSION = 205          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
@@ -125,6 +127,12 @@ def _declare(lib):
     lib.fabhip_ais_workspace_bytes.restype = sz
     lib.fabhip_ais_workspace_bytes.argtypes = [i64, i32, i32]
     lib.fabhip_ais_run.argtypes = [C.POINTER(AisArgs), vp]
+    lib.fabhip_ais_phase.argtypes = [C.POINTER(AisArgs), i32, i32, i32, vp, vp]
+    lib.fabhip_hmc_partials_floats.restype = i64
+    lib.fabhip_hmc_partials_floats.argtypes = [i64]
+    lib.fabhip_hmc_adapt_gathered.argtypes = [vp, i32, i64, vp, vp, C.c_float, i32, vp, vp, vp]
+    lib.fabhip_set_option.argtypes = [C.c_int, C.c_int]
+    lib.fabhip_get_option.argtypes = [C.c_int]
     lib.fabhip_ess_workspace_bytes.restype = sz
     lib.fabhip_ess_workspace_bytes.argtypes = [i64]
     lib.fabhip_ess_logz.argtypes = [vp, i64, vp, dbl, vp, vp, sz, vp]

@@ -458,10 +458,15 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
 // step-size adaptation from the block partials (hmc.py:122-123,162-170), fixed summation order
 // (4-chain tiles hand over per-chain values: the 64 threads first add each block's 16 rows in row order, which is
 // what a 16-chain workgroup writes, so both tile shapes give the step-size rule bit-identical sums)
+__device__ __forceinline__ void hmc_adapt_rule(float s, float d, long nv, float* eps_ptr, float* ceps_ptr,
+                                               float target_p_accept, int tune, float* p_accept_out, float* dist_out);
+
+// `slab` != nullptr (chains sharded over ranks): publish [acc[nblk] | dist[nblk] | n] for the all-gather instead of
+// adapting (k_hmc_adapt_gathered does that on every rank's slab, in rank order)
 __global__ void k_hmc_adapt(float* __restrict__ part_acc, float* __restrict__ part_dist, int nblk,
                             const int* n_valid, long B, float* eps_ptr, float* ceps_ptr, float target_p_accept,
                             int tune, float* p_accept_out, float* dist_out, const float* __restrict__ row_acc,
-                            const float* __restrict__ row_dist) {
+                            const float* __restrict__ row_dist, float* __restrict__ slab) {
     if (row_acc) {
         for (int b = threadIdx.x; b < nblk; b += blockDim.x) {
             float s = 0.f, d = 0.f;
@@ -470,11 +475,38 @@ __global__ void k_hmc_adapt(float* __restrict__ part_acc, float* __restrict__ pa
         }
         __syncthreads();
     }
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const long nv = n_valid ? (long)*n_valid : B;
+    if (slab) {
+        for (int b = threadIdx.x; b < nblk; b += blockDim.x) { slab[b] = part_acc[b]; slab[nblk + b] = part_dist[b]; }
+        if (threadIdx.x == 0) slab[2 * nblk] = (float)(nv > 0 ? nv : 0);      // (exact: chain counts are far below 2^24)
+        return;
+    }
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (nv <= 0) return;
     float s = 0.f, d = 0.f;
     for (int i = 0; i < nblk; ++i) { s += part_acc[i]; d += part_dist[i]; }
+    hmc_adapt_rule(s, d, nv, eps_ptr, ceps_ptr, target_p_accept, tune, p_accept_out, dist_out);
+}
+
+// the slabs of all ranks, in rank order: the same additions, in the same order, as one device holding every chain
+__global__ void k_hmc_adapt_gathered(const float* __restrict__ slabs, int n_ranks, int nblk, float* eps_ptr,
+                                     float* ceps_ptr, float target_p_accept, int tune, float* p_accept_out,
+                                     float* dist_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int stride = 2 * nblk + 1;
+    float s = 0.f, d = 0.f;
+    long nv = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        const float* sl = slabs + (long)r * stride;
+        for (int i = 0; i < nblk; ++i) { s += sl[i]; d += sl[nblk + i]; }
+        nv += (long)sl[2 * nblk];
+    }
+    if (nv <= 0) return;
+    hmc_adapt_rule(s, d, nv, eps_ptr, ceps_ptr, target_p_accept, tune, p_accept_out, dist_out);
+}
+
+__device__ __forceinline__ void hmc_adapt_rule(float s, float d, long nv, float* eps_ptr, float* ceps_ptr,
+                                               float target_p_accept, int tune, float* p_accept_out, float* dist_out) {
     const float log_mean = logf(s) - logf((float)nv);
     if (p_accept_out) *p_accept_out = expf(log_mean);
     if (dist_out) *dist_out = d / (float)nv;
@@ -789,6 +821,7 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
     const int D = f.D;
     const int nblk = nblk_of(a->B);
     if (a->workspace_bytes < fabhip_hmc_workspace_bytes(a->B, D, a->n_outer)) return FABHIP_ENOSPC;
+    if (a->partials && a->n_outer != 1) return FABHIP_ENOTSUP;      // (the next outer loop needs the adapted common_epsilon)
     char* ws = (char*)a->workspace;
     float* part_acc = (float*)ws; ws += align256((size_t)nblk * 4);
     float* part_dist = (float*)ws; ws += align256((size_t)nblk * 4);
@@ -819,7 +852,7 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
         hipLaunchKernelGGL(k_hmc_adapt, dim3(1), dim3(64), 0, st, part_acc, part_dist, nblk, a->n_valid, (long)a->B,
                            a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
                            a->p_accept ? a->p_accept + n : nullptr, a->avg_distance,
-                           r4 ? row_acc : (const float*)nullptr, r4 ? row_dist : (const float*)nullptr);
+                           r4 ? row_acc : (const float*)nullptr, r4 ? row_dist : (const float*)nullptr, a->partials);
         FAB_TRY(check_launch());
     }
     return FABHIP_OK;
@@ -886,6 +919,17 @@ size_t fabhip_hmc_workspace_bytes(int64_t B, int32_t dim, int32_t n_outer) {
     return s + 256;
 }
 
+int64_t fabhip_hmc_partials_floats(int64_t B) { return B < 0 ? -1 : 2 * (int64_t)nblk_of(B) + 1; }
+
+int fabhip_hmc_adapt_gathered(const float* gathered, int32_t n_ranks, int64_t B_rank, float* epsilon, float* common_epsilon,
+                              float target_p_accept, int32_t tune, float* p_accept, float* avg_distance,
+                              fabhip_stream_t stream) {
+    if (!gathered || n_ranks < 1 || B_rank < 1 || !epsilon || !common_epsilon) return FABHIP_EINVAL;
+    hipLaunchKernelGGL(k_hmc_adapt_gathered, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, n_ranks, nblk_of(B_rank),
+                       epsilon, common_epsilon, target_p_accept, tune, p_accept, avg_distance);
+    return check_launch();
+}
+
 int fabhip_hmc_transition(const fabhip_hmc_args* a, fabhip_stream_t stream) {
     if (!a || !a->flow.packed || !a->noise_p || !a->noise_e || !a->epsilons || !a->common_epsilon || !a->mass ||
         !a->workspace || a->B < 0 || a->n_outer < 1 || a->L < 0)
@@ -938,9 +982,19 @@ static int compact(const fabhip_ais_args* a, const int* n_in, int* n_out, float*
 }
 
 int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
-    if (!a || !a->flow.packed || !a->betas || !a->eps0 || !a->noise_a || !a->noise_b || !a->step_state || !a->log_w ||
+    if (!a) return FABHIP_EINVAL;
+    return fabhip_ais_phase(a, FABHIP_AIS_INIT | FABHIP_AIS_FINISH, 1, a->M, nullptr, stream);
+}
+
+int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, int32_t j_end, float* partials,
+                     fabhip_stream_t stream) {
+    if (!a || !a->flow.packed || !a->betas || !a->noise_a || !a->noise_b || !a->step_state || !a->log_w ||
         !a->n_valid || !a->stats || !a->workspace || a->B < 1 || a->M < 1 || a->n_inner < 1)
         return FABHIP_EINVAL;
+    const bool do_init = (phases & FABHIP_AIS_INIT) != 0, do_finish = (phases & FABHIP_AIS_FINISH) != 0;
+    if (do_init && !a->eps0) return FABHIP_EINVAL;
+    if (j_begin <= j_end && (j_begin < 1 || j_end > a->M)) return FABHIP_EINVAL;
+    if (partials && (j_begin != j_end || a->transition != FABHIP_TRANSITION_HMC)) return FABHIP_ENOTSUP;
     const bool hmc = a->transition == FABHIP_TRANSITION_HMC;
     if (!hmc && a->transition != FABHIP_TRANSITION_METROPOLIS) return FABHIP_EINVAL;
     if (hmc && (!a->common_epsilon || !a->mass)) return FABHIP_EINVAL;
@@ -966,6 +1020,7 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
     void* ess_ws = ws;
     const size_t ess_bytes = fabhip_ess_workspace_bytes(B);
 
+    if (do_init) {
     // 1. chain initialisation
     fabhip_anneal a1;
     fabhip_anneal_coefs(a->betas[1], a->alpha, a->p_target, &a1);
@@ -982,8 +1037,9 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
     // 3. ESS over the base samples (ais.py:68-71) -> stats[0..2]
     hipLaunchKernelGGL(k_sub, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_p, a->point.log_q, lwb, B);
     FAB_TRY(fabhip_ess_logz(lwb, B, a->n_valid, 1.0, a->stats + 0, ess_ws, ess_bytes, stream));
+    }
     // 4. transitions
-    for (int j = 1; j <= a->M; ++j) {
+    for (int j = j_begin; j <= j_end; ++j) {
         fabhip_anneal cj, cn;
         fabhip_anneal_coefs(a->betas[j], a->alpha, a->p_target, &cj);
         fabhip_anneal_coefs(a->betas[j + 1], a->alpha, a->p_target, &cn);
@@ -999,6 +1055,7 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
             h.tune = a->tune;
             h.p_accept = nullptr; h.avg_distance = nullptr;
             h.workspace = trans_ws; h.workspace_bytes = tws;
+            h.partials = partials;
             // logging slots of the first / last distribution (hmc.py:173-183), one acceptance per outer loop
             if (j == 1) { h.p_accept = a->p_accept_first; h.avg_distance = a->avg_distance_first; }
             else if (j == a->M) { h.p_accept = a->p_accept_last; h.avg_distance = a->avg_distance_last; }
@@ -1015,8 +1072,10 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
         }
     }
     // 5. remove nan/inf ("chain end"), 6. ESS / log Z over the survivors (ais.py:77-86)
-    FAB_TRY(compact(a, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, st));
-    FAB_TRY(fabhip_ess_logz(a->log_w, B, a->n_valid + 1, (double)B, a->stats + 3, ess_ws, ess_bytes, stream));
+    if (do_finish) {
+        FAB_TRY(compact(a, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, st));
+        FAB_TRY(fabhip_ess_logz(a->log_w, B, a->n_valid + 1, (double)B, a->stats + 3, ess_ws, ess_bytes, stream));
+    }
     return check_launch();
 }
 

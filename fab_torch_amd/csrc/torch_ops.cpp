@@ -453,6 +453,7 @@ void hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t
     const size_t nb = fabhip_hmc_workspace_bytes(B, (int32_t)dim, (int32_t)n_outer);
     Tensor ws = scratch(nb, x);
     a.workspace = aligned(ws); a.workspace_bytes = nb;
+    a.partials = nullptr;
     chk(fabhip_hmc_transition(&a, stream_of(x)), "hmc_transition");
 }
 
@@ -721,6 +722,75 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     return {x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw};
 }
 
+// The same call in pieces (fabhip_ais_phase): the state tensors are the caller's, in/out across the phases of one AIS
+// run.  Used when chains are sharded over ranks and the step sizes adapt on the acceptance of ALL chains: one transition
+// per call with `partials`, the caller all-gathers the slabs and calls hmc_adapt_gathered (fab_torch_amd/parallel.py).
+void ais_phase(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind, at::ArrayRef<double> prm,
+               const optional<Tensor>& locs, const optional<Tensor>& scales, at::ArrayRef<double> betas, double alpha,
+               bool p_target, int64_t transition, int64_t phases, int64_t j_begin, int64_t j_end,
+               const optional<Tensor>& eps0, const Tensor& noise_a, const Tensor& noise_b, Tensor step_state,
+               optional<Tensor> common_epsilon, const optional<Tensor>& mass, int64_t n_inner, int64_t L, double max_grad,
+               double target_p_accept, bool tune, Tensor x, Tensor log_q, Tensor log_p, optional<Tensor> grad_log_q,
+               optional<Tensor> grad_log_p, Tensor log_w, Tensor n_valid, Tensor stats, optional<Tensor> partials,
+               optional<Tensor> p_accept_first, optional<Tensor> p_accept_last, optional<Tensor> avg_distance_first,
+               optional<Tensor> avg_distance_last, optional<Tensor> base_x, optional<Tensor> base_log_w) {
+    c10::DeviceGuard g(x.device());
+    fabhip_ais_args a;
+    a.flow = make_flow(packed, dim, n_layers, width);
+    a.target = make_target(kind, prm, locs, scales, dim);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
+    const int64_t B = x.size(0), M = (int64_t)betas.size() - 2;
+    TORCH_CHECK(M >= 1, "fabhip: betas must hold M + 2 values");
+    TORCH_CHECK(n_inner >= 1, "fabhip: n_inner must be >= 1");
+    const bool hmc = transition == FABHIP_TRANSITION_HMC;
+    TORCH_CHECK(hmc || transition == FABHIP_TRANSITION_METROPOLIS, "fabhip: unknown transition kind ", transition);
+    TORCH_CHECK(!hmc || (common_epsilon.has_value() && mass.has_value() && grad_log_q.has_value() && grad_log_p.has_value()),
+                "fabhip: an HMC AIS run needs common_epsilon, the mass vector and the gradient fields of the Point");
+    a.B = B; a.M = (int32_t)M;
+    std::vector<double> bt(betas.begin(), betas.end());
+    a.betas = bt.data();
+    a.alpha = alpha; a.p_target = p_target ? 1 : 0; a.transition = (int32_t)transition;
+    a.eps0 = eps0.has_value() ? fpn(*eps0, B * dim, x, "eps0") : nullptr;
+    a.noise_a = fpn(noise_a, M * n_inner * B * dim, x, "noise_a"); a.noise_b = fpn(noise_b, M * n_inner * B, x, "noise_b");
+    a.step_state = fpmn(step_state, M * n_inner, x, "step_state");
+    a.common_epsilon = fpmn_opt(common_epsilon, 1, x, "common_epsilon", true);
+    a.mass = mass.has_value() ? fpn(*mass, dim, x, "mass") : nullptr;
+    a.n_inner = (int32_t)n_inner; a.L = (int32_t)L; a.max_grad = (float)max_grad;
+    a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
+    a.point = fabhip_point{fpm(x, "x"), fpmn(log_q, B, x, "log_q"), fpmn(log_p, B, x, "log_p"),
+                           hmc ? fpmn(*grad_log_q, B * dim, x, "grad_log_q") : nullptr,
+                           hmc ? fpmn(*grad_log_p, B * dim, x, "grad_log_p") : nullptr};
+    a.log_w = fpmn(log_w, B, x, "log_w");
+    need(n_valid, at::kInt, "n_valid"); need_n(n_valid, 2, x, "n_valid");
+    a.n_valid = n_valid.data_ptr<int32_t>();
+    a.stats = fpmn(stats, 16, x, "stats");
+    a.p_accept_first = fpmn_opt(p_accept_first, n_inner, x, "p_accept_first", true);
+    a.p_accept_last = fpmn_opt(p_accept_last, n_inner, x, "p_accept_last", true);
+    a.avg_distance_first = fpmn_opt(avg_distance_first, 1, x, "avg_distance_first", true);
+    a.avg_distance_last = fpmn_opt(avg_distance_last, 1, x, "avg_distance_last", true);
+    a.base_x = fpmn_opt(base_x, B * dim, x, "base_x");
+    a.base_log_w = fpmn_opt(base_log_w, B, x, "base_log_w");
+    const size_t nb = fabhip_ais_workspace_bytes(B, (int32_t)dim, (int32_t)n_inner);
+    Tensor ws = scratch(nb, x);
+    a.workspace = aligned(ws); a.workspace_bytes = nb;
+    float* slab = fpmn_opt(partials, fabhip_hmc_partials_floats(B), x, "partials");
+    chk(fabhip_ais_phase(&a, (int32_t)phases, (int32_t)j_begin, (int32_t)j_end, slab, stream_of(x)), "ais_phase");
+}
+
+int64_t hmc_partials_floats(int64_t B) { return fabhip_hmc_partials_floats(B); }
+
+void hmc_adapt_gathered(const Tensor& gathered, int64_t n_ranks, int64_t B_rank, Tensor epsilon, Tensor common_epsilon,
+                        double target_p_accept, bool tune, optional<Tensor> p_accept, optional<Tensor> avg_distance) {
+    c10::DeviceGuard g(gathered.device());
+    TORCH_CHECK(n_ranks >= 1 && B_rank >= 1, "fabhip: hmc_adapt_gathered needs n_ranks, B_rank >= 1");
+    need_n(gathered, n_ranks * fabhip_hmc_partials_floats(B_rank), gathered, "gathered partials");
+    chk(fabhip_hmc_adapt_gathered(fp(gathered, "gathered partials"), (int32_t)n_ranks, B_rank,
+                                  fpmn(epsilon, 1, gathered, "epsilon"), fpmn(common_epsilon, 1, gathered, "common_epsilon", true),
+                                  (float)target_p_accept, tune ? 1 : 0, fpmn_opt(p_accept, 1, gathered, "p_accept", true),
+                                  fpmn_opt(avg_distance, 1, gathered, "avg_distance", true), stream_of(gathered)),
+        "hmc_adapt_gathered");
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // ESS / log Z, resampling, top-k
 // ------------------------------------------------------------------------------------------------------------------
@@ -866,6 +936,16 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
 
+    m.def("ais_phase(" FLW ", " TGT ", float[] betas, float alpha, bool p_target, int transition, int phases, int j_begin, "
+          "int j_end, Tensor? eps0, Tensor noise_a, Tensor noise_b, Tensor(a!) step_state, Tensor(b!)? common_epsilon, "
+          "Tensor? mass, int n_inner, int L, float max_grad, float target_p_accept, bool tune, Tensor(c!) x, "
+          "Tensor(d!) log_q, Tensor(e!) log_p, Tensor(f!)? grad_log_q, Tensor(g!)? grad_log_p, Tensor(h!) log_w, "
+          "Tensor(i!) n_valid, Tensor(j!) stats, Tensor(k!)? partials, Tensor(l!)? p_accept_first, "
+          "Tensor(m!)? p_accept_last, Tensor(n!)? avg_distance_first, Tensor(o!)? avg_distance_last, Tensor(p!)? base_x, "
+          "Tensor(q!)? base_log_w) -> ()");
+    m.def("hmc_partials_floats(int B) -> int", hmc_partials_floats);
+    m.def("hmc_adapt_gathered(Tensor gathered, int n_ranks, int B_rank, Tensor(a!) epsilon, Tensor(b!) common_epsilon, "
+          "float target_p_accept, bool tune, Tensor(c!)? p_accept, Tensor(d!)? avg_distance) -> ()");
     m.def("generic_workspace(Tensor like, int B, int dim) -> Tensor");
     m.def("hmc_generic_begin(Tensor start_x, Tensor start_gq, Tensor start_gp, Tensor cur_lq, Tensor cur_lp, float beta, "
           "float alpha, bool p_target, Tensor noise_p, Tensor mass, float max_grad, Tensor(a!) ws) -> ()");
@@ -918,6 +998,8 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("hmc_transition", hmc_transition);
     m.impl("metropolis_transition", metropolis_transition);
     m.impl("ais_run", ais_run);
+    m.impl("ais_phase", ais_phase);
+    m.impl("hmc_adapt_gathered", hmc_adapt_gathered);
     m.impl("generic_workspace", generic_workspace);
     m.impl("hmc_generic_begin", hmc_generic_begin);
     m.impl("hmc_generic_leap_pre", hmc_generic_leap_pre);

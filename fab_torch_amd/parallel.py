@@ -5,8 +5,16 @@ The reference has no distributed code; chains are independent ev
 (§8e), so rank r owns chains [r*B/R, (r+1)*B/R) with replicated flow/target parameters and there is no
 data-path collective until the particles are gathered.  Payload per rank: [B/R, D+2] fp32 (x | log_w |
 log_q) — a few hundred KiB, latency-bound on xGMI, hence a single direct all-gather (no ring of
-small buckets).  Step sizes adapt per rank on the local shard (`sync_step_size=False`, default) or are
-kept identical across ranks by averaging the adapted values with one tiny all-reduce per call.
+small buckets).
+
+Step sizes: the reference adapts every transition's step size on the mean acceptance of the WHOLE batch
+(hmc.py:122-123,162-170).  `ShardedAnnealedImportanceSampler` keeps exactly that: each transition publishes its acceptance
+sums per 16-chain block (a slab of 2 ceil(B/16R) + 1 floats), ONE tiny all-gather per transition joins the slabs in rank
+order and every rank applies the rule to the same numbers (fabhip_hmc_adapt_gathered) - with shards that are multiples
+of 16 chains the sums are added in the order a single device uses, so the sharded run reproduces the single-device step
+sizes bit for bit.  With tuning frozen (`set_eval_mode(True)`, the reference's own evaluation setting) no such collective
+is needed and the rank-local call is the fused one.  `ShardedAIS` (per-rank adaptation, optional averaging) is kept
+for callers that bring their own rank-local sampler.
 """
 from typing import Callable, Optional, Tuple
 
@@ -43,17 +51,36 @@ def unpack_particles(buf: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, tor
     return flat[:, :D], flat[:, D], flat[:, D + 1]
 
 
+def _world(group=None):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+
+
+def _rank(group=None):
+    return dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+
+
+def all_gather_rows(buf: torch.Tensor, group=None) -> torch.Tensor:
+    """[n, ...] on every rank -> [world * n, ...] in rank order: ONE all-gather.  RCCL ("nccl") takes device tensors
+    directly; a host-only backend (gloo: the CPU tests, and the 2-process run on a 1-GPU box) is fed through the host."""
+    world = _world(group)
+    if world == 1:
+        return buf
+    out = torch.empty((world * buf.shape[0],) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+    if buf.is_cuda and dist.get_backend(group) != "nccl":
+        host = torch.empty(out.shape, dtype=buf.dtype)
+        dist.all_gather_into_tensor(host, buf.cpu().contiguous(), group=group)
+        out.copy_(host)
+    else:
+        dist.all_gather_into_tensor(out, buf.contiguous(), group=group)
+    return out
+
+
 def gather_particles(x, log_w, log_q, capacity: int, group=None, compact: bool = True):
     """All-gather fixed-size shards (invalid rows stay in place with log_w = -inf, compaction after).
     compact=False skips the compaction - and with it the host synchronisation of the boolean-mask indexing: the result
     keeps `world * capacity` rows, dropped chains appear as rows with log_w = -inf (weight 0 for ESS / log Z /
     resampling) and x = 0."""
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
-    buf = pack_particles(x, log_w, log_q, capacity)
-    if world > 1:
-        out = torch.empty((world * buf.shape[0], buf.shape[1]), dtype=buf.dtype, device=buf.device)
-        dist.all_gather_into_tensor(out, buf, group=group)
-        buf = out
+    buf = all_gather_rows(pack_particles(x, log_w, log_q, capacity), group)
     if compact:
         return unpack_particles(buf)
     D = buf.shape[-1] - 3
@@ -89,3 +116,143 @@ class ShardedAIS:
                 t.copy_(flat[o:o + t.numel()].view_as(t))
                 o += t.numel()
         return gather_particles(x, log_w, log_q, max(sizes), self.group)
+
+
+class HipShardBackend:
+    """The rank-local pieces of one sharded AIS call on the GPU (torch.ops.fabhip.ais_phase / hmc_adapt_gathered over
+    an `AnnealedImportanceSampler` whose plug-ins are fabhip-native).  `ShardedAnnealedImportanceSampler` drives these
+    four methods; the CPU tests drive the same loop with an oracle-backed stand-in."""
+
+    def __init__(self, ais):
+        from . import _ops
+        from .transition_operators import HamiltonianMonteCarlo
+        self.ais, self.ops, self._ops_mod = ais, _ops.load(), _ops
+        self.op = ais.transition_operator
+        self.hmc = isinstance(self.op, HamiltonianMonteCarlo)
+        if not ais.is_native:
+            raise _ops.FabhipError("sharded AIS needs fabhip-native plug-ins (RealNVP flow, ManyWell / GMM target)")
+
+    @property
+    def n_transitions(self) -> int:
+        return self.ais.n_intermediate_distributions
+
+    @property
+    def tuning(self) -> bool:
+        """True when a transition's step size depends on the acceptance of the whole batch: HMC outside eval mode.
+        (Metropolis with `adjust_step_size` adapts per rank - cfg 1 runs it untuned, gmm.yaml:29-34.)"""
+        return self.hmc and not self.op.eval_mode
+
+    def run_fused(self, b, eps0=None, noise_a=None, noise_b=None):
+        pt, log_w = self.ais.sample_and_log_weights(b, eps0=eps0, noise_a=noise_a, noise_b=noise_b)
+        return pt, log_w
+
+    def _common(self, st):
+        ais, op = self.ais, self.op
+        flow, target = ais._native_parts()
+        alpha = float(ais.alpha) if ais.alpha is not None else 0.0
+        return (*flow.native(), *target.native_target(), [float(v) for v in ais.B_space], alpha, bool(ais.p_target),
+                self._ops_mod.TRANSITION_HMC)
+
+    def _phase(self, st, phases, j0, j1, partials=None, tune=False):
+        op = self.op
+        self.ops.ais_phase(*self._common(st), int(phases), int(j0), int(j1), st["eps0"], st["noise_a"], st["noise_b"],
+                           op.epsilons, op.common_epsilon, op.mass_vector, 1, op.L, float(op.max_grad),
+                           float(op.target_p_accept), bool(tune), st["x"], st["lq"], st["lp"], st["gq"], st["gp"],
+                           st["log_w"], st["n_valid"], st["stats"], partials, None, None, None, None, None, None)
+
+    def begin(self, b, eps0=None, noise_a=None, noise_b=None):
+        """Chain initialisation + "chain init" filter + base ESS of this rank's b chains (FABHIP_AIS_INIT)."""
+        if not self.hmc or self.op.n_outer != 1:
+            raise self._ops_mod.FabhipError("exact sharded step-size adaptation: HMC with n_outer == 1 "
+                                            "(every shipped config, experiments/setup_run.py:190)")
+        flow, _ = self.ais._native_parts()
+        dev = flow._nf_model.q0.loc.device
+        D, M = flow.dim, self.n_transitions
+        f32 = dict(dtype=torch.float32, device=dev)
+        st = {"b": int(b),
+              "eps0": (torch.randn((b, D), **f32) if eps0 is None else eps0.contiguous()),
+              "noise_a": (torch.randn((M, 1, b, D), **f32) if noise_a is None else noise_a.contiguous()),
+              "noise_b": (torch.empty((M, 1, b), **f32).exponential_(1.0) if noise_b is None else noise_b.contiguous()),
+              "x": torch.empty((b, D), **f32), "lq": torch.empty(b, **f32), "lp": torch.empty(b, **f32),
+              "gq": torch.empty((b, D), **f32), "gp": torch.empty((b, D), **f32), "log_w": torch.empty(b, **f32),
+              "n_valid": torch.zeros(2, dtype=torch.int32, device=dev), "stats": torch.zeros(16, **f32),
+              "slab": torch.empty(int(self.ops.hmc_partials_floats(int(b))), **f32)}
+        self._phase(st, 1, 1, 0)
+        return st
+
+    def step(self, st, j) -> torch.Tensor:
+        """Transition j with the adaptation deferred: returns this rank's acceptance slab."""
+        self._phase(st, 0, j, j, partials=st["slab"], tune=True)
+        return st["slab"]
+
+    def adapt(self, st, j, gathered, world):
+        op, M = self.op, self.n_transitions
+        pa, ad = (op._p_accept_first, op._dist_first) if j == 1 else ((op._p_accept_last, op._dist_last) if j == M
+                                                                      else (None, None))
+        self.ops.hmc_adapt_gathered(gathered, int(world), st["b"], op.epsilons[j - 1], op.common_epsilon,
+                                    float(op.target_p_accept), True, pa, ad)
+
+    def finish(self, st):
+        """"chain end" filter + local ESS / log Z (FABHIP_AIS_FINISH); one device->host read for the row counts."""
+        from .point import Point
+        self._phase(st, 2, 1, 0)
+        host = torch.cat([st["n_valid"].float(), st["stats"][:6]]).cpu()
+        n_init, n_end = int(host[0]), int(host[1])
+        if n_init == 0:
+            raise Exception("No valid points generated in sampling the chain init")
+        if n_end == 0:
+            raise Exception("No valid points generated in sampling the chain end")
+        from .ais import LoggingInfo                      # this rank's own chains (the gathered set: logging_info)
+        self.ais._logging_info = LoggingInfo(ess_base=float(host[2]), ess_ais=float(host[5]), log_Z=float(host[6]))
+        pt = Point(st["x"][:n_end], st["lq"][:n_end], st["lp"][:n_end], st["gq"][:n_end], st["gp"][:n_end])
+        return pt, st["log_w"][:n_end].detach()
+
+
+class ShardedAnnealedImportanceSampler:
+    """`AnnealedImportanceSampler.sample_and_log_weights(total_batch)` over the ranks of a process group with the
+    semantics of ONE device holding every chain: rank r runs chains [r b, (r + 1) b), the step sizes adapt on the
+    acceptance of all chains (one slab all-gather per transition while tuning is on), the particles are joined by one
+    all-gather at the end, ESS / log Z are those of the gathered set.  Returns (x, log_w, log_q) of all chains on every
+    rank (`compact=False`: fixed `world * b` rows, dropped chains as log_w = -inf rows, no host synchronisation)."""
+
+    def __init__(self, ais=None, group=None, backend=None):
+        self.group = group
+        self.backend = backend if backend is not None else HipShardBackend(ais)
+        self.logging_info = None
+        self.n_slab_gathers = 0                 # collectives issued by the last call besides the particle gather
+
+    def local_batch(self, total_batch: int) -> int:
+        world = _world(self.group)
+        if total_batch % world:
+            raise ValueError(f"sharded AIS: {total_batch} chains do not split evenly over {world} ranks")
+        return total_batch // world
+
+    def sample_and_log_weights(self, total_batch: int, eps0=None, noise_a=None, noise_b=None, compact: bool = True,
+                               logging: bool = True):
+        world = _world(self.group)
+        b = self.local_batch(total_batch)
+        be = self.backend
+        self.n_slab_gathers = 0
+        if world == 1 or not be.tuning:
+            pt, log_w = be.run_fused(b, eps0, noise_a, noise_b)
+        else:
+            st = be.begin(b, eps0, noise_a, noise_b)
+            for j in range(1, be.n_transitions + 1):
+                slab = be.step(st, j)
+                gathered = all_gather_rows(slab.reshape(1, -1), self.group).reshape(-1)
+                self.n_slab_gathers += 1
+                be.adapt(st, j, gathered, world)
+            pt, log_w = be.finish(st)
+        x, lw, lq = gather_particles(pt.x, log_w, pt.log_q, b, self.group, compact=compact)
+        if logging:
+            self.logging_info = self._global_stats(lw, total_batch)
+        return x, lw, lq
+
+    @staticmethod
+    def _global_stats(log_w, total_batch):
+        """ESS and log Z of the gathered set (ais.py:80-86; log Z normalised by the REQUESTED batch), lazily: device
+        scalars, no synchronisation here."""
+        lw = log_w.double()
+        lse = torch.logsumexp(lw, 0)
+        ess = torch.exp(2 * lse - torch.logsumexp(2 * lw, 0)) / torch.isfinite(lw).sum()
+        return {"ess_ais": ess, "log_Z": lse - torch.log(torch.tensor(float(total_batch), dtype=torch.float64))}

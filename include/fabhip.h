@@ -314,10 +314,25 @@ typedef struct {
     float* avg_distance;    /* [1] out, store_info's distance statistic, or NULL     */
     void* workspace;
     size_t workspace_bytes;
+    /* Sharded chains: NULL = adapt from this call's own chains (above).  Otherwise the step sizes, p_accept
+     * and avg_distance are left alone and the call publishes its acceptance statistics as ONE slab of
+     * fabhip_hmc_partials_floats(B) floats - per 16-chain block the sum of min(1, acceptance) and of store_info's
+     * distance, then the number of chains in use: [acc[nblk] | dist[nblk] | n] - which the caller all-gathers over the
+     * ranks and hands to fabhip_hmc_adapt_gathered.  Requires n_outer == 1 (every shipped config, setup_run.py:190). */
+    float* partials;
 } fabhip_hmc_args;
 
 size_t fabhip_hmc_workspace_bytes(int64_t B, int32_t dim, int32_t n_outer);
 int fabhip_hmc_transition(const fabhip_hmc_args* args, fabhip_stream_t stream);
+
+/* Step-size adaptation of hmc.py:122-123,162-170 on the mean acceptance of ALL chains of a sharded batch: `gathered` =
+ * the partials slabs of n_ranks ranks in rank order (each fabhip_hmc_partials_floats(B_rank) floats, equal B_rank).
+ * The sums run over ranks, then blocks, in order - with shards that are multiples of 16 chains exactly the sequence a
+ * single device adds for the whole batch, so every rank ends up with the single-device step sizes bit for bit. */
+int64_t fabhip_hmc_partials_floats(int64_t B);
+int fabhip_hmc_adapt_gathered(const float* gathered, int32_t n_ranks, int64_t B_rank, float* epsilon, float* common_epsilon,
+                              float target_p_accept, int32_t tune, float* p_accept, float* avg_distance,
+                              fabhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Metropolis transition (fab/sampling_methods/transition_operators/metropolis.py:51-74)
@@ -440,6 +455,16 @@ typedef struct {
 
 size_t fabhip_ais_workspace_bytes(int64_t B, int32_t dim, int32_t n_inner);
 int fabhip_ais_run(const fabhip_ais_args* args, fabhip_stream_t stream);
+
+/* The same call in pieces, for chains sharded over ranks with exact step-size adaptation: `phases` selects
+ * FABHIP_AIS_INIT (chain initialisation, "chain init" filter, base ESS), the transitions j_begin .. j_end (1-based,
+ * j_begin > j_end: none) and FABHIP_AIS_FINISH ("chain end" filter, ESS / log Z).  point / log_w / n_valid / stats are
+ * in/out across the calls of one AIS run, eps0 is read by INIT only.  With `partials` != NULL (HMC, n_inner == 1,
+ * j_begin == j_end) the transition leaves the step sizes alone and publishes its acceptance slab instead
+ * (fabhip_hmc_args.partials); fabhip_ais_run(args) == fabhip_ais_phase(args, INIT | FINISH, 1, M, NULL). */
+enum { FABHIP_AIS_INIT = 1, FABHIP_AIS_FINISH = 2 };
+int fabhip_ais_phase(const fabhip_ais_args* args, int32_t phases, int32_t j_begin, int32_t j_end, float* partials,
+                     fabhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * ESS / log Z  (fab/utils/numerical.py:18-23, fab/sampling_methods/ais.py:80-86)

@@ -1,0 +1,136 @@
+"""Chains sharded over ranks with the single-device step-size rule (fab/sampling_methods/transition_operators/
+hmc.py:122-123,162-170: the rule sees the acceptance of ALL chains): fabhip_ais_phase + fabhip_hmc_adapt_gathered through
+`parallel.HipShardBackend` / `parallel.ShardedAnnealedImportanceSampler`.
+
+(1) two shards emulated in ONE process (slabs concatenated in rank order) against the fused single-device call on the
+    same noise rows, tuning ON: particles, log-weights and every adapted step size bit for bit;
+(2) the same as two real processes (gloo rendezvous; both use the one GPU of the box, the collectives' payload is staged
+    through the host - RCCL itself needs one GPU per rank and is exercised by `bench.py --gpus N` on a multi-GPU node).
+"""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+fa = pytest.importorskip("fab_torch_amd")
+from fab_torch_amd import _ops, parallel      # noqa: E402
+
+DEV = "cuda"
+D, K, NODES, M, L = 32, 4, 10, 4, 3          # hidden width 320 (the headline tile variant), 4 layers
+
+
+def _sampler(seed=0, eps=0.2, dev=DEV):
+    torch.manual_seed(seed)
+    flow = fa.RealNVP(D, K, NODES)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for l1, l2, l3, aff in flow._layers():
+            l3.weight.copy_(torch.randn(l3.weight.shape, generator=g) * 0.02)
+            l3.bias.copy_(torch.randn(l3.bias.shape, generator=g) * 0.02)
+    flow = flow.to(dev).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=eps, L=L).to(dev)
+    return fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, False, 2.0, M), hmc
+
+
+def _noise(total, scale_second_half=1.0):
+    g = torch.Generator().manual_seed(5)
+    eps0 = torch.randn(total, D, generator=g)
+    na = torch.randn(M, 1, total, D, generator=g)
+    na[:, :, total // 2:] *= scale_second_half        # the second shard accepts less often: a per-rank rule would differ
+    nb = torch.empty(M, 1, total).exponential_(generator=g)
+    return eps0, na, nb
+
+
+@pytest.mark.parametrize("total,shape", [(128, 4), (2048, 16), (2048, 4)])
+def test_emulated_shards_reproduce_the_fused_single_device_run_bit_for_bit(total, shape):
+    eps0, na, nb = (t.to(DEV) for t in _noise(total, 1.7))
+    with _ops.option(_ops.OPT_TILE_SHAPE, shape):          # (chains are bit-independent of the batch WITHIN a tile shape)
+        ais1, hmc1 = _sampler()
+        pt, lw = ais1.sample_and_log_weights(total, eps0=eps0, noise_a=na, noise_b=nb)       # fused, tuning on
+        world, b = 2, total // 2
+        ranks = []
+        for r in range(world):
+            ais, hmc = _sampler()
+            ranks.append((parallel.HipShardBackend(ais), hmc))
+        sts = []
+        for r, (be, _) in enumerate(ranks):
+            sl = slice(r * b, (r + 1) * b)
+            sts.append(be.begin(b, eps0[sl], na[:, :, sl].contiguous(), nb[:, :, sl].contiguous()))
+        for j in range(1, M + 1):
+            gathered = torch.cat([be.step(st, j).clone() for (be, _), st in zip(ranks, sts)])
+            for (be, _), st in zip(ranks, sts):
+                be.adapt(st, j, gathered, world)
+        outs = [be.finish(st) for (be, _), st in zip(ranks, sts)]
+    for _, hmc in ranks:
+        assert torch.equal(hmc.epsilons, hmc1.epsilons) and torch.equal(hmc.common_epsilon, hmc1.common_epsilon)
+        assert torch.equal(hmc._p_accept_first, hmc1._p_accept_first) and torch.equal(hmc._p_accept_last, hmc1._p_accept_last)
+    assert not torch.equal(hmc1.epsilons, torch.full_like(hmc1.epsilons, 0.2 * 0.9))
+    x = torch.cat([o[0].x for o in outs]); lws = torch.cat([o[1] for o in outs])
+    assert x.shape[0] == total and torch.equal(x, pt.x) and torch.equal(lws, lw)
+    assert torch.equal(torch.cat([o[0].log_q for o in outs]), pt.log_q)
+
+
+def test_deferred_adaptation_is_refused_where_it_cannot_be_exact():
+    ais, hmc = _sampler()
+    with pytest.raises(RuntimeError, match="fabhip"):       # slab of the wrong size
+        be = parallel.HipShardBackend(ais)
+        st = be.begin(64)
+        st["slab"] = torch.empty(3, device=DEV)
+        be.step(st, 1)
+    flow, target = ais._native_parts()
+    hmc2 = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.2, L=L,
+                                    n_outer=2).to(DEV)
+    ais2 = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc2, False, 2.0, M)
+    with pytest.raises(_ops.FabhipError, match="n_outer == 1"):
+        parallel.HipShardBackend(ais2).begin(64)
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    ais, hmc = _sampler(dev="cuda:0")
+    sh = parallel.ShardedAnnealedImportanceSampler(ais)
+    b = total // world
+    eps0, na, nb = (t.to("cuda:0") for t in _noise(total, 1.7))
+    sl = slice(rank * b, (rank + 1) * b)
+    res = {}
+    for it in range(2):                                     # two calls: the adapted step sizes carry over
+        x, lw, lq = sh.sample_and_log_weights(total, eps0=eps0[sl], noise_a=na[:, :, sl].contiguous(),
+                                              noise_b=nb[:, :, sl].contiguous(), compact=(it == 0))
+        res[it] = (x.cpu(), lw.cpu())
+    torch.save({"res": res, "eps": hmc.epsilons.cpu(), "ceps": hmc.common_epsilon.cpu(), "n_gathers": sh.n_slab_gathers,
+                "ess": float(sh.logging_info["ess_ais"]), "log_Z": float(sh.logging_info["log_Z"])}, out + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_reproduce_the_single_process_run(tmp_path):
+    world, total = 2, 256
+    out = str(tmp_path / "g")
+    mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    ais, hmc = _sampler()
+    eps0, na, nb = (t.to(DEV) for t in _noise(total, 1.7))
+    with _ops.option(_ops.OPT_TILE_SHAPE, 4):               # 128-chain shards ran 4-chain tiles
+        for it in range(2):
+            pt, lw = ais.sample_and_log_weights(total, eps0=eps0, noise_a=na, noise_b=nb)
+            for r in (r0, r1):
+                assert torch.equal(r["res"][it][0], pt.x.cpu()) and torch.equal(r["res"][it][1], lw.cpu())
+    for r in (r0, r1):
+        assert torch.equal(r["eps"], hmc.epsilons.cpu()) and torch.equal(r["ceps"], hmc.common_epsilon.cpu())
+        assert r["n_gathers"] == M
+    info = ais.get_logging_info()
+    assert abs(r0["ess"] - info["ess_ais"]) <= 1e-5 * info["ess_ais"] + 1e-7
+    assert abs(r0["log_Z"] - info["log_Z"]) <= 1e-4 * abs(info["log_Z"])

@@ -132,3 +132,134 @@ def test_two_rank_gather_without_compaction_keeps_fixed_size_and_marks_dropped_c
         xs.append(x); lws.append(lw)
     np.testing.assert_array_equal(got["x"][keep].numpy(), torch.cat(xs).numpy())
     np.testing.assert_array_equal(got["lw"][keep].numpy(), torch.cat(lws).numpy())
+
+
+# ---- exact cross-rank step-size adaptation (hmc.py:122-123,162-170: the rule sees the acceptance of ALL chains) ------
+class _OracleShardBackend:
+    """Stand-in for parallel.HipShardBackend on the CPU: the oracle's HMC with the adaptation taken out and restated the
+    way the kernels do it (per-16-chain-block fp32 sums of min(1, acceptance), then one sequential sum over the slabs
+    in rank order)."""
+    tuning = True
+
+    def __init__(self):
+        sys.path.insert(0, ROOT)
+        from oracle import ais as oais, flow as oflow, targets as otgt
+        self.oais = oais
+        self.D, self.M = 6, 4
+        torch.manual_seed(0)
+        self.nf = oflow.make_realnvp(self.D, 2, 5)
+        oflow.randomize_last_layers(self.nf, 0.05, 1)
+        self.target = otgt.ManyWell(self.D)
+        self.hmc = oais.HMC(self.M, self.D, self.nf.log_prob, self.target.log_prob, alpha=2.0, p_target=False, epsilon=0.25,
+                            L=3, eval_mode=True)          # (eval_mode: its own adaptation off - `adapt` below does it)
+        self.betas = oais.beta_schedule(self.M)
+        self.trace = []
+
+    n_transitions = property(lambda self: self.M)
+
+    def begin(self, b, eps0, noise_a, noise_b):
+        oais = self.oais
+        x, lq0 = (t.detach() for t in self.nf.sample_eps(eps0))
+        pt = oais.create_point(x, self.nf.log_prob, self.target.log_prob, with_grad=True)
+        lw = (oais.intermediate_log_prob(pt, self.betas[1], 2.0, False) - lq0).detach()
+        return {"b": b, "pt": pt, "lw": lw, "na": noise_a, "nb": noise_b}
+
+    def step(self, st, j):
+        oais, b = self.oais, st["b"]
+        st["pt"] = self.hmc.transition(st["pt"], j, self.betas[j], st["na"][j - 1], st["nb"][j - 1])
+        num = oais.intermediate_log_prob(st["pt"], self.betas[j + 1], 2.0, False)
+        den = oais.intermediate_log_prob(st["pt"], self.betas[j], 2.0, False)
+        st["lw"] = st["lw"] + (num - den)
+        log_acc = self.hmc.last_margin - st["nb"][j - 1][0, :b]
+        log_acc = torch.nan_to_num(log_acc, nan=-float("inf"), posinf=-float("inf"), neginf=-float("inf"))
+        contrib = torch.exp(torch.clamp(log_acc, max=0.0)).float()
+        nblk = (b + 15) // 16
+        acc = torch.zeros(nblk)
+        for k in range(nblk):
+            s = torch.tensor(0.0)
+            for v in contrib[16 * k:16 * k + 16]:
+                s = s + v                                 # fp32, row order (k_hmc_step's block partial)
+            acc[k] = s
+        return torch.cat([acc, torch.zeros(nblk), torch.tensor([float(b)])])
+
+    def adapt(self, st, j, gathered, world):
+        nblk = (st["b"] + 15) // 16
+        slabs = gathered.reshape(world, 2 * nblk + 1)
+        s, nv = torch.tensor(0.0), 0
+        for r in range(world):                            # k_hmc_adapt_gathered: ranks, then blocks, in order
+            for k in range(nblk):
+                s = s + slabs[r, k]
+            nv += int(slabs[r, 2 * nblk])
+        up = bool(torch.log(s) - torch.log(torch.tensor(float(nv))) > torch.log(torch.tensor(0.65)))
+        h = self.hmc
+        h.epsilons[j - 1, 0] = h.epsilons[j - 1, 0] * 1.05 if up else h.epsilons[j - 1, 0] / 1.05
+        h.common_epsilon = h.common_epsilon * 1.02 if up else h.common_epsilon / 1.02
+        self.trace.append((up, float(s)))
+
+    def finish(self, st):
+        return st["pt"], st["lw"]
+
+
+def _sharded_noise(total, D, M):
+    g = torch.Generator().manual_seed(11)
+    eps0 = torch.randn(total, D, generator=g)
+    na = torch.randn(M, 1, total, D, generator=g)
+    na[:, :, total // 2:] *= 2.0                          # the second shard's chains accept far less often than the first's
+    nb = torch.empty(M, 1, total).exponential_(generator=g)
+    return eps0, na, nb
+
+
+def _worker_exact(rank, world, port, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    be = _OracleShardBackend()
+    sh = parallel.ShardedAnnealedImportanceSampler(backend=be)
+    b = total // world
+    eps0, na, nb = _sharded_noise(total, be.D, be.M)
+    sl = slice(rank * b, (rank + 1) * b)
+    x, lw, lq = sh.sample_and_log_weights(total, eps0=eps0[sl], noise_a=na[:, :, sl].contiguous(),
+                                          noise_b=nb[:, :, sl].contiguous())
+    torch.save({"x": x, "lw": lw, "eps": be.hmc.epsilons.clone(), "ceps": be.hmc.common_epsilon.clone(),
+                "trace": be.trace, "n_gathers": sh.n_slab_gathers,
+                "ess": float(sh.logging_info["ess_ais"]), "log_Z": float(sh.logging_info["log_Z"])}, out + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_run_reproduces_the_single_device_step_size_trajectory(tmp_path):
+    """SURVEY 8e / VERDICT r2 #5: with tuning ON the step-size rule must see the acceptance of the whole batch.  Two gloo
+    ranks x 32 chains against ONE process holding all 64 chains (same noise rows): identical up / down decisions, step
+    sizes bit for bit on both ranks, exactly one slab all-gather per transition - and the shards are built so that a
+    per-rank rule would have decided differently."""
+    world, total = 2, 64
+    out = str(tmp_path / "e")
+    mp.spawn(_worker_exact, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    # the single-device run: same pieces, all chains in one process, its own slab as the "gathered" set
+    torch.set_num_threads(1)
+    be = _OracleShardBackend()
+    eps0, na, nb = _sharded_noise(total, be.D, be.M)
+    st = be.begin(total, eps0, na, nb)
+    local_decisions = []
+    for j in range(1, be.M + 1):
+        slab = be.step(st, j)
+        nblk = total // 16
+        for half in (slice(0, nblk // 2), slice(nblk // 2, nblk)):           # what each rank ALONE would have decided
+            s = float(slab[half].sum())
+            local_decisions.append(s / (total // 2) > 0.65)
+        be.adapt(st, j, slab, 1)
+    pt, lw = be.finish(st)
+    for r in (r0, r1):
+        assert torch.equal(r["eps"], be.hmc.epsilons) and torch.equal(r["ceps"], be.hmc.common_epsilon)
+        assert [t[0] for t in r["trace"]] == [t[0] for t in be.trace]
+        assert [t[1] for t in r["trace"]] == [t[1] for t in be.trace]          # the very same fp32 sums
+        assert r["n_gathers"] == be.M
+    per_rank = list(zip(local_decisions[0::2], local_decisions[1::2]))
+    assert any(a != b for a, b in per_rank), "test set-up: the two shards must disagree on some transition"
+    assert torch.equal(r0["x"], r1["x"]) and torch.equal(r0["lw"], r1["lw"])
+    np.testing.assert_allclose(r0["x"].numpy(), pt.x.numpy(), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r0["lw"].numpy(), lw.numpy(), rtol=1e-4, atol=1e-4)
+    from oracle.numerical import effective_sample_size
+    assert abs(r0["ess"] - float(effective_sample_size(lw))) < 1e-4
+    assert abs(r0["log_Z"] - float(torch.logsumexp(lw.double(), 0) - np.log(total))) < 1e-4
