@@ -317,6 +317,51 @@ def g8_full_chain():
     npz("g8_ais_gmm_metropolis.npz", **out)
 
 
+def g14_headline_arch():
+    """The reference's own AIS call and one HMC transition at the HEADLINE flow architecture (many_well.yaml:7-10: RealNVP
+    10 x (16-320-320-32) + InvertibleAffine, D = 32; ais.yaml / many_well.yaml:25-29: HMC, L = 5, M = 8 here as in
+    BASELINE.json's metric), B = 64 chains.  The 4.8 MB of weights are NOT stored: `helpers.seeded_oracle_flow`
+    rebuilds them from the seed (same routine, same torch CPU generator); the fixture holds noise, every transition's
+    input step sizes and output state (snapshots for teacher-forced per-transition checks) and the final outputs."""
+    from helpers import seeded_oracle_flow
+    D, K, nodes, M, L, B, alpha, seed, std = 32, 10, 10, 8, 5, 64, 2.0, 140, 0.05
+    nf = seeded_oracle_flow(D, K, nodes, seed, std)
+    target = ManyWellEnergy(dim=D, use_gpu=False)
+    hmc = tuned_hmc(M, D, nf, target, 0.2, L, 1, alpha, False)
+    torch.manual_seed(141)
+    eps0 = torch.randn(B, D)
+    ais = AnnealedImportanceSampler(EpsFlow(nf, eps0), target.log_prob, hmc, p_target=False, alpha=alpha,
+                                    n_intermediate_distributions=M)
+    in_eps, in_ceps = hmc.epsilons.clone(), hmc.common_epsilon.clone()
+    snaps, eps_in, ceps_in = [], [], []
+    orig = hmc.transition
+
+    def recording_transition(point, i, beta):
+        if i == 1:
+            snaps.append((point.x.clone(), point.log_q.clone(), point.log_p.clone()))       # the chains' starting state
+        eps_in.append(hmc.epsilons[i - 1].clone()); ceps_in.append(hmc.common_epsilon.clone())
+        out = orig(point, i, beta)
+        snaps.append((out.x.clone(), out.log_q.clone(), out.log_p.clone()))
+        return out
+    hmc.transition = recording_transition
+    with Capture() as cap:
+        pt, log_w = ais.sample_and_log_weights(B)
+    hmc.transition = orig
+    info = ais.get_logging_info()
+    npz("g14_ais_headline.npz", D=D, K=K, nodes=nodes, flow_seed=seed, flow_std=std, M=M, L=L, alpha=alpha, p_target=0,
+        eps0=eps0, B_space=ais.B_space, in_epsilons=in_eps, in_common_epsilon=in_ceps,
+        noise_p=torch.stack(cap.randn_like)[:, None], noise_e=torch.stack(cap.expo)[:, None],
+        snap_x=torch.stack([s_[0] for s_ in snaps]), snap_log_q=torch.stack([s_[1] for s_ in snaps]),
+        snap_log_p=torch.stack([s_[2] for s_ in snaps]),
+        tr_epsilon=torch.stack(eps_in), tr_common_epsilon=torch.stack(ceps_in),
+        out_x=pt.x, out_log_q=pt.log_q, out_log_p=pt.log_p, out_gq=pt.grad_log_q, out_gp=pt.grad_log_p, log_w=log_w,
+        out_epsilons=hmc.epsilons, out_common_epsilon=hmc.common_epsilon, ess_base=info["ess_base"],
+        ess_ais=info["ess_ais"], log_Z=info["log_Z"], dist0_p_accept_0=info["dist0_p_accept_0"],
+        # a probe of the rebuilt weights: the fixture is only valid for the flow `seeded_oracle_flow` returns
+        flow_probe=torch.stack([nf.flows[0].flows[1].param_map.net[2].weight[0, :8].detach(),
+                                nf.flows[-2].flows[1].param_map.net[4].weight[1, :8].detach()]))
+
+
 def g9_buffer():
     """Deterministic part of the reference's PrioritisedReplayBuffer (add ring wrap-around, adjust incl. the
     invalid-entry kill); sampling itself is random and is tested through properties."""
@@ -564,8 +609,12 @@ def g13_trained_flow():
     npz("g13_trained_flow_mw6.npz", **out)
 
 
+GENERATORS_NOTE = "g14 needs tests/ on sys.path (helpers.seeded_oracle_flow)"
+sys.path.insert(0, os.path.dirname(HERE))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(1)      # deterministic reduction order in the fixtures
     g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
     g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval(); g11_gmm_eval()
-    g12_trainer_traces(); g13_trained_flow()
+    g12_trainer_traces(); g13_trained_flow(); g14_headline_arch()

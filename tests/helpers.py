@@ -71,3 +71,24 @@ def oracle_flow_from_golden(g):
     nf = oflow.make_realnvp(D, K, W // D)
     nf.load_state_dict(sd)
     return nf
+
+
+def seeded_oracle_flow(dim, n_layers, nodes, seed, std=0.05):
+    """The oracle RealNVP with seeded parameters: torch.manual_seed(seed) -> nn.Linear default initialisation and the
+    QR-based InvertibleAffine of oracle.flow.make_realnvp, last coupling Linear re-drawn N(0, std^2) with seed + 1 (the
+    reference's `init_zeros` makes an untrained flow the identity).  tests/golden/make_golden.py builds the flow of the
+    g14 fixtures with this very function, so the fixtures store the seed instead of 4.8 MB of weights."""
+    from oracle import flow as oflow
+    torch.manual_seed(seed)
+    nf = oflow.make_realnvp(dim, n_layers, nodes)
+    oflow.randomize_last_layers(nf, std=std, seed=seed + 1)
+    return nf
+
+
+def flow_from_g14(g):
+    """The oracle flow of a g14 fixture, rebuilt from its seed and checked against the stored weight probe."""
+    nf = seeded_oracle_flow(int(g["D"]), int(g["K"]), int(g["nodes"]), int(g["flow_seed"]), float(g["flow_std"]))
+    probe = torch.stack([nf.flows[0].flows[1].param_map.net[2].weight[0, :8].detach(),
+                         nf.flows[-2].flows[1].param_map.net[4].weight[1, :8].detach()])
+    assert np.array_equal(probe.numpy(), g["flow_probe"]), "seeded flow differs from the one the fixture was made with"
+    return nf

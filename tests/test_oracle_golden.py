@@ -187,6 +187,32 @@ def test_g8_full_ais_hmc_matches_reference(tag):
     assert abs(info.log_Z - float(g["log_Z"])) <= RTOL * abs(float(g["log_Z"])) + 1e-4
 
 
+def test_g14_headline_architecture_ais_matches_reference():
+    """The reference's AIS call at the HEADLINE flow architecture (10 x (16-320-320-32) + InvertibleAffine, D = 32, M = 8,
+    L = 5; fab/experiments/config/many_well.yaml:7-10,25-29) with the weights rebuilt from the fixture's seed: the oracle
+    replays it - every transition's snapshot, the adapted step sizes bit for bit."""
+    from helpers import flow_from_g14
+    g = load_golden("g14_ais_headline.npz")
+    nf = flow_from_g14(g)
+    D, M = int(g["D"]), int(g["M"])
+    target = otgt.ManyWell(D)
+    hmc = oais.HMC(M, D, nf.log_prob, target.log_prob, alpha=float(g["alpha"]), p_target=False, L=int(g["L"]))
+    hmc.epsilons = torch.tensor(g["in_epsilons"])
+    hmc.common_epsilon = torch.tensor(g["in_common_epsilon"])
+    ais = oais.AIS(lambda e: _noq(nf, e), nf.log_prob, target.log_prob, hmc, False, float(g["alpha"]), M)
+    pt, log_w, info = ais.sample_and_log_weights(torch.tensor(g["eps0"]), torch.tensor(g["noise_p"]),
+                                                 torch.tensor(g["noise_e"]), keep_snapshots=True)
+    assert len(ais.snapshots) == M + 1 == g["snap_x"].shape[0]
+    for j, (sp, _) in enumerate(ais.snapshots):
+        assert close(sp.x, g["snap_x"][j], 1e-4), f"snapshot {j}"
+        assert close(sp.log_q, g["snap_log_q"][j], 1e-4) and close(sp.log_p, g["snap_log_p"][j], 1e-4)
+    assert close(pt.x, g["out_x"], 1e-4) and close(log_w, g["log_w"], 1e-4)
+    np.testing.assert_array_equal(hmc.epsilons.numpy(), g["out_epsilons"])
+    np.testing.assert_array_equal(hmc.common_epsilon.numpy(), g["out_common_epsilon"])
+    assert abs(info.ess_ais - float(g["ess_ais"])) <= 0.01 * float(g["ess_ais"])
+    assert abs(info.log_Z - float(g["log_Z"])) <= RTOL * abs(float(g["log_Z"])) + 1e-4
+
+
 def _noq(nf, e):
     with torch.no_grad():
         return nf.sample_eps(e)
