@@ -98,7 +98,8 @@ SYMBOLS = [
     "fabhip_spline_packed_floats", "fabhip_spline_pack", "fabhip_spline_workspace_bytes", "fabhip_spline_log_prob",
     "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
     "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_set_option", "fabhip_get_option", "fabhip_ais_phase", "fabhip_hmc_partials_floats",
-    "fabhip_hmc_adapt_gathered", "fabhip_debug_spline_timeline",
+    "fabhip_hmc_adapt_gathered", "fabhip_spline_hmc_workspace_bytes", "fabhip_spline_hmc_transition",
+    "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_debug_spline_timeline",
 ]
 ABI_VERSION = 205          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 

@@ -69,10 +69,47 @@ class AnnealedImportanceSampler:
         target = _owner(self.target_log_prob, _NativeTarget, "target_log_prob")
         return flow, target
 
+    def _spline_parts(self):
+        """(spline flow, native target) when the fused SPLINE call applies: this package's spline flow as base
+        distribution, a native target, HMC transitions (fabhip_spline_ais_run); else None."""
+        from .spline_flow import CircularCoupledRQSFlow
+        op = self.transition_operator
+        if not isinstance(self.base_distribution, CircularCoupledRQSFlow) or not isinstance(op, HamiltonianMonteCarlo) \
+                or op.force_stepwise:
+            return None
+        target = _owner_or_none(self.target_log_prob, _NativeTarget)
+        return (self.base_distribution, target) if target is not None else None
+
+    def _run_spline(self, batch_size: int, eps0=None, noise_a=None, noise_b=None, want_base: bool = False, u0=None):
+        """`run` for the spline family: ONE op call (torch.ops.fabhip.spline_ais_run).  `eps0` / `u0` [B, D]: the normal /
+        uniform draws of the flow's base sample."""
+        ops = _ops.load()
+        flow, target = self._spline_parts()
+        op = self.transition_operator
+        if bool(op.p_target) != bool(self.p_target) or (not self.p_target and op.alpha != self.alpha):
+            raise _ops.FabhipError("AIS and transition operator disagree on p_target / alpha")
+        dev = flow._tail_bound.device
+        B, D, M = int(batch_size), flow.dim, self.n_intermediate_distributions
+        f32 = dict(dtype=torch.float32, device=dev)
+        u0 = torch.rand((B, D), **f32) if u0 is None else u0.contiguous()
+        eps0 = torch.randn((B, D), **f32) if eps0 is None else eps0.contiguous()
+        noise_a = torch.randn((M, op.n_outer, B, D), **f32) if noise_a is None else noise_a.contiguous()
+        noise_b = torch.empty((M, op.n_outer, B), **f32).exponential_(1.0) if noise_b is None else noise_b.contiguous()
+        alpha = float(self.alpha) if self.alpha is not None else 0.0
+        out = ops.spline_ais_run(*flow.native(), *target.native_target(), [float(b) for b in self.B_space], alpha,
+                                 bool(self.p_target), u0, eps0, noise_a, noise_b, op.epsilons, op.common_epsilon,
+                                 op.mass_vector, op.n_outer, op.L, float(op.max_grad), float(op.target_p_accept),
+                                 not op.eval_mode, op._p_accept_first, op._p_accept_last, op._dist_first, op._dist_last,
+                                 bool(want_base))
+        x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw = out
+        return Point(x, lq, lp, gq, gp), log_w, n_valid, stats, base_x, base_lw
+
     def run(self, batch_size: int, eps0=None, noise_a=None, noise_b=None, want_base: bool = False):
         """Enqueue one AIS call; returns device tensors (Point fields sized [batch_size], log_w, n_valid[2],
         stats[16], base_x, base_log_w) without synchronising.  `want_base`: also return the chains' starting points
         after the "chain init" filtering and their log p - log q (generate_eval_data, ais.py:152-166)."""
+        if self._spline_parts() is not None:
+            return self._run_spline(batch_size, eps0, noise_a, noise_b, want_base)
         ops = _ops.load()
         flow, target = self._native_parts()
         op = self.transition_operator
@@ -185,14 +222,18 @@ class AnnealedImportanceSampler:
         g = lambda t: None if t is None else t[keep].contiguous()      # noqa: E731
         return Point(g(point.x), g(point.log_q), g(point.log_p), g(point.grad_log_q), g(point.grad_log_p)), g(log_w)
 
-    def sample_and_log_weights(self, batch_size: int, logging: bool = True, eps0=None, noise_a=None, noise_b=None
-                               ) -> Tuple[Point, torch.Tensor]:
-        if not self.is_native:
+    def sample_and_log_weights(self, batch_size: int, logging: bool = True, eps0=None, noise_a=None, noise_b=None,
+                               u0=None) -> Tuple[Point, torch.Tensor]:
+        fused_spline = self._spline_parts() is not None
+        if not self.is_native and not fused_spline:
             if eps0 is not None:
                 raise _ops.FabhipError("eps0 is the base noise of a fab_torch_amd RealNVP; a generic base_distribution "
                                        "draws its own samples in sample_and_log_prob")
             return self._sample_generic(batch_size, logging, noise_a, noise_b)
-        point, log_w, n_valid, stats, _, _ = self.run(batch_size, eps0, noise_a, noise_b)
+        if fused_spline:
+            point, log_w, n_valid, stats, _, _ = self._run_spline(batch_size, eps0, noise_a, noise_b, u0=u0)
+        else:
+            point, log_w, n_valid, stats, _, _ = self.run(batch_size, eps0, noise_a, noise_b)
         host = torch.cat([n_valid.float(), stats[:6]]).cpu()          # the single device->host read
         n_init, n_end = int(host[0]), int(host[1])
         if n_init == 0:
@@ -216,13 +257,12 @@ class AnnealedImportanceSampler:
         assert outer_batch_size % inner_batch_size == 0
         n_batches = outer_batch_size // inner_batch_size
         B = inner_batch_size
-        if not self.is_native:
+        if not self.is_native and self._spline_parts() is None:
             bx, blw, ax, alw = [], [], [], []
             for _ in range(n_batches):
                 point, log_w, base = self._sample_generic(B, logging=False, want_base=True, raise_at_end=False)
                 bx.append(base[0]); blw.append(base[1]); ax.append(point.x.detach()); alw.append(log_w)
             return torch.cat(bx), torch.cat(blw), torch.cat(ax), torch.cat(alw)
-        flow, _ = self._native_parts()
         base_x, base_lw, ais_x, ais_lw, counts = [], [], [], [], []
         for i in range(n_batches):
             point, log_w, n_valid, _, bx, blw = self.run(B, want_base=True)

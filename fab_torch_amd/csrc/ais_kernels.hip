@@ -970,14 +970,137 @@ size_t fabhip_ais_workspace_bytes(int64_t B, int32_t dim, int32_t n_inner) {
     return s + 256;
 }
 
-static int compact(const fabhip_ais_args* a, const int* n_in, int* n_out, float* tmp, int* dest, float* extra,
-                   hipStream_t st) {
-    hipLaunchKernelGGL(k_valid_scan, dim3(1), dim3(1024), 0, st, a->point.log_q, a->point.log_p, n_in, (long)a->B,
-                       dest, n_out);
-    CompactK c{make_point_dev(a->point), a->log_w, extra, tmp, dest, n_in, n_out, (long)a->B, a->flow.dim};
-    const int grid = (int)(a->B < 4096 ? a->B : 4096);
+static int compact_rows(const fabhip_point& point, float* log_w, long B, int dim, const int* n_in, int* n_out, float* tmp,
+                        int* dest, float* extra, hipStream_t st) {
+    hipLaunchKernelGGL(k_valid_scan, dim3(1), dim3(1024), 0, st, point.log_q, point.log_p, n_in, B, dest, n_out);
+    CompactK c{make_point_dev(point), log_w, extra, tmp, dest, n_in, n_out, B, dim};
+    const int grid = (int)(B < 4096 ? B : 4096);
     hipLaunchKernelGGL(k_compact_scatter, dim3(grid), dim3(64), 0, st, c);
     hipLaunchKernelGGL(k_compact_copyback, dim3(grid), dim3(64), 0, st, c);
+    return check_launch();
+}
+
+static int compact(const fabhip_ais_args* a, const int* n_in, int* n_out, float* tmp, int* dest, float* extra,
+                   hipStream_t st) {
+    return compact_rows(a->point, a->log_w, (long)a->B, a->flow.dim, n_in, n_out, tmp, dest, extra, st);
+}
+
+// ---- spline flow as base distribution (csrc/spline_kernels.hip) ------------------------------------------------------
+__global__ void k_spline_init_logw(const float* __restrict__ lq, const float* __restrict__ lp, const float* __restrict__ lq0,
+                                   fabhip_anneal an, float* __restrict__ log_w, float* __restrict__ base_log_w, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        log_w[i] = (an.c_q * lq[i] + an.c_p * lp[i]) - lq0[i];              // ais.py:62-64
+        if (base_log_w) base_log_w[i] = lp[i] - lq0[i];                     // ais.py:160
+    }
+}
+
+size_t fabhip_spline_hmc_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B) {
+    return align256(fabhip_generic_workspace_bytes(B, dim)) +
+           align256(fabhip_spline_workspace_bytes(dim, n_layers, hidden, B, 1)) + align256((size_t)B * (3 * dim + 2) * 4) + 256;
+}
+
+int fabhip_spline_hmc_transition(const fabhip_spline_hmc_args* a, fabhip_stream_t stream) {
+    if (!a || !a->flow.packed || !a->noise_p || !a->noise_e || !a->epsilons || !a->common_epsilon || !a->mass ||
+        !a->workspace || a->B < 0 || a->n_outer < 1 || a->L < 1)
+        return FABHIP_EINVAL;
+    FAB_TRY(check_target(&a->target, a->flow.dim));
+    FAB_TRY(check_point(a->point, true));
+    const int D = a->flow.dim;
+    const long B = a->B;
+    if (a->workspace_bytes < fabhip_spline_hmc_workspace_bytes(D, a->flow.n_layers, a->flow.hidden, B)) return FABHIP_ENOSPC;
+    if (B == 0) return FABHIP_OK;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    const size_t gb = fabhip_generic_workspace_bytes(B, D);
+    void* gws = ws; ws += align256(gb);
+    const size_t sb = fabhip_spline_workspace_bytes(D, a->flow.n_layers, a->flow.hidden, B, 1);
+    void* sws = ws; ws += align256(sb);
+    float* pb = (float*)ws;
+    fabhip_point prop{pb, pb + 3 * B * D, pb + 3 * B * D + B, pb + B * D, pb + 2 * B * D};
+    const fabhip_point cur = a->point;
+    fabhip_point start = cur;
+    for (int n = 0; n < a->n_outer; ++n) {
+        FAB_TRY(gen_hmc_begin(&start, &cur, B, D, a->cur, a->noise_p + (size_t)n * B * D, a->mass, a->max_grad, gws, a->n_valid, st));
+        for (int l = 0; l < a->L; ++l) {
+            FAB_TRY(fabhip_hmc_generic_leap_pre(B, D, a->epsilons + n, a->common_epsilon, a->mass, prop.x, gws, gb, stream));
+            FAB_TRY(fabhip_spline_log_prob(&a->flow, prop.x, prop.log_q, prop.grad_log_q, B, sws, sb, stream));
+            FAB_TRY(fabhip_target_log_prob(&a->target, prop.x, prop.log_p, prop.grad_log_p, B, stream));
+            FAB_TRY(fabhip_hmc_generic_leap_post(B, D, prop.grad_log_q, prop.grad_log_p, a->cur, a->max_grad, a->epsilons + n,
+                                                 a->common_epsilon, gws, gb, stream));
+        }
+        const bool last = n + 1 == a->n_outer;
+        FAB_TRY(gen_hmc_accept(&prop, &cur, B, D, a->cur, a->next, last ? a->log_w : nullptr, a->noise_e + (size_t)n * B, a->mass,
+                               a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
+                               a->p_accept ? a->p_accept + n : nullptr, a->avg_distance, gws, a->n_valid, st));
+        start = prop;                                  // the reference continues from the PROPOSAL (hmc.py:133-142)
+    }
+    return FABHIP_OK;
+}
+
+size_t fabhip_spline_ais_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B) {
+    size_t s = align256(fabhip_spline_hmc_workspace_bytes(dim, n_layers, hidden, B));
+    s += align256((size_t)B * (3 * dim + 4) * 4);    // compaction staging
+    s += 3 * align256((size_t)B * 4);                // dest ranks, log_p - log_q, log q of the sampling pass
+    s += align256(fabhip_ess_workspace_bytes(B));
+    return s + 256;
+}
+
+int fabhip_spline_ais_run(const fabhip_spline_ais_args* a, fabhip_stream_t stream) {
+    if (!a || !a->flow.packed || !a->betas || !a->u0 || !a->eps0 || !a->noise_p || !a->noise_e || !a->epsilons ||
+        !a->common_epsilon || !a->mass || !a->log_w || !a->n_valid || !a->stats || !a->workspace || a->B < 1 || a->M < 1 ||
+        a->n_outer < 1 || a->L < 1)
+        return FABHIP_EINVAL;
+    FAB_TRY(check_target(&a->target, a->flow.dim));
+    FAB_TRY(check_point(a->point, true));
+    const int D = a->flow.dim;
+    const long B = a->B;
+    if (a->workspace_bytes < fabhip_spline_ais_workspace_bytes(D, a->flow.n_layers, a->flow.hidden, B)) return FABHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)a->workspace;
+    const size_t tws = align256(fabhip_spline_hmc_workspace_bytes(D, a->flow.n_layers, a->flow.hidden, B));
+    void* trans_ws = ws; ws += tws;
+    float* tmp = (float*)ws; ws += align256((size_t)B * (3 * D + 4) * 4);
+    int* dest = (int*)ws; ws += align256((size_t)B * 4);
+    float* lwb = (float*)ws; ws += align256((size_t)B * 4);
+    float* lq0 = (float*)ws; ws += align256((size_t)B * 4);
+    void* ess_ws = ws;
+    const size_t ess_bytes = fabhip_ess_workspace_bytes(B);
+    // the spline kernels' own scratch: the transition workspace is free until the first transition
+    const size_t sb = fabhip_spline_workspace_bytes(D, a->flow.n_layers, a->flow.hidden, B, 1);
+    // 1. chain initialisation: x, log q0 = flow.sample ; point = create_point(x) ; log_w = pi_beta1(point) - log q0
+    FAB_TRY(fabhip_spline_sample(&a->flow, a->u0, a->eps0, a->point.x, lq0, B, trans_ws, sb, stream));
+    FAB_TRY(fabhip_spline_log_prob(&a->flow, a->point.x, a->point.log_q, a->point.grad_log_q, B, trans_ws, sb, stream));
+    FAB_TRY(fabhip_target_log_prob(&a->target, a->point.x, a->point.log_p, a->point.grad_log_p, B, stream));
+    fabhip_anneal a1;
+    fabhip_anneal_coefs(a->betas[1], a->alpha, a->p_target, &a1);
+    hipLaunchKernelGGL(k_spline_init_logw, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_q, a->point.log_p, lq0,
+                       a1, a->log_w, a->base_log_w, B);
+    // 2. "chain init" filter, 3. base ESS
+    FAB_TRY(compact_rows(a->point, a->log_w, B, D, nullptr, a->n_valid, tmp, dest, a->base_log_w, st));
+    if (a->base_x && hipMemcpyAsync(a->base_x, a->point.x, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return FABHIP_ELAUNCH;
+    hipLaunchKernelGGL(k_sub, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_p, a->point.log_q, lwb, B);
+    FAB_TRY(fabhip_ess_logz(lwb, B, a->n_valid, 1.0, a->stats + 0, ess_ws, ess_bytes, stream));
+    // 4. transitions
+    for (int j = 1; j <= a->M; ++j) {
+        fabhip_spline_hmc_args h;
+        h.flow = a->flow; h.target = a->target; h.point = a->point; h.B = B; h.n_valid = a->n_valid;
+        fabhip_anneal_coefs(a->betas[j], a->alpha, a->p_target, &h.cur);
+        fabhip_anneal_coefs(a->betas[j + 1], a->alpha, a->p_target, &h.next);
+        h.log_w = (a->betas[j + 1] != a->betas[j]) ? a->log_w : nullptr;      // ais.py:93
+        const size_t nslab = (size_t)(j - 1) * a->n_outer;
+        h.noise_p = a->noise_p + nslab * B * D; h.noise_e = a->noise_e + nslab * B;
+        h.epsilons = a->epsilons + nslab; h.common_epsilon = a->common_epsilon; h.mass = a->mass;
+        h.n_outer = a->n_outer; h.L = a->L; h.max_grad = a->max_grad; h.target_p_accept = a->target_p_accept; h.tune = a->tune;
+        h.p_accept = nullptr; h.avg_distance = nullptr;
+        if (j == 1) { h.p_accept = a->p_accept_first; h.avg_distance = a->avg_distance_first; }
+        else if (j == a->M) { h.p_accept = a->p_accept_last; h.avg_distance = a->avg_distance_last; }
+        h.workspace = trans_ws; h.workspace_bytes = tws;
+        FAB_TRY(fabhip_spline_hmc_transition(&h, stream));
+    }
+    // 5. "chain end" filter, 6. ESS / log Z
+    FAB_TRY(compact_rows(a->point, a->log_w, B, D, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, st));
+    FAB_TRY(fabhip_ess_logz(a->log_w, B, a->n_valid + 1, (double)B, a->stats + 3, ess_ws, ess_bytes, stream));
     return check_launch();
 }
 

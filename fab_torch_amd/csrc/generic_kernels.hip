@@ -36,7 +36,8 @@ __global__ __launch_bounds__(256) void k_gen_hmc_begin(long B, int D, const floa
                                                        const float* __restrict__ noise_p, const float* __restrict__ mass,
                                                        fabhip_anneal c, float max_grad, float* __restrict__ XP,
                                                        float* __restrict__ P, float* __restrict__ GU,
-                                                       float* __restrict__ logp_cur) {
+                                                       float* __restrict__ logp_cur, const int* __restrict__ n_valid) {
+    if (n_valid) B = *n_valid < B ? *n_valid : B;           // (fused AIS calls: rows in use after the "chain init" filter)
     const long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int cc = threadIdx.x & 15;
     float k0 = 0.f;
@@ -89,6 +90,7 @@ struct GenAccK {
     fabhip_anneal c, nx;
     float* log_w;                                                   // nullptr: no AIS increment in this outer step
     float *part_acc, *part_dist;                                    // [gridDim.x]
+    const int* n_valid;                                             // device scalar: rows in use (nullptr: B)
 };
 
 __global__ __launch_bounds__(256) void k_gen_hmc_accept(GenAccK a) {
@@ -96,7 +98,8 @@ __global__ __launch_bounds__(256) void k_gen_hmc_accept(GenAccK a) {
     const int r = threadIdx.x >> 4, cc = threadIdx.x & 15;
     const long g = (long)blockIdx.x * 16 + r;
     const int D = a.D;
-    const bool active = g < a.B;
+    const long nv = a.n_valid ? (*a.n_valid < a.B ? (long)*a.n_valid : a.B) : a.B;
+    const bool active = g < nv;
     float k1 = 0.f, dist2 = 0.f;
     if (active) {
         for (int j = cc; j < D; j += 16) {
@@ -146,7 +149,8 @@ __global__ __launch_bounds__(256) void k_gen_hmc_accept(GenAccK a) {
 // step-size adaptation (hmc.py:122-123,162-170), same fixed-order reduction as the fused path's k_hmc_adapt
 __global__ void k_gen_hmc_adapt(const float* __restrict__ part_acc, const float* __restrict__ part_dist, int nblk, long B,
                                 float* eps_ptr, float* ceps_ptr, float target_p_accept, int tune, float* p_accept_out,
-                                float* dist_out) {
+                                float* dist_out, const int* __restrict__ n_valid) {
+    if (n_valid) B = *n_valid < B ? *n_valid : B;
     if (threadIdx.x != 0 || blockIdx.x != 0 || B <= 0) return;
     float s = 0.f, d = 0.f;
     for (int i = 0; i < nblk; ++i) { s += part_acc[i]; d += part_dist[i]; }
@@ -227,6 +231,46 @@ __global__ void k_gen_met_adapt(const float* __restrict__ part_acc, int nblk, lo
 static inline int ew_grid(long n) { long g = (n + 255) / 256; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 static inline int row_blocks(long B) { return (int)((B + 15) / 16); }
 
+static void split_ws(void* ws, long B, int D, float*& XP, float*& P, float*& GU, float*& row, float*& pa, float*& pd) {
+    float* w = (float*)ws;
+    XP = w; w += B * D;
+    P = w; w += B * D;
+    GU = w; w += B * D;
+    row = w; w += B;
+    pa = w; w += row_blocks(B);
+    pd = w;
+}
+
+// begin / accept with the row count read on the device (launch.h): the fused spline AIS call (ais_kernels.hip) keeps
+// fixed-size buffers after the "chain init" filter, like fabhip_ais_run
+int gen_hmc_begin(const fabhip_point* start, const fabhip_point* cur, long B, int dim, fabhip_anneal c, const float* noise_p,
+                  const float* mass, float max_grad, void* workspace, const int* n_valid, hipStream_t st) {
+    float *XP, *P, *GU, *row, *pa, *pd;
+    split_ws(workspace, B, dim, XP, P, GU, row, pa, pd);
+    hipLaunchKernelGGL(k_gen_hmc_begin, dim3(row_blocks(B)), dim3(256), 0, st, B, dim, start->x, start->grad_log_q,
+                       start->grad_log_p, cur->log_q, cur->log_p, noise_p, mass, c, max_grad, XP, P, GU, row, n_valid);
+    return check_launch();
+}
+
+int gen_hmc_accept(const fabhip_point* prop, const fabhip_point* cur, long B, int dim, fabhip_anneal c, fabhip_anneal next,
+                   float* log_w, const float* noise_e, const float* mass, float* eps_ptr, float* ceps_ptr,
+                   float target_p_accept, int tune, float* p_accept, float* avg_distance, void* workspace,
+                   const int* n_valid, hipStream_t st) {
+    float *XP, *P, *GU, *row, *pa, *pd;
+    split_ws(workspace, B, dim, XP, P, GU, row, pa, pd);
+    GenAccK a;
+    a.B = B; a.D = dim; a.XP = XP; a.P = P;
+    a.prop_lq = prop->log_q; a.prop_lp = prop->log_p; a.prop_gq = prop->grad_log_q; a.prop_gp = prop->grad_log_p;
+    a.cur_x = cur->x; a.cur_lq = cur->log_q; a.cur_lp = cur->log_p; a.cur_gq = cur->grad_log_q; a.cur_gp = cur->grad_log_p;
+    a.logp_cur = row; a.noise_e = noise_e; a.mass = mass; a.c = c; a.nx = next; a.log_w = log_w;
+    a.part_acc = pa; a.part_dist = pd; a.n_valid = n_valid;
+    const int nblk = row_blocks(B);
+    hipLaunchKernelGGL(k_gen_hmc_accept, dim3(nblk), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_gen_hmc_adapt, dim3(1), dim3(64), 0, st, pa, pd, nblk, B, eps_ptr, ceps_ptr, target_p_accept, tune,
+                       p_accept, avg_distance, n_valid);
+    return check_launch();
+}
+
 }  // namespace fab
 
 using namespace fab;
@@ -239,16 +283,6 @@ size_t fabhip_generic_workspace_bytes(int64_t B, int32_t dim) {
     return ((size_t)3 * B * dim + B + 2 * nblk) * sizeof(float) + 1024;
 }
 
-static void split_ws(void* ws, long B, int D, float*& XP, float*& P, float*& GU, float*& row, float*& pa, float*& pd) {
-    float* w = (float*)ws;
-    XP = w; w += B * D;
-    P = w; w += B * D;
-    GU = w; w += B * D;
-    row = w; w += B;
-    pa = w; w += row_blocks(B);
-    pd = w;
-}
-
 int fabhip_hmc_generic_begin(const fabhip_point* start, const fabhip_point* cur, int64_t B, int32_t dim,
                              fabhip_anneal c, const float* noise_p, const float* mass, float max_grad,
                              void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
@@ -257,12 +291,7 @@ int fabhip_hmc_generic_begin(const fabhip_point* start, const fabhip_point* cur,
         return FABHIP_EINVAL;
     if (workspace_bytes < fabhip_generic_workspace_bytes(B, dim)) return FABHIP_ENOSPC;
     if (B == 0) return FABHIP_OK;
-    float *XP, *P, *GU, *row, *pa, *pd;
-    split_ws(workspace, (long)B, dim, XP, P, GU, row, pa, pd);
-    hipLaunchKernelGGL(k_gen_hmc_begin, dim3(row_blocks(B)), dim3(256), 0, (hipStream_t)stream, (long)B, (int)dim,
-                       start->x, start->grad_log_q, start->grad_log_p, cur->log_q, cur->log_p, noise_p, mass, c, max_grad,
-                       XP, P, GU, row);
-    return check_launch();
+    return gen_hmc_begin(start, cur, (long)B, dim, c, noise_p, mass, max_grad, workspace, nullptr, (hipStream_t)stream);
 }
 
 int fabhip_hmc_generic_leap_pre(int64_t B, int32_t dim, const float* eps_ptr, const float* ceps_ptr, const float* mass,
@@ -303,20 +332,8 @@ int fabhip_hmc_generic_accept(const fabhip_point* prop, const fabhip_point* cur,
         return FABHIP_EINVAL;
     if (workspace_bytes < fabhip_generic_workspace_bytes(B, dim)) return FABHIP_ENOSPC;
     if (B == 0) return FABHIP_OK;
-    float *XP, *P, *GU, *row, *pa, *pd;
-    split_ws(workspace, (long)B, dim, XP, P, GU, row, pa, pd);
-    GenAccK a;
-    a.B = B; a.D = dim; a.XP = XP; a.P = P;
-    a.prop_lq = prop->log_q; a.prop_lp = prop->log_p; a.prop_gq = prop->grad_log_q; a.prop_gp = prop->grad_log_p;
-    a.cur_x = cur->x; a.cur_lq = cur->log_q; a.cur_lp = cur->log_p; a.cur_gq = cur->grad_log_q; a.cur_gp = cur->grad_log_p;
-    a.logp_cur = row; a.noise_e = noise_e; a.mass = mass; a.c = c; a.nx = next; a.log_w = log_w;
-    a.part_acc = pa; a.part_dist = pd;
-    hipStream_t st = (hipStream_t)stream;
-    const int nblk = row_blocks(B);
-    hipLaunchKernelGGL(k_gen_hmc_accept, dim3(nblk), dim3(256), 0, st, a);
-    hipLaunchKernelGGL(k_gen_hmc_adapt, dim3(1), dim3(64), 0, st, pa, pd, nblk, (long)B, eps_ptr, ceps_ptr,
-                       target_p_accept, (int)tune, p_accept, avg_distance);
-    return check_launch();
+    return gen_hmc_accept(prop, cur, (long)B, dim, c, next, log_w, noise_e, mass, eps_ptr, ceps_ptr, target_p_accept, (int)tune,
+                          p_accept, avg_distance, workspace, nullptr, (hipStream_t)stream);
 }
 
 int fabhip_anneal_log_prob(const float* log_q, const float* log_p, int64_t n, fabhip_anneal c, float* out,

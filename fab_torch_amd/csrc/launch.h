@@ -14,6 +14,13 @@ namespace fab {
 int fast_mode();
 // developer switches (fabhip_set_option; flow_kernels.hip): one int load, initialised from the environment at load time
 int option(int key);
+// generic HMC pieces with the row count on the device (generic_kernels.hip; used by the fused spline AIS call)
+int gen_hmc_begin(const fabhip_point* start, const fabhip_point* cur, long B, int dim, fabhip_anneal c, const float* noise_p,
+                  const float* mass, float max_grad, void* workspace, const int* n_valid, hipStream_t st);
+int gen_hmc_accept(const fabhip_point* prop, const fabhip_point* cur, long B, int dim, fabhip_anneal c, fabhip_anneal next,
+                   float* log_w, const float* noise_e, const float* mass, float* eps_ptr, float* ceps_ptr,
+                   float target_p_accept, int tune, float* p_accept, float* avg_distance, void* workspace,
+                   const int* n_valid, hipStream_t st);
 
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
 

@@ -582,38 +582,68 @@ void spline_hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, 
     if (p_accept.has_value()) need_n(*p_accept, n_outer, x, "p_accept", true);
     if (avg_distance.has_value()) need_n(*avg_distance, 1, x, "avg_distance", true);
     if (B == 0) return;
-    const fabhip_stream_t st = stream_of(x);
-    Tensor ws = generic_workspace(x, B, D);
-    const size_t sb = fabhip_spline_workspace_bytes(f.dim, f.n_layers, f.hidden, B, 1);
-    Tensor sws = scratch(sb, x);
-    Tensor xn = at::empty_like(x), gq = at::empty_like(x), gp = at::empty_like(x), lq = fempty({B}, x), lp = fempty({B}, x);
-    const fabhip_anneal c = coefs(beta, alpha, p_target), cn = coefs(beta_next, alpha, p_target);
-    fabhip_point cur{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), fpm(grad_log_q, "grad_log_q"),
-                     fpm(grad_log_p, "grad_log_p")};
-    fabhip_point start = cur;
-    fabhip_point prop{xn.data_ptr<float>(), lq.data_ptr<float>(), lp.data_ptr<float>(), gq.data_ptr<float>(),
-                      gp.data_ptr<float>()};
-    float* eps = fpm(eps_row, "epsilons"); float* ce = fpm(ceps, "common_epsilon");
-    const float* ms = fp(mass, "mass");
-    for (int64_t n = 0; n < n_outer; ++n) {
-        chk(fabhip_hmc_generic_begin(&start, &cur, B, (int32_t)D, c, fp(noise_p, "noise_p") + n * B * D, ms,
-                                     (float)max_grad, fpm(ws, "workspace"), ws_bytes(ws), st), "hmc_generic_begin");
-        for (int64_t l = 0; l < n_leap; ++l) {
-            chk(fabhip_hmc_generic_leap_pre(B, (int32_t)D, eps + n, ce, ms, prop.x, fpm(ws, "workspace"), ws_bytes(ws), st),
-                "hmc_generic_leap_pre");
-            chk(fabhip_spline_log_prob(&f, prop.x, prop.log_q, prop.grad_log_q, B, aligned(sws), sb, st), "spline_log_prob");
-            chk(fabhip_target_log_prob(&tg, prop.x, prop.log_p, prop.grad_log_p, B, st), "target_log_prob");
-            chk(fabhip_hmc_generic_leap_post(B, (int32_t)D, prop.grad_log_q, prop.grad_log_p, c, (float)max_grad, eps + n, ce,
-                                             fpm(ws, "workspace"), ws_bytes(ws), st), "hmc_generic_leap_post");
-        }
-        const bool last = n + 1 == n_outer;
-        chk(fabhip_hmc_generic_accept(&prop, &cur, B, (int32_t)D, c, cn, last ? fpm_opt(log_w, "log_w") : nullptr,
-                                      fp(noise_e, "noise_e") + n * B, ms, eps + n, ce, (float)target_p_accept, tune ? 1 : 0,
-                                      p_accept.has_value() ? fpm(*p_accept, "p_accept") + n : nullptr,
-                                      fpm_opt(avg_distance, "avg_distance"), fpm(ws, "workspace"), ws_bytes(ws), st),
-            "hmc_generic_accept");
-        start = prop;                                  // the reference continues from the PROPOSAL (hmc.py:133-142)
-    }
+    fabhip_spline_hmc_args a;
+    a.flow = f; a.target = tg;
+    a.point = fabhip_point{fpm(x, "x"), fpm(log_q, "log_q"), fpm(log_p, "log_p"), fpm(grad_log_q, "grad_log_q"),
+                           fpm(grad_log_p, "grad_log_p")};
+    a.B = B; a.n_valid = nullptr;
+    a.cur = coefs(beta, alpha, p_target); a.next = coefs(beta_next, alpha, p_target);
+    a.log_w = fpm_opt(log_w, "log_w");
+    a.noise_p = fp(noise_p, "noise_p"); a.noise_e = fp(noise_e, "noise_e");
+    a.epsilons = fpm(eps_row, "epsilons"); a.common_epsilon = fpm(ceps, "common_epsilon"); a.mass = fp(mass, "mass");
+    a.n_outer = (int32_t)n_outer; a.L = (int32_t)n_leap; a.max_grad = (float)max_grad;
+    a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
+    a.p_accept = fpm_opt(p_accept, "p_accept"); a.avg_distance = fpm_opt(avg_distance, "avg_distance");
+    const size_t nb = fabhip_spline_hmc_workspace_bytes(f.dim, f.n_layers, f.hidden, B);
+    Tensor ws = scratch(nb, x);
+    a.workspace = aligned(ws); a.workspace_bytes = nb;
+    chk(fabhip_spline_hmc_transition(&a, stream_of(x)), "spline_hmc_transition");
+}
+
+// The spline family's ais_run (fabhip_spline_ais_run): same outputs as ais_run.
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> spline_ais_run(
+    const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden, int64_t kind, at::ArrayRef<double> prm,
+    const optional<Tensor>& locs, const optional<Tensor>& scales, at::ArrayRef<double> betas, double alpha, bool p_target,
+    const Tensor& u0, const Tensor& eps0, const Tensor& noise_p, const Tensor& noise_e, Tensor epsilons, Tensor common_epsilon,
+    const Tensor& mass, int64_t n_outer, int64_t L, double max_grad, double target_p_accept, bool tune,
+    optional<Tensor> p_accept_first, optional<Tensor> p_accept_last, optional<Tensor> avg_distance_first,
+    optional<Tensor> avg_distance_last, bool want_base) {
+    c10::DeviceGuard g(eps0.device());
+    fabhip_spline_ais_args a;
+    a.flow = make_spline(packed, dim, n_layers, hidden);
+    a.target = make_target(kind, prm, locs, scales, dim);
+    TORCH_CHECK(eps0.dim() == 2 && eps0.size(1) == dim, "fabhip: eps0 must be [B, dim]");
+    const int64_t B = eps0.size(0), M = (int64_t)betas.size() - 2;
+    TORCH_CHECK(M >= 1 && n_outer >= 1 && L >= 1, "fabhip: spline_ais_run needs M, n_outer, L >= 1");
+    a.B = B; a.M = (int32_t)M;
+    std::vector<double> bt(betas.begin(), betas.end());
+    a.betas = bt.data(); a.alpha = alpha; a.p_target = p_target ? 1 : 0;
+    a.u0 = fpn(u0, B * dim, eps0, "u0"); a.eps0 = fp(eps0, "eps0");
+    a.noise_p = fpn(noise_p, M * n_outer * B * dim, eps0, "noise_p"); a.noise_e = fpn(noise_e, M * n_outer * B, eps0, "noise_e");
+    a.epsilons = fpmn(epsilons, M * n_outer, eps0, "epsilons");
+    a.common_epsilon = fpmn(common_epsilon, 1, eps0, "common_epsilon", true);
+    a.mass = fpn(mass, dim, eps0, "mass");
+    a.n_outer = (int32_t)n_outer; a.L = (int32_t)L; a.max_grad = (float)max_grad;
+    a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
+    Tensor x = fempty({B, dim}, eps0), lq = fempty({B}, eps0), lp = fempty({B}, eps0), log_w = fempty({B}, eps0);
+    Tensor gq = fempty({B, dim}, eps0), gp = fempty({B, dim}, eps0);
+    Tensor n_valid = at::zeros({2}, eps0.options().dtype(at::kInt)), stats = at::zeros({16}, eps0.options());
+    Tensor base_x = want_base ? fempty({B, dim}, eps0) : fempty({0}, eps0);
+    Tensor base_lw = want_base ? fempty({B}, eps0) : fempty({0}, eps0);
+    a.point = fabhip_point{x.data_ptr<float>(), lq.data_ptr<float>(), lp.data_ptr<float>(), gq.data_ptr<float>(),
+                           gp.data_ptr<float>()};
+    a.log_w = log_w.data_ptr<float>(); a.n_valid = n_valid.data_ptr<int32_t>(); a.stats = stats.data_ptr<float>();
+    a.p_accept_first = fpmn_opt(p_accept_first, n_outer, eps0, "p_accept_first", true);
+    a.p_accept_last = fpmn_opt(p_accept_last, n_outer, eps0, "p_accept_last", true);
+    a.avg_distance_first = fpmn_opt(avg_distance_first, 1, eps0, "avg_distance_first", true);
+    a.avg_distance_last = fpmn_opt(avg_distance_last, 1, eps0, "avg_distance_last", true);
+    a.base_x = want_base ? base_x.data_ptr<float>() : nullptr;
+    a.base_log_w = want_base ? base_lw.data_ptr<float>() : nullptr;
+    const size_t nb = fabhip_spline_ais_workspace_bytes(a.flow.dim, a.flow.n_layers, a.flow.hidden, B);
+    Tensor ws = scratch(nb, eps0);
+    a.workspace = aligned(ws); a.workspace_bytes = nb;
+    chk(fabhip_spline_ais_run(&a, stream_of(eps0)), "spline_ais_run");
+    return {x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw};
 }
 
 Tensor anneal_log_prob(const Tensor& log_q, const Tensor& log_p, double beta, double alpha, bool p_target) {
@@ -961,6 +991,11 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(e!) grad_log_p, Tensor(f!)? log_w, float beta, float beta_next, float alpha, bool p_target, Tensor noise_p, "
           "Tensor noise_e, Tensor(g!) eps_row, Tensor(h!) ceps, Tensor mass, int n_outer, int n_leap, float max_grad, "
           "float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance) -> ()");
+    m.def("spline_ais_run(Tensor packed, int dim, int n_layers, int hidden, " TGT ", float[] betas, float alpha, bool p_target, "
+          "Tensor u0, Tensor eps0, Tensor noise_p, Tensor noise_e, Tensor(a!) epsilons, Tensor(b!) common_epsilon, Tensor mass, "
+          "int n_outer, int L, float max_grad, float target_p_accept, bool tune, Tensor(c!)? p_accept_first, "
+          "Tensor(d!)? p_accept_last, Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base) -> "
+          "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("anneal_log_prob(Tensor log_q, Tensor log_p, float beta, float alpha, bool p_target) -> Tensor");
     m.def("log_w_update(Tensor log_q, Tensor log_p, float beta, float beta_next, float alpha, bool p_target, "
           "Tensor(a!) log_w) -> ()");
@@ -999,6 +1034,7 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("metropolis_transition", metropolis_transition);
     m.impl("ais_run", ais_run);
     m.impl("ais_phase", ais_phase);
+    m.impl("spline_ais_run", spline_ais_run);
     m.impl("hmc_adapt_gathered", hmc_adapt_gathered);
     m.impl("generic_workspace", generic_workspace);
     m.impl("hmc_generic_begin", hmc_generic_begin);

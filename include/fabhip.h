@@ -467,6 +467,78 @@ int fabhip_ais_phase(const fabhip_ais_args* args, int32_t phases, int32_t j_begi
                      fabhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * The same with the RQ-spline flow (fabhip_spline_*) as base distribution
+ * ---------------------------------------------------------------------------------------- */
+/* One HMC transition (hmc.py:129-160: n_outer x (momentum refresh, L leapfrogs, Metropolis test, in-place commit,
+ * step-size adaptation) + the AIS log-weight increment when log_w != NULL) with the SPLINE flow as base distribution and a
+ * native target, enqueued by one host call: per leapfrog the generic element-wise kernels, the one-launch spline density +
+ * gradient kernel and the target kernel.  Same argument meaning as fabhip_hmc_args; `n_valid` (device scalar, may be
+ * NULL) = rows in use.  workspace: fabhip_spline_hmc_workspace_bytes. */
+typedef struct {
+    fabhip_spline_flow flow;
+    fabhip_target target;
+    fabhip_point point;     /* in/out */
+    int64_t B;
+    const int32_t* n_valid;
+    fabhip_anneal cur, next;
+    float* log_w;
+    const float* noise_p;   /* [n_outer][B][dim] */
+    const float* noise_e;   /* [n_outer][B]      */
+    float* epsilons;        /* -> epsilons[i-1][0..n_outer) */
+    float* common_epsilon;
+    const float* mass;
+    int32_t n_outer, L;
+    float max_grad, target_p_accept;
+    int32_t tune;
+    float* p_accept;        /* [n_outer] or NULL */
+    float* avg_distance;    /* [1] or NULL       */
+    void* workspace;
+    size_t workspace_bytes;
+} fabhip_spline_hmc_args;
+size_t fabhip_spline_hmc_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B);
+int fabhip_spline_hmc_transition(const fabhip_spline_hmc_args* args, fabhip_stream_t stream);
+
+/* AnnealedImportanceSampler.sample_and_log_weights (ais.py:53-105) with the spline flow as base distribution, a native
+ * target and HMC transitions - the spline family's fabhip_ais_run: flow sample, point creation (log q re-evaluated
+ * through log_prob, base.py:65-68), initial log-weights, "chain init" filter, base ESS, M transitions, "chain end"
+ * filter, ESS / log Z, enqueued by ONE host call without host synchronisation.  u0 / eps0 [B][dim]: the uniforms /
+ * normals of the flow's base sample (fabhip_spline_sample); everything else as in fabhip_ais_args. */
+typedef struct {
+    fabhip_spline_flow flow;
+    fabhip_target target;
+    int64_t B;
+    int32_t M;
+    const double* betas;
+    double alpha;
+    int32_t p_target;
+    const float* u0;
+    const float* eps0;
+    const float* noise_p;   /* [M][n_outer][B][dim] */
+    const float* noise_e;   /* [M][n_outer][B]      */
+    float* epsilons;        /* [M][n_outer]         */
+    float* common_epsilon;
+    const float* mass;
+    int32_t n_outer, L;
+    float max_grad, target_p_accept;
+    int32_t tune;
+    fabhip_point point;     /* out */
+    float* log_w;
+    int32_t* n_valid;       /* out device int32[2] */
+    float* stats;           /* out device float[16], layout of fabhip_ais_args.stats */
+    float* p_accept_first;
+    float* p_accept_last;
+    float* avg_distance_first;
+    float* avg_distance_last;
+    float* base_x;          /* optional, see fabhip_ais_args */
+    float* base_log_w;
+    void* workspace;
+    size_t workspace_bytes;
+} fabhip_spline_ais_args;
+size_t fabhip_spline_ais_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B);
+int fabhip_spline_ais_run(const fabhip_spline_ais_args* args, fabhip_stream_t stream);
+
+
+/* ------------------------------------------------------------------------------------------
  * ESS / log Z  (fab/utils/numerical.py:18-23, fab/sampling_methods/ais.py:80-86)
  * out[0] = normalised ESS of log_w[0..n), out[1] = logsumexp(log_w) - log(n_norm), out[2] = n used.
  * n is read from n_ptr (device) when n_ptr != NULL.

@@ -438,3 +438,42 @@ def test_host_fused_spline_transition_equals_the_step_by_step_generic_path(monke
         assert torch.equal(a, b)
     assert res["fused"][6] == res["stepwise"][6]
     assert not torch.equal(res["fused"][3], torch.zeros(B, device=DEV))
+
+
+@pytest.mark.parametrize("D,L,hidden,circ,B,n_outer", [(8, 3, 64, (1, 6), 200, 1), (32, 4, 256, (), 130, 2)])
+def test_fused_spline_ais_call_equals_the_step_by_step_generic_path(monkeypatch, D, L, hidden, circ, B, n_outer):
+    """`fabhip_spline_ais_run` (flow sample, point creation, initial weights, "chain init" filter, base ESS,
+    M HMC transitions, "chain end" filter, ESS / log Z in ONE op call, like fabhip_ais_run for the RealNVP family) against the
+    reference's loop stepped from Python over the same kernels (`_sample_generic`): particles, log-weights, adapted step sizes
+    and the logging scalars bit for bit; a chain whose flow sample is non-finite is dropped by both."""
+    M, LF = 4, 3
+    tb = torch.full((D,), 5.0)
+    if circ:
+        tb[list(circ)] = math.pi
+    torch.manual_seed(0)
+    hf = fa.make_wrapped_normflow_spline(D, L, hidden, circ, tb).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    g = torch.Generator(device=DEV).manual_seed(9)
+    na = torch.randn(M, n_outer, B, D, device=DEV, generator=g)
+    nb = torch.empty(M, n_outer, B, device=DEV).exponential_(generator=g)
+    res = {}
+    for mode in ("fused", "stepwise"):
+        monkeypatch.setattr(fa.HamiltonianMonteCarlo, "force_stepwise", mode == "stepwise")
+        hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.15, L=LF,
+                                       n_outer=n_outer).to(DEV)
+        ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, M)
+        assert (ais._spline_parts() is not None) == (mode == "fused")
+        torch.manual_seed(21)                               # the flow's base draws: u = rand, eps = randn, in that order
+        pt, lw = ais.sample_and_log_weights(B, noise_a=na, noise_b=nb)
+        res[mode] = (pt.x.clone(), pt.log_q.clone(), pt.log_p.clone(), pt.grad_log_q.clone(), lw.clone(),
+                     hmc.epsilons.clone(), hmc.common_epsilon.clone(), ais.get_logging_info())
+    for a, b in zip(res["fused"][:7], res["stepwise"][:7]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    fi, si = res["fused"][7], res["stepwise"][7]
+    assert fi.keys() == si.keys()
+    for k in fi:
+        assert abs(fi[k] - si[k]) <= 1e-6 * max(1.0, abs(si[k])), (k, fi[k], si[k])
+    assert res["fused"][0].shape[0] == B and not torch.equal(res["fused"][5], torch.full_like(res["fused"][5], 0.15 * 0.9))
