@@ -27,7 +27,11 @@ class FlowParams(C.Structure):
 
 
 class Flow(C.Structure):
-    _fields_ = [("dim", C.c_int32), ("n_layers", C.c_int32), ("width", C.c_int32), ("packed", C.c_void_p)]
+    _fields_ = [("dim", C.c_int32), ("n_layers", C.c_int32), ("width", C.c_int32), ("precision", C.c_int32),
+                ("packed", C.c_void_p)]
+
+    def __init__(self, dim=0, n_layers=0, width=0, packed=None, precision=0):      # (positional order of the old 4-field struct)
+        super().__init__(dim, n_layers, width, precision, packed)
 
 
 class Target(C.Structure):
@@ -101,7 +105,7 @@ SYMBOLS = [
     "fabhip_hmc_adapt_gathered", "fabhip_spline_hmc_workspace_bytes", "fabhip_spline_hmc_transition",
     "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_debug_spline_timeline",
 ]
-ABI_VERSION = 205          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 206          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):

@@ -14,10 +14,22 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 205          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+ABI_VERSION = 206          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
 TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
+PRECISION_DEFAULT, PRECISION_FP32, PRECISION_FAST = 0, 1, 2          # FABHIP_PRECISION_* (per-call fast mode)
+
+
+def precision_of(flow) -> int:
+    """FABHIP_PRECISION_* of a flow module: its `precision` attribute (None: the process default of `fast_mode`,
+    "fp32" / "fast": this flow's calls override it)."""
+    p = getattr(flow, "precision", None)
+    if p is None:
+        return PRECISION_DEFAULT
+    if p in ("fp32", "fast"):
+        return PRECISION_FP32 if p == "fp32" else PRECISION_FAST
+    raise FabhipError(f"flow.precision must be None, 'fp32' or 'fast' (got {p!r})")
 # developer / test switches of include/fabhip.h (fabhip_set_option)
 OPT_TILE_SHAPE, OPT_R4_STREAM, OPT_SCAN_VARIANT, OPT_SYSTEMATIC_VARIANT, OPT_SPLINE_STAGED, OPT_TIMELINE = range(6)
 

@@ -100,7 +100,7 @@ class AnnealedImportanceSampler:
                                  bool(self.p_target), u0, eps0, noise_a, noise_b, op.epsilons, op.common_epsilon,
                                  op.mass_vector, op.n_outer, op.L, float(op.max_grad), float(op.target_p_accept),
                                  not op.eval_mode, op._p_accept_first, op._p_accept_last, op._dist_first, op._dist_last,
-                                 bool(want_base))
+                                 bool(want_base), _ops.precision_of(flow))
         x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw = out
         return Point(x, lq, lp, gq, gp), log_w, n_valid, stats, base_x, base_lw
 
@@ -139,12 +139,13 @@ class AnnealedImportanceSampler:
                               _ops.TRANSITION_HMC, eps0, noise_a, noise_b, op.epsilons, op.common_epsilon,
                               op.mass_vector, n_inner, op.L, float(op.max_grad), float(op.target_p_accept),
                               not op.eval_mode, op._p_accept_first, op._p_accept_last, op._dist_first, op._dist_last,
-                              bool(want_base))
+                              bool(want_base), _ops.precision_of(flow))
         else:
             out = ops.ais_run(*flow.native(), *target.native_target(), betas, alpha, bool(self.p_target),
                               _ops.TRANSITION_METROPOLIS, eps0, noise_a, noise_b, op.noise_scalings, None, None,
                               n_inner, 0, 0.0, float(op.target_prob_accept),
-                              bool(op.adjust_step_size and not op.eval_mode), None, None, None, None, bool(want_base))
+                              bool(op.adjust_step_size and not op.eval_mode), None, None, None, None, bool(want_base),
+                              _ops.precision_of(flow))
         x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw = out
         point = Point(x, lq, lp, gq if hmc else None, gp if hmc else None)
         return point, log_w, n_valid, stats, base_x, base_lw

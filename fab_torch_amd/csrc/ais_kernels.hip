@@ -715,7 +715,7 @@ static int launch_create_point(const FlowDims& f, const float* packed, const Tar
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid(nblk_of(B)), block(NTHREADS);
     if (with_grad) {
-        if (fast_mode()) {
+        if (f.fast) {
             FAB_TRY(set_max_lds((const void*)k_create_point_fast<NTWM, true>, bytes));
             hipLaunchKernelGGL((k_create_point_fast<NTWM, true>), grid, block, bytes, st, f, l, x, packed, tg, pt, B);
             return check_launch();
@@ -738,7 +738,7 @@ static int launch_ais_init(const FlowDims& f, const float* packed, const TargetD
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid(nblk_of(B)), block(NTHREADS);
     if (with_grad) {
-        if (fast_mode()) {
+        if (f.fast) {
             FAB_TRY(set_max_lds((const void*)k_ais_init_fast<NTWM>, bytes));
             hipLaunchKernelGGL((k_ais_init_fast<NTWM>), grid, block, bytes, st, f, l, x, packed, tg, eps0, pt, log_w, base_log_w, an, B);
             return check_launch();
@@ -757,7 +757,7 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
     const FlowLds l = make_flow_lds(f, true);
     const ExtraLds x = make_extra_lds(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
-    if (fast_mode()) {
+    if (f.fast) {
         FAB_TRY(set_max_lds((const void*)k_hmc_step_fast<NTWM>, bytes));
         hipLaunchKernelGGL((k_hmc_step_fast<NTWM>), dim3(nblk_of(a.B)), dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);
         return check_launch();
@@ -769,8 +769,8 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
 
 // 4-chain tiles pay when 16-chain tiles cannot fill the chip: up to 288 workgroups of 4 chains (B <= 1152); off in fast
 // mode (no bf16 variant of the 4-chain kernel).  FABHIP_OPT_TILE_SHAPE = 16 / 4 forces the choice (tests exercise both).
-static bool use_r4_tiles(long B) {
-    if (fast_mode()) return false;
+static bool use_r4_tiles(const FlowDims& f, long B) {
+    if (f.fast) return false;
     const int shape = option(FABHIP_OPT_TILE_SHAPE);
     if (shape == 16) return false;
     if (shape == 4) return true;
@@ -816,7 +816,7 @@ static int launch_metropolis(const FlowDims& f, const float* packed, const Targe
 }
 
 static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
-    const FlowDims f = make_flow_dims(a->flow.dim, a->flow.n_layers, a->flow.width);
+    const FlowDims f = flow_dims_of(a->flow);
     const TargetDev tg = make_target_dev(a->target);
     const int D = f.D;
     const int nblk = nblk_of(a->B);
@@ -827,7 +827,7 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
     float* part_dist = (float*)ws; ws += align256((size_t)nblk * 4);
     float* row_acc = (float*)ws; ws += align256((size_t)nblk * ROWS * 4);
     float* row_dist = (float*)ws; ws += align256((size_t)nblk * ROWS * 4);
-    const bool r4 = use_r4_tiles(a->B);
+    const bool r4 = use_r4_tiles(f, a->B);
     PointDev prop{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (a->n_outer > 1) {
         float* pb = (float*)ws;
@@ -859,7 +859,7 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
 }
 
 static int metropolis_transition_impl(const fabhip_metropolis_args* a, hipStream_t st) {
-    const FlowDims f = make_flow_dims(a->flow.dim, a->flow.n_layers, a->flow.width);
+    const FlowDims f = flow_dims_of(a->flow);
     const TargetDev tg = make_target_dev(a->target);
     const int nblk = nblk_of(a->B);
     if (a->workspace_bytes < fabhip_metropolis_workspace_bytes(a->B, f.D, a->n_updates)) return FABHIP_ENOSPC;
@@ -907,7 +907,7 @@ int fabhip_create_point(const fabhip_flow* flow, const fabhip_target* target, co
     FAB_TRY(check_target(target, flow->dim));
     FAB_TRY(check_point(*point, with_grad != 0));
     if (B == 0) return FABHIP_OK;
-    const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    const FlowDims f = flow_dims_of(*flow);
     FAB_DISPATCH_NTW(f, launch_create_point, f, flow->packed, make_target_dev(*target), make_point_dev(*point),
                      with_grad, (long)B, (hipStream_t)stream);
 }
@@ -1126,7 +1126,7 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     FAB_TRY(check_point(a->point, hmc));
     if (a->workspace_bytes < fabhip_ais_workspace_bytes(a->B, a->flow.dim, a->n_inner)) return FABHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
-    const FlowDims f = make_flow_dims(a->flow.dim, a->flow.n_layers, a->flow.width);
+    const FlowDims f = flow_dims_of(a->flow);
     const TargetDev tg = make_target_dev(a->target);
     const int D = f.D;
     const long B = a->B;

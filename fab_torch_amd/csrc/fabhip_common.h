@@ -43,6 +43,7 @@ struct FlowDims {
     int o_r4s;                  // the same tiles in per-wave consumption order (flow_r4.h: R4Stream; D <= 32, Wp >= 128), else -1
     int total;                  // total floats
     long long* timeline;        // dev-only: s_memtime stamps of workgroup 0 (nullptr in production)
+    int fast;                   // this call runs the fast-mode kernels (resolved from fabhip_flow::precision by the entry point)
 };
 
 FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
@@ -93,6 +94,7 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
         f.total += (2 * K * (4 * ntw + 4) + 8) * 4 * ntw * 256;
     }
     f.timeline = nullptr;
+    f.fast = 0;
     return f;
 }
 

@@ -318,7 +318,7 @@ static int launch_log_prob(const FlowDims& f, const float* packed, const float* 
     if (grad) {
         const FlowLds l = make_flow_lds(f, true);
         const size_t bytes = (size_t)l.total * 4;
-        if (fast_mode()) {
+        if (f.fast) {
             FAB_TRY(set_max_lds((const void*)k_flow_log_prob_fast<NTWM>, bytes));
             hipLaunchKernelGGL((k_flow_log_prob_fast<NTWM>), grid, block, bytes, st, f, l, packed, x, log_q, grad, B);
             return check_launch();
@@ -545,7 +545,7 @@ int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, 
     if (!flow || !flow->packed || !x || !log_q || B < 0) return FABHIP_EINVAL;
     FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
     if (B == 0) return FABHIP_OK;
-    FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
+    FlowDims f = flow_dims_of(*flow);
     if (option(FABHIP_OPT_TIMELINE)) {        // diagnostics only: never set in production (allocates once)
         if (!g_timeline && hipMalloc((void**)&g_timeline, 64 * 8) != hipSuccess) return FABHIP_ELAUNCH;
         hipMemsetAsync(g_timeline, 0, 64 * 8, (hipStream_t)stream);

@@ -12,6 +12,15 @@ namespace fab {
 
 // process-wide fast-mode switch (fabhip_set_fast_mode, flow_kernels.hip)
 int fast_mode();
+// fast mode of ONE call: the flow descriptor's FABHIP_PRECISION_* over the process default
+static inline int resolve_fast(int precision) {
+    return precision == FABHIP_PRECISION_FAST ? 1 : (precision == FABHIP_PRECISION_FP32 ? 0 : fast_mode());
+}
+static inline FlowDims flow_dims_of(const fabhip_flow& fl) {
+    FlowDims f = make_flow_dims(fl.dim, fl.n_layers, fl.width);
+    f.fast = resolve_fast(fl.precision);
+    return f;
+}
 // developer switches (fabhip_set_option; flow_kernels.hip): one int load, initialised from the environment at load time
 int option(int key);
 // generic HMC pieces with the row count on the device (generic_kernels.hip; used by the fused spline AIS call)

@@ -1151,11 +1151,11 @@ static long long* sp_timeline(hipStream_t st) {
 
 template <int NTWM>
 static int launch_logprob(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
-                          float* Zsave, float* Psave, unsigned long long* bitsave, hipStream_t st) {
+                          float* Zsave, float* Psave, unsigned long long* bitsave, int fast, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
     const NetLds l = make_net_lds(f, grad_x != nullptr, true);
     const size_t bytes = (size_t)l.total * 4;
-    if (grad_x && fast_mode()) {
+    if (grad_x && fast) {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob_fast<NTWM>, bytes));
         hipLaunchKernelGGL((k_spline_logprob_fast<NTWM>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
                            Psave, bitsave, sp_timeline(st));
@@ -1266,9 +1266,9 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
     if (!tape && !option(FABHIP_OPT_SPLINE_STAGED)) {           // one launch (the staged kernels below: tape, debugging)
-        if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
-        if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
-        if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, (hipStream_t)stream);
+        if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);
+        if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);
+        if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);
         return FABHIP_ENOTSUP;
     }
     const SplineTape tp = make_spline_tape(f, (long)B, tape);

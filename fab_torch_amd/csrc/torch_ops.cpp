@@ -72,9 +72,10 @@ void* aligned(const Tensor& ws) {
     return (void*)((p + 255) & ~(uintptr_t)255);
 }
 
-fabhip_flow make_flow(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width) {
+fabhip_flow make_flow(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t precision = 0) {
     fabhip_flow f;
-    f.dim = (int32_t)dim; f.n_layers = (int32_t)n_layers; f.width = (int32_t)width;
+    TORCH_CHECK(precision >= 0 && precision <= 2, "fabhip: precision must be 0 (process default), 1 (fp32) or 2 (fast)");
+    f.dim = (int32_t)dim; f.n_layers = (int32_t)n_layers; f.width = (int32_t)width; f.precision = (int32_t)precision;
     f.packed = fp(packed, "packed flow image");
     const int64_t n = fabhip_flow_packed_floats(f.dim, f.n_layers, f.width);
     TORCH_CHECK(n > 0, "fabhip: flow shape not supported (dim ", dim, ", width ", width, ")");
@@ -198,9 +199,9 @@ std::tuple<Tensor, Tensor> realnvp_sample(const Tensor& packed, int64_t dim, int
 }
 
 std::tuple<Tensor, Tensor> realnvp_logprob_grad(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width,
-                                                const Tensor& x, bool with_grad) {
+                                                const Tensor& x, bool with_grad, int64_t precision) {
     c10::DeviceGuard g(x.device());
-    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width, precision);
     TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0);
     Tensor log_q = fempty({B}, x), grad = with_grad ? at::empty_like(x) : fempty({0}, x);
@@ -291,9 +292,10 @@ void adam_clip_step(Tensor theta, const Tensor& grad, Tensor m, Tensor v, double
 // RQ-spline coupling flow.  `Tensor[] params`: per layer {meta, w0, b0, wa, ba, wb, bb, wf, bf, pfw, uw, uh, ud}
 // (pfw may be an empty tensor), then {base_scale, base_circ}.
 // ------------------------------------------------------------------------------------------------------------------
-fabhip_spline_flow make_spline(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden) {
+fabhip_spline_flow make_spline(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden, int64_t precision = 0) {
     fabhip_spline_flow f;
-    f.dim = (int32_t)dim; f.n_layers = (int32_t)n_layers; f.hidden = (int32_t)hidden;
+    TORCH_CHECK(precision >= 0 && precision <= 2, "fabhip: precision must be 0 (process default), 1 (fp32) or 2 (fast)");
+    f.dim = (int32_t)dim; f.n_layers = (int32_t)n_layers; f.hidden = (int32_t)hidden; f.precision = (int32_t)precision;
     f.packed = fp(packed, "packed spline image");
     const int64_t n = fabhip_spline_packed_floats(f.dim, f.n_layers, f.hidden);
     TORCH_CHECK(n > 0, "fabhip: spline flow shape not supported (dim ", dim, ", hidden ", hidden, ")");
@@ -322,9 +324,9 @@ void spline_pack(at::TensorList params, int64_t dim, int64_t n_layers, int64_t h
 }
 
 std::tuple<Tensor, Tensor> spline_logprob_grad(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden,
-                                               const Tensor& x, bool with_grad) {
+                                               const Tensor& x, bool with_grad, int64_t precision) {
     c10::DeviceGuard g(x.device());
-    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
+    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden, precision);
     TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0);
     Tensor log_q = fempty({B}, x), grad = with_grad ? at::empty_like(x) : fempty({0}, x);
@@ -405,9 +407,9 @@ std::tuple<Tensor, Tensor> gmm_logp_grad(const Tensor& x, const Tensor& locs, co
 std::tuple<Tensor, Tensor, Tensor, Tensor> create_point(const Tensor& packed, int64_t dim, int64_t n_layers,
                                                         int64_t width, int64_t kind, at::ArrayRef<double> prm,
                                                         const optional<Tensor>& locs, const optional<Tensor>& scales,
-                                                        const Tensor& x, bool with_grad) {
+                                                        const Tensor& x, bool with_grad, int64_t precision) {
     c10::DeviceGuard g(x.device());
-    const fabhip_flow f = make_flow(packed, dim, n_layers, width);
+    const fabhip_flow f = make_flow(packed, dim, n_layers, width, precision);
     const fabhip_target t = make_target(kind, prm, locs, scales, dim);
     TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0);
@@ -428,10 +430,10 @@ void hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t
                     double beta, double beta_next, double alpha, bool p_target, const Tensor& noise_p,
                     const Tensor& noise_e, Tensor epsilons_row, Tensor common_epsilon, const Tensor& mass, int64_t L,
                     double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept,
-                    optional<Tensor> avg_distance) {
+                    optional<Tensor> avg_distance, int64_t precision) {
     c10::DeviceGuard g(x.device());
     fabhip_hmc_args a;
-    a.flow = make_flow(packed, dim, n_layers, width);
+    a.flow = make_flow(packed, dim, n_layers, width, precision);
     a.target = make_target(kind, prm, locs, scales, dim);
     TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0), n_outer = epsilons_row.numel();
@@ -567,9 +569,9 @@ void spline_hmc_transition(const Tensor& packed, int64_t dim, int64_t n_layers, 
                            double beta, double beta_next, double alpha, bool p_target, const Tensor& noise_p,
                            const Tensor& noise_e, Tensor eps_row, Tensor ceps, const Tensor& mass, int64_t n_outer,
                            int64_t n_leap, double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept,
-                           optional<Tensor> avg_distance) {
+                           optional<Tensor> avg_distance, int64_t precision) {
     c10::DeviceGuard g(x.device());
-    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
+    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden, precision);
     const fabhip_target tg = make_target(kind, prm, locs, scales, dim);
     TORCH_CHECK(x.dim() == 2, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0), D = x.size(1);
@@ -607,10 +609,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     const Tensor& u0, const Tensor& eps0, const Tensor& noise_p, const Tensor& noise_e, Tensor epsilons, Tensor common_epsilon,
     const Tensor& mass, int64_t n_outer, int64_t L, double max_grad, double target_p_accept, bool tune,
     optional<Tensor> p_accept_first, optional<Tensor> p_accept_last, optional<Tensor> avg_distance_first,
-    optional<Tensor> avg_distance_last, bool want_base) {
+    optional<Tensor> avg_distance_last, bool want_base, int64_t precision) {
     c10::DeviceGuard g(eps0.device());
     fabhip_spline_ais_args a;
-    a.flow = make_spline(packed, dim, n_layers, hidden);
+    a.flow = make_spline(packed, dim, n_layers, hidden, precision);
     a.target = make_target(kind, prm, locs, scales, dim);
     TORCH_CHECK(eps0.dim() == 2 && eps0.size(1) == dim, "fabhip: eps0 must be [B, dim]");
     const int64_t B = eps0.size(0), M = (int64_t)betas.size() - 2;
@@ -705,10 +707,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     bool p_target, int64_t transition, const Tensor& eps0, const Tensor& noise_a, const Tensor& noise_b,
     Tensor step_state, optional<Tensor> common_epsilon, const optional<Tensor>& mass, int64_t n_inner, int64_t L,
     double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept_first, optional<Tensor> p_accept_last,
-    optional<Tensor> avg_distance_first, optional<Tensor> avg_distance_last, bool want_base) {
+    optional<Tensor> avg_distance_first, optional<Tensor> avg_distance_last, bool want_base, int64_t precision) {
     c10::DeviceGuard g(eps0.device());
     fabhip_ais_args a;
-    a.flow = make_flow(packed, dim, n_layers, width);
+    a.flow = make_flow(packed, dim, n_layers, width, precision);
     a.target = make_target(kind, prm, locs, scales, dim);
     TORCH_CHECK(eps0.dim() == 2 && eps0.size(1) == dim, "fabhip: eps0 must be [B, dim]");
     const int64_t B = eps0.size(0), M = (int64_t)betas.size() - 2;
@@ -763,10 +765,10 @@ void ais_phase(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t widt
                double target_p_accept, bool tune, Tensor x, Tensor log_q, Tensor log_p, optional<Tensor> grad_log_q,
                optional<Tensor> grad_log_p, Tensor log_w, Tensor n_valid, Tensor stats, optional<Tensor> partials,
                optional<Tensor> p_accept_first, optional<Tensor> p_accept_last, optional<Tensor> avg_distance_first,
-               optional<Tensor> avg_distance_last, optional<Tensor> base_x, optional<Tensor> base_log_w) {
+               optional<Tensor> avg_distance_last, optional<Tensor> base_x, optional<Tensor> base_log_w, int64_t precision) {
     c10::DeviceGuard g(x.device());
     fabhip_ais_args a;
-    a.flow = make_flow(packed, dim, n_layers, width);
+    a.flow = make_flow(packed, dim, n_layers, width, precision);
     a.target = make_target(kind, prm, locs, scales, dim);
     TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [B, dim]");
     const int64_t B = x.size(0), M = (int64_t)betas.size() - 2;
@@ -932,7 +934,7 @@ TORCH_LIBRARY(fabhip, m) {
 
     m.def("realnvp_pack(Tensor[] params, int dim, int n_layers, int width, bool with_inverse, Tensor(a!) packed) -> ()");
     m.def("realnvp_sample(" FLW ", Tensor eps) -> (Tensor, Tensor)");
-    m.def("realnvp_logprob_grad(" FLW ", Tensor x, bool with_grad) -> (Tensor, Tensor)");
+    m.def("realnvp_logprob_grad(" FLW ", Tensor x, bool with_grad, int precision=0) -> (Tensor, Tensor)");
     m.def("realnvp_logprob_tape(Tensor theta, Tensor x, Tensor packed, Tensor[] params, int dim, int n_layers, "
           "int width, bool want_grad_x) -> (Tensor, Tensor, Tensor)");
     m.def("realnvp_param_grad(Tensor[] params, " FLW ", Tensor tape, Tensor coef) -> Tensor");
@@ -944,26 +946,26 @@ TORCH_LIBRARY(fabhip, m) {
 
     m.def("spline_packed_floats(int dim, int n_layers, int hidden) -> int", spline_packed_floats);
     m.def("spline_pack(Tensor[] params, int dim, int n_layers, int hidden, Tensor(a!) packed) -> ()");
-    m.def("spline_logprob_grad(Tensor packed, int dim, int n_layers, int hidden, Tensor x, bool with_grad) -> (Tensor, Tensor)");
+    m.def("spline_logprob_grad(Tensor packed, int dim, int n_layers, int hidden, Tensor x, bool with_grad, int precision=0) -> (Tensor, Tensor)");
     m.def("spline_tape_layout(int dim, int n_layers, int hidden, int B) -> int[]", spline_tape_layout);
     m.def("spline_logprob_tape(Tensor packed, int dim, int n_layers, int hidden, Tensor x) -> (Tensor, Tensor, Tensor)");
     m.def("spline_sample(Tensor packed, int dim, int n_layers, int hidden, Tensor u, Tensor eps) -> (Tensor, Tensor)");
     m.def("target_logp_grad(" TGT ", Tensor x, bool with_grad) -> (Tensor, Tensor)");
     m.def("manywell_logp_grad(Tensor x, float a, float b, float c, float log_norm) -> (Tensor, Tensor)");
     m.def("gmm_logp_grad(Tensor x, Tensor locs, Tensor scales) -> (Tensor, Tensor)");
-    m.def("create_point(" FLW ", " TGT ", Tensor x, bool with_grad) -> (Tensor, Tensor, Tensor, Tensor)");
+    m.def("create_point(" FLW ", " TGT ", Tensor x, bool with_grad, int precision=0) -> (Tensor, Tensor, Tensor, Tensor)");
 
     m.def("hmc_transition(" FLW ", " TGT ", Tensor(a!) x, Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!) grad_log_q, "
           "Tensor(e!) grad_log_p, Tensor(f!)? log_w, float beta, float beta_next, float alpha, bool p_target, "
           "Tensor noise_p, Tensor noise_e, Tensor(g!) epsilons_row, Tensor(h!) common_epsilon, Tensor mass, int L, "
-          "float max_grad, float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance) -> ()");
+          "float max_grad, float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance, int precision=0) -> ()");
     m.def("metropolis_transition(" FLW ", " TGT ", Tensor(a!) x, Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!)? log_w, "
           "float beta, float beta_next, float alpha, bool p_target, Tensor noise_x, Tensor noise_u, "
           "Tensor(e!) noise_scalings_row, float target_p_accept, bool tune) -> ()");
     m.def("ais_run(" FLW ", " TGT ", float[] betas, float alpha, bool p_target, int transition, Tensor eps0, "
           "Tensor noise_a, Tensor noise_b, Tensor(a!) step_state, Tensor(b!)? common_epsilon, Tensor? mass, int n_inner, "
           "int L, float max_grad, float target_p_accept, bool tune, Tensor(c!)? p_accept_first, Tensor(d!)? p_accept_last, "
-          "Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base) -> "
+          "Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base, int precision=0) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
 
     m.def("ais_phase(" FLW ", " TGT ", float[] betas, float alpha, bool p_target, int transition, int phases, int j_begin, "
@@ -972,7 +974,7 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(d!) log_q, Tensor(e!) log_p, Tensor(f!)? grad_log_q, Tensor(g!)? grad_log_p, Tensor(h!) log_w, "
           "Tensor(i!) n_valid, Tensor(j!) stats, Tensor(k!)? partials, Tensor(l!)? p_accept_first, "
           "Tensor(m!)? p_accept_last, Tensor(n!)? avg_distance_first, Tensor(o!)? avg_distance_last, Tensor(p!)? base_x, "
-          "Tensor(q!)? base_log_w) -> ()");
+          "Tensor(q!)? base_log_w, int precision=0) -> ()");
     m.def("hmc_partials_floats(int B) -> int", hmc_partials_floats);
     m.def("hmc_adapt_gathered(Tensor gathered, int n_ranks, int B_rank, Tensor(a!) epsilon, Tensor(b!) common_epsilon, "
           "float target_p_accept, bool tune, Tensor(c!)? p_accept, Tensor(d!)? avg_distance) -> ()");
@@ -990,11 +992,11 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor? locs, Tensor? scales, Tensor(a!) x, Tensor(b!) log_q, Tensor(c!) log_p, Tensor(d!) grad_log_q, "
           "Tensor(e!) grad_log_p, Tensor(f!)? log_w, float beta, float beta_next, float alpha, bool p_target, Tensor noise_p, "
           "Tensor noise_e, Tensor(g!) eps_row, Tensor(h!) ceps, Tensor mass, int n_outer, int n_leap, float max_grad, "
-          "float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance) -> ()");
+          "float target_p_accept, bool tune, Tensor(i!)? p_accept, Tensor(j!)? avg_distance, int precision=0) -> ()");
     m.def("spline_ais_run(Tensor packed, int dim, int n_layers, int hidden, " TGT ", float[] betas, float alpha, bool p_target, "
           "Tensor u0, Tensor eps0, Tensor noise_p, Tensor noise_e, Tensor(a!) epsilons, Tensor(b!) common_epsilon, Tensor mass, "
           "int n_outer, int L, float max_grad, float target_p_accept, bool tune, Tensor(c!)? p_accept_first, "
-          "Tensor(d!)? p_accept_last, Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base) -> "
+          "Tensor(d!)? p_accept_last, Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base, int precision=0) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("anneal_log_prob(Tensor log_q, Tensor log_p, float beta, float alpha, bool p_target) -> Tensor");
     m.def("log_w_update(Tensor log_q, Tensor log_p, float beta, float beta_next, float alpha, bool p_target, "

@@ -125,6 +125,10 @@ class RealNVP(nn.Module):
         self.d = int((dim / 2) + 0.5)
         self.act_norm = bool(act_norm)
         self._act_norm_ready = False
+        # None: follow the process default (`fab_torch_amd.fast_mode`); "fp32" / "fast": every density + gradient /
+        # transition / AIS call that evaluates THIS flow runs the parity / the bf16 fast-mode kernels (per call:
+        # fabhip_flow::precision), so two samplers of one process can differ
+        self.precision = None
         self._nf_model = _NormalizingFlow(dim, n_flow_layers, self.width, self.act_norm)
         self._packed = None
         self._packed_key = None
@@ -304,7 +308,8 @@ class RealNVP(nn.Module):
     def native_log_prob(self, x: torch.Tensor, with_grad: bool = False):
         _ops.require_device(x, "x")
         fargs = self.native(need_inverse=False)
-        log_q, grad = _ops.load().realnvp_logprob_grad(*fargs, x.detach().contiguous().float(), bool(with_grad))
+        log_q, grad = _ops.load().realnvp_logprob_grad(*fargs, x.detach().contiguous().float(), bool(with_grad),
+                                                       _ops.precision_of(self))
         return log_q, (grad if with_grad else None)
 
     # ---- autograd-free training entry points (the same two ops the autograd path runs) -------------------------------

@@ -158,7 +158,8 @@ class HipShardBackend:
         self.ops.ais_phase(*self._common(st), int(phases), int(j0), int(j1), st["eps0"], st["noise_a"], st["noise_b"],
                            op.epsilons, op.common_epsilon, op.mass_vector, 1, op.L, float(op.max_grad),
                            float(op.target_p_accept), bool(tune), st["x"], st["lq"], st["lp"], st["gq"], st["gp"],
-                           st["log_w"], st["n_valid"], st["stats"], partials, None, None, None, None, None, None)
+                           st["log_w"], st["n_valid"], st["stats"], partials, None, None, None, None, None, None,
+                           self._ops_mod.precision_of(self.ais.base_distribution))
 
     def begin(self, b, eps0=None, noise_a=None, noise_b=None):
         """Chain initialisation + "chain init" filter + base ESS of this rank's b chains (FABHIP_AIS_INIT)."""

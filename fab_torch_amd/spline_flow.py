@@ -200,6 +200,7 @@ class CircularCoupledRQSFlow(nn.Module):
         if ind_circ:
             layers.append(_PeriodicWrap(ind_circ, bound_circ))
         self._nf_model = _NormalizingFlow(_UniformGaussian(dim, ind_circ, scale), layers)
+        self.precision = None             # None / "fp32" / "fast": see RealNVP.precision (the density + gradient kernel)
         self.register_buffer("_circ", circ)
         self.register_buffer("_tail_bound", tail_bound.clone())
         self._packed = None
@@ -291,7 +292,8 @@ class CircularCoupledRQSFlow(nn.Module):
 
     def native_log_prob(self, x: torch.Tensor, with_grad: bool = False):
         _ops.require_device(x, "x")
-        lq, g = _ops.load().spline_logprob_grad(*self.native(), x.detach().contiguous().float(), bool(with_grad))
+        lq, g = _ops.load().spline_logprob_grad(*self.native(), x.detach().contiguous().float(), bool(with_grad),
+                                                _ops.precision_of(self))
         return lq, (g if with_grad else None)
 
     # ---- packing -----------------------------------------------------------------------------------------------------

@@ -145,7 +145,8 @@ def create_point(x: torch.Tensor, flow: RealNVP, target: _NativeTarget, with_gra
     """fab/sampling_methods/base.py:59-72 on the GPU (one fused launch)."""
     _ops.require_device(x, "x")
     x = x.detach().contiguous().float()
-    lq, lp, gq, gp = _ops.load().create_point(*flow.native(), *target.native_target(), x, bool(with_grad))
+    lq, lp, gq, gp = _ops.load().create_point(*flow.native(), *target.native_target(), x, bool(with_grad),
+                                              _ops.precision_of(flow))
     if not with_grad and log_q_x is not None:
         lq = log_q_x.detach()
     return Point(x, lq, lp, gq if with_grad else None, gp if with_grad else None)
@@ -242,7 +243,8 @@ class HamiltonianMonteCarlo(TransitionOperator):
                     point.grad_log_p, log_w, float(beta), float(beta_next if beta_next is not None else beta),
                     float(self.alpha if self.alpha is not None else 0.0), bool(self.p_target), noise_p.contiguous(),
                     noise_e.contiguous(), self.epsilons[i - 1], self.common_epsilon, self.mass_vector, self.n_outer, self.L,
-                    float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance)
+                    float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance,
+                    _ops.precision_of(flow))
                 return point
             return self._transition_generic(point, i, beta, log_w, beta_next, noise_p.contiguous(),
                                             noise_e.contiguous(), p_accept, avg_distance)
@@ -251,7 +253,8 @@ class HamiltonianMonteCarlo(TransitionOperator):
             point.grad_log_p, log_w, float(beta), float(beta_next if beta_next is not None else beta),
             float(self.alpha if self.alpha is not None else 0.0), bool(self.p_target), noise_p.contiguous(),
             noise_e.contiguous(), self.epsilons[i - 1], self.common_epsilon, self.mass_vector, self.L,
-            float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance)
+            float(self.max_grad), float(self.target_p_accept), not self.eval_mode, p_accept, avg_distance,
+            _ops.precision_of(self.flow))
         return point
 
 

@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 205
+#define FABHIP_ABI_VERSION 206
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -110,8 +110,13 @@ int fabhip_flow_pack(const fabhip_flow_params* params, float* packed, fabhip_str
  * fabhip_flow_sample and fabhip_ais_run need a full fabhip_flow_pack first. */
 int fabhip_flow_pack_density(const fabhip_flow_params* params, float* packed, fabhip_stream_t stream);
 
+/* `precision`: per CALL choice between the fp32 parity kernels and fast mode (below) for the entry points that have both -
+ * FABHIP_PRECISION_DEFAULT (0, what a zero-initialised struct gets) follows the process default of fabhip_set_fast_mode,
+ * _FP32 / _FAST override it, so two samplers of one process can differ. */
+enum { FABHIP_PRECISION_DEFAULT = 0, FABHIP_PRECISION_FP32 = 1, FABHIP_PRECISION_FAST = 2 };
 typedef struct {
     int32_t dim, n_layers, width;
+    int32_t precision;   /* FABHIP_PRECISION_* */
     const float* packed; /* fabhip_flow_pack output */
 } fabhip_flow;
 
@@ -167,6 +172,7 @@ typedef struct {
 
 typedef struct {
     int32_t dim, n_layers, hidden;
+    int32_t precision;   /* FABHIP_PRECISION_* (the density + gradient kernel has a fast variant) */
     const float* packed; /* fabhip_spline_pack output */
 } fabhip_spline_flow;
 

@@ -191,3 +191,49 @@ def test_fast_mode_with_actnorm_layers_matches_its_emulation():
     with fa.fast_mode():
         pt, lw = ais.sample_and_log_weights(256)
     assert pt.x.shape == (256, D) and torch.isfinite(lw).all()
+
+
+def test_precision_is_a_per_call_choice_of_the_flow_not_only_a_process_switch():
+    """`fabhip_set_fast_mode` alone is process-wide - two samplers of one process could not differ.
+    `flow.precision` ("fp32" / "fast" / None = process default) travels with every call (fabhip_flow::precision): a "fast"
+    flow and an "fp32" flow side by side, under either process default, each give bit for bit what the process switch gives."""
+    D, K, nodes, M, B, L = 32, 4, 10, 3, 96, 3
+    torch.manual_seed(3)
+    nf = oflow.make_realnvp(D, K, nodes)
+    oflow.randomize_last_layers(nf, 0.02, 5)
+    flows = {}
+    for prec in (None, "fp32", "fast"):
+        hf = fa.RealNVP(D, K, nodes)
+        hf._nf_model.load_state_dict(nf.state_dict())
+        hf = hf.to(DEV).requires_grad_(False)
+        hf.precision = prec
+        flows[prec] = hf
+    target = fa.ManyWellEnergy(D)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    eps0 = torch.randn(B, D, device=DEV, generator=g)
+    na = torch.randn(M, 1, B, D, device=DEV, generator=g)
+    nb = torch.empty(M, 1, B, device=DEV).exponential_(generator=g)
+
+    def run(hf):
+        hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1, L=L).to(DEV)
+        ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, M)
+        pt, lw = ais.sample_and_log_weights(B, eps0=eps0, noise_a=na, noise_b=nb)
+        lq, gr = hf.log_prob_and_grad(pt.x)
+        return pt.x.clone(), lw.clone(), lq.clone(), gr.clone(), hmc.epsilons.clone()
+
+    ref32 = run(flows[None])                                    # process default off
+    with fa.fast_mode():
+        ref_fast = run(flows[None])                             # process default on
+        in_fast_fp32 = run(flows["fp32"])                       # the flow's own choice wins over the switch
+    own_fast = run(flows["fast"])                               # ... in both directions
+    own_fp32 = run(flows["fp32"])
+    for a, b in zip(ref32, own_fp32):
+        assert torch.equal(a, b)
+    for a, b in zip(ref32, in_fast_fp32):
+        assert torch.equal(a, b)
+    for a, b in zip(ref_fast, own_fast):
+        assert torch.equal(a, b)
+    assert not torch.equal(ref32[2], ref_fast[2])               # and the two modes do differ
+    flows["fast"].precision = "bf16"
+    with pytest.raises(fa._ops.FabhipError, match="precision"):
+        flows["fast"].log_prob_and_grad(eps0)
