@@ -14,8 +14,24 @@ LIB = os.path.join(HERE, "libfabhip.so")
 SOURCES = ["flow_kernels.hip", "ais_kernels.hip", "reduce_resample.hip", "train_kernels.hip", "topk.hip",
            "generic_kernels.hip", "spline_kernels.hip"]
 ARCH = "gfx950"
-FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-pass-failed"] + \
-    os.environ.get("FABHIP_EXTRA_FLAGS", "").split()
+FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-pass-failed",
+         "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("FABHIP_EXTRA_FLAGS", "").split()
+
+
+def spilling_kernels(remarks: str):
+    """(kernel, spilled VGPRs) of every kernel hipcc's resource-usage remarks report with a register spill: each
+    instantiation in the library can be selected by some shape, and a spilling one turns its hot loop into scratch
+    traffic - the build fails instead (shipped k_hmc_step_r4<8, *> spilled 163 - 772 VGPRs)."""
+    import re
+    out, name = [], None
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"remark:\s+VGPRs Spill: (\d+)", line)
+        if m and name and int(m.group(1)) > 0:
+            out.append((name, int(m.group(1))))
+    return out
 
 
 def _hipcc():
@@ -99,6 +115,10 @@ def _build_locked(hipcc, verbose):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stderr[-8000:]}")
+        spills = spilling_kernels(r.stderr) if src != TORCH_SRC else []
+        if spills and os.environ.get("FABHIP_ALLOW_SPILLS") != "1":
+            raise RuntimeError(f"{src}: kernels with register spills (remove the instantiation or cut its registers): "
+                               + ", ".join(f"{k} ({n} VGPRs)" for k, n in spills))
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:

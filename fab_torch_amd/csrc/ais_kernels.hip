@@ -769,8 +769,10 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
 
 // 4-chain tiles pay when 16-chain tiles cannot fill the chip: up to 288 workgroups of 4 chains (B <= 1152); off in fast
 // mode (no bf16 variant of the 4-chain kernel).  FABHIP_OPT_TILE_SHAPE = 16 / 4 forces the choice (tests exercise both).
+// Shapes: D <= 32 and hidden width <= 320 only - the D > 32 and the 512-wide instantiations of the 4-chain kernel spill
+// registers (hipcc: 52 .. 772 VGPRs), so they are neither compiled nor selectable (16-chain tiles there).
 static bool use_r4_tiles(const FlowDims& f, long B) {
-    if (f.fast) return false;
+    if (f.fast || f.D > 32 || f.NTW / 4 > 5) return false;
     const int shape = option(FABHIP_OPT_TILE_SHAPE);
     if (shape == 16) return false;
     if (shape == 4) return true;
@@ -791,16 +793,17 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
     // the last chain take the early-return branch and write zeros): the scratch is never read uninitialised
     const dim3 grid((unsigned)(nblk_of(a.B) * (ROWS / R4)));
     const bool stream = option(FABHIP_OPT_R4_STREAM) != 0;  // 0: per-stage request groups also where the stream image exists
-    if (f.D > 32) {
-        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, true, false>, bytes));
-        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, true, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
-    } else if (NTWM >= 2 && f.o_r4s >= 0 && stream) {
+    if constexpr (NTWM > 5) {
+        return FABHIP_ENOTSUP;                              // (use_r4_tiles never selects it)
+    } else if (NTWM >= 2 && f.o_r4s >= 0 && (stream || NTWM >= 5)) {    // (the per-stage schedule spills at 5 tiles per wave)
         constexpr int NS = NTWM >= 2 ? NTWM : 2;           // (never instantiates the stream code for NTWM = 1)
         FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, true>, bytes));
         hipLaunchKernelGGL((k_hmc_step_r4<NS, false, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
-    } else {
+    } else if constexpr (NTWM < 5) {
         FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, false, false>, bytes));
         hipLaunchKernelGGL((k_hmc_step_r4<NTWM, false, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+    } else {
+        return FABHIP_ENOTSUP;
     }
     return check_launch();
 }

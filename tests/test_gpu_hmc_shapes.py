@@ -146,7 +146,7 @@ def test_four_chain_tiles_are_bitwise_reproducible():
             assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1]) and torch.equal(o[2], outs[0][2])
 
 
-@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 1024), (6, 3, 40, 70), (16, 3, 8, 257)])
+@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 8, 1024), (6, 3, 40, 70), (16, 3, 8, 257)])
 def test_stream_and_staged_four_chain_kernels_are_bit_identical(monkeypatch, D, K, nodes, B):
     """The 4-chain kernel exists in two request schedules - one continuous weight stream per wave (D <= 32, hidden width
     >= 128) and per-stage request groups (everything else; FABHIP_OPT_R4_STREAM = 0 forces it) - with the same arithmetic in the
