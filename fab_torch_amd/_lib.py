@@ -103,7 +103,7 @@ SYMBOLS = [
     "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
     "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_set_option", "fabhip_get_option", "fabhip_ais_phase", "fabhip_hmc_partials_floats",
     "fabhip_hmc_adapt_gathered", "fabhip_spline_hmc_workspace_bytes", "fabhip_spline_hmc_transition",
-    "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_debug_spline_timeline",
+    "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_tape_gemm", "fabhip_debug_spline_timeline",
 ]
 ABI_VERSION = 206          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 

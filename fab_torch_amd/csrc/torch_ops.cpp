@@ -809,6 +809,24 @@ void ais_phase(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t widt
     chk(fabhip_ais_phase(&a, (int32_t)phases, (int32_t)j_begin, (int32_t)j_end, slab, stream_of(x)), "ais_phase");
 }
 
+// Linear backward over a tape (fabhip_tape_gemm): Y / X are views INTO `tape` given as float offsets of layer 0
+std::tuple<Tensor, Tensor> tape_gemm(const Tensor& tape, int64_t layer_stride, int64_t L, int64_t off_y, int64_t ldy, int64_t P,
+                                     int64_t off_x, int64_t ldx, int64_t Q, const Tensor& coef, bool want_colsum) {
+    c10::DeviceGuard g(tape.device());
+    const int64_t B = coef.numel();
+    TORCH_CHECK(L >= 1 && P >= 1 && Q >= 1 && ldy >= P && ldx >= Q && off_y >= 0 && off_x >= 0, "fabhip: tape_gemm shapes");
+    TORCH_CHECK((L - 1) * layer_stride + off_y + B * ldy <= tape.numel() && (L - 1) * layer_stride + off_x + B * ldx <= tape.numel(),
+                "fabhip: tape_gemm operands leave the tape");
+    need_n(coef, B, tape, "coef");
+    Tensor C = fempty({L, P, Q}, tape), S = want_colsum ? fempty({L, P}, tape) : fempty({0}, tape);
+    const float* t = fp(tape, "tape");
+    chk(fabhip_tape_gemm(t + off_y, layer_stride, (int32_t)ldy, (int32_t)P, t + off_x, layer_stride, (int32_t)ldx, (int32_t)Q,
+                         fp(coef, "coef"), B, (int32_t)L, C.data_ptr<float>(), want_colsum ? S.data_ptr<float>() : nullptr,
+                         stream_of(tape)),
+        "tape_gemm");
+    return {C, S};
+}
+
 int64_t hmc_partials_floats(int64_t B) { return fabhip_hmc_partials_floats(B); }
 
 void hmc_adapt_gathered(const Tensor& gathered, int64_t n_ranks, int64_t B_rank, Tensor epsilon, Tensor common_epsilon,
@@ -976,6 +994,8 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(m!)? p_accept_last, Tensor(n!)? avg_distance_first, Tensor(o!)? avg_distance_last, Tensor(p!)? base_x, "
           "Tensor(q!)? base_log_w, int precision=0) -> ()");
     m.def("hmc_partials_floats(int B) -> int", hmc_partials_floats);
+    m.def("tape_gemm(Tensor tape, int layer_stride, int L, int off_y, int ldy, int P, int off_x, int ldx, int Q, Tensor coef, "
+          "bool want_colsum) -> (Tensor, Tensor)");
     m.def("hmc_adapt_gathered(Tensor gathered, int n_ranks, int B_rank, Tensor(a!) epsilon, Tensor(b!) common_epsilon, "
           "float target_p_accept, bool tune, Tensor(c!)? p_accept, Tensor(d!)? avg_distance) -> ()");
     m.def("generic_workspace(Tensor like, int B, int dim) -> Tensor");
@@ -1036,6 +1056,7 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("metropolis_transition", metropolis_transition);
     m.impl("ais_run", ais_run);
     m.impl("ais_phase", ais_phase);
+    m.impl("tape_gemm", tape_gemm);
     m.impl("spline_ais_run", spline_ais_run);
     m.impl("hmc_adapt_gathered", hmc_adapt_gathered);
     m.impl("generic_workspace", generic_workspace);

@@ -222,6 +222,108 @@ __device__ __forceinline__ int prm_row(int p, int DO, int DOp) {      // packed 
     return j < DO ? 2 * j + 1 : -1;
 }
 
+// The same 64 x 64-block batch-reduction GEMM for ANY tape (the spline flow's, fabhip_spline_log_prob_tape): L problems
+// of one shape, C[l][p][q] = sum_b coef[b] Y[l][b][p] X[l][b][q] and, from the blocks with q0 = 0, the bias gradients
+// S[l][p] = sum_b coef[b] Y[l][b][p].  Rows are added in chunk order, chunks by the matrix cores' k order: deterministic.
+struct TapeGemm {
+    const float *Y, *X, *coef;
+    long y_stride, x_stride, B;
+    int ldy, ldx, P, Q, pblocks, qblocks;
+    float *C, *S;                      // [L][P][Q], [L][P] (S may be nullptr)
+};
+
+__global__ __launch_bounds__(256) void k_tape_gemm(TapeGemm g) {
+    __shared__ __attribute__((aligned(16))) float Ys[2][GK * GLD];
+    __shared__ __attribute__((aligned(16))) float Xs[2][GK * GLD];
+    __shared__ float Ss[16][64];
+    const int per = g.pblocks * g.qblocks;
+    const int layer = blockIdx.x / per, b = blockIdx.x % per;
+    const int p0 = 64 * (b / g.qblocks), q0 = 64 * (b % g.qblocks);
+    const float* Y = g.Y + (size_t)layer * g.y_stride;
+    const float* X = g.X + (size_t)layer * g.x_stride;
+    const int P = g.P, Q = g.Q, ldy = g.ldy, ldx = g.ldx;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n = lane & 15, kg = lane >> 4;
+    const int lr = tid >> 4, lc = (tid & 15) * 4;
+    const bool pvalid = p0 + 16 * wave < P;
+    const bool want_s = g.S != nullptr && q0 == 0;
+    float4 ry[2], rx[2];
+    float4 ssum = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto ld4 = [&](const float* base, long k, int ld, int c0, int lim) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < g.B) {
+            const float* r = base + k * ld;
+            if (c0 + 3 < lim && ((ld | c0) & 3) == 0) v = *reinterpret_cast<const float4*>(r + c0);
+            else {
+                if (c0 + 0 < lim) v.x = r[c0 + 0];
+                if (c0 + 1 < lim) v.y = r[c0 + 1];
+                if (c0 + 2 < lim) v.z = r[c0 + 2];
+                if (c0 + 3 < lim) v.w = r[c0 + 3];
+            }
+        }
+        return v;
+    };
+    auto gload = [&](long k0) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long k = k0 + lr + 16 * h;
+            const float c = k < g.B ? g.coef[k] : 0.f;
+            const float4 y = ld4(Y, k, ldy, p0 + lc, P);
+            ry[h] = make_float4(y.x * c, y.y * c, y.z * c, y.w * c);
+            rx[h] = ld4(X, k, ldx, q0 + lc, Q);
+            if (want_s) { ssum.x += ry[h].x; ssum.y += ry[h].y; ssum.z += ry[h].z; ssum.w += ry[h].w; }
+        }
+    };
+    auto sstore = [&](int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            *reinterpret_cast<float4*>(&Ys[buf][(lr + 16 * h) * GLD + lc]) = ry[h];
+            *reinterpret_cast<float4*>(&Xs[buf][(lr + 16 * h) * GLD + lc]) = rx[h];
+        }
+    };
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nch = (int)((g.B + GK - 1) / GK);
+    gload(0);
+    sstore(0);
+    __syncthreads();
+    for (int ch = 0; ch < nch; ++ch) {
+        const int buf = ch & 1;
+        if (ch + 1 < nch) gload((long)(ch + 1) * GK);
+        if (pvalid) {
+#pragma unroll
+            for (int s = 0; s < GK / 4; ++s) {
+                const float a = Ys[buf][(4 * s + kg) * GLD + 16 * wave + n];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = mfma4(a, Xs[buf][(4 * s + kg) * GLD + 16 * j + n], acc[j]);
+            }
+        }
+        if (ch + 1 < nch) sstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (want_s) {                                           // column sums: 16 row groups x 64 columns, added in row-group order
+        Ss[lr][lc] = ssum.x; Ss[lr][lc + 1] = ssum.y; Ss[lr][lc + 2] = ssum.z; Ss[lr][lc + 3] = ssum.w;
+        __syncthreads();
+        if (tid < 64 && p0 + tid < P) {
+            float s = 0.f;
+            for (int r = 0; r < 16; ++r) s += Ss[r][tid];
+            g.S[(size_t)layer * P + p0 + tid] = s;
+        }
+    }
+    if (!pvalid) return;
+    float* C = g.C + (size_t)layer * P * Q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int q = q0 + 16 * j + n;
+        if (q >= Q) continue;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = p0 + 16 * wave + 4 * kg + r;
+            if (p < P) C[(size_t)p * Q + q] = acc[j][r];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, GemmBlocks gb, GradLayout gl,
                                                     const float* __restrict__ tape, const float* __restrict__ coef,
                                                     long B, float* __restrict__ grads, float* __restrict__ ga_ws) {
@@ -649,6 +751,18 @@ int fabhip_adam_clip_step(float* theta, const float* grad, float* m, float* v, i
                        (const int*)step_count, norm);
     hipLaunchKernelGGL(fab::k_adam_commit, dim3(1), dim3(1), 0, st, (const float*)norm, (int*)step_count);
     return fab::check_launch();
+}
+
+int fabhip_tape_gemm(const float* Y, int64_t y_layer_stride, int32_t ldy, int32_t P, const float* X, int64_t x_layer_stride,
+                     int32_t ldx, int32_t Q, const float* coef, int64_t B, int32_t L, float* C, float* colsum,
+                     fabhip_stream_t stream) {
+    if (!Y || !X || !coef || !C || B < 1 || L < 1 || P < 1 || Q < 1 || ldy < P || ldx < Q) return FABHIP_EINVAL;
+    fab::TapeGemm g;
+    g.Y = Y; g.X = X; g.coef = coef; g.y_stride = y_layer_stride; g.x_stride = x_layer_stride; g.B = B;
+    g.ldy = ldy; g.ldx = ldx; g.P = P; g.Q = Q; g.pblocks = ceil_div(P, 64); g.qblocks = ceil_div(Q, 64);
+    g.C = C; g.S = colsum;
+    hipLaunchKernelGGL(fab::k_tape_gemm, dim3((unsigned)(L * g.pblocks * g.qblocks)), dim3(256), 0, (hipStream_t)stream, g);
+    return check_launch();
 }
 
 }  // extern "C"

@@ -264,13 +264,13 @@ class CircularCoupledRQSFlow(nn.Module):
         def m3(off, width):
             return T[:, off: off + B * width].view(L, B, width)
         cc = c.view(1, B, 1)
-        a0, r0, r1, h1 = m3(o_a0, 64), m3(o_r0, Wp)[..., :W], m3(o_r1, Wp)[..., :W], m3(o_h1, Wp)[..., :W]
-        dh0, dt, dh1 = cc * m3(o_dh0, Wp)[..., :W], cc * m3(o_dt, Wp)[..., :W], cc * m3(o_dh1, Wp)[..., :W]
-        dp = cc * m3(o_dp, NFP)
-        gw0, gb0 = torch.bmm(dh0.transpose(1, 2), a0), dh0.sum(1)                 # [L, W, 64], [L, W]
-        gwa, gba = torch.bmm(dt.transpose(1, 2), r0), dt.sum(1)
-        gwb, gbb = torch.bmm(dh1.transpose(1, 2), r1), dh1.sum(1)
-        gwf, gbf = torch.bmm(dp.transpose(1, 2), h1), dp.sum(1)                   # [L, NFP, W], [L, NFP]
+        # weight AND bias gradient of each Linear: ONE launch of the batch-reduction GEMM kernel over all layers
+        # (fabhip_tape_gemm: coefficients folded into the cotangent operand, bias = its column sums)
+        tg = _ops.load().tape_gemm
+        gw0, gb0 = tg(tape, stride, L, o_dh0, Wp, W, o_a0, 64, 64, c, True)       # [L, W, 64], [L, W]
+        gwa, gba = tg(tape, stride, L, o_dt, Wp, W, o_r0, Wp, W, c, True)
+        gwb, gbb = tg(tape, stride, L, o_dh1, Wp, W, o_r1, Wp, W, c, True)
+        gwf, gbf = tg(tape, stride, L, o_dp, NFP, NFP, o_h1, Wp, W, c, True)      # [L, NFP, W], [L, NFP]
         du = (cc * m3(o_du, UW)).sum(1)                                            # [L, 64 * 25] (rows >= n_id: unwritten)
         grads = []
         for l, (f, _, _) in enumerate(self._structure()):

@@ -197,6 +197,14 @@ int fabhip_spline_log_prob(const fabhip_spline_flow* flow, const float* x, float
  * gradient of sum_b c_b log q(x_b) w.r.t. a Linear's weight is (c * cotangent)^T @ activation - plain GEMMs over the
  * tape, left to the caller's BLAS (rocBLAS; fab_torch_amd/spline_flow.py uses torch.mm). */
 int fabhip_spline_tape_layout(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B, int64_t out16[16]);
+/* The GEMMs over a tape: for L layers of one shape  C[l][p][q] = sum_b coef[b] Y[l][b][p] X[l][b][q]  (Y: cotangents
+ * [B][ldy], X: activations [B][ldx], layer l at Y + l * y_layer_stride / X + l * x_layer_stride; C row-major [L][P][Q])
+ * and, if colsum != NULL, the bias gradients colsum[l][p] = sum_b coef[b] Y[l][b][p] - the backward of a Linear
+ * (loss.backward() through flow.log_prob, fab/train_with_prioritised_buffer.py:162-177) on the fp32 matrix cores,
+ * deterministic summation order.  ldy / ldx multiples of 4 and 16-byte aligned bases take the vector path. */
+int fabhip_tape_gemm(const float* Y, int64_t y_layer_stride, int32_t ldy, int32_t P, const float* X, int64_t x_layer_stride,
+                     int32_t ldx, int32_t Q, const float* coef, int64_t B, int32_t L, float* C, float* colsum,
+                     fabhip_stream_t stream);
 int fabhip_spline_log_prob_tape(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
                                 float* tape, int64_t tape_floats, void* workspace, size_t workspace_bytes,
                                 fabhip_stream_t stream);
