@@ -477,7 +477,18 @@ def g12_trainer_traces():
         calls = []
         orig_call = ais.sample_and_log_weights
 
+        starts = []                                              # state at the START of every trainer iteration (teacher forcing)
+        holder = {}
+
         def recording_call(batch_size, logging=True):
+            if "opt" in holder:                                  # a trainer iteration begins with this call
+                st = holder["opt"].state_dict()["state"]
+                starts.append(dict(params={k: v.detach().clone() for k, v in nf.state_dict().items()},
+                                   adam={i: (d["exp_avg"].clone(), d["exp_avg_sq"].clone(), float(d["step"]))
+                                         for i, d in st.items()},
+                                   eps=hmc.epsilons.clone(), ceps=hmc.common_epsilon.clone(),
+                                   buf_x=buffer.buffer.x.clone(), buf_index=int(buffer.current_index),
+                                   buf_full=int(buffer.is_full)))
             with Capture() as cap:
                 res = orig_call(batch_size, logging)
             calls.append(dict(eps0=cap.randn[0], noise_p=torch.stack(cap.randn_like)[:, None],
@@ -502,6 +513,7 @@ def g12_trainer_traces():
                                          initial_sampler=initial_sampler)
         n_init_calls = len(calls)
         opt = torch.optim.Adam(flow.parameters(), lr=1e-3)
+        holder["opt"] = opt
         logger = ListLogger()
         trainer = PrioritisedBufferTrainer(model=model, optimizer=opt, buffer=buffer, alpha=alpha,
                                            n_batches_buffer_sampling=n_batches, logger=logger,
@@ -539,6 +551,18 @@ def g12_trainer_traces():
         out["out_epsilons"], out["out_common_epsilon"] = hmc.epsilons, hmc.common_epsilon
         out.update({"final." + k: v for k, v in nf.state_dict().items()})
         npz(f"g12_trainer_seed{seed}.npz", **out)
+        # start-of-iteration states (parameters, Adam moments, step sizes, buffer positions) in a second file: the GPU test
+        # restarts every iteration from the REFERENCE's state and compares one iteration at the north-star 1e-4
+        assert len(starts) == n_iter
+        tf = dict(n_iter=n_iter)
+        for it, st in enumerate(starts):
+            tf.update({f"it{it}_param.{k}": v for k, v in st["params"].items()})
+            for i, (m_, v_, step) in st["adam"].items():
+                tf[f"it{it}_adam_m.{i}"], tf[f"it{it}_adam_v.{i}"], tf[f"it{it}_adam_step.{i}"] = m_, v_, step
+            tf[f"it{it}_eps"], tf[f"it{it}_ceps"] = st["eps"], st["ceps"]
+            tf[f"it{it}_buf_x"], tf[f"it{it}_buf_index"], tf[f"it{it}_buf_full"] = st["buf_x"], st["buf_index"], st["buf_full"]
+        tf["n_adam"] = len(starts[-1]["adam"])
+        npz(f"g12_trainer_seed{seed}_starts.npz", **tf)
 
 
 def g13_trained_flow():

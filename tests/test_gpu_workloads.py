@@ -375,6 +375,100 @@ def test_trainer_replays_reference_traces(seed, optimiser):
             assert float((v.cpu() - torch.tensor(ref)).abs().max()) <= 2e-5 + 1e-4 * float(np.abs(ref).max()), k
 
 
+@pytest.mark.parametrize("optimiser", ["torch_adam", "flat_adam"])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_trainer_iterations_from_the_reference_state_at_the_north_star_tolerance(seed, optimiser):
+    """VERDICT r2 (weak, d): the free-running replay above compares later iterations at 5e-4 because its parameters are
+    the product of its own earlier optimiser steps.  Here EVERY iteration restarts from the reference's state at that point
+    (g12 *_starts: flow parameters, Adam moments + step, HMC step sizes, buffer contents and ring position, written by
+    make_golden.py from the reference trainer's run) and ONE iteration is compared at the north-star 1e-4: sampled index
+    set and order, loss, gradient norm, ESS / log Z, the buffer after the on-the-fly adjust, the parameters after the
+    optimiser steps."""
+    g = load_golden(f"g12_trainer_seed{seed}.npz")
+    gs = load_golden(f"g12_trainer_seed{seed}_starts.npz")
+    D, M, L, B = int(g["D"]), int(g["M"]), int(g["L"]), int(g["B"])
+    alpha, n_iter, n_batches, n_init = float(g["alpha"]), int(g["n_iter"]), int(g["n_batches"]), int(g["n_init_calls"])
+    nf = oracle_flow_from_golden(g)
+    hf = hip_flow_from_oracle(nf).requires_grad_(True)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=alpha, p_target=False, epsilon=0.2, L=L).to(DEV)
+    model = fa.FABModel(hf, target, M, alpha=alpha, transition_operator=hmc)
+    ais = model.annealed_importance_sampler
+    T = lambda d, k: torch.tensor(d[k]).to(DEV)          # noqa: E731
+    calls = iter(range(n_init))
+
+    def initial_sampler():
+        c = next(calls)
+        pt, lw = ais.sample_and_log_weights(B, logging=False, eps0=T(g, f"call{c}_eps0"), noise_a=T(g, f"call{c}_noise_p"),
+                                            noise_b=T(g, f"call{c}_noise_e"))
+        return pt.x, lw, pt.log_q
+    buf = fa.PrioritisedReplayBuffer(D, int(g["buf_len"]), int(g["buf_min"]), initial_sampler, device=DEV)
+    opt = (torch.optim.Adam(hf.parameters(), lr=float(g["lr"])) if optimiser == "torch_adam"
+           else fa.FlatAdam(hf, lr=float(g["lr"])))
+    trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=alpha, n_batches_buffer_sampling=n_batches,
+                                          max_gradient_norm=float(g["max_gradient_norm"]),
+                                          w_adjust_max_clip=float(g["w_adjust_max_clip"]))
+    params = list(hf.parameters())
+    names = [k for k, _ in hf._nf_model.named_parameters()]
+    assert len(params) == int(gs["n_adam"])
+
+    def restore(it):
+        with torch.no_grad():
+            sd = {k[len(f"it{it}_param."):]: torch.tensor(v) for k, v in gs.items() if k.startswith(f"it{it}_param.")}
+            for k, p_ in hf._nf_model.state_dict().items():
+                p_.copy_(sd[k].to(DEV))                    # in place: FlatAdam's parameters are views of its flat buffer
+            hmc.epsilons.copy_(T(gs, f"it{it}_eps")); hmc.common_epsilon.copy_(T(gs, f"it{it}_ceps"))
+            buf.buffer.x.copy_(T(gs, f"it{it}_buf_x"))
+            if it > 0:
+                buf.buffer.log_w.copy_(T(g, f"it{it - 1}_buf_log_w")); buf.buffer.log_q_old.copy_(T(g, f"it{it - 1}_buf_log_q_old"))
+            buf.current_index, buf.is_full = int(gs[f"it{it}_buf_index"]), bool(int(gs[f"it{it}_buf_full"]))
+            have = f"it{it}_adam_m.0" in gs                 # (iteration 0: no optimiser state yet)
+            if optimiser == "torch_adam":
+                opt.state.clear()
+                if have:
+                    for i, p_ in enumerate(params):
+                        opt.state[p_] = {"step": torch.tensor(float(gs[f"it{it}_adam_step.{i}"])),
+                                         "exp_avg": T(gs, f"it{it}_adam_m.{i}").clone(),
+                                         "exp_avg_sq": T(gs, f"it{it}_adam_v.{i}").clone()}
+            else:
+                opt.m.zero_(); opt.v.zero_(); opt.steps.zero_()
+                if have:
+                    index = {id(p_): i for i, p_ in enumerate(params)}
+                    for mv, key in ((opt.m, "adam_m"), (opt.v, "adam_v")):
+                        for view, p_ in zip(hf._grad_views(mv), hf._grad_tensors()):
+                            view.copy_(T(gs, f"it{it}_{key}.{index[id(p_)]}").reshape(view.shape))
+                    opt.steps.fill_(int(float(gs[f"it{it}_adam_step.0"])))
+    del names
+    for it in range(n_iter):
+        restore(it)
+        c = n_init + it
+        ref_idx = torch.tensor(g[f"it{it}_indices"])
+        order = torch.searchsorted(ref_idx.sort().values, ref_idx)
+        info = trainer.step(it + 1, B, noise=dict(eps0=T(g, f"call{c}_eps0"), noise_a=T(g, f"call{c}_noise_p"),
+                                                  noise_b=T(g, f"call{c}_noise_e"), gumbel=T(g, f"it{it}_gumbel"),
+                                                  perm=order.to(DEV)))
+        assert torch.equal(trainer.last_indices.cpu(), ref_idx), f"iteration {it}: the sampled set differs"
+        for key in ("loss", "grad_norm", "ess_ais", "log_Z", "w_adjust_mean", "log_q_x_mean"):
+            ref = float(g[f"it{it}_{key}"])
+            assert abs(info[key] - ref) <= RTOL * max(1.0, abs(ref)), (it, key, info[key], ref)
+        # the adjusted entries moved by log q_new - log q_old after the iteration's own Adam steps, on samples all over the
+        # buffer (one Adam step moves a sample next to a ReLU kink by more than it moves the others): at most 1 entry in
+        # 200 outside the north-star 1e-4, none outside 1e-3
+        for got, key in ((buf.buffer.log_w, "buf_log_w"), (buf.buffer.log_q_old, "buf_log_q_old")):
+            ref = torch.tensor(g[f"it{it}_{key}"])
+            assert close(got, ref, 10 * RTOL), (it, key, worst(got, ref, 10 * RTOL))
+            fin = torch.isfinite(ref)
+            err = (got.cpu()[fin] - ref[fin]).abs()
+            tol = 2e-6 * max(1.0, float(ref[fin].abs().max())) + RTOL * ref[fin].abs()
+            assert int((err > tol).sum()) <= max(1, int(fin.sum()) // 200), (it, key, int((err > tol).sum()))
+        nxt = ({k[len(f"it{it + 1}_param."):]: v for k, v in gs.items() if k.startswith(f"it{it + 1}_param.")}
+               if it + 1 < n_iter else {k[len("final."):]: v for k, v in g.items() if k.startswith("final.")})
+        for k, v in hf._nf_model.state_dict().items():
+            if k in nxt and v.dtype.is_floating_point:
+                ref = nxt[k]
+                assert float((v.cpu() - torch.tensor(ref)).abs().max()) <= 2e-6 + RTOL * float(np.abs(ref).max()), (it, k)
+
+
 @pytest.mark.parametrize("tag,p_target", [("p", True), ("g", False)])
 def test_trained_flow_ess_matches_the_reference_within_one_percent(tag, p_target):
     """SURVEY 8(d) / north_star "ESS within 1 % of reference" where the ESS is MEANINGFUL: the committed small trained
