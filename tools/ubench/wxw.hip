@@ -22,17 +22,18 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 // tile behind every 4 RB MFMAs of this item (sched_group_barrier pipeline).  2: no MFMAs at all (pure stream through
 // the same ring, each tile touched by one v_add).  3: MFMAs only (the ring is loaded once and never refilled).
 // SYNC 1: after every NQ items the partial products go through LDS with two LDS-only barriers (a stage boundary).
-template <int G, int RD, int RB, int ILV, int SYNC, int NQ>
-__global__ __launch_bounds__(256) void k_wxw(const float4* __restrict__ src, int n_stages, float* __restrict__ sink,
+template <int G, int RD, int RB, int ILV, int SYNC, int NQ, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void k_wxw(const float4* __restrict__ src, int n_stages, float* __restrict__ sink,
                                              long long* __restrict__ cycles) {
     static_assert(NQ % RD == 0, "slot indices must be compile-time constants");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WS = 64 * G + 4;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, arow = lane & 3;
-    for (int e = tid; e < RB * 4 * WS; e += 256) lds[e] = 0.001f * (float)(e % 97);
+    for (int e = tid; e < RB * 4 * WS; e += 64 * NW) lds[e] = 0.001f * (float)(e % 97);
     float* part = lds + RB * 4 * WS;
+    if (tid == 0) reinterpret_cast<int*>(part + NW * 4 * 64 * G - 4)[0] = 0;
     __syncthreads();
-    constexpr int IS = 4 * G * 64;                                     // float4 between consecutive items of one wave
+    constexpr int IS = NW * G * 64;                                    // float4 between consecutive items of one wave
     const float4* sp = src + ((size_t)wave * G) * 64 + lane;
     float4 ring[RD][G];
 #pragma unroll
@@ -97,11 +98,47 @@ __global__ __launch_bounds__(256) void k_wxw(const float4* __restrict__ src, int
             float v = 0.f;
 #pragma unroll
             for (int i = 0; i < G; ++i) {
-                const float* p = part + (256 * i + tid);
-                v += (p[0] + p[4 * 64 * G]) + (p[2 * 4 * 64 * G] + p[3 * 4 * 64 * G]);
+                const float* p = part + ((256 * i + tid) % (4 * 64 * G));
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += p[w * 4 * 64 * G];
             }
             lds[(tid % (4 * WS))] = v * 1e-9f;
             lds_barrier();
+        } else if constexpr (SYNC == 2) {                 // partial store + ONE barrier, no reduction
+            float* pw = part + (size_t)wave * 4 * 64 * G + lane;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[r * 64 * G + 64 * g] = acc[0][g][r];
+            lds_barrier();
+        } else if constexpr (SYNC == 3) {                 // two bare barriers
+            lds_barrier();
+            lds_barrier();
+        } else if constexpr (SYNC == 6) {                 // software barrier: an LDS counter every wave bumps and polls
+            volatile int* ctr = reinterpret_cast<volatile int*>(part + NW * 4 * 64 * G - 4);
+            if (lane == 0) atomicAdd(const_cast<int*>(ctr), 1);
+            const int want = NW * (st + 1);
+            while (*ctr < want) __builtin_amdgcn_s_sleep(1);
+        } else if constexpr (SYNC >= 50) {                // two bare barriers, then the second wave of every SIMD waits
+            lds_barrier();
+            lds_barrier();
+            if (wave >= 4) __builtin_amdgcn_s_sleep(SYNC - 50);          // (64 cycles per unit)
+        } else if constexpr (SYNC == 4) {                 // one barrier; every wave reduces only the slice it consumes next
+            float* pw = part + (size_t)wave * 4 * 64 * G + lane;
+#pragma unroll
+            for (int g = 0; g < G; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pw[r * 64 * G + 64 * g] = acc[0][g][r];
+            lds_barrier();
+            float v = 0.f;
+            constexpr int SL = 64 * G / NW;               // columns of this wave's slice
+            if (lane < SL) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) v += part[(size_t)w * 4 * 64 * G + r * 64 * G + SL * wave + lane];
+                lds[arow * WS + SL * wave + lane] = v * 1e-9f;
+            }
         }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -118,14 +155,14 @@ __global__ __launch_bounds__(256) void k_wxw(const float4* __restrict__ src, int
     if (tid == 0) cycles[blockIdx.x] = t1 - t0;
 }
 
-template <int G, int RD, int RB, int ILV, int SYNC, int NQ>
+template <int G, int RD, int RB, int ILV, int SYNC, int NQ, int NW = 4>
 static void run(const char* name, const float4* src, size_t region_bytes, int n_wg, float* sink, long long* cyc) {
-    const size_t item_round = (size_t)4 * G * 1024;                         // bytes per item of all four waves
+    const size_t item_round = (size_t)NW * G * 1024;                        // bytes per item of all the waves
     const int n_stages = (int)(region_bytes / item_round / NQ) - 1;          // (the ring runs RD items ahead)
-    const size_t lds = (size_t)(RB * 4 * (64 * G + 4) + 4 * 4 * 64 * G) * 4;
-    auto kern = k_wxw<G, RD, RB, ILV, SYNC, NQ>;
+    const size_t lds = (size_t)(RB * 4 * (64 * G + 4) + NW * 4 * 64 * G) * 4;
+    auto kern = k_wxw<G, RD, RB, ILV, SYNC, NQ, NW>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(n_wg), dim3(256), lds, 0, src, n_stages, sink, cyc);
+    for (int rep = 0; rep < 3; ++rep) hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64 * NW), lds, 0, src, n_stages, sink, cyc);
     if (hipDeviceSynchronize() != hipSuccess) { printf("%s: launch failed\n", name); return; }
     std::vector<long long> h(n_wg);
     (void)hipMemcpy(h.data(), cyc, n_wg * 8, hipMemcpyDeviceToHost);
@@ -133,8 +170,8 @@ static void run(const char* name, const float4* src, size_t region_bytes, int n_
     for (auto v : h) mean += (double)v;
     mean /= n_wg;
     const double items = (double)n_stages * NQ;
-    printf("%-34s G=%d RD=%2d RB=%d NQ=%2d %3d WGs: %7.1f cycles/item  %5.1f B/clk/CU  (MFMA floor %d cycles/item)\n", name, G, RD,
-           RB, NQ, n_wg, mean / items, item_round * items / mean, ILV == 2 ? 0 : 32 * G * RB);
+    printf("%-34s G=%d RD=%2d RB=%d NQ=%2d NW=%d %3d WGs: %7.1f cycles per 20 KiB  %5.1f B/clk/CU\n", name, G, RD,
+           RB, NQ, NW, n_wg, mean / items * (20480.0 / item_round), item_round * items / mean);
 }
 
 int main() {
@@ -156,6 +193,28 @@ int main() {
         run<5, 6, 2, 1, 0, 24>("interleaved, 2 row blocks", src, region, n_wg, sink, cyc);
         run<5, 6, 2, 1, 1, 24>("interleaved, 2 row blocks + sync", src, region, n_wg, sink, cyc);
         run<5, 8, 2, 1, 0, 24>("interleaved, 2 row blocks, ring 8", src, region, n_wg, sink, cyc);
+        // two waves per SIMD (8 per workgroup, each half the K range): does the second wave fill the request-issue stalls?
+        run<5, 3, 1, 2, 0, 12, 8>("8 waves: pure stream, ring 3", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 0, 12, 8>("8 waves: MFMAs then refill, ring 3", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 1, 12, 8>("8 waves: ... + stage sync", src, region, n_wg, sink, cyc);
+        run<5, 4, 1, 0, 1, 12, 8>("8 waves: ring 4 + stage sync", src, region, n_wg, sink, cyc);
+        run<5, 6, 1, 0, 1, 12, 8>("8 waves: ring 6 + stage sync", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 2, 12, 8>("8 waves: store + 1 barrier", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 3, 12, 8>("8 waves: 2 bare barriers", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 4, 12, 8>("8 waves: 1 barrier + slice reduce", src, region, n_wg, sink, cyc);
+        run<5, 6, 1, 0, 4, 12, 8>("8 waves: same, ring 6", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 6, 12, 8>("8 waves: software barrier (LDS counter)", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 2, 6, 12, 8>("8 waves: pure stream + software barrier", src, region, n_wg, sink, cyc);
+        run<5, 6, 1, 0, 6, 24, 4>("4 waves: software barrier", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 51, 12, 8>("8 waves: 2 barriers + skew 64", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 53, 12, 8>("8 waves: 2 barriers + skew 192", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 56, 12, 8>("8 waves: 2 barriers + skew 384", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 0, 3, 24, 8>("8 waves: 2 barriers per 24 items", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 3, 3, 12, 8>("8 waves: MFMA only + 2 barriers", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 3, 0, 12, 8>("8 waves: MFMA only", src, region, n_wg, sink, cyc);
+        run<5, 3, 1, 2, 3, 12, 8>("8 waves: pure stream + 2 barriers", src, region, n_wg, sink, cyc);
+        run<5, 6, 1, 0, 3, 24, 4>("4 waves: 2 bare barriers", src, region, n_wg, sink, cyc);
+        run<5, 6, 1, 0, 4, 24, 4>("4 waves: 1 barrier + slice reduce", src, region, n_wg, sink, cyc);
     }
     return 0;
 }
