@@ -455,6 +455,54 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
     if (t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = contrib; a.row_dist[g] = dist; }
 }
 
+// Chain initialisation on 4-chain tiles (HMC runs of <= 1152 chains): the flow SAMPLE stays on the 16-chain kernel
+// (fabhip_flow_sample: no 4-chain tile code for that direction), this kernel re-evaluates log q + d/dx at the samples (the
+// reference does, base.py:65-68), the target and the initial log-weight - two of the three flow passes of k_ais_init on
+// 256 instead of 64 workgroups.
+template <int NTWM, bool STREAM>
+__global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
+                                                          const float* __restrict__ packed, TargetDev tg,
+                                                          const float* __restrict__ lq0, PointDev pt,
+                                                          float* __restrict__ log_w, float* __restrict__ base_log_w,
+                                                          fabhip_anneal an, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid4 t4;
+    Tid t;
+    const int D = f.D;
+    const long row0 = (long)blockIdx.x * R4;
+    const bool ew = t.tid < 64;
+    const long g = row0 + t.row;
+    float* XP = lds + x.o_XP;
+    float* GP = lds + x.o_GP;
+    for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
+    for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) {
+        const int r = e / R4_DS, j = e % R4_DS;
+        const float v = (j < D && row0 + r < B) ? pt.x[(row0 + r) * D + j] : 0.f;
+        lds[l.o_X0 + e] = v;
+        if (j < D) XP[r * D + j] = v;
+    }
+    __syncthreads();
+    int goff = 0;
+    float lq;
+    if constexpr (STREAM) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
+    else lq = flow_log_prob_r4<NTWM, 2, 2, 2, 1>(f, rd, l, packed, lds, t4, &goff);
+    if (!ew) return;
+    const float lp = target_tile<true>(tg, XP, D, GP, D, t);
+    if (g < B) {
+        for (int j = t.c; j < D; j += 16) {
+            pt.gq[g * D + j] = lds[goff + t.row * R4_DS + j];
+            pt.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) {
+            const float q0 = lq0[g];
+            pt.lq[g] = lq;
+            pt.lp[g] = lp;
+            log_w[g] = (an.c_q * lq + an.c_p * lp) - q0;
+            if (base_log_w) base_log_w[g] = lp - q0;
+        }
+    }
+}
+
 // step-size adaptation from the block partials (hmc.py:122-123,162-170), fixed summation order
 // (4-chain tiles hand over per-chain values: the 64 threads first add each block's 16 rows in row order, which is
 // what a 16-chain workgroup writes, so both tile shapes give the step-size rule bit-identical sums)
@@ -809,6 +857,31 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
 }
 
 template <int NTWM>
+static int launch_ais_init_r4(const FlowDims& f, const float* packed, const TargetDev& tg, const float* lq0,
+                              const PointDev& pt, float* log_w, float* base_log_w, fabhip_anneal an, long B, hipStream_t st) {
+    const R4Dims rd = make_r4_dims(f);
+    const R4Lds l = make_r4_lds(f);
+    const ExtraLds4 x = make_extra_lds4(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    const dim3 grid((unsigned)((B + R4 - 1) / R4));
+    if constexpr (NTWM > 5) {
+        return FABHIP_ENOTSUP;
+    } else if (NTWM >= 2 && f.o_r4s >= 0) {
+        constexpr int NS = NTWM >= 2 ? NTWM : 2;
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NS, true>, bytes));
+        hipLaunchKernelGGL((k_ais_init_r4<NS, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, pt, log_w,
+                           base_log_w, an, B);
+    } else if constexpr (NTWM < 5) {
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NTWM, false>, bytes));
+        hipLaunchKernelGGL((k_ais_init_r4<NTWM, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, pt,
+                           log_w, base_log_w, an, B);
+    } else {
+        return FABHIP_ENOTSUP;
+    }
+    return check_launch();
+}
+
+template <int NTWM>
 static int launch_metropolis(const FlowDims& f, const float* packed, const TargetDev& tg, const MetK& a, hipStream_t st) {
     const FlowLds l = make_flow_lds(f, false);
     const ExtraLds x = make_extra_lds(l, f.D);
@@ -1152,8 +1225,14 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     fabhip_anneal_coefs(a->betas[1], a->alpha, a->p_target, &a1);
     {
         const PointDev pt = make_point_dev(a->point);
-        FAB_DISPATCH_NTW_NORET(f, launch_ais_init, f, a->flow.packed, tg, a->eps0, pt, a->log_w, a->base_log_w, a1,
-                               hmc ? 1 : 0, B, st);
+        if (hmc && use_r4_tiles(f, B) && option(FABHIP_OPT_R4_STREAM) != 0) {
+            // 4-chain tiles: flow sample (16-chain kernel) -> x, log q0 ; then log q + d/dx, target, log w on 4-chain tiles
+            FAB_TRY(fabhip_flow_sample(&a->flow, a->eps0, a->point.x, lwb, B, stream));
+            FAB_DISPATCH_NTW_NORET(f, launch_ais_init_r4, f, a->flow.packed, tg, lwb, pt, a->log_w, a->base_log_w, a1, B, st);
+        } else {
+            FAB_DISPATCH_NTW_NORET(f, launch_ais_init, f, a->flow.packed, tg, a->eps0, pt, a->log_w, a->base_log_w, a1,
+                                   hmc ? 1 : 0, B, st);
+        }
     }
     // 2. remove nan/inf ("chain init")
     FAB_TRY(compact(a, nullptr, a->n_valid, tmp, dest, a->base_log_w, st));

@@ -273,8 +273,13 @@ __device__ __forceinline__ float exp_spec(float x) {
 }
 
 __device__ __forceinline__ unsigned long long fixed_weight(float w, float mx) {
-    if (!isfinite(w)) return 0ull;
-    return (unsigned long long)(exp_spec(w - mx) * 68719476736.0f);   // floor(p * 2^36), exact scaling
+    // floor(p * 2^36): the scaling is exact, and so is the split into two 32-bit halves (v < 2^37 carries 24 significant
+    // bits: hi = trunc(v 2^-32), v - hi 2^32 is a sub-range of those bits) - two v_cvt_u32_f32 instead of the generic
+    // float -> uint64 sequence.  Non-finite weights count 0.
+    const float v = isfinite(w) ? exp_spec(w - mx) * 68719476736.0f : 0.f;
+    const unsigned hi = (unsigned)(v * 2.3283064365386963e-10f);
+    const unsigned lo = (unsigned)(v - (float)hi * 4294967296.0f);
+    return ((unsigned long long)hi << 32) | lo;
 }
 
 __device__ __forceinline__ unsigned long long shfl_up_u64(unsigned long long v, int off) {
@@ -900,6 +905,22 @@ __device__ __forceinline__ int stratum_rel(const Strata& m, unsigned long long c
     return (int)(k - Kref);
 }
 
+// The same for the items of ONE wave whose strata span T < 2^20: relative to the wave's first stratum K0 the quotient is
+// small, so an fp32 estimate of ceil(X / S), X = Bw + (d << F) with the wave constant Bw = (c_start << F) - U - K0 S in
+// (-S, 0], is off by less than one stratum and ONE exact 64-bit check decides (branch-free: 22 instead of ~45
+// instructions + 3 divergent branches per item).  Same value as stratum_rel(..., Kref = K0) by construction.
+__device__ __forceinline__ int stratum_rel_small(const Strata& m, long long Bw, float invS_f, unsigned long long C_abs,
+                                                 unsigned long long d, int ns_rel) {
+    const long long X = Bw + (long long)(d << m.F);
+    const float xf = (float)(int)(X >> 32) * 4294967296.0f + (float)(unsigned)X;
+    int k = (int)ceilf(xf * invS_f);
+    k = k < 0 ? 0 : (k > ns_rel ? ns_rel : k);
+    const long long R = X - (long long)((unsigned long long)(unsigned)k * m.S);        // X - k S, exact
+    k += (R > 0 && k < ns_rel) ? 1 : 0;
+    k -= (R + (long long)m.S <= 0 && k > 0) ? 1 : 0;
+    return C_abs >= m.total ? ns_rel : k;
+}
+
 __global__ __launch_bounds__(64 * EM_NW) void k_emit_systematic(const float* __restrict__ lw, long n,
                                                                 const float* __restrict__ max_val,
                                                                 const unsigned long long* __restrict__ wave_sum,
@@ -962,15 +983,24 @@ __global__ __launch_bounds__(64 * EM_NW) void k_emit_systematic(const float* __r
     const unsigned long long B0 = c_start << m.F;
     const double num0 = B0 >= m.U ? (double)(B0 - m.U) : -(double)(m.U - B0);
     const long K0 = (long)stratum_rel(m, c_start, 0ull, num0, pow2F, invS, 0, ns) ;   // wave-uniform (Kref = 0: < 2^31)
+    const int T = stratum_rel(m, c_start, wtot, num0, pow2F, invS, K0, ns);            // strata owned by this wave (uniform)
+    if (T <= 0) return;
     int ke[16];
+    if (T < (1 << 20)) {                                   // wave-uniform: the usual case
+        const long long Bw = (long long)(B0 - m.U - (unsigned long long)K0 * m.S);
+        const float invS_f = 1.0f / (float)m.S;
+        const int ns_rel = (int)(ns - K0);
 #pragma unroll
-    for (int j = 0; j < 16; ++j)
-        ke[j] = (j > 0 && run[j] == run[j - 1]) ? ke[j - 1]
-                                                : stratum_rel(m, c_start, lane_off + run[j], num0, pow2F, invS, K0, ns);
+        for (int j = 0; j < 16; ++j)
+            ke[j] = stratum_rel_small(m, Bw, invS_f, c_start + lane_off + run[j], lane_off + run[j], ns_rel);
+    } else {                                               // giant runs: float64 estimate per item
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            ke[j] = (j > 0 && run[j] == run[j - 1]) ? ke[j - 1]
+                                                    : stratum_rel(m, c_start, lane_off + run[j], num0, pow2F, invS, K0, ns);
+    }
     int kprev = __shfl_up(ke[15], 1);
     if (lane == 0) kprev = 0;
-    const int T = __shfl(ke[15], 63);                      // strata owned by this wave: K0 .. K0 + T
-    if (T <= 0) return;
     __builtin_amdgcn_wave_barrier();                       // every lane is done reading the float staging
     const long item0 = wbase;
     // giant runs: publish, the grid-wide fill kernel writes them; this wave skips windows entirely inside one
