@@ -129,8 +129,6 @@ class HipShardBackend:
         self.ais, self.ops, self._ops_mod = ais, _ops.load(), _ops
         self.op = ais.transition_operator
         self.hmc = isinstance(self.op, HamiltonianMonteCarlo)
-        if not ais.is_native:
-            raise _ops.FabhipError("sharded AIS needs fabhip-native plug-ins (RealNVP flow, ManyWell / GMM target)")
 
     @property
     def n_transitions(self) -> int:
@@ -166,6 +164,12 @@ class HipShardBackend:
         if not self.hmc or self.op.n_outer != 1:
             raise self._ops_mod.FabhipError("exact sharded step-size adaptation: HMC with n_outer == 1 "
                                             "(every shipped config, experiments/setup_run.py:190)")
+        if not self.ais.is_native:
+            raise self._ops_mod.FabhipError("sharded AIS with step-size tuning on needs a RealNVP flow and a native target "
+                                            "(fabhip_ais_phase); other plug-ins: set_eval_mode(True), or tune on one rank")
+        op, ais = self.op, self.ais
+        if bool(op.p_target) != bool(ais.p_target) or (not ais.p_target and op.alpha != ais.alpha):
+            raise self._ops_mod.FabhipError("AIS and transition operator disagree on p_target / alpha")
         flow, _ = self.ais._native_parts()
         dev = flow._nf_model.q0.loc.device
         D, M = flow.dim, self.n_transitions
