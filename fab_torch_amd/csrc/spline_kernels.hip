@@ -41,6 +41,8 @@ struct SplineDims {
     int o_meta, o_unc, o_pfw, o_W0, o_b0, o_Wa, o_ba, o_Wb, o_bb, o_Wf, o_bf, o_WfT, o_WbT, o_WaT, o_W0T;
     int o_h;                             // fast mode: bf16 images [Wa | Wb | Wf (NCH chunks) | WfT | WbT | WaT], Wp^2/2 floats per Wp x Wp
     int layer_stride, o_base, total;
+    // 8-chain-tile image (spline_r8.h; Wp == 256 only, else o_r8 == 0): per layer [head | forward tiles | reverse tiles]
+    int o_r8, r8_head, r8_tpl, r8_layer; // head floats, 1-KiB tiles per wave and direction, floats per layer
 };
 
 FAB_HD SplineDims make_spline_dims(int D, int L, int W) {
@@ -72,6 +74,14 @@ FAB_HD SplineDims make_spline_dims(int D, int L, int W) {
     f.layer_stride = o;
     f.o_base = L * f.layer_stride;                         // scale[64], circ[64]
     f.total = f.o_base + 128;
+    f.o_r8 = 0;
+    f.r8_head = ((SP_META_ROWS + 2) * 64 + 1664 + 128) + 3 * 256 + 128 + f.NFP;   // spline_r8.h: S8H_*
+    f.r8_tpl = 16 + 64 * (2 + f.NCH);
+    f.r8_layer = f.r8_head + 2 * NWAVE * f.r8_tpl * 256;
+    if (f.NTWM == 4) {
+        f.o_r8 = (f.total + 255) & ~255;
+        f.total = f.o_r8 + L * f.r8_layer;
+    }
     return f;
 }
 
@@ -1120,6 +1130,8 @@ __device__ __forceinline__ void spline_logprob_body(const SplineDims& f, const N
 #undef SP_TL
 }
 
+#include "spline_r8.h"
+
 template <int NTWM, bool GRAD>
 __global__ __launch_bounds__(NTHREADS) void k_spline_logprob(SplineDims f, NetLds l, const float* __restrict__ packed,
                                                              const float* __restrict__ x, float* __restrict__ log_q,
@@ -1167,6 +1179,44 @@ static int launch_logprob(const SplineDims& f, const float* packed, const float*
         FAB_TRY(set_max_lds((const void*)k_spline_logprob<NTWM, false>, bytes));
         hipLaunchKernelGGL((k_spline_logprob<NTWM, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
                            Psave, bitsave, sp_timeline(st));
+    }
+    return check_launch();
+}
+
+// 8-chain tiles (spline_r8.h): hidden width padded to 256, fp32 path.  FABHIP_OPT_TILE_SHAPE 16 / 8 (or 4) forces a shape;
+// otherwise 8-chain tiles whenever 16-chain tiles would leave CUs without a workgroup.
+static int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+// one workgroup per CU (the kernel's registers allow no second one): 8-chain tiles up to 8 chains per CU = 2048 chains on
+// MI355X; above, 16-chain tiles (one round of up to 4096 chains) are at least as fast.
+static bool use_r8_tiles(const SplineDims& f, long B, int fast) {
+    if (f.NTWM != 4 || !f.o_r8 || fast) return false;
+    const int sel = option(FABHIP_OPT_TILE_SHAPE);
+    if (sel == 16) return false;
+    if (sel == 8 || sel == 4) return true;
+    return B <= (long)S8 * cu_count();
+}
+
+template <int NCH>
+static int launch_logprob_r8(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
+                             float* Zsave, float* Psave, hipStream_t st) {
+    const dim3 grid((unsigned)ceil_div((int)B, S8)), block(NTHREADS);
+    const S8Lds l = make_s8_lds(f, grad_x != nullptr);
+    const size_t bytes = (size_t)l.total * 4;
+    if (grad_x) {
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, true>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+                           Psave, sp_timeline(st));
+    } else {
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, false>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+                           Psave, sp_timeline(st));
     }
     return check_launch();
 }
@@ -1229,6 +1279,9 @@ int fabhip_spline_pack(const fabhip_spline_params* p, float* packed, fabhip_stre
         hipLaunchKernelGGL(k_spline_pack_layer, dim3(ceil_div(f.o_h, 256 * 8)), dim3(256), 0, st, f, s, l, packed);
         hipLaunchKernelGGL(k_spline_pack_bf16, dim3(ceil_div((4 + 2 * f.NCH) * (f.Wp * f.Wp / 2), 256 * 8)), dim3(256), 0, st,
                            f, s, l, packed);
+        if (f.o_r8)
+            hipLaunchKernelGGL(k_spline_pack_r8, dim3(ceil_div(f.r8_layer, 256 * 8)), dim3(256), 0, st, f, s,
+                               l > 0 ? p->meta[l - 1] : (const float*)nullptr, l, packed);
     }
     hipLaunchKernelGGL(k_spline_pack_base, dim3(1), dim3(64), 0, st, f, p->base_scale, p->base_circ, packed);
     return check_launch();
@@ -1266,6 +1319,14 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
     if (!tape && !option(FABHIP_OPT_SPLINE_STAGED)) {           // one launch (the staged kernels below: tape, debugging)
+        if (use_r8_tiles(f, (long)B, resolve_fast(flow->precision)))
+            switch (f.NCH) {
+                case 1: return launch_logprob_r8<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
+                case 2: return launch_logprob_r8<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
+                case 3: return launch_logprob_r8<3>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
+                case 4: return launch_logprob_r8<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
+                default: return FABHIP_ENOTSUP;
+            }
         if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);
         if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);
         if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);

@@ -1,0 +1,585 @@
+// 8-chain tiles (S8) for the one-launch spline density kernel: hidden width padded to 256 (the shape of BASELINE cfg 3 and
+// of the alanine-dipeptide flow), EIGHT chains per workgroup on v_mfma_f32_4x4x1_16b_f32.
+//
+// Why: k_spline_logprob (16 chains per workgroup) gives B / 16 workgroups - 128 of 256 CUs at cfg 3's 2048 chains - and its
+// element-wise stages (splines, reverse mode, tile reloads: a third of its time) run on those 128 CUs only.  With 8 chains
+// per workgroup 2048 chains fill the chip.
+//
+// GEMM shape: OUT[8][256] = ACT[8][K] @ B[K][256], N-split: wave w owns columns 64 w .. 64 w + 63 for all of K.  One
+// v_mfma_f32_4x4x1_16b = 16 independent 4x4 outer products: lane l = 4 b + j supplies A[i = l % 4] and B[64 w + l] and holds
+// D[i = VGPR r][64 w + l]; two row blocks (chains 0-3, 4-7) share every weight register.  The instruction has a ~54-cycle
+// dependent latency, so k mod 4 goes to four accumulators per row block (8 independent chains of 8 issue cycles each),
+// added as (a0 + a1) + (a2 + a3) at the end: no partial sums through LDS, ONE workgroup barrier per GEMM stage.
+//
+// Weight stream: every wave reads ITS tiles (1 KiB = 4 k x 64 columns) of a layer and direction as one contiguous stream in
+// the order it consumes them ([W0 | Wa | Wb | Wf chunks] forward, [WfT | WbT | WaT | W0T] reverse; k_spline_pack_r8),
+// through a ring of S8_RD = 32 tiles that stays full ACROSS the stages of a layer (requested at the layer top, topped up one
+// tile per k-quad, drained by the layer's last stage): the stream does not stop at stage boundaries.  The loads are issued
+// from inline asm with hand-counted s_waitcnt (flow_device.h) into ACCUMULATION registers ("=a"): hipcc copies / re-allocates
+// VGPRs it believes idle - an in-flight VGPR ring that outlives its loop got corrupted that way in round 1 - but the AGPR
+// file has no other tenant here, and v_mfma reads its B operand from it directly.
+// Everything else a layer needs (metadata rows, unconditional spline parameters, periodic-feature weights, biases) is one
+// contiguous head block per layer, copied to LDS at the layer top with plain loads BEFORE the ring is requested, so no
+// compiler-tracked load ever waits behind the stream.  ReLU decisions: one 64-bit ballot per (wave, chain), kept in LDS.
+// Included from spline_kernels.hip (namespace fab, after the rqs_* helpers).
+
+constexpr int S8 = 8;                  // chains per workgroup
+constexpr int S8_RD = 32;              // ring depth: 1-KiB tiles in flight per wave
+constexpr int S8_AS = 64 + 4;          // leading dim of the identity-feature tile (K = 64)
+constexpr int S8_WS = 256 + 4;         // leading dim of the hidden tiles
+constexpr int S8_INF = 1 << 20;
+
+// head block of a layer in the r8 image (floats); the first three regions sit where SplineDims puts them in a layer image
+constexpr int S8H_META = 0, S8H_UNC = (SP_META_ROWS + 2) * 64, S8H_PFW = S8H_UNC + 1664, S8H_B0 = S8H_PFW + 128,
+              S8H_BA = S8H_B0 + 256, S8H_BB = S8H_BA + 256, S8H_NXT = S8H_BB + 256, S8H_BF = S8H_NXT + 128;
+
+static_assert(S8H_BF == (SP_META_ROWS + 2) * 64 + 1664 + 128 + 3 * 256 + 128, "make_spline_dims: r8_head");
+FAB_HD int s8_head_floats(const SplineDims& f) { return f.r8_head; }                      // S8H_BF + NFP: a multiple of 128
+FAB_HD int s8_tiles_per_wave(const SplineDims& f) { return f.r8_tpl; }                    // per layer and direction: 16 + 64 (2 + NCH)
+FAB_HD long s8_layer_floats(const SplineDims& f) { return f.r8_layer; }
+
+struct S8Lds {
+    int PS;                            // leading dim of the conditioner-output tile
+    int o_A0, o_X1, o_X2, o_T, o_PT, o_ZT, o_GT, o_HD, o_MASK, total;      // PART (K-split partials of W0T) aliases X1
+};
+
+FAB_HD S8Lds make_s8_lds(const SplineDims& f, bool grad) {
+    S8Lds l;
+    l.PS = f.NFP + 4;
+    int o = 0;
+    l.o_A0 = o; o += S8 * S8_AS;
+    l.o_X1 = o; o += S8 * S8_WS;
+    l.o_X2 = o; o += S8 * S8_WS;
+    l.o_T = o; o += S8 * S8_WS;
+    l.o_PT = o; o += S8 * l.PS;
+    l.o_ZT = o; o += S8 * 64;
+    l.o_GT = o; if (grad) o += S8 * 64;
+    l.o_HD = o; o += s8_head_floats(f);
+    l.o_MASK = o; if (grad) o += f.L * 2 * NWAVE * S8 * 2;          // u64 words
+    l.total = (o + 3) & ~3;
+    return l;
+}
+
+struct Tid8 {
+    int tid, wave, lane, arow, row, c;
+    __device__ __forceinline__ Tid8() {
+        tid = threadIdx.x;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lane = tid & 63;
+        arow = lane & 3;               // the chain (of a row block) whose activations this lane feeds to the MFMA
+        row = tid >> 5;                // element-wise stages: 8 chains x 32 coordinate lanes
+        c = tid & 31;
+    }
+};
+
+__device__ __forceinline__ void s8_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ float row32_sum(float v) {
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void s8_for(F&& fn) {
+    if constexpr (I < N) {
+        fn(std::integral_constant<int, I>{});
+        s8_for<I + 1, N>(fn);
+    }
+}
+
+// ---- the wave's weight stream ---------------------------------------------------------------------------------------
+struct S8Stream {
+    f32x4 r[S8_RD];                    // ring slot of stream tile k: k % S8_RD   ("a" registers)
+    unsigned voff[8];                  // lane * 16 + 4096 j: with the 4 immediate offsets, 32 tiles from one scalar base
+    const float4* next;                // tile that step 0 of the next iteration requests
+};
+
+template <int IMM>
+__device__ __forceinline__ void s8_load(f32x4& dst, unsigned voff, const float4* sbase) {
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(IMM));
+}
+template <int IMM>
+__device__ __forceinline__ void s8_load_first(f32x4& dst, unsigned voff, const float4* sbase) {   // fresh scalar base: see gload16s_first
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(IMM));
+}
+template <int N>
+__device__ __forceinline__ void s8_wait(f32x4& r) {
+    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+    asm volatile("s_waitcnt vmcnt(%1)" : "+a"(r) : "n"(N));
+}
+
+__device__ __forceinline__ void s8_stream_init(S8Stream& s, const Tid8& t) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s.voff[j] = (unsigned)(t.lane * 16 + 4096 * j);
+}
+
+// layer top: request tiles 0 .. RD-2 of the wave's stream at `base`
+__device__ __forceinline__ void s8_prologue(S8Stream& s, const float4* base) {
+    s8_for<0, S8_RD - 1>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        if constexpr (d == 0) s8_load_first<0>(s.r[0], s.voff[0], base);
+        else s8_load<(d % 4) * 1024>(s.r[d], s.voff[d / 4], base);
+    });
+    s.next = base + (size_t)(S8_RD - 1) * 64;
+}
+
+// NSTEP k-quads (stream tiles T0 .. T0 + NSTEP - 1, T0 % RD == PHASE) of which the first USE are multiplied:
+//   acc[k % 4][rb] += A[rb][4 q + k] (x) B[4 q + k][64 w + lane]
+// REMAIN = stream tiles of this layer after T0 (S8_INF: more than 2 RD): a refill is issued only for a tile that exists and
+// the wait counts only loads that were issued (the last stages of a layer drain the ring).
+// `ap`: this lane's row of the activation tile at the iteration's first quad; `rb1`: float offset of row block 1.
+template <int NSTEP, int USE, int PHASE, int REMAIN>
+__device__ __forceinline__ void s8_iter(S8Stream& s, const float* ap, int rb1, f32x4 (&acc)[4][2]) {
+    float4 a0n = *reinterpret_cast<const float4*>(ap), a1n = *reinterpret_cast<const float4*>(ap + rb1);
+    s8_for<0, NSTEP>([&](auto dc) {
+        constexpr int d = decltype(dc)::value;
+        constexpr int slot = (PHASE + d) % S8_RD;
+        constexpr int left = REMAIN - d;                                   // tiles after this one
+        constexpr int N = left < S8_RD - 2 ? (left < 0 ? 0 : left) : S8_RD - 2;
+        s8_wait<N>(s.r[slot]);
+        __builtin_amdgcn_sched_barrier(0);
+        float4 a0 = a0n, a1 = a1n;
+        if constexpr (d < USE) {
+            if constexpr (d + 1 < USE) {
+                a0n = *reinterpret_cast<const float4*>(ap + 4 * (d + 1));
+                a1n = *reinterpret_cast<const float4*>(ap + rb1 + 4 * (d + 1));
+            }
+            acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, s.r[slot].x, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, s.r[slot].x, acc[0][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (d - 1 + S8_RD <= REMAIN) {                          // top up: tile T0 + d - 1 + RD into the slot of T0 + d - 1
+            constexpr int dp = (slot + S8_RD - 1) % S8_RD;
+            if constexpr (d == 0) s8_load_first<0>(s.r[dp], s.voff[0], s.next);
+            else s8_load<(d % 4) * 1024>(s.r[dp], s.voff[d / 4], s.next);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (d < USE) {
+            acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, s.r[slot].y, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, s.r[slot].y, acc[1][1], 0, 0, 0);
+            acc[2][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, s.r[slot].z, acc[2][0], 0, 0, 0);
+            acc[2][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, s.r[slot].z, acc[2][1], 0, 0, 0);
+            acc[3][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, s.r[slot].w, acc[3][0], 0, 0, 0);
+            acc[3][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, s.r[slot].w, acc[3][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+    s.next += (size_t)NSTEP * 64;
+}
+
+__device__ __forceinline__ void s8_zero(f32x4 (&acc)[4][2]) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) acc[k][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void s8_fold(const f32x4 (&acc)[4][2], f32x4 (&o)[2]) {
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb) o[rb] = (acc[0][rb] + acc[1][rb]) + (acc[2][rb] + acc[3][rb]);
+}
+
+// OUT[8][64 w ..] = ACT[8][256] @ B: two iterations of 32 k-quads; LAST = REMAIN of the second one.
+// Straight-line on purpose: around a loop hipcc carries the ring as loop variables and COPIES slots at the back edge
+// (v_accvgpr_mov of a register whose load is still in flight; seen in the ISA of a first version) - every iteration of
+// every stage of a layer is therefore unrolled (NCH is a template parameter of the kernel).
+template <int PHASE, int LAST = S8_INF>
+__device__ __forceinline__ void s8_gemm64(S8Stream& s, const float* act, int lda, const Tid8& t, f32x4 (&o)[2]) {
+    f32x4 acc[4][2];
+    s8_zero(acc);
+    const float* ap = act + t.arow * lda;
+    s8_iter<32, 32, PHASE, S8_INF>(s, ap, 4 * lda, acc);
+    s8_iter<32, 32, PHASE, LAST>(s, ap + 128, 4 * lda, acc);
+    s8_fold(acc, o);
+}
+
+// ---- image -----------------------------------------------------------------------------------------------------------
+// Layer block of the r8 image: [head | forward tiles: wave 0 .. 3 | reverse tiles: wave 0 .. 3], a wave's tiles in stream order.
+__global__ __launch_bounds__(256) void k_spline_pack_r8(SplineDims f, SplineSrc s, const float* __restrict__ prev_meta,
+                                                        int layer, float* __restrict__ packed) {
+    const int H = s8_head_floats(f), TPL = s8_tiles_per_wave(f);
+    const long total = s8_layer_floats(f);
+    float* __restrict__ dst = packed + f.o_r8 + (size_t)layer * total;
+    const int n_id = (int)s.meta[M_CNT * 64 + 0], n_tr = (int)s.meta[M_CNT * 64 + 1], n_pf = (int)s.meta[M_CNT * 64 + 2];
+    const int W = f.W, nout = n_tr * SP_NP;
+    for (long off = (long)blockIdx.x * blockDim.x + threadIdx.x; off < total; off += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (off < H) {
+            const int e = (int)off;
+            if (e < SP_META_ROWS * 64) v = s.meta[e];
+            else if (e < S8H_UNC) {                                            // M_POSID / M_POSTR (k_spline_pack_layer)
+                const int q = e - SP_META_ROWS * 64, row = q >> 6, j = q & 63;
+                const int cnt = row == 0 ? n_id : n_tr;
+                const float* feats = s.meta + (row == 0 ? M_IDF : M_TRF) * 64;
+                v = -1.f;
+                for (int i = 0; i < cnt; ++i) if ((int)feats[i] == j) v = (float)i;
+            } else if (e < S8H_PFW) {
+                const int q = e - S8H_UNC, i = q / SP_NP, p = q % SP_NP;
+                if (i < n_id && q < SP_MD * SP_NP)
+                    v = p < SP_K ? s.uw[i * SP_K + p] : (p < 2 * SP_K ? s.uh[i * SP_K + p - SP_K] : s.ud[i * (SP_K + 1) + p - 2 * SP_K]);
+            } else if (e < S8H_B0) { const int q = e - S8H_PFW; if (q < 2 * n_pf) v = s.pfw[q]; }
+            else if (e < S8H_BA) { const int j = e - S8H_B0; if (j < W) v = s.b0[j]; }
+            else if (e < S8H_BB) { const int j = e - S8H_BA; if (j < W) v = s.ba[j]; }
+            else if (e < S8H_NXT) { const int j = e - S8H_BB; if (j < W) v = s.bb[j]; }
+            else if (e < S8H_BF) {                                             // pre-shift of the NEXT stage (layer - 1): shift | on
+                const int q = e - S8H_NXT;
+                if (prev_meta) v = prev_meta[(q < 64 ? M_PRESH : M_PREON) * 64 + (q & 63)];
+            } else { const int j = e - S8H_BF; if (j < nout) v = s.bf[j]; }
+        } else {
+            const long e = off - H;
+            const int kk = (int)(e & 3), lane = (int)((e >> 2) & 63);
+            const long tl = e >> 8;
+            const int tile = (int)(tl % TPL), wave = (int)((tl / TPL) % NWAVE), dir = (int)(tl / ((long)TPL * NWAVE));
+            const int n = 64 * wave + lane;
+            if (dir == 0) {
+                if (tile < 16) {                                               // W0: B[k][n] = w0[n][k]
+                    const int k = 4 * tile + kk;
+                    if (k < n_id && n < W) v = s.w0[n * n_id + k];
+                } else {
+                    const int t2 = tile - 16, m = t2 >> 6, k = 4 * (t2 & 63) + kk;
+                    if (m == 0) { if (k < W && n < W) v = s.wa[n * W + k]; }
+                    else if (m == 1) { if (k < W && n < W) v = s.wb[n * W + k]; }
+                    else { const int col = (m - 2) * 256 + n; if (k < W && col < nout) v = s.wf[col * W + k]; }
+                }
+            } else {
+                const int nwf = 64 * f.NCH;
+                if (tile < nwf) {                                              // WfT: B[k][n] = wf[k][n]
+                    const int k = 4 * tile + kk;
+                    if (k < nout && n < W) v = s.wf[k * W + n];
+                } else {
+                    const int t2 = tile - nwf;
+                    if (t2 < 64) { const int k = 4 * t2 + kk; if (k < W && n < W) v = s.wb[k * W + n]; }
+                    else if (t2 < 128) { const int k = 4 * (t2 - 64) + kk; if (k < W && n < W) v = s.wa[k * W + n]; }
+                    else {                                                     // W0T, K split over the waves: B[k][i] = w0[k][i]
+                        const int k = 64 * wave + 4 * (t2 - 128) + kk;
+                        if (k < W && lane < n_id) v = s.w0[k * n_id + lane];
+                    }
+                }
+            }
+        }
+        dst[off] = v;
+    }
+}
+
+// ---- the kernel ------------------------------------------------------------------------------------------------------
+template <int NCH, bool GRAD>
+__global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8Lds l, const float* __restrict__ packed,
+                                                                const float* __restrict__ x, float* __restrict__ log_q,
+                                                                float* __restrict__ grad_x, long B, float* __restrict__ Zsave,
+                                                                float* __restrict__ Psave, long long* tlp) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid8 t;
+#define S8_TL(idx) do { if (tlp && blockIdx.x == 0 && threadIdx.x == 0) tlp[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    const long row0 = (long)blockIdx.x * S8;
+    float* A0 = lds + l.o_A0; float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* T = lds + l.o_T;
+    float* PT = lds + l.o_PT; float* ZT = lds + l.o_ZT; float* GT = lds + l.o_GT; float* HD = lds + l.o_HD;
+    float* PART = X1;
+    unsigned long long* MASK = reinterpret_cast<unsigned long long*>(lds + l.o_MASK);
+    const float* meta = HD + S8H_META;
+    const float isq = 1.f / sqrtf((float)f.W);
+    const int H = s8_head_floats(f), TPL = s8_tiles_per_wave(f);
+    const long lfl = s8_layer_floats(f);
+    const float* img = packed + f.o_r8;
+    const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
+    const int col = 64 * t.wave + t.lane;                                      // this lane's output column of a GEMM stage
+    S8Stream s;
+    s8_stream_init(s, t);
+    // The next layer's head block (and, in the reverse sweep, its state and conditioner-output tiles) is requested with plain
+    // loads at the start of a mid-layer GEMM stage - the requests queue up between the ring's tiles and have landed long before
+    // the layer ends - and committed to LDS at the next layer top: a layer top then starts on data that is already there.
+    constexpr int HP = (S8H_BF + 256 * NCH + 1023) / 1024;                     // float4 per thread of a head block
+    float4 hpre[HP], ppre[2][NCH];
+    float zpre[2];
+    auto head_fetch = [&](const float* Lr) {
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            const int e = t.tid + NTHREADS * i;
+            hpre[i] = e < H / 4 ? reinterpret_cast<const float4*>(Lr)[e] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto head_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < HP; ++i) {
+            const int e = t.tid + NTHREADS * i;
+            if (e < H / 4) reinterpret_cast<float4*>(HD)[e] = hpre[i];
+        }
+    };
+    const int w4max = (f.n_tr_max * SP_NP + 3) >> 2;
+    auto tile_fetch = [&](int layer) {                                         // reverse sweep: layer input state + conditioner output
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const long g = row0 + t.wave + NWAVE * i;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int c4 = t.lane + 64 * k;
+                ppre[i][k] = (g < B && c4 < w4max) ? *reinterpret_cast<const float4*>(Psave + (size_t)layer * ps + g * f.NFP + 4 * c4)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            const int e = t.tid + NTHREADS * i, r = e >> 6, j = e & 63;
+            zpre[i] = (j < f.D && row0 + r < B) ? Zsave[(size_t)layer * zs + (row0 + r) * f.D + j] : 0.f;
+        }
+    };
+    auto tile_commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+                *reinterpret_cast<float4*>(PT + (t.wave + NWAVE * i) * l.PS + 4 * (t.lane + 64 * k)) = ppre[i][k];
+            ZT[t.tid + NTHREADS * i] = zpre[i];
+        }
+    };
+    head_fetch(img + (size_t)(f.L - 1) * lfl);
+    // x <- wrap(x - pre-shift of the top layer)
+    {
+        const float* mt = packed + (size_t)(f.L - 1) * f.layer_stride + f.o_meta;
+        for (int e = t.tid; e < S8 * 64; e += NTHREADS) {
+            const int r = e >> 6, j = e & 63;
+            const long g = row0 + r;
+            float v = 0.f;
+            if (j < f.D && g < B) {
+                v = x[g * f.D + j];
+                if (mt[M_PREON * 64 + j] != 0.f) v = sp_wrap(v - mt[M_PRESH * 64 + j], mt[M_TB * 64 + j]);
+            }
+            ZT[e] = v;
+        }
+    }
+    float ld_acc = 0.f;
+    for (int layer = f.L - 1; layer >= 0; --layer) {
+        const float* Lr = img + (size_t)layer * lfl;
+        const bool tl = layer == 1;
+        __syncthreads();                                                       // ZT complete; HD / PT free
+        if (tl) S8_TL(0);
+        head_commit();
+        if (GRAD) {
+            for (int e = t.tid; e < S8 * f.D; e += NTHREADS) {
+                const int r = e / f.D, j = e % f.D;
+                if (row0 + r < B) Zsave[(size_t)layer * zs + (row0 + r) * f.D + j] = ZT[r * 64 + j];
+            }
+        }
+        __syncthreads();
+        s8_prologue(s, reinterpret_cast<const float4*>(Lr + H) + (size_t)t.wave * TPL * 64);
+        const int n_id = (int)meta[M_CNT * 64];
+        for (int e = t.tid; e < S8 * S8_AS; e += NTHREADS) {                   // identity coordinates + periodic features
+            const int r = e / S8_AS, i = e % S8_AS;
+            float v = 0.f;
+            if (i < n_id) {
+                v = ZT[r * 64 + (int)meta[M_IDF * 64 + i]];
+                if (meta[M_PFON * 64 + i] != 0.f) {
+                    const int k = (int)meta[M_PFK * 64 + i];
+                    const float sc = meta[M_PFS * 64 + i];
+                    v = HD[S8H_PFW + 2 * k] * sinf(sc * v) + HD[S8H_PFW + 2 * k + 1] * cosf(sc * v);
+                }
+            }
+            A0[e] = v;
+        }
+        s8_barrier();
+        if (tl) S8_TL(1);
+        f32x4 o[2];
+        float h0[2][4];
+        unsigned long long* mk = GRAD ? MASK + ((size_t)layer * 2 * NWAVE + t.wave) * S8 : nullptr;
+        {   // h0 = A0 W0 + b0; X2 = relu(h0)
+            f32x4 acc[4][2];
+            s8_zero(acc);
+            s8_iter<16, 16, 0, S8_INF>(s, A0 + t.arow * S8_AS, 4 * S8_AS, acc);
+            s8_fold(acc, o);
+            const float bv = HD[S8H_B0 + col];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = o[rb][r] + bv;
+                    h0[rb][r] = v;
+                    X2[(4 * rb + r) * S8_WS + col] = v > 0.f ? v : 0.f;
+                    if (GRAD) { const unsigned long long m = __ballot(v > 0.f); if (t.lane == 0) mk[4 * rb + r] = m; }
+                }
+        }
+        s8_barrier();
+        {   // t = relu(h0) Wa + ba; X1 = relu(t)
+            if (layer > 0) head_fetch(Lr - lfl);
+            s8_gemm64<16>(s, X2, S8_WS, t, o);
+            const float bv = HD[S8H_BA + col];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = o[rb][r] + bv;
+                    X1[(4 * rb + r) * S8_WS + col] = v > 0.f ? v : 0.f;
+                    if (GRAD) { const unsigned long long m = __ballot(v > 0.f); if (t.lane == 0) mk[NWAVE * S8 + 4 * rb + r] = m; }
+                }
+        }
+        s8_barrier();
+        {   // h1 = h0 + relu(t) Wb + bb -> T
+            s8_gemm64<16>(s, X1, S8_WS, t, o);
+            const float bv = HD[S8H_BB + col];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) T[(4 * rb + r) * S8_WS + col] = h0[rb][r] + (o[rb][r] + bv);
+        }
+        s8_barrier();
+        if (tl) S8_TL(2);
+        s8_for<0, NCH>([&](auto cc) {                                          // P = h1 Wf + bf, chunks of 256 outputs
+            constexpr int c = decltype(cc)::value;
+            if constexpr (c + 1 < NCH) s8_gemm64<16>(s, T, S8_WS, t, o);
+            else s8_gemm64<16, 31>(s, T, S8_WS, t, o);                         // the layer's last tiles: the ring drains
+            const float bv = HD[S8H_BF + c * 256 + col];
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) PT[(4 * rb + r) * l.PS + c * 256 + col] = o[rb][r] + bv;
+        });
+        __syncthreads();
+        if (tl) S8_TL(3);
+        const int n_tr = (int)meta[M_CNT * 64 + 1];
+        if (GRAD) {                                                            // conditioner output, for the reverse sweep
+            const int w4 = (n_tr * SP_NP + 3) >> 2;
+            for (int r = t.wave; r < S8; r += NWAVE)
+                if (row0 + r < B)
+                    for (int c4 = t.lane; c4 < w4; c4 += 64)
+                        *reinterpret_cast<float4*>(Psave + (size_t)layer * ps + (row0 + r) * f.NFP + 4 * c4) =
+                            *reinterpret_cast<const float4*>(PT + r * l.PS + 4 * c4);
+        }
+        for (int j = t.c; j < f.D; j += 32) {
+            float p[SP_NP];
+            int pos;
+            const int kind = sp_coord_params(f, HD, meta, PT, l.PS, t.row, j, isq, p, pos);
+            const float tb = meta[M_TB * 64 + j];
+            float out = ZT[t.row * 64 + j];
+            if (kind) {
+                Rqs sp;
+                rqs_setup(p, meta[M_CIRC * 64 + j] != 0.f, tb, sp);
+                float l1;
+                rqs_forward(sp, out, tb, out, l1);
+                ld_acc += l1;
+            }
+            if (layer > 0 && HD[S8H_NXT + 64 + j] != 0.f) out = sp_wrap(out - HD[S8H_NXT + j], tb);   // next stage's shift
+            ZT[t.row * 64 + j] = out;
+        }
+        if (tl) S8_TL(4);
+    }
+    __syncthreads();
+    if constexpr (GRAD) { head_fetch(img); tile_fetch(0); }
+    // base UniformGaussian
+    for (int j = t.c; j < f.D; j += 32) {
+        const float sc = packed[f.o_base + j];
+        const float z = ZT[t.row * 64 + j];
+        if (packed[f.o_base + 64 + j] != 0.f) { ld_acc += -logf(sc); if (GRAD) GT[t.row * 64 + j] = 0.f; }
+        else {
+            ld_acc += -0.5f * 1.8378770664093453f - logf(sc) - 0.5f * ((z / sc) * (z / sc));
+            if (GRAD) GT[t.row * 64 + j] = -(z / sc) / sc;
+        }
+    }
+    const float lq = row32_sum(ld_acc);
+    if (t.c == 0 && row0 + t.row < B) log_q[row0 + t.row] = lq;
+    if constexpr (GRAD) {
+        // ---- reverse sweep: GT = d log q / d(state), layers 0 .. L-1 -------------------------------------------------
+        for (int layer = 0; layer < f.L; ++layer) {
+            const float* Lr = img + (size_t)layer * lfl;
+            const bool tl = layer == 1;
+            __syncthreads();
+            if (tl) S8_TL(8);
+            head_commit();
+            tile_commit();
+            __syncthreads();
+            s8_prologue(s, reinterpret_cast<const float4*>(Lr + H) + (size_t)(NWAVE + t.wave) * TPL * 64);
+            if (tl) S8_TL(9);
+            const int n_id = (int)meta[M_CNT * 64], n_tr = (int)meta[M_CNT * 64 + 1];
+            for (int j = t.c; j < f.D; j += 32) {
+                float p[SP_NP];
+                int pos;
+                const int kind = sp_coord_params(f, HD, meta, PT, l.PS, t.row, j, isq, p, pos);
+                if (kind) {
+                    const float tb = meta[M_TB * 64 + j];
+                    const bool circ = meta[M_CIRC * 64 + j] != 0.f;
+                    Rqs sp;
+                    rqs_setup(p, circ, tb, sp);
+                    const float z = ZT[t.row * 64 + j], gy = GT[t.row * 64 + j];
+                    if (kind == 2) {
+                        float dp[SP_NP];
+                        GT[t.row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, isq, dp);
+#pragma unroll
+                        for (int k = 0; k < SP_NP; ++k) PT[t.row * l.PS + pos * SP_NP + k] = dp[k];
+                    } else {
+                        GT[t.row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, 1.f, nullptr);
+                    }
+                }
+            }
+            // columns of dP no coordinate owns: the stored tile has the conditioner's padding there, Psave beyond w4 was never written
+            for (int c = n_tr * SP_NP + t.c; c < f.NFP; c += 32) PT[t.row * l.PS + c] = 0.f;
+            s8_barrier();
+            if (tl) S8_TL(10);
+            const unsigned long long* mk = MASK + ((size_t)layer * 2 * NWAVE + t.wave) * S8;
+            f32x4 o[2];
+            float dh1[2][4];
+            {   // dh1 = dP WfT   (K = NFP)
+                f32x4 acc[4][2];
+                s8_zero(acc);
+                const float* ap = PT + t.arow * l.PS;
+                s8_for<0, 2 * NCH>([&](auto ic) { s8_iter<32, 32, 0, S8_INF>(s, ap + 128 * decltype(ic)::value, 4 * l.PS, acc); });
+                s8_fold(acc, o);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { dh1[rb][r] = o[rb][r]; X1[(4 * rb + r) * S8_WS + col] = o[rb][r]; }
+            }
+            s8_barrier();
+            if (tl) S8_TL(11);
+            {   // d relu(t) = dh1 WbT, masked by t > 0
+                if (layer + 1 < f.L) { head_fetch(Lr + lfl); tile_fetch(layer + 1); }
+                s8_gemm64<0>(s, X1, S8_WS, t, o);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        X2[(4 * rb + r) * S8_WS + col] = ((mk[NWAVE * S8 + 4 * rb + r] >> t.lane) & 1ull) ? o[rb][r] : 0.f;
+            }
+            s8_barrier();
+            {   // dh0 = dh1 + (d t WaT masked by h0 > 0)
+                s8_gemm64<0, 47>(s, X2, S8_WS, t, o);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        T[(4 * rb + r) * S8_WS + col] = dh1[rb][r] + (((mk[4 * rb + r] >> t.lane) & 1ull) ? o[rb][r] : 0.f);
+            }
+            s8_barrier();
+            if (tl) S8_TL(12);
+            {   // dA0 = dh0 W0T: K split over the waves (wave w: k = 64 w .. 64 w + 63), partial [8][64] products through LDS
+                f32x4 acc[4][2];
+                s8_zero(acc);
+                s8_iter<16, 16, 0, 15>(s, T + t.arow * S8_WS + 64 * t.wave, 4 * S8_WS, acc);
+                s8_fold(acc, o);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) PART[(t.wave * S8 + 4 * rb + r) * S8_AS + t.lane] = o[rb][r];
+            }
+            s8_barrier();
+            if (tl) S8_TL(13);
+            for (int e = t.tid; e < S8 * 64; e += NTHREADS) {
+                const int r = e >> 6, i = e & 63;
+                if (i < n_id) {
+                    const float* pp = PART + r * S8_AS + i;
+                    float d = (pp[0] + pp[S8 * S8_AS]) + (pp[2 * S8 * S8_AS] + pp[3 * S8 * S8_AS]);
+                    const int feat = (int)meta[M_IDF * 64 + i];
+                    if (meta[M_PFON * 64 + i] != 0.f) {
+                        const int k = (int)meta[M_PFK * 64 + i];
+                        const float sc = meta[M_PFS * 64 + i], zz = ZT[r * 64 + feat];
+                        d = d * (sc * (HD[S8H_PFW + 2 * k] * cosf(sc * zz) - HD[S8H_PFW + 2 * k + 1] * sinf(sc * zz)));
+                    }
+                    GT[r * 64 + feat] += d;
+                }
+            }
+            if (tl) S8_TL(14);
+        }
+        __syncthreads();
+        for (int e = t.tid; e < S8 * f.D; e += NTHREADS) {
+            const int r = e / f.D, j = e % f.D;
+            if (row0 + r < B) grad_x[(row0 + r) * f.D + j] = GT[r * 64 + j];
+        }
+    }
+#undef S8_TL
+}
