@@ -1193,32 +1193,46 @@ static int cu_count() {
     }();
     return n;
 }
-// one workgroup per CU (the kernel's registers allow no second one): 8-chain tiles up to 8 chains per CU = 2048 chains on
-// MI355X; above, 16-chain tiles (one round of up to 4096 chains) are at least as fast.
-static bool use_r8_tiles(const SplineDims& f, long B, int fast) {
-    if (f.NTWM != 4 || !f.o_r8 || fast) return false;
+// The 4x4x1 stream kernels (spline_r8.h; hidden width padded to 256, fp32 path): 8 chains per workgroup while that leaves no
+// CU with more than one workgroup (the kernel's registers allow no second one: 2048 chains on MI355X), 16 chains above.
+// FABHIP_OPT_TILE_SHAPE 8 (or 4) / 16 forces the tile; FABHIP_OPT_SPLINE_MFMA = 16 selects the 16x16x4 kernel
+// (k_spline_logprob: the only one for other widths and for fast mode).  Returns row blocks (0: not this kernel).
+static int r8_row_blocks(const SplineDims& f, long B, int fast) {
+    if (f.NTWM != 4 || !f.o_r8 || fast || option(FABHIP_OPT_SPLINE_MFMA) == 16) return 0;
     const int sel = option(FABHIP_OPT_TILE_SHAPE);
-    if (sel == 16) return false;
-    if (sel == 8 || sel == 4) return true;
-    return B <= (long)S8 * cu_count();
+    if (sel == 16) return 4;
+    if (sel == 8 || sel == 4) return 2;
+    return B <= 8L * cu_count() ? 2 : 4;
 }
 
-template <int NCH>
+template <int NCH, int RB>
 static int launch_logprob_r8(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
                              float* Zsave, float* Psave, hipStream_t st) {
-    const dim3 grid((unsigned)ceil_div((int)B, S8)), block(NTHREADS);
-    const S8Lds l = make_s8_lds(f, grad_x != nullptr);
+    const dim3 grid((unsigned)ceil_div((int)B, 4 * RB)), block(NTHREADS);
+    const S8Lds l = make_s8_lds(f, grad_x != nullptr, 4 * RB);
     const size_t bytes = (size_t)l.total * 4;
     if (grad_x) {
-        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, true>, bytes));
-        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, true>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
                            Psave, sp_timeline(st));
     } else {
-        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, false>, bytes));
-        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, false>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
                            Psave, sp_timeline(st));
     }
     return check_launch();
+}
+
+template <int RB>
+static int launch_logprob_r8_nch(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
+                                 float* Zsave, float* Psave, hipStream_t st) {
+    switch (f.NCH) {
+        case 1: return launch_logprob_r8<1, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
+        case 2: return launch_logprob_r8<2, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
+        case 3: return launch_logprob_r8<3, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
+        case 4: return launch_logprob_r8<4, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
+        default: return FABHIP_ENOTSUP;
+    }
 }
 
 template <int NTWM>
@@ -1319,14 +1333,9 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
     if (!tape && !option(FABHIP_OPT_SPLINE_STAGED)) {           // one launch (the staged kernels below: tape, debugging)
-        if (use_r8_tiles(f, (long)B, resolve_fast(flow->precision)))
-            switch (f.NCH) {
-                case 1: return launch_logprob_r8<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
-                case 2: return launch_logprob_r8<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
-                case 3: return launch_logprob_r8<3>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
-                case 4: return launch_logprob_r8<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
-                default: return FABHIP_ENOTSUP;
-            }
+        const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision));
+        if (rb == 2) return launch_logprob_r8_nch<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
+        if (rb == 4) return launch_logprob_r8_nch<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
         if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);
         if (f.NTWM == 2) return launch_logprob<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);
         if (f.NTWM == 4) return launch_logprob<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);

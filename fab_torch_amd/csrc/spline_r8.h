@@ -1,15 +1,18 @@
-// 8-chain tiles (S8) for the one-launch spline density kernel: hidden width padded to 256 (the shape of BASELINE cfg 3 and
-// of the alanine-dipeptide flow), EIGHT chains per workgroup on v_mfma_f32_4x4x1_16b_f32.
+// 4x4x1 stream kernels (S8) for the one-launch spline density: hidden width padded to 256 (the shape of BASELINE cfg 3 and of
+// the alanine-dipeptide flow), 4 RB chains per workgroup on v_mfma_f32_4x4x1_16b_f32 - RB = 2 row blocks (8 chains) while
+// that leaves at most one workgroup per CU, RB = 4 (16 chains) for larger batches; same arithmetic for both (bit-identical).
 //
-// Why: k_spline_logprob (16 chains per workgroup) gives B / 16 workgroups - 128 of 256 CUs at cfg 3's 2048 chains - and its
-// element-wise stages (splines, reverse mode, tile reloads: a third of its time) run on those 128 CUs only.  With 8 chains
-// per workgroup 2048 chains fill the chip.
+// Why: k_spline_logprob (16 chains per workgroup, 16x16x4 MFMAs) gives B / 16 workgroups - 128 of 256 CUs at cfg 3's 2048
+// chains - and its element-wise stages (splines, reverse mode, tile reloads: a third of its time) run on those 128 CUs only.
+// With 8 chains per workgroup 2048 chains fill the chip (0.43 ms per density + gradient instead of 0.74).
 //
-// GEMM shape: OUT[8][256] = ACT[8][K] @ B[K][256], N-split: wave w owns columns 64 w .. 64 w + 63 for all of K.  One
+// GEMM shape: OUT[4 RB][256] = ACT[4 RB][K] @ B[K][256], N-split: wave w owns columns 64 w .. 64 w + 63 for all of K.  One
 // v_mfma_f32_4x4x1_16b = 16 independent 4x4 outer products: lane l = 4 b + j supplies A[i = l % 4] and B[64 w + l] and holds
-// D[i = VGPR r][64 w + l]; two row blocks (chains 0-3, 4-7) share every weight register.  The instruction has a ~54-cycle
-// dependent latency, so k mod 4 goes to four accumulators per row block (8 independent chains of 8 issue cycles each),
-// added as (a0 + a1) + (a2 + a3) at the end: no partial sums through LDS, ONE workgroup barrier per GEMM stage.
+// D[i = VGPR r][64 w + l]; the row blocks (chains 0-3, 4-7, ..) share every weight register.  The instruction has a ~54-cycle
+// dependent latency (and issues every ~11 cycles, not 8: measured), so k mod 4 goes to four accumulators per row block
+// (>= 8 independent chains), added as (a0 + a1) + (a2 + a3) at the end: no partial sums through LDS, ONE workgroup barrier per
+// GEMM stage.  Measured: 98 cycles per k-quad (8 MFMAs + one 1-KiB tile per wave) at RB = 2 = 0.9 of the instruction's
+// issue rate, 47 B/clk per CU of weight stream; 186 at RB = 4.
 //
 // Weight stream: every wave reads ITS tiles (1 KiB = 4 k x 64 columns) of a layer and direction as one contiguous stream in
 // the order it consumes them ([W0 | Wa | Wb | Wf chunks] forward, [WfT | WbT | WaT | W0T] reverse; k_spline_pack_r8),
@@ -17,13 +20,13 @@
 // tile per k-quad, drained by the layer's last stage): the stream does not stop at stage boundaries.  The loads are issued
 // from inline asm with hand-counted s_waitcnt (flow_device.h) into ACCUMULATION registers ("=a"): hipcc copies / re-allocates
 // VGPRs it believes idle - an in-flight VGPR ring that outlives its loop got corrupted that way in round 1 - but the AGPR
-// file has no other tenant here, and v_mfma reads its B operand from it directly.
+// file has no other tenant here, and v_mfma reads its B operand from it directly.  tools/check_r8_isa.py walks the ISA of
+// every instantiation and fails if any instruction touches an AGPR whose load may still be in flight.
 // Everything else a layer needs (metadata rows, unconditional spline parameters, periodic-feature weights, biases) is one
 // contiguous head block per layer, copied to LDS at the layer top with plain loads BEFORE the ring is requested, so no
 // compiler-tracked load ever waits behind the stream.  ReLU decisions: one 64-bit ballot per (wave, chain), kept in LDS.
 // Included from spline_kernels.hip (namespace fab, after the rqs_* helpers).
 
-constexpr int S8 = 8;                  // chains per workgroup
 constexpr int S8_RD = 32;              // ring depth: 1-KiB tiles in flight per wave
 constexpr int S8_AS = 64 + 4;          // leading dim of the identity-feature tile (K = 64)
 constexpr int S8_WS = 256 + 4;         // leading dim of the hidden tiles
@@ -40,22 +43,22 @@ FAB_HD long s8_layer_floats(const SplineDims& f) { return f.r8_layer; }
 
 struct S8Lds {
     int PS;                            // leading dim of the conditioner-output tile
-    int o_A0, o_X1, o_X2, o_T, o_PT, o_ZT, o_GT, o_HD, o_MASK, total;      // PART (K-split partials of W0T) aliases X1
+    int o_A0, o_X1, o_X2, o_T, o_PT, o_ZT, o_GT, o_HD, o_MASK, total;      // PART (K-split partials of W0T, [4][rows][AS]) lies over X1 | X2
 };
 
-FAB_HD S8Lds make_s8_lds(const SplineDims& f, bool grad) {
+FAB_HD S8Lds make_s8_lds(const SplineDims& f, bool grad, int rows) {
     S8Lds l;
     l.PS = f.NFP + 4;
     int o = 0;
-    l.o_A0 = o; o += S8 * S8_AS;
-    l.o_X1 = o; o += S8 * S8_WS;
-    l.o_X2 = o; o += S8 * S8_WS;
-    l.o_T = o; o += S8 * S8_WS;
-    l.o_PT = o; o += S8 * l.PS;
-    l.o_ZT = o; o += S8 * 64;
-    l.o_GT = o; if (grad) o += S8 * 64;
+    l.o_A0 = o; o += rows * S8_AS;
+    l.o_X1 = o; o += rows * S8_WS;
+    l.o_X2 = o; o += rows * S8_WS;
+    l.o_T = o; o += rows * S8_WS;
+    l.o_PT = o; o += rows * l.PS;
+    l.o_ZT = o; o += rows * 64;
+    l.o_GT = o; if (grad) o += rows * 64;
     l.o_HD = o; o += s8_head_floats(f);
-    l.o_MASK = o; if (grad) o += f.L * 2 * NWAVE * S8 * 2;          // u64 words
+    l.o_MASK = o; if (grad) o += f.L * 2 * NWAVE * rows * 2;          // u64 words
     l.total = (o + 3) & ~3;
     return l;
 }
@@ -132,9 +135,18 @@ __device__ __forceinline__ void s8_prologue(S8Stream& s, const float4* base) {
 // REMAIN = stream tiles of this layer after T0 (S8_INF: more than 2 RD): a refill is issued only for a tile that exists and
 // the wait counts only loads that were issued (the last stages of a layer drain the ring).
 // `ap`: this lane's row of the activation tile at the iteration's first quad; `rb1`: float offset of row block 1.
-template <int NSTEP, int USE, int PHASE, int REMAIN>
-__device__ __forceinline__ void s8_iter(S8Stream& s, const float* ap, int rb1, f32x4 (&acc)[4][2]) {
-    float4 a0n = *reinterpret_cast<const float4*>(ap), a1n = *reinterpret_cast<const float4*>(ap + rb1);
+template <int RB>
+struct S8Acc {
+    static constexpr int KI = 4;                                           // accumulators per row block (k mod 4): the same sums for every RB
+    f32x4 a[KI][RB];
+};
+
+template <int NSTEP, int USE, int PHASE, int REMAIN, int RB>
+__device__ __forceinline__ void s8_iter(S8Stream& s, const float* ap, int rb1, S8Acc<RB>& acc) {
+    constexpr int KI = S8Acc<RB>::KI;
+    float4 an[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) an[rb] = *reinterpret_cast<const float4*>(ap + rb * rb1);
     s8_for<0, NSTEP>([&](auto dc) {
         constexpr int d = decltype(dc)::value;
         constexpr int slot = (PHASE + d) % S8_RD;
@@ -142,14 +154,17 @@ __device__ __forceinline__ void s8_iter(S8Stream& s, const float* ap, int rb1, f
         constexpr int N = left < S8_RD - 2 ? (left < 0 ? 0 : left) : S8_RD - 2;
         s8_wait<N>(s.r[slot]);
         __builtin_amdgcn_sched_barrier(0);
-        float4 a0 = a0n, a1 = a1n;
+        float4 a[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) a[rb] = an[rb];
         if constexpr (d < USE) {
             if constexpr (d + 1 < USE) {
-                a0n = *reinterpret_cast<const float4*>(ap + 4 * (d + 1));
-                a1n = *reinterpret_cast<const float4*>(ap + rb1 + 4 * (d + 1));
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) an[rb] = *reinterpret_cast<const float4*>(ap + rb * rb1 + 4 * (d + 1));
             }
-            acc[0][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.x, s.r[slot].x, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.x, s.r[slot].x, acc[0][1], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc.a[0][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].x, s.r[slot].x, acc.a[0][rb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (d - 1 + S8_RD <= REMAIN) {                          // top up: tile T0 + d - 1 + RD into the slot of T0 + d - 1
@@ -159,36 +174,44 @@ __device__ __forceinline__ void s8_iter(S8Stream& s, const float* ap, int rb1, f
         }
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (d < USE) {
-            acc[1][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.y, s.r[slot].y, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.y, s.r[slot].y, acc[1][1], 0, 0, 0);
-            acc[2][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.z, s.r[slot].z, acc[2][0], 0, 0, 0);
-            acc[2][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.z, s.r[slot].z, acc[2][1], 0, 0, 0);
-            acc[3][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(a0.w, s.r[slot].w, acc[3][0], 0, 0, 0);
-            acc[3][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(a1.w, s.r[slot].w, acc[3][1], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc.a[1 % KI][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].y, s.r[slot].y, acc.a[1 % KI][rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc.a[2 % KI][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].z, s.r[slot].z, acc.a[2 % KI][rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+                acc.a[3 % KI][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].w, s.r[slot].w, acc.a[3 % KI][rb], 0, 0, 0);
         }
         __builtin_amdgcn_sched_barrier(0);
     });
     s.next += (size_t)NSTEP * 64;
 }
 
-__device__ __forceinline__ void s8_zero(f32x4 (&acc)[4][2]) {
+template <int RB>
+__device__ __forceinline__ void s8_zero(S8Acc<RB>& acc) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
+    for (int k = 0; k < S8Acc<RB>::KI; ++k)
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb) acc[k][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int rb = 0; rb < RB; ++rb) acc.a[k][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
-__device__ __forceinline__ void s8_fold(const f32x4 (&acc)[4][2], f32x4 (&o)[2]) {
+template <int RB>
+__device__ __forceinline__ void s8_fold(const S8Acc<RB>& acc, f32x4 (&o)[RB]) {
 #pragma unroll
-    for (int rb = 0; rb < 2; ++rb) o[rb] = (acc[0][rb] + acc[1][rb]) + (acc[2][rb] + acc[3][rb]);
+    for (int rb = 0; rb < RB; ++rb) {
+        if constexpr (S8Acc<RB>::KI == 4) o[rb] = (acc.a[0][rb] + acc.a[1][rb]) + (acc.a[2][rb] + acc.a[3][rb]);
+        else o[rb] = acc.a[0][rb] + acc.a[1][rb];
+    }
 }
 
-// OUT[8][64 w ..] = ACT[8][256] @ B: two iterations of 32 k-quads; LAST = REMAIN of the second one.
+// OUT[4 RB][64 w ..] = ACT[4 RB][256] @ B: two iterations of 32 k-quads; LAST = REMAIN of the second one.
 // Straight-line on purpose: around a loop hipcc carries the ring as loop variables and COPIES slots at the back edge
 // (v_accvgpr_mov of a register whose load is still in flight; seen in the ISA of a first version) - every iteration of
 // every stage of a layer is therefore unrolled (NCH is a template parameter of the kernel).
-template <int PHASE, int LAST = S8_INF>
-__device__ __forceinline__ void s8_gemm64(S8Stream& s, const float* act, int lda, const Tid8& t, f32x4 (&o)[2]) {
-    f32x4 acc[4][2];
+template <int PHASE, int RB, int LAST = S8_INF>
+__device__ __forceinline__ void s8_gemm64(S8Stream& s, const float* act, int lda, const Tid8& t, f32x4 (&o)[RB]) {
+    S8Acc<RB> acc;
     s8_zero(acc);
     const float* ap = act + t.arow * lda;
     s8_iter<32, 32, PHASE, S8_INF>(s, ap, 4 * lda, acc);
@@ -265,15 +288,16 @@ __global__ __launch_bounds__(256) void k_spline_pack_r8(SplineDims f, SplineSrc 
 }
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
-template <int NCH, bool GRAD>
+template <int NCH, int RB, bool GRAD>
 __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8Lds l, const float* __restrict__ packed,
                                                                 const float* __restrict__ x, float* __restrict__ log_q,
                                                                 float* __restrict__ grad_x, long B, float* __restrict__ Zsave,
                                                                 float* __restrict__ Psave, long long* tlp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid8 t;
+    constexpr int R8 = 4 * RB;                                                 // chains of this workgroup
 #define S8_TL(idx) do { if (tlp && blockIdx.x == 0 && threadIdx.x == 0) tlp[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
-    const long row0 = (long)blockIdx.x * S8;
+    const long row0 = (long)blockIdx.x * R8;
     float* A0 = lds + l.o_A0; float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* T = lds + l.o_T;
     float* PT = lds + l.o_PT; float* ZT = lds + l.o_ZT; float* GT = lds + l.o_GT; float* HD = lds + l.o_HD;
     float* PART = X1;
@@ -291,8 +315,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     // loads at the start of a mid-layer GEMM stage - the requests queue up between the ring's tiles and have landed long before
     // the layer ends - and committed to LDS at the next layer top: a layer top then starts on data that is already there.
     constexpr int HP = (S8H_BF + 256 * NCH + 1023) / 1024;                     // float4 per thread of a head block
-    float4 hpre[HP], ppre[2][NCH];
-    float zpre[2];
+    constexpr bool TPRE = RB * NCH <= 8;                                       // else the tile prefetch does not fit the VGPRs: loaded at the layer top
+    float4 hpre[HP], ppre[TPRE ? RB : 1][TPRE ? NCH : 1];
+    float zpre[RB];
     auto head_fetch = [&](const float* Lr) {
 #pragma unroll
         for (int i = 0; i < HP; ++i) {
@@ -310,10 +335,10 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     const int w4max = (f.n_tr_max * SP_NP + 3) >> 2;
     auto tile_fetch = [&](int layer) {                                         // reverse sweep: layer input state + conditioner output
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RB; ++i) {
             const long g = row0 + t.wave + NWAVE * i;
 #pragma unroll
-            for (int k = 0; k < NCH; ++k) {
+            for (int k = 0; k < (TPRE ? NCH : 0); ++k) {
                 const int c4 = t.lane + 64 * k;
                 ppre[i][k] = (g < B && c4 < w4max) ? *reinterpret_cast<const float4*>(Psave + (size_t)layer * ps + g * f.NFP + 4 * c4)
                                                    : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -322,12 +347,21 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             zpre[i] = (j < f.D && row0 + r < B) ? Zsave[(size_t)layer * zs + (row0 + r) * f.D + j] : 0.f;
         }
     };
-    auto tile_commit = [&]() {
+    auto tile_commit = [&](int layer) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RB; ++i) {
 #pragma unroll
-            for (int k = 0; k < NCH; ++k)
-                *reinterpret_cast<float4*>(PT + (t.wave + NWAVE * i) * l.PS + 4 * (t.lane + 64 * k)) = ppre[i][k];
+            for (int k = 0; k < NCH; ++k) {
+                float4 v;
+                if constexpr (TPRE) v = ppre[i][k];
+                else {
+                    const long g = row0 + t.wave + NWAVE * i;
+                    const int c4 = t.lane + 64 * k;
+                    v = (g < B && c4 < w4max) ? *reinterpret_cast<const float4*>(Psave + (size_t)layer * ps + g * f.NFP + 4 * c4)
+                                              : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *reinterpret_cast<float4*>(PT + (t.wave + NWAVE * i) * l.PS + 4 * (t.lane + 64 * k)) = v;
+            }
             ZT[t.tid + NTHREADS * i] = zpre[i];
         }
     };
@@ -335,7 +369,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     // x <- wrap(x - pre-shift of the top layer)
     {
         const float* mt = packed + (size_t)(f.L - 1) * f.layer_stride + f.o_meta;
-        for (int e = t.tid; e < S8 * 64; e += NTHREADS) {
+        for (int e = t.tid; e < R8 * 64; e += NTHREADS) {
             const int r = e >> 6, j = e & 63;
             const long g = row0 + r;
             float v = 0.f;
@@ -346,7 +380,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             ZT[e] = v;
         }
     }
-    float ld_acc = 0.f;
+    float ld_acc[RB / 2];                                                      // element-wise stages: thread = (chain 8 i + tid / 32, coordinate tid % 32)
+#pragma unroll
+    for (int i = 0; i < RB / 2; ++i) ld_acc[i] = 0.f;
     for (int layer = f.L - 1; layer >= 0; --layer) {
         const float* Lr = img + (size_t)layer * lfl;
         const bool tl = layer == 1;
@@ -354,7 +390,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         if (tl) S8_TL(0);
         head_commit();
         if (GRAD) {
-            for (int e = t.tid; e < S8 * f.D; e += NTHREADS) {
+            for (int e = t.tid; e < R8 * f.D; e += NTHREADS) {
                 const int r = e / f.D, j = e % f.D;
                 if (row0 + r < B) Zsave[(size_t)layer * zs + (row0 + r) * f.D + j] = ZT[r * 64 + j];
             }
@@ -362,7 +398,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         __syncthreads();
         s8_prologue(s, reinterpret_cast<const float4*>(Lr + H) + (size_t)t.wave * TPL * 64);
         const int n_id = (int)meta[M_CNT * 64];
-        for (int e = t.tid; e < S8 * S8_AS; e += NTHREADS) {                   // identity coordinates + periodic features
+        for (int e = t.tid; e < R8 * S8_AS; e += NTHREADS) {                   // identity coordinates + periodic features
             const int r = e / S8_AS, i = e % S8_AS;
             float v = 0.f;
             if (i < n_id) {
@@ -377,17 +413,17 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         }
         s8_barrier();
         if (tl) S8_TL(1);
-        f32x4 o[2];
-        float h0[2][4];
-        unsigned long long* mk = GRAD ? MASK + ((size_t)layer * 2 * NWAVE + t.wave) * S8 : nullptr;
+        f32x4 o[RB];
+        float h0[RB][4];
+        unsigned long long* mk = GRAD ? MASK + ((size_t)layer * 2 * NWAVE + t.wave) * R8 : nullptr;
         {   // h0 = A0 W0 + b0; X2 = relu(h0)
-            f32x4 acc[4][2];
+            S8Acc<RB> acc;
             s8_zero(acc);
             s8_iter<16, 16, 0, S8_INF>(s, A0 + t.arow * S8_AS, 4 * S8_AS, acc);
             s8_fold(acc, o);
             const float bv = HD[S8H_B0 + col];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = o[rb][r] + bv;
@@ -399,23 +435,23 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         s8_barrier();
         {   // t = relu(h0) Wa + ba; X1 = relu(t)
             if (layer > 0) head_fetch(Lr - lfl);
-            s8_gemm64<16>(s, X2, S8_WS, t, o);
+            s8_gemm64<16, RB>(s, X2, S8_WS, t, o);
             const float bv = HD[S8H_BA + col];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = o[rb][r] + bv;
                     X1[(4 * rb + r) * S8_WS + col] = v > 0.f ? v : 0.f;
-                    if (GRAD) { const unsigned long long m = __ballot(v > 0.f); if (t.lane == 0) mk[NWAVE * S8 + 4 * rb + r] = m; }
+                    if (GRAD) { const unsigned long long m = __ballot(v > 0.f); if (t.lane == 0) mk[NWAVE * R8 + 4 * rb + r] = m; }
                 }
         }
         s8_barrier();
         {   // h1 = h0 + relu(t) Wb + bb -> T
-            s8_gemm64<16>(s, X1, S8_WS, t, o);
+            s8_gemm64<16, RB>(s, X1, S8_WS, t, o);
             const float bv = HD[S8H_BB + col];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) T[(4 * rb + r) * S8_WS + col] = h0[rb][r] + (o[rb][r] + bv);
         }
@@ -423,11 +459,11 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         if (tl) S8_TL(2);
         s8_for<0, NCH>([&](auto cc) {                                          // P = h1 Wf + bf, chunks of 256 outputs
             constexpr int c = decltype(cc)::value;
-            if constexpr (c + 1 < NCH) s8_gemm64<16>(s, T, S8_WS, t, o);
-            else s8_gemm64<16, 31>(s, T, S8_WS, t, o);                         // the layer's last tiles: the ring drains
+            if constexpr (c + 1 < NCH) s8_gemm64<16, RB>(s, T, S8_WS, t, o);
+            else s8_gemm64<16, RB, 31>(s, T, S8_WS, t, o);                         // the layer's last tiles: the ring drains
             const float bv = HD[S8H_BF + c * 256 + col];
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
+            for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) PT[(4 * rb + r) * l.PS + c * 256 + col] = o[rb][r] + bv;
         });
@@ -436,44 +472,55 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         const int n_tr = (int)meta[M_CNT * 64 + 1];
         if (GRAD) {                                                            // conditioner output, for the reverse sweep
             const int w4 = (n_tr * SP_NP + 3) >> 2;
-            for (int r = t.wave; r < S8; r += NWAVE)
+            for (int r = t.wave; r < R8; r += NWAVE)
                 if (row0 + r < B)
                     for (int c4 = t.lane; c4 < w4; c4 += 64)
                         *reinterpret_cast<float4*>(Psave + (size_t)layer * ps + (row0 + r) * f.NFP + 4 * c4) =
                             *reinterpret_cast<const float4*>(PT + r * l.PS + 4 * c4);
         }
+#pragma unroll 1
+        for (int ri = 0; ri < RB / 2; ++ri) {
+        const int row = 8 * ri + t.row;
+        float ldv = 0.f;
         for (int j = t.c; j < f.D; j += 32) {
             float p[SP_NP];
             int pos;
-            const int kind = sp_coord_params(f, HD, meta, PT, l.PS, t.row, j, isq, p, pos);
+            const int kind = sp_coord_params(f, HD, meta, PT, l.PS, row, j, isq, p, pos);
             const float tb = meta[M_TB * 64 + j];
-            float out = ZT[t.row * 64 + j];
+            float out = ZT[row * 64 + j];
             if (kind) {
                 Rqs sp;
                 rqs_setup(p, meta[M_CIRC * 64 + j] != 0.f, tb, sp);
                 float l1;
                 rqs_forward(sp, out, tb, out, l1);
-                ld_acc += l1;
+                ldv += l1;
             }
             if (layer > 0 && HD[S8H_NXT + 64 + j] != 0.f) out = sp_wrap(out - HD[S8H_NXT + j], tb);   // next stage's shift
-            ZT[t.row * 64 + j] = out;
+            ZT[row * 64 + j] = out;
+        }
+        if (RB / 2 == 1 || ri == 0) ld_acc[0] += ldv;
+        else ld_acc[RB / 2 - 1] += ldv;
         }
         if (tl) S8_TL(4);
     }
     __syncthreads();
     if constexpr (GRAD) { head_fetch(img); tile_fetch(0); }
     // base UniformGaussian
-    for (int j = t.c; j < f.D; j += 32) {
-        const float sc = packed[f.o_base + j];
-        const float z = ZT[t.row * 64 + j];
-        if (packed[f.o_base + 64 + j] != 0.f) { ld_acc += -logf(sc); if (GRAD) GT[t.row * 64 + j] = 0.f; }
-        else {
-            ld_acc += -0.5f * 1.8378770664093453f - logf(sc) - 0.5f * ((z / sc) * (z / sc));
-            if (GRAD) GT[t.row * 64 + j] = -(z / sc) / sc;
+#pragma unroll
+    for (int ri = 0; ri < RB / 2; ++ri) {
+        const int row = 8 * ri + t.row;
+        for (int j = t.c; j < f.D; j += 32) {
+            const float sc = packed[f.o_base + j];
+            const float z = ZT[row * 64 + j];
+            if (packed[f.o_base + 64 + j] != 0.f) { ld_acc[ri] += -logf(sc); if (GRAD) GT[row * 64 + j] = 0.f; }
+            else {
+                ld_acc[ri] += -0.5f * 1.8378770664093453f - logf(sc) - 0.5f * ((z / sc) * (z / sc));
+                if (GRAD) GT[row * 64 + j] = -(z / sc) / sc;
+            }
         }
+        const float lq = row32_sum(ld_acc[ri]);
+        if (t.c == 0 && row0 + row < B) log_q[row0 + row] = lq;
     }
-    const float lq = row32_sum(ld_acc);
-    if (t.c == 0 && row0 + t.row < B) log_q[row0 + t.row] = lq;
     if constexpr (GRAD) {
         // ---- reverse sweep: GT = d log q / d(state), layers 0 .. L-1 -------------------------------------------------
         for (int layer = 0; layer < f.L; ++layer) {
@@ -482,46 +529,50 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             __syncthreads();
             if (tl) S8_TL(8);
             head_commit();
-            tile_commit();
+            tile_commit(layer);
             __syncthreads();
             s8_prologue(s, reinterpret_cast<const float4*>(Lr + H) + (size_t)(NWAVE + t.wave) * TPL * 64);
             if (tl) S8_TL(9);
             const int n_id = (int)meta[M_CNT * 64], n_tr = (int)meta[M_CNT * 64 + 1];
+#pragma unroll 1
+            for (int ri = 0; ri < RB / 2; ++ri) {
+            const int row = 8 * ri + t.row;
             for (int j = t.c; j < f.D; j += 32) {
                 float p[SP_NP];
                 int pos;
-                const int kind = sp_coord_params(f, HD, meta, PT, l.PS, t.row, j, isq, p, pos);
+                const int kind = sp_coord_params(f, HD, meta, PT, l.PS, row, j, isq, p, pos);
                 if (kind) {
                     const float tb = meta[M_TB * 64 + j];
                     const bool circ = meta[M_CIRC * 64 + j] != 0.f;
                     Rqs sp;
                     rqs_setup(p, circ, tb, sp);
-                    const float z = ZT[t.row * 64 + j], gy = GT[t.row * 64 + j];
+                    const float z = ZT[row * 64 + j], gy = GT[row * 64 + j];
                     if (kind == 2) {
                         float dp[SP_NP];
-                        GT[t.row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, isq, dp);
+                        GT[row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, isq, dp);
 #pragma unroll
-                        for (int k = 0; k < SP_NP; ++k) PT[t.row * l.PS + pos * SP_NP + k] = dp[k];
+                        for (int k = 0; k < SP_NP; ++k) PT[row * l.PS + pos * SP_NP + k] = dp[k];
                     } else {
-                        GT[t.row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, 1.f, nullptr);
+                        GT[row * 64 + j] = rqs_backward(sp, p, circ, z, tb, gy, 1.f, nullptr);
                     }
                 }
             }
             // columns of dP no coordinate owns: the stored tile has the conditioner's padding there, Psave beyond w4 was never written
-            for (int c = n_tr * SP_NP + t.c; c < f.NFP; c += 32) PT[t.row * l.PS + c] = 0.f;
+            for (int c = n_tr * SP_NP + t.c; c < f.NFP; c += 32) PT[row * l.PS + c] = 0.f;
+            }
             s8_barrier();
             if (tl) S8_TL(10);
-            const unsigned long long* mk = MASK + ((size_t)layer * 2 * NWAVE + t.wave) * S8;
-            f32x4 o[2];
-            float dh1[2][4];
+            const unsigned long long* mk = MASK + ((size_t)layer * 2 * NWAVE + t.wave) * R8;
+            f32x4 o[RB];
+            float dh1[RB][4];
             {   // dh1 = dP WfT   (K = NFP)
-                f32x4 acc[4][2];
+                S8Acc<RB> acc;
                 s8_zero(acc);
                 const float* ap = PT + t.arow * l.PS;
                 s8_for<0, 2 * NCH>([&](auto ic) { s8_iter<32, 32, 0, S8_INF>(s, ap + 128 * decltype(ic)::value, 4 * l.PS, acc); });
                 s8_fold(acc, o);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { dh1[rb][r] = o[rb][r]; X1[(4 * rb + r) * S8_WS + col] = o[rb][r]; }
             }
@@ -529,18 +580,18 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             if (tl) S8_TL(11);
             {   // d relu(t) = dh1 WbT, masked by t > 0
                 if (layer + 1 < f.L) { head_fetch(Lr + lfl); tile_fetch(layer + 1); }
-                s8_gemm64<0>(s, X1, S8_WS, t, o);
+                s8_gemm64<0, RB>(s, X1, S8_WS, t, o);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        X2[(4 * rb + r) * S8_WS + col] = ((mk[NWAVE * S8 + 4 * rb + r] >> t.lane) & 1ull) ? o[rb][r] : 0.f;
+                        X2[(4 * rb + r) * S8_WS + col] = ((mk[NWAVE * R8 + 4 * rb + r] >> t.lane) & 1ull) ? o[rb][r] : 0.f;
             }
             s8_barrier();
             {   // dh0 = dh1 + (d t WaT masked by h0 > 0)
-                s8_gemm64<0, 47>(s, X2, S8_WS, t, o);
+                s8_gemm64<0, RB, 47>(s, X2, S8_WS, t, o);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
                         T[(4 * rb + r) * S8_WS + col] = dh1[rb][r] + (((mk[4 * rb + r] >> t.lane) & 1ull) ? o[rb][r] : 0.f);
@@ -548,22 +599,22 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             s8_barrier();
             if (tl) S8_TL(12);
             {   // dA0 = dh0 W0T: K split over the waves (wave w: k = 64 w .. 64 w + 63), partial [8][64] products through LDS
-                f32x4 acc[4][2];
+                S8Acc<RB> acc;
                 s8_zero(acc);
                 s8_iter<16, 16, 0, 15>(s, T + t.arow * S8_WS + 64 * t.wave, 4 * S8_WS, acc);
                 s8_fold(acc, o);
 #pragma unroll
-                for (int rb = 0; rb < 2; ++rb)
+                for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) PART[(t.wave * S8 + 4 * rb + r) * S8_AS + t.lane] = o[rb][r];
+                    for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * S8_AS + t.lane] = o[rb][r];
             }
             s8_barrier();
             if (tl) S8_TL(13);
-            for (int e = t.tid; e < S8 * 64; e += NTHREADS) {
+            for (int e = t.tid; e < R8 * 64; e += NTHREADS) {
                 const int r = e >> 6, i = e & 63;
                 if (i < n_id) {
                     const float* pp = PART + r * S8_AS + i;
-                    float d = (pp[0] + pp[S8 * S8_AS]) + (pp[2 * S8 * S8_AS] + pp[3 * S8 * S8_AS]);
+                    float d = (pp[0] + pp[R8 * S8_AS]) + (pp[2 * R8 * S8_AS] + pp[3 * R8 * S8_AS]);
                     const int feat = (int)meta[M_IDF * 64 + i];
                     if (meta[M_PFON * 64 + i] != 0.f) {
                         const int k = (int)meta[M_PFK * 64 + i];
@@ -576,7 +627,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             if (tl) S8_TL(14);
         }
         __syncthreads();
-        for (int e = t.tid; e < S8 * f.D; e += NTHREADS) {
+        for (int e = t.tid; e < R8 * f.D; e += NTHREADS) {
             const int r = e / f.D, j = e % f.D;
             if (row0 + r < B) grad_x[(row0 + r) * f.D + j] = GT[r * 64 + j];
         }

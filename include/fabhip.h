@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 206
+#define FABHIP_ABI_VERSION 207
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -95,7 +95,10 @@ int fabhip_get_fast_mode(void);
 #define FABHIP_OPT_SYSTEMATIC_VARIANT 3  /* FABHIP_SYSTEMATIC_VARIANT: 1 = fused systematic sampler (default), 0 = CDF in HBM */
 #define FABHIP_OPT_SPLINE_STAGED 4       /* FABHIP_SPLINE_STAGED: 1 = per-layer spline kernels instead of the one-launch kernel */
 #define FABHIP_OPT_TIMELINE 5            /* FABHIP_TIMELINE: 1 = workgroup 0 writes s_memtime stage stamps (fabhip_debug_timeline) */
-#define FABHIP_OPT_COUNT 6
+#define FABHIP_OPT_SPLINE_MFMA 6         /* FABHIP_SPLINE_MFMA: spline density kernel for hidden widths padded to 256: 0 = the
+                                            4x4x1 stream kernels (8 / 16 chains per workgroup by batch, or by TILE_SHAPE),
+                                            16 = the 16x16x4 kernel */
+#define FABHIP_OPT_COUNT 7
 int fabhip_set_option(int key, int value);
 int fabhip_get_option(int key);
 

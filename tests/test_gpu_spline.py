@@ -105,33 +105,36 @@ def test_spline_flow_log_prob_grad_and_sample_vs_oracle(D, L, hidden, circ, B):
     assert torch.equal(lq2, lq_h) and torch.equal(g2, g_h)
 
 
-@pytest.mark.parametrize("D,L,hidden,circ,B", [(32, 12, 256, (), 2048), (60, 4, 256, (1, 7, 30, 59), 333), (10, 3, 250, (3,), 64)])
-def test_8_chain_and_16_chain_tiles_of_the_spline_density_agree(D, L, hidden, circ, B):
-    """The two tile shapes of the one-launch density kernel (k_spline_logprob: 16 chains per workgroup on 16x16x4 MFMAs;
-    k_spline_logprob_r8: 8 chains on 4x4x1, own weight image) differ in the summation order of the conditioner GEMMs only:
-    log q to the parity tolerance, the gradient to it on all but ReLU-/knot-kink flips; each shape is deterministic and
+@pytest.mark.parametrize("D,L,hidden,circ,B", [(32, 12, 256, (), 2048), (60, 4, 256, (1, 7, 30, 59), 333), (10, 3, 250, (3,), 64),
+                                               (64, 2, 256, (0, 63), 41)])
+def test_the_tile_shapes_of_the_spline_density_kernels_agree(D, L, hidden, circ, B):
+    """The one-launch density kernels for hidden widths padded to 256: k_spline_logprob (16 chains per workgroup on 16x16x4
+    MFMAs) and k_spline_logprob_r8 (4x4x1 MFMAs, own weight image, 8 or 16 chains per workgroup) differ in the summation
+    order of the conditioner GEMMs only: log q to the parity tolerance, the gradient to it on all but ReLU- / knot-kink
+    flips.  The two tile shapes of the 4x4x1 kernel share their arithmetic: bit-identical.  Each is deterministic and
     independent of the batch around a chain."""
     from fab_torch_amd import _ops
     of, hf = make_pair(D, L, hidden, circ, seed=D + L, std=0.2)
     g = torch.Generator().manual_seed(11)
     x = (1.5 * torch.randn(B, D, generator=g)).to(DEV)
     out = {}
-    for shape in (16, 8):
-        with _ops.option(_ops.OPT_TILE_SHAPE, shape):
+    for name, mfma, shape in (("16x16x4", 16, 0), ("4x4x1 / 8 chains", 0, 8), ("4x4x1 / 16 chains", 0, 16)):
+        with _ops.option(_ops.OPT_SPLINE_MFMA, mfma), _ops.option(_ops.OPT_TILE_SHAPE, shape):
             lq, gr = hf.log_prob_and_grad(x)
             lq_only = hf.log_prob(x)
             lq_b, gr_b = hf.log_prob_and_grad(x[: B // 2 + 3].contiguous())
-        assert torch.equal(lq_only, lq), "density-only and density + gradient launches disagree"
-        assert torch.equal(lq_b, lq[: B // 2 + 3]) and torch.equal(gr_b, gr[: B // 2 + 3]), "a chain depends on its batch"
-        out[shape] = (lq, gr)
-    assert not torch.equal(out[8][0], out[16][0]), "both runs used the same kernel"
-    assert close(out[8][0], out[16][0], RTOL), f"log q: {worst(out[8][0], out[16][0]):.2f}x tol"
-    rel = (out[8][1] - out[16][1]).norm(dim=1) / out[16][1].norm(dim=1).clamp_min(1e-6)
+        assert torch.equal(lq_only, lq), f"{name}: density-only and density + gradient launches disagree"
+        assert torch.equal(lq_b, lq[: B // 2 + 3]) and torch.equal(gr_b, gr[: B // 2 + 3]), f"{name}: a chain depends on its batch"
+        out[name] = (lq, gr)
+    a, b8, b16 = out["16x16x4"], out["4x4x1 / 8 chains"], out["4x4x1 / 16 chains"]
+    assert torch.equal(b8[0], b16[0]) and torch.equal(b8[1], b16[1]), "8- and 16-chain tiles of the 4x4x1 kernel differ"
+    assert not torch.equal(a[0], b8[0]), "both runs used the same kernel"
+    assert close(b8[0], a[0], RTOL), f"log q: {worst(b8[0], a[0]):.2f}x tol"
+    rel = (b8[1] - a[1]).norm(dim=1) / a[1].norm(dim=1).clamp_min(1e-6)
     assert float(rel.median()) < 1e-5 and float((rel > 1e-3).float().mean()) <= 0.02, \
         f"gradient: median {float(rel.median()):.2e}, worst {float(rel.max()):.2e}"
-    with _ops.option(_ops.OPT_TILE_SHAPE, 0):                  # default: 8-chain tiles up to 8 chains per CU
-        lq, gr = hf.log_prob_and_grad(x)
-    assert torch.equal(lq, out[8][0]) and torch.equal(gr, out[8][1])
+    lq, gr = hf.log_prob_and_grad(x)                           # default: the 4x4x1 kernel, tile by batch
+    assert torch.equal(lq, b8[0]) and torch.equal(gr, b8[1])
 
 
 def test_identity_initialised_spline_flow_is_the_base_distribution():
@@ -229,12 +232,12 @@ def test_spline_flow_parameter_gradients_vs_oracle(D, L, hidden, circ, B):
     lq = hf.log_prob(xd)
     (c.to(DEV) * lq).sum().backward()
     from fab_torch_amd import _ops
-    with _ops.option(_ops.OPT_TILE_SHAPE, 16):
+    with _ops.option(_ops.OPT_SPLINE_MFMA, 16):
         lq0, gx0 = hf.log_prob_and_grad(x.to(DEV))
     # (the training forward runs the staged kernels with the tape, log_prob_and_grad the one-launch kernel ON THE SAME
-    # 16-CHAIN TILES: same arithmetic per coordinate, different order of the log-det row sums; the 8-chain-tile kernel
+    # 16x16x4 TILES: same arithmetic per coordinate, different order of the log-det row sums; the 4x4x1 stream kernel
     # that hidden 256 gets by default sums the conditioner GEMMs in another order - compared in
-    # test_8_chain_and_16_chain_tiles_of_the_spline_density_agree)
+    # test_the_tile_shapes_of_the_spline_density_kernels_agree)
     assert close(lq.detach(), lq0, 1e-6) and close(xd.grad, c.to(DEV)[:, None] * gx0, 1e-5)
     ref32, ref64 = dict(of.named_parameters()), dict(of64.named_parameters())
     names = [n for n, _ in hf._nf_model.named_parameters()]
