@@ -167,6 +167,43 @@ WORKLOADS = {
 }
 
 
+def spline_cfg3(dev):
+    """BASELINE cfg 3 with the flow family it names (reported next to the headline, not `value`): ManyWell-32, spline flow
+    12 x (hidden 256, 8 bins), 2048 chains, 12 intermediate distributions, HMC L = 5, through the fused spline AIS call
+    (fabhip_spline_ais_run; the density + gradient kernel is k_spline_logprob_r8: 8 chains per workgroup, spline_r8.h)."""
+    import fab_torch_amd as fa
+    D, L, H, M, B, LF = 32, 12, 256, 12, 2048, 5
+    torch.manual_seed(0)
+    flow = fa.make_wrapped_normflow_spline(D, L, H, (), 5.0).to(dev).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] % 25 == 0:
+                p.add_(0.02 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1, L=LF).to(dev)
+    ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, False, 2.0, M)
+    x, _ = flow.sample_and_log_prob((B,))
+    t_eval = _event_time(lambda: flow.log_prob_and_grad(x), n=30, warm=5)
+    for _ in range(2):
+        ais.sample_and_log_weights(B)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        ais.sample_and_log_weights(B)
+    torch.cuda.synchronize(dev)
+    t_call = (time.perf_counter() - t0) / n
+    flop = 4.0 * (64 * H + 2 * H * H + 512 * H) * L * B            # conditioner GEMMs as executed, forward + reverse
+    stream = 2 * 4 * 272 * 1024 * L                                # weight tiles one workgroup streams per evaluation
+    return {"workload": "cfg3: ManyWell-32, spline flow 12 x (hidden 256, 8 bins), 2048 chains, M = 12, HMC L = 5",
+            "value": B / t_call, "unit": "AIS samples/s", "ms_per_call": t_call * 1e3,
+            "density_grad_evals_per_call": M * LF + 1, "ms_per_density_grad": t_eval * 1e3,
+            "kernel": "k_spline_logprob_r8<2, 2, true> (8 chains per workgroup, v_mfma_f32_4x4x1, 256 workgroups)",
+            "achieved_TFLOPs": flop / t_eval / 1e12, "frac_fp32_mfma_peak": flop / t_eval / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "weight_stream_bytes_per_workgroup": stream,
+            "ess_ais": float(ais.get_logging_info()["ess_ais"])}
+
+
 def _relaunch_under_torchrun(args):
     """`python bench.py --gpus N` started directly (no torchrun environment): start N ranks of this same script, one per
     GPU, under torch.distributed.run on 127.0.0.1 and hand its exit code back.  (The driver's own torchrun command line
@@ -420,6 +457,7 @@ def main():
         roof_extra = resample_rooflines(dev)
         ess_trained = trained_flow_ess(dev)
         ess_trained_fast = trained_flow_ess(dev, fast=True)
+    spline3 = spline_cfg3(dev) if (rank == 0 and world == 1 and not custom and args.workload == "headline") else None
 
     if rank == 0:
         total = world * B_PER_GPU * args.steps
@@ -443,6 +481,7 @@ def main():
             "roofline": roof,
             "roofline_resample": roof_extra,
             "ess_trained": ess_trained,
+            "spline_cfg3": spline3,
             "fast_mode": {
                 "what": "NOT the parity path: the two 320x320 GEMMs of every coupling layer on the bf16 matrix cores "
                         "(v_mfma_f32_16x16x32_bf16, fp32 accumulation) inside the transition kernels; log q deviates "

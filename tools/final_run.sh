@@ -10,4 +10,15 @@ find gpurun_out/final/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {
 rm -rf gpurun_out/final/prof
 python tools/bench_extra.py > gpurun_out/final/bench_extra.json 2> gpurun_out/final/bench_extra.err
 python tools/bench_multinomial.py > gpurun_out/final/bench_multinomial.json 2>/dev/null
+
+# spline flow (cfg 3 / cfg 5 shapes): AIS rates, stage timeline of the 8-chain kernel, per-kernel times, stream micro-benchmark
+python tools/bench_spline.py 2>/dev/null | tail -1 > gpurun_out/final/spline_cfg3.json
+FABHIP_SPLINE_MFMA=16 python tools/bench_spline.py 2>/dev/null | tail -1 > gpurun_out/final/spline_cfg3_16x16x4.json
+CFG=5 N=3 python tools/bench_spline.py 2>/dev/null | tail -1 > gpurun_out/final/spline_cfg5_shape.json
+python tools/timeline_spline.py 2>/dev/null | tail -14 > gpurun_out/final/spline_r8_stage_timeline.txt
+FABHIP_TILE=16 python tools/timeline_spline.py 2>/dev/null | tail -14 > gpurun_out/final/spline_r8_16chain_stage_timeline.txt
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_sp -- python tools/bench_spline.py > gpurun_out/final/spline_prof.log 2>&1
+find gpurun_out/final/prof_sp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/final/spline_cfg3_kernel_stats.csv
+rm -rf gpurun_out/final/prof_sp
+[ -x tools/ubench/bin/nsplit ] && tools/ubench/bin/nsplit > gpurun_out/final/ubench_nsplit.txt 2>&1
 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
