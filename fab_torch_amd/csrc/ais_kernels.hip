@@ -10,6 +10,7 @@
 #include "flow_device.h"
 #include "target_device.h"
 #include "flow_r4.h"
+#include "flow_r8.h"
 #include "launch.h"
 
 #pragma clang fp contract(off)   // keep a*b+c un-fused in the elementwise code, like the eager CPU reference
@@ -503,6 +504,190 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same HMC outer step for EIGHT chains per workgroup (flow_r8.h; G = hidden width / 64 = 4 or 5): half the weight
+// bytes per chain of the 4-chain kernel.  Element-wise work on threads < 128 with the 16-chain code's (row = tid >> 4,
+// c = tid & 15) mapping; acceptance / distance contributions go out per chain, as from the 4-chain kernel.
+// ------------------------------------------------------------------------------------------------
+struct ExtraLds8 {
+    int o_XP, o_P, o_GU, o_GP, total;
+};
+static inline ExtraLds8 make_extra_lds8(const R8Lds& l, int D) {
+    ExtraLds8 e;
+    int o = l.total;
+    e.o_XP = o; o += R8 * D;
+    e.o_P = o; o += R8 * D;
+    e.o_GU = o; o += R8 * D;
+    e.o_GP = o; o += R8 * D;
+    e.total = (o + 3) & ~3;
+    return e;
+}
+
+template <int G>
+__global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, ExtraLds8 x, const float* __restrict__ packed,
+                                                        TargetDev tg, HmcK a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = NTHREADS;
+    Tid8f t8;
+    Tid t;                                           // (row, c) of the element-wise mapping; valid rows: tid < 128
+    const int D = f.D;
+    const long nv = a.n_valid ? (long)*a.n_valid : a.B;
+    const long row0 = (long)blockIdx.x * R8;
+    const bool ew = t.tid < 16 * R8;
+    const long g = row0 + t.row;
+    if (row0 >= nv) {
+        if (ew && t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = 0.f; a.row_dist[g] = 0.f; }
+        return;
+    }
+    float* XP = lds + x.o_XP;
+    float* P = lds + x.o_P;
+    float* GU = lds + x.o_GU;
+    float* GP = lds + x.o_GP;
+    const bool active = ew && g < nv;
+    const float eps = *a.eps_ptr + *a.ceps_ptr;
+    r8_load_heads(f, l, packed, lds, t.tid, NT);
+    for (int e = t.tid; e < R8 * R4_DS; e += NT) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
+    R8Stream s;
+    s8_stream_init(s, t8.lane);
+    float k0 = 0.f;
+    if (ew) {
+        for (int j = t.c; j < D; j += 16) {
+            const float m = a.mass[j];
+            float xs = 0.f, p = 0.f, gu = 0.f;
+            if (active) {
+                xs = a.start.x[g * D + j];
+                p = a.noise_p[g * D + j] * m;
+                const float gr = -(a.c.g_q * a.start.gq[g * D + j] + a.c.g_p * a.start.gp[g * D + j]);
+                gu = clamp_nan0(gr, a.max_grad);
+            }
+            XP[t.row * D + j] = xs; P[t.row * D + j] = p; GU[t.row * D + j] = gu;
+            k0 += p * p / m;
+        }
+        k0 = row16_sum(k0) / 2.f;
+    }
+    float lq_c = 0.f, lp_c = 0.f;
+    if (active) { lq_c = a.cur.lq[g]; lp_c = a.cur.lp[g]; }
+    const float logp_cur = (a.c.c_q * lq_c + a.c.c_p * lp_c) - k0;
+    float lq = 0.f, lp = 0.f;
+    int goff = 0;
+    for (int step = 0; step < a.L; ++step) {
+        if (ew) {
+            for (int j = t.c; j < D; j += 16) {
+                const float m = a.mass[j];
+                float p = P[t.row * D + j] - eps * GU[t.row * D + j] / 2.f;
+                const float xn = XP[t.row * D + j] + eps / m * p;
+                P[t.row * D + j] = p; XP[t.row * D + j] = xn;
+            }
+        }
+        __syncthreads();
+        for (int e = t.tid; e < R8 * R4_DS; e += NT) {
+            const int r = e / R4_DS, j = e % R4_DS;
+            lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
+        }
+        __syncthreads();
+        lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
+        if (ew) {
+            lp = target_tile<true>(tg, XP, D, GP, D, t);
+            for (int j = t.c; j < D; j += 16) {
+                const float gr = -(a.c.g_q * lds[goff + t.row * R4_DS + j] + a.c.g_p * GP[t.row * D + j]);
+                const float gu = clamp_nan0(gr, a.max_grad);
+                GU[t.row * D + j] = gu;
+                P[t.row * D + j] = P[t.row * D + j] - eps * gu / 2.f;
+            }
+        }
+    }
+    if (!ew) return;
+    // Metropolis test (hmc.py:105-124)
+    float k1 = 0.f, dist2 = 0.f;
+    for (int j = t.c; j < D; j += 16) {
+        const float p = P[t.row * D + j];
+        k1 += p * p / a.mass[j];
+        if (active) { const float dx = a.cur.x[g * D + j] - XP[t.row * D + j]; dist2 += dx * dx; }
+    }
+    k1 = row16_sum(k1) / 2.f;
+    dist2 = row16_sum(dist2);
+    const float logp_prop = (a.c.c_q * lq + a.c.c_p * lp) - k1;
+    const float delta = logp_prop - logp_cur;
+    const bool valid = isfinite(delta);
+    const float dd = valid ? delta : -INFINITY;
+    bool accept = false;
+    float contrib = 0.f, dist = 0.f;
+    if (active) {
+        accept = valid && (dd > -a.noise_e[g]);
+        contrib = expf(fminf(dd, 0.f));
+        dist = accept ? 0.f : sqrtf(dist2);
+    }
+    if (a.prop_out.x && active) {
+        for (int j = t.c; j < D; j += 16) {
+            a.prop_out.x[g * D + j] = XP[t.row * D + j];
+            a.prop_out.gq[g * D + j] = lds[goff + t.row * R4_DS + j];
+            a.prop_out.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) { a.prop_out.lq[g] = lq; a.prop_out.lp[g] = lp; }
+    }
+    if (accept) {
+        for (int j = t.c; j < D; j += 16) {
+            a.cur.x[g * D + j] = XP[t.row * D + j];
+            a.cur.gq[g * D + j] = lds[goff + t.row * R4_DS + j];
+            a.cur.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) { a.cur.lq[g] = lq; a.cur.lp[g] = lp; }
+    }
+    if (a.log_w && active && t.c == 0) {
+        const float lqf = accept ? lq : lq_c, lpf = accept ? lp : lp_c;
+        const float num = a.nx.c_q * lqf + a.nx.c_p * lpf;
+        const float den = a.c.c_q * lqf + a.c.c_p * lpf;
+        a.log_w[g] = a.log_w[g] + (num - den);
+    }
+    if (t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = contrib; a.row_dist[g] = dist; }
+}
+
+// Chain initialisation on 8-chain tiles (as k_ais_init_r4: the flow SAMPLE stays on the 16-chain kernel)
+template <int G>
+__global__ __launch_bounds__(NTHREADS) void k_ais_init_r8(FlowDims f, R8Lds l, ExtraLds8 x, const float* __restrict__ packed,
+                                                        TargetDev tg, const float* __restrict__ lq0, PointDev pt,
+                                                        float* __restrict__ log_w, float* __restrict__ base_log_w,
+                                                        fabhip_anneal an, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = NTHREADS;
+    Tid8f t8;
+    Tid t;
+    const int D = f.D;
+    const long row0 = (long)blockIdx.x * R8;
+    const bool ew = t.tid < 16 * R8;
+    const long g = row0 + t.row;
+    float* XP = lds + x.o_XP;
+    float* GP = lds + x.o_GP;
+    r8_load_heads(f, l, packed, lds, t.tid, NT);
+    for (int e = t.tid; e < R8 * R4_DS; e += NT) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
+    for (int e = t.tid; e < R8 * R4_DS; e += NT) {
+        const int r = e / R4_DS, j = e % R4_DS;
+        const float v = (j < D && row0 + r < B) ? pt.x[(row0 + r) * D + j] : 0.f;
+        lds[l.o_X0 + e] = v;
+        if (j < D) XP[r * D + j] = v;
+    }
+    R8Stream s;
+    s8_stream_init(s, t8.lane);
+    __syncthreads();
+    int goff = 0;
+    const float lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
+    if (!ew) return;
+    const float lp = target_tile<true>(tg, XP, D, GP, D, t);
+    if (g < B) {
+        for (int j = t.c; j < D; j += 16) {
+            pt.gq[g * D + j] = lds[goff + t.row * R4_DS + j];
+            pt.gp[g * D + j] = GP[t.row * D + j];
+        }
+        if (t.c == 0) {
+            const float q0 = lq0[g];
+            pt.lq[g] = lq;
+            pt.lp[g] = lp;
+            log_w[g] = (an.c_q * lq + an.c_p * lp) - q0;
+            if (base_log_w) base_log_w[g] = lp - q0;
+        }
+    }
+}
+
 // step-size adaptation from the block partials (hmc.py:122-123,162-170), fixed summation order
 // (4-chain tiles hand over per-chain values: the 64 threads first add each block's 16 rows in row order, which is
 // what a 16-chain workgroup writes, so both tile shapes give the step-size rule bit-identical sums)
@@ -822,9 +1007,21 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
 static bool use_r4_tiles(const FlowDims& f, long B) {
     if (f.fast || f.D > 32 || f.NTW / 4 > 5) return false;
     const int shape = option(FABHIP_OPT_TILE_SHAPE);
-    if (shape == 16) return false;
+    if (shape == 16 || shape == 8) return false;
     if (shape == 4) return true;
     return B <= 1152;
+}
+// 8-chain tiles (flow_r8.h: D <= 32, hidden width padded to 256 / 320, fp32): half the weight bytes per chain of the 4-chain
+// kernel on one stream per wave.  FABHIP_OPT_TILE_SHAPE = 8 forces them; by default they take the batches for which
+// R8_MIN_CHAINS < B <= 8 chains per CU (measured: DESIGN.md section 4).
+constexpr long R8_MIN_CHAINS = 1152;
+static bool r8_lds_fits(const FlowDims& f) { return (size_t)(make_r8_lds(f).total + 4 * R8 * f.D + 4) * 4 <= 160 * 1024; }
+static bool use_r8_tiles(const FlowDims& f, long B) {
+    if (f.fast || !r8_shape_ok(f) || !r8_lds_fits(f)) return false;
+    const int shape = option(FABHIP_OPT_TILE_SHAPE);
+    if (shape == 16 || shape == 4) return false;
+    if (shape == 8) return true;
+    return B > R8_MIN_CHAINS && B <= 8L * 256;
 }
 
 long long* debug_timeline(hipStream_t st);           // flow_kernels.hip (dev-only stage stamps)
@@ -881,6 +1078,43 @@ static int launch_ais_init_r4(const FlowDims& f, const float* packed, const Targ
     return check_launch();
 }
 
+static int launch_hmc_step_r8(const FlowDims& f0, const float* packed, const TargetDev& tg, const HmcK& a, hipStream_t st) {
+    FlowDims f = f0;
+    f.timeline = debug_timeline(st);
+    const R8Lds l = make_r8_lds(f);
+    const ExtraLds8 x = make_extra_lds8(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    const dim3 grid((unsigned)(nblk_of(a.B) * (ROWS / R8)));      // every row of the 16-row blocks k_hmc_adapt sums gets written
+    if (f.Wp == 320) {
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r8<5>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r8<5>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);
+    } else if (f.Wp == 256) {
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r8<4>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r8<4>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);
+    } else {
+        return FABHIP_ENOTSUP;
+    }
+    return check_launch();
+}
+
+static int launch_ais_init_r8(const FlowDims& f, const float* packed, const TargetDev& tg, const float* lq0, const PointDev& pt,
+                              float* log_w, float* base_log_w, fabhip_anneal an, long B, hipStream_t st) {
+    const R8Lds l = make_r8_lds(f);
+    const ExtraLds8 x = make_extra_lds8(l, f.D);
+    const size_t bytes = (size_t)x.total * 4;
+    const dim3 grid((unsigned)((B + R8 - 1) / R8));
+    if (f.Wp == 320) {
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r8<5>, bytes));
+        hipLaunchKernelGGL((k_ais_init_r8<5>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, lq0, pt, log_w, base_log_w, an, B);
+    } else if (f.Wp == 256) {
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r8<4>, bytes));
+        hipLaunchKernelGGL((k_ais_init_r8<4>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, lq0, pt, log_w, base_log_w, an, B);
+    } else {
+        return FABHIP_ENOTSUP;
+    }
+    return check_launch();
+}
+
 template <int NTWM>
 static int launch_metropolis(const FlowDims& f, const float* packed, const TargetDev& tg, const MetK& a, hipStream_t st) {
     const FlowLds l = make_flow_lds(f, false);
@@ -903,7 +1137,8 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
     float* part_dist = (float*)ws; ws += align256((size_t)nblk * 4);
     float* row_acc = (float*)ws; ws += align256((size_t)nblk * ROWS * 4);
     float* row_dist = (float*)ws; ws += align256((size_t)nblk * ROWS * 4);
-    const bool r4 = use_r4_tiles(f, a->B);
+    const bool r8 = use_r8_tiles(f, a->B);
+    const bool r4 = !r8 && use_r4_tiles(f, a->B);
     PointDev prop{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (a->n_outer > 1) {
         float* pb = (float*)ws;
@@ -923,12 +1158,13 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
         k.eps_ptr = a->epsilons + n; k.ceps_ptr = a->common_epsilon; k.mass = a->mass;
         k.L = a->L; k.max_grad = a->max_grad; k.part_acc = part_acc; k.part_dist = part_dist;
         k.row_acc = row_acc; k.row_dist = row_dist;
-        if (r4) FAB_DISPATCH_NTW_NORET(f, launch_hmc_step_r4, f, a->flow.packed, tg, k, st);
+        if (r8) FAB_TRY(launch_hmc_step_r8(f, a->flow.packed, tg, k, st));
+        else if (r4) FAB_DISPATCH_NTW_NORET(f, launch_hmc_step_r4, f, a->flow.packed, tg, k, st);
         else FAB_DISPATCH_NTW_NORET(f, launch_hmc_step, f, a->flow.packed, tg, k, st);
         hipLaunchKernelGGL(k_hmc_adapt, dim3(1), dim3(64), 0, st, part_acc, part_dist, nblk, a->n_valid, (long)a->B,
                            a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
                            a->p_accept ? a->p_accept + n : nullptr, a->avg_distance,
-                           r4 ? row_acc : (const float*)nullptr, r4 ? row_dist : (const float*)nullptr, a->partials);
+                           (r4 || r8) ? row_acc : (const float*)nullptr, (r4 || r8) ? row_dist : (const float*)nullptr, a->partials);
         FAB_TRY(check_launch());
     }
     return FABHIP_OK;
@@ -1225,7 +1461,10 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     fabhip_anneal_coefs(a->betas[1], a->alpha, a->p_target, &a1);
     {
         const PointDev pt = make_point_dev(a->point);
-        if (hmc && use_r4_tiles(f, B) && option(FABHIP_OPT_R4_STREAM) != 0) {
+        if (hmc && use_r8_tiles(f, B)) {
+            FAB_TRY(fabhip_flow_sample(&a->flow, a->eps0, a->point.x, lwb, B, stream));
+            FAB_TRY(launch_ais_init_r8(f, a->flow.packed, tg, lwb, pt, a->log_w, a->base_log_w, a1, B, st));
+        } else if (hmc && use_r4_tiles(f, B) && option(FABHIP_OPT_R4_STREAM) != 0) {
             // 4-chain tiles: flow sample (16-chain kernel) -> x, log q0 ; then log q + d/dx, target, log w on 4-chain tiles
             FAB_TRY(fabhip_flow_sample(&a->flow, a->eps0, a->point.x, lwb, B, stream));
             FAB_DISPATCH_NTW_NORET(f, launch_ais_init_r4, f, a->flow.packed, tg, lwb, pt, a->log_w, a->base_log_w, a1, B, st);

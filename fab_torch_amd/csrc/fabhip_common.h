@@ -41,6 +41,7 @@ struct FlowDims {
     int o_scratch;              // offset of affine scratch: per layer W[D*D], Winv[D*D]
     int o_r4;                   // 4-chain-tile weight image (flow_r4.h: R4Dims), K layer blocks
     int o_r4s;                  // the same tiles in per-wave consumption order (flow_r4.h: R4Stream; D <= 32, Wp >= 128), else -1
+    int o_r8;                   // 8-chain-tile weight image (flow_r8.h; D <= 32, Wp = 256 / 320), else -1
     int total;                  // total floats
     long long* timeline;        // dev-only: s_memtime stamps of workgroup 0 (nullptr in production)
     int fast;                   // this call runs the fast-mode kernels (resolved from fabhip_flow::precision by the entry point)
@@ -92,6 +93,13 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
         const int ntw = f.Wp / 64;
         f.o_r4s = f.total;
         f.total += (2 * K * (4 * ntw + 4) + 8) * 4 * ntw * 256;
+    }
+    // 8-chain-tile image: per layer 4 waves x (forward + reverse = 188 / 271 tiles of 1 KiB for G = Wp / 64 = 4 / 5; flow_r8.h)
+    f.o_r8 = -1;
+    if (D <= 32 && f.DOp == 16 && (f.Wp == 256 || f.Wp == 320)) {
+        const int G = f.Wp / 64;
+        f.o_r8 = (f.total + 63) & ~63;
+        f.total = f.o_r8 + K * NWAVE * (28 + 40 * G + (G - 4) * (3 + 8 * G)) * 256;
     }
     f.timeline = nullptr;
     f.fast = 0;

@@ -1,6 +1,7 @@
 // RealNVP flow: parameter packing, log_prob (+ d/dx) and sampling kernels + their C ABI.
 #include "flow_device.h"
 #include "flow_r4.h"
+#include "flow_r8.h"
 #include "launch.h"
 #include <stdlib.h>
 
@@ -374,6 +375,58 @@ __global__ __launch_bounds__(256) void k_pack_r4(FlowDims f, R4Dims rd, MlpTab t
     }
 }
 
+// 8-chain-tile image (flow_r8.h): per layer [forward: wave 0 .. 3 | reverse: wave 0 .. 3], a wave's 1-KiB tiles (lane =
+// column, float4 = 4 consecutive k) in the order it consumes them.  Forward [AW 8 | W1 4 (+1) | W2 16 G (+4 G) | W3 4 G],
+// reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T 4 G | AWT 8]; N-split matrices: columns 64 wave + lane, all of K; (+..): the
+// fifth column group (columns 256 + lane) of a 320-wide layer, this wave's quarter of the k-quads; K-split (W3, W1T): this
+// wave's quarter of K, columns = lane; the D x D maps are the same tiles for every wave.
+__global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed) {
+    const int D = f.D, d = f.d, DO = f.DO, W = f.W, G = f.Wp / 64, EX = G - 4;
+    const int TF = r8_tiles_fwd(G), TR = r8_tiles_rev(G), LF = r8_layer_floats(G);
+    const int NQW = 16 * G, NQK = 4 * G;
+    const int y = blockIdx.y, layer = k0 + y;
+    float* __restrict__ dst = packed + f.o_r8 + (size_t)layer * LF;
+    const float* Wm = packed + f.o_scratch + (size_t)layer * 2 * D * D;       // W' (assembled, ActNorm folded)
+    const float *w1 = tab.w1[y], *w2 = tab.w2[y], *w3 = tab.w3[y];
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < LF; off += gridDim.x * blockDim.x) {
+        const int kk = off & 3, lane = (off >> 2) & 63;
+        int tl = off >> 8;
+        const bool fwd = tl < NWAVE * TF;
+        if (!fwd) tl -= NWAVE * TF;
+        const int T = fwd ? TF : TR, wave = tl / T;
+        int ti = tl % T;
+        float v = 0.f;
+        // (matrix, k-quad, column) of the tile: mat 0 AW / AWT, 1 W1 / W1T, 2 W2 / W2T, 3 W3 / W3T
+        int mat, q, n;
+        if (fwd) {
+            if (ti < R8_KD4) { mat = 0; q = ti; n = lane; }
+            else if ((ti -= R8_KD4) < R8_Kd4) { mat = 1; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= R8_Kd4) < EX * (R8_Kd4 / 4)) { mat = 1; q = (R8_Kd4 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= EX * (R8_Kd4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else { ti -= EX * NQK; mat = 3; q = NQK * wave + ti; n = lane; }
+            const int k = 4 * q + kk;
+            if (mat == 0) { if (k < D && n < D) v = Wm[k * D + n]; }
+            else if (mat == 1) { if (k < d && n < W) v = w1[n * d + k]; }
+            else if (mat == 2) { if (k < W && n < W) v = w2[n * W + k]; }
+            else { const int o = prm_orig(n, DO, f.DOp); if (k < W && n < 2 * f.DOp && o >= 0) v = w3[o * W + k]; }
+        } else {
+            if (ti < R8_Ko4) { mat = 3; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= R8_Ko4) < EX * (R8_Ko4 / 4)) { mat = 3; q = (R8_Ko4 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= EX * (R8_Ko4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else if ((ti -= EX * NQK) < NQK) { mat = 1; q = NQK * wave + ti; n = lane; }
+            else { ti -= NQK; mat = 0; q = ti; n = lane; }
+            const int k = 4 * q + kk;
+            if (mat == 3) { const int o = prm_orig(k, DO, f.DOp); if (k < 2 * f.DOp && o >= 0 && n < W) v = w3[o * W + n]; }
+            else if (mat == 2) { if (k < W && n < W) v = w2[k * W + n]; }
+            else if (mat == 1) { if (k < W && n < d) v = w1[k * d + n]; }
+            else { if (k < D && n < D) v = Wm[n * D + k]; }
+        }
+        dst[off] = v;
+    }
+}
+
 // Stream image (flow_r4.h: R4Stream): the r4 tiles copied into the order a wave consumes them.  float4 index of a
 // stream element = ((item * 4 + wave) * G + g) * 64 + lane, item = global item number (forward layers K-1 .. 0, then
 // reverse layers 0 .. K-1, C = 4 G + 4 items each).  Source tiles come from the r4 image k_pack_r4 has just written.
@@ -526,6 +579,8 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
         hipLaunchKernelGGL(k_pack_bf16, dim3(ceil_div(f.Wp * f.Wp, 256 * 4), nl), dim3(256), 0, st, f, mt, k0, packed);
         const R4Dims rd = make_r4_dims(f);
         hipLaunchKernelGGL(k_pack_r4, dim3(ceil_div(rd.layer_stride, 256 * 8), nl), dim3(256), 0, st, f, rd, mt, k0, packed);
+        if (f.o_r8 >= 0)
+            hipLaunchKernelGGL(k_pack_r8, dim3(ceil_div(r8_layer_floats(f.Wp / 64), 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
     }
     if (f.o_r4s >= 0)
         hipLaunchKernelGGL(k_pack_r4s, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed);

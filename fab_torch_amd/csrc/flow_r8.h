@@ -1,0 +1,362 @@
+// 8-chain tiles (R8) for the RealNVP density + d/dx: EIGHT chains per workgroup (4 waves) on v_mfma_f32_4x4x1_16b_f32, hidden
+// width padded to 256 or 320 (G = Wp / 64 = 4 or 5 column groups), D <= 32.
+//
+// Why a third tile shape: the 4-chain kernel (flow_r4.h) is bound by the L2 -> CU weight stream - every CU streams the whole
+// flow for 4 chains (0.96 MB per layer pair at ~45 of the ~52 B/clk the path delivers) - and the 16-chain kernel leaves CUs
+// idle below 4096 chains.  Eight chains per workgroup halve the bytes per chain; with the structure of spline_r8.h the
+// extra MFMAs hide behind the stream:
+//   * the products into the hidden width (W1, W2, W3T, W2T) are N-split: wave w owns columns 64 w .. 64 w + 63 for all of
+//     K, k mod 4 on four accumulators per row block - no partial sums through LDS, one LDS-only barrier per stage.  The
+//     fifth column group of a 320-wide layer is K-split over the four waves (a quarter of its k-quads each, partial sums
+//     through LDS, wave w finishes rows 2 w, 2 w + 1): a fifth wave would share a SIMD with wave 0, and the 4x4x1 MFMA
+//     pipe (8 cycles per instruction) of that SIMD then bounds every stage (measured: 156 instead of 95 cycles per k-quad);
+//   * the narrow products out of the hidden width (W3 -> shift | scale, W1T -> the d input gradients) are K-split (wave w:
+//     k = 64 w .. 64 w + 63) with their partials summed by the element-wise stage that consumes them;
+//   * the D x D maps are evaluated by every wave (8 tiles), wave 0 stores;
+//   * every wave reads its tiles of a layer and direction as ONE stream through a 32-tile AGPR ring (stream_r8.h): forward
+//     [AW 8 | W1 4 (+1) | W2 16 G (+4 G) | W3 4 G], reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T 4 G | AWT 8] tiles of 1 KiB
+//     ((+..): its share of the fifth group); the next layer's ring is requested before the layer's last element-wise stage;
+//   * biases / log-det constants of ALL layers sit in LDS (copied once per kernel), ReLU decisions as ballots in LDS.
+// Same arithmetic as flow_log_prob_r4 / flow_log_prob_tile up to the summation order inside the GEMMs.
+#pragma once
+#include "flow_r4.h"
+#include "stream_r8.h"
+
+namespace fab {
+
+constexpr int R8 = 8;                  // chains per workgroup
+constexpr int R8_RD = 16;              // ring depth (1-KiB tiles in flight per wave; 32: the 31-request prologue of every layer costs more than it hides)
+using R8Stream = S8StreamT<R8_RD>;
+constexpr int R8_KD4 = 8, R8_Kd4 = 4, R8_Ko4 = 8;    // k-quads of the short K extents, padded to D = 32 / d = 16 / 2 DOp = 32
+
+FAB_HD bool r8_shape_ok(const FlowDims& f) { return f.o_r8 >= 0; }
+// tiles per wave, layer and direction (G = 4: 92 / 96, G = 5: 133 / 138); make_flow_dims sizes the image with the same sums
+FAB_HD int r8_tiles_fwd(int G) { const int EX = G - 4; return R8_KD4 + R8_Kd4 + EX + 16 * G + 4 * G * EX + 4 * G; }
+FAB_HD int r8_tiles_rev(int G) { const int EX = G - 4; return R8_Ko4 + 2 * EX + 16 * G + 4 * G * EX + 4 * G + R8_KD4; }
+FAB_HD int r8_layer_floats(int G) { return NWAVE * (r8_tiles_fwd(G) + r8_tiles_rev(G)) * 256; }
+
+// LDS plan of an r8 workgroup (floats)
+struct R8Lds {
+    int WS, HF;                        // leading dim of the hidden tiles; floats per layer of the head block
+    int o_X0, o_X1, o_HA, o_HB, o_PRM, o_DP, o_PART, o_ES, o_V2, o_MASK, o_HEAD, total;
+};
+// head block of a layer: ac[64] | b1[Wp] | b2[Wp] | b3[64] (shift | scale at 0 / DOp) | logS[16]
+FAB_HD R8Lds make_r8_lds(const FlowDims& f) {
+    R8Lds l;
+    const int G = f.Wp / 64;
+    l.WS = f.Wp + 4;
+    l.HF = 64 + 2 * f.Wp + 64 + 16;
+    int o = 0;
+    l.o_X0 = o; o += R8 * R4_DS;
+    l.o_X1 = o; o += R8 * R4_DS;
+    l.o_HA = o; o += R8 * l.WS;
+    l.o_HB = o; o += R8 * l.WS;
+    l.o_PRM = o; o += R8 * R4_DS;      // (unused columns stay zero)
+    l.o_DP = o; o += R8 * R4_DS;
+    l.o_PART = o; o += NWAVE * R8 * R4_DS;           // K-split partials: narrow outputs / the fifth column group
+    l.o_ES = o; o += f.K * R8 * f.DOp;
+    l.o_V2 = o; o += f.K * R8 * f.DOp;
+    l.o_MASK = o; o += f.K * 2 * G * R8 * 2;         // u64 ballots [layer][stage][column group][chain]
+    l.o_HEAD = o; o += f.K * l.HF;
+    l.total = (o + 3) & ~3;
+    return l;
+}
+
+struct Tid8f {
+    int tid, wave, lane, arow, row, c;
+    __device__ __forceinline__ Tid8f() {
+        tid = threadIdx.x;
+        wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+        lane = tid & 63;
+        arow = lane & 3;
+        row = tid >> 4;                // element-wise stages: threads < 128 = 8 chains x 16 lanes (the 16-chain code's mapping)
+        c = tid & 15;
+    }
+};
+
+// copy the head blocks of all layers into LDS (once per kernel; plain loads, nothing else in flight)
+__device__ __forceinline__ void r8_load_heads(const FlowDims& f, const R8Lds& l, const float* __restrict__ packed, float* lds,
+                                              int tid, int nthreads) {
+    for (int e = tid; e < f.K * l.HF; e += nthreads) {
+        const int layer = e / l.HF, i = e - layer * l.HF;
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        float v;
+        if (i < 64) v = Lp[f.o_ac + i];
+        else if (i < 64 + f.Wp) v = Lp[f.o_b1 + i - 64];
+        else if (i < 64 + 2 * f.Wp) v = Lp[f.o_b2 + i - 64 - f.Wp];
+        else if (i < 128 + 2 * f.Wp) { const int j = i - 64 - 2 * f.Wp; v = j < 2 * f.DOp ? Lp[f.o_b3 + j] : 0.f; }
+        else v = Lp[f.o_logS + i - 128 - 2 * f.Wp];
+        lds[l.o_HEAD + e] = v;
+    }
+}
+
+// An opaque zero, re-made in every layer iteration and added to the LDS base: hipcc otherwise hoists every LDS address of the
+// (large) layer body out of the loop - several hundred registers, spilled to scratch (G = 5: 500 VGPRs).
+__device__ __forceinline__ int r8_opaque_zero() {
+    int z;
+    asm volatile("s_mov_b32 %0, 0" : "=s"(z));
+    return z;
+}
+
+__device__ __forceinline__ float r8_part_sum(const float* p) {          // the 4 waves' partials of one output, fixed order
+    return (p[0] + p[R8 * R4_DS]) + (p[2 * R8 * R4_DS] + p[3 * R8 * R4_DS]);
+}
+
+// One product into the hidden width: OUT[8][Wp] = epilogue(ACT[8][4 NQ] @ B).  Stream tiles T0 .. : NQ of this wave's own
+// column group, then (G == 5) NQ / 4 of the fifth group (this wave's quarter of K).  `epi(v, col)` -> stored value of an
+// output BEFORE masking; EP 1: ReLU, decisions kept in mk; EP 2: multiplied by the decisions in mk.
+// mk: ballots of this layer and stage, [column group][chain].  Ends with a workgroup barrier.
+// (leading dimensions are template parameters: with run-time strides hipcc hoists one address register per LDS access out of
+// the layer loop - several hundred of them - and spills)
+template <int G, int T0, int NQ, int TOTAL, int EP, int lda, int ldo, class Bias>
+__device__ __forceinline__ void r8_dense_wide(R8Stream& s, const float* act, float* out, float* PART,
+                                              unsigned long long* mk, const Tid8f& t, Bias bias) {
+    constexpr int EX = G - 4;
+    f32x4 o[2];
+    {
+        S8Acc<2> acc;
+        s8_zero(acc);
+        s8_run<T0, NQ, TOTAL>(s, act + t.arow * lda, 4 * lda, acc);
+        s8_fold(acc, o);
+    }
+    {
+        const int col = 64 * t.wave + t.lane;
+        const float bv = bias(col);
+        unsigned long long* mw = mk + t.wave * R8;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = o[rb][r] + bv;
+                if constexpr (EP == 1) {
+                    const unsigned long long m = __ballot(v > 0.f);
+                    if (t.lane == 0) mw[4 * rb + r] = m;
+                    v = v > 0.f ? v : 0.f;
+                } else if constexpr (EP == 2) {
+                    v = ((mw[4 * rb + r] >> t.lane) & 1ull) ? v : 0.f;
+                }
+                out[(4 * rb + r) * ldo + col] = v;
+            }
+    }
+    // (the main epilogue comes FIRST: with the two GEMMs back to back hipcc's allocator runs out of registers - 500 spilled)
+    if constexpr (EX) {                // partial products of the fifth group: k-quads [w NQ / 4, (w + 1) NQ / 4)
+        static_assert(NQ % 4 == 0, "the fifth column group is K-split over 4 waves");
+        f32x4 ox[2];
+        S8Acc<2> acc;
+        s8_zero(acc);
+        s8_run<T0 + NQ, NQ / 4, TOTAL>(s, act + t.arow * lda + NQ * t.wave, 4 * lda, acc);
+        s8_fold(acc, ox);
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * R4_DS + t.lane] = ox[rb][r];
+    }
+    if constexpr (EX) {
+        s8_barrier();
+        const int col = 256 + t.lane;
+        const float bv = bias(col);
+        unsigned long long* mw = mk + 4 * R8;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                                   // wave w finishes chains 2 w, 2 w + 1 of the fifth group
+            const int rr = 2 * t.wave + i;
+            float v = r8_part_sum(PART + rr * R4_DS + t.lane) + bv;
+            if constexpr (EP == 1) {
+                const unsigned long long m = __ballot(v > 0.f);
+                if (t.lane == 0) mw[rr] = m;
+                v = v > 0.f ? v : 0.f;
+            } else if constexpr (EP == 2) {
+                v = ((mw[rr] >> t.lane) & 1ull) ? v : 0.f;
+            }
+            out[rr * ldo + col] = v;
+        }
+    }
+    s8_barrier();
+}
+
+// log q(x) and d log q / dx for the 8 rows in X0 (columns >= D zero; DP and PRM zeroed by the caller); the gradient is left
+// in the state buffer whose offset is returned through *grad_off.  Returns log q of row `tid >> 4` on threads < 128.
+// All 256 threads of the workgroup must call it; it ends with a workgroup barrier.
+template <int G>
+__device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds& l, const float* __restrict__ packed, float* lds,
+                                  const Tid8f& t, R8Stream& s, int* grad_off) {
+    constexpr int EX = G - 4, NQW = 16 * G, NQK = 4 * G;                  // k-quads of K = Wp; of a wave's quarter of it
+    constexpr int F_AW = 0, F_W1 = R8_KD4, F_W2 = F_W1 + R8_Kd4 + EX * (R8_Kd4 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK;
+    constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK, B_AWT = B_W1T + NQK,
+                  TR = B_AWT + R8_KD4;
+    constexpr int LF = NWAVE * (TF + TR) * 256;                             // floats per layer of the r8 image
+    constexpr int WS = 64 * G + 4;                                          // = l.WS, as a constant (see r8_dense_wide)
+    const float* img = packed + f.o_r8;
+    int cur = l.o_X0, nxt = l.o_X1;
+    float* const lds0 = lds;
+    const bool ew = t.tid < 128;
+    const int row = t.row, c = t.c;
+    const int DOp = f.DOp;
+    float logq = 0.f;
+    auto fwd_base = [&](int layer) { return reinterpret_cast<const float4*>(img + (size_t)layer * LF) + (size_t)t.wave * TF * 64; };
+    auto rev_base = [&](int layer) {
+        return reinterpret_cast<const float4*>(img + (size_t)layer * LF) + (size_t)(NWAVE * TF + t.wave * TR) * 64;
+    };
+    s8_prologue(s, fwd_base(f.K - 1));
+    for (int layer = f.K - 1; layer >= 0; --layer) {
+        float* lds = lds0 + r8_opaque_zero();
+        float* HA = lds + l.o_HA;
+        float* HB = lds + l.o_HB;
+        float* PART = lds + l.o_PART;
+        const float* HD = lds + l.o_HEAD + (size_t)layer * l.HF;
+        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * G * R8;
+        const bool tl = layer == f.K - 2;
+        if (tl) FAB_TL(f, 0);
+        {   // InvertibleAffine.inverse (+ folded ActNorm): z <- z @ W' + ac   (every wave; wave 0 stores)
+            f32x4 o[2];
+            S8Acc<2> acc;
+            s8_zero(acc);
+            s8_run<F_AW, R8_KD4, TF>(s, lds + cur + t.arow * R4_DS, 4 * R4_DS, acc);
+            s8_fold(acc, o);
+            if (t.wave == 0) {
+                const float bv = HD[t.lane];
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) lds[nxt + (4 * rb + r) * R4_DS + t.lane] = o[rb][r] + bv;
+            }
+        }
+        logq += HD[128 + 2 * f.Wp];
+        float* Z = lds + nxt;
+        s8_barrier();
+        if (tl) FAB_TL(f, 1);
+        // conditioner: HA = relu(z[:, :d] W1 + b1), HB = relu(HA W2 + b2)
+        r8_dense_wide<G, F_W1, R8_Kd4, TF, 1, R4_DS, WS>(s, Z, HA, PART, mk, t, [&](int col) { return HD[64 + col]; });
+        if (tl) FAB_TL(f, 2);
+        r8_dense_wide<G, F_W2, NQW, TF, 1, WS, WS>(s, HA, HB, PART, mk + G * R8, t, [&](int col) { return HD[64 + f.Wp + col]; });
+        if (tl) FAB_TL(f, 3);
+        {   // (shift | scale) = HB W3: K split over the waves, partial [8][64] products to PART
+            f32x4 o[2];
+            S8Acc<2> acc;
+            s8_zero(acc);
+            s8_run<F_W3, NQK, TF>(s, HB + t.arow * WS + 4 * NQK * t.wave, 4 * WS, acc);
+            s8_fold(acc, o);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * R4_DS + t.lane] = o[rb][r];
+        }
+        // the ring is empty here: request the next layer's (or the reverse sweep's first) tiles behind the element-wise stage
+        s8_prologue(s, layer > 0 ? fwd_base(layer - 1) : rev_base(0));
+        s8_barrier();
+        if (tl) FAB_TL(f, 4);
+        // AffineCoupling.inverse: z2 <- (z2 - shift) exp(-s), log_det = -sum(s)
+        if (ew) {
+            float ssum = 0.f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int j = c + 16 * it;
+                if (j < f.DO) {
+                    const float shift = r8_part_sum(PART + row * R4_DS + j) + HD[64 + 2 * f.Wp + j];
+                    const float sv = r8_part_sum(PART + row * R4_DS + DOp + j) + HD[64 + 2 * f.Wp + DOp + j];
+                    const float es = expf(-sv);
+                    const float v2 = (Z[row * R4_DS + f.d + j] - shift) * es;
+                    Z[row * R4_DS + f.d + j] = v2;
+                    lds[l.o_ES + ((size_t)layer * R8 + row) * DOp + j] = es;
+                    lds[l.o_V2 + ((size_t)layer * R8 + row) * DOp + j] = v2;
+                    ssum += sv;
+                }
+            }
+            logq += -row16_sum(ssum);
+        }
+        s8_barrier();
+        if (tl) FAB_TL(f, 5);
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    // DiagGaussian.log_prob, the seed of the reverse sweep, and the first layer's coupling cotangents
+    if (ew) {
+        float* DP = lds + l.o_DP;
+        const float* base = packed + f.o_base;
+        float* Zc = lds + cur;
+        float bsum = 0.f;
+        for (int j = c; j < f.D; j += 16) {
+            const float ls = base[f.Dp + j];
+            const float sc = expf(ls);
+            const float zn = (Zc[row * R4_DS + j] - base[j]) / sc;
+            bsum += ls + 0.5f * (zn * zn);
+            Zc[row * R4_DS + j] = -(zn / sc);
+        }
+        logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
+        // (the 16 lanes of a row wrote the whole row: same wave, program order)
+        for (int j = c; j < f.DO; j += 16) {
+            const float g2 = Zc[row * R4_DS + f.d + j];
+            const float es = lds[l.o_ES + (size_t)row * DOp + j];
+            const float v2 = lds[l.o_V2 + (size_t)row * DOp + j];
+            DP[row * R4_DS + j] = -(g2 * es);
+            DP[row * R4_DS + DOp + j] = -(g2 * v2) - 1.f;
+            Zc[row * R4_DS + f.d + j] = g2 * es;
+        }
+    }
+    s8_barrier();
+    // reverse sweep: g = d log q / d(state), layers 0 .. K-1
+    for (int layer = 0; layer < f.K; ++layer) {
+        float* lds = lds0 + r8_opaque_zero();
+        float* HA = lds + l.o_HA;
+        float* HB = lds + l.o_HB;
+        float* DP = lds + l.o_DP;
+        float* PART = lds + l.o_PART;
+        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * G * R8;
+        float* Gs = lds + cur;
+        const bool tl = layer == 1;
+        if (tl) FAB_TL(f, 16);
+        // d relu(h2) = DP W3T masked by h2 > 0 -> HA;  d relu(h1) = HA W2T masked by h1 > 0 -> HB
+        r8_dense_wide<G, B_W3T, R8_Ko4, TR, 2, R4_DS, WS>(s, DP, HA, PART, mk + G * R8, t, [](int) { return 0.f; });
+        if (tl) FAB_TL(f, 17);
+        r8_dense_wide<G, B_W2T, NQW, TR, 2, WS, WS>(s, HA, HB, PART, mk, t, [](int) { return 0.f; });
+        if (tl) FAB_TL(f, 18);
+        {   // conditioner input gradient = HB W1T: K split over the waves
+            f32x4 o[2];
+            S8Acc<2> acc;
+            s8_zero(acc);
+            s8_run<B_W1T, NQK, TR>(s, HB + t.arow * WS + 4 * NQK * t.wave, 4 * WS, acc);
+            s8_fold(acc, o);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * R4_DS + t.lane] = o[rb][r];
+        }
+        s8_barrier();
+        if (tl) FAB_TL(f, 19);
+        if (ew && c < f.d) Gs[row * R4_DS + c] += r8_part_sum(PART + row * R4_DS + c);        // g[:, :d] += ...   (d <= 16)
+        s8_barrier();
+        if (tl) FAB_TL(f, 20);
+        {   // g <- g W'^T (every wave; wave 0 stores, and forms the NEXT layer's coupling cotangents where its g2 appears)
+            f32x4 o[2];
+            S8Acc<2> acc;
+            s8_zero(acc);
+            s8_run<B_AWT, R8_KD4, TR>(s, Gs + t.arow * R4_DS, 4 * R4_DS, acc);
+            s8_fold(acc, o);
+            if (layer + 1 < f.K) s8_prologue(s, rev_base(layer + 1));
+            if (t.wave == 0) {
+                const int j = t.lane - f.d;
+                const bool cpl = layer + 1 < f.K && j >= 0 && j < f.DO;
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int rr = 4 * rb + r;
+                        float v = o[rb][r];
+                        if (cpl) {
+                            const float es = lds[l.o_ES + ((size_t)(layer + 1) * R8 + rr) * DOp + j];
+                            const float v2 = lds[l.o_V2 + ((size_t)(layer + 1) * R8 + rr) * DOp + j];
+                            DP[rr * R4_DS + j] = -(v * es);
+                            DP[rr * R4_DS + DOp + j] = -(v * v2) - 1.f;
+                            v = v * es;
+                        }
+                        lds[nxt + rr * R4_DS + t.lane] = v;
+                    }
+            }
+        }
+        s8_barrier();
+        if (tl) FAB_TL(f, 21);
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *grad_off = cur;
+    return logq;
+}
+
+}  // namespace fab

@@ -17,6 +17,7 @@
 //                      cotangents to the identity coordinates (transposed weight tiles on the matrix cores)
 // One wave handles one chain in the element-wise kernels (lane = coordinate, D <= 64).
 #include "flow_device.h"
+#include "stream_r8.h"
 #include "launch.h"
 #include <stdlib.h>
 
@@ -1197,12 +1198,15 @@ static int cu_count() {
 // CU with more than one workgroup (the kernel's registers allow no second one: 2048 chains on MI355X), 16 chains above.
 // FABHIP_OPT_TILE_SHAPE 8 (or 4) / 16 forces the tile; FABHIP_OPT_SPLINE_MFMA = 16 selects the 16x16x4 kernel
 // (k_spline_logprob: the only one for other widths and for fast mode).  Returns row blocks (0: not this kernel).
-static int r8_row_blocks(const SplineDims& f, long B, int fast) {
+static int r8_row_blocks(const SplineDims& f, long B, int fast, bool grad) {
     if (f.NTWM != 4 || !f.o_r8 || fast || option(FABHIP_OPT_SPLINE_MFMA) == 16) return 0;
     const int sel = option(FABHIP_OPT_TILE_SHAPE);
-    if (sel == 16) return 4;
-    if (sel == 8 || sel == 4) return 2;
-    return B <= 8L * cu_count() ? 2 : 4;
+    int rb = sel == 16 ? 4 : ((sel == 8 || sel == 4) ? 2 : (B <= 8L * cu_count() ? 2 : 4));
+    // the LDS plan grows with the layer count (ReLU ballots) and the output chunks: deep / wide flows fall back to the smaller
+    // tile, then to the 16x16x4 kernel (whose ballots live in the workspace)
+    if (rb == 4 && (size_t)make_s8_lds(f, grad, 16).total * 4 > 160 * 1024) rb = 2;
+    if (rb == 2 && (size_t)make_s8_lds(f, grad, 8).total * 4 > 160 * 1024) rb = 0;
+    return rb;
 }
 
 template <int NCH, int RB>
@@ -1333,7 +1337,7 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const float* pk = flow->packed;
     if (!tape && !option(FABHIP_OPT_SPLINE_STAGED)) {           // one launch (the staged kernels below: tape, debugging)
-        const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision));
+        const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision), grad_x != nullptr);
         if (rb == 2) return launch_logprob_r8_nch<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
         if (rb == 4) return launch_logprob_r8_nch<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
         if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);

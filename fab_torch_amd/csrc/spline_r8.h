@@ -25,12 +25,10 @@
 // Everything else a layer needs (metadata rows, unconditional spline parameters, periodic-feature weights, biases) is one
 // contiguous head block per layer, copied to LDS at the layer top with plain loads BEFORE the ring is requested, so no
 // compiler-tracked load ever waits behind the stream.  ReLU decisions: one 64-bit ballot per (wave, chain), kept in LDS.
-// Included from spline_kernels.hip (namespace fab, after the rqs_* helpers).
+// Included from spline_kernels.hip (namespace fab, after the rqs_* helpers); the stream / GEMM-step machinery is stream_r8.h.
 
-constexpr int S8_RD = 32;              // ring depth: 1-KiB tiles in flight per wave
 constexpr int S8_AS = 64 + 4;          // leading dim of the identity-feature tile (K = 64)
 constexpr int S8_WS = 256 + 4;         // leading dim of the hidden tiles
-constexpr int S8_INF = 1 << 20;
 
 // head block of a layer in the r8 image (floats); the first three regions sit where SplineDims puts them in a layer image
 constexpr int S8H_META = 0, S8H_UNC = (SP_META_ROWS + 2) * 64, S8H_PFW = S8H_UNC + 1664, S8H_B0 = S8H_PFW + 128,
@@ -75,8 +73,6 @@ struct Tid8 {
     }
 };
 
-__device__ __forceinline__ void s8_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
 __device__ __forceinline__ float row32_sum(float v) {
     v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 8);
@@ -84,125 +80,6 @@ __device__ __forceinline__ float row32_sum(float v) {
     v += __shfl_xor(v, 2);
     v += __shfl_xor(v, 1);
     return v;
-}
-
-template <int I, int N, class F>
-__device__ __forceinline__ void s8_for(F&& fn) {
-    if constexpr (I < N) {
-        fn(std::integral_constant<int, I>{});
-        s8_for<I + 1, N>(fn);
-    }
-}
-
-// ---- the wave's weight stream ---------------------------------------------------------------------------------------
-struct S8Stream {
-    f32x4 r[S8_RD];                    // ring slot of stream tile k: k % S8_RD   ("a" registers)
-    unsigned voff[8];                  // lane * 16 + 4096 j: with the 4 immediate offsets, 32 tiles from one scalar base
-    const float4* next;                // tile that step 0 of the next iteration requests
-};
-
-template <int IMM>
-__device__ __forceinline__ void s8_load(f32x4& dst, unsigned voff, const float4* sbase) {
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(IMM));
-}
-template <int IMM>
-__device__ __forceinline__ void s8_load_first(f32x4& dst, unsigned voff, const float4* sbase) {   // fresh scalar base: see gload16s_first
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=a"(dst) : "v"(voff), "s"(sbase), "n"(IMM));
-}
-template <int N>
-__device__ __forceinline__ void s8_wait(f32x4& r) {
-    static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
-    asm volatile("s_waitcnt vmcnt(%1)" : "+a"(r) : "n"(N));
-}
-
-__device__ __forceinline__ void s8_stream_init(S8Stream& s, const Tid8& t) {
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s.voff[j] = (unsigned)(t.lane * 16 + 4096 * j);
-}
-
-// layer top: request tiles 0 .. RD-2 of the wave's stream at `base`
-__device__ __forceinline__ void s8_prologue(S8Stream& s, const float4* base) {
-    s8_for<0, S8_RD - 1>([&](auto dc) {
-        constexpr int d = decltype(dc)::value;
-        if constexpr (d == 0) s8_load_first<0>(s.r[0], s.voff[0], base);
-        else s8_load<(d % 4) * 1024>(s.r[d], s.voff[d / 4], base);
-    });
-    s.next = base + (size_t)(S8_RD - 1) * 64;
-}
-
-// NSTEP k-quads (stream tiles T0 .. T0 + NSTEP - 1, T0 % RD == PHASE) of which the first USE are multiplied:
-//   acc[k % 4][rb] += A[rb][4 q + k] (x) B[4 q + k][64 w + lane]
-// REMAIN = stream tiles of this layer after T0 (S8_INF: more than 2 RD): a refill is issued only for a tile that exists and
-// the wait counts only loads that were issued (the last stages of a layer drain the ring).
-// `ap`: this lane's row of the activation tile at the iteration's first quad; `rb1`: float offset of row block 1.
-template <int RB>
-struct S8Acc {
-    static constexpr int KI = 4;                                           // accumulators per row block (k mod 4): the same sums for every RB
-    f32x4 a[KI][RB];
-};
-
-template <int NSTEP, int USE, int PHASE, int REMAIN, int RB>
-__device__ __forceinline__ void s8_iter(S8Stream& s, const float* ap, int rb1, S8Acc<RB>& acc) {
-    constexpr int KI = S8Acc<RB>::KI;
-    float4 an[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) an[rb] = *reinterpret_cast<const float4*>(ap + rb * rb1);
-    s8_for<0, NSTEP>([&](auto dc) {
-        constexpr int d = decltype(dc)::value;
-        constexpr int slot = (PHASE + d) % S8_RD;
-        constexpr int left = REMAIN - d;                                   // tiles after this one
-        constexpr int N = left < S8_RD - 2 ? (left < 0 ? 0 : left) : S8_RD - 2;
-        s8_wait<N>(s.r[slot]);
-        __builtin_amdgcn_sched_barrier(0);
-        float4 a[RB];
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) a[rb] = an[rb];
-        if constexpr (d < USE) {
-            if constexpr (d + 1 < USE) {
-#pragma unroll
-                for (int rb = 0; rb < RB; ++rb) an[rb] = *reinterpret_cast<const float4*>(ap + rb * rb1 + 4 * (d + 1));
-            }
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                acc.a[0][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].x, s.r[slot].x, acc.a[0][rb], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (d - 1 + S8_RD <= REMAIN) {                          // top up: tile T0 + d - 1 + RD into the slot of T0 + d - 1
-            constexpr int dp = (slot + S8_RD - 1) % S8_RD;
-            if constexpr (d == 0) s8_load_first<0>(s.r[dp], s.voff[0], s.next);
-            else s8_load<(d % 4) * 1024>(s.r[dp], s.voff[d / 4], s.next);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (d < USE) {
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                acc.a[1 % KI][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].y, s.r[slot].y, acc.a[1 % KI][rb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                acc.a[2 % KI][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].z, s.r[slot].z, acc.a[2 % KI][rb], 0, 0, 0);
-#pragma unroll
-            for (int rb = 0; rb < RB; ++rb)
-                acc.a[3 % KI][rb] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[rb].w, s.r[slot].w, acc.a[3 % KI][rb], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    });
-    s.next += (size_t)NSTEP * 64;
-}
-
-template <int RB>
-__device__ __forceinline__ void s8_zero(S8Acc<RB>& acc) {
-#pragma unroll
-    for (int k = 0; k < S8Acc<RB>::KI; ++k)
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) acc.a[k][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
-}
-template <int RB>
-__device__ __forceinline__ void s8_fold(const S8Acc<RB>& acc, f32x4 (&o)[RB]) {
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        if constexpr (S8Acc<RB>::KI == 4) o[rb] = (acc.a[0][rb] + acc.a[1][rb]) + (acc.a[2][rb] + acc.a[3][rb]);
-        else o[rb] = acc.a[0][rb] + acc.a[1][rb];
-    }
 }
 
 // OUT[4 RB][64 w ..] = ACT[4 RB][256] @ B: two iterations of 32 k-quads; LAST = REMAIN of the second one.
@@ -310,7 +187,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
     const int col = 64 * t.wave + t.lane;                                      // this lane's output column of a GEMM stage
     S8Stream s;
-    s8_stream_init(s, t);
+    s8_stream_init(s, t.lane);
     // The next layer's head block (and, in the reverse sweep, its state and conditioner-output tiles) is requested with plain
     // loads at the start of a mid-layer GEMM stage - the requests queue up between the ring's tiles and have landed long before
     // the layer ends - and committed to LDS at the next layer top: a layer top then starts on data that is already there.

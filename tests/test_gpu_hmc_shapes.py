@@ -88,10 +88,13 @@ def test_hmc_transition_is_bitwise_deterministic_over_repeated_launches(D, K, no
     assert (err > 1e-4).sum() <= 1, f"{int((err > 1e-4).sum())} of {len(idx)} sampled chains differ from the oracle"
 
 
-@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 1024), (6, 3, 8, 70), (60, 4, 4, 200), (2, 2, 40, 33), (16, 3, 16, 257)])
-def test_four_chain_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B):
-    """k_hmc_step_r4 (4 chains per workgroup on v_mfma_f32_4x4x1, used for B <= 1152) against k_hmc_step (16 chains per
-    workgroup): the same transition from the same point and noise.  The two differ only in the summation order inside
+@pytest.mark.parametrize("D,K,nodes,B,small", [(32, 10, 10, 1024, 4), (6, 3, 8, 70, 4), (60, 4, 4, 200, 4), (2, 2, 40, 33, 4),
+                                               (16, 3, 16, 257, 4), (32, 10, 10, 2048, 8), (16, 3, 16, 257, 8),
+                                               (32, 12, 8, 1501, 8), (8, 2, 32, 29, 8)])
+def test_small_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B, small):
+    """k_hmc_step_r4 (4 chains per workgroup on v_mfma_f32_4x4x1, used for B <= 1152) and k_hmc_step_r8 (8 chains per
+    workgroup, one wave per 64 hidden columns: D <= 32, hidden width 193 .. 320, used for 1152 < B <= 2048) against
+    k_hmc_step (16 chains per workgroup): the same transition from the same point and noise.  The two differ only in the summation order inside
     the GEMMs, so per-chain results agree to fp32 rounding except where an accept / reject decision flips; the
     acceptance sums feeding the step-size rule are added in the same order by construction (bit-equal epsilons
     whenever no decision flipped)."""
@@ -107,7 +110,7 @@ def test_four_chain_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B)
         pytest.skip("ManyWell needs an even dimension")
     res = {}
     for mode in ("0", "1"):
-        _ops.load().set_option(_ops.OPT_TILE_SHAPE, 4 if mode == "1" else 16)
+        _ops.load().set_option(_ops.OPT_TILE_SHAPE, small if mode == "1" else 16)
         hmc = fa.HamiltonianMonteCarlo(4, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
                                        n_outer=2, L=3).to(DEV)
         g = torch.Generator(device=DEV).manual_seed(5)
@@ -124,6 +127,37 @@ def test_four_chain_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B)
     assert float((lqa[same] - lqb[same]).abs().max()) <= 2e-3 * (1 + float(lqa[same].abs().max()))
     assert torch.allclose(ea, eb, rtol=0, atol=0) or float(same.float().mean()) < 1.0
     assert torch.allclose(ca, cb, rtol=1e-6)
+    if small == 8 or D <= 32:
+        assert not torch.equal(lqa, lqb), "both runs used the same kernel"
+
+
+def test_eight_chain_tiles_are_bitwise_reproducible_and_independent_of_the_batch():
+    """Race screen for k_hmc_step_r8 / k_ais_init_r8 (weight ring in AGPRs filled by inline-asm loads, LDS-only barriers):
+    the same AIS call on the same noise five times at 2048 chains (256 workgroups of 5 waves) and at a ragged 1499:
+    identical bits; and a chain's result does not depend on the chains around it."""
+    D, K, nodes, M = 32, 10, 10, 4
+    torch.manual_seed(1)
+    flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    with _ops.option(_ops.OPT_TILE_SHAPE, 8):
+        for B in (2048, 1499):
+            outs = []
+            for rep in range(5):
+                hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1,
+                                               n_outer=1, L=5, eval_mode=True).to(DEV)
+                ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, False, 2.0, M)
+                g = torch.Generator().manual_seed(3)
+                eps0 = torch.randn(B, D, generator=g).to(DEV)
+                na = torch.randn(M, 1, B, D, generator=g).to(DEV)
+                nb = torch.empty(M, 1, B).exponential_(generator=g).to(DEV)
+                pt, lw = ais.sample_and_log_weights(B, eps0=eps0, noise_a=na, noise_b=nb)
+                outs.append((pt.x.clone(), lw.clone()))
+            for o in outs[1:]:
+                assert torch.equal(o[0], outs[0][0]) and torch.equal(o[1], outs[0][1])
+            n = 517                                          # the first 517 chains alone (step sizes frozen: eval mode)
+            pt, lw = ais.sample_and_log_weights(n, eps0=eps0[:n].contiguous(), noise_a=na[:, :, :n].contiguous(),
+                                                noise_b=nb[:, :, :n].contiguous())
+            assert torch.equal(pt.x, outs[0][0][:n]) and torch.equal(lw, outs[0][1][:n])
 
 
 def test_four_chain_tiles_are_bitwise_reproducible():

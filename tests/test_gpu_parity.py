@@ -383,10 +383,10 @@ def test_full_ais_hmc_vs_reference_golden(tag):
     assert abs(info["dist0_p_accept_0"] - float(g["dist0_p_accept_0"])) < 1e-3
 
 
-@pytest.mark.parametrize("shape", [4, 16])
+@pytest.mark.parametrize("shape", [4, 8, 16])
 def test_headline_architecture_vs_reference_golden(shape):
     """the kernels the bench times (hidden width 320 = 5 column tiles per wave, K = 10, D = 32; 4-chain
-    stream kernel and 16-chain kernel) against the REFERENCE's own AIS call at that architecture (g14: weights rebuilt from
+    stream kernel, 8-chain stream kernel and 16-chain kernel) against the REFERENCE's own AIS call at that architecture (g14: weights rebuilt from
     the fixture's seed, noise and outputs stored).
     (b) every one of the 8 transitions teacher-forced from the reference's snapshot with the reference's step size of that
         transition: proposals, accept decisions, densities at 1e-4.  Through an untrained 10-layer flow ONE transition can

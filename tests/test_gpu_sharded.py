@@ -48,7 +48,7 @@ def _noise(total, scale_second_half=1.0):
     return eps0, na, nb
 
 
-@pytest.mark.parametrize("total,shape", [(128, 4), (2048, 16), (2048, 4)])
+@pytest.mark.parametrize("total,shape", [(128, 4), (2048, 16), (2048, 4), (2048, 8)])
 def test_emulated_shards_reproduce_the_fused_single_device_run_bit_for_bit(total, shape):
     eps0, na, nb = (t.to(DEV) for t in _noise(total, 1.7))
     with _ops.option(_ops.OPT_TILE_SHAPE, shape):          # (chains are bit-independent of the batch WITHIN a tile shape)

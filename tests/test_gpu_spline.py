@@ -137,6 +137,27 @@ def test_the_tile_shapes_of_the_spline_density_kernels_agree(D, L, hidden, circ,
     assert torch.equal(lq, b8[0]) and torch.equal(gr, b8[1])
 
 
+def test_a_deep_wide_spline_flow_falls_back_to_the_tile_that_fits_the_lds():
+    """40 layers x 64 dimensions: the LDS plan of the 16-chain stream kernel (ReLU ballots of every layer + 4 output chunks)
+    exceeds 160 KiB - the launch takes the 8-chain tile instead of failing, with the same numbers."""
+    from fab_torch_amd import _ops
+    D, L, hidden, B = 64, 40, 256, 24
+    hf = fa.make_wrapped_normflow_spline(D, L, hidden, (0, 5), torch.full((D,), 5.0)).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in hf.parameters():
+            if p.dim() == 2 and p.shape[0] % 25 == 0:
+                p.add_(0.01 * torch.randn_like(p))
+    x = torch.randn(B, D, generator=torch.Generator().manual_seed(1)).to(DEV)
+    with _ops.option(_ops.OPT_TILE_SHAPE, 8):
+        lq8, g8 = hf.log_prob_and_grad(x)
+    with _ops.option(_ops.OPT_TILE_SHAPE, 16):
+        lq16, g16 = hf.log_prob_and_grad(x)
+    with _ops.option(_ops.OPT_SPLINE_MFMA, 16):
+        lq0, g0 = hf.log_prob_and_grad(x)
+    assert torch.isfinite(lq8).all() and torch.equal(lq8, lq16) and torch.equal(g8, g16)
+    assert close(lq8, lq0, RTOL), f"log q: {worst(lq8, lq0):.2f}x tol"
+
+
 def test_identity_initialised_spline_flow_is_the_base_distribution():
     D, circ = 10, (2, 5)
     tb = torch.full((D,), 5.0); tb[list(circ)] = math.pi

@@ -173,10 +173,11 @@ def check_slice_vs_oracle_per_transition(w: Workload):
 @contextlib.contextmanager
 def same_tile_shape_as(B):
     """Chains are bit-independent of the batch they run in WITHIN a tile shape; the HMC kernel picks 4-chain tiles for
-    B <= 1152 and 16-chain tiles above (different summation order inside the GEMMs), so the small comparison runs are
-    pinned to the shape the B-chain run used."""
+    B <= 1152, 8-chain tiles up to 2048 (where that kernel exists: D <= 32, hidden width 193 .. 320; 16 otherwise) and
+    16-chain tiles above (different summation order inside the GEMMs), so the small comparison runs are pinned to the
+    shape the B-chain run used."""
     from fab_torch_amd import _ops
-    with _ops.option(_ops.OPT_TILE_SHAPE, 4 if B <= 1152 else 16):
+    with _ops.option(_ops.OPT_TILE_SHAPE, 4 if B <= 1152 else (8 if B <= 2048 else 16)):
         yield
 
 

@@ -3,7 +3,7 @@ inline-asm loads fill behind hipcc's back, so the compiler must never read or mo
 the hand-counted `s_waitcnt vmcnt(N)` that covers it.  Walks every k_spline_logprob_r8 kernel linearly (the GEMM stages are
 straight-line), tracks the loads in flight and flags (1) any non-load instruction that reads or writes an AGPR whose load may
 still be in flight, (2) a VMEM load whose scalar base was written by v_readlane / v_readfirstlane fewer than 5 wait states
-earlier.  Usage: python tools/check_r8_isa.py  (compiles spline_kernels.hip for gfx950 into /tmp; no GPU needed)."""
+earlier.  Usage: python tools/check_r8_isa.py [spline] [flow]  (compiles the .hip for gfx950 into /tmp; no GPU needed)."""
 import os
 import re
 import subprocess
@@ -14,11 +14,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LLVM = "/opt/rocm/lib/llvm/bin"
 
 
-def disassemble():
+SOURCES = {"spline": ("spline_kernels.hip", ("k_spline_logprob_r8",)),
+           "flow": ("ais_kernels.hip", ("k_hmc_step_r8", "k_ais_init_r8"))}
+
+
+def disassemble(src):
     tmp = tempfile.mkdtemp(prefix="r8isa")
     co, elf = os.path.join(tmp, "sp.co"), os.path.join(tmp, "sp.elf")
     subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-c",
-                           os.path.join(ROOT, "fab_torch_amd/csrc/spline_kernels.hip"), "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "fab_torch_amd/csrc", src), "-I", os.path.join(ROOT, "include"),
                            "-w", "-o", co])
     subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={co}",
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={elf}"])
@@ -75,20 +79,27 @@ def check_kernel(name, lines):
 
 
 def main():
-    text = disassemble()
+    rc = 0
+    for which in (sys.argv[1:] or sorted(SOURCES)):
+        rc |= check_source(*SOURCES[which])
+    return rc
+
+
+def check_source(src, patterns):
+    text = disassemble(src)
     kernels, cur, name = {}, None, None
     for raw in text.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", raw)
         if m:
             name = m.group(1)
-            cur = kernels.setdefault(name, []) if "k_spline_logprob_r8" in name else None
+            cur = kernels.setdefault(name, []) if any(p in name for p in patterns) else None
             continue
         if cur is not None:
             ins = raw.split("//")[0].strip()
             if ins:
                 cur.append(ins)
     if not kernels:
-        print("no k_spline_logprob_r8 kernel found")
+        print(f"{src}: no kernel matching {patterns} found")
         return 1
     rc = 0
     for name, lines in sorted(kernels.items()):

@@ -1,0 +1,35 @@
+"""Dev tool: stage timeline (s_memtime) of one forward and one reverse layer of the 8-chain-tile HMC kernel (flow_r8.h)."""
+import ctypes as C, os, sys
+os.environ["FABHIP_TIMELINE"] = "1"
+os.environ["FABHIP_TILE"] = "8"
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import fab_torch_amd as fa
+from fab_torch_amd import _lib
+from fab_torch_amd.transition_operators import create_point
+dev = torch.device("cuda", 0)
+torch.manual_seed(0)
+D, B = 32, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+nodes = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+flow = fa.RealNVP(D, 10, nodes).to(dev).requires_grad_(False)
+target = fa.ManyWellEnergy(D)
+hmc = fa.HamiltonianMonteCarlo(8, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05, L=5).to(dev)
+hmc.set_eval_mode(True)
+x0, _ = flow.native_sample(torch.randn(B, D, device=dev))
+pt = create_point(x0, flow, target, with_grad=True)
+for _ in range(5):
+    hmc.transition(pt, 4, 0.5)
+torch.cuda.synchronize()
+buf = (C.c_int64 * 64)()
+_lib.check(_lib.load().fabhip_debug_timeline(buf, 64), "timeline")
+ts = list(buf)
+names = {0: "fwd layer start", 1: "affine (every wave, 8 tiles)", 2: "W1 (d -> W, 4 tiles)", 3: "W2 (W x W, 16 G tiles)",
+         4: "W3 (K split, 16 tiles) + next ring", 5: "coupling", 16: "rev layer start", 17: "W3T (8 tiles)",
+         18: "W2T (16 G tiles)", 19: "W1T (K split, 16 tiles)", 20: "add", 21: "affine^T (8 tiles) + next ring"}
+prev = None
+for i in sorted(names):
+    if not ts[i]:
+        continue
+    print(f"{i:2d} {names[i]:36s}", "" if prev is None or i in (0, 16) else f"+{ts[i] - prev:6d} ticks")
+    prev = ts[i]
+print("fwd layer:", ts[5] - ts[0], "rev layer:", ts[21] - ts[16], "ticks")
