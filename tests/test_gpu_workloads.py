@@ -242,9 +242,10 @@ def test_cfg4_sharded_16384_chains_gather_equals_single_run():
         check_slice_vs_oracle_per_transition(w)
     pt, lw, info = check_full_size_properties(w)
     bufs = []
-    for r in range(R):
-        p_r, lw_r, _ = w.run(slice(r * per, (r + 1) * per))
-        bufs.append(parallel.pack_particles(p_r.x, lw_r, p_r.log_q, per))
+    with same_tile_shape_as(w.B):                 # (a 2048-chain rank takes 8-chain tiles by default, the 16384-chain
+        for r in range(R):                        # run 16-chain tiles: bit-identity holds within a tile shape)
+            p_r, lw_r, _ = w.run(slice(r * per, (r + 1) * per))
+            bufs.append(parallel.pack_particles(p_r.x, lw_r, p_r.log_q, per))
     x_g, lw_g, lq_g = parallel.unpack_particles(torch.cat(bufs))
     assert torch.equal(x_g, pt.x) and torch.equal(lw_g, lw) and torch.equal(lq_g, pt.log_q)
     st = fa.ess_and_log_z(lw_g, n_norm=R * per).cpu()
