@@ -417,9 +417,11 @@ def main():
         from fab_torch_amd import _ops
         shape = int(_ops.load().get_option(_ops.OPT_TILE_SHAPE))
         r4 = shape == 4 or (shape == 0 and B_PER_GPU <= 1152)               # 4-chain tiles (flow_r4.h) below 1153 chains
-        n_wg = (B_PER_GPU + 3) // 4 if r4 else (B_PER_GPU + 15) // 16
+        r8 = shape == 8 or (shape == 0 and 1152 < B_PER_GPU <= 2048)        # 8-chain tiles (flow_r8.h) up to 2048
+        n_wg = (B_PER_GPU + 3) // 4 if r4 else ((B_PER_GPU + 7) // 8 if r8 else (B_PER_GPU + 15) // 16)
         kname = "k_hmc_step_r4<5> (4 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r4 else \
-            "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)"
+            ("k_hmc_step_r8<5> (8 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r8 else
+             "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)")
         roof = {"bound": "mfma", "kernel": kname, "achieved": ach,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": None, "ms_per_launch": t_kernel * 1e3, "flop_per_launch": flop,
@@ -433,8 +435,9 @@ def main():
             per_pair = 4 * (2 * 32 * 64 + 16 * wp + 2 * wp * wp + wp * 32 + wp * 16 + 32 * wp)     # bytes per layer pair (D = 32)
             stream = per_pair * K_LAYERS * L
             roof["weight_stream"] = {"bytes_per_workgroup_per_launch": stream, "GBps_per_cu": stream / t_kernel / 1e9,
-                                     "note": "tools/ubench/stream.hip: 48 B/clk per CU for a pure stream of an image this size "
-                                             "(~100 GB/s at the ~2.1 GHz the kernel runs at); DESIGN.md section 4"}
+                                     "note": "tools/ubench/nsplit.hip: the L2 -> CU path delivers ~52 B/clk per CU to 256 workgroups "
+                                             "streaming the same image (~110 GB/s at the ~2.1 GHz the kernel runs at); "
+                                             "DESIGN.md section 4"}
         # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes restricted to this kernel
         # (tools/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed summary
         for path in ((os.path.join("profiles", "r3", "hmc_step_r4_traffic_pmc_summary.json"),) if r4 else
@@ -449,6 +452,11 @@ def main():
         ach_full = 4096 * L * 2 * F_FWD / t_full / 1e12
         roof["full_chip"] = {"chains": 4096, "ms_per_launch": t_full * 1e3, "achieved": ach_full,
                              "frac": ach_full / PEAK_FP32_MFMA_TFLOPS}
+        # 8-chain tiles (k_hmc_step_r8<5>) with one workgroup per CU (2048 chains: the shape of BASELINE cfg 4 per GPU):
+        t_2k = time_transition(2048)
+        ach_2k = 2048 * L * 2 * F_FWD / t_2k / 1e12
+        roof["chains_2048"] = {"chains": 2048, "kernel": "k_hmc_step_r8<5> (8 chains per workgroup)", "ms_per_launch": t_2k * 1e3,
+                               "achieved": ach_2k, "frac": ach_2k / PEAK_FP32_MFMA_TFLOPS}
         hmc.set_eval_mode(False)
 
     # ---- second roofline: the resample scan + the whole systematic resampler at N = 2^26 (HBM-bound) ----
