@@ -1021,7 +1021,7 @@ static bool use_r8_tiles(const FlowDims& f, long B) {
     const int shape = option(FABHIP_OPT_TILE_SHAPE);
     if (shape == 16 || shape == 4) return false;
     if (shape == 8) return true;
-    return B > R8_MIN_CHAINS && B <= 8L * 256;
+    return B > R8_MIN_CHAINS && B <= (long)R8 * cu_count();
 }
 
 long long* debug_timeline(hipStream_t st);           // flow_kernels.hip (dev-only stage stamps)

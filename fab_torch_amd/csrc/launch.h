@@ -45,6 +45,17 @@ static inline int set_max_lds(const void* fn, size_t bytes) {
     return FABHIP_OK;
 }
 
+// compute units of the current device (cached: the tile-shape choices compare the batch with chains-per-workgroup x CUs)
+static inline int cu_count() {
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
+        (void)hipGetLastError();
+        return v > 0 ? v : 256;
+    }();
+    return n;
+}
+
 static inline int check_flow_shape(int dim, int n_layers, int width) {
     if (dim < 2 || n_layers < 1 || width < 1) return FABHIP_EINVAL;
     if (dim > FABHIP_MAX_DIM || n_layers > FABHIP_MAX_LAYERS || width > FABHIP_MAX_WIDTH) return FABHIP_ENOTSUP;

@@ -1186,14 +1186,6 @@ static int launch_logprob(const SplineDims& f, const float* packed, const float*
 
 // 8-chain tiles (spline_r8.h): hidden width padded to 256, fp32 path.  FABHIP_OPT_TILE_SHAPE 16 / 8 (or 4) forces a shape;
 // otherwise 8-chain tiles whenever 16-chain tiles would leave CUs without a workgroup.
-static int cu_count() {
-    static const int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) v = 0;
-        return v > 0 ? v : 256;
-    }();
-    return n;
-}
 // The 4x4x1 stream kernels (spline_r8.h; hidden width padded to 256, fp32 path): 8 chains per workgroup while that leaves no
 // CU with more than one workgroup (the kernel's registers allow no second one: 2048 chains on MI355X), 16 chains above.
 // FABHIP_OPT_TILE_SHAPE 8 (or 4) / 16 forces the tile; FABHIP_OPT_SPLINE_MFMA = 16 selects the 16x16x4 kernel

@@ -87,8 +87,10 @@ int fabhip_get_fast_mode(void);
  * one load (nothing on a launch path calls getenv), changed at run time only through fabhip_set_option (returns the
  * previous value, or a negative FABHIP_E* code for an unknown key).  No reference counterpart (the reference has no
  * kernel variants); production code never sets them. */
-#define FABHIP_OPT_TILE_SHAPE 0          /* FABHIP_TILE: chains per workgroup of the fused RealNVP transitions: 0 = by batch
-                                            size (default), 4 / 8 = flow_r4.h tiles, 16 = flow_device.h tiles */
+#define FABHIP_OPT_TILE_SHAPE 0          /* FABHIP_TILE: chains per workgroup of the fused RealNVP transitions (4 = flow_r4.h,
+                                            8 = flow_r8.h, 16 = flow_device.h tiles; a shape that does not exist for the flow
+                                            falls back to 16) and of the 4x4x1 spline density kernel (8 / 16); 0 = by batch
+                                            size (default) */
 #define FABHIP_OPT_R4_STREAM 1           /* FABHIP_R4_STREAM: 1 = continuous weight stream where its image exists (default),
                                             0 = per-stage request groups */
 #define FABHIP_OPT_SCAN_VARIANT 2        /* FABHIP_SCAN_VARIANT: fixed-point CDF scan, 3 = LDS-transposed (default), 0-2 = A/B */
