@@ -90,7 +90,7 @@ def test_hmc_transition_is_bitwise_deterministic_over_repeated_launches(D, K, no
 
 @pytest.mark.parametrize("D,K,nodes,B,small", [(32, 10, 10, 1024, 4), (6, 3, 8, 70, 4), (60, 4, 4, 200, 4), (2, 2, 40, 33, 4),
                                                (16, 3, 16, 257, 4), (32, 10, 10, 2048, 8), (16, 3, 16, 257, 8),
-                                               (32, 12, 8, 1501, 8), (8, 2, 32, 29, 8)])
+                                               (32, 12, 8, 1501, 8), (8, 2, 32, 29, 8), (32, 3, 9, 100, 8), (20, 2, 13, 50, 8), (6, 2, 40, 33, 8)])
 def test_small_tiles_match_sixteen_chain_tiles(monkeypatch, D, K, nodes, B, small):
     """k_hmc_step_r4 (4 chains per workgroup on v_mfma_f32_4x4x1, used for B <= 1152) and k_hmc_step_r8 (8 chains per
     workgroup, one wave per 64 hidden columns: D <= 32, hidden width 193 .. 320, used for 1152 < B <= 2048) against
