@@ -346,9 +346,9 @@ def main():
         pt, log_w = ais.sample_and_log_weights(B_PER_GPU)
         return pt.x, log_w, pt.log_q
 
-    for _ in range(30):                         # untimed, same count on every rank (step() holds collectives): a fresh
-        step()                                  # box needs ~0.2 s of work to reach steady clocks (measured 105.7k vs
-    sync()                                      # 113.4k samples/s for a cold first process)
+    for _ in range(200):                        # untimed, same count on every rank (step() holds collectives): a fresh
+        step()                                  # box needs ~1 s of work to reach steady clocks (first process on a box
+    sync()                                      # after 30 such steps: 177.8k samples/s, any later process: 185.0k)
     for _ in range(args.warmup):
         step()
     barrier()

@@ -21,4 +21,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final/prof_sp
 find gpurun_out/final/prof_sp -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} gpurun_out/final/spline_cfg3_kernel_stats.csv
 rm -rf gpurun_out/final/prof_sp
 [ -x tools/ubench/bin/nsplit ] && tools/ubench/bin/nsplit > gpurun_out/final/ubench_nsplit.txt 2>&1
+python tools/time_hmc_shapes.py 2>/dev/null | grep "W=" > gpurun_out/final/hmc_tile_shapes.txt
+python tools/timeline_r8.py 2048 2>/dev/null | tail -13 > gpurun_out/final/hmc_r8_stage_timeline.txt
+python bench.py --workload cfg4 --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/final/bench_cfg4_1gpu.json
+FABHIP_BENCH_BACKEND=gloo python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/final/bench_2ranks_one_gpu_gloo.json
 python -m pytest tests -m gpu -q -x 2>&1 | tail -4
