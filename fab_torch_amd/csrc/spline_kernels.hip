@@ -1186,18 +1186,19 @@ static int launch_logprob(const SplineDims& f, const float* packed, const float*
 
 // 8-chain tiles (spline_r8.h): hidden width padded to 256, fp32 path.  FABHIP_OPT_TILE_SHAPE 16 / 8 (or 4) forces a shape;
 // otherwise 8-chain tiles whenever 16-chain tiles would leave CUs without a workgroup.
-// The 4x4x1 stream kernels (spline_r8.h; hidden width padded to 256, fp32 path): 8 chains per workgroup while that leaves no
-// CU with more than one workgroup (the kernel's registers allow no second one: 2048 chains on MI355X), 16 chains above.
-// FABHIP_OPT_TILE_SHAPE 8 (or 4) / 16 forces the tile; FABHIP_OPT_SPLINE_MFMA = 16 selects the 16x16x4 kernel
+// The 4x4x1 stream kernels (spline_r8.h; hidden width padded to 256, fp32 path): 4 / 8 chains per workgroup while that leaves
+// no CU with more than one workgroup (the kernel's registers allow no second one: 1024 / 2048 chains on MI355X), 16 above.
+// FABHIP_OPT_TILE_SHAPE 4 / 8 / 16 forces the tile; FABHIP_OPT_SPLINE_MFMA = 16 selects the 16x16x4 kernel
 // (k_spline_logprob: the only one for other widths and for fast mode).  Returns row blocks (0: not this kernel).
 static int r8_row_blocks(const SplineDims& f, long B, int fast, bool grad) {
     if (f.NTWM != 4 || !f.o_r8 || fast || option(FABHIP_OPT_SPLINE_MFMA) == 16) return 0;
     const int sel = option(FABHIP_OPT_TILE_SHAPE);
-    int rb = sel == 16 ? 4 : ((sel == 8 || sel == 4) ? 2 : (B <= 8L * cu_count() ? 2 : 4));
+    int rb = sel == 16 ? 4 : (sel == 8 ? 2 : (sel == 4 ? 1 : (B <= 4L * cu_count() ? 1 : (B <= 8L * cu_count() ? 2 : 4))));
     // the LDS plan grows with the layer count (ReLU ballots) and the output chunks: deep / wide flows fall back to the smaller
     // tile, then to the 16x16x4 kernel (whose ballots live in the workspace)
     if (rb == 4 && (size_t)make_s8_lds(f, grad, 16).total * 4 > 160 * 1024) rb = 2;
-    if (rb == 2 && (size_t)make_s8_lds(f, grad, 8).total * 4 > 160 * 1024) rb = 0;
+    if (rb == 2 && (size_t)make_s8_lds(f, grad, 8).total * 4 > 160 * 1024) rb = 1;
+    if (rb == 1 && (size_t)make_s8_lds(f, grad, 4).total * 4 > 160 * 1024) rb = 0;
     return rb;
 }
 
@@ -1330,6 +1331,7 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
     const float* pk = flow->packed;
     if (!tape && !option(FABHIP_OPT_SPLINE_STAGED)) {           // one launch (the staged kernels below: tape, debugging)
         const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision), grad_x != nullptr);
+        if (rb == 1) return launch_logprob_r8_nch<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
         if (rb == 2) return launch_logprob_r8_nch<2>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
         if (rb == 4) return launch_logprob_r8_nch<4>(f, pk, x, log_q, grad_x, (long)B, Z, P, (hipStream_t)stream);
         if (f.NTWM == 1) return launch_logprob<1>(f, pk, x, log_q, grad_x, (long)B, Z, P, bits, resolve_fast(flow->precision), (hipStream_t)stream);

@@ -1,6 +1,6 @@
 // 4x4x1 stream kernels (S8) for the one-launch spline density: hidden width padded to 256 (the shape of BASELINE cfg 3 and of
-// the alanine-dipeptide flow), 4 RB chains per workgroup on v_mfma_f32_4x4x1_16b_f32 - RB = 2 row blocks (8 chains) while
-// that leaves at most one workgroup per CU, RB = 4 (16 chains) for larger batches; same arithmetic for both (bit-identical).
+// the alanine-dipeptide flow), 4 RB chains per workgroup on v_mfma_f32_4x4x1_16b_f32 - RB = 1 / 2 row blocks (4 / 8 chains)
+// while that leaves at most one workgroup per CU, RB = 4 (16 chains) for larger batches; same arithmetic (bit-identical).
 //
 // Why: k_spline_logprob (16 chains per workgroup, 16x16x4 MFMAs) gives B / 16 workgroups - 128 of 256 CUs at cfg 3's 2048
 // chains - and its element-wise stages (splines, reverse mode, tile reloads: a third of its time) run on those 128 CUs only.
@@ -257,9 +257,10 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             ZT[e] = v;
         }
     }
-    float ld_acc[RB / 2];                                                      // element-wise stages: thread = (chain 8 i + tid / 32, coordinate tid % 32)
+    constexpr int NRG = (RB + 1) / 2;                                          // groups of 8 chains (RB = 1: half a group)
+    float ld_acc[NRG];                                                      // element-wise stages: thread = (chain 8 i + tid / 32, coordinate tid % 32)
 #pragma unroll
-    for (int i = 0; i < RB / 2; ++i) ld_acc[i] = 0.f;
+    for (int i = 0; i < NRG; ++i) ld_acc[i] = 0.f;
     for (int layer = f.L - 1; layer >= 0; --layer) {
         const float* Lr = img + (size_t)layer * lfl;
         const bool tl = layer == 1;
@@ -356,10 +357,10 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                             *reinterpret_cast<const float4*>(PT + r * l.PS + 4 * c4);
         }
 #pragma unroll 1
-        for (int ri = 0; ri < RB / 2; ++ri) {
+        for (int ri = 0; ri < NRG; ++ri) {
         const int row = 8 * ri + t.row;
         float ldv = 0.f;
-        for (int j = t.c; j < f.D; j += 32) {
+        for (int j = t.c; j < f.D && row < R8; j += 32) {
             float p[SP_NP];
             int pos;
             const int kind = sp_coord_params(f, HD, meta, PT, l.PS, row, j, isq, p, pos);
@@ -375,8 +376,8 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             if (layer > 0 && HD[S8H_NXT + 64 + j] != 0.f) out = sp_wrap(out - HD[S8H_NXT + j], tb);   // next stage's shift
             ZT[row * 64 + j] = out;
         }
-        if (RB / 2 == 1 || ri == 0) ld_acc[0] += ldv;
-        else ld_acc[RB / 2 - 1] += ldv;
+        if (NRG == 1 || ri == 0) ld_acc[0] += ldv;
+        else ld_acc[NRG - 1] += ldv;
         }
         if (tl) S8_TL(4);
     }
@@ -384,9 +385,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     if constexpr (GRAD) { head_fetch(img); tile_fetch(0); }
     // base UniformGaussian
 #pragma unroll
-    for (int ri = 0; ri < RB / 2; ++ri) {
+    for (int ri = 0; ri < NRG; ++ri) {
         const int row = 8 * ri + t.row;
-        for (int j = t.c; j < f.D; j += 32) {
+        for (int j = t.c; j < f.D && row < R8; j += 32) {
             const float sc = packed[f.o_base + j];
             const float z = ZT[row * 64 + j];
             if (packed[f.o_base + 64 + j] != 0.f) { ld_acc[ri] += -logf(sc); if (GRAD) GT[row * 64 + j] = 0.f; }
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             }
         }
         const float lq = row32_sum(ld_acc[ri]);
-        if (t.c == 0 && row0 + row < B) log_q[row0 + row] = lq;
+        if (t.c == 0 && row < R8 && row0 + row < B) log_q[row0 + row] = lq;
     }
     if constexpr (GRAD) {
         // ---- reverse sweep: GT = d log q / d(state), layers 0 .. L-1 -------------------------------------------------
@@ -412,9 +413,9 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             if (tl) S8_TL(9);
             const int n_id = (int)meta[M_CNT * 64], n_tr = (int)meta[M_CNT * 64 + 1];
 #pragma unroll 1
-            for (int ri = 0; ri < RB / 2; ++ri) {
+            for (int ri = 0; ri < NRG; ++ri) {
             const int row = 8 * ri + t.row;
-            for (int j = t.c; j < f.D; j += 32) {
+            for (int j = t.c; j < f.D && row < R8; j += 32) {
                 float p[SP_NP];
                 int pos;
                 const int kind = sp_coord_params(f, HD, meta, PT, l.PS, row, j, isq, p, pos);
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                 }
             }
             // columns of dP no coordinate owns: the stored tile has the conditioner's padding there, Psave beyond w4 was never written
-            for (int c = n_tr * SP_NP + t.c; c < f.NFP; c += 32) PT[row * l.PS + c] = 0.f;
+            for (int c = n_tr * SP_NP + t.c; c < f.NFP && row < R8; c += 32) PT[row * l.PS + c] = 0.f;
             }
             s8_barrier();
             if (tl) S8_TL(10);

@@ -109,16 +109,16 @@ def test_spline_flow_log_prob_grad_and_sample_vs_oracle(D, L, hidden, circ, B):
                                                (64, 2, 256, (0, 63), 41)])
 def test_the_tile_shapes_of_the_spline_density_kernels_agree(D, L, hidden, circ, B):
     """The one-launch density kernels for hidden widths padded to 256: k_spline_logprob (16 chains per workgroup on 16x16x4
-    MFMAs) and k_spline_logprob_r8 (4x4x1 MFMAs, own weight image, 8 or 16 chains per workgroup) differ in the summation
+    MFMAs) and k_spline_logprob_r8 (4x4x1 MFMAs, own weight image, 4, 8 or 16 chains per workgroup) differ in the summation
     order of the conditioner GEMMs only: log q to the parity tolerance, the gradient to it on all but ReLU- / knot-kink
-    flips.  The two tile shapes of the 4x4x1 kernel share their arithmetic: bit-identical.  Each is deterministic and
+    flips.  The three tile shapes of the 4x4x1 kernel share their arithmetic: bit-identical.  Each is deterministic and
     independent of the batch around a chain."""
     from fab_torch_amd import _ops
     of, hf = make_pair(D, L, hidden, circ, seed=D + L, std=0.2)
     g = torch.Generator().manual_seed(11)
     x = (1.5 * torch.randn(B, D, generator=g)).to(DEV)
     out = {}
-    for name, mfma, shape in (("16x16x4", 16, 0), ("4x4x1 / 8 chains", 0, 8), ("4x4x1 / 16 chains", 0, 16)):
+    for name, mfma, shape in (("16x16x4", 16, 0), ("4x4x1 / 8 chains", 0, 8), ("4x4x1 / 16 chains", 0, 16), ("4x4x1 / 4 chains", 0, 4)):
         with _ops.option(_ops.OPT_SPLINE_MFMA, mfma), _ops.option(_ops.OPT_TILE_SHAPE, shape):
             lq, gr = hf.log_prob_and_grad(x)
             lq_only = hf.log_prob(x)
@@ -126,8 +126,9 @@ def test_the_tile_shapes_of_the_spline_density_kernels_agree(D, L, hidden, circ,
         assert torch.equal(lq_only, lq), f"{name}: density-only and density + gradient launches disagree"
         assert torch.equal(lq_b, lq[: B // 2 + 3]) and torch.equal(gr_b, gr[: B // 2 + 3]), f"{name}: a chain depends on its batch"
         out[name] = (lq, gr)
-    a, b8, b16 = out["16x16x4"], out["4x4x1 / 8 chains"], out["4x4x1 / 16 chains"]
+    a, b8, b16, b4 = out["16x16x4"], out["4x4x1 / 8 chains"], out["4x4x1 / 16 chains"], out["4x4x1 / 4 chains"]
     assert torch.equal(b8[0], b16[0]) and torch.equal(b8[1], b16[1]), "8- and 16-chain tiles of the 4x4x1 kernel differ"
+    assert torch.equal(b8[0], b4[0]) and torch.equal(b8[1], b4[1]), "8- and 4-chain tiles of the 4x4x1 kernel differ"
     assert not torch.equal(a[0], b8[0]), "both runs used the same kernel"
     assert close(b8[0], a[0], RTOL), f"log q: {worst(b8[0], a[0]):.2f}x tol"
     rel = (b8[1] - a[1]).norm(dim=1) / a[1].norm(dim=1).clamp_min(1e-6)

@@ -14,6 +14,7 @@ if os.environ.get("CFG") == "5":                       # BASELINE cfg 5's shape:
     D, M, B, LF = 60, 20, 4096, 10
     CIRC = (3, 7, 8, 12, 20, 21, 22, 30, 41, 45, 52, 59)
     TB = torch.full((D,), 5.0); TB[list(CIRC)] = math.pi
+B = int(os.environ.get("B", B))
 torch.manual_seed(0)
 flow = fa.make_wrapped_normflow_spline(D, L, H, CIRC, TB).to(DEV).requires_grad_(False)
 with torch.no_grad():
