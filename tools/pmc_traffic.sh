@@ -8,7 +8,7 @@ i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_BUBBLE_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   i=$((i+1))
   t0=$(date +%s)
-  timeout 150 rocprofv3 --pmc $grp --kernel-include-regex "$kern" --output-format csv -d $out/p$i -- python tools/prof_hmc.py "$@" > $out/log$i.txt 2>&1
+  timeout 150 rocprofv3 --pmc $grp --kernel-include-regex "$kern" --output-format csv -d $out/p$i -- python ${PROF_SCRIPT:-tools/prof_hmc.py} "$@" > $out/log$i.txt 2>&1
   echo "pass $i ($grp) rc=$? $(( $(date +%s) - t0 )) s"
 done
 python tools/pmc_summary.py $out "$kern" 1 > $out/summary.json
