@@ -19,12 +19,22 @@ SOURCES = {"spline": ("spline_kernels.hip", ("k_spline_logprob_r8",)),
 
 
 def disassemble(src):
+    """ISA text of the gfx950 code object of `src`: taken from the in-tree build (fab_torch_amd/build/<stem>.o, when it is
+    newer than every source under csrc/) or compiled into a temporary directory."""
     tmp = tempfile.mkdtemp(prefix="r8isa")
-    co, elf = os.path.join(tmp, "sp.co"), os.path.join(tmp, "sp.elf")
-    subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-c",
-                           os.path.join(ROOT, "fab_torch_amd/csrc", src), "-I", os.path.join(ROOT, "include"),
-                           "-w", "-o", co])
-    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={co}",
+    elf = os.path.join(tmp, "dev.elf")
+    csrc = os.path.join(ROOT, "fab_torch_amd", "csrc")
+    obj = os.path.join(ROOT, "fab_torch_amd", "build", os.path.splitext(src)[0] + ".o")
+    newest = max(os.path.getmtime(os.path.join(csrc, f)) for f in os.listdir(csrc))
+    if os.path.exists(obj) and os.path.getmtime(obj) >= newest and not os.environ.get("R8ISA_RECOMPILE"):
+        fat = os.path.join(tmp, "fat.bin")
+        subprocess.check_call([f"{LLVM}/llvm-objcopy", "--dump-section", f".hip_fatbin={fat}", obj])
+        bundle = fat
+    else:
+        bundle = os.path.join(tmp, "sp.co")
+        subprocess.check_call(["hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "--cuda-device-only", "-c",
+                               os.path.join(csrc, src), "-I", os.path.join(ROOT, "include"), "-w", "-o", bundle])
+    subprocess.check_call([f"{LLVM}/clang-offload-bundler", "--unbundle", "--type=o", f"--input={bundle}",
                            "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={elf}"])
     return subprocess.check_output([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", elf], text=True)
 
