@@ -1191,9 +1191,12 @@ static int launch_logprob(const SplineDims& f, const float* packed, const float*
 // FABHIP_OPT_TILE_SHAPE 4 / 8 / 16 forces the tile; FABHIP_OPT_SPLINE_MFMA = 16 selects the 16x16x4 kernel
 // (k_spline_logprob: the only one for other widths and for fast mode).  Returns row blocks (0: not this kernel).
 static int r8_row_blocks(const SplineDims& f, long B, int fast, bool grad) {
-    if (f.NTWM != 4 || !f.o_r8 || fast || option(FABHIP_OPT_SPLINE_MFMA) == 16) return 0;
+    if (f.NTWM != 4 || !f.o_r8 || option(FABHIP_OPT_SPLINE_MFMA) == 16) return 0;
     const int sel = option(FABHIP_OPT_TILE_SHAPE);
     int rb = sel == 16 ? 4 : (sel == 8 ? 2 : (sel == 4 ? 1 : (B <= 4L * cu_count() ? 1 : (B <= 8L * cu_count() ? 2 : 4))));
+    // fast mode is a PERMISSION to use bf16: up to 8 chains per CU the fp32 stream kernel is the faster one (cfg 3: 0.39 ms
+    // against 0.45 for the bf16 16-chain kernel), so fast-mode calls take it too; above, the bf16 kernel (0.68 against 1.03 ms)
+    if (fast && rb == 4) return 0;
     // the LDS plan grows with the layer count (ReLU ballots) and the output chunks: deep / wide flows fall back to the smaller
     // tile, then to the 16x16x4 kernel (whose ballots live in the workspace)
     if (rb == 4 && (size_t)make_s8_lds(f, grad, 16).total * 4 > 160 * 1024) rb = 2;

@@ -132,12 +132,22 @@ def test_fast_mode_of_the_spline_flow_is_the_conditioner_with_bf16_rounded_inner
     with torch.no_grad():
         x, _ = of.sample_eps(torch.rand(B, D, generator=g), torch.randn(B, D, generator=g))
     x = x + 0.2 * torch.randn(B, D, generator=g)
+    from fab_torch_amd import _ops
     lq32, g32 = hf.log_prob_and_grad(x.to(DEV))
-    with fa.fast_mode():
-        lqf, gf = hf.log_prob_and_grad(x.to(DEV))
-        lqf2, gf2 = hf.log_prob_and_grad(x.to(DEV))
-        lq_plain = hf.log_prob(x.to(DEV))
-    lq32b, g32b = hf.log_prob_and_grad(x.to(DEV))
+    if hidden > 192:
+        # hidden widths padded to 256 have the fp32 stream kernel (spline_r8.h), which is FASTER than the bf16 kernel up to
+        # 8 chains per CU: fast mode (a permission, not an order) takes it there - same bits as the parity path
+        with fa.fast_mode():
+            lq_s, g_s = hf.log_prob_and_grad(x.to(DEV))
+        assert torch.equal(lq_s, lq32) and torch.equal(g_s, g32)
+    # the bf16 kernel itself (the 16x16x4 family; what fast mode runs for other widths and above 8 chains per CU)
+    with _ops.option(_ops.OPT_SPLINE_MFMA, 16):
+        lq32, g32 = hf.log_prob_and_grad(x.to(DEV))
+        with fa.fast_mode():
+            lqf, gf = hf.log_prob_and_grad(x.to(DEV))
+            lqf2, gf2 = hf.log_prob_and_grad(x.to(DEV))
+            lq_plain = hf.log_prob(x.to(DEV))
+        lq32b, g32b = hf.log_prob_and_grad(x.to(DEV))
     assert torch.equal(lq32, lq32b) and torch.equal(g32, g32b) and torch.equal(lqf, lqf2) and torch.equal(gf, gf2)
     assert close(lq_plain, lq32, 1e-5)
     em = copy.deepcopy(of).double()
