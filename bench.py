@@ -434,7 +434,10 @@ def main():
             wp = 64 * ((D * NODES + 63) // 64)
             per_pair = 4 * (2 * 32 * 64 + 16 * wp + 2 * wp * wp + wp * 32 + wp * 16 + 32 * wp)     # bytes per layer pair (D = 32)
             stream = per_pair * K_LAYERS * L
+            clk = 2.09e9                                     # shader clock under this kernel (s_memtime stamps against HIP events)
             roof["weight_stream"] = {"bytes_per_workgroup_per_launch": stream, "GBps_per_cu": stream / t_kernel / 1e9,
+                                     "B_per_clk_per_cu": stream / t_kernel / clk, "path_B_per_clk_per_cu": 52.0,
+                                     "frac_of_path": stream / t_kernel / clk / 52.0,
                                      "note": "tools/ubench/nsplit.hip: the L2 -> CU path delivers ~52 B/clk per CU to 256 workgroups "
                                              "streaming the same image (~110 GB/s at the ~2.1 GHz the kernel runs at); "
                                              "DESIGN.md section 4"}
