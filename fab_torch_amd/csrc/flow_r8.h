@@ -39,6 +39,7 @@ FAB_HD int r8_layer_floats(int G) { return NWAVE * (r8_tiles_fwd(G) + r8_tiles_r
 struct R8Lds {
     int WS, HF;                        // leading dim of the hidden tiles; floats per layer of the head block
     int o_X0, o_X1, o_HA, o_HB, o_PRM, o_DP, o_PART, o_ES, o_V2, o_MASK, o_HEAD, total;
+    int o_X2, o_PARTX;                 // flow_r8f.h: third state slot; partials of the fifth column group
 };
 // head block of a layer: ac[64] | b1[Wp] | b2[Wp] | b3[64] (shift | scale at 0 / DOp) | logS[16]
 FAB_HD R8Lds make_r8_lds(const FlowDims& f) {
@@ -58,6 +59,8 @@ FAB_HD R8Lds make_r8_lds(const FlowDims& f) {
     l.o_V2 = o; o += f.K * R8 * f.DOp;
     l.o_MASK = o; o += f.K * 2 * G * R8 * 2;         // u64 ballots [layer][stage][column group][chain]
     l.o_HEAD = o; o += f.K * l.HF;
+    l.o_X2 = o; o += R8 * R4_DS;
+    l.o_PARTX = o; o += NWAVE * R8 * R4_DS;
     l.total = (o + 3) & ~3;
     return l;
 }
