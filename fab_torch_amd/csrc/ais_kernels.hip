@@ -1340,6 +1340,16 @@ int fabhip_spline_hmc_transition(const fabhip_spline_hmc_args* a, fabhip_stream_
     for (int n = 0; n < a->n_outer; ++n) {
         FAB_TRY(gen_hmc_begin(&start, &cur, B, D, a->cur, a->noise_p + (size_t)n * B * D, a->mass, a->max_grad, gws, a->n_valid, st));
         for (int l = 0; l < a->L; ++l) {
+            {   // one launch per leapfrog where the 4x4x1 spline kernel applies (launch.h: SplineLeap)
+                float *XPw, *Pw, *GUw;
+                gen_hmc_state(gws, B, D, &XPw, &Pw, &GUw);
+                SplineLeap lp;
+                lp.XP = XPw; lp.x_out = prop.x; lp.P = Pw; lp.GU = GUw; lp.eps_ptr = a->epsilons + n; lp.ceps_ptr = a->common_epsilon; lp.mass = a->mass;
+                lp.c = a->cur; lp.max_grad = a->max_grad; lp.tg = a->target; lp.prop_lp = prop.log_p; lp.prop_gp = prop.grad_log_p;
+                const int rc = spline_log_prob_leap(&a->flow, lp, prop.log_q, prop.grad_log_q, B, sws, sb, st);
+                if (rc == FABHIP_OK) continue;
+                if (rc != FABHIP_ENOTSUP) return rc;
+            }
             FAB_TRY(fabhip_hmc_generic_leap_pre(B, D, a->epsilons + n, a->common_epsilon, a->mass, prop.x, gws, gb, stream));
             FAB_TRY(fabhip_spline_log_prob(&a->flow, prop.x, prop.log_q, prop.grad_log_q, B, sws, sb, stream));
             FAB_TRY(fabhip_target_log_prob(&a->target, prop.x, prop.log_p, prop.grad_log_p, B, stream));

@@ -243,6 +243,11 @@ static void split_ws(void* ws, long B, int D, float*& XP, float*& P, float*& GU,
 
 // begin / accept with the row count read on the device (launch.h): the fused spline AIS call (ais_kernels.hip) keeps
 // fixed-size buffers after the "chain init" filter, like fabhip_ais_run
+void gen_hmc_state(void* workspace, long B, int dim, float** XP, float** P, float** GU) {
+    float *row, *pa, *pd;
+    split_ws(workspace, B, dim, *XP, *P, *GU, row, pa, pd);
+}
+
 int gen_hmc_begin(const fabhip_point* start, const fabhip_point* cur, long B, int dim, fabhip_anneal c, const float* noise_p,
                   const float* mass, float max_grad, void* workspace, const int* n_valid, hipStream_t st) {
     float *XP, *P, *GU, *row, *pa, *pd;

@@ -31,6 +31,23 @@ int gen_hmc_accept(const fabhip_point* prop, const fabhip_point* cur, long B, in
                    float target_p_accept, int tune, float* p_accept, float* avg_distance, void* workspace,
                    const int* n_valid, hipStream_t st);
 
+// the transition state inside a generic-HMC workspace (generic_kernels.hip)
+void gen_hmc_state(void* workspace, long B, int dim, float** XP, float** P, float** GU);
+// One leapfrog of the spline family in ONE launch (spline_kernels.hip; r4): first half step, spline density + gradient, target
+// + gradient and second half step inside k_spline_logprob_r8.  FABHIP_ENOTSUP where that kernel does not apply (the caller
+// then runs the four launches of the generic pieces - the same arithmetic, bit for bit).
+struct SplineLeap {
+    float *XP, *P, *GU;                // [B][D] of the transition workspace: position, momentum, clamped grad U
+    float* x_out;                      // the proposal's x (a copy of XP, as fabhip_hmc_generic_leap_pre leaves it)
+    const float *eps_ptr, *ceps_ptr, *mass;
+    fabhip_anneal c;
+    float max_grad;
+    fabhip_target tg;
+    float *prop_lp, *prop_gp;          // target log-density and gradient of the proposal
+};
+int spline_log_prob_leap(const fabhip_spline_flow* flow, const SplineLeap& lp, float* log_q, float* grad_x, int64_t B,
+                         void* workspace, size_t workspace_bytes, hipStream_t st);
+
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
 
 // Allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU).

@@ -17,6 +17,7 @@
 //                      cotangents to the identity coordinates (transposed weight tiles on the matrix cores)
 // One wave handles one chain in the element-wise kernels (lane = coordinate, D <= 64).
 #include "flow_device.h"
+#include "target_device.h"
 #include "stream_r8.h"
 #include "launch.h"
 #include <stdlib.h>
@@ -1207,30 +1208,30 @@ static int r8_row_blocks(const SplineDims& f, long B, int fast, bool grad) {
 
 template <int NCH, int RB>
 static int launch_logprob_r8(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
-                             float* Zsave, float* Psave, hipStream_t st) {
+                             float* Zsave, float* Psave, hipStream_t st, const SplineLeapDev& lp = SplineLeapDev{}) {
     const dim3 grid((unsigned)ceil_div((int)B, 4 * RB)), block(NTHREADS);
     const S8Lds l = make_s8_lds(f, grad_x != nullptr, 4 * RB);
     const size_t bytes = (size_t)l.total * 4;
     if (grad_x) {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, true>, bytes));
         hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, sp_timeline(st));
+                           Psave, sp_timeline(st), lp);
     } else {
         FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, false>, bytes));
         hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
-                           Psave, sp_timeline(st));
+                           Psave, sp_timeline(st), SplineLeapDev{});
     }
     return check_launch();
 }
 
 template <int RB>
 static int launch_logprob_r8_nch(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
-                                 float* Zsave, float* Psave, hipStream_t st) {
+                                 float* Zsave, float* Psave, hipStream_t st, const SplineLeapDev& lp = SplineLeapDev{}) {
     switch (f.NCH) {
-        case 1: return launch_logprob_r8<1, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
-        case 2: return launch_logprob_r8<2, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
-        case 3: return launch_logprob_r8<3, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
-        case 4: return launch_logprob_r8<4, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st);
+        case 1: return launch_logprob_r8<1, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
+        case 2: return launch_logprob_r8<2, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
+        case 3: return launch_logprob_r8<3, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
+        case 4: return launch_logprob_r8<4, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
         default: return FABHIP_ENOTSUP;
     }
 }
@@ -1262,6 +1263,29 @@ static int net(const SplineDims& f, const float* packed, int layer, const float*
 }
 
 static inline size_t sp_al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// launch.h: one leapfrog of the spline family in one launch
+int spline_log_prob_leap(const fabhip_spline_flow* flow, const SplineLeap& a, float* log_q, float* grad_x, int64_t B,
+                         void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (!flow || !flow->packed || !a.XP || !a.x_out || !a.P || !a.GU || !log_q || !grad_x || !workspace || B < 0) return FABHIP_EINVAL;
+    if (!option(FABHIP_OPT_SPLINE_LEAP) || option(FABHIP_OPT_SPLINE_STAGED)) return FABHIP_ENOTSUP;
+    FAB_TRY(check_spline_shape(flow->dim, flow->n_layers, flow->hidden));
+    FAB_TRY(check_target(&a.tg, flow->dim));
+    if (B == 0) return FABHIP_OK;
+    if (workspace_bytes < fabhip_spline_workspace_bytes(flow->dim, flow->n_layers, flow->hidden, B, 1)) return FABHIP_ENOSPC;
+    const SplineDims f = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
+    const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision), true);
+    if (rb == 0) return FABHIP_ENOTSUP;
+    char* ws = (char*)workspace;
+    float* Z = (float*)ws; ws += sp_al((size_t)(f.L + 1) * B * f.D * 4);
+    float* P = (float*)ws;
+    SplineLeapDev d;
+    d.XP = a.XP; d.x_out = a.x_out; d.P = a.P; d.GU = a.GU; d.eps_ptr = a.eps_ptr; d.ceps_ptr = a.ceps_ptr; d.mass = a.mass; d.c = a.c;
+    d.max_grad = a.max_grad; d.tg = make_target_dev(a.tg); d.prop_lp = a.prop_lp; d.prop_gp = a.prop_gp;
+    if (rb == 1) return launch_logprob_r8_nch<1>(f, flow->packed, a.XP, log_q, grad_x, (long)B, Z, P, st, d);
+    if (rb == 2) return launch_logprob_r8_nch<2>(f, flow->packed, a.XP, log_q, grad_x, (long)B, Z, P, st, d);
+    return launch_logprob_r8_nch<4>(f, flow->packed, a.XP, log_q, grad_x, (long)B, Z, P, st, d);
+}
 
 }  // namespace fab
 

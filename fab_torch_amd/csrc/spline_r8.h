@@ -164,12 +164,23 @@ __global__ __launch_bounds__(256) void k_spline_pack_r8(SplineDims f, SplineSrc 
     }
 }
 
+// optional leapfrog around the density evaluation (launch.h: SplineLeap; XP == nullptr: a plain density call)
+struct SplineLeapDev {
+    float *XP, *P, *GU, *x_out;
+    const float *eps_ptr, *ceps_ptr, *mass;
+    fabhip_anneal c;
+    float max_grad;
+    TargetDev tg;
+    float *prop_lp, *prop_gp;
+};
+__device__ __forceinline__ float g_clamp_nan0_s8(float g, float mg) { return (g != g) ? 0.f : fminf(fmaxf(g, -mg), mg); }   // hmc.py:194-199
+
 // ---- the kernel ------------------------------------------------------------------------------------------------------
 template <int NCH, int RB, bool GRAD>
 __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8Lds l, const float* __restrict__ packed,
                                                                 const float* __restrict__ x, float* __restrict__ log_q,
                                                                 float* __restrict__ grad_x, long B, float* __restrict__ Zsave,
-                                                                float* __restrict__ Psave, long long* tlp) {
+                                                                float* __restrict__ Psave, long long* tlp, SplineLeapDev lp) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid8 t;
     constexpr int R8 = 4 * RB;                                                 // chains of this workgroup
@@ -251,7 +262,18 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             const long g = row0 + r;
             float v = 0.f;
             if (j < f.D && g < B) {
-                v = x[g * f.D + j];
+                if (GRAD && lp.XP) {                                            // first half of a leapfrog (k_gen_leap_pre, hmc.py:140-142)
+                    const long i = g * f.D + j;
+                    const float eps = *lp.eps_ptr + *lp.ceps_ptr;
+                    const float m = lp.mass[j];
+                    const float p = lp.P[i] - eps * lp.GU[i] / 2.f;
+                    lp.P[i] = p;
+                    v = lp.XP[i] + eps / m * p;
+                    lp.XP[i] = v;
+                    lp.x_out[i] = v;
+                } else {
+                    v = x[g * f.D + j];
+                }
                 if (mt[M_PREON * 64 + j] != 0.f) v = sp_wrap(v - mt[M_PRESH * 64 + j], mt[M_TB * 64 + j]);
             }
             ZT[e] = v;
@@ -508,6 +530,34 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         for (int e = t.tid; e < R8 * f.D; e += NTHREADS) {
             const int r = e / f.D, j = e % f.D;
             if (row0 + r < B) grad_x[(row0 + r) * f.D + j] = GT[r * 64 + j];
+        }
+        if (lp.XP) {
+            // target + gradient of the moved point (k_target) and the second half step (k_gen_leap_post, hmc.py:145-147) for this
+            // workgroup's chains, on the 16-row mapping of target_tile (rows >= R8: zeros, not stored)
+            const int D = f.D;
+            float* XH = X1;                                                     // [16][D]; X1 / X2 (the K-split partials) are free now
+            float* GPH = X2;
+            Tid tt;
+            for (int e = t.tid; e < 16 * D; e += NTHREADS) {
+                const int r = e / D, j = e - r * D;
+                const long g = row0 + r;
+                XH[e] = (r < R8 && g < B) ? lp.XP[g * D + j] : 0.f;
+            }
+            __syncthreads();
+            const float lpv = target_tile<true>(lp.tg, XH, D, GPH, D, tt);
+            const long g = row0 + tt.row;
+            if (tt.row < R8 && g < B) {
+                if (tt.c == 0) lp.prop_lp[g] = lpv;
+                const float eps = *lp.eps_ptr + *lp.ceps_ptr;
+                for (int j = tt.c; j < D; j += 16) {
+                    const long i = g * D + j;
+                    const float gpv = GPH[tt.row * D + j];
+                    lp.prop_gp[i] = gpv;
+                    const float gu = g_clamp_nan0_s8(-(lp.c.g_q * GT[tt.row * 64 + j] + lp.c.g_p * gpv), lp.max_grad);
+                    lp.GU[i] = gu;
+                    lp.P[i] = lp.P[i] - eps * gu / 2.f;
+                }
+            }
         }
     }
 #undef S8_TL
