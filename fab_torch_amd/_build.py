@@ -63,13 +63,36 @@ def _src_hash():
     return h.hexdigest()
 
 
+_HIPCC_VERSION = None
+
+
+def _version_digest(v):
+    import hashlib
+    return hashlib.sha256(v.encode()).hexdigest()[:16]
+
+
+def _hipcc_version():
+    global _HIPCC_VERSION
+    if _HIPCC_VERSION is None:
+        try:
+            _HIPCC_VERSION = subprocess.run([_hipcc(), "--version"], capture_output=True, text=True).stdout.strip()
+        except Exception:                    # no compiler here (a box that only loads the prebuilt library): the stamp decides
+            _HIPCC_VERSION = ""
+    return _HIPCC_VERSION
+
+
 def is_stale():
     """True when libfabhip.so is missing or was built from different sources (content hash, not mtimes:
     the snapshot that travels to the GPU box does not preserve them)."""
     if not (os.path.exists(LIB) and os.path.exists(TORCH_LIB) and os.path.exists(STAMP)):
         return True
     with open(STAMP) as fh:
-        return fh.read().strip() != _src_hash()
+        lines = fh.read().splitlines()
+    if not lines or lines[0].strip() != _src_hash():
+        return True
+    # another compiler = other machine code (whose ISA has not been checked): rebuild.  A box without hipcc can only load.
+    here = _hipcc_version()
+    return bool(here) and len(lines) > 1 and lines[1].strip() != _version_digest(here)
 
 
 def build(force: bool = False, verbose: bool = True) -> str:
@@ -103,6 +126,24 @@ def _torch_flags():
            ["-I", "/opt/rocm/include"]
 
 
+def _check_isa(obj):
+    """The hand-counted waits of the ring / stream kernels are only sound for machine code in which no instruction touches a
+    register whose load is still in flight (_isa_check.py): verified on every object right after it is compiled - a library
+    whose code fails the check is never produced.  Own process: the objects are checked in parallel."""
+    from . import _isa_check
+    if os.environ.get("FABHIP_SKIP_ISA_CHECK") == "1":
+        return
+    if not _isa_check.tools_available():
+        print(f"[fab_torch_amd] WARNING: ROCm LLVM tools not found under {_isa_check.LLVM}: the ISA of {os.path.basename(obj)} "
+              "was NOT checked for ring registers used before their load has landed", file=sys.stderr)
+        return
+    r = subprocess.run([sys.executable, "-m", "fab_torch_amd._isa_check", obj], capture_output=True, text=True,
+                       cwd=os.path.dirname(HERE))
+    if r.returncode != 0:
+        raise RuntimeError(f"{os.path.basename(obj)}: generated code touches a register whose load may still be in flight "
+                           f"(hand-counted s_waitcnt no longer matches what hipcc emitted):\n{r.stdout[-4000:]}{r.stderr[-2000:]}")
+
+
 def _build_locked(hipcc, verbose):
 
     def compile_one(src):
@@ -119,6 +160,8 @@ def _build_locked(hipcc, verbose):
         if spills and os.environ.get("FABHIP_ALLOW_SPILLS") != "1":
             raise RuntimeError(f"{src}: kernels with register spills (remove the instantiation or cut its registers): "
                                + ", ".join(f"{k} ({n} VGPRs)" for k, n in spills))
+        if src != TORCH_SRC:
+            _check_isa(obj)
         return obj
 
     with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
@@ -130,7 +173,7 @@ def _build_locked(hipcc, verbose):
         raise RuntimeError(f"link failed:\n{r.stderr[-8000:]}")
     _link_torch_ops(hipcc, torch_obj)
     with open(STAMP, "w") as fh:
-        fh.write(_src_hash())
+        fh.write(_src_hash() + "\n" + _version_digest(_hipcc_version()) + "\n")
     if verbose:
         print(f"[fab_torch_amd] built {LIB} and {TORCH_LIB}", file=sys.stderr)
     return LIB

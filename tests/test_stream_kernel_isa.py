@@ -1,17 +1,16 @@
-"""The 4x4x1 stream kernels (csrc/stream_r8.h, spline_r8.h, flow_r8.h) keep their weight ring in AGPRs that inline-asm loads
-fill behind hipcc's back, waited for with hand-counted s_waitcnt.  That is only sound while the compiler never reads, moves or
-re-allocates such a register between its load and the wait that covers it - a property of the GENERATED code, so it is
-checked on the ISA of the in-tree build (tools/check_r8_isa.py) for every instantiation of the kernels; no GPU needed."""
-import importlib.util
+"""The flow / spline kernels keep weight rings in registers that inline-asm loads fill behind hipcc's back (csrc/flow_device.h,
+flow_r4.h, stream_r8.h, spline_r8.h, flow_r8.h), waited for with hand-counted s_waitcnt.  That is only sound while the compiler
+never reads, moves or re-allocates such a register between its load and the wait that covers it - a property of the GENERATED
+code, so it is checked on the ISA of the in-tree build (fab_torch_amd/_isa_check.py; the build itself runs the same check and
+refuses to produce a library that fails it) for EVERY kernel of the library, along every control-flow path; no GPU needed."""
 import os
-import shutil
 
 import pytest
 
+from fab_torch_amd import _isa_check as chk
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-spec = importlib.util.spec_from_file_location("check_r8_isa", os.path.join(ROOT, "tools", "check_r8_isa.py"))
-chk = importlib.util.module_from_spec(spec)
-spec.loader.exec_module(chk)
+BUILD = os.path.join(ROOT, "fab_torch_amd", "build")
 
 
 def test_checker_flags_a_copy_of_an_in_flight_ring_register_and_a_scalar_base_hazard():
@@ -20,34 +19,45 @@ def test_checker_flags_a_copy_of_an_in_flight_ring_register_and_a_scalar_base_ha
           "v_mfma_f32_4x4x1_16b_f32 a[8:11], v2, a4, a[8:11]"]
     assert chk.check_kernel("ok", ok) == []
     copied = ok[:2] + ["v_accvgpr_mov_b32 a20, a5"] + ok[2:]                     # a5's load is still in flight
-    assert [b[1] for b in chk.check_kernel("copied", copied)] == ["touches an AGPR with a load in flight"]
+    assert [b[1] for b in chk.check_kernel("copied", copied)] == ["touches a register with a load in flight"]
     early = ok[:2] + ["v_mfma_f32_4x4x1_16b_f32 a[8:11], v2, a4, a[8:11]"] + ok[2:]   # used before its wait
     assert len(chk.check_kernel("early", early)) == 1
+    vgpr = ["global_load_dwordx4 v[10:13], v1, s[2:3]", "v_add_f32_e32 v4, v11, v5", "s_waitcnt vmcnt(0)"]   # VGPR rings too (flow_r4.h)
+    assert len(chk.check_kernel("vgpr", vgpr)) == 1
+    store_counts = ["global_load_dwordx4 v[10:13], v1, s[2:3]", "global_store_dword v[2:3], v4, off", "s_waitcnt vmcnt(1)",
+                    "v_add_f32_e32 v4, v11, v5"]                                # the store is the newest entry: the load has landed
+    assert chk.check_kernel("store", store_counts) == []
     hazard = ["v_readlane_b32 s2, v9, 0", "s_nop 1", "global_load_dwordx4 a[0:3], v1, s[2:3]", "s_waitcnt vmcnt(0)"]
     assert [b[1] for b in chk.check_kernel("hazard", hazard)] == ["scalar-base hazard"]
     padded = ["v_readlane_b32 s2, v9, 0", "s_nop 4", "global_load_dwordx4 a[0:3], v1, s[2:3]", "s_waitcnt vmcnt(0)"]
     assert chk.check_kernel("padded", padded) == []
 
 
-@pytest.mark.parametrize("which", sorted(chk.SOURCES))
-def test_no_instruction_touches_a_ring_register_whose_load_is_in_flight(which):
-    src, patterns = chk.SOURCES[which]
-    obj = os.path.join(ROOT, "fab_torch_amd", "build", os.path.splitext(src)[0] + ".o")
-    if not os.path.exists(obj) and not shutil.which("hipcc"):
-        pytest.skip("needs the in-tree build or hipcc")
-    if not os.path.exists(os.path.join(chk.LLVM, "llvm-objdump")):
+def test_checker_follows_loop_back_edges():
+    """A ring slot requested at the bottom of a loop and read at its top, before the wait: only visible along the back edge."""
+    loop = [(0, "s_mov_b32 s0, 0", None), (4, "v_add_f32_e32 v4, v10, v5", None), (8, "s_waitcnt vmcnt(0)", None),
+            (12, "global_load_dwordx4 v[10:13], v1, s[2:3]", None), (16, "s_cbranch_scc1 65533", 4), (20, "s_waitcnt vmcnt(0)", None),
+            (24, "s_endpgm", None)]
+    assert [b[0] for b in chk.check_kernel("loop", loop)] == [1]
+    fixed = list(loop)
+    fixed[1], fixed[2] = (4, "s_waitcnt vmcnt(0)", None), (8, "v_add_f32_e32 v4, v10, v5", None)
+    assert chk.check_kernel("fixed", fixed) == []
+
+
+@pytest.mark.parametrize("stem", ["flow_kernels", "ais_kernels", "spline_kernels", "train_kernels"])
+def test_no_instruction_touches_a_register_whose_load_is_in_flight(stem):
+    obj = os.path.join(BUILD, stem + ".o")
+    if not os.path.exists(obj):
+        pytest.skip("needs the in-tree build (fab_torch_amd/build/*.o)")
+    if not chk.tools_available():
         pytest.skip("needs the ROCm LLVM tools")
-    text = chk.disassemble(src)
-    kernels, cur = {}, None
-    for raw in text.splitlines():
-        m = chk.re.match(r"^[0-9a-f]+ <(\S+)>:", raw)
-        if m:
-            cur = kernels.setdefault(m.group(1), []) if any(p in m.group(1) for p in patterns) else None
-        elif cur is not None:
-            ins = raw.split("//")[0].strip()
-            if ins:
-                cur.append(ins)
-    assert kernels, f"{src}: no kernel matching {patterns}"
-    for name, lines in kernels.items():
-        assert sum(1 for l in lines if l.startswith("global_load_dwordx4 a[")) >= 100, f"{name}: the ring loads are gone"
-        assert chk.check_kernel(name, lines) == [], name
+    res = chk.check_object(obj)
+    assert res, f"{stem}: no kernels found"
+    names = " ".join(res)
+    if stem == "ais_kernels":
+        for k in ("k_hmc_step_r4", "k_ais_init_r4", "k_hmc_step_r8", "k_ais_init_r8", "k_hmc_stepILi5E"):
+            assert k in names, f"{k} is not in the library any more"
+    if stem == "spline_kernels":
+        assert "k_spline_logprob_r8" in names
+    bad = {k: v for k, v in res.items() if v}
+    assert not bad, bad
