@@ -141,7 +141,17 @@ class HipShardBackend:
         return self.hmc and not self.op.eval_mode
 
     def run_fused(self, b, eps0=None, noise_a=None, noise_b=None):
-        pt, log_w = self.ais.sample_and_log_weights(b, eps0=eps0, noise_a=noise_a, noise_b=noise_b)
+        from .point import Point
+        try:
+            pt, log_w = self.ais.sample_and_log_weights(b, eps0=eps0, noise_a=noise_a, noise_b=noise_b)
+        except Exception as e:                            # the reference's "No valid points ..." (ais.py:201,211) of THIS shard:
+            if "No valid points" not in str(e):           # an empty shard - the gathered set decides (see finish)
+                raise
+            flow = self.ais.base_distribution
+            dev = next(flow.parameters()).device
+            z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)      # noqa: E731
+            D = int(flow.dim)
+            pt, log_w = Point(z(0, D), z(0), z(0), z(0, D), z(0, D)), z(0)
         return pt, log_w
 
     def _common(self, st):
@@ -203,10 +213,9 @@ class HipShardBackend:
         self._phase(st, 2, 1, 0)
         host = torch.cat([st["n_valid"].float(), st["stats"][:6]]).cpu()
         n_init, n_end = int(host[0]), int(host[1])
-        if n_init == 0:
-            raise Exception("No valid points generated in sampling the chain init")
-        if n_end == 0:
-            raise Exception("No valid points generated in sampling the chain end")
+        # a shard without survivors is NOT an error here: the other ranks are about to enter the particle all-gather, and one
+        # device holding every chain would only fail if NO chain survived - the caller decides from the gathered set, on every
+        # rank alike (a rank-local raise left the others blocked in the collective)
         from .ais import LoggingInfo                      # this rank's own chains (the gathered set: logging_info)
         self.ais._logging_info = LoggingInfo(ess_base=float(host[2]), ess_ais=float(host[5]), log_Z=float(host[6]))
         pt = Point(st["x"][:n_end], st["lq"][:n_end], st["lp"][:n_end], st["gq"][:n_end], st["gp"][:n_end])
@@ -218,7 +227,12 @@ class ShardedAnnealedImportanceSampler:
     semantics of ONE device holding every chain: rank r runs chains [r b, (r + 1) b), the step sizes adapt on the
     acceptance of all chains (one slab all-gather per transition while tuning is on), the particles are joined by one
     all-gather at the end, ESS / log Z are those of the gathered set.  Returns (x, log_w, log_q) of all chains on every
-    rank (`compact=False`: fixed `world * b` rows, dropped chains as log_w = -inf rows, no host synchronisation)."""
+    rank (`compact=False`: fixed `world * b` rows, dropped chains as log_w = -inf rows; the fused rank-local call and the
+    "chain end" filter each read their row counts once, the gather itself adds no host synchronisation).  A shard that loses all
+    of its chains is an empty shard, not an error: "No valid points" is raised - on every rank - only when the GATHERED set is
+    empty (compact=True; with compact=False `logging_info` shows it).  Bit-for-bit equality with one device holds when both
+    use the same tile shape (`FABHIP_OPT_TILE_SHAPE`, or batches that select the same one: chains per workgroup follow the
+    LOCAL batch)."""
 
     def __init__(self, ais=None, group=None, backend=None):
         self.group = group
@@ -248,16 +262,31 @@ class ShardedAnnealedImportanceSampler:
                 self.n_slab_gathers += 1
                 be.adapt(st, j, gathered, world)
             pt, log_w = be.finish(st)
-        x, lw, lq = gather_particles(pt.x, log_w, pt.log_q, b, self.group, compact=compact)
+        buf = all_gather_rows(pack_particles(pt.x, log_w, pt.log_q, b), self.group)
+        D = buf.shape[-1] - 3
+        n_valid = buf[:, D + 2].sum()                      # device scalar: chains that survived on any rank
+        if compact:                                        # (the boolean-mask indexing synchronises with the host anyway)
+            x, lw, lq = unpack_particles(buf)
+            if x.shape[0] == 0:                            # every rank sees the same gathered set: all raise together
+                raise Exception("No valid points generated in sampling the chain end")
+        else:
+            x, lw, lq = buf[:, :D], buf[:, D], buf[:, D + 1]
         if logging:
-            self.logging_info = self._global_stats(lw, total_batch)
+            self.logging_info = self._global_stats(lw, total_batch, n_valid)
         return x, lw, lq
 
     @staticmethod
-    def _global_stats(log_w, total_batch):
-        """ESS and log Z of the gathered set (ais.py:80-86; log Z normalised by the REQUESTED batch), lazily: device
-        scalars, no synchronisation here."""
+    def _global_stats(log_w, total_batch, n_valid=None):
+        """ESS and log Z of the gathered set (ais.py:80-86: ESS = (sum w)^2 / sum w^2 / N with N the chains that SURVIVED -
+        dropped chains are padding rows with weight 0 here -, log Z normalised by the REQUESTED batch), lazily: device scalars,
+        no synchronisation.  On the GPU: fabhip_ess_logz, the kernel the single-device call uses."""
+        n = log_w.shape[0]
+        nv = torch.isfinite(log_w).sum() if n_valid is None else n_valid
+        if log_w.is_cuda:
+            from . import _ops
+            out = _ops.load().ess_logz(log_w.detach().contiguous().float(), None, float(total_batch))   # ESS / n rows, log Z
+            return {"ess_ais": out[0].double() * (float(n) / nv.double()), "log_Z": out[1].double()}
         lw = log_w.double()
         lse = torch.logsumexp(lw, 0)
-        ess = torch.exp(2 * lse - torch.logsumexp(2 * lw, 0)) / torch.isfinite(lw).sum()
+        ess = torch.exp(2 * lse - torch.logsumexp(2 * lw, 0)) / nv
         return {"ess_ais": ess, "log_Z": lse - torch.log(torch.tensor(float(total_batch), dtype=torch.float64))}

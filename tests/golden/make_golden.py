@@ -317,18 +317,20 @@ def g8_full_chain():
     npz("g8_ais_gmm_metropolis.npz", **out)
 
 
-def g14_headline_arch():
-    """The reference's own AIS call and one HMC transition at the HEADLINE flow architecture (many_well.yaml:7-10: RealNVP
+def g14_headline_arch(name="g14_ais_headline.npz", std=0.05, eps_init=0.2, seed=140):
+    """(`g15_ais_headline_mild.npz`: the same call in a MILD regime - last coupling Linears N(0, 0.01^2), initial step size
+    0.05 - in which one transition does not amplify fp32 rounding: the GPU test allows no waiver on it)
+    The reference's own AIS call and one HMC transition at the HEADLINE flow architecture (many_well.yaml:7-10: RealNVP
     10 x (16-320-320-32) + InvertibleAffine, D = 32; ais.yaml / many_well.yaml:25-29: HMC, L = 5, M = 8 here as in
     BASELINE.json's metric), B = 64 chains.  The 4.8 MB of weights are NOT stored: `helpers.seeded_oracle_flow`
     rebuilds them from the seed (same routine, same torch CPU generator); the fixture holds noise, every transition's
     input step sizes and output state (snapshots for teacher-forced per-transition checks) and the final outputs."""
     from helpers import seeded_oracle_flow
-    D, K, nodes, M, L, B, alpha, seed, std = 32, 10, 10, 8, 5, 64, 2.0, 140, 0.05
+    D, K, nodes, M, L, B, alpha = 32, 10, 10, 8, 5, 64, 2.0
     nf = seeded_oracle_flow(D, K, nodes, seed, std)
     target = ManyWellEnergy(dim=D, use_gpu=False)
-    hmc = tuned_hmc(M, D, nf, target, 0.2, L, 1, alpha, False)
-    torch.manual_seed(141)
+    hmc = tuned_hmc(M, D, nf, target, eps_init, L, 1, alpha, False)
+    torch.manual_seed(seed + 1)
     eps0 = torch.randn(B, D)
     ais = AnnealedImportanceSampler(EpsFlow(nf, eps0), target.log_prob, hmc, p_target=False, alpha=alpha,
                                     n_intermediate_distributions=M)
@@ -348,7 +350,7 @@ def g14_headline_arch():
         pt, log_w = ais.sample_and_log_weights(B)
     hmc.transition = orig
     info = ais.get_logging_info()
-    npz("g14_ais_headline.npz", D=D, K=K, nodes=nodes, flow_seed=seed, flow_std=std, M=M, L=L, alpha=alpha, p_target=0,
+    npz(name, D=D, K=K, nodes=nodes, flow_seed=seed, flow_std=std, M=M, L=L, alpha=alpha, p_target=0,
         eps0=eps0, B_space=ais.B_space, in_epsilons=in_eps, in_common_epsilon=in_ceps,
         noise_p=torch.stack(cap.randn_like)[:, None], noise_e=torch.stack(cap.expo)[:, None],
         snap_x=torch.stack([s_[0] for s_ in snaps]), snap_log_q=torch.stack([s_[1] for s_ in snaps]),
@@ -642,3 +644,4 @@ if __name__ == "__main__":
     g1_beta(); g2_intermediate(); g3_targets(); g4_ess(); g5_multinomial()
     g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval(); g11_gmm_eval()
     g12_trainer_traces(); g13_trained_flow(); g14_headline_arch()
+    g14_headline_arch("g15_ais_headline_mild.npz", std=0.01, eps_init=0.05, seed=150)

@@ -134,3 +134,63 @@ def test_two_processes_on_one_gpu_reproduce_the_single_process_run(tmp_path):
     info = ais.get_logging_info()
     assert abs(r0["ess"] - info["ess_ais"]) <= 1e-5 * info["ess_ais"] + 1e-7
     assert abs(r0["log_Z"] - info["log_Z"]) <= 1e-4 * abs(info["log_Z"])
+
+
+@pytest.mark.parametrize("total,shape", [(256, 4), (2048, 8)])
+def test_tuned_shards_with_a_chain_dropped_at_chain_init_reproduce_the_single_device_run(total, shape):
+    """tuning ON and a chain that dies at "chain init" (non-finite base draw) inside the LAST shard.  One device
+    removes the chain, the later chains move up one row and take the noise rows of their new positions (ais.py:190-213); the
+    rank that owns it does the same locally, its acceptance slab counts one chain less, and the gathered rule sees total - 1
+    chains in the blocks one device forms: particles, log-weights, every adapted step size and the gathered ESS / log Z equal
+    the single-device run bit for bit (ESS / log Z to fp32 rounding: other summation tree)."""
+    eps0, na, nb = (t.to(DEV) for t in _noise(total, 1.7))
+    eps0[total - 21, 3] = float("nan")
+    with _ops.option(_ops.OPT_TILE_SHAPE, shape):
+        ais1, hmc1 = _sampler()
+        pt, lw = ais1.sample_and_log_weights(total, eps0=eps0, noise_a=na, noise_b=nb)
+        info1 = ais1.get_logging_info()
+        assert pt.x.shape[0] == total - 1
+        world, b = 2, total // 2
+        ranks = [(parallel.HipShardBackend(_sampler()[0]),) for _ in range(world)]
+        sts = []
+        for r, (be,) in enumerate(ranks):
+            sl = slice(r * b, (r + 1) * b)
+            sts.append(be.begin(b, eps0[sl], na[:, :, sl].contiguous(), nb[:, :, sl].contiguous()))
+        for j in range(1, M + 1):
+            gathered = torch.cat([be.step(st, j).clone() for (be,), st in zip(ranks, sts)])
+            for (be,), st in zip(ranks, sts):
+                be.adapt(st, j, gathered, world)
+        outs = [be.finish(st) for (be,), st in zip(ranks, sts)]
+    for (be,) in ranks:
+        assert torch.equal(be.op.epsilons, hmc1.epsilons) and torch.equal(be.op.common_epsilon, hmc1.common_epsilon)
+    assert [o[0].x.shape[0] for o in outs] == [b, b - 1]
+    x = torch.cat([o[0].x for o in outs]); lws = torch.cat([o[1] for o in outs])
+    assert torch.equal(x, pt.x) and torch.equal(lws, lw)
+    # what the ranks would gather (fixed-size shards, the dropped chain as a log_w = -inf padding row) and its statistics
+    buf = torch.cat([parallel.pack_particles(o[0].x, o[1], o[0].log_q, b) for o in outs])
+    st = parallel.ShardedAnnealedImportanceSampler._global_stats(buf[:, D], total, buf[:, D + 2].sum())
+    assert abs(float(st["ess_ais"]) - info1["ess_ais"]) <= 1e-5 * info1["ess_ais"]
+    assert abs(float(st["log_Z"]) - info1["log_Z"]) <= 1e-5 * max(1.0, abs(info1["log_Z"]))
+
+
+def test_a_shard_without_survivors_is_an_empty_shard_not_a_rank_local_error():
+    """a rank whose chains all die must not raise before the particle all-gather (the other ranks would block in
+    it): `finish` / `run_fused` hand back an empty shard; "No valid points" is decided from the gathered set."""
+    b = 32
+    eps0, na, nb = (t.to(DEV) for t in _noise(b))
+    eps0[:] = float("nan")
+    ais, hmc = _sampler()
+    be = parallel.HipShardBackend(ais)
+    st = be.begin(b, eps0, na, nb)
+    for j in range(1, M + 1):
+        be.step(st, j)
+    pt, lw = be.finish(st)
+    assert pt.x.shape == (0, D) and lw.shape == (0,)
+    hmc.set_eval_mode(True)
+    pt, lw = be.run_fused(b, eps0, na, nb)
+    assert pt.x.shape == (0, D) and lw.shape == (0,)
+    sh = parallel.ShardedAnnealedImportanceSampler(ais)                 # one rank: the gathered set IS this shard -> raises
+    with pytest.raises(Exception, match="No valid points"):
+        sh.sample_and_log_weights(b, eps0=eps0, noise_a=na, noise_b=nb)
+    x, lw, lq = sh.sample_and_log_weights(b, eps0=eps0, noise_a=na, noise_b=nb, compact=False, logging=False)
+    assert x.shape == (b, D) and bool(torch.isinf(lw).all())

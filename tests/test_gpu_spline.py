@@ -538,3 +538,59 @@ def test_fused_spline_ais_call_equals_the_step_by_step_generic_path(monkeypatch,
     for k in fi:
         assert abs(fi[k] - si[k]) <= 1e-6 * max(1.0, abs(si[k])), (k, fi[k], si[k])
     assert res["fused"][0].shape[0] == B and not torch.equal(res["fused"][5], torch.full_like(res["fused"][5], 0.15 * 0.9))
+
+
+@pytest.mark.parametrize("name,D,L,hidden,circ,B,M,LF,shape", [
+    ("cfg3", 32, 12, 256, (), 2048, 3, 5, 8),
+    ("cfg5-shape", 60, 12, 256, (3, 7, 8, 12, 20, 21, 22, 30, 41, 45, 52, 59), 4096, 2, 10, 16)])
+def test_spline_transitions_at_the_baseline_tile_shapes_vs_oracle(name, D, L, hidden, circ, B, M, LF, shape):
+    """the spline family's transitions AT THE TILE SHAPES THE BASELINE BATCHES SELECT - cfg 3: 2048 chains =
+    8-chain tiles, cfg 5's shape: 4096 chains = 16-chain stream tiles, one launch per leapfrog (half steps + target inside the
+    density kernel) - against the CPU oracle per transition: a FULL-SIZE batch whose first 32 rows are the oracle's state
+    (teacher-forced), the other rows filler chains; at most 2 of the 32 may differ (an accept decision / ReLU kink within
+    rounding), everything else within 1e-4.  Then the fused AIS call at full size: its first 32 chains are, bit for bit, what
+    a 32-chain call at the same tile shape gives on the same noise rows (chains do not depend on the batch they run in)."""
+    from fab_torch_amd import _ops
+    SL = 32
+    of, hf = make_pair(D, L, hidden, circ, seed=11, std=0.15)
+    target, otarget = fa.ManyWellEnergy(D), otgt.ManyWell(D)
+    hop = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05, L=LF,
+                                   eval_mode=True).to(DEV)
+    oop = oais.HMC(M, D, of.log_prob, otarget.log_prob, alpha=2.0, p_target=False, epsilon=0.05, L=LF, eval_mode=True)
+    g = torch.Generator().manual_seed(5)
+    u, eps = torch.rand(B, D, generator=g), torch.randn(B, D, generator=g)
+    noise_p = torch.randn(M, 1, B, D, generator=g); noise_e = torch.empty(M, 1, B).exponential_(generator=g)
+    with torch.no_grad():
+        x0, _ = of.sample_eps(u[:SL], eps[:SL])
+    filler, _ = hf.sample_and_log_prob((B - SL,))
+    pt = oais.create_point(x0, of.log_prob, otarget.log_prob, with_grad=True)
+    betas = oais.beta_schedule(M, "linear")
+    assert shape == (8 if B <= 8 * 256 else 16)            # what r8_row_blocks picks for this batch on a 256-CU device
+    for j in range(1, M + 1):
+        xfull = torch.cat([pt.x.to(DEV), filler], 0)
+        hp = hop.create_new_point(xfull)
+        assert close(hp.log_q[:SL], pt.log_q, RTOL) and close(hp.grad_log_q[:SL], pt.grad_log_q, 5e-4)
+        lw_h = torch.zeros(B, device=DEV)
+        hop.transition(hp, j, float(betas[j]), log_w=lw_h, beta_next=float(betas[j + 1]), noise_p=noise_p[j - 1].to(DEV),
+                       noise_e=noise_e[j - 1].to(DEV))
+        ref = oop.transition(pt.clone(), j, betas[j], noise_p[j - 1][:, :SL], noise_e[j - 1][:, :SL])
+        scale = max(1.0, float(ref.x.abs().max()))
+        err = (hp.x[:SL].cpu() - ref.x).abs().max(1).values / scale
+        ok = err <= 1e-4
+        assert int((~ok).sum()) <= 2, f"{name} transition {j}: {int((~ok).sum())} chains differ (max {float(err.max()):.2e})"
+        assert close(hp.log_q[:SL].cpu()[ok], ref.log_q[ok], RTOL) and close(hp.log_p[:SL].cpu()[ok], ref.log_p[ok], RTOL)
+        lw_ref = (oais.intermediate_log_prob(ref, betas[j + 1], 2.0, False) - oais.intermediate_log_prob(ref, betas[j], 2.0, False))
+        assert close(lw_h[:SL].cpu()[ok], lw_ref[ok].detach(), RTOL, atol=1e-3)
+        assert torch.isfinite(hp.x).all()
+        filler = hp.x[SL:].clone()
+        pt = ref
+    # the fused call: full size vs its first 32 chains alone at the same tile shape
+    ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hop, False, 2.0, M)
+    assert ais._spline_parts() is not None
+    na, nb = noise_p.to(DEV), noise_e.to(DEV)
+    full, lw_full = ais.sample_and_log_weights(B, eps0=eps.to(DEV), u0=u.to(DEV), noise_a=na, noise_b=nb)
+    assert full.x.shape[0] == B, "a chain was dropped: pick another seed"
+    with _ops.option(_ops.OPT_TILE_SHAPE, shape):
+        part, lw_part = ais.sample_and_log_weights(SL, eps0=eps[:SL].to(DEV), u0=u[:SL].to(DEV),
+                                                   noise_a=na[:, :, :SL].contiguous(), noise_b=nb[:, :, :SL].contiguous())
+    assert torch.equal(full.x[:SL], part.x) and torch.equal(lw_full[:SL], lw_part) and torch.equal(full.log_q[:SL], part.log_q)

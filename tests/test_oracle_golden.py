@@ -187,12 +187,13 @@ def test_g8_full_ais_hmc_matches_reference(tag):
     assert abs(info.log_Z - float(g["log_Z"])) <= RTOL * abs(float(g["log_Z"])) + 1e-4
 
 
-def test_g14_headline_architecture_ais_matches_reference():
-    """The reference's AIS call at the HEADLINE flow architecture (10 x (16-320-320-32) + InvertibleAffine, D = 32, M = 8,
+@pytest.mark.parametrize("fixture", ["g14_ais_headline.npz", "g15_ais_headline_mild.npz"])
+def test_g14_headline_architecture_ais_matches_reference(fixture):
+    """(g15: the same call in the mild regime the zero-waiver GPU test uses.)  The reference's AIS call at the HEADLINE flow architecture (10 x (16-320-320-32) + InvertibleAffine, D = 32, M = 8,
     L = 5; fab/experiments/config/many_well.yaml:7-10,25-29) with the weights rebuilt from the fixture's seed: the oracle
     replays it - every transition's snapshot, the adapted step sizes bit for bit."""
     from helpers import flow_from_g14
-    g = load_golden("g14_ais_headline.npz")
+    g = load_golden(fixture)
     nf = flow_from_g14(g)
     D, M = int(g["D"]), int(g["M"])
     target = otgt.ManyWell(D)
