@@ -514,7 +514,10 @@ def test_headline_architecture_mild_regime_no_waivers(shape):
             pt = fa.create_point(T("snap_x")[j - 1].clone(), hf, target, with_grad=True)
             assert close(pt.log_q, g["snap_log_q"][j - 1], RTOL) and close(pt.log_p, g["snap_log_p"][j - 1], RTOL)
             out = hmc.transition(pt, j, float(betas[j]), noise_p=T("noise_p")[j - 1], noise_e=T("noise_e")[j - 1])
-            assert close(out.x, g["snap_x"][j], RTOL), f"transition {j}: x err {max_rel_err(out.x, g['snap_x'][j]):.2e}"
+            # positions: 1e-4 of the state scale (the metric of every per-transition test: a leapfrog's error is absolute in x)
+            assert max_rel_err(out.x, g["snap_x"][j]) <= RTOL, f"transition {j}: x err {max_rel_err(out.x, g['snap_x'][j]):.2e}"
+            assert bool((out.x.cpu() != T("snap_x")[j - 1].cpu()).any(1).eq(
+                torch.tensor((g["snap_x"][j] != g["snap_x"][j - 1]).any(1))).all()), f"transition {j}: an accept decision differs"
             assert close(out.log_q, g["snap_log_q"][j], RTOL), f"transition {j}: log q err {max_rel_err(out.log_q, g['snap_log_q'][j]):.2e}"
             assert close(out.log_p, g["snap_log_p"][j], RTOL), f"transition {j}: log p err {max_rel_err(out.log_p, g['snap_log_p'][j]):.2e}"
         hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=alpha, p_target=False, L=L).to(DEV)
@@ -524,7 +527,7 @@ def test_headline_architecture_mild_regime_no_waivers(shape):
         pt, log_w = ais.sample_and_log_weights(B, eps0=T("eps0"), noise_a=T("noise_p"), noise_b=T("noise_e"))
         info = ais.get_logging_info()
         FR = M * RTOL
-        assert close(pt.x, g["out_x"], FR, atol_scale=M), f"x err {max_rel_err(pt.x, g['out_x']):.2e}"
+        assert max_rel_err(pt.x, g["out_x"]) <= FR, f"x err {max_rel_err(pt.x, g['out_x']):.2e}"
         assert close(log_w, g["log_w"], FR, atol_scale=M), f"log_w err {max_rel_err(log_w, g['log_w']):.2e}"
         assert close(pt.log_q, g["out_log_q"], FR, atol_scale=M) and close(pt.log_p, g["out_log_p"], FR, atol_scale=M)
         np.testing.assert_allclose(hmc.epsilons.cpu().numpy(), g["out_epsilons"], rtol=1e-6)
