@@ -42,9 +42,14 @@ def build_flow_state(seed=0):
     return flow
 
 
-def cpu_baseline(flow_state, n_calls=2):
-    """The oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores on the
-    same workload; bounded sample: n_calls full AIS calls of 1024 chains after one warm-up call."""
+CPU_THREADS = 16                     # the thread count the oracle's eager CPU path is timed at (best of the 8/16/32/64 sweeps of r1-r3)
+
+
+def cpu_baseline(flow_state, n_calls=5):
+    """The oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores on the same workload at a
+    FIXED thread count (CPU_THREADS): median of n_calls full AIS calls of 1024 chains after one warm-up call (SURVEY 8d;
+    VERDICT r3: rounds 1-3 reported 2 calls at whatever count a sweep picked).  A one-call-each sweep over other thread
+    counts is reported next to it as information, never as `value`."""
     from oracle import ais as oais, flow as oflow, targets as otgt
     nf = oflow.make_realnvp(D, K_LAYERS, NODES)
     nf.load_state_dict(flow_state)
@@ -57,30 +62,39 @@ def cpu_baseline(flow_state, n_calls=2):
         eps0 = torch.randn(B_PER_GPU, D)
         noise_p = torch.randn(M, 1, B_PER_GPU, D)
         noise_e = torch.empty(M, 1, B_PER_GPU).exponential_()
-        return ais.sample_and_log_weights(eps0, noise_p, noise_e)
-
-    # pick the thread count the eager CPU path likes best on this host (1 call each), then time n_calls
-    best_threads, best_dt = torch.get_num_threads(), float("inf")
-    for nt in sorted({8, 16, 32, min(64, os.cpu_count() or 8)}):
-        torch.set_num_threads(nt)
-        call()
         t0 = time.perf_counter()
-        call()
-        dt = time.perf_counter() - t0
-        if dt < best_dt:
-            best_threads, best_dt = nt, dt
-    torch.set_num_threads(best_threads)
-    t0 = time.perf_counter()
-    for _ in range(n_calls):
-        _, _, info = call()
-    dt = (time.perf_counter() - t0) / n_calls
-    return {"value": B_PER_GPU / dt, "unit": "AIS samples/s", "cores": best_threads, "kind": "port",
-            "sample": f"{n_calls} calls of sample_and_log_weights({B_PER_GPU}) (after a thread-count sweep over "
-                      f"8/16/32/64, 2 calls each), fp32, oracle/ = PyTorch-CPU eager + autograd per leapfrog",
-            "sec_per_call": dt, "host_cpus": os.cpu_count()}
+        ais.sample_and_log_weights(eps0, noise_p, noise_e)
+        return time.perf_counter() - t0
+
+    threads = min(CPU_THREADS, os.cpu_count() or CPU_THREADS)
+    torch.set_num_threads(threads)
+    call()                                                         # warm-up
+    dts = sorted(call() for _ in range(n_calls))
+    dt = dts[n_calls // 2]
+    sweep = {}
+    for nt in (8, 32, 64):
+        if nt <= (os.cpu_count() or 8) and nt != threads:
+            torch.set_num_threads(nt)
+            call()
+            sweep[str(nt)] = B_PER_GPU / call()
+    torch.set_num_threads(threads)
+    return {"value": B_PER_GPU / dt, "unit": "AIS samples/s", "cores": threads, "kind": "port",
+            "sample": f"median of {n_calls} calls of sample_and_log_weights({B_PER_GPU}) after one warm-up call, {threads} threads "
+                      f"(fixed), fp32, oracle/ = PyTorch-CPU eager + autograd per leapfrog",
+            "sec_per_call": dt, "sec_per_call_min_max": [dts[0], dts[-1]], "host_cpus": os.cpu_count(),
+            "thread_sweep_samples_per_s": sweep}
 
 
 PEAK_HBM_TBPS = 8.0                  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def _lib_srchash():
+    """Content hash of the sources libfabhip.so was built from (fab_torch_amd/_build.py stamp): identifies the kernels."""
+    try:
+        with open(os.path.join(ROOT, "fab_torch_amd", "libfabhip.so.srchash")) as f:
+            return f.read().split()[0]
+    except (OSError, IndexError):
+        return "unknown"
 
 
 def _event_time(fn, n=20, warm=3):
@@ -110,13 +124,18 @@ def resample_rooflines(dev, log2n=26):
     ws = ops.fixed_cdf(lw, None)                                   # max + scan once: leaves the max in the workspace
     t_scan = _event_time(lambda: ops.fixed_cdf(lw, ws))            # memset of the descriptors (~5 us) + the scan kernel
     t_sys = _event_time(lambda: ops.resample_systematic(lw, 0.3, N))
+    u = torch.rand(N, device=dev, generator=g, dtype=torch.float64)
+    t_mult = _event_time(lambda: ops.resample_multinomial(lw, u), n=8, warm=2)
+    del u
     rows = []
     for name, t, alg, traffic in (("k_scan_fixed_lds (fixed-point CDF scan, decoupled look-back)", t_scan, 12 * N, 12 * N),
                                   ("fabhip_resample_systematic end to end (max, tile sums, prefix, fused emit)", t_sys,
-                                   12 * N, 20 * N)):
+                                   12 * N, 20 * N),
+                                  ("fabhip_resample_multinomial end to end (scan + per-draw 16-ary search of the CDF: random 128-byte "
+                                   "lines, not a stream)", t_mult, 20 * N, None)):
         ach = alg / t / 1e12
         rows.append({"bound": "hbm", "kernel": name, "N": N, "achieved": ach, "peak": PEAK_HBM_TBPS, "unit": "TB/s",
-                     "frac": ach / PEAK_HBM_TBPS, "traffic": traffic, "traffic_TBps": traffic / t / 1e12,
+                     "frac": ach / PEAK_HBM_TBPS, "traffic": traffic, "traffic_TBps": (traffic / t / 1e12) if traffic else None,
                      "us_per_call": t * 1e6, "algorithmic_bytes": alg})
     del lw, ws
     torch.cuda.empty_cache()
@@ -194,12 +213,16 @@ def spline_cfg3(dev):
     torch.cuda.synchronize(dev)
     t_call = (time.perf_counter() - t0) / n
     flop = 4.0 * (64 * H + 2 * H * H + 512 * H) * L * B            # conditioner GEMMs as executed, forward + reverse
+    flop_alg = 4.0 * (16 * H + 2 * H * H + 400 * H) * L * B        # algorithmic: 16 identity features in, 25 x 16 parameters out
     stream = 2 * 4 * 272 * 1024 * L                                # weight tiles one workgroup streams per evaluation
     return {"workload": "cfg3: ManyWell-32, spline flow 12 x (hidden 256, 8 bins), 2048 chains, M = 12, HMC L = 5",
             "value": B / t_call, "unit": "AIS samples/s", "ms_per_call": t_call * 1e3,
             "density_grad_evals_per_call": M * LF + 1, "ms_per_density_grad": t_eval * 1e3,
             "kernel": "k_spline_logprob_r8<2, 2, true> (8 chains per workgroup, v_mfma_f32_4x4x1, 256 workgroups)",
-            "achieved_TFLOPs": flop / t_eval / 1e12, "frac_fp32_mfma_peak": flop / t_eval / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "achieved_TFLOPs": flop_alg / t_eval / 1e12, "frac_fp32_mfma_peak": flop_alg / t_eval / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+            "flop_per_eval_algorithmic": flop_alg, "flop_per_eval_as_executed": flop,
+            "as_executed": {"achieved_TFLOPs": flop / t_eval / 1e12, "frac_fp32_mfma_peak": flop / t_eval / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                            "note": "64-wide input and 512-wide output tiles for 16 / 400 real columns: 17 % padding"},
             "weight_stream_bytes_per_workgroup": stream,
             "ess_ais": float(ais.get_logging_info()["ess_ais"])}
 
@@ -318,7 +341,9 @@ def main():
                               "data": "stub (launcher self-test on CPU ranks, not a measurement)",
                               "config": {"workload": "launcher self-test", "chains_per_gpu": B_PER_GPU,
                                          "global_chains": world * B_PER_GPU},
-                              "ranks": world, "backend": backend, "gathered_rows": int(out[0].shape[0])}))
+                              "ranks": world, "backend": backend, "gathered_rows": int(out[0].shape[0]),
+                              "process_group_ranks": (dist.get_world_size() if distributed else 1),
+                              "rccl_ranks": 0, "collectives_per_step": 1 if distributed else 0}))
         if distributed:
             dist.barrier()
             dist.destroy_process_group()
@@ -417,7 +442,8 @@ def main():
         from fab_torch_amd import _ops
         shape = int(_ops.load().get_option(_ops.OPT_TILE_SHAPE))
         r4 = shape == 4 or (shape == 0 and B_PER_GPU <= 1152)               # 4-chain tiles (flow_r4.h) below 1153 chains
-        r8 = shape == 8 or (shape == 0 and 1152 < B_PER_GPU <= 2048)        # 8-chain tiles (flow_r8.h) up to 2048
+        n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+        r8 = shape == 8 or (shape == 0 and 1152 < B_PER_GPU <= 8 * n_cu)    # 8-chain tiles (flow_r8.h) up to 8 chains per CU
         n_wg = (B_PER_GPU + 3) // 4 if r4 else ((B_PER_GPU + 7) // 8 if r8 else (B_PER_GPU + 15) // 16)
         kname = "k_hmc_step_r4<5> (4 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r4 else \
             ("k_hmc_step_r8<5> (8 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r8 else
@@ -443,12 +469,19 @@ def main():
                                              "DESIGN.md section 4"}
         # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes restricted to this kernel
         # (tools/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed summary
-        for path in ((os.path.join("profiles", "r3", "hmc_step_r4_traffic_pmc_summary.json"),) if r4 else
-                     tuple(os.path.join("profiles", rnd, "hmc_step_pmc_summary.json") for rnd in ("r3", "r2", "r1"))):
+        for path in ((os.path.join("profiles", "r4", "hmc_step_r4_traffic_pmc_summary.json"),) if r4 else
+                     tuple(os.path.join("profiles", rnd, "hmc_step_pmc_summary.json") for rnd in ("r4",))):
             if os.path.exists(os.path.join(ROOT, path)) and args.workload == "headline" and not custom:
                 with open(os.path.join(ROOT, path)) as f:
-                    roof["traffic"] = json.load(f).get("_derived", {}).get("hbm_bytes_per_launch")
-                roof["traffic_source"] = path + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes)"
+                    summ = json.load(f)
+                lib_hash = _lib_srchash()
+                if summ.get("lib_srchash") == lib_hash:
+                    roof["traffic"] = summ.get("_derived", {}).get("hbm_bytes_per_launch")
+                    roof["traffic_source"] = path + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE, separate passes; taken on this library)"
+                else:                                       # counters of ANOTHER build of the kernels: not this run's traffic
+                    roof["traffic"] = None
+                    roof["traffic_source"] = (f"{path} was taken on library {str(summ.get('lib_srchash'))[:12]}, this run uses "
+                                              f"{lib_hash[:12]}: stale, not reported (tools/pmc_traffic.sh refreshes it)")
                 break
         # 16-chain tiles (k_hmc_step<5>) with one workgroup per CU (4096 chains):
         t_full = time_transition(4096)
@@ -484,6 +517,9 @@ def main():
                        "parallelism": (f"chains sharded x{world}: single-device step-size rule ({slab_gathers} acceptance-slab "
                                        "all-gathers per step) + one particle all-gather" if world > 1 else "single GPU")},
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend) if distributed else None,
+            "rccl_ranks": (dist.get_world_size() if (distributed and backend == "nccl") else 0),
+            "collectives_per_step": (slab_gathers + 1) if distributed else 0,
+            "lib_srchash": _lib_srchash(),
             "gathered_rows": int(out[0].shape[0]), "particle_all_gather_us": gather_us,
             "slab_all_gathers_per_step": slab_gathers,
             "value_eval_mode": total / elapsed_eval,

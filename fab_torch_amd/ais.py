@@ -104,12 +104,15 @@ class AnnealedImportanceSampler:
         x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw = out
         return Point(x, lq, lp, gq, gp), log_w, n_valid, stats, base_x, base_lw
 
-    def run(self, batch_size: int, eps0=None, noise_a=None, noise_b=None, want_base: bool = False):
-        """Enqueue one AIS call; returns device tensors (Point fields sized [batch_size], log_w, n_valid[2],
+    def run(self, batch_size: int, eps0=None, noise_a=None, noise_b=None, want_base: bool = False, u0=None):
+        """(`u0` [B, D]: the uniform base draws of the SPLINE flow; an error for any other base distribution.)
+        Enqueue one AIS call; returns device tensors (Point fields sized [batch_size], log_w, n_valid[2],
         stats[16], base_x, base_log_w) without synchronising.  `want_base`: also return the chains' starting points
         after the "chain init" filtering and their log p - log q (generate_eval_data, ais.py:152-166)."""
         if self._spline_parts() is not None:
-            return self._run_spline(batch_size, eps0, noise_a, noise_b, want_base)
+            return self._run_spline(batch_size, eps0, noise_a, noise_b, want_base, u0=u0)
+        if u0 is not None:
+            raise _ops.FabhipError("u0 (uniform base draws) belongs to the fused spline-flow call; a RealNVP takes eps0 only")
         ops = _ops.load()
         flow, target = self._native_parts()
         op = self.transition_operator
@@ -226,6 +229,9 @@ class AnnealedImportanceSampler:
     def sample_and_log_weights(self, batch_size: int, logging: bool = True, eps0=None, noise_a=None, noise_b=None,
                                u0=None) -> Tuple[Point, torch.Tensor]:
         fused_spline = self._spline_parts() is not None
+        if u0 is not None and not fused_spline:               # (it used to be dropped silently)
+            raise _ops.FabhipError("u0 (uniform base draws) belongs to the fused spline-flow call: this sampler's base "
+                                   "distribution / transition operator does not take that path")
         if not self.is_native and not fused_spline:
             if eps0 is not None:
                 raise _ops.FabhipError("eps0 is the base noise of a fab_torch_amd RealNVP; a generic base_distribution "

@@ -37,10 +37,16 @@ __global__ __launch_bounds__(256) void k_gen_hmc_begin(long B, int D, const floa
                                                        fabhip_anneal c, float max_grad, float* __restrict__ XP,
                                                        float* __restrict__ P, float* __restrict__ GU,
                                                        float* __restrict__ logp_cur, const int* __restrict__ n_valid) {
+    const long B_all = B;
     if (n_valid) B = *n_valid < B ? *n_valid : B;           // (fused AIS calls: rows in use after the "chain init" filter)
     const long g = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
     const int cc = threadIdx.x & 15;
     float k0 = 0.f;
+    if (g >= B && g < B_all) {                              // rows of dropped chains: the leapfrog / density / target kernels run
+        for (int j = cc; j < D; j += 16) {                  // over all B_all rows - give them a defined state
+            XP[g * D + j] = 0.f; P[g * D + j] = 0.f; GU[g * D + j] = 0.f;
+        }
+    }
     if (g < B) {
         for (int j = cc; j < D; j += 16) {
             const float m = mass[j];

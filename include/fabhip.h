@@ -306,6 +306,9 @@ int fabhip_create_point(const fabhip_flow* flow, const fabhip_target* target, co
 /* Coefficients of the annealed density (fab/sampling_methods/base.py:76-118), float32:
  *   log pi_beta = c_q log_q + c_p log_p ;  grad = g_q grad_log_q + g_p grad_log_p
  * (g_p = 2 beta when not p_target: the reference's hard-coded factor, base.py:116). */
+/* C callers: ZERO-INITIALISE fabhip_flow / fabhip_spline_flow (`fabhip_flow f = {0};`) before filling them in.  `precision`
+ * (ABI 207) sits where padding used to be, so sizeof did not change and fabhip_abi_sizes cannot tell a caller compiled against
+ * the older header apart - only FABHIP_ABI_VERSION can; an uninitialised value of 1 / 2 would silently select a precision. */
 typedef struct {
     float c_q, c_p, g_q, g_p;
 } fabhip_anneal;

@@ -32,3 +32,11 @@ def test_gpus_2_relaunches_itself_as_two_ranks():
 def test_default_is_one_rank_without_a_process_group():
     line = _run([])
     assert line["n_gpus"] == 1 and line["gathered_rows"] == 64
+
+
+def test_gpus_2_cfg4_line_counts_ranks_and_collectives():
+    """the line of a 2-rank run states how many ranks the process group had and how many collectives a
+    step issued (the stub's step = the particle all-gather alone), for BASELINE cfg 4's per-GPU workload too."""
+    line = _run(["--gpus", "2", "--workload", "cfg4"])
+    assert line["n_gpus"] == 2 and line["process_group_ranks"] == 2 and line["collectives_per_step"] == 1
+    assert line["rccl_ranks"] == 0 and line["backend"] == "gloo"          # gloo on CPU ranks: RCCL itself needs one GPU per rank

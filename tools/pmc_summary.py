@@ -49,6 +49,12 @@ def main():
     if g("SQ_LDS_BANK_CONFLICT") is not None and g("SQ_LDS_IDX_ACTIVE"):
         d["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT") / g("SQ_LDS_IDX_ACTIVE")
     out["_derived"] = d
+    try:                                     # the build these counters were taken on (bench.py reports traffic only for its own)
+        here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        with open(os.path.join(here, "fab_torch_amd", "libfabhip.so.srchash")) as f:
+            out["lib_srchash"] = f.read().split()[0]
+    except (OSError, IndexError):
+        out["lib_srchash"] = None
     print(json.dumps(out, indent=1))
 
 
