@@ -14,7 +14,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 209          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+ABI_VERSION = 210          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
 TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
@@ -32,7 +32,7 @@ def precision_of(flow) -> int:
     raise FabhipError(f"flow.precision must be None, 'fp32' or 'fast' (got {p!r})")
 # developer / test switches of include/fabhip.h (fabhip_set_option)
 (OPT_TILE_SHAPE, OPT_R4_STREAM, OPT_SCAN_VARIANT, OPT_SYSTEMATIC_VARIANT, OPT_SPLINE_STAGED, OPT_TIMELINE,
- OPT_SPLINE_MFMA, OPT_R8_FUSED, OPT_SPLINE_LEAP) = range(9)
+ OPT_SPLINE_MFMA, OPT_SPLINE_LEAP) = range(8)
 
 
 class FabhipError(RuntimeError):

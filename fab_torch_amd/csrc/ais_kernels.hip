@@ -10,7 +10,7 @@
 #include "flow_device.h"
 #include "target_device.h"
 #include "flow_r4.h"
-#include "flow_r8f.h"
+#include "flow_r8.h"
 #include "launch.h"
 
 #pragma clang fp contract(off)   // keep a*b+c un-fused in the elementwise code, like the eager CPU reference
@@ -523,7 +523,7 @@ static inline ExtraLds8 make_extra_lds8(const R8Lds& l, int D) {
     return e;
 }
 
-template <int G, int V>                                 // V = 1: fused stages (flow_r8f.h, default), 0: flow_r8.h's stage per product
+template <int G>
 __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, ExtraLds8 x, const float* __restrict__ packed,
                                                         TargetDev tg, HmcK a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -585,8 +585,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
             lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
         }
         __syncthreads();
-        if constexpr (V == 1) lq = flow_log_prob_r8f<G>(f, l, packed, lds, t8, s, &goff);
-        else lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
+        lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
         if (ew) {
             lp = target_tile<true>(tg, XP, D, GP, D, t);
             for (int j = t.c; j < D; j += 16) {
@@ -644,7 +643,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
 }
 
 // Chain initialisation on 8-chain tiles (as k_ais_init_r4: the flow SAMPLE stays on the 16-chain kernel)
-template <int G, int V>
+template <int G>
 __global__ __launch_bounds__(NTHREADS) void k_ais_init_r8(FlowDims f, R8Lds l, ExtraLds8 x, const float* __restrict__ packed,
                                                         TargetDev tg, const float* __restrict__ lq0, PointDev pt,
                                                         float* __restrict__ log_w, float* __restrict__ base_log_w,
@@ -671,9 +670,7 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r8(FlowDims f, R8Lds l, E
     s8_stream_init(s, t8.lane);
     __syncthreads();
     int goff = 0;
-    float lq;
-    if constexpr (V == 1) lq = flow_log_prob_r8f<G>(f, l, packed, lds, t8, s, &goff);
-    else lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
+    const float lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
     if (!ew) return;
     const float lp = target_tile<true>(tg, XP, D, GP, D, t);
     if (g < B) {
@@ -1088,14 +1085,13 @@ static int launch_hmc_step_r8(const FlowDims& f0, const float* packed, const Tar
     const ExtraLds8 x = make_extra_lds8(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid((unsigned)(nblk_of(a.B) * (ROWS / R8)));      // every row of the 16-row blocks k_hmc_adapt sums gets written
-    const bool fused = option(FABHIP_OPT_R8_FUSED) != 0;
-#define FAB_R8_STEP(G, V)                                                                                         \
+#define FAB_R8_STEP(G)                                                                                            \
     do {                                                                                                          \
-        FAB_TRY(set_max_lds((const void*)k_hmc_step_r8<G, V>, bytes));                                            \
-        hipLaunchKernelGGL((k_hmc_step_r8<G, V>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);       \
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r8<G>, bytes));                                               \
+        hipLaunchKernelGGL((k_hmc_step_r8<G>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);          \
     } while (0)
-    if (f.Wp == 320) { if (fused) FAB_R8_STEP(5, 1); else FAB_R8_STEP(5, 0); }
-    else if (f.Wp == 256) { if (fused) FAB_R8_STEP(4, 1); else FAB_R8_STEP(4, 0); }
+    if (f.Wp == 320) FAB_R8_STEP(5);
+    else if (f.Wp == 256) FAB_R8_STEP(4);
     else return FABHIP_ENOTSUP;
 #undef FAB_R8_STEP
     return check_launch();
@@ -1107,15 +1103,14 @@ static int launch_ais_init_r8(const FlowDims& f, const float* packed, const Targ
     const ExtraLds8 x = make_extra_lds8(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid((unsigned)((B + R8 - 1) / R8));
-    const bool fused = option(FABHIP_OPT_R8_FUSED) != 0;
-#define FAB_R8_INIT(G, V)                                                                                         \
+#define FAB_R8_INIT(G)                                                                                            \
     do {                                                                                                          \
-        FAB_TRY(set_max_lds((const void*)k_ais_init_r8<G, V>, bytes));                                            \
-        hipLaunchKernelGGL((k_ais_init_r8<G, V>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, lq0, pt, log_w, \
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r8<G>, bytes));                                               \
+        hipLaunchKernelGGL((k_ais_init_r8<G>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, lq0, pt, log_w, \
                            base_log_w, an, B);                                                                    \
     } while (0)
-    if (f.Wp == 320) { if (fused) FAB_R8_INIT(5, 1); else FAB_R8_INIT(5, 0); }
-    else if (f.Wp == 256) { if (fused) FAB_R8_INIT(4, 1); else FAB_R8_INIT(4, 0); }
+    if (f.Wp == 320) FAB_R8_INIT(5);
+    else if (f.Wp == 256) FAB_R8_INIT(4);
     else return FABHIP_ENOTSUP;
 #undef FAB_R8_INIT
     return check_launch();

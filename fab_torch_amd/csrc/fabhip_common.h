@@ -94,12 +94,13 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
         f.o_r4s = f.total;
         f.total += (2 * K * (4 * ntw + 4) + 8) * 4 * ntw * 256;
     }
-    // 8-chain-tile image: per layer 4 waves x (forward + reverse = 188 / 271 tiles of 1 KiB for G = Wp / 64 = 4 / 5; flow_r8.h)
+    // 8-chain-tile image: per layer 4 waves x (forward + reverse = 160 / 238 tiles of 1 KiB for G = Wp / 64 = 4 / 5; flow_r8.h,
+    // r4: the narrow matrices as dense tiles)
     f.o_r8 = -1;
     if (D <= 32 && f.DOp == 16 && (f.Wp == 256 || f.Wp == 320)) {
         const int G = f.Wp / 64;
         f.o_r8 = (f.total + 63) & ~63;
-        f.total = f.o_r8 + K * NWAVE * (28 + 40 * G + (G - 4) * (3 + 8 * G)) * 256;
+        f.total = f.o_r8 + K * NWAVE * (20 + 35 * G + (G - 4) * (3 + 8 * G)) * 256;
     }
     f.timeline = nullptr;
     f.fast = 0;

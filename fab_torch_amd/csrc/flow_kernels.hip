@@ -399,12 +399,12 @@ __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0,
         // (matrix, k-quad, column) of the tile: mat 0 AW / AWT, 1 W1 / W1T, 2 W2 / W2T, 3 W3 / W3T
         int mat, q, n;
         if (fwd) {
-            if (ti < R8_KD4) { mat = 0; q = ti; n = lane; }
-            else if ((ti -= R8_KD4) < R8_Kd4) { mat = 1; q = ti; n = 64 * wave + lane; }
+            if (ti < R8_TD) { mat = 0; q = 2 * ti + (lane >> 5); n = lane & 31; }               // dense: 2 k-quads x 32 columns
+            else if ((ti -= R8_TD) < R8_Kd4) { mat = 1; q = ti; n = 64 * wave + lane; }
             else if ((ti -= R8_Kd4) < EX * (R8_Kd4 / 4)) { mat = 1; q = (R8_Kd4 / 4) * wave + ti; n = 256 + lane; }
             else if ((ti -= EX * (R8_Kd4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
             else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
-            else { ti -= EX * NQK; mat = 3; q = NQK * wave + ti; n = lane; }
+            else { ti -= EX * NQK; mat = 3; q = NQK * wave + 2 * ti + (lane >> 5); n = lane & 31; }   // dense: 2 k-quads x (shift | scale)
             const int k = 4 * q + kk;
             if (mat == 0) { if (k < D && n < D) v = Wm[k * D + n]; }
             else if (mat == 1) { if (k < d && n < W) v = w1[n * d + k]; }
@@ -415,8 +415,8 @@ __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0,
             else if ((ti -= R8_Ko4) < EX * (R8_Ko4 / 4)) { mat = 3; q = (R8_Ko4 / 4) * wave + ti; n = 256 + lane; }
             else if ((ti -= EX * (R8_Ko4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
             else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
-            else if ((ti -= EX * NQK) < NQK) { mat = 1; q = NQK * wave + ti; n = lane; }
-            else { ti -= NQK; mat = 0; q = ti; n = lane; }
+            else if ((ti -= EX * NQK) < NQK / 4) { mat = 1; q = NQK * wave + 4 * ti + (lane >> 4); n = lane & 15; }   // dense: 4 k-quads x 16
+            else { ti -= NQK / 4; mat = 0; q = 2 * ti + (lane >> 5); n = lane & 31; }
             const int k = 4 * q + kk;
             if (mat == 3) { const int o = prm_orig(k, DO, f.DOp); if (k < 2 * f.DOp && o >= 0 && n < W) v = w3[o * W + n]; }
             else if (mat == 2) { if (k < W && n < W) v = w2[k * W + n]; }
@@ -508,8 +508,7 @@ struct Options {
             {FABHIP_OPT_TILE_SHAPE, "FABHIP_TILE", 0},           {FABHIP_OPT_R4_STREAM, "FABHIP_R4_STREAM", 1},
             {FABHIP_OPT_SCAN_VARIANT, "FABHIP_SCAN_VARIANT", 3}, {FABHIP_OPT_SYSTEMATIC_VARIANT, "FABHIP_SYSTEMATIC_VARIANT", 1},
             {FABHIP_OPT_SPLINE_STAGED, "FABHIP_SPLINE_STAGED", 0}, {FABHIP_OPT_TIMELINE, "FABHIP_TIMELINE", 0},
-            {FABHIP_OPT_SPLINE_MFMA, "FABHIP_SPLINE_MFMA", 0},   {FABHIP_OPT_R8_FUSED, "FABHIP_R8_FUSED", 0},
-            {FABHIP_OPT_SPLINE_LEAP, "FABHIP_SPLINE_LEAP", 1}};
+            {FABHIP_OPT_SPLINE_MFMA, "FABHIP_SPLINE_MFMA", 0},   {FABHIP_OPT_SPLINE_LEAP, "FABHIP_SPLINE_LEAP", 1}};
         for (const auto& t : tab) {
             const char* e = getenv(t.env);
             v[t.key] = (e && e[0]) ? atoi(e) : t.dflt;

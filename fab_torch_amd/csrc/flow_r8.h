@@ -12,9 +12,12 @@
 //     pipe (8 cycles per instruction) of that SIMD then bounds every stage (measured: 156 instead of 95 cycles per k-quad);
 //   * the narrow products out of the hidden width (W3 -> shift | scale, W1T -> the d input gradients) are K-split (wave w:
 //     k = 64 w .. 64 w + 63) with their partials summed by the element-wise stage that consumes them;
-//   * the D x D maps are evaluated by every wave (8 tiles), wave 0 stores;
+//   * the D x D maps are evaluated by every wave, wave 0 stores;
+//   * r4: the narrow products are streamed as DENSE tiles - 2 k-quads of a 32-column matrix (D x D maps, W3), 4 k-quads of a
+//     16-column one (W1T) side by side in one 1-KiB tile, each lane half / quarter multiplying its own k-quad: 33 tiles (12 %)
+//     fewer per wave and layer pair; the 2 / 4 partial products per wave are summed with the other waves' by the consumer;
 //   * every wave reads its tiles of a layer and direction as ONE stream through a 32-tile AGPR ring (stream_r8.h): forward
-//     [AW 8 | W1 4 (+1) | W2 16 G (+4 G) | W3 4 G], reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T 4 G | AWT 8] tiles of 1 KiB
+//     [AW 4 | W1 4 (+1) | W2 16 G (+4 G) | W3 2 G], reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T G | AWT 4] tiles of 1 KiB
 //     ((+..): its share of the fifth group); the next layer's ring is requested before the layer's last element-wise stage;
 //   * biases / log-det constants of ALL layers sit in LDS (copied once per kernel), ReLU decisions as ballots in LDS.
 // Same arithmetic as flow_log_prob_r4 / flow_log_prob_tile up to the summation order inside the GEMMs.
@@ -28,18 +31,18 @@ constexpr int R8 = 8;                  // chains per workgroup
 constexpr int R8_RD = 16;              // ring depth (1-KiB tiles in flight per wave; 32: the 31-request prologue of every layer costs more than it hides)
 using R8Stream = S8StreamT<R8_RD>;
 constexpr int R8_KD4 = 8, R8_Kd4 = 4, R8_Ko4 = 8;    // k-quads of the short K extents, padded to D = 32 / d = 16 / 2 DOp = 32
+constexpr int R8_TD = R8_KD4 / 2;                    // dense tiles of a D x D map (2 k-quads x 32 columns each)
 
 FAB_HD bool r8_shape_ok(const FlowDims& f) { return f.o_r8 >= 0; }
-// tiles per wave, layer and direction (G = 4: 92 / 96, G = 5: 133 / 138); make_flow_dims sizes the image with the same sums
-FAB_HD int r8_tiles_fwd(int G) { const int EX = G - 4; return R8_KD4 + R8_Kd4 + EX + 16 * G + 4 * G * EX + 4 * G; }
-FAB_HD int r8_tiles_rev(int G) { const int EX = G - 4; return R8_Ko4 + 2 * EX + 16 * G + 4 * G * EX + 4 * G + R8_KD4; }
+// tiles per wave, layer and direction (G = 4: 80 / 80, G = 5: 119 / 119); make_flow_dims sizes the image with the same sums
+FAB_HD int r8_tiles_fwd(int G) { const int EX = G - 4; return R8_TD + R8_Kd4 + EX + 16 * G + 4 * G * EX + 2 * G; }
+FAB_HD int r8_tiles_rev(int G) { const int EX = G - 4; return R8_Ko4 + 2 * EX + 16 * G + 4 * G * EX + G + R8_TD; }
 FAB_HD int r8_layer_floats(int G) { return NWAVE * (r8_tiles_fwd(G) + r8_tiles_rev(G)) * 256; }
 
 // LDS plan of an r8 workgroup (floats)
 struct R8Lds {
     int WS, HF;                        // leading dim of the hidden tiles; floats per layer of the head block
     int o_X0, o_X1, o_HA, o_HB, o_PRM, o_DP, o_PART, o_ES, o_V2, o_MASK, o_HEAD, total;
-    int o_X2, o_PARTX;                 // flow_r8f.h: third state slot; partials of the fifth column group
 };
 // head block of a layer: ac[64] | b1[Wp] | b2[Wp] | b3[64] (shift | scale at 0 / DOp) | logS[16]
 FAB_HD R8Lds make_r8_lds(const FlowDims& f) {
@@ -59,8 +62,6 @@ FAB_HD R8Lds make_r8_lds(const FlowDims& f) {
     l.o_V2 = o; o += f.K * R8 * f.DOp;
     l.o_MASK = o; o += f.K * 2 * G * R8 * 2;         // u64 ballots [layer][stage][column group][chain]
     l.o_HEAD = o; o += f.K * l.HF;
-    l.o_X2 = o; o += R8 * R4_DS;
-    l.o_PARTX = o; o += NWAVE * R8 * R4_DS;
     l.total = (o + 3) & ~3;
     return l;
 }
@@ -103,6 +104,26 @@ __device__ __forceinline__ int r8_opaque_zero() {
 
 __device__ __forceinline__ float r8_part_sum(const float* p) {          // the 4 waves' partials of one output, fixed order
     return (p[0] + p[R8 * R4_DS]) + (p[2 * R8 * R4_DS] + p[3 * R8 * R4_DS]);
+}
+// dense narrow products: NP = 8 (W3: 4 waves x 2 k-quad halves, [NP][8][32]) or 16 (W1T: 4 waves x 4 quarters, [NP][8][16])
+// partial products of one output, `st` floats apart, added as a fixed balanced tree
+template <int NP>
+__device__ __forceinline__ float r8_part_sum_n(const float* p, int st) {
+    float v[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) v[i] = p[i * st];
+#pragma unroll
+    for (int w = 1; w < NP; w *= 2)
+#pragma unroll
+        for (int i = 0; i < NP; i += 2 * w) v[i] = v[i] + v[i + w];
+    return v[0];
+}
+// sum of the two k-quad halves of a dense D x D product (lanes l and l ^ 32 hold the partial products of column l & 31), on
+// every lane: v_permlane32_swap (gfx950) makes [lower | lower] and [upper | upper] of the register - no LDS round trip
+__device__ __forceinline__ float r8_sum_halves(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
 // One product into the hidden width: OUT[8][Wp] = epilogue(ACT[8][4 NQ] @ B).  Stream tiles T0 .. : NQ of this wave's own
@@ -183,10 +204,11 @@ template <int G>
 __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds& l, const float* __restrict__ packed, float* lds,
                                   const Tid8f& t, R8Stream& s, int* grad_off) {
     constexpr int EX = G - 4, NQW = 16 * G, NQK = 4 * G;                  // k-quads of K = Wp; of a wave's quarter of it
-    constexpr int F_AW = 0, F_W1 = R8_KD4, F_W2 = F_W1 + R8_Kd4 + EX * (R8_Kd4 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK;
-    constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK, B_AWT = B_W1T + NQK,
-                  TR = B_AWT + R8_KD4;
+    constexpr int F_AW = 0, F_W1 = R8_TD, F_W2 = F_W1 + R8_Kd4 + EX * (R8_Kd4 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK / 2;
+    constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK, B_AWT = B_W1T + NQK / 4,
+                  TR = B_AWT + R8_TD;
     constexpr int LF = NWAVE * (TF + TR) * 256;                             // floats per layer of the r8 image
+    const int h2 = t.lane >> 5, h4 = t.lane >> 4;                           // this lane's k-quad inside a dense tile of 2 / 4
     constexpr int WS = 64 * G + 4;                                          // = l.WS, as a constant (see r8_dense_wide)
     const float* img = packed + f.o_r8;
     int cur = l.o_X0, nxt = l.o_X1;
@@ -213,14 +235,18 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run<F_AW, R8_KD4, TF>(s, lds + cur + t.arow * R4_DS, 4 * R4_DS, acc);
+            s8_run_k<8, F_AW, R8_TD, TF>(s, lds + cur + t.arow * R4_DS + 4 * h2, 4 * R4_DS, acc);
             s8_fold(acc, o);
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[rb][r] = r8_sum_halves(o[rb][r]);
             if (t.wave == 0) {
                 const float bv = HD[t.lane];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) lds[nxt + (4 * rb + r) * R4_DS + t.lane] = o[rb][r] + bv;
+                    for (int r = 0; r < 4; ++r) lds[nxt + (4 * rb + r) * R4_DS + t.lane] = t.lane < 32 ? o[rb][r] + bv : 0.f;
             }
         }
         logq += HD[128 + 2 * f.Wp];
@@ -236,12 +262,12 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run<F_W3, NQK, TF>(s, HB + t.arow * WS + 4 * NQK * t.wave, 4 * WS, acc);
+            s8_run_k<8, F_W3, NQK / 2, TF>(s, HB + t.arow * WS + 4 * NQK * t.wave + 4 * h2, 4 * WS, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * R4_DS + t.lane] = o[rb][r];
+                for (int r = 0; r < 4; ++r) PART[((2 * t.wave + h2) * R8 + 4 * rb + r) * 32 + (t.lane & 31)] = o[rb][r];
         }
         // the ring is empty here: request the next layer's (or the reverse sweep's first) tiles behind the element-wise stage
         s8_prologue(s, layer > 0 ? fwd_base(layer - 1) : rev_base(0));
@@ -254,8 +280,8 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             for (int it = 0; it < 2; ++it) {
                 const int j = c + 16 * it;
                 if (j < f.DO) {
-                    const float shift = r8_part_sum(PART + row * R4_DS + j) + HD[64 + 2 * f.Wp + j];
-                    const float sv = r8_part_sum(PART + row * R4_DS + DOp + j) + HD[64 + 2 * f.Wp + DOp + j];
+                    const float shift = r8_part_sum_n<8>(PART + row * 32 + j, R8 * 32) + HD[64 + 2 * f.Wp + j];
+                    const float sv = r8_part_sum_n<8>(PART + row * 32 + DOp + j, R8 * 32) + HD[64 + 2 * f.Wp + DOp + j];
                     const float es = expf(-sv);
                     const float v2 = (Z[row * R4_DS + f.d + j] - shift) * es;
                     Z[row * R4_DS + f.d + j] = v2;
@@ -315,25 +341,29 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run<B_W1T, NQK, TR>(s, HB + t.arow * WS + 4 * NQK * t.wave, 4 * WS, acc);
+            s8_run_k<16, B_W1T, NQK / 4, TR>(s, HB + t.arow * WS + 4 * NQK * t.wave + 4 * h4, 4 * WS, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * R4_DS + t.lane] = o[rb][r];
+                for (int r = 0; r < 4; ++r) PART[((4 * t.wave + h4) * R8 + 4 * rb + r) * 16 + (t.lane & 15)] = o[rb][r];
         }
         s8_barrier();
         if (tl) FAB_TL(f, 19);
-        if (ew && c < f.d) Gs[row * R4_DS + c] += r8_part_sum(PART + row * R4_DS + c);        // g[:, :d] += ...   (d <= 16)
+        if (ew && c < f.d) Gs[row * R4_DS + c] += r8_part_sum_n<16>(PART + row * 16 + c, R8 * 16);   // g[:, :d] += ...   (d <= 16)
         s8_barrier();
         if (tl) FAB_TL(f, 20);
         {   // g <- g W'^T (every wave; wave 0 stores, and forms the NEXT layer's coupling cotangents where its g2 appears)
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run<B_AWT, R8_KD4, TR>(s, Gs + t.arow * R4_DS, 4 * R4_DS, acc);
+            s8_run_k<8, B_AWT, R8_TD, TR>(s, Gs + t.arow * R4_DS + 4 * h2, 4 * R4_DS, acc);
             s8_fold(acc, o);
             if (layer + 1 < f.K) s8_prologue(s, rev_base(layer + 1));
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[rb][r] = r8_sum_halves(o[rb][r]);
             if (t.wave == 0) {
                 const int j = t.lane - f.d;
                 const bool cpl = layer + 1 < f.K && j >= 0 && j < f.DO;
@@ -342,7 +372,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int rr = 4 * rb + r;
-                        float v = o[rb][r];
+                        float v = t.lane < 32 ? o[rb][r] : 0.f;
                         if (cpl) {
                             const float es = lds[l.o_ES + ((size_t)(layer + 1) * R8 + rr) * DOp + j];
                             const float v2 = lds[l.o_V2 + ((size_t)(layer + 1) * R8 + rr) * DOp + j];

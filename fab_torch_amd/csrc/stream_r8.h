@@ -78,8 +78,10 @@ struct S8Acc {
     f32x4 a[KI][RB];
 };
 
-template <int NSTEP, int USE, int PHASE, int REMAIN, int RB, class ST>
-__device__ __forceinline__ void s8_iter(ST& s, const float* ap, int rb1, S8Acc<RB>& acc) {
+// KSTEP: floats between the A operands of consecutive tiles (4: one k-quad per tile; 8 / 16: DENSE tiles of a narrow output -
+// 2 / 4 k-quads side by side in the tile's lane halves / quarters, the lane's sub-block offset is part of `ap`)
+template <int KSTEP, int NSTEP, int USE, int PHASE, int REMAIN, int RB, class ST>
+__device__ __forceinline__ void s8_iter_k(ST& s, const float* ap, int rb1, S8Acc<RB>& acc) {
     constexpr int KI = S8Acc<RB>::KI;
     constexpr int S8_RD = ST::RD;
     float4 an[RB];
@@ -98,7 +100,7 @@ __device__ __forceinline__ void s8_iter(ST& s, const float* ap, int rb1, S8Acc<R
         if constexpr (d < USE) {
             if constexpr (d + 1 < USE) {
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb) an[rb] = *reinterpret_cast<const float4*>(ap + rb * rb1 + 4 * (d + 1));
+                for (int rb = 0; rb < RB; ++rb) an[rb] = *reinterpret_cast<const float4*>(ap + rb * rb1 + KSTEP * (d + 1));
             }
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -127,6 +129,11 @@ __device__ __forceinline__ void s8_iter(ST& s, const float* ap, int rb1, S8Acc<R
     s.next += (size_t)NSTEP * 64;
 }
 
+template <int NSTEP, int USE, int PHASE, int REMAIN, int RB, class ST>
+__device__ __forceinline__ void s8_iter(ST& s, const float* ap, int rb1, S8Acc<RB>& acc) {
+    s8_iter_k<4, NSTEP, USE, PHASE, REMAIN>(s, ap, rb1, acc);
+}
+
 template <int RB>
 __device__ __forceinline__ void s8_zero(S8Acc<RB>& acc) {
 #pragma unroll
@@ -144,11 +151,15 @@ __device__ __forceinline__ void s8_fold(const S8Acc<RB>& acc, f32x4 (&o)[RB]) {
 }
 
 // NQ k-quads from stream tile T0 of a layer stream of TOTAL tiles, in iterations of at most 32 (static ring slots)
+template <int KSTEP, int T0, int NQ, int TOTAL, int RB, class ST>
+__device__ __forceinline__ void s8_run_k(ST& s, const float* ap, int rb1, S8Acc<RB>& acc) {
+    constexpr int N0 = NQ < 32 ? NQ : 32;
+    s8_iter_k<KSTEP, N0, N0, T0 % ST::RD, TOTAL - 1 - T0>(s, ap, rb1, acc);
+    if constexpr (NQ > N0) s8_run_k<KSTEP, T0 + N0, NQ - N0, TOTAL>(s, ap + KSTEP * N0, rb1, acc);
+}
 template <int T0, int NQ, int TOTAL, int RB, class ST>
 __device__ __forceinline__ void s8_run(ST& s, const float* ap, int rb1, S8Acc<RB>& acc) {
-    constexpr int N0 = NQ < 32 ? NQ : 32;
-    s8_iter<N0, N0, T0 % ST::RD, TOTAL - 1 - T0>(s, ap, rb1, acc);
-    if constexpr (NQ > N0) s8_run<T0 + N0, NQ - N0, TOTAL>(s, ap + 4 * N0, rb1, acc);
+    s8_run_k<4, T0, NQ, TOTAL>(s, ap, rb1, acc);
 }
 
 }  // namespace fab

@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 209
+#define FABHIP_ABI_VERSION 210
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -100,12 +100,9 @@ int fabhip_get_fast_mode(void);
 #define FABHIP_OPT_SPLINE_MFMA 6         /* FABHIP_SPLINE_MFMA: spline density kernel for hidden widths padded to 256: 0 = the
                                             4x4x1 stream kernels (8 / 16 chains per workgroup by batch, or by TILE_SHAPE),
                                             16 = the 16x16x4 kernel */
-#define FABHIP_OPT_R8_FUSED 7            /* FABHIP_R8_FUSED: 8-chain RealNVP tiles: 1 = fused stages (flow_r8f.h: 3 instead of 7
-                                            barriers per layer and direction, measured 4 % SLOWER), 0 = one stage per product
-                                            (flow_r8.h, default); bit-identical results */
-#define FABHIP_OPT_SPLINE_LEAP 8         /* FABHIP_SPLINE_LEAP: fused spline transitions: 1 = one launch per leapfrog (half steps and
+#define FABHIP_OPT_SPLINE_LEAP 7         /* FABHIP_SPLINE_LEAP: fused spline transitions: 1 = one launch per leapfrog (half steps and
                                             the target inside the 4x4x1 spline density kernel, default), 0 = four launches */
-#define FABHIP_OPT_COUNT 9
+#define FABHIP_OPT_COUNT 8
 int fabhip_set_option(int key, int value);
 int fabhip_get_option(int key);
 

@@ -23,9 +23,9 @@ torch.cuda.synchronize()
 buf = (C.c_int64 * 64)()
 _lib.check(_lib.load().fabhip_debug_timeline(buf, 64), "timeline")
 ts = list(buf)
-names = {0: "fwd layer start", 1: "affine (every wave, 8 tiles)", 2: "W1 (d -> W, 4 tiles)", 3: "W2 (W x W, 16 G tiles)",
-         4: "W3 (K split, 16 tiles) + next ring", 5: "coupling", 16: "rev layer start", 17: "W3T (8 tiles)",
-         18: "W2T (16 G tiles)", 19: "W1T (K split, 16 tiles)", 20: "add", 21: "affine^T (8 tiles) + next ring"}
+names = {0: "fwd layer start", 1: "affine (every wave, 4 dense tiles)", 2: "W1 (d -> W, 4 tiles)", 3: "W2 (W x W, 16 G tiles)",
+         4: "W3 (K split, 2 G dense tiles) + next ring", 5: "coupling", 16: "rev layer start", 17: "W3T (8 tiles)",
+         18: "W2T (16 G tiles)", 19: "W1T (K split, G dense tiles)", 20: "add", 21: "affine^T (4 dense tiles) + next ring"}
 prev = None
 for i in sorted(names):
     if not ts[i]:
