@@ -100,7 +100,8 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     if (D <= 32 && f.DOp == 16 && (f.Wp == 256 || f.Wp == 320)) {
         const int G = f.Wp / 64;
         f.o_r8 = (f.total + 63) & ~63;
-        f.total = f.o_r8 + K * NWAVE * (20 + 35 * G + (G - 4) * (3 + 8 * G)) * 256;
+        // per wave: K layers x 2 directions x (80 / 120 tiles: 119 padded to a multiple of the ring depth) + 64 tiles of tail
+        f.total = f.o_r8 + NWAVE * (2 * K * (G == 5 ? 120 : 80) + 64) * 256;
     }
     f.timeline = nullptr;
     f.fast = 0;

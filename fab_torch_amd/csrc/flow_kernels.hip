@@ -375,26 +375,33 @@ __global__ __launch_bounds__(256) void k_pack_r4(FlowDims f, R4Dims rd, MlpTab t
     }
 }
 
-// 8-chain-tile image (flow_r8.h): per layer [forward: wave 0 .. 3 | reverse: wave 0 .. 3], a wave's 1-KiB tiles (lane =
-// column, float4 = 4 consecutive k) in the order it consumes them.  Forward [AW 8 | W1 4 (+1) | W2 16 G (+4 G) | W3 4 G],
-// reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T 4 G | AWT 8]; N-split matrices: columns 64 wave + lane, all of K; (+..): the
+// 8-chain-tile image (flow_r8.h): ONE contiguous stream per wave - [layers K-1 .. 0 forward | layers 0 .. K-1 reverse | tail] -
+// of 1-KiB tiles (lane = column, float4 = 4 consecutive k) in the order the wave consumes them, every layer and direction
+// padded to r8_tiles_p(G) tiles (a multiple of the ring depth).  Forward [AW 4 | W1 4 (+1) | W2 16 G (+4 G) | W3 2 G],
+// reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T G | AWT 4]; N-split matrices: columns 64 wave + lane, all of K; (+..): the
 // fifth column group (columns 256 + lane) of a 320-wide layer, this wave's quarter of the k-quads; K-split (W3, W1T): this
-// wave's quarter of K, columns = lane; the D x D maps are the same tiles for every wave.
+// wave's quarter of K as DENSE tiles (2 / 4 k-quads side by side); the D x D maps (dense) are the same tiles for every wave.
 __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed) {
-    const int D = f.D, d = f.d, DO = f.DO, W = f.W, G = f.Wp / 64, EX = G - 4;
-    const int TF = r8_tiles_fwd(G), TR = r8_tiles_rev(G), LF = r8_layer_floats(G);
+    const int D = f.D, d = f.d, DO = f.DO, W = f.W, G = f.Wp / 64, EX = G - 4, K = f.K;
+    const int TF = r8_tiles_fwd(G), TR = r8_tiles_rev(G), TP = r8_tiles_p(G);
     const int NQW = 16 * G, NQK = 4 * G;
     const int y = blockIdx.y, layer = k0 + y;
-    float* __restrict__ dst = packed + f.o_r8 + (size_t)layer * LF;
+    float* __restrict__ img = packed + f.o_r8;
+    const long WT = r8_wave_tiles(G, K);
     const float* Wm = packed + f.o_scratch + (size_t)layer * 2 * D * D;       // W' (assembled, ActNorm folded)
     const float *w1 = tab.w1[y], *w2 = tab.w2[y], *w3 = tab.w3[y];
-    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < LF; off += gridDim.x * blockDim.x) {
+    const int LT = NWAVE * 2 * TP * 256;                                        // floats of this layer, over waves and directions
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < LT; off += gridDim.x * blockDim.x) {
         const int kk = off & 3, lane = (off >> 2) & 63;
         int tl = off >> 8;
-        const bool fwd = tl < NWAVE * TF;
-        if (!fwd) tl -= NWAVE * TF;
-        const int T = fwd ? TF : TR, wave = tl / T;
-        int ti = tl % T;
+        const int wave = tl / (2 * TP);
+        tl -= wave * 2 * TP;
+        const bool fwd = tl < TP;
+        int ti = fwd ? tl : tl - TP;
+        // position of the tile in the wave's stream: forward layers run K-1 .. 0, then reverse layers 0 .. K-1
+        const long pos = fwd ? (long)(K - 1 - layer) * TP + ti : (long)(K + layer) * TP + ti;
+        float* dstp = img + ((size_t)wave * WT + pos) * 256 + ((size_t)lane << 2) + kk;
+        if (ti >= (fwd ? TF : TR)) { *dstp = 0.f; continue; }                  // the padding tile
         float v = 0.f;
         // (matrix, k-quad, column) of the tile: mat 0 AW / AWT, 1 W1 / W1T, 2 W2 / W2T, 3 W3 / W3T
         int mat, q, n;
@@ -423,7 +430,7 @@ __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0,
             else if (mat == 1) { if (k < W && n < d) v = w1[k * d + n]; }
             else { if (k < D && n < D) v = Wm[n * D + k]; }
         }
-        dst[off] = v;
+        *dstp = v;
     }
 }
 
@@ -580,7 +587,7 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
         const R4Dims rd = make_r4_dims(f);
         hipLaunchKernelGGL(k_pack_r4, dim3(ceil_div(rd.layer_stride, 256 * 8), nl), dim3(256), 0, st, f, rd, mt, k0, packed);
         if (f.o_r8 >= 0)
-            hipLaunchKernelGGL(k_pack_r8, dim3(ceil_div(r8_layer_floats(f.Wp / 64), 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
+            hipLaunchKernelGGL(k_pack_r8, dim3(ceil_div(NWAVE * 2 * r8_tiles_p(f.Wp / 64) * 256, 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
     }
     if (f.o_r4s >= 0)
         hipLaunchKernelGGL(k_pack_r4s, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed);

@@ -28,7 +28,10 @@
 namespace fab {
 
 constexpr int R8 = 8;                  // chains per workgroup
-constexpr int R8_RD = 16;              // ring depth (1-KiB tiles in flight per wave; 32: the 31-request prologue of every layer costs more than it hides)
+constexpr int R8_RD = 40;              // ring depth: 1-KiB tiles in flight per wave.  r4: ONE stream per wave for a whole evaluation (all
+                                       // layers forward, then reverse), never drained - a layer's padded tile count (80 / 120) is a
+                                       // multiple of the depth, so every slot index is a compile-time constant
+constexpr int R8_TAIL = 64;            // tiles of slack behind a wave's stream (the last requests read past its end)
 using R8Stream = S8StreamT<R8_RD>;
 constexpr int R8_KD4 = 8, R8_Kd4 = 4, R8_Ko4 = 8;    // k-quads of the short K extents, padded to D = 32 / d = 16 / 2 DOp = 32
 constexpr int R8_TD = R8_KD4 / 2;                    // dense tiles of a D x D map (2 k-quads x 32 columns each)
@@ -37,7 +40,10 @@ FAB_HD bool r8_shape_ok(const FlowDims& f) { return f.o_r8 >= 0; }
 // tiles per wave, layer and direction (G = 4: 80 / 80, G = 5: 119 / 119); make_flow_dims sizes the image with the same sums
 FAB_HD int r8_tiles_fwd(int G) { const int EX = G - 4; return R8_TD + R8_Kd4 + EX + 16 * G + 4 * G * EX + 2 * G; }
 FAB_HD int r8_tiles_rev(int G) { const int EX = G - 4; return R8_Ko4 + 2 * EX + 16 * G + 4 * G * EX + G + R8_TD; }
-FAB_HD int r8_layer_floats(int G) { return NWAVE * (r8_tiles_fwd(G) + r8_tiles_rev(G)) * 256; }
+FAB_HD int r8_tiles_pad(int G) { return G == 5 ? 1 : 0; }               // zero tiles at the end of a layer and direction: 119 -> 120
+FAB_HD int r8_tiles_p(int G) { return r8_tiles_fwd(G) + r8_tiles_pad(G); }   // per layer and direction, padded (fwd == rev: 80 / 120)
+FAB_HD long r8_wave_tiles(int G, int K) { return 2L * K * r8_tiles_p(G) + R8_TAIL; }   // one wave's stream
+FAB_HD long r8_image_floats(int G, int K) { return (long)NWAVE * r8_wave_tiles(G, K) * 256; }
 
 // LDS plan of an r8 workgroup (floats)
 struct R8Lds {
@@ -207,7 +213,9 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
     constexpr int F_AW = 0, F_W1 = R8_TD, F_W2 = F_W1 + R8_Kd4 + EX * (R8_Kd4 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK / 2;
     constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK, B_AWT = B_W1T + NQK / 4,
                   TR = B_AWT + R8_TD;
-    constexpr int LF = NWAVE * (TF + TR) * 256;                             // floats per layer of the r8 image
+    static_assert(TF == TR && (TF + EX) % R8_RD == 0, "a layer's padded tile count must be a multiple of the ring depth");
+    constexpr int TP = TF + EX;                                             // padded tiles per layer and direction (EX: one zero tile)
+    constexpr int CONT = S8_INF;                                            // "tiles left in the stream": never drained
     const int h2 = t.lane >> 5, h4 = t.lane >> 4;                           // this lane's k-quad inside a dense tile of 2 / 4
     constexpr int WS = 64 * G + 4;                                          // = l.WS, as a constant (see r8_dense_wide)
     const float* img = packed + f.o_r8;
@@ -217,11 +225,14 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
     const int row = t.row, c = t.c;
     const int DOp = f.DOp;
     float logq = 0.f;
-    auto fwd_base = [&](int layer) { return reinterpret_cast<const float4*>(img + (size_t)layer * LF) + (size_t)t.wave * TF * 64; };
-    auto rev_base = [&](int layer) {
-        return reinterpret_cast<const float4*>(img + (size_t)layer * LF) + (size_t)(NWAVE * TF + t.wave * TR) * 64;
+    // this wave's stream: [layers K-1 .. 0 forward | layers 0 .. K-1 reverse | tail], TP tiles per layer and direction
+    s8_prologue(s, reinterpret_cast<const float4*>(img) + (size_t)t.wave * r8_wave_tiles(G, f.K) * 64);
+    auto pad_tile = [&](float* lds) {                                       // the zero tile that rounds a layer up to TP (G = 5)
+        if constexpr (EX) {
+            S8Acc<2> acc;
+            s8_iter_k<4, 1, 0, TF % R8_RD, CONT>(s, lds + l.o_X0 + t.arow * R4_DS, 4 * R4_DS, acc);
+        }
     };
-    s8_prologue(s, fwd_base(f.K - 1));
     for (int layer = f.K - 1; layer >= 0; --layer) {
         float* lds = lds0 + r8_opaque_zero();
         float* HA = lds + l.o_HA;
@@ -235,7 +246,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run_k<8, F_AW, R8_TD, TF>(s, lds + cur + t.arow * R4_DS + 4 * h2, 4 * R4_DS, acc);
+            s8_run_k<8, F_AW, R8_TD, CONT + F_AW>(s, lds + cur + t.arow * R4_DS + 4 * h2, 4 * R4_DS, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
@@ -254,23 +265,22 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         s8_barrier();
         if (tl) FAB_TL(f, 1);
         // conditioner: HA = relu(z[:, :d] W1 + b1), HB = relu(HA W2 + b2)
-        r8_dense_wide<G, F_W1, R8_Kd4, TF, 1, R4_DS, WS>(s, Z, HA, PART, mk, t, [&](int col) { return HD[64 + col]; });
+        r8_dense_wide<G, F_W1, R8_Kd4, CONT + TP, 1, R4_DS, WS>(s, Z, HA, PART, mk, t, [&](int col) { return HD[64 + col]; });
         if (tl) FAB_TL(f, 2);
-        r8_dense_wide<G, F_W2, NQW, TF, 1, WS, WS>(s, HA, HB, PART, mk + G * R8, t, [&](int col) { return HD[64 + f.Wp + col]; });
+        r8_dense_wide<G, F_W2, NQW, CONT + TP, 1, WS, WS>(s, HA, HB, PART, mk + G * R8, t, [&](int col) { return HD[64 + f.Wp + col]; });
         if (tl) FAB_TL(f, 3);
         {   // (shift | scale) = HB W3: K split over the waves, partial [8][64] products to PART
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run_k<8, F_W3, NQK / 2, TF>(s, HB + t.arow * WS + 4 * NQK * t.wave + 4 * h2, 4 * WS, acc);
+            s8_run_k<8, F_W3, NQK / 2, CONT + F_W3>(s, HB + t.arow * WS + 4 * NQK * t.wave + 4 * h2, 4 * WS, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) PART[((2 * t.wave + h2) * R8 + 4 * rb + r) * 32 + (t.lane & 31)] = o[rb][r];
         }
-        // the ring is empty here: request the next layer's (or the reverse sweep's first) tiles behind the element-wise stage
-        s8_prologue(s, layer > 0 ? fwd_base(layer - 1) : rev_base(0));
+        pad_tile(lds);                 // (the stream runs on into the next layer: nothing to request here)
         s8_barrier();
         if (tl) FAB_TL(f, 4);
         // AffineCoupling.inverse: z2 <- (z2 - shift) exp(-s), log_det = -sum(s)
@@ -333,15 +343,15 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         const bool tl = layer == 1;
         if (tl) FAB_TL(f, 16);
         // d relu(h2) = DP W3T masked by h2 > 0 -> HA;  d relu(h1) = HA W2T masked by h1 > 0 -> HB
-        r8_dense_wide<G, B_W3T, R8_Ko4, TR, 2, R4_DS, WS>(s, DP, HA, PART, mk + G * R8, t, [](int) { return 0.f; });
+        r8_dense_wide<G, B_W3T, R8_Ko4, CONT + TP, 2, R4_DS, WS>(s, DP, HA, PART, mk + G * R8, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 17);
-        r8_dense_wide<G, B_W2T, NQW, TR, 2, WS, WS>(s, HA, HB, PART, mk, t, [](int) { return 0.f; });
+        r8_dense_wide<G, B_W2T, NQW, CONT + TP, 2, WS, WS>(s, HA, HB, PART, mk, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 18);
         {   // conditioner input gradient = HB W1T: K split over the waves
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run_k<16, B_W1T, NQK / 4, TR>(s, HB + t.arow * WS + 4 * NQK * t.wave + 4 * h4, 4 * WS, acc);
+            s8_run_k<16, B_W1T, NQK / 4, CONT + B_W1T>(s, HB + t.arow * WS + 4 * NQK * t.wave + 4 * h4, 4 * WS, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
@@ -357,9 +367,9 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             f32x4 o[2];
             S8Acc<2> acc;
             s8_zero(acc);
-            s8_run_k<8, B_AWT, R8_TD, TR>(s, Gs + t.arow * R4_DS + 4 * h2, 4 * R4_DS, acc);
+            s8_run_k<8, B_AWT, R8_TD, CONT + B_AWT>(s, Gs + t.arow * R4_DS + 4 * h2, 4 * R4_DS, acc);
             s8_fold(acc, o);
-            if (layer + 1 < f.K) s8_prologue(s, rev_base(layer + 1));
+            pad_tile(lds);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -388,6 +398,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         if (tl) FAB_TL(f, 21);
         const int tmp = cur; cur = nxt; nxt = tmp;
     }
+    s8_drain(s);                       // the requests past the end of the stream (R8_TAIL)
     *grad_off = cur;
     return logq;
 }

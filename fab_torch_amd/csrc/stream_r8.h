@@ -30,7 +30,8 @@ template <int RD_>
 struct S8StreamT {
     static constexpr int RD = RD_;
     f32x4 r[RD_];                      // ring slot of stream tile k: k % RD   ("a" registers)
-    unsigned voff[8];                  // lane * 16 + 4096 j: with the 4 immediate offsets, 32 tiles from one scalar base
+    static constexpr int NV = RD_ > 32 ? (RD_ + 3) / 4 : 8;
+    unsigned voff[NV];                 // lane * 16 + 4096 j: with the 4 immediate offsets, 4 NV tiles from one scalar base
     const float4* next;                // tile that step 0 of the next iteration requests
 };
 using S8Stream = S8StreamT<S8_RD>;
@@ -52,7 +53,7 @@ __device__ __forceinline__ void s8_wait(f32x4& r) {
 template <class ST>
 __device__ __forceinline__ void s8_stream_init(ST& s, int lane) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s.voff[j] = (unsigned)(lane * 16 + 4096 * j);
+    for (int j = 0; j < ST::NV; ++j) s.voff[j] = (unsigned)(lane * 16 + 4096 * j);
 }
 
 // layer top: request tiles 0 .. RD-2 of the wave's stream at `base`
@@ -65,6 +66,12 @@ __device__ __forceinline__ void s8_prologue(ST& s, const float4* base) {
         else s8_load<(d % 4) * 1024>(s.r[d], s.voff[d / 4], base);
     });
     s.next = base + (size_t)(S8_RD - 1) * 64;
+}
+
+// wait for everything the ring has in flight (end of a never-drained stream: the last RD - 1 requests read past its end)
+template <class ST>
+__device__ __forceinline__ void s8_drain(ST& s) {
+    s8_for<0, ST::RD>([&](auto dc) { s8_wait<0>(s.r[decltype(dc)::value]); });
 }
 
 // NSTEP k-quads (stream tiles T0 .. T0 + NSTEP - 1, T0 % RD == PHASE) of which the first USE are multiplied:
