@@ -29,12 +29,20 @@ __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// lane i <- lane (i + N) mod 16 of its 16-lane row: one DPP move (row_ror), no LDS crossbar (ds_bpermute, which is what
+// __shfl_xor compiles to, costs an LDS round trip per step)
+template <int N>
+__device__ __forceinline__ float row_ror(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x120 + N, 0xF, 0xF, false));
+}
 __device__ __forceinline__ float row16_sum(float v) {
-    // sum over the 16 lanes that share a chain row (tid = row*16 + c); fixed xor tree => deterministic
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
+    // sum over the 16 lanes that share a chain row (tid = row*16 + c); fixed tree => deterministic.  The xor-butterfly 8, 4, 2, 1
+    // as rotations: after the first step the values have period 8, so "+ 4 mod 16" reads the lane "xor 4" would (and so on):
+    // bit for bit the sums of the __shfl_xor form.
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
     return v;
 }
 

@@ -12,7 +12,7 @@
 //     pipe (8 cycles per instruction) of that SIMD then bounds every stage (measured: 156 instead of 95 cycles per k-quad);
 //   * the narrow products out of the hidden width (W3 -> shift | scale, W1T -> the d input gradients) are K-split (wave w:
 //     k = 64 w .. 64 w + 63) with their partials summed by the element-wise stage that consumes them;
-//   * the D x D maps are evaluated by every wave, wave 0 stores;
+//   * the D x D maps are evaluated by every wave, wave w stores chains 2 w, 2 w + 1;
 //   * r4: the narrow products are streamed as DENSE tiles - 2 k-quads of a 32-column matrix (D x D maps, W3), 4 k-quads of a
 //     16-column one (W1T) side by side in one 1-KiB tile, each lane half / quarter multiplying its own k-quad: 33 tiles (12 %)
 //     fewer per wave and layer pair; the 2 / 4 partial products per wave are summed with the other waves' by the consumer;
@@ -252,12 +252,13 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[rb][r] = r8_sum_halves(o[rb][r]);
-            if (t.wave == 0) {
+            {   // every wave holds the whole product: wave w stores chains 2 w, 2 w + 1 (a quarter of the epilogue's latency each)
                 const float bv = HD[t.lane];
 #pragma unroll
                 for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) lds[nxt + (4 * rb + r) * R4_DS + t.lane] = t.lane < 32 ? o[rb][r] + bv : 0.f;
+                    for (int r = 0; r < 4; ++r)
+                        if (((4 * rb + r) >> 1) == t.wave) lds[nxt + (4 * rb + r) * R4_DS + t.lane] = t.lane < 32 ? o[rb][r] + bv : 0.f;
             }
         }
         logq += HD[128 + 2 * f.Wp];
@@ -374,7 +375,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[rb][r] = r8_sum_halves(o[rb][r]);
-            if (t.wave == 0) {
+            {   // wave w finishes chains 2 w, 2 w + 1 (every wave holds the whole product)
                 const int j = t.lane - f.d;
                 const bool cpl = layer + 1 < f.K && j >= 0 && j < f.DO;
 #pragma unroll
@@ -382,6 +383,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int rr = 4 * rb + r;
+                        if ((rr >> 1) != t.wave) continue;
                         float v = t.lane < 32 ? o[rb][r] : 0.f;
                         if (cpl) {
                             const float es = lds[l.o_ES + ((size_t)(layer + 1) * R8 + rr) * DOp + j];

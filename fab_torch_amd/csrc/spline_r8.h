@@ -74,11 +74,15 @@ struct Tid8 {
 };
 
 __device__ __forceinline__ float row32_sum(float v) {
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 8);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 1);
+    {   // v + v(lane ^ 16): v_permlane16_swap of the register with itself gives [r0 r0 r2 r2] and [r1 r1 r3 r3] (16-lane rows)
+        const unsigned u = __float_as_uint(v);
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
     return v;
 }
 

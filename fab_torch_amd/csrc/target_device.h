@@ -30,10 +30,10 @@ static inline int check_target(const fabhip_target* t, int dim) {
 }
 
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 8));
-    v = fmaxf(v, __shfl_xor(v, 4));
-    v = fmaxf(v, __shfl_xor(v, 2));
-    v = fmaxf(v, __shfl_xor(v, 1));
+    v = fmaxf(v, row_ror<8>(v));
+    v = fmaxf(v, row_ror<4>(v));
+    v = fmaxf(v, row_ror<2>(v));
+    v = fmaxf(v, row_ror<1>(v));
     return v;
 }
 
