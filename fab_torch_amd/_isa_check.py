@@ -106,6 +106,12 @@ def _decode(texts, i):
                 if mm and mm.group(1) in base:
                     hazard = ws < 5
                     break
+                if p.startswith("s_") and " " in p:      # a scalar-ALU write in between: the load reads THAT value, no hazard
+                    d0 = p.split(None, 1)[1].split(",")[0].strip()
+                    md = re.match(r"s\[(\d+):(\d+)\]$", d0)
+                    base -= ({"s%d" % k for k in range(int(md.group(1)), int(md.group(2)) + 1)} if md else {d0})
+                    if not base:
+                        break
                 ws += 1
                 if ws >= 5:
                     break
