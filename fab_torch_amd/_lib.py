@@ -105,7 +105,7 @@ SYMBOLS = [
     "fabhip_hmc_adapt_gathered", "fabhip_spline_hmc_workspace_bytes", "fabhip_spline_hmc_transition",
     "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_tape_gemm", "fabhip_debug_spline_timeline",
 ]
-ABI_VERSION = 210          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 211          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):

@@ -14,7 +14,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 210          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+ABI_VERSION = 211          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
 TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
@@ -32,7 +32,7 @@ def precision_of(flow) -> int:
     raise FabhipError(f"flow.precision must be None, 'fp32' or 'fast' (got {p!r})")
 # developer / test switches of include/fabhip.h (fabhip_set_option)
 (OPT_TILE_SHAPE, OPT_R4_STREAM, OPT_SCAN_VARIANT, OPT_SYSTEMATIC_VARIANT, OPT_SPLINE_STAGED, OPT_TIMELINE,
- OPT_SPLINE_MFMA, OPT_SPLINE_LEAP) = range(8)
+ OPT_SPLINE_MFMA, OPT_SPLINE_LEAP, OPT_FUSED_TAIL, OPT_ADAPT_FOLD) = range(10)
 
 
 class FabhipError(RuntimeError):
@@ -149,6 +149,45 @@ def _register_autograd():
                                     setup_context=_tape_setup_context)
     torch.library.register_autograd("fabhip::realnvp_sample_tape", _sample_backward,
                                     setup_context=_sample_setup_context)
+
+
+_pinned = {}
+
+
+def _read_small(t: torch.Tensor) -> torch.Tensor:
+    """Device -> host copy of a few words at the END of a call the host is waiting for: into a pinned buffer, then the copy's
+    event is polled (hipEventQuery) instead of sleeping in a blocking synchronise - the wake-up of a blocked thread costs tens of
+    microseconds during which the GPU has nothing queued.  Polling is bounded (a call of this library lasts milliseconds); past
+    the bound the thread blocks."""
+    key = (t.device, t.dtype, t.numel())
+    ent = _pinned.get(key)
+    if ent is None:
+        ent = (torch.empty(t.numel(), dtype=t.dtype, pin_memory=True), torch.cuda.Event())
+        _pinned[key] = ent
+    buf, ev = ent
+    buf.copy_(t, non_blocking=True)
+    ev.record()
+    for _ in range(200000):
+        if ev.query():
+            break
+    else:
+        ev.synchronize()
+    return buf                                          # (valid until the next read of the same size on this device)
+
+
+def read_counts_and_stats(n_valid: torch.Tensor, stats: torch.Tensor):
+    """(stats[:6] on the host, (n_valid[0], n_valid[1])) with ONE device->host copy: the AIS ops allocate `stats` (float[16]) and
+    `n_valid` (int32[2]) as views of one 18-word buffer, which is read whole; tensors from elsewhere (the phase ops of the
+    sharded sampler own theirs) take the two-kernel route."""
+    if stats.is_cuda and stats.dtype == torch.float32 and n_valid.dtype == torch.int32:
+        st = stats.untyped_storage()
+        if (n_valid.untyped_storage().data_ptr() == st.data_ptr() and st.nbytes() == 72 and stats.storage_offset() == 0
+                and n_valid.storage_offset() == 16 and stats.numel() == 16 and n_valid.numel() == 2):
+            h = _read_small(stats.as_strided((18,), (1,)))
+            n = h[16:18].view(torch.int32)
+            return h[:6], (int(n[0]), int(n[1]))
+    h = torch.cat([n_valid.float(), stats[:6]]).cpu()
+    return h[2:], (int(h[0]), int(h[1]))
 
 
 # ---- shape functions (torch.compile / fake tensors) for the tensor-in / tensor-out density ops ---------------------

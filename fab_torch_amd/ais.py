@@ -96,7 +96,7 @@ class AnnealedImportanceSampler:
         noise_a = torch.randn((M, op.n_outer, B, D), **f32) if noise_a is None else noise_a.contiguous()
         noise_b = torch.empty((M, op.n_outer, B), **f32).exponential_(1.0) if noise_b is None else noise_b.contiguous()
         alpha = float(self.alpha) if self.alpha is not None else 0.0
-        out = ops.spline_ais_run(*flow.native(), *target.native_target(), [float(b) for b in self.B_space], alpha,
+        out = ops.spline_ais_run(*flow.native(), *target.native_target(), self._betas(), alpha,
                                  bool(self.p_target), u0, eps0, noise_a, noise_b, op.epsilons, op.common_epsilon,
                                  op.mass_vector, op.n_outer, op.L, float(op.max_grad), float(op.target_p_accept),
                                  not op.eval_mode, op._p_accept_first, op._p_accept_last, op._dist_first, op._dist_last,
@@ -135,7 +135,7 @@ class AnnealedImportanceSampler:
                        else torch.rand((M, n_inner, B), **f32))
         eps0, noise_a, noise_b = eps0.contiguous(), noise_a.contiguous(), noise_b.contiguous()
         assert noise_a.shape == (M, n_inner, B, D) and noise_b.shape == (M, n_inner, B)
-        betas = [float(b) for b in self.B_space]
+        betas = self._betas()
         alpha = float(self.alpha) if self.alpha is not None else 0.0
         if hmc:
             out = ops.ais_run(*flow.native(), *target.native_target(), betas, alpha, bool(self.p_target),
@@ -152,6 +152,16 @@ class AnnealedImportanceSampler:
         x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw = out
         point = Point(x, lq, lp, gq if hmc else None, gp if hmc else None)
         return point, log_w, n_valid, stats, base_x, base_lw
+
+    def _betas(self):
+        """B_space as a list of Python floats (the ops' `float[] betas`), converted once per B_space tensor / version."""
+        bs = self.B_space
+        c = self.__dict__.get("_betas_cache")
+        ver = getattr(bs, "_version", None)
+        if c is None or c[0] is not bs or c[1] != ver:
+            c = (bs, ver, [float(b) for b in bs])
+            self.__dict__["_betas_cache"] = c
+        return c[2]
 
     def perform_transition(self, x_new: Point, log_w: torch.Tensor, j: int):
         """ais.py:90-105: one MCMC transition towards the j-th intermediate distribution + the log-weight increment
@@ -241,8 +251,7 @@ class AnnealedImportanceSampler:
             point, log_w, n_valid, stats, _, _ = self._run_spline(batch_size, eps0, noise_a, noise_b, u0=u0)
         else:
             point, log_w, n_valid, stats, _, _ = self.run(batch_size, eps0, noise_a, noise_b)
-        host = torch.cat([n_valid.float(), stats[:6]]).cpu()          # the single device->host read
-        n_init, n_end = int(host[0]), int(host[1])
+        host, (n_init, n_end) = _ops.read_counts_and_stats(n_valid, stats)   # the single device->host read
         if n_init == 0:
             raise Exception("No valid points generated in sampling the chain init")
         if n_end == 0:
@@ -250,7 +259,7 @@ class AnnealedImportanceSampler:
         if n_end != batch_size:
             print(f"{batch_size - n_end} nan/inf samples/log-probs/log-weights encountered.")
             point, log_w = point[:n_end], log_w[:n_end]
-        st = host[2:]
+        st = host
         if logging:
             self._logging_info = LoggingInfo(ess_base=float(st[0]), ess_ais=float(st[3]), log_Z=float(st[4]))
         return point, log_w.detach()

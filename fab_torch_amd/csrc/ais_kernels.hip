@@ -194,7 +194,65 @@ struct HmcK {
     float* part_dist;                // [nblk] sum of the store_info distance
     float* row_acc;                  // 4-chain tiles: the same two quantities per chain [16 nblk]; k_hmc_adapt adds them
     float* row_dist;                 //   in the 16-chain kernel's order (16 rows, then blocks)
+    // step-size rule inside the transition kernel (4- / 8-chain tiles of a fused AIS call; hmc_adapt_last): ticket == nullptr
+    // leaves it to k_hmc_adapt
+    int* ticket;                     // zero before the launch; the last wave to finish resets it
+    float* eps_w;                    // = eps_ptr / ceps_ptr, writable
+    float* ceps_w;
+    float target_p_accept;
+    int tune;
+    float* p_accept_out;
+    float* dist_out;
+    int nblk;
 };
+
+__device__ __forceinline__ void hmc_adapt_rule(float s, float d, long nv, float* eps_ptr, float* ceps_ptr,
+                                               float target_p_accept, int tune, float* p_accept_out, float* dist_out);
+
+// k_hmc_adapt's work (per-chain values -> blocks of 16 rows in row order -> blocks in order -> the rule: the same additions, bit
+// for bit) done by the LAST wave of the launch to finish, instead of a launch of its own after every transition kernel (6 us + the
+// launch gap, eight times per AIS call).  Every wave that stores row_acc / row_dist calls this once, after its stores
+// (`n_waves` = such waves per workgroup).  The L2s of the 8 XCDs are not coherent with each other, and a device-scope release
+// fence (buffer_wbl2) costs as much as the launch it would save (measured: +6 us per kernel): the per-chain values are written
+// and read with DEVICE-SCOPE relaxed atomics instead (sc1: written through / read past the XCD's L2), the wave waits for its
+// stores (vmcnt) before it draws its ticket, and the wave that draws the last one sums and applies the rule.  Nobody reads the
+// step sizes any more by then (every workgroup loads them at its top); the next launch sees the new ones.
+// `scratch`: 2 nblk floats of LDS that no wave of this workgroup still reads.
+__device__ __forceinline__ void hmc_store_row_stats(const HmcK& a, long g, float contrib, float dist) {
+    if (a.ticket) {
+        __hip_atomic_store(a.row_acc + g, contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.row_dist + g, dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        a.row_acc[g] = contrib; a.row_dist[g] = dist;
+    }
+}
+__device__ __forceinline__ void hmc_adapt_last(const HmcK& a, float* scratch, int lane, int n_waves) {
+    if (!a.ticket) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    if (tk != (int)gridDim.x * n_waves - 1) return;
+    const int nblk = a.nblk;
+    for (int b = lane; b < nblk; b += 64) {
+        float s = 0.f, d = 0.f;
+        for (int r = 0; r < ROWS; ++r) {
+            s += __hip_atomic_load(a.row_acc + (long)b * ROWS + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d += __hip_atomic_load(a.row_dist + (long)b * ROWS + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        scratch[b] = s; scratch[nblk + b] = d;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // one wave: its LDS writes are done before lane 0 reads them
+    if (lane == 0) {
+        const long nv = a.n_valid ? (long)*a.n_valid : a.B;
+        if (nv > 0) {
+            float s = 0.f, d = 0.f;
+            for (int i = 0; i < nblk; ++i) { s += scratch[i]; d += scratch[nblk + i]; }
+            hmc_adapt_rule(s, d, nv, a.eps_w, a.ceps_w, a.target_p_accept, a.tune, a.p_accept_out, a.dist_out);
+        }
+        __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 template <int NTWM, bool FAST>
 __device__ __forceinline__ void hmc_step_body(const FlowDims& f, const FlowLds& l, const ExtraLds& x,
@@ -352,7 +410,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
     const bool ew = t.tid < 64;
     const long g = row0 + t.row;
     if (row0 >= nv) {
-        if (ew && t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = 0.f; a.row_dist[g] = 0.f; }
+        if (ew && t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, 0.f, 0.f);
+        if (ew) hmc_adapt_last(a, lds, t.tid, 1);
         return;
     }
     float* XP = lds + x.o_XP;
@@ -453,7 +512,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
         const float den = a.c.c_q * lqf + a.c.c_p * lpf;
         a.log_w[g] = a.log_w[g] + (num - den);
     }
-    if (t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = contrib; a.row_dist[g] = dist; }
+    if (t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, contrib, dist);
+    hmc_adapt_last(a, lds, t.tid, 1);                 // (wave 0 is the only wave left)
 }
 
 // Chain initialisation on 4-chain tiles (HMC runs of <= 1152 chains): the flow SAMPLE stays on the 16-chain kernel
@@ -536,7 +596,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
     const bool ew = t.tid < 16 * R8;
     const long g = row0 + t.row;
     if (row0 >= nv) {
-        if (ew && t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = 0.f; a.row_dist[g] = 0.f; }
+        if (ew && t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, 0.f, 0.f);
+        if (ew) hmc_adapt_last(a, lds, t.tid & 63, 16 * R8 / 64);
         return;
     }
     float* XP = lds + x.o_XP;
@@ -639,7 +700,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
         const float den = a.c.c_q * lqf + a.c.c_p * lpf;
         a.log_w[g] = a.log_w[g] + (num - den);
     }
-    if (t.c == 0 && g < (a.B + 15) / 16 * 16) { a.row_acc[g] = contrib; a.row_dist[g] = dist; }
+    if (t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, contrib, dist);
+    hmc_adapt_last(a, lds, t.tid & 63, 16 * R8 / 64);   // (the two element-wise waves; the others have returned)
 }
 
 // Chain initialisation on 8-chain tiles (as k_ais_init_r4: the flow SAMPLE stays on the 16-chain kernel)
@@ -1126,7 +1188,7 @@ static int launch_metropolis(const FlowDims& f, const float* packed, const Targe
     return check_launch();
 }
 
-static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
+static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st, int* ticket = nullptr) {
     const FlowDims f = flow_dims_of(a->flow);
     const TargetDev tg = make_target_dev(a->target);
     const int D = f.D;
@@ -1159,9 +1221,15 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st) {
         k.eps_ptr = a->epsilons + n; k.ceps_ptr = a->common_epsilon; k.mass = a->mass;
         k.L = a->L; k.max_grad = a->max_grad; k.part_acc = part_acc; k.part_dist = part_dist;
         k.row_acc = row_acc; k.row_dist = row_dist;
+        // the step-size rule in the transition kernel's last workgroup (4- / 8-chain tiles; `ticket` is zero: fabhip_ais_phase)
+        const bool fold = ticket && (r4 || r8) && !a->partials;
+        k.ticket = fold ? ticket : nullptr;
+        k.eps_w = a->epsilons + n; k.ceps_w = a->common_epsilon; k.target_p_accept = a->target_p_accept; k.tune = a->tune;
+        k.p_accept_out = a->p_accept ? a->p_accept + n : nullptr; k.dist_out = a->avg_distance; k.nblk = nblk;
         if (r8) FAB_TRY(launch_hmc_step_r8(f, a->flow.packed, tg, k, st));
         else if (r4) FAB_DISPATCH_NTW_NORET(f, launch_hmc_step_r4, f, a->flow.packed, tg, k, st);
         else FAB_DISPATCH_NTW_NORET(f, launch_hmc_step, f, a->flow.packed, tg, k, st);
+        if (fold) { FAB_TRY(check_launch()); continue; }
         hipLaunchKernelGGL(k_hmc_adapt, dim3(1), dim3(64), 0, st, part_acc, part_dist, nblk, a->n_valid, (long)a->B,
                            a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
                            a->p_accept ? a->p_accept + n : nullptr, a->avg_distance,
@@ -1280,8 +1348,14 @@ size_t fabhip_ais_workspace_bytes(int64_t B, int32_t dim, int32_t n_inner) {
     s += align256((size_t)B * 4);                    // dest ranks
     s += align256((size_t)B * 4);                    // log_p - log_q
     s += align256(fabhip_ess_workspace_bytes(B));
+    s += 256;                                         // ticket of the in-kernel step-size rule
     return s + 256;
 }
+
+// the tail of a chain phase: compaction (+ log_p - log_q) + ESS / log Z - one launch for small batches, else the separate kernels
+static int phase_tail(const fabhip_point& point, float* log_w, long B, int dim, const int* n_in, int* n_out, float* tmp, int* dest,
+                      float* extra, float* diff, double n_norm, float* stats_out, void* ess_ws, size_t ess_bytes, float* base_x,
+                      int* zero_word, hipStream_t st);
 
 static int compact_rows(const fabhip_point& point, float* log_w, long B, int dim, const int* n_in, int* n_out, float* tmp,
                         int* dest, float* extra, hipStream_t st) {
@@ -1293,9 +1367,30 @@ static int compact_rows(const fabhip_point& point, float* log_w, long B, int dim
     return check_launch();
 }
 
-static int compact(const fabhip_ais_args* a, const int* n_in, int* n_out, float* tmp, int* dest, float* extra,
-                   hipStream_t st) {
-    return compact_rows(a->point, a->log_w, (long)a->B, a->flow.dim, n_in, n_out, tmp, dest, extra, st);
+static int phase_tail(const fabhip_point& point, float* log_w, long B, int dim, const int* n_in, int* n_out, float* tmp, int* dest,
+                      float* extra, float* diff, double n_norm, float* stats_out, void* ess_ws, size_t ess_bytes, float* base_x,
+                      int* zero_word, hipStream_t st) {
+    int rc = FABHIP_ENOTSUP;
+    if (option(FABHIP_OPT_FUSED_TAIL) != 0) {
+        TailArgs t;
+        t.x = point.x; t.lq = point.log_q; t.lp = point.log_p; t.gq = point.grad_log_q; t.gp = point.grad_log_p;
+        t.log_w = log_w; t.extra = extra; t.n_in = n_in; t.n_out = n_out; t.B = B; t.D = dim; t.diff = diff; t.n_norm = n_norm;
+        t.stats_out = stats_out; t.zero_word = zero_word;
+        rc = tail_small(t, dest, st);
+        if (rc != FABHIP_OK && rc != FABHIP_ENOTSUP) return rc;
+    }
+    if (rc == FABHIP_ENOTSUP) {
+        if (zero_word && hipMemsetAsync(zero_word, 0, 4, st) != hipSuccess) return FABHIP_ELAUNCH;
+        FAB_TRY(compact_rows(point, log_w, B, dim, n_in, n_out, tmp, dest, extra, st));
+    }
+    if (base_x &&         // the compacted starting points (rows beyond the count are don't-care)
+        hipMemcpyAsync(base_x, point.x, (size_t)B * dim * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return FABHIP_ELAUNCH;
+    if (rc == FABHIP_ENOTSUP) {
+        if (diff) hipLaunchKernelGGL(k_sub, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, point.log_p, point.log_q, diff, B);
+        FAB_TRY(fabhip_ess_logz(diff ? diff : log_w, B, n_out, n_norm, stats_out, ess_ws, ess_bytes, (fabhip_stream_t)st));
+    }
+    return check_launch();
 }
 
 // ---- spline flow as base distribution (csrc/spline_kernels.hip) ------------------------------------------------------
@@ -1399,11 +1494,8 @@ int fabhip_spline_ais_run(const fabhip_spline_ais_args* a, fabhip_stream_t strea
     hipLaunchKernelGGL(k_spline_init_logw, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_q, a->point.log_p, lq0,
                        a1, a->log_w, a->base_log_w, B);
     // 2. "chain init" filter, 3. base ESS
-    FAB_TRY(compact_rows(a->point, a->log_w, B, D, nullptr, a->n_valid, tmp, dest, a->base_log_w, st));
-    if (a->base_x && hipMemcpyAsync(a->base_x, a->point.x, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return FABHIP_ELAUNCH;
-    hipLaunchKernelGGL(k_sub, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_p, a->point.log_q, lwb, B);
-    FAB_TRY(fabhip_ess_logz(lwb, B, a->n_valid, 1.0, a->stats + 0, ess_ws, ess_bytes, stream));
+    FAB_TRY(phase_tail(a->point, a->log_w, B, D, nullptr, a->n_valid, tmp, dest, a->base_log_w, lwb, 1.0, a->stats + 0, ess_ws,
+                       ess_bytes, a->base_x, nullptr, st));
     // 4. transitions
     for (int j = 1; j <= a->M; ++j) {
         fabhip_spline_hmc_args h;
@@ -1422,8 +1514,8 @@ int fabhip_spline_ais_run(const fabhip_spline_ais_args* a, fabhip_stream_t strea
         FAB_TRY(fabhip_spline_hmc_transition(&h, stream));
     }
     // 5. "chain end" filter, 6. ESS / log Z
-    FAB_TRY(compact_rows(a->point, a->log_w, B, D, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, st));
-    FAB_TRY(fabhip_ess_logz(a->log_w, B, a->n_valid + 1, (double)B, a->stats + 3, ess_ws, ess_bytes, stream));
+    FAB_TRY(phase_tail(a->point, a->log_w, B, D, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, nullptr, (double)B, a->stats + 3,
+                       ess_ws, ess_bytes, nullptr, nullptr, st));
     return check_launch();
 }
 
@@ -1463,8 +1555,11 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     float* tmp = (float*)ws; ws += align256((size_t)B * (3 * D + 4) * 4);
     int* dest = (int*)ws; ws += align256((size_t)B * 4);
     float* lwb = (float*)ws; ws += align256((size_t)B * 4);
-    void* ess_ws = ws;
+    void* ess_ws = ws; ws += align256(fabhip_ess_workspace_bytes(B));
     const size_t ess_bytes = fabhip_ess_workspace_bytes(B);
+    // step-size rule inside the transition kernels (hmc_adapt_last): only where this call zeroes the ticket itself (the init phase)
+    int* ticket = (do_init && hmc && !partials && option(FABHIP_OPT_ADAPT_FOLD) != 0 && nblk_of(B) <= 2048 &&
+                   (use_r8_tiles(f, B) || use_r4_tiles(f, B))) ? (int*)ws : nullptr;      // (2 nblk floats of LDS scratch)
 
     if (do_init) {
     // 1. chain initialisation
@@ -1484,14 +1579,9 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
                                    hmc ? 1 : 0, B, st);
         }
     }
-    // 2. remove nan/inf ("chain init")
-    FAB_TRY(compact(a, nullptr, a->n_valid, tmp, dest, a->base_log_w, st));
-    if (a->base_x &&      // the compacted starting points (rows beyond n_valid[0] are don't-care)
-        hipMemcpyAsync(a->base_x, a->point.x, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
-        return FABHIP_ELAUNCH;
-    // 3. ESS over the base samples (ais.py:68-71) -> stats[0..2]
-    hipLaunchKernelGGL(k_sub, dim3(ceil_div((int)B, 256)), dim3(256), 0, st, a->point.log_p, a->point.log_q, lwb, B);
-    FAB_TRY(fabhip_ess_logz(lwb, B, a->n_valid, 1.0, a->stats + 0, ess_ws, ess_bytes, stream));
+    // 2. remove nan/inf ("chain init"), 3. ESS over the base samples (ais.py:68-71) -> stats[0..2]
+    FAB_TRY(phase_tail(a->point, a->log_w, B, D, nullptr, a->n_valid, tmp, dest, a->base_log_w, lwb, 1.0, a->stats + 0, ess_ws,
+                       ess_bytes, a->base_x, ticket, st));
     }
     // 4. transitions
     for (int j = j_begin; j <= j_end; ++j) {
@@ -1514,7 +1604,7 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
             // logging slots of the first / last distribution (hmc.py:173-183), one acceptance per outer loop
             if (j == 1) { h.p_accept = a->p_accept_first; h.avg_distance = a->avg_distance_first; }
             else if (j == a->M) { h.p_accept = a->p_accept_last; h.avg_distance = a->avg_distance_last; }
-            FAB_TRY(hmc_transition_impl(&h, st));
+            FAB_TRY(hmc_transition_impl(&h, st, ticket));
         } else {
             fabhip_metropolis_args m;
             m.flow = a->flow; m.target = a->target; m.point = a->point; m.B = B; m.n_valid = a->n_valid;
@@ -1527,10 +1617,9 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
         }
     }
     // 5. remove nan/inf ("chain end"), 6. ESS / log Z over the survivors (ais.py:77-86)
-    if (do_finish) {
-        FAB_TRY(compact(a, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, st));
-        FAB_TRY(fabhip_ess_logz(a->log_w, B, a->n_valid + 1, (double)B, a->stats + 3, ess_ws, ess_bytes, stream));
-    }
+    if (do_finish)
+        FAB_TRY(phase_tail(a->point, a->log_w, B, D, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, nullptr, (double)B,
+                           a->stats + 3, ess_ws, ess_bytes, nullptr, nullptr, st));
     return check_launch();
 }
 

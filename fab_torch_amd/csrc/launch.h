@@ -48,6 +48,24 @@ struct SplineLeap {
 int spline_log_prob_leap(const fabhip_spline_flow* flow, const SplineLeap& lp, float* log_q, float* grad_x, int64_t B,
                          void* workspace, size_t workspace_bytes, hipStream_t st);
 
+// The tail of a chain phase in one launch for small batches (reduce_resample.hip: k_tail_small): compaction of the rows with
+// finite log_p / log_q, optionally diff = log_p - log_q over all B rows, ESS / log Z over the survivors (of diff, or of log_w).
+// FABHIP_ENOTSUP above 8192 rows (the caller then runs the separate kernels: the same results, bit for bit).
+struct TailArgs {
+    float *x, *lq, *lp, *gq, *gp;      // the point's fields (gq / gp null: a Metropolis run)
+    float* log_w;
+    float* extra;                      // optional per-row scalar carried along by the compaction
+    const int* n_in;                   // rows in (device; null: B)
+    int* n_out;                        // rows out (device)
+    long B;
+    int D;
+    float* diff;                       // null: ESS over log_w
+    double n_norm;
+    float* stats_out;                  // [3]: ESS, log Z, n
+    int* zero_word;                    // optional: one word the kernel zeroes (the ticket of the in-kernel step-size rule)
+};
+int tail_small(const TailArgs& a, int* dest, hipStream_t st);
+
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
 
 // Allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU).

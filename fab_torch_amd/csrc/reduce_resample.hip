@@ -76,13 +76,12 @@ __device__ __forceinline__ Msum msum_push_chunk(const Msum& a, const float (&x)[
     return Msum{md, a.s1 * r + (double)s1, a.s2 * r * r + (double)s2};
 }
 
-__global__ __launch_bounds__(ESS_THREADS) void k_ess_partial(const float* __restrict__ lw, long n_cap, const int* n_ptr,
-                                                             Msum* __restrict__ part) {
-    __shared__ Msum sh[ESS_THREADS];
-    const long n = n_ptr ? (long)*n_ptr : n_cap;
+// the work of block `vb` of `nb` of the partial pass (ltid = thread in the block): shared by k_ess_partial and the one-launch
+// tail kernel, which runs the blocks one after the other - the same additions in the same order, bit for bit
+__device__ __forceinline__ Msum ess_partial_body(const float* __restrict__ lw, long n, int vb, int nb, Msum* sh) {
     Msum v = msum_id();
-    const long stride = (long)gridDim.x * blockDim.x;
-    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long stride = (long)nb * blockDim.x;
+    const long tid = (long)vb * blockDim.x + threadIdx.x;
     long done = 0;
     if ((((size_t)lw) & 15) == 0) {                     // 16 values per thread per step: four coalesced 16-byte loads
         const long n16 = n / (16 * stride) * (16 * stride);
@@ -99,14 +98,10 @@ __global__ __launch_bounds__(ESS_THREADS) void k_ess_partial(const float* __rest
         done = n16;
     }
     for (long i = done + tid; i < n; i += stride) v = msum_push(v, (double)lw[i]);
-    v = msum_block_reduce(v, sh);
-    if (threadIdx.x == 0) part[blockIdx.x] = v;
+    return msum_block_reduce(v, sh);
 }
-
-__global__ __launch_bounds__(ESS_THREADS) void k_ess_final(const Msum* __restrict__ part, int nblk, long n_cap,
-                                                           const int* n_ptr, double n_norm, float* __restrict__ out) {
-    __shared__ Msum sh[ESS_THREADS];
-    const long n = n_ptr ? (long)*n_ptr : n_cap;
+__device__ __forceinline__ void ess_final_body(const Msum* __restrict__ part, int nblk, long n, double n_norm,
+                                               float* __restrict__ out, Msum* sh) {
     Msum v = msum_id();
     for (int i = threadIdx.x; i < nblk; i += blockDim.x) v = msum_merge(v, part[i]);
     v = msum_block_reduce(v, sh);
@@ -117,6 +112,111 @@ __global__ __launch_bounds__(ESS_THREADS) void k_ess_final(const Msum* __restric
         out[1] = (float)logz;
         out[2] = (float)n;
     }
+}
+
+__global__ __launch_bounds__(ESS_THREADS) void k_ess_partial(const float* __restrict__ lw, long n_cap, const int* n_ptr,
+                                                             Msum* __restrict__ part) {
+    __shared__ Msum sh[ESS_THREADS];
+    const long n = n_ptr ? (long)*n_ptr : n_cap;
+    const Msum v = ess_partial_body(lw, n, blockIdx.x, gridDim.x, sh);
+    if (threadIdx.x == 0) part[blockIdx.x] = v;
+}
+
+__global__ __launch_bounds__(ESS_THREADS) void k_ess_final(const Msum* __restrict__ part, int nblk, long n_cap,
+                                                           const int* n_ptr, double n_norm, float* __restrict__ out) {
+    __shared__ Msum sh[ESS_THREADS];
+    const long n = n_ptr ? (long)*n_ptr : n_cap;
+    ess_final_body(part, nblk, n, n_norm, out, sh);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The tail of a chain phase for SMALL batches in ONE launch (launch.h: TailArgs; <= TAIL_MAX_ROWS rows): stable compaction of the
+// rows with finite log_p and log_q (ais.py:190-213), optionally log_p - log_q, then ESS / log Z over the survivors - what
+// k_valid_scan, k_compact_scatter, k_compact_copyback, k_sub, k_ess_partial and k_ess_final do in six launches (~5 us each on an
+// otherwise idle GPU: the work of 1024 rows is a few hundred nanoseconds).  One workgroup: the rows move IN PLACE, in row order,
+// through an LDS chunk (destination <= source, so a chunk's writes only touch rows already read); nothing moves when no row was
+// dropped.  The ESS runs the partial pass's blocks one after the other (ess_partial_body): bit-identical to the two-kernel form.
+// ------------------------------------------------------------------------------------------------
+constexpr int TAIL_CHUNK = 32;                         // rows staged in LDS per step of the in-place move
+constexpr int TAIL_MAX_BLOCKS = 8;                     // ESS blocks of 1024 values: batches of <= 8192 rows
+
+__global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __restrict__ dest, int nb) {
+    extern __shared__ __attribute__((aligned(16))) float stage[];          // [TAIL_CHUNK][3 D + 4]
+    __shared__ Msum sh[ESS_THREADS];
+    __shared__ Msum part[TAIL_MAX_BLOCKS];
+    __shared__ int wsum[ESS_THREADS / 64];
+    __shared__ int running;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    constexpr int NWV = ESS_THREADS / 64;
+    const long n_in = a.n_in ? (long)*a.n_in : a.B;
+    if (tid == 0) { running = 0; if (a.zero_word) *a.zero_word = 0; }
+    __syncthreads();
+    for (long base = 0; base < n_in; base += ESS_THREADS) {               // k_valid_scan's ranks (integers: any order of work agrees)
+        const long r = base + tid;
+        const bool v = r < n_in && isfinite(a.lq[r]) && isfinite(a.lp[r]);
+        const unsigned long long bal = __ballot(v);
+        const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(bal);
+        __syncthreads();
+        int woff = 0, tot = 0;
+        for (int i = 0; i < NWV; ++i) { if (i < w) woff += wsum[i]; tot += wsum[i]; }
+        if (r < n_in) dest[r] = v ? running + woff + pre : -1;
+        __syncthreads();
+        if (tid == 0) running += tot;
+        __syncthreads();
+    }
+    const long n_out = running;
+    if (tid == 0) *a.n_out = (int)n_out;
+    const int D = a.D, RW = 3 * D + 4;
+    const bool hg = a.gq != nullptr;
+    if (n_out != n_in) {
+        for (long r0 = 0; r0 < n_in; r0 += TAIL_CHUNK) {
+            const int nr = (int)(n_in - r0 < TAIL_CHUNK ? n_in - r0 : TAIL_CHUNK);
+            for (int e = tid; e < nr * D; e += ESS_THREADS) {
+                const int i = e / D, j = e % D;
+                const long r = r0 + i;
+                float* o = stage + i * RW;
+                o[j] = a.x[r * D + j];
+                if (hg) { o[D + j] = a.gq[r * D + j]; o[2 * D + j] = a.gp[r * D + j]; }
+            }
+            if (tid < nr) {
+                const long r = r0 + tid;
+                float* o = stage + tid * RW;
+                o[3 * D] = a.lq[r]; o[3 * D + 1] = a.lp[r]; o[3 * D + 2] = a.log_w[r];
+                if (a.extra) o[3 * D + 3] = a.extra[r];
+            }
+            __syncthreads();
+            for (int e = tid; e < nr * D; e += ESS_THREADS) {
+                const int i = e / D, j = e % D;
+                const long d = dest[r0 + i];
+                if (d < 0 || d == r0 + i) continue;
+                const float* o = stage + i * RW;
+                a.x[d * D + j] = o[j];
+                if (hg) { a.gq[d * D + j] = o[D + j]; a.gp[d * D + j] = o[2 * D + j]; }
+            }
+            if (tid < nr) {
+                const long d = dest[r0 + tid];
+                if (d >= 0 && d != r0 + tid) {
+                    const float* o = stage + tid * RW;
+                    a.lq[d] = o[3 * D]; a.lp[d] = o[3 * D + 1]; a.log_w[d] = o[3 * D + 2];
+                    if (a.extra) a.extra[d] = o[3 * D + 3];
+                }
+            }
+            __syncthreads();
+        }
+    }
+    const float* lw = a.log_w;
+    if (a.diff) {
+        for (long i = tid; i < a.B; i += ESS_THREADS) a.diff[i] = a.lp[i] - a.lq[i];
+        lw = a.diff;
+    }
+    __syncthreads();
+    for (int vb = 0; vb < nb; ++vb) {
+        const Msum v = ess_partial_body(lw, n_out, vb, nb, sh);
+        if (tid == 0) part[vb] = v;
+        __syncthreads();
+    }
+    ess_final_body(part, nb, n_out, a.n_norm, a.stats_out, sh);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1208,6 +1308,15 @@ static int build_fixed_cdf(const float* log_w, long n, const ScanWs& ws, hipStre
     } else {
         hipLaunchKernelGGL(k_scan_fixed, grid, block, 0, st, log_w, n, ws.max_val, ws);
     }
+    return check_launch();
+}
+
+int tail_small(const TailArgs& a, int* dest, hipStream_t st) {
+    if (a.B > (long)TAIL_MAX_BLOCKS * ESS_THREADS * 4 || a.B < 1) return FABHIP_ENOTSUP;
+    const int nb = grid_for(a.B, ESS_THREADS * 4, ESS_MAX_BLOCKS);          // fabhip_ess_logz's grid for the same row capacity
+    const size_t bytes = (size_t)TAIL_CHUNK * (3 * a.D + 4) * 4;
+    if (bytes > 48 * 1024) return FABHIP_ENOTSUP;
+    hipLaunchKernelGGL(k_tail_small, dim3(1), dim3(ESS_THREADS), bytes, st, a, dest, nb);
     return check_launch();
 }
 

@@ -276,6 +276,32 @@ class RealNVP(nn.Module):
             tensors += [an.s.reshape(-1), an.t.reshape(-1)]
         return tensors
 
+    _LEAF_ATTRS = (("weight", "bias"), ("weight", "bias"), ("weight", "bias"), ("L", "U", "log_S", "sign_S", "P"))
+
+    def _param_list_fast(self):
+        """`_param_list()` for the per-call currency check of `native()`: the leaf MODULES are looked up once (the module tree
+        of a flow is fixed after construction; a replaced `_nf_model` rebuilds the cache), their tensors are read from the
+        modules' parameter / buffer dicts on every call (a re-assigned Parameter is seen).  ~10x cheaper than walking
+        `nn.Module.__getattr__` 200 times per AIS call while the GPU waits for the host."""
+        nf = self._nf_model
+        c = self.__dict__.get("_leaf_cache")
+        if c is None or c[0] is not nf or c[1] != (self.n_layers, self.act_norm):
+            c = (nf, (self.n_layers, self.act_norm), list(self._layers()), self._act_norms(), nf.q0)
+            self.__dict__["_leaf_cache"] = c
+        tensors = []
+        for mods in c[2]:
+            for m, names in zip(mods, self._LEAF_ATTRS):
+                pr, bf = m._parameters, m._buffers
+                for n in names:
+                    t = pr.get(n)
+                    tensors.append(t if t is not None else bf[n])
+        q0 = c[4]
+        tensors.append(q0._parameters["loc"] if "loc" in q0._parameters else q0.loc)
+        tensors.append(q0._parameters["log_scale"] if "log_scale" in q0._parameters else q0.log_scale)
+        for an in c[3]:
+            tensors += [an.s.reshape(-1), an.t.reshape(-1)]
+        return tensors
+
     def native(self, need_inverse: bool = True):
         """(packed image, dim, n_layers, width) - the flow arguments of the ops; the image is re-tiled by the pack
         kernels whenever a parameter changed.  need_inverse=False (density evaluations only, e.g. the minibatch loop of
@@ -284,8 +310,8 @@ class RealNVP(nn.Module):
         q0 = self._nf_model.q0
         _ops.require_device(q0.loc, "RealNVP parameters")
         self._ensure_act_norm()
-        tensors = self._param_list()
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        tensors = self._param_list_fast()
+        key = tuple(ops.tensors_key(tensors))                  # (storage address, version) of every tensor, mixed in C++
         if key != self._packed_key or (need_inverse and not self._packed_has_inverse):
             n = ops.flow_packed_floats(self.dim, self.n_layers, self.width)
             if n < 0:

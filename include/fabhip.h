@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 210
+#define FABHIP_ABI_VERSION 211
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -102,7 +102,12 @@ int fabhip_get_fast_mode(void);
                                             16 = the 16x16x4 kernel */
 #define FABHIP_OPT_SPLINE_LEAP 7         /* FABHIP_SPLINE_LEAP: fused spline transitions: 1 = one launch per leapfrog (half steps and
                                             the target inside the 4x4x1 spline density kernel, default), 0 = four launches */
-#define FABHIP_OPT_COUNT 8
+#define FABHIP_OPT_FUSED_TAIL 8          /* FABHIP_FUSED_TAIL: AIS calls of <= 8192 chains: 1 = the compaction + ESS / log Z after the chain
+                                            initialisation and after the last transition in ONE launch each (default), 0 = the six / five
+                                            separate kernels (the same results, bit for bit) */
+#define FABHIP_OPT_ADAPT_FOLD 9          /* FABHIP_ADAPT_FOLD: fused AIS calls on 4- / 8-chain tiles: 1 = the step-size rule runs in the LAST
+                                            workgroup of every transition kernel (ticket; default), 0 = its own launch per transition */
+#define FABHIP_OPT_COUNT 10
 int fabhip_set_option(int key, int value);
 int fabhip_get_option(int key);
 

@@ -202,3 +202,62 @@ def test_stream_and_staged_four_chain_kernels_are_bit_identical(monkeypatch, D, 
     _ops.load().set_option(_ops.OPT_R4_STREAM, 1)
     for a, b in zip(res[0], res[1]):
         assert torch.equal(a, b)
+
+
+def _poisoned_noise(B, D, M, dev, rows, seed):
+    """AIS noise of a run in which the chains `rows` die at "chain init" (NaN base noise: the compaction has rows to move) and two
+    proposals of the last transition are NaN (rejected: a chain cannot die inside a transition)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    eps0 = torch.randn(B, D, device=dev, generator=g)
+    noise_a = torch.randn(M, 1, B, D, device=dev, generator=g)
+    noise_b = torch.empty(M, 1, B, device=dev).exponential_(1.0, generator=g)
+    for r in rows:
+        eps0[r, 0] = float("nan")
+    for r in (5, B - 2):
+        noise_a[M - 1, 0, r, 1] = float("nan")
+    return eps0, noise_a, noise_b
+
+
+@pytest.mark.parametrize("B,rows", [(1024, ()), (1024, (0, 3, 517, 1023)), (2048, (7, 1000, 2047)), (300, (299,)), (37, (0, 1, 2))])
+def test_one_launch_tail_and_in_kernel_step_size_rule_are_bit_identical_to_the_separate_kernels(B, rows):
+    """fabhip_ais_run with FABHIP_OPT_FUSED_TAIL / FABHIP_OPT_ADAPT_FOLD on (default: compaction + log_p - log_q + ESS / log Z in
+    one launch per phase, k_tail_small; the step-size rule in the last workgroup of every transition kernel, hmc_adapt_last)
+    against both off (k_valid_scan / k_compact_* / k_sub / k_ess_* and k_hmc_adapt as launches of their own): every output of
+    the call, the counts, the statistics and every step size bit for bit - with chains dying at "chain init" (rows move in the
+    compaction), on 4-chain (B <= 1152) and 8-chain tiles."""
+    D, K, nodes, M = 32, 4, 320 // 32, 3
+    torch.manual_seed(11)
+    flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.05 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    eps0, noise_a, noise_b = _poisoned_noise(B, D, M, DEV, rows, seed=B)
+    outs = {}
+    ops = _ops.load()
+    try:
+        for mode in (1, 0):
+            ops.set_option(_ops.OPT_FUSED_TAIL, mode)
+            ops.set_option(_ops.OPT_ADAPT_FOLD, mode)
+            hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
+                                           n_outer=1, L=3).to(DEV)
+            ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target=False, alpha=2.0,
+                                               n_intermediate_distributions=M)
+            res = []
+            for _ in range(2):                                     # the second call starts from the first call's step sizes
+                pt, log_w, n_valid, stats, base_x, base_lw = ais.run(B, eps0, noise_a, noise_b, want_base=True)
+                n0, n1 = (int(v) for v in n_valid.cpu())
+                res += [pt.x[:n1].clone(), pt.log_q[:n1].clone(), pt.log_p[:n1].clone(), pt.grad_log_q[:n1].clone(),
+                        pt.grad_log_p[:n1].clone(), log_w[:n1].clone(), n_valid.clone(), stats[:6].clone(), base_x[:n0].clone(),
+                        base_lw[:n0].clone(), hmc.epsilons.clone(), hmc.common_epsilon.clone()]
+            outs[mode] = res
+    finally:
+        ops.set_option(_ops.OPT_FUSED_TAIL, 1)
+        ops.set_option(_ops.OPT_ADAPT_FOLD, 1)
+    n0, n1 = (int(v) for v in outs[1][6].cpu())
+    assert n0 == B - len(rows) and n1 == n0
+    for a, b in zip(outs[1], outs[0]):
+        assert a.shape == b.shape and torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
+                                                  b.view(torch.int32) if b.dtype == torch.float32 else b)
+    assert not torch.equal(outs[1][-2], torch.full_like(outs[1][-2], 0.05))        # the rule ran: the step sizes moved
