@@ -20,6 +20,7 @@
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
 
+#include <mutex>
 #include <vector>
 
 #include "../../include/fabhip.h"
@@ -157,6 +158,23 @@ std::vector<int64_t> tensors_key(at::TensorList ts) {
         h2 = mix(mix(h2, v ^ 0x5555555555555555ull, 0xD6E8FEB86659FD93ull), p, 0xFF51AFD7ED558CCDull);
     }
     return {(int64_t)h1, (int64_t)h2, (int64_t)ts.size()};
+}
+// The same for a parameter set registered once: the op layer keeps the tensor handles (the Python side keeps the objects alive
+// and re-registers when the set itself changes), so the per-call check passes ONE integer through the dispatcher instead of a
+// list of 112 tensors.  `param.data = ...`, `.to()`, load_state_dict and in-place updates all act on the registered TensorImpl.
+static std::mutex g_keysets_mu;
+static std::vector<std::vector<Tensor>> g_keysets;
+int64_t tensors_key_register(at::TensorList ts, int64_t reuse) {
+    std::lock_guard<std::mutex> lk(g_keysets_mu);
+    std::vector<Tensor> v(ts.begin(), ts.end());
+    if (reuse >= 0 && reuse < (int64_t)g_keysets.size()) { g_keysets[(size_t)reuse] = std::move(v); return reuse; }
+    g_keysets.push_back(std::move(v));
+    return (int64_t)g_keysets.size() - 1;
+}
+std::vector<int64_t> tensors_key_of(int64_t handle) {
+    std::lock_guard<std::mutex> lk(g_keysets_mu);
+    TORCH_CHECK(handle >= 0 && handle < (int64_t)g_keysets.size(), "fabhip: unknown parameter-set handle ", handle);
+    return tensors_key(g_keysets[(size_t)handle]);
 }
 int64_t flow_grad_floats(int64_t dim, int64_t n_layers, int64_t width) {
     return fabhip_flow_grad_floats((int32_t)dim, (int32_t)n_layers, (int32_t)width);
@@ -751,8 +769,18 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     a.mass = mass.has_value() ? fpn(*mass, dim, eps0, "mass") : nullptr;
     a.n_inner = (int32_t)n_inner; a.L = (int32_t)L; a.max_grad = (float)max_grad;
     a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
-    Tensor x = fempty({B, dim}, eps0), lq = fempty({B}, eps0), lp = fempty({B}, eps0), log_w = fempty({B}, eps0);
-    Tensor gq = hmc ? fempty({B, dim}, eps0) : fempty({0}, eps0), gp = hmc ? fempty({B, dim}, eps0) : fempty({0}, eps0);
+    // the outputs are views of ONE allocation (each padded to 256 bytes): one trip through the caching allocator instead of six
+    // on the host path the GPU waits for
+    auto pad64 = [](int64_t n) { return (n + 63) / 64 * 64; };
+    Tensor pool = fempty({(hmc ? 3 : 1) * pad64(B * dim) + 3 * pad64(B)}, eps0);
+    int64_t pool_off = 0;
+    auto take = [&](int64_t rows, int64_t cols) {
+        Tensor t = cols > 0 ? pool.narrow(0, pool_off, rows * cols).view({rows, cols}) : pool.narrow(0, pool_off, rows);
+        pool_off += pad64(rows * (cols > 0 ? cols : 1));
+        return t;
+    };
+    Tensor x = take(B, dim), lq = take(B, 0), lp = take(B, 0), log_w = take(B, 0);
+    Tensor gq = hmc ? take(B, dim) : fempty({0}, eps0), gp = hmc ? take(B, dim) : fempty({0}, eps0);
     Tensor counts_stats = at::zeros({18}, eps0.options());      // one zero fill, one device->host copy (_ops.read_counts_and_stats)
     Tensor stats = counts_stats.narrow(0, 0, 16), n_valid = counts_stats.narrow(0, 16, 2).view(at::kInt);
     Tensor base_x = want_base ? fempty({B, dim}, eps0) : fempty({0}, eps0);
@@ -961,6 +989,8 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("abi_version() -> int", abi_version);
     m.def("flow_packed_floats(int dim, int n_layers, int width) -> int", flow_packed_floats);
     m.def("tensors_key(Tensor[] ts) -> int[]", tensors_key);
+    m.def("tensors_key_register(Tensor[] ts, int reuse) -> int", tensors_key_register);
+    m.def("tensors_key_of(int handle) -> int[]", tensors_key_of);
     m.def("flow_grad_floats(int dim, int n_layers, int width) -> int", flow_grad_floats);
     m.def("flow_grad_layout(int dim, int n_layers, int width) -> int[]", flow_grad_layout);
     m.def("flow_tape_layout(int dim, int n_layers, int width, int B) -> int[]", flow_tape_layout);

@@ -278,7 +278,7 @@ class RealNVP(nn.Module):
 
     _LEAF_ATTRS = (("weight", "bias"), ("weight", "bias"), ("weight", "bias"), ("L", "U", "log_S", "sign_S", "P"))
 
-    def _param_list_fast(self):
+    def _param_list_fast(self, for_key: bool = False):
         """`_param_list()` for the per-call currency check of `native()`: the leaf MODULES are looked up once (the module tree
         of a flow is fixed after construction; a replaced `_nf_model` rebuilds the cache), their tensors are read from the
         modules' parameter / buffer dicts on every call (a re-assigned Parameter is seen).  ~10x cheaper than walking
@@ -299,8 +299,45 @@ class RealNVP(nn.Module):
         tensors.append(q0._parameters["loc"] if "loc" in q0._parameters else q0.loc)
         tensors.append(q0._parameters["log_scale"] if "log_scale" in q0._parameters else q0.log_scale)
         for an in c[3]:
-            tensors += [an.s.reshape(-1), an.t.reshape(-1)]
+            tensors += [an.s, an.t] if for_key else [an.s.reshape(-1), an.t.reshape(-1)]
         return tensors
+
+    def invalidate_native(self):
+        """Forget the registered parameter set (`_param_key`).  Needed only after ASSIGNING a new nn.Parameter object to a layer of
+        `_nf_model` (in-place updates, `.data = ...`, `.to()`, `load_state_dict` keep the objects and are seen by the key) - the
+        same contract torch.optim has with the parameters it was given."""
+        self.__dict__.pop("_pset", None)
+        self.__dict__.pop("_leaf_cache", None)
+        self._packed_key = None
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self.invalidate_native()                                # (conversions may replace parameter objects under a torch.__future__ flag)
+        return out
+
+    def _param_key(self, ops):
+        """Identity of the current parameter values: the tensors are registered with the op layer ONCE (112 dict look-ups and a
+        112-tensor list through the dispatcher cost 35 us per AIS call while the GPU has nothing to do); per call, three probe
+        objects are compared by identity and one integer goes through the dispatcher."""
+        nf = self._nf_model
+        c = self.__dict__.get("_pset")
+        if c is not None and c[0] is nf and c[1] == (self.n_layers, self.act_norm):
+            ok = True
+            for d, n, obj in c[3]:
+                if d.get(n) is not obj:
+                    ok = False
+                    break
+            if ok:
+                return tuple(ops.tensors_key_of(c[2]))
+        # (the Parameter / buffer OBJECTS themselves, not detached aliases: `param.data = ...` acts on the registered TensorImpl)
+        handle = ops.tensors_key_register(self._param_list_fast(for_key=True), c[2] if c is not None else -1)
+        lc = self.__dict__["_leaf_cache"]
+        first, last, q0 = lc[2][0], lc[2][-1], lc[4]
+        probes = [(first[0]._parameters, "weight", first[0]._parameters["weight"]),
+                  (last[3]._parameters, "L", last[3]._parameters["L"]),
+                  (q0._parameters, "loc", q0._parameters.get("loc"))]
+        self.__dict__["_pset"] = (nf, (self.n_layers, self.act_norm), handle, probes)
+        return tuple(ops.tensors_key_of(handle))
 
     def native(self, need_inverse: bool = True):
         """(packed image, dim, n_layers, width) - the flow arguments of the ops; the image is re-tiled by the pack
@@ -310,9 +347,9 @@ class RealNVP(nn.Module):
         q0 = self._nf_model.q0
         _ops.require_device(q0.loc, "RealNVP parameters")
         self._ensure_act_norm()
-        tensors = self._param_list_fast()
-        key = tuple(ops.tensors_key(tensors))                  # (storage address, version) of every tensor, mixed in C++
+        key = self._param_key(ops)                             # (storage address, version) of every tensor, mixed in C++
         if key != self._packed_key or (need_inverse and not self._packed_has_inverse):
+            tensors = self._param_list_fast()
             n = ops.flow_packed_floats(self.dim, self.n_layers, self.width)
             if n < 0:
                 raise _ops.FabhipError(f"flow shape not supported by the kernels: dim={self.dim} width={self.width}")

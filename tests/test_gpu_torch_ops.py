@@ -372,3 +372,53 @@ def test_option_table_is_read_without_the_environment():
     assert lib.fabhip_set_option(99, 1) < 0
     with pytest.raises(RuntimeError, match="unknown option"):
         ops.set_option(99, 1)
+
+
+def test_packed_image_follows_every_kind_of_parameter_update():
+    """flow.native() decides from (storage address, version) of the REGISTERED parameter objects whether the packed image is
+    current (one integer through the dispatcher per call).  Every way the values can change must be seen: in-place updates
+    (optimizer steps), load_state_dict, `param.data = ...`, .to() round trips, a re-assigned Parameter of a probed or
+    un-probed layer (the latter through invalidate_native(), the documented contract)."""
+    torch.manual_seed(3)
+    D, K = 6, 3
+    flow = fa.RealNVP(D, K, 8).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():                # (the builder zero-initialises the conditioners' last layers)
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.1 * torch.randn_like(p))
+    x = torch.randn(40, D, device=DEV)
+
+    def lq():
+        return flow.log_prob(x).clone()
+
+    def fresh():                                   # the same parameters through a flow that never cached anything
+        f2 = fa.RealNVP(D, K, 8).to(DEV).requires_grad_(False)
+        f2._nf_model.load_state_dict(flow._nf_model.state_dict())
+        return f2.log_prob(x).clone()
+
+    base = lq()
+    assert torch.equal(base, fresh())
+    mid = list(flow._layers())[1]                  # a layer none of the probes looks at
+    with torch.no_grad():
+        mid[1].weight.add_(0.1)                    # in place
+    a = lq()
+    assert not torch.equal(a, base) and torch.equal(a, fresh())
+    mid[1].weight.data = mid[1].weight.data * 0.5  # .data assignment: new storage, same Parameter object
+    b = lq()
+    assert not torch.equal(b, a) and torch.equal(b, fresh())
+    sd = {k: v.clone() * 1.01 for k, v in flow._nf_model.state_dict().items()}
+    flow._nf_model.load_state_dict(sd)
+    c = lq()
+    assert not torch.equal(c, b) and torch.equal(c, fresh())
+    flow.cpu()
+    flow.to(DEV)                                    # .to(): _apply invalidates the registration
+    assert torch.equal(lq(), c)
+    first = list(flow._layers())[0]
+    first[0].weight = torch.nn.Parameter(first[0].weight.detach() * 0.9, requires_grad=False)   # probed object replaced
+    d = lq()
+    assert not torch.equal(d, c) and torch.equal(d, fresh())
+    mid = list(flow._layers())[1]
+    mid[2].bias = torch.nn.Parameter(mid[2].bias.detach() + 0.2, requires_grad=False)           # un-probed object replaced
+    flow.invalidate_native()
+    e = lq()
+    assert not torch.equal(e, d) and torch.equal(e, fresh())
