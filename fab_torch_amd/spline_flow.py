@@ -360,16 +360,55 @@ class CircularCoupledRQSFlow(nn.Module):
         q0 = self._nf_model.q0
         return tensors + [q0.scale, q0.circ.float()]
 
+    def invalidate_native(self):
+        """Forget the registered parameter / buffer sets (`_param_keys`): needed only after ASSIGNING a new Parameter / buffer
+        object to a sub-module (in-place updates, `.data = ...`, `.to()`, `load_state_dict` keep the objects and are seen)."""
+        self.__dict__.pop("_pset", None)
+        self._packed_key = None
+
+    def _apply(self, fn, recurse=True):
+        out = super()._apply(fn, recurse)
+        self.invalidate_native()
+        return out
+
+    def _param_keys(self, ops):
+        """((storage address, version) mix of the parameters, the same of the buffers): the tensor objects are registered with
+        the op layer once (fabhip::tensors_key_register), three of each are compared by identity per call, two integers go
+        through the dispatcher - instead of walking `parameters()` / `buffers()` (hundreds of attribute reads per AIS call)."""
+        c = self.__dict__.get("_pset")
+        if c is not None:
+            for d, n, obj in c[2]:
+                if d.get(n) is not obj:
+                    c = None
+                    break
+        if c is None:
+            plist, blist, seen = [], [], set()
+            for m in self.modules():
+                for n, t in m._parameters.items():
+                    if t is not None and id(t) not in seen:
+                        seen.add(id(t)); plist.append((m._parameters, n, t))
+                for n, t in m._buffers.items():
+                    if t is not None and id(t) not in seen:
+                        seen.add(id(t)); blist.append((m._buffers, n, t))
+            old = self.__dict__.get("_pset_handles", (-1, -1))
+            hp = ops.tensors_key_register([e[2] for e in plist], old[0])
+            hb = ops.tensors_key_register([e[2] for e in blist], old[1])
+            self.__dict__["_pset_handles"] = (hp, hb)
+            probes = [lst[i] for lst in (plist, blist) if lst for i in sorted({0, len(lst) // 2, len(lst) - 1})]
+            c = (hp, hb, probes)
+            self.__dict__["_pset"] = c
+        return tuple(ops.tensors_key_of(c[0])), tuple(ops.tensors_key_of(c[1]))
+
     def native(self):
         """(packed image, dim, n_layers, hidden): the flow arguments of torch.ops.fabhip.spline_*; re-packed whenever a
         parameter changed."""
         ops = _ops.load()
         _ops.require_device(self._tail_bound, "spline flow parameters")
-        bkey = tuple((b.data_ptr(), b._version) for b in self.buffers())
+        pkey, bkey = self._param_keys(ops)
         if bkey != self.__dict__.get("_bkey"):                 # masks / shifts / bounds changed (e.g. load_state_dict)
             self.__dict__["_meta_cache"] = {}
             self.__dict__["_bkey"] = bkey
-        key = tuple((t.data_ptr(), t._version) for t in self.parameters()) + bkey
+        key = pkey + bkey
         if key != self._packed_key:
             n = ops.spline_packed_floats(self.dim, self.n_layers, self.hidden)
             if n < 0:
