@@ -128,13 +128,17 @@ class AnnealedImportanceSampler:
         f32 = dict(dtype=torch.float32, device=dev)
         if eps0 is None:
             eps0 = torch.randn((B, D), **f32)
-        if noise_a is None:
-            noise_a = torch.randn((M, n_inner, B, D), **f32)
-        if noise_b is None:
-            noise_b = (torch.empty((M, n_inner, B), **f32).exponential_(1.0) if hmc
-                       else torch.rand((M, n_inner, B), **f32))
-        eps0, noise_a, noise_b = eps0.contiguous(), noise_a.contiguous(), noise_b.contiguous()
-        assert noise_a.shape == (M, n_inner, B, D) and noise_b.shape == (M, n_inner, B)
+        eps0 = eps0.contiguous()
+        if noise_a is None and noise_b is None:
+            pass        # drawn inside the op, in this order, AFTER the chain initialisation is enqueued (the device works meanwhile)
+        else:
+            if noise_a is None:
+                noise_a = torch.randn((M, n_inner, B, D), **f32)
+            if noise_b is None:
+                noise_b = (torch.empty((M, n_inner, B), **f32).exponential_(1.0) if hmc
+                           else torch.rand((M, n_inner, B), **f32))
+            noise_a, noise_b = noise_a.contiguous(), noise_b.contiguous()
+            assert noise_a.shape == (M, n_inner, B, D) and noise_b.shape == (M, n_inner, B)
         betas = self._betas()
         alpha = float(self.alpha) if self.alpha is not None else 0.0
         if hmc:

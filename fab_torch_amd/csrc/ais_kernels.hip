@@ -1526,10 +1526,12 @@ int fabhip_ais_run(const fabhip_ais_args* a, fabhip_stream_t stream) {
 
 int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, int32_t j_end, float* partials,
                      fabhip_stream_t stream) {
-    if (!a || !a->flow.packed || !a->betas || !a->noise_a || !a->noise_b || !a->step_state || !a->log_w ||
+    if (!a || !a->flow.packed || !a->betas || !a->step_state || !a->log_w ||
         !a->n_valid || !a->stats || !a->workspace || a->B < 1 || a->M < 1 || a->n_inner < 1)
         return FABHIP_EINVAL;
+    if (j_begin <= j_end && (!a->noise_a || !a->noise_b)) return FABHIP_EINVAL;       // (read by the transitions only)
     const bool do_init = (phases & FABHIP_AIS_INIT) != 0, do_finish = (phases & FABHIP_AIS_FINISH) != 0;
+    const bool ws_kept = do_init || (phases & FABHIP_AIS_CONTINUE) != 0;              // the ticket word of this workspace is zero
     if (do_init && !a->eps0) return FABHIP_EINVAL;
     if (j_begin <= j_end && (j_begin < 1 || j_end > a->M)) return FABHIP_EINVAL;
     if (partials && (j_begin != j_end || a->transition != FABHIP_TRANSITION_HMC)) return FABHIP_ENOTSUP;
@@ -1557,8 +1559,9 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     float* lwb = (float*)ws; ws += align256((size_t)B * 4);
     void* ess_ws = ws; ws += align256(fabhip_ess_workspace_bytes(B));
     const size_t ess_bytes = fabhip_ess_workspace_bytes(B);
-    // step-size rule inside the transition kernels (hmc_adapt_last): only where this call zeroes the ticket itself (the init phase)
-    int* ticket = (do_init && hmc && !partials && option(FABHIP_OPT_ADAPT_FOLD) != 0 && nblk_of(B) <= 2048 &&
+    // step-size rule inside the transition kernels (hmc_adapt_last): only where the ticket word is known to be zero (this call's or,
+    // with FABHIP_AIS_CONTINUE, an earlier call's init phase zeroed it; every transition kernel leaves it zero)
+    int* ticket = (ws_kept && hmc && !partials && option(FABHIP_OPT_ADAPT_FOLD) != 0 && nblk_of(B) <= 2048 &&
                    (use_r8_tiles(f, B) || use_r4_tiles(f, B))) ? (int*)ws : nullptr;      // (2 nblk floats of LDS scratch)
 
     if (do_init) {

@@ -740,18 +740,26 @@ void metropolis_generic_accept(const Tensor& x_new, const Tensor& new_lq, const 
 std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor> ais_run(
     const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind, at::ArrayRef<double> prm,
     const optional<Tensor>& locs, const optional<Tensor>& scales, at::ArrayRef<double> betas, double alpha,
-    bool p_target, int64_t transition, const Tensor& eps0, const Tensor& noise_a, const Tensor& noise_b,
-    Tensor step_state, optional<Tensor> common_epsilon, const optional<Tensor>& mass, int64_t n_inner, int64_t L,
-    double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept_first, optional<Tensor> p_accept_last,
-    optional<Tensor> avg_distance_first, optional<Tensor> avg_distance_last, bool want_base, int64_t precision) {
+    bool p_target, int64_t transition, const Tensor& eps0, const optional<Tensor>& noise_a_in,
+    const optional<Tensor>& noise_b_in, Tensor step_state, optional<Tensor> common_epsilon, const optional<Tensor>& mass,
+    int64_t n_inner, int64_t L, double max_grad, double target_p_accept, bool tune, optional<Tensor> p_accept_first,
+    optional<Tensor> p_accept_last, optional<Tensor> avg_distance_first, optional<Tensor> avg_distance_last, bool want_base,
+    int64_t precision) {
     c10::DeviceGuard g(eps0.device());
+    // noise_a / noise_b absent: drawn HERE, from the default generator in the order the Python side draws them (normal
+    // [M, n_inner, B, dim], then exponential(1) / uniform [M, n_inner, B]) - but AFTER the chain initialisation is enqueued, so the
+    // device works while the host launches the draws (FABHIP_AIS_CONTINUE)
+    const bool draw_inside = !noise_a_in.has_value() || !noise_b_in.has_value();
+    TORCH_CHECK(noise_a_in.has_value() == noise_b_in.has_value(), "fabhip: pass both noise tensors or neither");
+    Tensor noise_a = draw_inside ? Tensor() : *noise_a_in, noise_b = draw_inside ? Tensor() : *noise_b_in;
     fabhip_ais_args a;
     a.flow = make_flow(packed, dim, n_layers, width, precision);
     a.target = make_target(kind, prm, locs, scales, dim);
     TORCH_CHECK(eps0.dim() == 2 && eps0.size(1) == dim, "fabhip: eps0 must be [B, dim]");
     const int64_t B = eps0.size(0), M = (int64_t)betas.size() - 2;
     TORCH_CHECK(M >= 1, "fabhip: betas must hold M + 2 values");
-    TORCH_CHECK(noise_a.numel() == M * n_inner * B * dim && noise_b.numel() == M * n_inner * B, "fabhip: AIS noise shapes");
+    TORCH_CHECK(draw_inside || (noise_a.numel() == M * n_inner * B * dim && noise_b.numel() == M * n_inner * B),
+                "fabhip: AIS noise shapes");
     TORCH_CHECK(step_state.numel() == M * n_inner, "fabhip: step-size state must be [M, n_inner]");
     const bool hmc = transition == FABHIP_TRANSITION_HMC;
     a.B = B; a.M = (int32_t)M;
@@ -763,7 +771,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     TORCH_CHECK(!hmc || (common_epsilon.has_value() && mass.has_value()),
                 "fabhip: an HMC AIS run needs common_epsilon and the mass vector");
     a.eps0 = fp(eps0, "eps0");
-    a.noise_a = fpn(noise_a, M * n_inner * B * dim, eps0, "noise_a"); a.noise_b = fpn(noise_b, M * n_inner * B, eps0, "noise_b");
+    a.noise_a = a.noise_b = nullptr;
+    if (!draw_inside) {
+        a.noise_a = fpn(noise_a, M * n_inner * B * dim, eps0, "noise_a"); a.noise_b = fpn(noise_b, M * n_inner * B, eps0, "noise_b");
+    }
     a.step_state = fpmn(step_state, M * n_inner, eps0, "step_state");
     a.common_epsilon = fpmn_opt(common_epsilon, 1, eps0, "common_epsilon", true);
     a.mass = mass.has_value() ? fpn(*mass, dim, eps0, "mass") : nullptr;
@@ -797,7 +808,16 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     const size_t nb = fabhip_ais_workspace_bytes(B, (int32_t)dim, (int32_t)n_inner);
     Tensor ws = scratch(nb, eps0);
     a.workspace = aligned(ws); a.workspace_bytes = nb;
-    chk(fabhip_ais_run(&a, stream_of(eps0)), "ais_run");
+    if (!draw_inside) {
+        chk(fabhip_ais_run(&a, stream_of(eps0)), "ais_run");
+    } else {
+        chk(fabhip_ais_phase(&a, FABHIP_AIS_INIT, 1, 0, nullptr, stream_of(eps0)), "ais_run (chain initialisation)");
+        noise_a = at::randn({M, n_inner, B, dim}, eps0.options());
+        noise_b = hmc ? at::empty({M, n_inner, B}, eps0.options()).exponential_(1.0) : at::rand({M, n_inner, B}, eps0.options());
+        a.noise_a = noise_a.data_ptr<float>(); a.noise_b = noise_b.data_ptr<float>();
+        chk(fabhip_ais_phase(&a, FABHIP_AIS_CONTINUE | FABHIP_AIS_FINISH, 1, (int32_t)M, nullptr, stream_of(eps0)),
+            "ais_run (transitions)");
+    }
     return {x, lq, lp, gq, gp, log_w, n_valid, stats, base_x, base_lw};
 }
 
@@ -1031,7 +1051,7 @@ TORCH_LIBRARY(fabhip, m) {
           "float beta, float beta_next, float alpha, bool p_target, Tensor noise_x, Tensor noise_u, "
           "Tensor(e!) noise_scalings_row, float target_p_accept, bool tune) -> ()");
     m.def("ais_run(" FLW ", " TGT ", float[] betas, float alpha, bool p_target, int transition, Tensor eps0, "
-          "Tensor noise_a, Tensor noise_b, Tensor(a!) step_state, Tensor(b!)? common_epsilon, Tensor? mass, int n_inner, "
+          "Tensor? noise_a, Tensor? noise_b, Tensor(a!) step_state, Tensor(b!)? common_epsilon, Tensor? mass, int n_inner, "
           "int L, float max_grad, float target_p_accept, bool tune, Tensor(c!)? p_accept_first, Tensor(d!)? p_accept_last, "
           "Tensor(e!)? avg_distance_first, Tensor(f!)? avg_distance_last, bool want_base, int precision=0) -> "
           "(Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor)");

@@ -491,7 +491,12 @@ int fabhip_ais_run(const fabhip_ais_args* args, fabhip_stream_t stream);
  * in/out across the calls of one AIS run, eps0 is read by INIT only.  With `partials` != NULL (HMC, n_inner == 1,
  * j_begin == j_end) the transition leaves the step sizes alone and publishes its acceptance slab instead
  * (fabhip_hmc_args.partials); fabhip_ais_run(args) == fabhip_ais_phase(args, INIT | FINISH, 1, M, NULL). */
-enum { FABHIP_AIS_INIT = 1, FABHIP_AIS_FINISH = 2 };
+enum { FABHIP_AIS_INIT = 1, FABHIP_AIS_FINISH = 2,
+       FABHIP_AIS_CONTINUE = 4 };   /* this call continues a run whose INIT phase was enqueued with the SAME workspace on the same
+                                      * stream and nothing else touched the workspace since (lets the later phases keep using the
+                                      * state INIT left there: the ticket of the in-kernel step-size rule).  noise_a / noise_b are
+                                      * read by the transitions only: a call without transitions may pass NULL (a host can draw the
+                                      * transition noise while the device runs the chain initialisation). */
 int fabhip_ais_phase(const fabhip_ais_args* args, int32_t phases, int32_t j_begin, int32_t j_end, float* partials,
                      fabhip_stream_t stream);
 

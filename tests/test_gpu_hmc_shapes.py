@@ -261,3 +261,42 @@ def test_one_launch_tail_and_in_kernel_step_size_rule_are_bit_identical_to_the_s
         assert a.shape == b.shape and torch.equal(a.view(torch.int32) if a.dtype == torch.float32 else a,
                                                   b.view(torch.int32) if b.dtype == torch.float32 else b)
     assert not torch.equal(outs[1][-2], torch.full_like(outs[1][-2], 0.05))        # the rule ran: the step sizes moved
+
+
+@pytest.mark.parametrize("B,metropolis", [(1024, False), (2048, False), (4096, False), (300, True)])
+def test_noise_drawn_inside_the_op_equals_noise_drawn_by_the_caller(B, metropolis):
+    """`AnnealedImportanceSampler.run` without noise tensors lets the op draw the transition noise itself - after the chain
+    initialisation is enqueued (FABHIP_AIS_INIT, then FABHIP_AIS_CONTINUE | FABHIP_AIS_FINISH), from the default generator in
+    the order the Python side would have used.  Same seed: the call equals the one-piece call on caller-drawn noise bit for
+    bit (4-, 8- and 16-chain tiles, HMC with the in-kernel step-size rule and Metropolis)."""
+    D, K, M = 32, 3, 3
+    torch.manual_seed(21)
+    flow = fa.RealNVP(D, K, 10).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.05 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    outs = []
+    for inside in (True, False):
+        if metropolis:
+            op = fa.Metropolis(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, n_updates=2).to(DEV)
+            n_inner = 2
+        else:
+            op = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
+                                          n_outer=1, L=2).to(DEV)
+            n_inner = 1
+        ais = fa.AnnealedImportanceSampler(flow, target.log_prob, op, p_target=False, alpha=2.0, n_intermediate_distributions=M)
+        torch.manual_seed(1000 + B)
+        if inside:
+            res = ais.run(B)
+        else:
+            eps0 = torch.randn(B, D, device=DEV)
+            na = torch.randn(M, n_inner, B, D, device=DEV)
+            nb = torch.rand(M, n_inner, B, device=DEV) if metropolis else torch.empty(M, n_inner, B, device=DEV).exponential_(1.0)
+            res = ais.run(B, eps0, na, nb)
+        pt, log_w, n_valid, stats = res[0], res[1], res[2], res[3]
+        state = op.noise_scalings.clone() if metropolis else torch.cat([op.epsilons.flatten(), op.common_epsilon.flatten()])
+        outs.append((pt.x.clone(), pt.log_q.clone(), pt.log_p.clone(), log_w.clone(), n_valid.clone(), stats[:6].clone(), state))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
