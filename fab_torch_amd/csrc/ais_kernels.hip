@@ -523,9 +523,9 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
 template <int NTWM, bool STREAM>
 __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
                                                           const float* __restrict__ packed, TargetDev tg,
-                                                          const float* __restrict__ lq0, PointDev pt,
-                                                          float* __restrict__ log_w, float* __restrict__ base_log_w,
-                                                          fabhip_anneal an, long B) {
+                                                          const float* __restrict__ lq0, const float* __restrict__ eps0,
+                                                          PointDev pt, float* __restrict__ log_w,
+                                                          float* __restrict__ base_log_w, fabhip_anneal an, long B) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid4 t4;
     Tid t;
@@ -535,10 +535,33 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd,
     const long g = row0 + t.row;
     float* XP = lds + x.o_XP;
     float* GP = lds + x.o_GP;
+    float q0s = 0.f;                                   // log q of the sampling pass (eps0 given: the flow SAMPLE runs here as well)
+    bool sampled = false;
+    if constexpr (STREAM) {
+        if (eps0) {                                    // x, log q0 = flow.sample(eps0) on this tile (k_flow_sample_r4's work)
+            for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) {
+                const int r = e / R4_DS, j = e % R4_DS;
+                lds[l.o_X0 + e] = (j < D && row0 + r < B) ? eps0[(row0 + r) * D + j] : 0.f;
+            }
+            __syncthreads();
+            int xoff = 0;
+            q0s = flow_sample_r4s<NTWM>(f, rd, l, packed, lds, t4, &xoff);
+            for (int e = t.tid; e < R4 * D; e += NTHREADS) {
+                const int r = e / D, j = e % D;
+                const float v = lds[xoff + r * R4_DS + j];
+                XP[r * D + j] = v;
+                if (row0 + r < B) pt.x[(row0 + r) * D + j] = v;
+            }
+            __syncthreads();
+            sampled = true;
+        }
+    }
     for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
     for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) {
         const int r = e / R4_DS, j = e % R4_DS;
-        const float v = (j < D && row0 + r < B) ? pt.x[(row0 + r) * D + j] : 0.f;
+        float v;
+        if (sampled) v = (j < D && row0 + r < B) ? XP[r * D + j] : 0.f;
+        else v = (j < D && row0 + r < B) ? pt.x[(row0 + r) * D + j] : 0.f;
         lds[l.o_X0 + e] = v;
         if (j < D) XP[r * D + j] = v;
     }
@@ -555,7 +578,7 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd,
             pt.gp[g * D + j] = GP[t.row * D + j];
         }
         if (t.c == 0) {
-            const float q0 = lq0[g];
+            const float q0 = sampled ? q0s : lq0[g];
             pt.lq[g] = lq;
             pt.lp[g] = lp;
             log_w[g] = (an.c_q * lq + an.c_p * lp) - q0;
@@ -1066,13 +1089,7 @@ static int launch_hmc_step(const FlowDims& f, const float* packed, const TargetD
 // mode (no bf16 variant of the 4-chain kernel).  FABHIP_OPT_TILE_SHAPE = 16 / 4 forces the choice (tests exercise both).
 // Shapes: D <= 32 and hidden width <= 320 only - the D > 32 and the 512-wide instantiations of the 4-chain kernel spill
 // registers (hipcc: 52 .. 772 VGPRs), so they are neither compiled nor selectable (16-chain tiles there).
-static bool use_r4_tiles(const FlowDims& f, long B) {
-    if (f.fast || f.D > 32 || f.NTW / 4 > 5) return false;
-    const int shape = option(FABHIP_OPT_TILE_SHAPE);
-    if (shape == 16 || shape == 8) return false;
-    if (shape == 4) return true;
-    return B <= 1152;
-}
+// (use_r4_tiles: launch.h - the flow sample follows the same choice)
 // 8-chain tiles (flow_r8.h: D <= 32, hidden width padded to 256 / 320, fp32): half the weight bytes per chain of the 4-chain
 // kernel on one stream per wave.  FABHIP_OPT_TILE_SHAPE = 8 forces them; by default they take the batches for which
 // R8_MIN_CHAINS < B <= 8 chains per CU (measured: DESIGN.md section 4).
@@ -1116,7 +1133,7 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
 }
 
 template <int NTWM>
-static int launch_ais_init_r4(const FlowDims& f, const float* packed, const TargetDev& tg, const float* lq0,
+static int launch_ais_init_r4(const FlowDims& f, const float* packed, const TargetDev& tg, const float* lq0, const float* eps0,
                               const PointDev& pt, float* log_w, float* base_log_w, fabhip_anneal an, long B, hipStream_t st) {
     const R4Dims rd = make_r4_dims(f);
     const R4Lds l = make_r4_lds(f);
@@ -1128,12 +1145,13 @@ static int launch_ais_init_r4(const FlowDims& f, const float* packed, const Targ
     } else if (NTWM >= 2 && f.o_r4s >= 0) {
         constexpr int NS = NTWM >= 2 ? NTWM : 2;
         FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NS, true>, bytes));
-        hipLaunchKernelGGL((k_ais_init_r4<NS, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, pt, log_w,
-                           base_log_w, an, B);
+        hipLaunchKernelGGL((k_ais_init_r4<NS, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, eps0, pt,
+                           log_w, base_log_w, an, B);
     } else if constexpr (NTWM < 5) {
         FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NTWM, false>, bytes));
-        hipLaunchKernelGGL((k_ais_init_r4<NTWM, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, pt,
-                           log_w, base_log_w, an, B);
+        if (eps0) return FABHIP_ENOTSUP;                    // (the sampling direction exists on the stream image only)
+        hipLaunchKernelGGL((k_ais_init_r4<NTWM, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0,
+                           (const float*)nullptr, pt, log_w, base_log_w, an, B);
     } else {
         return FABHIP_ENOTSUP;
     }
@@ -1574,9 +1592,16 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
             FAB_TRY(fabhip_flow_sample(&a->flow, a->eps0, a->point.x, lwb, B, stream));
             FAB_TRY(launch_ais_init_r8(f, a->flow.packed, tg, lwb, pt, a->log_w, a->base_log_w, a1, B, st));
         } else if (hmc && use_r4_tiles(f, B) && option(FABHIP_OPT_R4_STREAM) != 0) {
-            // 4-chain tiles: flow sample (16-chain kernel) -> x, log q0 ; then log q + d/dx, target, log w on 4-chain tiles
-            FAB_TRY(fabhip_flow_sample(&a->flow, a->eps0, a->point.x, lwb, B, stream));
-            FAB_DISPATCH_NTW_NORET(f, launch_ais_init_r4, f, a->flow.packed, tg, lwb, pt, a->log_w, a->base_log_w, a1, B, st);
+            // 4-chain tiles: x, log q0 = flow.sample(eps0), then log q + d/dx (the reference re-evaluates: base.py:65-68), target,
+            // log w - one kernel where the stream image exists (f.o_r4s), else the flow-sample kernel first
+            if (f.o_r4s >= 0 && f.NTW / 4 >= 2) {
+                FAB_DISPATCH_NTW_NORET(f, launch_ais_init_r4, f, a->flow.packed, tg, (const float*)nullptr, a->eps0, pt, a->log_w,
+                                       a->base_log_w, a1, B, st);
+            } else {
+                FAB_TRY(fabhip_flow_sample(&a->flow, a->eps0, a->point.x, lwb, B, stream));
+                FAB_DISPATCH_NTW_NORET(f, launch_ais_init_r4, f, a->flow.packed, tg, lwb, (const float*)nullptr, pt, a->log_w,
+                                       a->base_log_w, a1, B, st);
+            }
         } else {
             FAB_DISPATCH_NTW_NORET(f, launch_ais_init, f, a->flow.packed, tg, a->eps0, pt, a->log_w, a->base_log_w, a1,
                                    hmc ? 1 : 0, B, st);

@@ -87,12 +87,13 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     // W3T [pad16(2 DOp) x Wp]
     f.total = f.o_r4 + K * (2 * pad16(D) * 64 + pad16(f.d) * f.Wp + 2 * f.Wp * f.Wp + f.Wp * 2 * f.DOp + f.Wp * pad16(f.d) +
                             pad16(2 * f.DOp) * f.Wp);
-    // stream image: (4 NTW + 4) items per layer and direction, each 4 waves x NTW tiles of 1 KiB, + 8 items of padding
+    // stream image: (4 NTW + 4) items per layer and section (density forward, density reverse, sampling), each 4 waves x NTW
+    // tiles of 1 KiB; 8 items of padding behind the reverse and behind the sampling section
     f.o_r4s = -1;
     if (D <= 32 && f.Wp >= 128) {
         const int ntw = f.Wp / 64;
         f.o_r4s = f.total;
-        f.total += (2 * K * (4 * ntw + 4) + 8) * 4 * ntw * 256;
+        f.total += (3 * K * (4 * ntw + 4) + 16) * 4 * ntw * 256;
     }
     // 8-chain-tile image: per layer 4 waves x (forward + reverse = 160 / 238 tiles of 1 KiB for G = Wp / 64 = 4 / 5; flow_r8.h,
     // r4: the narrow matrices as dense tiles)

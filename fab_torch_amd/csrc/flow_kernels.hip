@@ -312,6 +312,30 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_sample(FlowDims f, FlowLds l,
     }
 }
 
+// the same on 4-chain tiles (flow_r4.h: flow_sample_r4s) - 256 workgroups for 1024 chains instead of 64
+template <int NTWM>
+__global__ __launch_bounds__(NTHREADS) void k_flow_sample_r4(FlowDims f, R4Dims rd, R4Lds l, const float* __restrict__ packed,
+                                                             const float* __restrict__ eps, float* __restrict__ x,
+                                                             float* __restrict__ log_q, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    Tid4 t4;
+    const long row0 = (long)blockIdx.x * R4;
+    for (int e = t4.tid; e < R4 * R4_DS; e += NTHREADS) {
+        const int r = e / R4_DS, j = e % R4_DS;
+        const long g = row0 + r;
+        lds[l.o_X0 + e] = (j < f.D && g < B) ? eps[g * f.D + j] : 0.f;
+    }
+    __syncthreads();
+    int xoff = 0;
+    const float lq = flow_sample_r4s<NTWM>(f, rd, l, packed, lds, t4, &xoff);
+    if (t4.tid < 64 && (t4.tid & 15) == 0 && row0 + (t4.tid >> 4) < B) log_q[row0 + (t4.tid >> 4)] = lq;
+    for (int e = t4.tid; e < R4 * f.D; e += NTHREADS) {
+        const int r = e / f.D, j = e % f.D;
+        const long g = row0 + r;
+        if (g < B) x[g * f.D + j] = lds[xoff + r * R4_DS + j];
+    }
+}
+
 template <int NTWM>
 static int launch_log_prob(const FlowDims& f, const float* packed, const float* x, float* log_q, float* grad,
                            long B, hipStream_t st) {
@@ -440,7 +464,8 @@ __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0,
 __global__ __launch_bounds__(256) void k_pack_r4s(FlowDims f, R4Dims rd, float* __restrict__ packed) {
     const int G = rd.G, C = 4 * G + 4, K = f.K;
     const int nqD = rd.KD / 16;
-    const long total4 = (long)(2 * K * C + 8) * 4 * G * 64;                  // float4 elements incl. the padding items
+    const long total4 = (long)(3 * K * C + 16) * 4 * G * 64;                 // float4 elements incl. the padding items
+    const int D = f.D;
     const float4* r4 = reinterpret_cast<const float4*>(packed + f.o_r4);
     float4* dst = reinterpret_cast<float4*>(packed + f.o_r4s);
     const long LS4 = rd.layer_stride / 4;
@@ -471,6 +496,21 @@ __global__ __launch_bounds__(256) void k_pack_r4s(FlowDims f, R4Dims rd, float* 
                 else { if (g < nqD) src = rd.o_AWT / 4 + (long)(nqD * w + g) * 64 + lane; }
             }
             if (src >= 0) v = L[src];
+        } else if (item >= 2L * K * C + 8 && item < 3L * K * C + 8) {       // sampling section (flow_sample_r4s): layers 0 .. K-1
+            const long li = item - (2L * K * C + 8);
+            const int layer = (int)(li / C), i = (int)(li % C);
+            const float4* L = r4 + (long)layer * LS4;
+            if (i == 0) v = L[rd.o_W1 / 4 + ((long)(1 * w) * G + g) * 64 + lane];
+            else if (i < 1 + 4 * G) v = L[rd.o_W2 / 4 + ((long)(4 * G * w + (i - 1)) * G + g) * 64 + lane];
+            else if (i < 3 + 4 * G) { const int fi = (i - 1 - 4 * G) * G + g, Q = fi / 2, ct = fi % 2;
+                                      v = L[rd.o_W3 / 4 + ((long)(G * w + Q) * 2 + ct) * 64 + lane]; }
+            else if (g < nqD) {                                               // W'^-1: tile q = nqD w + g, lane = column
+                const float* Winv = packed + f.o_scratch + (size_t)layer * 2 * D * D + (size_t)D * D;
+                const int k0 = 4 * (nqD * w + g);
+                float t4[4];
+                for (int kk = 0; kk < 4; ++kk) t4[kk] = (k0 + kk < D && lane < D) ? Winv[(k0 + kk) * D + lane] : 0.f;
+                v = make_float4(t4[0], t4[1], t4[2], t4[3]);
+            }
         }
         dst[e] = v;
     }
@@ -479,6 +519,18 @@ __global__ __launch_bounds__(256) void k_pack_r4s(FlowDims f, R4Dims rd, float* 
 template <int NTWM>
 static int launch_sample(const FlowDims& f, const float* packed, const float* eps, float* x, float* log_q, long B,
                          hipStream_t st) {
+    if constexpr (NTWM >= 2 && NTWM <= 5) {
+        // batches the transitions run on 4-chain tiles (<= 1152 chains): the sample on 4-chain tiles as well
+        if (use_r4_tiles(f, B) && f.o_r4s >= 0 && option(FABHIP_OPT_R4_STREAM) != 0) {
+            const R4Dims rd = make_r4_dims(f);
+            const R4Lds l4 = make_r4_lds(f);
+            const size_t bytes4 = (size_t)l4.total * 4;
+            FAB_TRY(set_max_lds((const void*)k_flow_sample_r4<NTWM>, bytes4));
+            hipLaunchKernelGGL((k_flow_sample_r4<NTWM>), dim3((unsigned)((B + R4 - 1) / R4)), dim3(NTHREADS), bytes4, st, f, rd, l4,
+                               packed, eps, x, log_q, B);
+            return check_launch();
+        }
+    }
     const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
     const FlowLds l = make_flow_lds(f, false);
     const size_t bytes = (size_t)l.total * 4;

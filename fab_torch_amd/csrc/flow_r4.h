@@ -749,4 +749,116 @@ __device__ float flow_log_prob_r4s(const FlowDims& f, const R4Dims& rd, const R4
     return logq;
 }
 
+// ================================================================================================
+// x, log q = flow.sample(eps) for the 4 rows whose base noise is in X0 (columns >= D zero): the SAMPLING direction on the same
+// 4-chain tiles and stage code (r4: the flow sample of a <= 1152-chain AIS call ran on 64 workgroups of 16 chains for 110 us).
+// Stream section 3 of the r4s image (k_pack_r4s: after the forward and reverse sections and their 8 padding items), layers
+// 0 .. K-1, C items per layer in consumption order: W1 | 4 NTWM quads of W2 | 2 of W3 | W'^-1 (the forward D x D map).
+// Arithmetic of flow_sample_tile (flow_device.h) stage by stage; the sums inside the products are the 4-chain tiles' (4 waves
+// K-split, ((P0 + P1) + (P2 + P3)) + bias), so x agrees with the 16-chain kernel to fp32 rounding, not bit for bit.
+// Leaves x in the state buffer at *x_off (leading dimension R4_DS) and returns log q of row tid >> 4 (threads < 64).
+// ================================================================================================
+template <int NTWM>
+__device__ float flow_sample_r4s(const FlowDims& f, const R4Dims& rd, const R4Lds& l, const float* __restrict__ packed,
+                                 float* lds, const Tid4& t, int* x_off) {
+    using S = R4Stream<NTWM>;
+    constexpr int G = NTWM, RD = S::RD, IS = S::IS;
+    constexpr int JW1 = 0, JW2 = 1, JW3 = 1 + 4 * NTWM, JA = 3 + 4 * NTWM;      // items of a sampling layer
+    static_assert(JA + 1 == S::C, "a sampling layer has as many items as a density layer");
+    int cur = l.o_X0, nxt = l.o_X1;
+    float* HA = lds + l.o_HA;
+    float* HB = lds + l.o_HB;
+    float* PRM = lds + l.o_PRM;
+    float* PART = lds + l.o_PART;
+    const bool ew = t.tid < 64;
+    const int row = t.tid >> 4, c = t.tid & 15;
+    const int nqD = rd.KD / 16;
+    const float4* sp = reinterpret_cast<const float4*>(packed + f.o_r4s) +
+                       ((size_t)(2 * f.K * S::C + 8) * 4 * G + (size_t)t.wave * G) * 64 + t.lane;
+    float4 ring[RD][G];
+#pragma unroll
+    for (int i = 0; i < RD; ++i)
+#pragma unroll
+        for (int g = 0; g < G; ++g) ring[i][g] = sp[(size_t)i * IS + g * 64];
+    auto refill = [&](auto ic) {
+        constexpr int I = decltype(ic)::value;
+#pragma unroll
+        for (int g = 0; g < G; ++g) ring[I % RD][g] = sp[(size_t)(I + RD) * IS + g * 64];
+    };
+    float bvA[1], bv1[G], bv2[G];
+    float logq = 0.f;
+    if (ew) {                                          // z = loc + exp(log_scale) eps ; log N(eps)
+        const float* base = packed + f.o_base;
+        float* Z = lds + cur;
+        float bsum = 0.f;
+        for (int j = c; j < f.D; j += 16) {
+            const float e = Z[row * R4_DS + j];
+            const float ls = base[f.Dp + j];
+            Z[row * R4_DS + j] = base[j] + expf(ls) * e;
+            bsum += ls + 0.5f * (e * e);
+        }
+        logq = -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
+    }
+    r4_bias_load<G>(bv1, packed + f.o_b1, t);
+    r4_barrier();
+    for (int layer = 0; layer < f.K; ++layer) {
+        const float* Lp = packed + (size_t)layer * f.layer_stride;
+        unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;   // (ReLU signs: scratch here)
+        float* Z = lds + cur;
+        {   // conditioner, first layer (K = 16: one k-quad per wave)
+            R4Pre<1, G> p1;
+#pragma unroll
+            for (int g = 0; g < G; ++g) p1.b[0][g] = ring[JW1 % RD][g];
+            refill(IC<JW1>{});
+            r4_dense_short<1, G, 1>(Z, R4_DS, f.d, 1, p1, bv1, HA, l.WS, mk, PART, l.PN, t);
+        }
+        float b3s[2] = {0.f, 0.f}, b3c[2] = {0.f, 0.f};
+        r4_bias_load<G>(bv2, Lp + f.o_b2, t);
+        r4_bias_load<1>(bvA, Lp + f.o_at, t);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int j = c + 16 * it;
+            if (ew && j < f.DO) { b3s[it] = Lp[f.o_b3 + j]; b3c[it] = Lp[f.o_b3 + f.DOp + j]; }
+        }
+        if (layer + 1 < f.K) r4_bias_load<G>(bv1, Lp + f.layer_stride + f.o_b1, t);
+        r4s_dense_wide<NTWM, 1, JW2>(HA, l.WS, ring, refill, bv2, HB, l.WS, mk + NTHREADS, PART, l.PN, t);
+        {   // coupling parameters
+            R4PreT<NTWM, 2> p3;
+#pragma unroll
+            for (int Q = 0; Q < NTWM; ++Q)
+#pragma unroll
+                for (int ct = 0; ct < 2; ++ct) p3.b[Q][ct] = ring[(JW3 + (2 * Q + ct) / G) % RD][(2 * Q + ct) % G];
+            refill(IC<JW3>{});
+            refill(IC<JW3 + 1>{});
+            r4_dense_n16<NTWM, 2>(HB, l.WS, p3, PRM, R4_DS, PART, l.PN, t);
+        }
+        if (ew) {
+            float ssum = 0.f;
+#pragma unroll
+            for (int it = 0; it < 2; ++it) {
+                const int j = c + 16 * it;
+                if (j < f.DO) {
+                    const float shift = PRM[row * R4_DS + j] + b3s[it];
+                    const float s = PRM[row * R4_DS + f.DOp + j] + b3c[it];
+                    Z[row * R4_DS + f.d + j] = Z[row * R4_DS + f.d + j] * expf(s) + shift;
+                    ssum += s;
+                }
+            }
+            logq -= row16_sum(ssum);
+        }
+        r4_barrier();
+        {   // InvertibleAffine.forward (+ folded ActNorm): z <- z @ W'^-1 + at, log_det = -sum(log_S)
+            R4Pre<2, 1> pa;
+            pa.b[0][0] = ring[JA % RD][0]; pa.b[1][0] = ring[JA % RD][1];
+            refill(IC<JA>{});
+            r4_dense_short<2, 1, 0>(Z, R4_DS, f.D, nqD, pa, bvA, lds + nxt, R4_DS, nullptr, PART, l.PN, t);
+        }
+        logq -= -Lp[f.o_logS];
+        sp += (size_t)S::C * IS;
+        const int tmp = cur; cur = nxt; nxt = tmp;
+    }
+    *x_off = cur;
+    return logq;
+}
+
 }  // namespace fab

@@ -66,6 +66,18 @@ struct TailArgs {
 };
 int tail_small(const TailArgs& a, int* dest, hipStream_t st);
 
+// 4-chain tiles (flow_r4.h) pay when 16-chain tiles cannot fill the chip: up to 288 workgroups of 4 chains (B <= 1152); off in fast
+// mode (no bf16 variant).  FABHIP_OPT_TILE_SHAPE = 16 / 4 forces the choice (tests exercise both).  D <= 32 and hidden width <= 320
+// only (the other instantiations spill registers and are not compiled).  Used by the transitions, the chain initialisation and
+// the flow sample alike.
+static inline bool use_r4_tiles(const FlowDims& f, long B) {
+    if (f.fast || f.D > 32 || f.NTW / 4 > 5) return false;
+    const int shape = option(FABHIP_OPT_TILE_SHAPE);
+    if (shape == 16 || shape == 8) return false;
+    if (shape == 4) return true;
+    return B <= 1152;
+}
+
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
 
 // Allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU).

@@ -189,13 +189,13 @@ def test_stream_and_staged_four_chain_kernels_are_bit_identical(monkeypatch, D, 
     flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
     target = fa.ManyWellEnergy(D)
     res = []
-    for mode in ("1", "0"):
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x0, _ = flow.native_sample(torch.randn(B, D, device=DEV, generator=g))     # (one starting point: the flow SAMPLE has a 4-chain
+    for mode in ("1", "0"):                                                    #  form on the stream image only)
         _ops.load().set_option(_ops.OPT_R4_STREAM, int(mode))
         hmc = fa.HamiltonianMonteCarlo(3, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
                                        n_outer=2, L=4).to(DEV)
-        g = torch.Generator(device=DEV).manual_seed(5)
-        x0, _ = flow.native_sample(torch.randn(B, D, device=DEV, generator=g))
-        pt = fa.create_point(x0, flow, target, with_grad=True)
+        pt = fa.create_point(x0.clone(), flow, target, with_grad=True)        # (the transition commits in place)
         torch.manual_seed(7)
         out = hmc.transition(pt, 1, 0.3)
         res.append((out.x.clone(), out.log_q.clone(), out.grad_log_q.clone(), hmc.epsilons.clone()))
@@ -300,3 +300,28 @@ def test_noise_drawn_inside_the_op_equals_noise_drawn_by_the_caller(B, metropoli
         outs.append((pt.x.clone(), pt.log_q.clone(), pt.log_p.clone(), log_w.clone(), n_valid.clone(), stats[:6].clone(), state))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 1024), (32, 4, 8, 300), (6, 3, 40, 70), (16, 3, 16, 257), (2, 2, 64, 33),
+                                         (32, 2, 4, 1152), (32, 3, 10, 4)])
+def test_four_chain_flow_sample_matches_sixteen_chain_sample_and_the_oracle(D, K, nodes, B):
+    """fabhip_flow_sample on 4-chain tiles (flow_sample_r4s: batches of <= 1152 chains, D <= 32, hidden width 128 .. 320; r4)
+    against the 16-chain kernel (FABHIP_OPT_TILE_SHAPE = 16) on the same base noise - x and log q to fp32 rounding (the two
+    differ in the summation order inside the products only) - against the density of its own samples, and against the CPU
+    oracle's sampling direction."""
+    from test_gpu_parity import seeded_flow, hip_flow_from_oracle
+    nf = seeded_flow(D, K, nodes, 70 + D + K)
+    hf = hip_flow_from_oracle(nf)
+    torch.manual_seed(B)
+    eps = torch.randn(B, D)
+    ops = _ops.load()
+    try:
+        ops.set_option(_ops.OPT_TILE_SHAPE, 16)
+        x16, lq16 = hf.native_sample(eps.to(DEV))
+    finally:
+        ops.set_option(_ops.OPT_TILE_SHAPE, 0)
+    x4, lq4 = hf.native_sample(eps.to(DEV))
+    xo, lqo = (t.detach() for t in nf.sample_eps(eps))
+    assert max_rel_err(x4, x16) <= 5e-6 and max_rel_err(lq4, lq16) <= 5e-6
+    assert max_rel_err(x4.cpu(), xo) <= 1e-5 and max_rel_err(lq4.cpu(), lqo) <= 1e-5
+    assert max_rel_err(hf.log_prob(x4), lq4) <= 1e-5
