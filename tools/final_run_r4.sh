@@ -4,8 +4,7 @@ set -x
 cd ${GRAFT_REPO_ROOT:-.}
 O=gpurun_out/final_r4; mkdir -p $O
 export TMPDIR=/tmp
-timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
-timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json
+timeout 600 python bench.py 2>$O/bench.err | tail -1 > $O/bench.json      # first: what the driver's round-end run sees (a fresh box)
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python bench.py --no-cpu-baseline --steps 20 --warmup 5 > $O/bench_prof.log 2>&1
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv; rm -rf $O/prof
 bash tools/pmc_traffic.sh k_hmc_step_r4 $O/pmc_traffic_r4 3 > $O/pmc_traffic_r4.log 2>&1; cp $O/pmc_traffic_r4/summary.json $O/hmc_step_r4_traffic_pmc_summary.json
@@ -18,4 +17,7 @@ CFG=5 N=3 timeout 300 python tools/bench_spline.py 2>/dev/null | tail -1 > $O/sp
 bash tools/pmc_stream_kernels.sh > $O/pmc_stream.log 2>&1
 cp gpurun_out/pmc_stream_hmc/summary.json $O/hmc_step_r8_pmc_summary.json; cp gpurun_out/pmc_stream_spline/summary.json $O/spline_r8_pmc_summary.json
 rm -rf $O/pmc_traffic_r4 gpurun_out/pmc_stream_hmc gpurun_out/pmc_stream_spline
+bash tools/trace_step.sh > /dev/null 2>&1; cp gpurun_out/trace_step/step_timeline.txt $O/step_timeline.txt
+timeout 300 python tools/host_overhead.py 2>/dev/null | tail -9 > $O/host_overhead.txt
+timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -6 > $O/pytest_gpu.txt; cat $O/pytest_gpu.txt
 ls -la $O
