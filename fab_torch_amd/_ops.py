@@ -151,6 +151,15 @@ def _register_autograd():
                                     setup_context=_sample_setup_context)
 
 
+PROC_NONCE = os.urandom(8).hex()      # marks state that is only valid inside this process (registered parameter sets)
+
+
+def owner_token(obj):
+    """Identity of `obj` in THIS process: a copy (copy.deepcopy) or an un-pickled module carries its source's cached state in
+    `__dict__` - handles of the op layer's parameter-set registry among it - and must not use it."""
+    return (PROC_NONCE, id(obj))
+
+
 _pinned = {}
 
 

@@ -490,6 +490,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
         contrib = expf(fminf(dd, 0.f));
         dist = accept ? 0.f : sqrtf(dist2);
     }
+    // (first: the latency of the write-through stores of the in-kernel step-size rule hides behind the commit stores)
+    if (t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, contrib, dist);
     if (a.prop_out.x && active) {
         for (int j = t.c; j < D; j += 16) {
             a.prop_out.x[g * D + j] = XP[t.row * D + j];
@@ -512,7 +514,6 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
         const float den = a.c.c_q * lqf + a.c.c_p * lpf;
         a.log_w[g] = a.log_w[g] + (num - den);
     }
-    if (t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, contrib, dist);
     hmc_adapt_last(a, lds, t.tid, 1);                 // (wave 0 is the only wave left)
 }
 
@@ -701,6 +702,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
         contrib = expf(fminf(dd, 0.f));
         dist = accept ? 0.f : sqrtf(dist2);
     }
+    // (first: the latency of the write-through stores of the in-kernel step-size rule hides behind the commit stores)
+    if (t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, contrib, dist);
     if (a.prop_out.x && active) {
         for (int j = t.c; j < D; j += 16) {
             a.prop_out.x[g * D + j] = XP[t.row * D + j];
@@ -723,7 +726,6 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
         const float den = a.c.c_q * lqf + a.c.c_p * lpf;
         a.log_w[g] = a.log_w[g] + (num - den);
     }
-    if (t.c == 0 && g < (a.B + 15) / 16 * 16) hmc_store_row_stats(a, g, contrib, dist);
     hmc_adapt_last(a, lds, t.tid & 63, 16 * R8 / 64);   // (the two element-wise waves; the others have returned)
 }
 
@@ -1373,7 +1375,7 @@ size_t fabhip_ais_workspace_bytes(int64_t B, int32_t dim, int32_t n_inner) {
 // the tail of a chain phase: compaction (+ log_p - log_q) + ESS / log Z - one launch for small batches, else the separate kernels
 static int phase_tail(const fabhip_point& point, float* log_w, long B, int dim, const int* n_in, int* n_out, float* tmp, int* dest,
                       float* extra, float* diff, double n_norm, float* stats_out, void* ess_ws, size_t ess_bytes, float* base_x,
-                      int* zero_word, hipStream_t st);
+                      int* zero_word, float* zero_f, hipStream_t st);
 
 static int compact_rows(const fabhip_point& point, float* log_w, long B, int dim, const int* n_in, int* n_out, float* tmp,
                         int* dest, float* extra, hipStream_t st) {
@@ -1387,18 +1389,19 @@ static int compact_rows(const fabhip_point& point, float* log_w, long B, int dim
 
 static int phase_tail(const fabhip_point& point, float* log_w, long B, int dim, const int* n_in, int* n_out, float* tmp, int* dest,
                       float* extra, float* diff, double n_norm, float* stats_out, void* ess_ws, size_t ess_bytes, float* base_x,
-                      int* zero_word, hipStream_t st) {
+                      int* zero_word, float* zero_f, hipStream_t st) {
     int rc = FABHIP_ENOTSUP;
     if (option(FABHIP_OPT_FUSED_TAIL) != 0) {
         TailArgs t;
         t.x = point.x; t.lq = point.log_q; t.lp = point.log_p; t.gq = point.grad_log_q; t.gp = point.grad_log_p;
         t.log_w = log_w; t.extra = extra; t.n_in = n_in; t.n_out = n_out; t.B = B; t.D = dim; t.diff = diff; t.n_norm = n_norm;
-        t.stats_out = stats_out; t.zero_word = zero_word;
+        t.stats_out = stats_out; t.zero_word = zero_word; t.zero_f = zero_f; t.n_zero_f = zero_f ? 10 : 0;
         rc = tail_small(t, dest, st);
         if (rc != FABHIP_OK && rc != FABHIP_ENOTSUP) return rc;
     }
     if (rc == FABHIP_ENOTSUP) {
         if (zero_word && hipMemsetAsync(zero_word, 0, 4, st) != hipSuccess) return FABHIP_ELAUNCH;
+        if (zero_f && hipMemsetAsync(zero_f, 0, 10 * 4, st) != hipSuccess) return FABHIP_ELAUNCH;
         FAB_TRY(compact_rows(point, log_w, B, dim, n_in, n_out, tmp, dest, extra, st));
     }
     if (base_x &&         // the compacted starting points (rows beyond the count are don't-care)
@@ -1513,7 +1516,7 @@ int fabhip_spline_ais_run(const fabhip_spline_ais_args* a, fabhip_stream_t strea
                        a1, a->log_w, a->base_log_w, B);
     // 2. "chain init" filter, 3. base ESS
     FAB_TRY(phase_tail(a->point, a->log_w, B, D, nullptr, a->n_valid, tmp, dest, a->base_log_w, lwb, 1.0, a->stats + 0, ess_ws,
-                       ess_bytes, a->base_x, nullptr, st));
+                       ess_bytes, a->base_x, nullptr, a->stats + 6, st));
     // 4. transitions
     for (int j = 1; j <= a->M; ++j) {
         fabhip_spline_hmc_args h;
@@ -1533,7 +1536,7 @@ int fabhip_spline_ais_run(const fabhip_spline_ais_args* a, fabhip_stream_t strea
     }
     // 5. "chain end" filter, 6. ESS / log Z
     FAB_TRY(phase_tail(a->point, a->log_w, B, D, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, nullptr, (double)B, a->stats + 3,
-                       ess_ws, ess_bytes, nullptr, nullptr, st));
+                       ess_ws, ess_bytes, nullptr, nullptr, nullptr, st));
     return check_launch();
 }
 
@@ -1609,7 +1612,7 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     }
     // 2. remove nan/inf ("chain init"), 3. ESS over the base samples (ais.py:68-71) -> stats[0..2]
     FAB_TRY(phase_tail(a->point, a->log_w, B, D, nullptr, a->n_valid, tmp, dest, a->base_log_w, lwb, 1.0, a->stats + 0, ess_ws,
-                       ess_bytes, a->base_x, ticket, st));
+                       ess_bytes, a->base_x, ticket, a->stats + 6, st));
     }
     // 4. transitions
     for (int j = j_begin; j <= j_end; ++j) {
@@ -1647,7 +1650,7 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     // 5. remove nan/inf ("chain end"), 6. ESS / log Z over the survivors (ais.py:77-86)
     if (do_finish)
         FAB_TRY(phase_tail(a->point, a->log_w, B, D, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, nullptr, (double)B,
-                           a->stats + 3, ess_ws, ess_bytes, nullptr, nullptr, st));
+                           a->stats + 3, ess_ws, ess_bytes, nullptr, nullptr, nullptr, st));
     return check_launch();
 }
 

@@ -1,5 +1,7 @@
 // Host-side launch helpers (no allocation, no synchronisation).
 #pragma once
+#include <mutex>
+#include <vector>
 #include "fabhip_common.h"
 
 namespace fab {
@@ -63,6 +65,8 @@ struct TailArgs {
     double n_norm;
     float* stats_out;                  // [3]: ESS, log Z, n
     int* zero_word;                    // optional: one word the kernel zeroes (the ticket of the in-kernel step-size rule)
+    float* zero_f;                     // optional: n_zero_f floats the kernel zeroes (the unused tail of the caller's stats[16]:
+    int n_zero_f;                      //   the binding allocates stats uninitialised - one fill launch less per call)
 };
 int tail_small(const TailArgs& a, int* dest, hipStream_t st);
 
@@ -81,13 +85,26 @@ static inline bool use_r4_tiles(const FlowDims& f, long B) {
 static inline int check_launch() { return hipGetLastError() == hipSuccess ? FABHIP_OK : FABHIP_ELAUNCH; }
 
 // Allow > 64 KiB of dynamic LDS (gfx950 has 160 KiB per CU).
+// (the attribute sticks to the function on its device: the driver call is made once per (kernel, device, larger size) and
+// remembered - it sat on the host path of every launch, and the first launch of a call is one the GPU waits for)
 static inline int set_max_lds(const void* fn, size_t bytes) {
     if (bytes > 160 * 1024) return FABHIP_ENOTSUP;
     if (bytes > 48 * 1024) {
+        struct Seen { const void* fn; int dev; size_t bytes; };
+        static std::mutex mu;
+        static std::vector<Seen> seen;
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return FABHIP_ELAUNCH; }
+        std::lock_guard<std::mutex> lk(mu);
+        Seen* hit = nullptr;
+        for (Seen& e : seen)
+            if (e.fn == fn && e.dev == dev) { hit = &e; break; }
+        if (hit && hit->bytes >= bytes) return FABHIP_OK;
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
             (void)hipGetLastError();
             return FABHIP_ELAUNCH;
         }
+        if (hit) hit->bytes = bytes; else seen.push_back(Seen{fn, dev, bytes});
     }
     return FABHIP_OK;
 }

@@ -150,6 +150,7 @@ __global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __r
     constexpr int NWV = ESS_THREADS / 64;
     const long n_in = a.n_in ? (long)*a.n_in : a.B;
     if (tid == 0) { running = 0; if (a.zero_word) *a.zero_word = 0; }
+    if (a.zero_f && tid < a.n_zero_f) a.zero_f[tid] = 0.f;
     __syncthreads();
     for (long base = 0; base < n_in; base += ESS_THREADS) {               // k_valid_scan's ranks (integers: any order of work agrees)
         const long r = base + tid;
@@ -216,7 +217,18 @@ __global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __r
         if (tid == 0) part[vb] = v;
         __syncthreads();
     }
-    ess_final_body(part, nb, n_out, a.n_norm, a.stats_out, sh);
+    if (nb == 1) {
+        // k_ess_final with one partial merges it with 255 identities: msum_merge(v, identity) == v bit for bit (exp(0) = 1,
+        // exp(-inf) = 0; -inf and NaN maxima propagate the same way), so the tree is skipped
+        if (tid == 0) {
+            const Msum v = msum_merge(msum_id(), part[0]);
+            const double ess = (v.s1 * v.s1 / v.s2) / (double)n_out;
+            const double logz = v.m + log(v.s1) - log(a.n_norm);
+            a.stats_out[0] = (float)ess; a.stats_out[1] = (float)logz; a.stats_out[2] = (float)n_out;
+        }
+    } else {
+        ess_final_body(part, nb, n_out, a.n_norm, a.stats_out, sh);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -164,12 +164,27 @@ std::vector<int64_t> tensors_key(at::TensorList ts) {
 // list of 112 tensors.  `param.data = ...`, `.to()`, load_state_dict and in-place updates all act on the registered TensorImpl.
 static std::mutex g_keysets_mu;
 static std::vector<std::vector<Tensor>> g_keysets;
+static std::vector<int64_t> g_keysets_free;        // released slots (tensors_key_release)
 int64_t tensors_key_register(at::TensorList ts, int64_t reuse) {
     std::lock_guard<std::mutex> lk(g_keysets_mu);
     std::vector<Tensor> v(ts.begin(), ts.end());
     if (reuse >= 0 && reuse < (int64_t)g_keysets.size()) { g_keysets[(size_t)reuse] = std::move(v); return reuse; }
+    if (!g_keysets_free.empty()) {
+        const int64_t h = g_keysets_free.back();
+        g_keysets_free.pop_back();
+        g_keysets[(size_t)h] = std::move(v);
+        return h;
+    }
     g_keysets.push_back(std::move(v));
     return (int64_t)g_keysets.size() - 1;
+}
+// a flow that is garbage-collected gives its slot back (the handles of dropped tensors are released; the slot is reused)
+void tensors_key_release(int64_t handle) {
+    std::lock_guard<std::mutex> lk(g_keysets_mu);
+    if (handle < 0 || handle >= (int64_t)g_keysets.size()) return;
+    g_keysets[(size_t)handle].clear();
+    g_keysets[(size_t)handle].shrink_to_fit();
+    g_keysets_free.push_back(handle);
 }
 std::vector<int64_t> tensors_key_of(int64_t handle) {
     std::lock_guard<std::mutex> lk(g_keysets_mu);
@@ -664,7 +679,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     a.target_p_accept = (float)target_p_accept; a.tune = tune ? 1 : 0;
     Tensor x = fempty({B, dim}, eps0), lq = fempty({B}, eps0), lp = fempty({B}, eps0), log_w = fempty({B}, eps0);
     Tensor gq = fempty({B, dim}, eps0), gp = fempty({B, dim}, eps0);
-    Tensor counts_stats = at::zeros({18}, eps0.options());      // one zero fill, one device->host copy (_ops.read_counts_and_stats)
+    Tensor counts_stats = at::empty({18}, eps0.options());      // one device->host copy (_ops.read_counts_and_stats); every word is
+                                                                // written by the call (the counts and statistics by the phase tails, stats[6..15] = 0)
     Tensor stats = counts_stats.narrow(0, 0, 16), n_valid = counts_stats.narrow(0, 16, 2).view(at::kInt);
     Tensor base_x = want_base ? fempty({B, dim}, eps0) : fempty({0}, eps0);
     Tensor base_lw = want_base ? fempty({B}, eps0) : fempty({0}, eps0);
@@ -792,7 +808,8 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
     };
     Tensor x = take(B, dim), lq = take(B, 0), lp = take(B, 0), log_w = take(B, 0);
     Tensor gq = hmc ? take(B, dim) : fempty({0}, eps0), gp = hmc ? take(B, dim) : fempty({0}, eps0);
-    Tensor counts_stats = at::zeros({18}, eps0.options());      // one zero fill, one device->host copy (_ops.read_counts_and_stats)
+    Tensor counts_stats = at::empty({18}, eps0.options());      // one device->host copy (_ops.read_counts_and_stats); every word is
+                                                                // written by the call (the counts and statistics by the phase tails, stats[6..15] = 0)
     Tensor stats = counts_stats.narrow(0, 0, 16), n_valid = counts_stats.narrow(0, 16, 2).view(at::kInt);
     Tensor base_x = want_base ? fempty({B, dim}, eps0) : fempty({0}, eps0);
     Tensor base_lw = want_base ? fempty({B}, eps0) : fempty({0}, eps0);
@@ -1011,6 +1028,7 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("tensors_key(Tensor[] ts) -> int[]", tensors_key);
     m.def("tensors_key_register(Tensor[] ts, int reuse) -> int", tensors_key_register);
     m.def("tensors_key_of(int handle) -> int[]", tensors_key_of);
+    m.def("tensors_key_release(int handle) -> ()", tensors_key_release);
     m.def("flow_grad_floats(int dim, int n_layers, int width) -> int", flow_grad_floats);
     m.def("flow_grad_layout(int dim, int n_layers, int width) -> int[]", flow_grad_layout);
     m.def("flow_tape_layout(int dim, int n_layers, int width, int B) -> int[]", flow_tape_layout);

@@ -306,9 +306,21 @@ class RealNVP(nn.Module):
         """Forget the registered parameter set (`_param_key`).  Needed only after ASSIGNING a new nn.Parameter object to a layer of
         `_nf_model` (in-place updates, `.data = ...`, `.to()`, `load_state_dict` keep the objects and are seen by the key) - the
         same contract torch.optim has with the parameters it was given."""
-        self.__dict__.pop("_pset", None)
+        self.__dict__.pop("_pset", None)                       # (the slot of the op layer, `_pset_handle`, is kept and re-used)
         self.__dict__.pop("_leaf_cache", None)
         self._packed_key = None
+
+    def _own_handle(self):
+        h = self.__dict__.get("_pset_handle")                  # (owner token, slot): a deep copy / un-pickled flow carries its
+        return h[1] if h is not None and h[0] == _ops.owner_token(self) else -1    # source's entry and must not use it
+
+    def __del__(self):
+        try:
+            h = self._own_handle()
+            if h >= 0:
+                _ops.load().tensors_key_release(h)             # the op layer drops its references to this flow's tensors
+        except Exception:                                      # noqa: BLE001 (interpreter shutdown)
+            pass
 
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
@@ -321,7 +333,7 @@ class RealNVP(nn.Module):
         objects are compared by identity and one integer goes through the dispatcher."""
         nf = self._nf_model
         c = self.__dict__.get("_pset")
-        if c is not None and c[0] is nf and c[1] == (self.n_layers, self.act_norm):
+        if c is not None and c[0] is nf and c[1] == (self.n_layers, self.act_norm) and c[2] == self._own_handle():
             ok = True
             for d, n, obj in c[3]:
                 if d.get(n) is not obj:
@@ -330,7 +342,9 @@ class RealNVP(nn.Module):
             if ok:
                 return tuple(ops.tensors_key_of(c[2]))
         # (the Parameter / buffer OBJECTS themselves, not detached aliases: `param.data = ...` acts on the registered TensorImpl)
-        handle = ops.tensors_key_register(self._param_list_fast(for_key=True), c[2] if c is not None else -1)
+        self.__dict__.pop("_leaf_cache", None)                 # (a copy's cache names the source's modules)
+        handle = ops.tensors_key_register(self._param_list_fast(for_key=True), self._own_handle())
+        self.__dict__["_pset_handle"] = (_ops.owner_token(self), handle)
         lc = self.__dict__["_leaf_cache"]
         first, last, q0 = lc[2][0], lc[2][-1], lc[4]
         probes = [(first[0]._parameters, "weight", first[0]._parameters["weight"]),

@@ -366,6 +366,18 @@ class CircularCoupledRQSFlow(nn.Module):
         self.__dict__.pop("_pset", None)
         self._packed_key = None
 
+    def _own_handles(self):
+        h = self.__dict__.get("_pset_handles")                 # (owner token, (slot, slot)): a deep copy / un-pickled flow carries
+        return h[1] if h is not None and h[0] == _ops.owner_token(self) else (-1, -1)    # its source's entry and must not use it
+
+    def __del__(self):
+        try:
+            for h in self._own_handles():
+                if h >= 0:
+                    _ops.load().tensors_key_release(h)         # the op layer drops its references to this flow's tensors
+        except Exception:                                      # noqa: BLE001 (interpreter shutdown)
+            pass
+
     def _apply(self, fn, recurse=True):
         out = super()._apply(fn, recurse)
         self.invalidate_native()
@@ -376,6 +388,8 @@ class CircularCoupledRQSFlow(nn.Module):
         the op layer once (fabhip::tensors_key_register), three of each are compared by identity per call, two integers go
         through the dispatcher - instead of walking `parameters()` / `buffers()` (hundreds of attribute reads per AIS call)."""
         c = self.__dict__.get("_pset")
+        if c is not None and (c[0], c[1]) != self._own_handles():
+            c = None
         if c is not None:
             for d, n, obj in c[2]:
                 if d.get(n) is not obj:
@@ -390,10 +404,10 @@ class CircularCoupledRQSFlow(nn.Module):
                 for n, t in m._buffers.items():
                     if t is not None and id(t) not in seen:
                         seen.add(id(t)); blist.append((m._buffers, n, t))
-            old = self.__dict__.get("_pset_handles", (-1, -1))
+            old = self._own_handles()
             hp = ops.tensors_key_register([e[2] for e in plist], old[0])
             hb = ops.tensors_key_register([e[2] for e in blist], old[1])
-            self.__dict__["_pset_handles"] = (hp, hb)
+            self.__dict__["_pset_handles"] = (_ops.owner_token(self), (hp, hb))
             probes = [lst[i] for lst in (plist, blist) if lst for i in sorted({0, len(lst) // 2, len(lst) - 1})]
             c = (hp, hb, probes)
             self.__dict__["_pset"] = c

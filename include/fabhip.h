@@ -464,7 +464,8 @@ typedef struct {
     float* log_w;             /* out [B]                                                     */
     int32_t* n_valid;         /* out device int32[2]: rows after "chain init" / "chain end"  */
     float* stats;             /* out device float[16]: [0] ess_base [1] - [2] rows after init
-                                 [3] ess_ais [4] log_Z [5] rows at chain end, rest reserved              */
+                                 [3] ess_ais [4] log_Z [5] rows at chain end, [6..15] reserved (the init phase
+                                 writes zeros): the caller need not initialise any of it                 */
     /* HMC logging slots (hmc.py:173-183, store_info), device, each may be NULL: mean acceptance probability of
      * every outer loop [n_inner] and store_info's mean distance [1], for the first (i = 1) and the last (i = M)
      * intermediate distribution.  With M = 1 only the "first" pair is written, like the reference. */

@@ -422,3 +422,36 @@ def test_packed_image_follows_every_kind_of_parameter_update():
     flow.invalidate_native()
     e = lq()
     assert not torch.equal(e, d) and torch.equal(e, fresh())
+
+
+def test_deep_copied_flow_registers_its_own_parameter_set():
+    """A copy.deepcopy of a flow carries the source's cached state in __dict__ (the handle of the op layer's parameter-set
+    registry among it); it must register its OWN tensors, follow its own updates, and its deletion must not release the
+    source's entry."""
+    import copy
+    import gc
+    torch.manual_seed(5)
+    D, K = 6, 2
+    flow = fa.RealNVP(D, K, 8).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.1 * torch.randn_like(p))
+    x = torch.randn(30, D, device=DEV)
+    a0 = flow.log_prob(x).clone()
+    twin = copy.deepcopy(flow)
+    assert torch.equal(twin.log_prob(x), a0)
+    with torch.no_grad():
+        list(twin._layers())[0][1].weight.mul_(1.5)
+    b = twin.log_prob(x).clone()
+    assert not torch.equal(b, a0)
+    assert torch.equal(flow.log_prob(x), a0)                  # the source did not see the copy's update ...
+    with torch.no_grad():
+        list(flow._layers())[1][0].weight.add_(0.05)
+    a1 = flow.log_prob(x).clone()
+    assert not torch.equal(a1, a0) and torch.equal(twin.log_prob(x), b)      # ... nor the copy the source's
+    del twin
+    gc.collect()
+    with torch.no_grad():
+        list(flow._layers())[1][0].weight.add_(0.05)
+    assert not torch.equal(flow.log_prob(x), a1)              # the source's registration survived the copy's deletion
