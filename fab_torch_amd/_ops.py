@@ -160,7 +160,7 @@ def owner_token(obj):
     return (PROC_NONCE, id(obj))
 
 
-_pinned = {}
+_pinned = threading.local()          # (per thread: the buffer is handed back to the caller)
 
 
 def _read_small(t: torch.Tensor) -> torch.Tensor:
@@ -169,10 +169,11 @@ def _read_small(t: torch.Tensor) -> torch.Tensor:
     microseconds during which the GPU has nothing queued.  Polling is bounded (a call of this library lasts milliseconds); past
     the bound the thread blocks."""
     key = (t.device, t.dtype, t.numel())
-    ent = _pinned.get(key)
+    cache = _pinned.__dict__.setdefault("cache", {})
+    ent = cache.get(key)
     if ent is None:
         ent = (torch.empty(t.numel(), dtype=t.dtype, pin_memory=True), torch.cuda.Event())
-        _pinned[key] = ent
+        cache[key] = ent
     buf, ev = ent
     buf.copy_(t, non_blocking=True)
     ev.record()

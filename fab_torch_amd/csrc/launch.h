@@ -52,7 +52,7 @@ int spline_log_prob_leap(const fabhip_spline_flow* flow, const SplineLeap& lp, f
 
 // The tail of a chain phase in one launch for small batches (reduce_resample.hip: k_tail_small): compaction of the rows with
 // finite log_p / log_q, optionally diff = log_p - log_q over all B rows, ESS / log Z over the survivors (of diff, or of log_w).
-// FABHIP_ENOTSUP above 8192 rows (the caller then runs the separate kernels: the same results, bit for bit).
+// FABHIP_ENOTSUP above 2048 rows (the caller then runs the separate kernels: the same results, bit for bit).
 struct TailArgs {
     float *x, *lq, *lp, *gq, *gp;      // the point's fields (gq / gp null: a Metropolis run)
     float* log_w;

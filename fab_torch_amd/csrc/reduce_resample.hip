@@ -39,16 +39,18 @@ __device__ __forceinline__ Msum msum_push(const Msum& a, double x) {
     return Msum{x, a.s1 * r + 1.0, a.s2 * r * r + 1.0};
 }
 
-__device__ __forceinline__ Msum msum_block_reduce(Msum v, Msum* sh) {
+// tree over the first `bdim` threads of the workgroup (every thread of the workgroup must call it: barriers)
+__device__ __forceinline__ Msum msum_block_reduce(Msum v, Msum* sh, int bdim) {
     const int tid = threadIdx.x;
-    sh[tid] = v;
+    if (tid < bdim) sh[tid] = v;
     __syncthreads();
-    for (int s = blockDim.x >> 1; s > 0; s >>= 1) {
+    for (int s = bdim >> 1; s > 0; s >>= 1) {
         if (tid < s) sh[tid] = msum_merge(sh[tid], sh[tid + s]);
         __syncthreads();
     }
     return sh[0];
 }
+__device__ __forceinline__ Msum msum_block_reduce(Msum v, Msum* sh) { return msum_block_reduce(v, sh, (int)blockDim.x); }
 
 constexpr int ESS_THREADS = 256;
 constexpr int ESS_MAX_BLOCKS = 1024;
@@ -78,11 +80,13 @@ __device__ __forceinline__ Msum msum_push_chunk(const Msum& a, const float (&x)[
 
 // the work of block `vb` of `nb` of the partial pass (ltid = thread in the block): shared by k_ess_partial and the one-launch
 // tail kernel, which runs the blocks one after the other - the same additions in the same order, bit for bit
-__device__ __forceinline__ Msum ess_partial_body(const float* __restrict__ lw, long n, int vb, int nb, Msum* sh) {
+// (`bdim`: threads per block of the partial pass; threads beyond it - the tail kernel runs 1024 - only keep the barriers company)
+__device__ __forceinline__ Msum ess_partial_body(const float* __restrict__ lw, long n, int vb, int nb, Msum* sh, int bdim) {
     Msum v = msum_id();
-    const long stride = (long)nb * blockDim.x;
-    const long tid = (long)vb * blockDim.x + threadIdx.x;
+    const long stride = (long)nb * bdim;
+    const long tid = (long)vb * bdim + threadIdx.x;
     long done = 0;
+    if ((int)threadIdx.x >= bdim) return msum_block_reduce(v, sh, bdim);
     if ((((size_t)lw) & 15) == 0) {                     // 16 values per thread per step: four coalesced 16-byte loads
         const long n16 = n / (16 * stride) * (16 * stride);
         const float4* p4 = reinterpret_cast<const float4*>(lw);
@@ -98,13 +102,17 @@ __device__ __forceinline__ Msum ess_partial_body(const float* __restrict__ lw, l
         done = n16;
     }
     for (long i = done + tid; i < n; i += stride) v = msum_push(v, (double)lw[i]);
-    return msum_block_reduce(v, sh);
+    return msum_block_reduce(v, sh, bdim);
+}
+__device__ __forceinline__ Msum ess_partial_body(const float* __restrict__ lw, long n, int vb, int nb, Msum* sh) {
+    return ess_partial_body(lw, n, vb, nb, sh, (int)blockDim.x);
 }
 __device__ __forceinline__ void ess_final_body(const Msum* __restrict__ part, int nblk, long n, double n_norm,
-                                               float* __restrict__ out, Msum* sh) {
+                                               float* __restrict__ out, Msum* sh, int bdim) {
     Msum v = msum_id();
-    for (int i = threadIdx.x; i < nblk; i += blockDim.x) v = msum_merge(v, part[i]);
-    v = msum_block_reduce(v, sh);
+    if ((int)threadIdx.x < bdim)
+        for (int i = threadIdx.x; i < nblk; i += bdim) v = msum_merge(v, part[i]);
+    v = msum_block_reduce(v, sh, bdim);
     if (threadIdx.x == 0) {
         const double ess = (v.s1 * v.s1 / v.s2) / (double)n;       // 1 / sum(softmax^2) / n
         const double logz = v.m + log(v.s1) - log(n_norm);         // logsumexp - log(n_norm)
@@ -126,33 +134,35 @@ __global__ __launch_bounds__(ESS_THREADS) void k_ess_final(const Msum* __restric
                                                            const int* n_ptr, double n_norm, float* __restrict__ out) {
     __shared__ Msum sh[ESS_THREADS];
     const long n = n_ptr ? (long)*n_ptr : n_cap;
-    ess_final_body(part, nblk, n, n_norm, out, sh);
+    ess_final_body(part, nblk, n, n_norm, out, sh, (int)blockDim.x);
 }
 
 // ------------------------------------------------------------------------------------------------
-// The tail of a chain phase for SMALL batches in ONE launch (launch.h: TailArgs; <= TAIL_MAX_ROWS rows): stable compaction of the
+// The tail of a chain phase for SMALL batches in ONE launch (launch.h: TailArgs; <= 2048 rows): stable compaction of the
 // rows with finite log_p and log_q (ais.py:190-213), optionally log_p - log_q, then ESS / log Z over the survivors - what
 // k_valid_scan, k_compact_scatter, k_compact_copyback, k_sub, k_ess_partial and k_ess_final do in six launches (~5 us each on an
 // otherwise idle GPU: the work of 1024 rows is a few hundred nanoseconds).  One workgroup: the rows move IN PLACE, in row order,
 // through an LDS chunk (destination <= source, so a chunk's writes only touch rows already read); nothing moves when no row was
 // dropped.  The ESS runs the partial pass's blocks one after the other (ess_partial_body): bit-identical to the two-kernel form.
 // ------------------------------------------------------------------------------------------------
+constexpr int TAIL_THREADS = 1024;                     // scan / move / difference on 1024 threads, the ESS on the first ESS_THREADS
 constexpr int TAIL_CHUNK = 32;                         // rows staged in LDS per step of the in-place move
-constexpr int TAIL_MAX_BLOCKS = 8;                     // ESS blocks of 1024 values: batches of <= 8192 rows
+constexpr int TAIL_MAX_BLOCKS = 2;                     // ESS blocks of 1024 values: batches of <= 2048 rows (tools/time_tail.py: one
+                                                       // workgroup is level with the separate kernels at 2048 rows and behind from 4096)
 
-__global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __restrict__ dest, int nb) {
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail_small(TailArgs a, int* __restrict__ dest, int nb) {
     extern __shared__ __attribute__((aligned(16))) float stage[];          // [TAIL_CHUNK][3 D + 4]
     __shared__ Msum sh[ESS_THREADS];
     __shared__ Msum part[TAIL_MAX_BLOCKS];
-    __shared__ int wsum[ESS_THREADS / 64];
+    __shared__ int wsum[TAIL_THREADS / 64];
     __shared__ int running;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    constexpr int NWV = ESS_THREADS / 64;
+    constexpr int NWV = TAIL_THREADS / 64;
     const long n_in = a.n_in ? (long)*a.n_in : a.B;
     if (tid == 0) { running = 0; if (a.zero_word) *a.zero_word = 0; }
     if (a.zero_f && tid < a.n_zero_f) a.zero_f[tid] = 0.f;
     __syncthreads();
-    for (long base = 0; base < n_in; base += ESS_THREADS) {               // k_valid_scan's ranks (integers: any order of work agrees)
+    for (long base = 0; base < n_in; base += TAIL_THREADS) {               // k_valid_scan's ranks (integers: any order of work agrees)
         const long r = base + tid;
         const bool v = r < n_in && isfinite(a.lq[r]) && isfinite(a.lp[r]);
         const unsigned long long bal = __ballot(v);
@@ -173,7 +183,7 @@ __global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __r
     if (n_out != n_in) {
         for (long r0 = 0; r0 < n_in; r0 += TAIL_CHUNK) {
             const int nr = (int)(n_in - r0 < TAIL_CHUNK ? n_in - r0 : TAIL_CHUNK);
-            for (int e = tid; e < nr * D; e += ESS_THREADS) {
+            for (int e = tid; e < nr * D; e += TAIL_THREADS) {
                 const int i = e / D, j = e % D;
                 const long r = r0 + i;
                 float* o = stage + i * RW;
@@ -187,7 +197,7 @@ __global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __r
                 if (a.extra) o[3 * D + 3] = a.extra[r];
             }
             __syncthreads();
-            for (int e = tid; e < nr * D; e += ESS_THREADS) {
+            for (int e = tid; e < nr * D; e += TAIL_THREADS) {
                 const int i = e / D, j = e % D;
                 const long d = dest[r0 + i];
                 if (d < 0 || d == r0 + i) continue;
@@ -208,12 +218,12 @@ __global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __r
     }
     const float* lw = a.log_w;
     if (a.diff) {
-        for (long i = tid; i < a.B; i += ESS_THREADS) a.diff[i] = a.lp[i] - a.lq[i];
+        for (long i = tid; i < a.B; i += TAIL_THREADS) a.diff[i] = a.lp[i] - a.lq[i];
         lw = a.diff;
     }
     __syncthreads();
     for (int vb = 0; vb < nb; ++vb) {
-        const Msum v = ess_partial_body(lw, n_out, vb, nb, sh);
+        const Msum v = ess_partial_body(lw, n_out, vb, nb, sh, ESS_THREADS);
         if (tid == 0) part[vb] = v;
         __syncthreads();
     }
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(ESS_THREADS) void k_tail_small(TailArgs a, int* __r
             a.stats_out[0] = (float)ess; a.stats_out[1] = (float)logz; a.stats_out[2] = (float)n_out;
         }
     } else {
-        ess_final_body(part, nb, n_out, a.n_norm, a.stats_out, sh);
+        ess_final_body(part, nb, n_out, a.n_norm, a.stats_out, sh, ESS_THREADS);
     }
 }
 
@@ -1328,7 +1338,7 @@ int tail_small(const TailArgs& a, int* dest, hipStream_t st) {
     const int nb = grid_for(a.B, ESS_THREADS * 4, ESS_MAX_BLOCKS);          // fabhip_ess_logz's grid for the same row capacity
     const size_t bytes = (size_t)TAIL_CHUNK * (3 * a.D + 4) * 4;
     if (bytes > 48 * 1024) return FABHIP_ENOTSUP;
-    hipLaunchKernelGGL(k_tail_small, dim3(1), dim3(ESS_THREADS), bytes, st, a, dest, nb);
+    hipLaunchKernelGGL(k_tail_small, dim3(1), dim3(TAIL_THREADS), bytes, st, a, dest, nb);
     return check_launch();
 }
 

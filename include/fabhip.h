@@ -102,7 +102,7 @@ int fabhip_get_fast_mode(void);
                                             16 = the 16x16x4 kernel */
 #define FABHIP_OPT_SPLINE_LEAP 7         /* FABHIP_SPLINE_LEAP: fused spline transitions: 1 = one launch per leapfrog (half steps and
                                             the target inside the 4x4x1 spline density kernel, default), 0 = four launches */
-#define FABHIP_OPT_FUSED_TAIL 8          /* FABHIP_FUSED_TAIL: AIS calls of <= 8192 chains: 1 = the compaction + ESS / log Z after the chain
+#define FABHIP_OPT_FUSED_TAIL 8          /* FABHIP_FUSED_TAIL: AIS calls of <= 2048 chains: 1 = the compaction + ESS / log Z after the chain
                                             initialisation and after the last transition in ONE launch each (default), 0 = the six / five
                                             separate kernels (the same results, bit for bit) */
 #define FABHIP_OPT_ADAPT_FOLD 9          /* FABHIP_ADAPT_FOLD: fused AIS calls on 4- / 8-chain tiles: 1 = the step-size rule runs in the LAST
