@@ -158,7 +158,7 @@ class HipShardBackend:
         ais, op = self.ais, self.op
         flow, target = ais._native_parts()
         alpha = float(ais.alpha) if ais.alpha is not None else 0.0
-        return (*flow.native(), *target.native_target(), [float(v) for v in ais.B_space], alpha, bool(ais.p_target),
+        return (*flow.native(), *target.native_target(), ais._betas(), alpha, bool(ais.p_target),
                 self._ops_mod.TRANSITION_HMC)
 
     def _phase(self, st, phases, j0, j1, partials=None, tune=False):
@@ -184,13 +184,14 @@ class HipShardBackend:
         dev = flow._nf_model.q0.loc.device
         D, M = flow.dim, self.n_transitions
         f32 = dict(dtype=torch.float32, device=dev)
+        counts_stats = torch.zeros(18, **f32)                 # stats[16] | n_valid[2]: ONE device->host read at the end
         st = {"b": int(b),
               "eps0": (torch.randn((b, D), **f32) if eps0 is None else eps0.contiguous()),
               "noise_a": (torch.randn((M, 1, b, D), **f32) if noise_a is None else noise_a.contiguous()),
               "noise_b": (torch.empty((M, 1, b), **f32).exponential_(1.0) if noise_b is None else noise_b.contiguous()),
               "x": torch.empty((b, D), **f32), "lq": torch.empty(b, **f32), "lp": torch.empty(b, **f32),
               "gq": torch.empty((b, D), **f32), "gp": torch.empty((b, D), **f32), "log_w": torch.empty(b, **f32),
-              "n_valid": torch.zeros(2, dtype=torch.int32, device=dev), "stats": torch.zeros(16, **f32),
+              "n_valid": counts_stats[16:18].view(torch.int32), "stats": counts_stats[:16],
               "slab": torch.empty(int(self.ops.hmc_partials_floats(int(b))), **f32)}
         self._phase(st, 1, 1, 0)
         return st
@@ -211,13 +212,12 @@ class HipShardBackend:
         """"chain end" filter + local ESS / log Z (FABHIP_AIS_FINISH); one device->host read for the row counts."""
         from .point import Point
         self._phase(st, 2, 1, 0)
-        host = torch.cat([st["n_valid"].float(), st["stats"][:6]]).cpu()
-        n_init, n_end = int(host[0]), int(host[1])
+        hs, (n_init, n_end) = self._ops_mod.read_counts_and_stats(st["n_valid"], st["stats"])
         # a shard without survivors is NOT an error here: the other ranks are about to enter the particle all-gather, and one
         # device holding every chain would only fail if NO chain survived - the caller decides from the gathered set, on every
         # rank alike (ADVICE r3: a rank-local raise left the others blocked in the collective)
         from .ais import LoggingInfo                      # this rank's own chains (the gathered set: logging_info)
-        self.ais._logging_info = LoggingInfo(ess_base=float(host[2]), ess_ais=float(host[5]), log_Z=float(host[6]))
+        self.ais._logging_info = LoggingInfo(ess_base=float(hs[0]), ess_ais=float(hs[3]), log_Z=float(hs[4]))
         pt = Point(st["x"][:n_end], st["lq"][:n_end], st["lp"][:n_end], st["gq"][:n_end], st["gp"][:n_end])
         return pt, st["log_w"][:n_end].detach()
 
