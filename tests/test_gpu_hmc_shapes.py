@@ -325,3 +325,41 @@ def test_four_chain_flow_sample_matches_sixteen_chain_sample_and_the_oracle(D, K
     assert max_rel_err(x4, x16) <= 5e-6 and max_rel_err(lq4, lq16) <= 5e-6
     assert max_rel_err(x4.cpu(), xo) <= 1e-5 and max_rel_err(lq4.cpu(), lqo) <= 1e-5
     assert max_rel_err(hf.log_prob(x4), lq4) <= 1e-5
+
+
+@pytest.mark.parametrize("B", [1024, 2048])
+def test_in_kernel_step_size_rule_is_race_free_over_many_calls(B):
+    """The last-wave step-size rule (hmc_adapt_last: device-scope relaxed atomics + a ticket across the 8 XCDs' L2s) against the
+    separate k_hmc_adapt launch over 120 consecutive AIS calls of the headline architecture (8 transitions each, step sizes
+    carried from call to call): the step-size state after every call and a checksum of every call's log-weights are bit-identical.
+    A lost or stale per-chain value anywhere in ~1000 launches would change a sum and with it every later step size."""
+    D, K, M = 32, 10, 8
+    torch.manual_seed(4)
+    flow = fa.RealNVP(D, K, 10).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.03 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    ops = _ops.load()
+    trace = {}
+    try:
+        for mode in (1, 0):
+            ops.set_option(_ops.OPT_ADAPT_FOLD, mode)
+            hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.1,
+                                           n_outer=1, L=2).to(DEV)
+            ais = fa.AnnealedImportanceSampler(flow, target.log_prob, hmc, p_target=False, alpha=2.0,
+                                               n_intermediate_distributions=M)
+            torch.manual_seed(99)
+            rows = []
+            for _ in range(120):
+                res = ais.run(B)
+                rows.append(torch.cat([hmc.epsilons.flatten(), hmc.common_epsilon.flatten(), res[1].double().sum().float().reshape(1),
+                                       res[3][:6]]).clone())
+            trace[mode] = torch.stack(rows)
+    finally:
+        ops.set_option(_ops.OPT_ADAPT_FOLD, 1)
+    a, b = trace[1].view(torch.int32), trace[0].view(torch.int32)
+    bad = (a != b).any(dim=1).nonzero().flatten()
+    assert bad.numel() == 0, f"first differing call: {int(bad[0])} of 120"
+    assert not torch.equal(trace[1][0, :M], trace[1][-1, :M])                        # the step sizes did move
