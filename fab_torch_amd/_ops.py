@@ -160,6 +160,9 @@ def owner_token(obj):
     return (PROC_NONCE, id(obj))
 
 
+# the host thread spins on the copy's event while it waits for the end of a call (a core at 100 % for the call's few milliseconds:
+# what a latency-bound sampler wants); FABHIP_POLL_READS=0 (or `_ops.POLL_READS = False`) blocks in the driver instead
+POLL_READS = os.environ.get("FABHIP_POLL_READS", "1") != "0"
 _pinned = threading.local()          # (per thread: the buffer is handed back to the caller)
 
 
@@ -177,9 +180,12 @@ def _read_small(t: torch.Tensor) -> torch.Tensor:
     buf, ev = ent
     buf.copy_(t, non_blocking=True)
     ev.record()
-    for _ in range(200000):
-        if ev.query():
-            break
+    if POLL_READS:
+        for _ in range(200000):
+            if ev.query():
+                break
+        else:
+            ev.synchronize()
     else:
         ev.synchronize()
     return buf                                          # (valid until the next read of the same size on this device)
