@@ -32,6 +32,34 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert b"workspace" in lib.fabhip_strerror(-4)
 
 
+def test_abi_revision_and_developer_switches_without_gpu():
+    """The ABI revision of the header, of both bindings and of the library agree; every developer switch of the header exists in
+    the library with the default the header documents (the round-4 paths - one-launch phase tails, the in-kernel step-size rule,
+    fused spline leapfrogs - are ON by default) and can be set / restored; an unknown key is rejected."""
+    from fab_torch_amd import _ops
+    lib = _lib.load()
+    txt = open(os.path.join(ROOT, "include", "fabhip.h")).read()
+    rev = int(re.search(r"#define FABHIP_ABI_VERSION (\d+)", txt).group(1))
+    assert lib.fabhip_version() == rev == _lib.ABI_VERSION == _ops.ABI_VERSION
+    keys = dict(re.findall(r"#define (FABHIP_OPT_[A-Z0-9_]+) (\d+)", txt))
+    count = int(keys.pop("FABHIP_OPT_COUNT"))
+    assert sorted(int(v) for v in keys.values()) == list(range(count)) == list(range(10))
+    defaults = {"FABHIP_OPT_TILE_SHAPE": 0, "FABHIP_OPT_R4_STREAM": 1, "FABHIP_OPT_SCAN_VARIANT": 3, "FABHIP_OPT_SYSTEMATIC_VARIANT": 1,
+                "FABHIP_OPT_SPLINE_STAGED": 0, "FABHIP_OPT_TIMELINE": 0, "FABHIP_OPT_SPLINE_MFMA": 0, "FABHIP_OPT_SPLINE_LEAP": 1,
+                "FABHIP_OPT_FUSED_TAIL": 1, "FABHIP_OPT_ADAPT_FOLD": 1}
+    for name, key in keys.items():
+        env = name.replace("FABHIP_OPT_", "FABHIP_").replace("TILE_SHAPE", "TILE")
+        if env in os.environ:
+            continue                                                   # (the library read the developer's override at load time)
+        assert lib.fabhip_get_option(int(key)) == defaults[name], name
+    assert (_ops.OPT_FUSED_TAIL, _ops.OPT_ADAPT_FOLD) == (int(keys["FABHIP_OPT_FUSED_TAIL"]), int(keys["FABHIP_OPT_ADAPT_FOLD"]))
+    prev = lib.fabhip_set_option(int(keys["FABHIP_OPT_ADAPT_FOLD"]), 0)
+    assert prev == 1 and lib.fabhip_get_option(int(keys["FABHIP_OPT_ADAPT_FOLD"])) == 0
+    lib.fabhip_set_option(int(keys["FABHIP_OPT_ADAPT_FOLD"]), prev)
+    assert lib.fabhip_set_option(count, 1) < 0 and lib.fabhip_get_option(-1) < 0
+    assert {"FABHIP_AIS_INIT = 1", "FABHIP_AIS_FINISH = 2", "FABHIP_AIS_CONTINUE = 4"} <= set(re.findall(r"FABHIP_AIS_[A-Z]+ = \d", txt))
+
+
 def test_geometry_queries_and_argument_validation_without_gpu():
     lib = _lib.load()
     n = lib.fabhip_flow_packed_floats(32, 10, 320)
