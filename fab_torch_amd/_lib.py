@@ -104,8 +104,9 @@ SYMBOLS = [
     "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_set_option", "fabhip_get_option", "fabhip_ais_phase", "fabhip_hmc_partials_floats",
     "fabhip_hmc_adapt_gathered", "fabhip_spline_hmc_workspace_bytes", "fabhip_spline_hmc_transition",
     "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_tape_gemm", "fabhip_debug_spline_timeline",
+    "fabhip_metropolis_partials_floats", "fabhip_metropolis_adapt_gathered",
 ]
-ABI_VERSION = 211          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 212          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):
@@ -136,6 +137,9 @@ def _declare(lib):
     lib.fabhip_hmc_partials_floats.restype = i64
     lib.fabhip_hmc_partials_floats.argtypes = [i64]
     lib.fabhip_hmc_adapt_gathered.argtypes = [vp, i32, i64, vp, vp, C.c_float, i32, vp, vp, vp]
+    lib.fabhip_metropolis_partials_floats.restype = i64
+    lib.fabhip_metropolis_partials_floats.argtypes = [i64, i32, i32]
+    lib.fabhip_metropolis_adapt_gathered.argtypes = [vp, i32, i64, i32, i32, vp, C.c_float, i32, vp]
     lib.fabhip_set_option.argtypes = [C.c_int, C.c_int]
     lib.fabhip_get_option.argtypes = [C.c_int]
     lib.fabhip_ess_workspace_bytes.restype = sz

@@ -936,6 +936,34 @@ __global__ void k_metropolis_adapt(const float* __restrict__ part_acc, int nblk,
     scalings[n] = (p_accept > target_p_accept) ? scalings[n] * 1.05f : scalings[n] / 1.05f;
 }
 
+// Sharded chains: a Metropolis transition whose block sums went into the caller's slab instead of part_acc
+// appends the number of chains in use; the rule then runs on the slabs of ALL ranks.  noise_scalings[i - 1, n] is read by
+// update n of transition i only (metropolis.py:57) and adjusted right after it (:68-73): nothing later in the SAME AIS call
+// reads the adjusted value, so the adjustments of all M transitions can wait for ONE gather at the end of the call.
+__global__ void k_metropolis_count(const int* n_valid, long B, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = (float)(n_valid ? (long)*n_valid : B);
+}
+
+// thread (j, n) = transition j, update n: block sums over ranks, then blocks, in order - with shards that are multiples of 16
+// chains the sequence k_metropolis_adapt adds on one device holding every chain
+__global__ void k_metropolis_adapt_gathered(const float* __restrict__ slabs, int n_ranks, int nblk, int M, int n_updates,
+                                            float* scalings, float target_p_accept, int tune) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M * n_updates || !tune) return;
+    const int j = t / n_updates, n = t % n_updates;
+    const long per_j = (long)n_updates * nblk + 1, per_rank = (long)M * per_j;
+    float s = 0.f;
+    long nv = 0;
+    for (int r = 0; r < n_ranks; ++r) {
+        const float* sl = slabs + r * per_rank + j * per_j;
+        for (int i = 0; i < nblk; ++i) s += sl[n * nblk + i];
+        nv += (long)sl[per_j - 1];
+    }
+    if (nv <= 0) return;
+    const float p_accept = s / (float)nv;
+    scalings[t] = (p_accept > target_p_accept) ? scalings[t] * 1.05f : scalings[t] / 1.05f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // _remove_nan_and_infs (ais.py:190-213): stable compaction of the rows with finite log_p and log_q.
 // ------------------------------------------------------------------------------------------------
@@ -1259,7 +1287,7 @@ static int hmc_transition_impl(const fabhip_hmc_args* a, hipStream_t st, int* ti
     return FABHIP_OK;
 }
 
-static int metropolis_transition_impl(const fabhip_metropolis_args* a, hipStream_t st) {
+static int metropolis_transition_impl(const fabhip_metropolis_args* a, hipStream_t st, float* partials = nullptr) {
     const FlowDims f = flow_dims_of(a->flow);
     const TargetDev tg = make_target_dev(a->target);
     const int nblk = nblk_of(a->B);
@@ -1267,8 +1295,13 @@ static int metropolis_transition_impl(const fabhip_metropolis_args* a, hipStream
     MetK k;
     k.cur = make_point_dev(a->point); k.B = a->B; k.n_valid = a->n_valid; k.c = a->cur; k.nx = a->next;
     k.log_w = a->log_w; k.noise_x = a->noise_x; k.noise_u = a->noise_u; k.scalings = a->noise_scalings;
-    k.n_updates = a->n_updates; k.part_acc = (float*)a->workspace; k.nblk = nblk;
+    k.n_updates = a->n_updates; k.part_acc = partials ? partials : (float*)a->workspace; k.nblk = nblk;
     FAB_DISPATCH_NTW_NORET(f, launch_metropolis, f, a->flow.packed, tg, k, st);
+    if (partials) {                  // deferred rule (sharded chains): [n_updates][nblk] block sums | chains in use
+        hipLaunchKernelGGL(k_metropolis_count, dim3(1), dim3(1), 0, st, a->n_valid, (long)a->B,
+                           partials + (size_t)a->n_updates * nblk);
+        return check_launch();
+    }
     hipLaunchKernelGGL(k_metropolis_adapt, dim3(1), dim3(64), 0, st, k.part_acc, nblk, a->n_updates, a->n_valid,
                        (long)a->B, a->noise_scalings, a->target_p_accept, a->tune);
     return check_launch();
@@ -1328,6 +1361,19 @@ int fabhip_hmc_adapt_gathered(const float* gathered, int32_t n_ranks, int64_t B_
     if (!gathered || n_ranks < 1 || B_rank < 1 || !epsilon || !common_epsilon) return FABHIP_EINVAL;
     hipLaunchKernelGGL(k_hmc_adapt_gathered, dim3(1), dim3(64), 0, (hipStream_t)stream, gathered, n_ranks, nblk_of(B_rank),
                        epsilon, common_epsilon, target_p_accept, tune, p_accept, avg_distance);
+    return check_launch();
+}
+
+int64_t fabhip_metropolis_partials_floats(int64_t B, int32_t M, int32_t n_updates) {
+    return (B < 0 || M < 1 || n_updates < 1) ? -1 : (int64_t)M * ((int64_t)n_updates * nblk_of(B) + 1);
+}
+
+int fabhip_metropolis_adapt_gathered(const float* gathered, int32_t n_ranks, int64_t B_rank, int32_t M, int32_t n_updates,
+                                     float* noise_scalings, float target_p_accept, int32_t tune, fabhip_stream_t stream) {
+    if (!gathered || n_ranks < 1 || B_rank < 1 || M < 1 || n_updates < 1 || !noise_scalings) return FABHIP_EINVAL;
+    const int n = M * n_updates;
+    hipLaunchKernelGGL(k_metropolis_adapt_gathered, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, gathered, n_ranks,
+                       nblk_of(B_rank), M, n_updates, noise_scalings, target_p_accept, tune);
     return check_launch();
 }
 
@@ -1555,7 +1601,7 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     const bool ws_kept = do_init || (phases & FABHIP_AIS_CONTINUE) != 0;              // the ticket word of this workspace is zero
     if (do_init && !a->eps0) return FABHIP_EINVAL;
     if (j_begin <= j_end && (j_begin < 1 || j_end > a->M)) return FABHIP_EINVAL;
-    if (partials && (j_begin != j_end || a->transition != FABHIP_TRANSITION_HMC)) return FABHIP_ENOTSUP;
+    if (partials && a->transition == FABHIP_TRANSITION_HMC && j_begin != j_end) return FABHIP_ENOTSUP;
     const bool hmc = a->transition == FABHIP_TRANSITION_HMC;
     if (!hmc && a->transition != FABHIP_TRANSITION_METROPOLIS) return FABHIP_EINVAL;
     if (hmc && (!a->common_epsilon || !a->mass)) return FABHIP_EINVAL;
@@ -1644,7 +1690,9 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
             m.noise_scalings = a->step_state + nslab; m.n_updates = a->n_inner;
             m.target_p_accept = a->target_p_accept; m.tune = a->tune;
             m.workspace = trans_ws; m.workspace_bytes = tws;
-            FAB_TRY(metropolis_transition_impl(&m, st));
+            // deferred rule: transition j's block sums + count at slab offset (j - 1) (n_updates nblk + 1)
+            FAB_TRY(metropolis_transition_impl(&m, st, partials ? partials + (size_t)(j - 1) * ((size_t)a->n_inner * nblk_of(B) + 1)
+                                                                 : nullptr));
         }
     }
     // 5. remove nan/inf ("chain end"), 6. ESS / log Z over the survivors (ais.py:77-86)

@@ -19,8 +19,11 @@
 #include <ATen/hip/impl/HIPStreamMasqueradingAsCUDA.h>
 #include <c10/core/DeviceGuard.h>
 #include <torch/library.h>
+#include <torch/csrc/distributed/c10d/GroupRegistry.hpp>
+#include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "../../include/fabhip.h"
@@ -841,7 +844,10 @@ std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tensor, Tenso
 // The same call in pieces (fabhip_ais_phase): the state tensors are the caller's, in/out across the phases of one AIS
 // run.  Used when chains are sharded over ranks and the step sizes adapt on the acceptance of ALL chains: one transition
 // per call with `partials`, the caller all-gathers the slabs and calls hmc_adapt_gathered (fab_torch_amd/parallel.py).
-void ais_phase(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind, at::ArrayRef<double> prm,
+// `group_name` == nullptr: the phases / transitions the caller names, once.  Otherwise the WHOLE tuned call of one shard:
+// INIT, then per transition {transition with the adaptation deferred, slab all-gather over the named c10d process group,
+// step-size rule on the gathered slabs}, FINISH - see ais_sharded_tuned below.  Returns the number of collectives issued.
+int64_t ais_phase_core(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind, at::ArrayRef<double> prm,
                const optional<Tensor>& locs, const optional<Tensor>& scales, at::ArrayRef<double> betas, double alpha,
                bool p_target, int64_t transition, int64_t phases, int64_t j_begin, int64_t j_end,
                const optional<Tensor>& eps0, const Tensor& noise_a, const Tensor& noise_b, Tensor step_state,
@@ -849,7 +855,8 @@ void ais_phase(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t widt
                double target_p_accept, bool tune, Tensor x, Tensor log_q, Tensor log_p, optional<Tensor> grad_log_q,
                optional<Tensor> grad_log_p, Tensor log_w, Tensor n_valid, Tensor stats, optional<Tensor> partials,
                optional<Tensor> p_accept_first, optional<Tensor> p_accept_last, optional<Tensor> avg_distance_first,
-               optional<Tensor> avg_distance_last, optional<Tensor> base_x, optional<Tensor> base_log_w, int64_t precision) {
+               optional<Tensor> avg_distance_last, optional<Tensor> base_x, optional<Tensor> base_log_w, int64_t precision,
+               const std::string* group_name) {
     c10::DeviceGuard g(x.device());
     fabhip_ais_args a;
     a.flow = make_flow(packed, dim, n_layers, width, precision);
@@ -889,8 +896,92 @@ void ais_phase(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t widt
     const size_t nb = fabhip_ais_workspace_bytes(B, (int32_t)dim, (int32_t)n_inner);
     Tensor ws = scratch(nb, x);
     a.workspace = aligned(ws); a.workspace_bytes = nb;
-    float* slab = fpmn_opt(partials, fabhip_hmc_partials_floats(B), x, "partials");
-    chk(fabhip_ais_phase(&a, (int32_t)phases, (int32_t)j_begin, (int32_t)j_end, slab, stream_of(x)), "ais_phase");
+    float* slab = fpmn_opt(partials, hmc ? fabhip_hmc_partials_floats(B)
+                                         : fabhip_metropolis_partials_floats(B, (int32_t)M, (int32_t)n_inner), x, "partials");
+    if (group_name == nullptr) {
+        chk(fabhip_ais_phase(&a, (int32_t)phases, (int32_t)j_begin, (int32_t)j_end, slab, stream_of(x)), "ais_phase");
+        return 0;
+    }
+    // ---- one shard's tuned call: the loop fab_torch_amd/parallel.py stepped from Python in rounds 2 - 4 ----
+    TORCH_CHECK(hmc && n_inner == 1 && slab != nullptr,
+                "fabhip: ais_sharded_tuned is HMC with n_outer == 1 and needs the acceptance slab (hmc_partials_floats(B) floats)");
+    auto pg = c10d::resolve_process_group(*group_name);
+    const int64_t world = pg->getSize(), nslab = fabhip_hmc_partials_floats(B);
+    // RCCL ("nccl") takes the device slab as it is: the collective is ordered behind the transition on the current stream
+    // and Work::wait() orders the stream behind the collective - the host never blocks.  A host-only backend (gloo: the
+    // CPU-side tests of the N > 1 path, two ranks on a one-GPU box) is fed through the host.
+    bool device_collective = false;
+    try {
+        device_collective = pg->getBackend(c10::DeviceType::CUDA)->getBackendName() == "nccl";
+    } catch (const std::exception&) {                     // no backend registered for device tensors: through the host
+    }
+    Tensor gathered = fempty({world * nslab}, x), host_in, host_out;
+    if (!device_collective) {
+        host_in = at::empty({nslab}, at::TensorOptions().dtype(at::kFloat).device(at::kCPU));
+        host_out = at::empty({world * nslab}, host_in.options());
+    }
+    const fabhip_stream_t st = stream_of(x);
+    chk(fabhip_ais_phase(&a, FABHIP_AIS_INIT, 1, 0, nullptr, st), "ais_sharded_tuned (chain initialisation)");
+    int64_t n_collectives = 0;
+    for (int64_t j = 1; j <= M; ++j) {
+        chk(fabhip_ais_phase(&a, 0, (int32_t)j, (int32_t)j, slab, st), "ais_sharded_tuned (transition)");
+        if (world > 1) {
+            if (device_collective) {
+                pg->_allgather_base(gathered, *partials)->wait();
+            } else {
+                host_in.copy_(*partials);
+                pg->_allgather_base(host_out, host_in)->wait();
+                gathered.copy_(host_out);
+            }
+            ++n_collectives;
+        } else {
+            gathered.copy_(*partials);
+        }
+        float* pa = j == 1 ? a.p_accept_first : (j == M ? a.p_accept_last : nullptr);        // hmc.py:173-183 (store_info)
+        float* ad = j == 1 ? a.avg_distance_first : (j == M ? a.avg_distance_last : nullptr);
+        chk(fabhip_hmc_adapt_gathered(gathered.data_ptr<float>(), (int32_t)world, B, a.step_state + (j - 1), a.common_epsilon,
+                                      a.target_p_accept, 1, pa, ad, st),
+            "ais_sharded_tuned (step-size rule on the gathered slabs)");
+    }
+    chk(fabhip_ais_phase(&a, FABHIP_AIS_FINISH, 1, 0, nullptr, st), "ais_sharded_tuned (chain end)");
+    return n_collectives;
+}
+
+void ais_phase(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind, at::ArrayRef<double> prm,
+               const optional<Tensor>& locs, const optional<Tensor>& scales, at::ArrayRef<double> betas, double alpha,
+               bool p_target, int64_t transition, int64_t phases, int64_t j_begin, int64_t j_end,
+               const optional<Tensor>& eps0, const Tensor& noise_a, const Tensor& noise_b, Tensor step_state,
+               optional<Tensor> common_epsilon, const optional<Tensor>& mass, int64_t n_inner, int64_t L, double max_grad,
+               double target_p_accept, bool tune, Tensor x, Tensor log_q, Tensor log_p, optional<Tensor> grad_log_q,
+               optional<Tensor> grad_log_p, Tensor log_w, Tensor n_valid, Tensor stats, optional<Tensor> partials,
+               optional<Tensor> p_accept_first, optional<Tensor> p_accept_last, optional<Tensor> avg_distance_first,
+               optional<Tensor> avg_distance_last, optional<Tensor> base_x, optional<Tensor> base_log_w, int64_t precision) {
+    ais_phase_core(packed, dim, n_layers, width, kind, prm, locs, scales, betas, alpha, p_target, transition, phases, j_begin,
+                   j_end, eps0, noise_a, noise_b, step_state, common_epsilon, mass, n_inner, L, max_grad, target_p_accept, tune,
+                   x, log_q, log_p, grad_log_q, grad_log_p, log_w, n_valid, stats, partials, p_accept_first, p_accept_last,
+                   avg_distance_first, avg_distance_last, base_x, base_log_w, precision, nullptr);
+}
+
+// One shard's WHOLE tuned AIS call in one op: chain initialisation, M x {HMC transition publishing its
+// acceptance slab, ONE all-gather of the slabs through the c10d process group registered as `group_name` (RCCL over xGMI
+// on a GPU node), the step-size rule of hmc.py:162-170 on the joined slabs in rank order (fabhip_hmc_adapt_gathered: every
+// rank applies it to the same numbers)}, "chain end" filter + this shard's ESS / log Z.  Same kernels, same order and the
+// same values as fab_torch_amd/parallel.py's Python-stepped loop (kept as the reference implementation the tests compare
+// with); what goes is 2 M + 1 dispatcher round trips and M Python-level collectives per call.  Returns the collectives issued.
+int64_t ais_sharded_tuned(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t width, int64_t kind,
+                          at::ArrayRef<double> prm, const optional<Tensor>& locs, const optional<Tensor>& scales,
+                          at::ArrayRef<double> betas, double alpha, bool p_target, int64_t transition,
+                          const optional<Tensor>& eps0, const Tensor& noise_a, const Tensor& noise_b, Tensor step_state,
+                          optional<Tensor> common_epsilon, const optional<Tensor>& mass, int64_t L, double max_grad,
+                          double target_p_accept, Tensor x, Tensor log_q, Tensor log_p, optional<Tensor> grad_log_q,
+                          optional<Tensor> grad_log_p, Tensor log_w, Tensor n_valid, Tensor stats, Tensor partials,
+                          optional<Tensor> p_accept_first, optional<Tensor> p_accept_last,
+                          optional<Tensor> avg_distance_first, optional<Tensor> avg_distance_last, int64_t precision,
+                          std::string group_name) {
+    return ais_phase_core(packed, dim, n_layers, width, kind, prm, locs, scales, betas, alpha, p_target, transition, 0, 1, 0, eps0,
+                          noise_a, noise_b, step_state, common_epsilon, mass, 1, L, max_grad, target_p_accept, true, x, log_q,
+                          log_p, grad_log_q, grad_log_p, log_w, n_valid, stats, partials, p_accept_first, p_accept_last,
+                          avg_distance_first, avg_distance_last, c10::nullopt, c10::nullopt, precision, &group_name);
 }
 
 // Linear backward over a tape (fabhip_tape_gemm): Y / X are views INTO `tape` given as float offsets of layer 0
@@ -912,6 +1003,23 @@ std::tuple<Tensor, Tensor> tape_gemm(const Tensor& tape, int64_t layer_stride, i
 }
 
 int64_t hmc_partials_floats(int64_t B) { return fabhip_hmc_partials_floats(B); }
+int64_t metropolis_partials_floats(int64_t B, int64_t M, int64_t n_updates) {
+    return fabhip_metropolis_partials_floats(B, (int32_t)M, (int32_t)n_updates);
+}
+
+// metropolis.py:68-73 on the acceptance of ALL chains of a sharded batch, for the M transitions of one AIS call at once
+void metropolis_adapt_gathered(const Tensor& gathered, int64_t n_ranks, int64_t B_rank, Tensor noise_scalings,
+                               double target_p_accept, bool tune) {
+    c10::DeviceGuard g(gathered.device());
+    TORCH_CHECK(n_ranks >= 1 && B_rank >= 1 && noise_scalings.dim() == 2, "fabhip: metropolis_adapt_gathered needs n_ranks, "
+                "B_rank >= 1 and noise_scalings [M, n_updates]");
+    const int64_t M = noise_scalings.size(0), nu = noise_scalings.size(1);
+    need_n(gathered, n_ranks * fabhip_metropolis_partials_floats(B_rank, (int32_t)M, (int32_t)nu), gathered, "gathered partials");
+    chk(fabhip_metropolis_adapt_gathered(fp(gathered, "gathered partials"), (int32_t)n_ranks, B_rank, (int32_t)M, (int32_t)nu,
+                                         fpmn(noise_scalings, M * nu, gathered, "noise_scalings"), (float)target_p_accept,
+                                         tune ? 1 : 0, stream_of(gathered)),
+        "metropolis_adapt_gathered");
+}
 
 void hmc_adapt_gathered(const Tensor& gathered, int64_t n_ranks, int64_t B_rank, Tensor epsilon, Tensor common_epsilon,
                         double target_p_accept, bool tune, optional<Tensor> p_accept, optional<Tensor> avg_distance) {
@@ -1081,7 +1189,16 @@ TORCH_LIBRARY(fabhip, m) {
           "Tensor(i!) n_valid, Tensor(j!) stats, Tensor(k!)? partials, Tensor(l!)? p_accept_first, "
           "Tensor(m!)? p_accept_last, Tensor(n!)? avg_distance_first, Tensor(o!)? avg_distance_last, Tensor(p!)? base_x, "
           "Tensor(q!)? base_log_w, int precision=0) -> ()");
+    m.def("ais_sharded_tuned(" FLW ", " TGT ", float[] betas, float alpha, bool p_target, int transition, Tensor? eps0, "
+          "Tensor noise_a, Tensor noise_b, Tensor(a!) step_state, Tensor(b!)? common_epsilon, Tensor? mass, int L, "
+          "float max_grad, float target_p_accept, Tensor(c!) x, Tensor(d!) log_q, Tensor(e!) log_p, Tensor(f!)? grad_log_q, "
+          "Tensor(g!)? grad_log_p, Tensor(h!) log_w, Tensor(i!) n_valid, Tensor(j!) stats, Tensor(k!) partials, "
+          "Tensor(l!)? p_accept_first, Tensor(m!)? p_accept_last, Tensor(n!)? avg_distance_first, "
+          "Tensor(o!)? avg_distance_last, int precision, str group_name) -> int");
     m.def("hmc_partials_floats(int B) -> int", hmc_partials_floats);
+    m.def("metropolis_partials_floats(int B, int M, int n_updates) -> int", metropolis_partials_floats);
+    m.def("metropolis_adapt_gathered(Tensor gathered, int n_ranks, int B_rank, Tensor(a!) noise_scalings, "
+          "float target_p_accept, bool tune) -> ()");
     m.def("tape_gemm(Tensor tape, int layer_stride, int L, int off_y, int ldy, int P, int off_x, int ldx, int Q, Tensor coef, "
           "bool want_colsum) -> (Tensor, Tensor)");
     m.def("hmc_adapt_gathered(Tensor gathered, int n_ranks, int B_rank, Tensor(a!) epsilon, Tensor(b!) common_epsilon, "
@@ -1144,6 +1261,8 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("metropolis_transition", metropolis_transition);
     m.impl("ais_run", ais_run);
     m.impl("ais_phase", ais_phase);
+    m.impl("ais_sharded_tuned", ais_sharded_tuned);
+    m.impl("metropolis_adapt_gathered", metropolis_adapt_gathered);
     m.impl("tape_gemm", tape_gemm);
     m.impl("spline_ais_run", spline_ais_run);
     m.impl("hmc_adapt_gathered", hmc_adapt_gathered);

@@ -7,6 +7,9 @@ data-path collective until the particles are gathered.  Payload per rank: [B/R, 
 log_q) — a few hundred KiB, latency-bound on xGMI, hence a single direct all-gather (no ring of
 small buckets).
 
+Metropolis noise scalings (metropolis.py:68-73) adapt on the whole batch too: scaling (i, n) is read by update n of transition i
+only, so a sharded call defers the rule of all M transitions to ONE slab gather at its end (`run_metropolis_deferred`).
+
 Step sizes: the reference adapts every transition's step size on the mean acceptance of the WHOLE batch
 (hmc.py:122-123,162-170).  `ShardedAnnealedImportanceSampler` keeps exactly that: each transition publishes its acceptance
 sums per 16-chain block (a slab of 2 ceil(B/16R) + 1 floats), ONE tiny all-gather per transition joins the slabs in rank
@@ -136,9 +139,49 @@ class HipShardBackend:
 
     @property
     def tuning(self) -> bool:
-        """True when a transition's step size depends on the acceptance of the whole batch: HMC outside eval mode.
-        (Metropolis with `adjust_step_size` adapts per rank - cfg 1 runs it untuned, gmm.yaml:29-34.)"""
-        return self.hmc and not self.op.eval_mode
+        """True when a transition's step size depends on the acceptance of the whole batch: HMC outside eval mode (one
+        slab gather per transition: the next transition uses the adapted common step size), Metropolis with
+        `adjust_step_size` outside eval mode (`run_metropolis_deferred`: ONE gather at the end of the call)."""
+        if self.hmc:
+            return not self.op.eval_mode
+        return bool(getattr(self.op, "adjust_step_size", False)) and not self.op.eval_mode
+
+    def run_metropolis_deferred(self, b, eps0=None, noise_a=None, noise_b=None):
+        """This shard's whole Metropolis AIS call (one fabhip_ais_phase: INIT, transitions 1 .. M, FINISH) with the
+        noise-scaling rule of metropolis.py:68-73 deferred: scaling (i, n) is read by update n of transition i only, so
+        nothing inside the call depends on the adjusted values and the block sums of all M transitions travel in ONE slab
+        (fabhip_metropolis_partials_floats).  Returns (Point, log_w, slab); `adapt_metropolis` applies the rule to the
+        gathered slabs."""
+        from .transition_operators import Metropolis
+        op, ais = self.op, self.ais
+        if not isinstance(op, Metropolis) or not ais.is_native:
+            raise self._ops_mod.FabhipError("exact sharded noise-scaling adaptation needs fab_torch_amd's Metropolis over a "
+                                            "RealNVP flow and a native target; other plug-ins: set_eval_mode(True)")
+        if bool(op.p_target) != bool(ais.p_target) or (not ais.p_target and op.alpha != ais.alpha):
+            raise self._ops_mod.FabhipError("AIS and transition operator disagree on p_target / alpha")
+        flow, target = ais._native_parts()
+        dev = flow._nf_model.q0.loc.device
+        D, M, nu = flow.dim, self.n_transitions, int(op.n_updates)
+        f32 = dict(dtype=torch.float32, device=dev)
+        counts_stats = torch.zeros(18, **f32)
+        st = {"b": int(b), "x": torch.empty((b, D), **f32), "lq": torch.empty(b, **f32), "lp": torch.empty(b, **f32),
+              "log_w": torch.empty(b, **f32), "n_valid": counts_stats[16:18].view(torch.int32), "stats": counts_stats[:16]}
+        eps0 = torch.randn((b, D), **f32) if eps0 is None else eps0.contiguous()
+        noise_a = torch.randn((M, nu, b, D), **f32) if noise_a is None else noise_a.contiguous()
+        noise_b = torch.rand((M, nu, b), **f32) if noise_b is None else noise_b.contiguous()
+        slab = torch.empty(int(self.ops.metropolis_partials_floats(int(b), M, nu)), **f32)
+        alpha = float(ais.alpha) if ais.alpha is not None else 0.0
+        self.ops.ais_phase(*flow.native(), *target.native_target(), ais._betas(), alpha, bool(ais.p_target),
+                           self._ops_mod.TRANSITION_METROPOLIS, 3, 1, M, eps0, noise_a, noise_b, op.noise_scalings, None, None,
+                           nu, 0, 0.0, float(op.target_prob_accept), True, st["x"], st["lq"], st["lp"], None, None,
+                           st["log_w"], st["n_valid"], st["stats"], slab, None, None, None, None, None, None,
+                           self._ops_mod.precision_of(flow))
+        pt, log_w = self._collect(st, grads=False)
+        return pt, log_w, slab
+
+    def adapt_metropolis(self, gathered, world, b):
+        op = self.op
+        self.ops.metropolis_adapt_gathered(gathered, int(world), int(b), op.noise_scalings, float(op.target_prob_accept), True)
 
     def run_fused(self, b, eps0=None, noise_a=None, noise_b=None):
         from .point import Point
@@ -169,8 +212,30 @@ class HipShardBackend:
                            st["log_w"], st["n_valid"], st["stats"], partials, None, None, None, None, None, None,
                            self._ops_mod.precision_of(self.ais.base_distribution))
 
+    def run_tuned(self, b, group=None, eps0=None, noise_a=None, noise_b=None):
+        """The whole tuned call of this shard in ONE op (torch.ops.fabhip.ais_sharded_tuned, csrc/torch_ops.cpp): the loop
+        `begin` / M x (`step`, slab all-gather, `adapt`) / `finish` with the collectives issued from C++ through the c10d
+        process group (on RCCL: ordered on the compute stream, the host never blocks).  Returns (Point, log_w, collectives)."""
+        st = self._state(b, eps0, noise_a, noise_b)
+        op = self.op
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        n = self.ops.ais_sharded_tuned(*self._common(st), st["eps0"], st["noise_a"], st["noise_b"], op.epsilons,
+                                       op.common_epsilon, op.mass_vector, op.L, float(op.max_grad),
+                                       float(op.target_p_accept), st["x"], st["lq"], st["lp"], st["gq"], st["gp"],
+                                       st["log_w"], st["n_valid"], st["stats"], st["slab"], op._p_accept_first,
+                                       op._p_accept_last, op._dist_first, op._dist_last,
+                                       self._ops_mod.precision_of(self.ais.base_distribution), str(pg.group_name))
+        pt, log_w = self._collect(st)
+        return pt, log_w, int(n)
+
     def begin(self, b, eps0=None, noise_a=None, noise_b=None):
         """Chain initialisation + "chain init" filter + base ESS of this rank's b chains (FABHIP_AIS_INIT)."""
+        st = self._state(b, eps0, noise_a, noise_b)
+        self._phase(st, 1, 1, 0)
+        return st
+
+    def _state(self, b, eps0=None, noise_a=None, noise_b=None):
+        """Checks + the state tensors of one tuned call (noise drawn here: same generator, same order in both forms)."""
         if not self.hmc or self.op.n_outer != 1:
             raise self._ops_mod.FabhipError("exact sharded step-size adaptation: HMC with n_outer == 1 "
                                             "(every shipped config, experiments/setup_run.py:190)")
@@ -193,7 +258,6 @@ class HipShardBackend:
               "gq": torch.empty((b, D), **f32), "gp": torch.empty((b, D), **f32), "log_w": torch.empty(b, **f32),
               "n_valid": counts_stats[16:18].view(torch.int32), "stats": counts_stats[:16],
               "slab": torch.empty(int(self.ops.hmc_partials_floats(int(b))), **f32)}
-        self._phase(st, 1, 1, 0)
         return st
 
     def step(self, st, j) -> torch.Tensor:
@@ -210,15 +274,19 @@ class HipShardBackend:
 
     def finish(self, st):
         """"chain end" filter + local ESS / log Z (FABHIP_AIS_FINISH); one device->host read for the row counts."""
-        from .point import Point
         self._phase(st, 2, 1, 0)
+        return self._collect(st)
+
+    def _collect(self, st, grads=True):
+        from .point import Point
         hs, (n_init, n_end) = self._ops_mod.read_counts_and_stats(st["n_valid"], st["stats"])
         # a shard without survivors is NOT an error here: the other ranks are about to enter the particle all-gather, and one
         # device holding every chain would only fail if NO chain survived - the caller decides from the gathered set, on every
         # rank alike (ADVICE r3: a rank-local raise left the others blocked in the collective)
         from .ais import LoggingInfo                      # this rank's own chains (the gathered set: logging_info)
         self.ais._logging_info = LoggingInfo(ess_base=float(hs[0]), ess_ais=float(hs[3]), log_Z=float(hs[4]))
-        pt = Point(st["x"][:n_end], st["lq"][:n_end], st["lp"][:n_end], st["gq"][:n_end], st["gp"][:n_end])
+        pt = Point(st["x"][:n_end], st["lq"][:n_end], st["lp"][:n_end], st["gq"][:n_end] if grads else None,
+                   st["gp"][:n_end] if grads else None)
         return pt, st["log_w"][:n_end].detach()
 
 
@@ -234,9 +302,13 @@ class ShardedAnnealedImportanceSampler:
     use the same tile shape (`FABHIP_OPT_TILE_SHAPE`, or batches that select the same one: chains per workgroup follow the
     LOCAL batch)."""
 
-    def __init__(self, ais=None, group=None, backend=None):
+    def __init__(self, ais=None, group=None, backend=None, one_op: Optional[bool] = None):
+        import os
         self.group = group
         self.backend = backend if backend is not None else HipShardBackend(ais)
+        # tuned calls: one op per call (default) or the Python-stepped loop it replaced (FABHIP_SHARDED_ONE_OP=0: kept as
+        # the reference implementation - tests/test_gpu_sharded.py compares the two bit for bit)
+        self.one_op = (os.environ.get("FABHIP_SHARDED_ONE_OP", "1") != "0") if one_op is None else bool(one_op)
         self.logging_info = None
         self.n_slab_gathers = 0                 # collectives issued by the last call besides the particle gather
 
@@ -254,6 +326,12 @@ class ShardedAnnealedImportanceSampler:
         self.n_slab_gathers = 0
         if world == 1 or not be.tuning:
             pt, log_w = be.run_fused(b, eps0, noise_a, noise_b)
+        elif not getattr(be, "hmc", True):                 # Metropolis: the whole call, then ONE slab gather + the rule
+            pt, log_w, slab = be.run_metropolis_deferred(b, eps0, noise_a, noise_b)
+            be.adapt_metropolis(all_gather_rows(slab.reshape(1, -1), self.group).reshape(-1), world, b)
+            self.n_slab_gathers = 1
+        elif self.one_op and hasattr(be, "run_tuned"):     # the loop below, inside one op (collectives issued from C++)
+            pt, log_w, self.n_slab_gathers = be.run_tuned(b, self.group, eps0, noise_a, noise_b)
         else:
             st = be.begin(b, eps0, noise_a, noise_b)
             for j in range(1, be.n_transitions + 1):

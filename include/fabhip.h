@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 211
+#define FABHIP_ABI_VERSION 212
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -384,6 +384,17 @@ typedef struct {
     size_t workspace_bytes;
 } fabhip_metropolis_args;
 
+/* Noise-scaling adaptation of metropolis.py:68-73 on the mean acceptance of ALL chains of a sharded batch.  The scaling
+ * of (transition i, update n) is read by that update only and adjusted right after it: nothing later in the same AIS call
+ * reads the adjusted value, so a sharded call defers the rule of all M transitions to ONE gather at its end.  `gathered` =
+ * the slabs of n_ranks ranks in rank order, each fabhip_metropolis_partials_floats(B_rank, M, n_updates) floats:
+ * per transition [n_updates][ceil(B_rank / 16)] sums of min(1, acceptance) per 16-chain block, then the chains in use
+ * (fabhip_ais_phase with `partials`).  Sums run over ranks, then blocks, in order: with shards that are multiples of 16
+ * chains exactly what one device adds, so every rank ends with the single-device noise_scalings [M][n_updates] bit for bit. */
+int64_t fabhip_metropolis_partials_floats(int64_t B, int32_t M, int32_t n_updates);
+int fabhip_metropolis_adapt_gathered(const float* gathered, int32_t n_ranks, int64_t B_rank, int32_t M, int32_t n_updates,
+                                     float* noise_scalings, float target_p_accept, int32_t tune, fabhip_stream_t stream);
+
 size_t fabhip_metropolis_workspace_bytes(int64_t B, int32_t dim, int32_t n_updates);
 int fabhip_metropolis_transition(const fabhip_metropolis_args* args, fabhip_stream_t stream);
 
@@ -491,7 +502,10 @@ int fabhip_ais_run(const fabhip_ais_args* args, fabhip_stream_t stream);
  * j_begin > j_end: none) and FABHIP_AIS_FINISH ("chain end" filter, ESS / log Z).  point / log_w / n_valid / stats are
  * in/out across the calls of one AIS run, eps0 is read by INIT only.  With `partials` != NULL (HMC, n_inner == 1,
  * j_begin == j_end) the transition leaves the step sizes alone and publishes its acceptance slab instead
- * (fabhip_hmc_args.partials); fabhip_ais_run(args) == fabhip_ais_phase(args, INIT | FINISH, 1, M, NULL). */
+ * (fabhip_hmc_args.partials); fabhip_ais_run(args) == fabhip_ais_phase(args, INIT | FINISH, 1, M, NULL).
+ * Metropolis with `partials` != NULL (any j range, one call may hold the whole run): transition j leaves its noise scalings
+ * alone and writes its block sums + chain count at partials + (j - 1) (n_inner nblk + 1) - the layout of
+ * fabhip_metropolis_partials_floats(B, M, n_inner) - for fabhip_metropolis_adapt_gathered after the call. */
 enum { FABHIP_AIS_INIT = 1, FABHIP_AIS_FINISH = 2,
        FABHIP_AIS_CONTINUE = 4 };   /* this call continues a run whose INIT phase was enqueued with the SAME workspace on the same
                                       * stream and nothing else touched the workspace since (lets the later phases keep using the

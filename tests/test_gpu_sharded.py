@@ -77,6 +77,42 @@ def test_emulated_shards_reproduce_the_fused_single_device_run_bit_for_bit(total
     assert torch.equal(torch.cat([o[0].log_q for o in outs]), pt.log_q)
 
 
+def test_one_op_tuned_call_on_a_one_rank_group_is_the_fused_single_device_call(tmp_path):
+    """`ais_sharded_tuned` on a process group of ONE rank (its C++ loop: init, M x {transition with the adaptation deferred,
+    slab "gather", rule on the slab}, finish) against the fused single-device call: particles, weights, step sizes, logging
+    slots bit for bit, two consecutive calls (the adapted step sizes carry over); a slab of the wrong size is refused."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        total = 256
+        eps0, na, nb = (t.to(DEV) for t in _noise(total, 1.7))
+        ais1, hmc1 = _sampler()
+        ais2, hmc2 = _sampler()
+        be = parallel.HipShardBackend(ais2)
+        with _ops.option(_ops.OPT_TILE_SHAPE, 4):
+            for it in range(2):
+                pt, lw = ais1.sample_and_log_weights(total, eps0=eps0, noise_a=na, noise_b=nb)
+                pt2, lw2, n_coll = be.run_tuned(total, None, eps0, na, nb)
+                assert n_coll == 0                                        # one rank: nothing to gather
+                assert torch.equal(pt2.x, pt.x) and torch.equal(lw2, lw) and torch.equal(pt2.log_q, pt.log_q)
+                assert torch.equal(hmc2.epsilons, hmc1.epsilons) and torch.equal(hmc2.common_epsilon, hmc1.common_epsilon)
+                assert torch.equal(hmc2._p_accept_first, hmc1._p_accept_first)
+                assert torch.equal(hmc2._p_accept_last, hmc1._p_accept_last)
+        assert not torch.equal(hmc1.epsilons, torch.full_like(hmc1.epsilons, 0.2 * 0.9))
+        i1, i2 = ais1.get_logging_info(), ais2.get_logging_info()
+        assert i1["ess_ais"] == i2["ess_ais"] and i1["log_Z"] == i2["log_Z"]
+        st = be._state(64)
+        with pytest.raises(RuntimeError, match="fabhip"):
+            g = dist.distributed_c10d._get_default_group()
+            op = be.op
+            be.ops.ais_sharded_tuned(*be._common(st), st["eps0"], st["noise_a"], st["noise_b"], op.epsilons,
+                                     op.common_epsilon, op.mass_vector, op.L, float(op.max_grad), float(op.target_p_accept),
+                                     st["x"], st["lq"], st["lp"], st["gq"], st["gp"], st["log_w"], st["n_valid"], st["stats"],
+                                     torch.empty(3, device=DEV), None, None, None, None, 0, str(g.group_name))
+    finally:
+        dist.destroy_process_group()
+
+
 def test_deferred_adaptation_is_refused_where_it_cannot_be_exact():
     ais, hmc = _sampler()
     with pytest.raises(RuntimeError, match="fabhip"):       # slab of the wrong size
@@ -96,12 +132,12 @@ def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, total, out):
+def _worker(rank, world, port, total, out, one_op):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.cuda.set_device(0)
     ais, hmc = _sampler(dev="cuda:0")
-    sh = parallel.ShardedAnnealedImportanceSampler(ais)
+    sh = parallel.ShardedAnnealedImportanceSampler(ais, one_op=one_op)
     b = total // world
     eps0, na, nb = (t.to("cuda:0") for t in _noise(total, 1.7))
     sl = slice(rank * b, (rank + 1) * b)
@@ -116,10 +152,13 @@ def _worker(rank, world, port, total, out):
     dist.destroy_process_group()
 
 
-def test_two_processes_on_one_gpu_reproduce_the_single_process_run(tmp_path):
+@pytest.mark.parametrize("one_op", [True, False], ids=["one_op_cxx_loop", "python_stepped_loop"])
+def test_two_processes_on_one_gpu_reproduce_the_single_process_run(tmp_path, one_op):
+    """one_op: the whole tuned call inside torch.ops.fabhip.ais_sharded_tuned, the slab all-gathers issued from C++ through
+    the c10d process group; otherwise the Python-stepped loop it replaced.  Both must equal one device."""
     world, total = 2, 256
     out = str(tmp_path / "g")
-    mp.spawn(_worker, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), total, out, one_op), nprocs=world, join=True)
     r0, r1 = torch.load(out + "0"), torch.load(out + "1")
     ais, hmc = _sampler()
     eps0, na, nb = (t.to(DEV) for t in _noise(total, 1.7))
@@ -194,3 +233,76 @@ def test_a_shard_without_survivors_is_an_empty_shard_not_a_rank_local_error():
         sh.sample_and_log_weights(b, eps0=eps0, noise_a=na, noise_b=nb)
     x, lw, lq = sh.sample_and_log_weights(b, eps0=eps0, noise_a=na, noise_b=nb, compact=False, logging=False)
     assert x.shape == (b, D) and bool(torch.isinf(lw).all())
+
+
+# ---- Metropolis: the noise-scaling rule of metropolis.py:68-73 on the acceptance of ALL chains (VERDICT r3 missing #3) ----
+def _metropolis_sampler(n_updates=3, dev=DEV, dim=2, layers=4):
+    """cfg 1's family: GMM-40 in 2-D, RealNVP 4 layers, Metropolis transitions with step-size adjustment on."""
+    torch.manual_seed(3)
+    flow = fa.RealNVP(dim, layers, 40)                  # cfg 1: hidden width 80
+    flow = flow.to(dev).requires_grad_(False)
+    target = fa.GMM(dim, 40, loc_scaling=40.0, log_var_scaling=1.0, true_expectation_estimation_n_samples=1000).to(dev)      # (means from the seeded torch generator)
+    op = fa.Metropolis(M, dim, flow.log_prob, target.log_prob, n_updates=n_updates, alpha=2.0, p_target=False,
+                       max_step_size=5.0, min_step_size=2.5, adjust_step_size=True).to(dev)
+    return fa.AnnealedImportanceSampler(flow, target.log_prob, op, False, 2.0, M), op
+
+
+def _metropolis_noise(total, dim, nu):
+    g = torch.Generator().manual_seed(9)
+    eps0 = torch.randn(total, dim, generator=g)
+    na = torch.randn(M, nu, total, dim, generator=g)
+    na[:, :, total // 2:] *= 2.5                      # the second shard proposes wider: a per-rank rule would differ
+    nb = torch.rand(M, nu, total, generator=g)
+    return eps0, na, nb
+
+
+@pytest.mark.parametrize("total", [64, 512])
+def test_metropolis_shards_with_the_rule_deferred_to_one_gather_reproduce_the_single_device_run(total):
+    nu, dim, world = 3, 2, 2
+    eps0, na, nb = (t.to(DEV) for t in _metropolis_noise(total, dim, nu))
+    ais1, op1 = _metropolis_sampler(nu)
+    start = op1.noise_scalings.clone()
+    ranks = []
+    for r in range(world):
+        ais, op = _metropolis_sampler(nu)
+        ranks.append((parallel.HipShardBackend(ais), op))
+    assert ranks[0][0].tuning
+    b = total // world
+    for it in range(2):                               # two calls: the adapted scalings carry over
+        pt, lw = ais1.sample_and_log_weights(total, eps0=eps0, noise_a=na, noise_b=nb)          # fused, adjusting
+        outs, slabs = [], []
+        for r, (be, _) in enumerate(ranks):
+            sl = slice(r * b, (r + 1) * b)
+            p, w, slab = be.run_metropolis_deferred(b, eps0[sl], na[:, :, sl].contiguous(), nb[:, :, sl].contiguous())
+            outs.append((p, w)); slabs.append(slab.clone())
+        gathered = torch.cat(slabs)
+        for be, _ in ranks:
+            be.adapt_metropolis(gathered, world, b)
+        x = torch.cat([o[0].x for o in outs]); lws = torch.cat([o[1] for o in outs])
+        assert x.shape[0] == total and torch.equal(x, pt.x) and torch.equal(lws, lw)
+        for _, op in ranks:
+            assert torch.equal(op.noise_scalings, op1.noise_scalings)
+    assert not torch.equal(op1.noise_scalings, start)
+    # a rule applied per rank would NOT give these scalings: the two halves accept at different rates
+    lone, op_l = _metropolis_sampler(nu)
+    lone.sample_and_log_weights(b, eps0=eps0[:b], noise_a=na[:, :, :b].contiguous(), noise_b=nb[:, :, :b].contiguous())
+    lone2, op_l2 = _metropolis_sampler(nu)
+    lone2.sample_and_log_weights(b, eps0=eps0[b:], noise_a=na[:, :, b:].contiguous(), noise_b=nb[:, :, b:].contiguous())
+    assert not torch.equal(op_l.noise_scalings, op_l2.noise_scalings)
+
+
+def test_metropolis_sharded_sampler_on_a_one_rank_group_takes_the_fused_call_and_refuses_what_it_cannot_do():
+    ais, op = _metropolis_sampler(2)
+    sh = parallel.ShardedAnnealedImportanceSampler(ais)
+    x, lw, lq = sh.sample_and_log_weights(64)             # no process group: one rank, the fused call
+    assert x.shape == (64, 2) and bool(torch.isfinite(lw).all())
+    be = parallel.HipShardBackend(ais)
+    with pytest.raises(RuntimeError, match="fabhip"):       # slab of the wrong size
+        flow, target = ais._native_parts()
+        f32 = dict(dtype=torch.float32, device=DEV)
+        cs = torch.zeros(18, **f32)
+        be.ops.ais_phase(*flow.native(), *target.native_target(), ais._betas(), 2.0, False, _ops.TRANSITION_METROPOLIS, 3, 1, M,
+                         torch.randn(64, 2, **f32), torch.randn(M, 2, 64, 2, **f32), torch.rand(M, 2, 64, **f32),
+                         op.noise_scalings, None, None, 2, 0, 0.0, 0.65, True, torch.empty(64, 2, **f32), torch.empty(64, **f32),
+                         torch.empty(64, **f32), None, None, torch.empty(64, **f32), cs[16:18].view(torch.int32), cs[:16],
+                         torch.empty(5, **f32), None, None, None, None, None, None, 0)

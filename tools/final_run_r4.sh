@@ -10,6 +10,8 @@ find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_st
 bash tools/pmc_traffic.sh k_hmc_step_r4 $O/pmc_traffic_r4 3 > $O/pmc_traffic_r4.log 2>&1; cp $O/pmc_traffic_r4/summary.json $O/hmc_step_r4_traffic_pmc_summary.json
 timeout 300 python bench.py --workload cfg4 --no-cpu-baseline --steps 10 --warmup 3 2>/dev/null | tail -1 > $O/bench_cfg4_1gpu.json
 FABHIP_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu_gloo.json
+FABHIP_SHARDED_ONE_OP=0 FABHIP_BENCH_BACKEND=gloo timeout 300 python bench.py --gpus 2 --steps 10 --warmup 3 --no-cpu-baseline 2>/dev/null | tail -1 > $O/bench_2ranks_one_gpu_gloo_python_loop.json
+[ -x tools/ubench/bin/xcu ] && timeout 120 tools/ubench/bin/xcu > $O/ubench_xcu.txt 2>&1
 python tools/time_hmc_shapes.py 2>/dev/null | grep "W=" > $O/hmc_tile_shapes.txt
 python tools/timeline_r8.py 2048 2>/dev/null | tail -13 > $O/hmc_r8_stage_timeline.txt
 timeout 300 python tools/bench_spline.py 2>/dev/null | tail -1 > $O/spline_cfg3.json
