@@ -121,6 +121,11 @@ int main() {
         run<4, 32, 96, 1, 1>("4 waves, stage, 4 chains", src, region, n_wg, sink, cyc);
         run<8, 24, 48, 0, 1>("8 waves, free, 4 chains", src, region, n_wg, sink, cyc);
         run<8, 24, 48, 1, 1>("8 waves, stage, 4 chains", src, region, n_wg, sink, cyc);
+        // the 16-chain shape (RB = 4: 16 MFMAs per tile) - what one member of a 4-CU group would run on its quarter of the
+        // columns (tools/ubench/xcu.hip): is a 16-chain stream stage MFMA-bound?
+        run<4, 32, 96, 0, 4>("4 waves, free, 16 chains", src, region, n_wg, sink, cyc);
+        run<4, 32, 96, 1, 4>("4 waves, stage, 16 chains", src, region, n_wg, sink, cyc);
+        run<4, 16, 32, 1, 4>("4 waves, stage, 16 chains", src, region, n_wg, sink, cyc);
     }
     return 0;
 }

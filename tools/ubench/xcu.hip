@@ -20,16 +20,31 @@
 
 constexpr int NT = 256;                       // threads per workgroup
 constexpr int MAXG = 8;
-constexpr unsigned POLL_LIMIT = 1u << 20;
+constexpr unsigned POLL_LIMIT = 1u << 17;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ unsigned ld_sc0(const unsigned* p) {
-    unsigned v;
-    asm volatile("global_load_dword %0, %1, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+// POLL 0: buffer_inv sc0 (drop the CU's vector-L1 lines) + plain load per poll; POLL 1: an atomic OR of 0 that returns the word
+// (read-modify-writes execute in the L2).  (A load with sc0 alone is NOT enough: outside threadgroup-split mode the L1 may serve
+// "workgroup scope" - the first version of this benchmark polled its own L1 copy until the limit.)
+__device__ __forceinline__ void inv_l1() { asm volatile("buffer_inv sc0" ::: "memory"); }
+template <int POLL>
+__device__ __forceinline__ unsigned poll_word(unsigned* p) {
+    unsigned v = 0;
+    if constexpr (POLL == 2) return v;
+    if constexpr (POLL == 0) {
+        asm volatile("buffer_inv sc0\n\tglobal_load_dword %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    } else {
+        const unsigned zero = 0u;
+        asm volatile("global_atomic_or %0, %1, %2, off sc0\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p), "v"(zero) : "memory");
+    }
     return v;
 }
-__device__ __forceinline__ void issue_ld4_sc0(f32x4& v, const f32x4* p) {
-    asm volatile("global_load_dwordx4 %0, %1, off sc0" : "=&v"(v) : "v"(p) : "memory");
+// DATA 0: one buffer_inv sc0 after the flags, then plain loads; DATA 1: loads with sc1 (device scope), no invalidate;
+// DATA 2: plain loads without any invalidate (expected to return stale lines from the second stage pair on: the control)
+template <int DATA>
+__device__ __forceinline__ void issue_ld4(f32x4& v, const f32x4* p) {
+    if constexpr (DATA == 1) asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(v) : "v"(p) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
 }
 __device__ __forceinline__ void wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
@@ -39,7 +54,7 @@ struct Out {
 };
 
 // F4 = float4 per member and stage (F4 / NT per thread), G = members per group
-template <int G, int F4>
+template <int G, int F4, int POLL, int DATA>
 __global__ __launch_bounds__(NT) void k_xcu(f32x4* __restrict__ data, unsigned* __restrict__ flags, int n_stages, int work,
                                             float* __restrict__ sink, Out* __restrict__ out) {
     extern __shared__ float lds[];
@@ -55,33 +70,56 @@ __global__ __launch_bounds__(NT) void k_xcu(f32x4* __restrict__ data, unsigned* 
     __syncthreads();
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     float filler = (float)tid * 1e-3f;
-    unsigned fail = 0;
+    unsigned fail = 0, stale = 0;
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 1; it <= n_stages; ++it) {
         f32x4* mine = gdata + ((size_t)(it & 1) * G + member) * F4;
 #pragma unroll
         for (int p = 0; p < PER; ++p) mine[p * NT + tid] = (f32x4){(float)it, filler, acc.x, (float)member};
+        f32x4 v[G * PER];
+        if constexpr (POLL == 2) {
+            // tagged data, no flags: every float4 carries its stage in .x; a thread re-reads its own G x PER elements (sc1)
+            // until all of them carry this stage - no store wait, no flag, no workgroup barrier inside the exchange
+            unsigned n = 0;
+            bool ok;
+            do {
+#pragma unroll
+                for (int k = 0; k < G; ++k)
+#pragma unroll
+                    for (int p = 0; p < PER; ++p)
+                        issue_ld4<1>(v[k * PER + p], gdata + ((size_t)(it & 1) * G + k) * F4 + p * NT + tid);
+                wait_all();
+                ok = true;
+#pragma unroll
+                for (int q = 0; q < G * PER; ++q) { asm volatile("" : "+v"(v[q])); ok = ok && v[q].x == (float)it; }
+            } while (!ok && ++n <= POLL_LIMIT);
+            if (!ok) abort_flag = 1;
+            __syncthreads();                                                 // (the stage's own barrier in a real kernel)
+            if (abort_flag) { fail = (unsigned)it; break; }
+        } else {
         wait_all();                                                          // this thread's stores are in the L2
         __syncthreads();
         if (tid == 0) gflags[member * 32] = (unsigned)it;
         if (tid < G) {                                                       // lane k watches member k
             unsigned n = 0;
-            while (ld_sc0(gflags + tid * 32) < (unsigned)it) {
+            while (poll_word<POLL>(gflags + tid * 32) < (unsigned)it) {
                 if (++n > POLL_LIMIT) { abort_flag = 1; break; }
             }
         }
         __syncthreads();
         if (abort_flag) { fail = (unsigned)it; break; }
-        f32x4 v[G * PER];
+        if constexpr (DATA == 0) inv_l1();                                   // the slices were last read one stage pair ago
 #pragma unroll
         for (int k = 0; k < G; ++k)
 #pragma unroll
-            for (int p = 0; p < PER; ++p) issue_ld4_sc0(v[k * PER + p], gdata + ((size_t)(it & 1) * G + k) * F4 + p * NT + tid);
+            for (int p = 0; p < PER; ++p) issue_ld4<DATA>(v[k * PER + p], gdata + ((size_t)(it & 1) * G + k) * F4 + p * NT + tid);
         wait_all();
+        }
 #pragma unroll
         for (int q = 0; q < G * PER; ++q) {
             asm volatile("" : "+v"(v[q]));
             acc += v[q];
+            stale += v[q].x != (float)it;                                    // every slice carries the stage it was written in
         }
         for (int w = 0; w < work; ++w) filler = filler * 1.0000001f + 1e-7f;          // the member's own arithmetic
     }
@@ -91,12 +129,13 @@ __global__ __launch_bounds__(NT) void k_xcu(f32x4* __restrict__ data, unsigned* 
         out[wg].xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));               // HW_REG_XCC_ID[3:0]
         out[wg].fail = fail;
     }
+    if (stale) atomicAdd(&out[wg].pad0, stale);
     sink[(size_t)wg * NT + tid] = acc.x + acc.y + acc.z + acc.w + filler;
 }
 
-template <int G, int F4>
+template <int G, int F4, int POLL = 1, int DATA = 0>
 void run(const char* name, f32x4* data, unsigned* flags, float* sink, Out* out, int n_stages, int work) {
-    auto kern = k_xcu<G, F4>;
+    auto kern = k_xcu<G, F4, POLL, DATA>;
     const size_t lds = 96 * 1024;                                            // one workgroup per CU
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipEvent_t e0, e1;
@@ -104,6 +143,7 @@ void run(const char* name, f32x4* data, unsigned* flags, float* sink, Out* out, 
     float ms = 0.f;
     for (int rep = 0; rep < 2; ++rep) {
         (void)hipMemset(flags, 0, 256 * MAXG * 32 * 4);
+        (void)hipMemset(out, 0, 256 * sizeof(Out));
         (void)hipEventRecord(e0, 0);
         hipLaunchKernelGGL(kern, dim3(256), dim3(NT), lds, 0, data, flags, n_stages, work, sink, out);
         (void)hipEventRecord(e1, 0);
@@ -115,17 +155,19 @@ void run(const char* name, f32x4* data, unsigned* flags, float* sink, Out* out, 
     (void)hipMemcpy(h.data(), out, 256 * sizeof(Out), hipMemcpyDeviceToHost);
     double mean = 0, mx = 0;
     int failed = 0, split = 0;
+    unsigned long long stale = 0;
     for (int wg = 0; wg < 256; ++wg) {
         mean += (double)h[wg].cycles;
         mx = h[wg].cycles > mx ? (double)h[wg].cycles : mx;
         failed += h[wg].fail != 0;
+        stale += h[wg].pad0;
         const int first = (wg & 7) + 8 * ((wg >> 3) / G * G);                // first member of this workgroup's group
         split += h[wg].xcc != h[first].xcc;
     }
     mean /= 256;
-    printf("%-28s G=%d %5d B/member work=%4d: %7.0f cycles per stage (max WG %7.0f), %6.2f us per stage by events; "
-           "%d WGs timed out, %d WGs not on their group's XCD (xcc of WG 0..7: %u %u %u %u %u %u %u %u)\n",
-           name, G, F4 * 16, work, mean / n_stages, mx / n_stages, 1e3 * ms / n_stages, failed, split, h[0].xcc, h[1].xcc,
+    printf("%-16s poll=%d data=%d G=%d %5d B/member work=%4d: %7.0f cycles per stage (max WG %7.0f), %6.2f us per stage by events; "
+           "%llu stale float4 read, %d WGs timed out, %d WGs not on their group's XCD (xcc of WG 0..7: %u %u %u %u %u %u %u %u)\n",
+           name, POLL, DATA, G, F4 * 16, work, mean / n_stages, mx / n_stages, 1e3 * ms / n_stages, stale, failed, split, h[0].xcc, h[1].xcc,
            h[2].xcc, h[3].xcc, h[4].xcc, h[5].xcc, h[6].xcc, h[7].xcc);
     fflush(stdout);
 }
@@ -138,15 +180,26 @@ int main() {
     (void)hipMalloc((void**)&out, 256 * sizeof(Out));
     (void)hipMemset(data, 0, (size_t)256 * 2 * MAXG * 1024 * 16);
     const int n = 2000;
-    // exchange alone (the latency of one all-to-all through the XCD's L2)
-    run<2, 256>("exchange only", data, flags, sink, out, n, 0);
-    run<4, 256>("exchange only", data, flags, sink, out, n, 0);
-    run<8, 256>("exchange only", data, flags, sink, out, n, 0);
-    run<4, 512>("exchange only", data, flags, sink, out, n, 0);
-    run<4, 1024>("exchange only", data, flags, sink, out, n, 0);
-    // with the member's own work between exchanges (dependent ALU chain: ~4 cycles per iteration on one wave per SIMD)
-    run<4, 256>("exchange + work", data, flags, sink, out, n, 250);
-    run<4, 256>("exchange + work", data, flags, sink, out, n, 500);
-    run<4, 512>("exchange + work", data, flags, sink, out, n, 250);
+    // the poll that does not work, once (kept as the record of what buffer_inv sc0 + a plain load sees: its own L1 line)
+    run<4, 256, 0, 0>("exchange only", data, flags, sink, out, 20, 0);
+    // exchange alone (the latency of one all-to-all through the XCD's L2): atomic poll, three ways to read the slices
+    run<2, 256, 1, 0>("exchange only", data, flags, sink, out, n, 0);
+    run<4, 256, 1, 0>("exchange only", data, flags, sink, out, n, 0);
+    run<8, 256, 1, 0>("exchange only", data, flags, sink, out, n, 0);
+    run<4, 256, 1, 1>("exchange only", data, flags, sink, out, n, 0);
+    run<4, 256, 1, 2>("exchange only", data, flags, sink, out, n, 0);
+    run<4, 512, 1, 0>("exchange only", data, flags, sink, out, n, 0);
+    run<4, 1024, 1, 0>("exchange only", data, flags, sink, out, n, 0);
+    run<4, 1024, 1, 1>("exchange only", data, flags, sink, out, n, 0);
+    // tagged data instead of flags (poll=2)
+    run<2, 256, 2, 1>("tagged data", data, flags, sink, out, n, 0);
+    run<4, 256, 2, 1>("tagged data", data, flags, sink, out, n, 0);
+    run<8, 256, 2, 1>("tagged data", data, flags, sink, out, n, 0);
+    run<4, 512, 2, 1>("tagged data", data, flags, sink, out, n, 0);
+    run<4, 1024, 2, 1>("tagged data", data, flags, sink, out, n, 0);
+    // with the member's own work between exchanges (a dependent ALU chain of `work` steps on every wave)
+    run<4, 256, 1, 0>("exchange + work", data, flags, sink, out, n, 250);
+    run<4, 256, 1, 0>("exchange + work", data, flags, sink, out, n, 1000);
+    run<4, 512, 1, 1>("exchange + work", data, flags, sink, out, n, 1000);
     return 0;
 }
