@@ -10,9 +10,8 @@
 //       the member's partial [16][64]; EXCHANGE: written as 256 tagged float4, every thread re-reads its element of the four
 //       members' slabs (sc1) until all carry this layer, adds them in member order -> next layer's input [16][16]
 // 24 tiles per wave and layer = the ring depth (static slots).  SOLO = 1: the same stages without the exchange (one member's
-// timing alone: what the exchange costs on top).  TIMING ONLY: in the exchanging instantiation hipcc assigns the ring other
-// registers inside the loop than in front of it and copies the in-flight slots once at the loop entry (the build's ISA check
-// flags exactly that: the first layer multiplies garbage) - harmless for cycles per layer, a blocker for product code.  Prints cycles per layer; the 4-chain product kernel spends ~10 k cycles on the
+// timing alone: what the exchange costs on top).  The object passes the build's ISA check
+// (fab_torch_amd/_isa_check.py) - see the note at the ring request below for what did not.  Prints cycles per layer; the 4-chain product kernel spends ~10 k cycles on the
 // forward half of a width-256 layer for its 4 chains (0.470 ms per transition / 50 layer pairs / 2).
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -53,13 +52,16 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
     S8StreamT<XRD> s;
     s8_stream_init(s, lane);
     const float4* wbase = src + (size_t)wave * wave_f4;
-    s8_prologue(s, wbase);                                                   // a layer's 24 tiles = the ring: drained at its end,
-                                                                             // re-requested at the loop latch (the ISA rule of stream_r8.h)
+    // a layer's 24 tiles = the ring: drained at the layer's end and re-requested at the loop latch (the ISA rule of stream_r8.h).
+    // ONE request site: iteration 0 only requests (a second s8_prologue in front of the loop made hipcc give the ring other
+    // registers inside the loop - as soon as the loop contains any global access - and copy the in-flight slots at its entry)
     const int arow = lane & 3;
     unsigned fail = 0, timed_out = 0;
     const long long t0 = __builtin_amdgcn_s_memtime();
-    for (int it = 1; it <= n_layers; ++it) {
+    for (int it = 0; it <= n_layers; ++it) {
         f32x4 o[XRB];
+        f32x4 mine = {0.f, 0.f, 0.f, 0.f};
+        if (it > 0) {
         {   // S1: W1, redundant
             S8Acc<XRB> acc;
             s8_zero(acc);
@@ -100,10 +102,10 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
                 for (int r = 0; r < 4; ++r) PART[(wave * 16 + 4 * rb + r) * 64 + lane] = o[rb][r];
             s8_barrier();
         }
-        f32x4 mine;
         {
             const f32x4* P = reinterpret_cast<const f32x4*>(PART);
             mine = (P[tid] + P[256 + tid]) + (P[512 + tid] + P[768 + tid]);    // this member's partial, 4 outputs per thread
+        }
         }
         f32x4 total;
         if constexpr (SOLO) {
@@ -164,7 +166,7 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
     fail = timed_out;
     const long long t1 = __builtin_amdgcn_s_memtime();
     s8_drain(s);
-    sink[(size_t)wg * 256 + tid] = XA[tid] + s.r[0][0];
+    sink[(size_t)wg * 256 + tid] = XA[tid];
     if (tid == 0) {
         out[wg].cycles = t1 - t0;
         out[wg].xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
@@ -196,7 +198,7 @@ static void run(const char* name, const float4* src, size_t region, f32x4* xbuf,
     }
     mean /= 256;
     printf("%-44s %3d layers: %7.0f cycles per forward layer of 16 chains (slowest WG %7.0f), %d WGs timed out\n", name, n_layers,
-           mean / n_layers, mx / n_layers, failed);
+           mean / (n_layers + 1), mx / (n_layers + 1), failed);
     fflush(stdout);
 }
 
