@@ -5,7 +5,8 @@
 // 1 / G of the output columns, stream 1 / G of the weights each - at the price of an all-to-all of the activations between
 // the G CUs at every GEMM stage (~10 stages per layer pair, ~2500 per transition).  CDNA4 has no workgroup clusters: the
 // exchange goes through the L2 of the XCD the G workgroups share (workgroup i runs on XCD i mod 8), data written with plain
-// stores (the L2 is the coherence point inside an XCD), flags and data read with sc0 loads (miss the CU's vector L1).
+// stores (the L2 is the coherence point inside an XCD), flags polled with L2 read-modify-writes or carried as tags in the data,
+// data read with sc1 loads (measured here: sc0 loads and buffer_inv sc0 + plain loads are served by the CU's own vector L1).
 //
 // This benchmark prices exactly that exchange: 256 workgroups (one per CU: the LDS request keeps a second one out), groups
 // of G workgroups {xcd + 8 (G g + k)}, per stage every member stores a slice (BYTES per member), waits for its stores,

@@ -31,9 +31,13 @@ __device__ __forceinline__ void x_ld4_sc1(f32x4& v, const f32x4* p) {
 struct XOut {
     long long cycles;
     unsigned xcc, fail, pad0, pad1;
+    long long stage[6];                       // TL = 1: cycles summed per stage (S1, S2 GEMM, S2 sum, S3, exchange + request, update)
 };
 
-template <int SOLO>
+// ND = 1: never-drained ring (TOTAL = S8_INF, no s8_prologue at all): iteration 0 runs the SAME body on an empty ring - its
+// top-ups are the initial fill (s.next starts one tile early so that tile j lands in slot j mod RD), its results are discarded by
+// a select - so the loop carries in-flight slots but has no second request site for hipcc to give other registers.
+template <int SOLO, int ORDER, int TL, int ND>
 __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src, size_t wave_f4, f32x4* __restrict__ xbuf,
                                                  int n_layers, float* __restrict__ sink, XOut* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -51,38 +55,45 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
     __syncthreads();
     S8StreamT<XRD> s;
     s8_stream_init(s, lane);
+    constexpr int XT = ND ? S8_INF : XRD;                                    // tiles of a "layer stream": never drained / one ring
     const float4* wbase = src + (size_t)wave * wave_f4;
     // a layer's 24 tiles = the ring: drained at the layer's end and re-requested at the loop latch (the ISA rule of stream_r8.h).
     // ONE request site: iteration 0 only requests (a second s8_prologue in front of the loop made hipcc give the ring other
     // registers inside the loop - as soon as the loop contains any global access - and copy the in-flight slots at its entry)
     const int arow = lane & 3;
     unsigned fail = 0, timed_out = 0;
+    long long tl[6] = {0, 0, 0, 0, 0, 0}, tp = 0;
+#define XSTAMP(i) if constexpr (TL) { const long long tn = __builtin_amdgcn_s_memtime(); tl[i] += tn - tp; tp = tn; }
+    if constexpr (ND) s.next = wbase - 64;                                   // (one tile early: see ND above; the buffer has slack in front)
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it <= n_layers; ++it) {
         f32x4 o[XRB];
         f32x4 mine = {0.f, 0.f, 0.f, 0.f};
-        if (it > 0) {
+        if constexpr (TL) tp = __builtin_amdgcn_s_memtime();
+        if (ND || it > 0) {
         {   // S1: W1, redundant
             S8Acc<XRB> acc;
             s8_zero(acc);
-            s8_run_k<4, 0, 4, XRD>(s, XA + arow * WS_A, 4 * WS_A, acc);
+            s8_run_k<4, 0, 4, XT>(s, XA + arow * WS_A, 4 * WS_A, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < XRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) H1[(4 * rb + r) * WS_H + 64 * wave + lane] = fmaxf(o[rb][r], 0.f) * 1e-2f;
             s8_barrier();
+            XSTAMP(0)
         }
         {   // S2: W2, the member's column group, K-split over the waves
             S8Acc<XRB> acc;
             s8_zero(acc);
-            s8_run_k<4, 4, 16, XRD>(s, H1 + arow * WS_H + 64 * wave, 4 * WS_H, acc);
+            s8_run_k<4, 4, 16, XT>(s, H1 + arow * WS_H + 64 * wave, 4 * WS_H, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < XRB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) PART[(wave * 16 + 4 * rb + r) * 64 + lane] = o[rb][r];
             s8_barrier();
+            XSTAMP(1)
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int e = tid + 256 * i, row = e >> 6, col = e & 63;
@@ -90,11 +101,12 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
                 H2[row * WS_S + col] = fmaxf(v, 0.f) * 1e-2f;
             }
             s8_barrier();
+            XSTAMP(2)
         }
         {   // S3: W3, K-split over the members (own 64 rows of K), over the waves inside the member
             S8Acc<XRB> acc;
             s8_zero(acc);
-            s8_run_k<4, 20, 4, XRD>(s, H2 + arow * WS_S + 16 * wave, 4 * WS_S, acc);
+            s8_run_k<4, 20, 4, XT>(s, H2 + arow * WS_S + 16 * wave, 4 * WS_S, acc);
             s8_fold(acc, o);
 #pragma unroll
             for (int rb = 0; rb < XRB; ++rb)
@@ -106,11 +118,13 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
             const f32x4* P = reinterpret_cast<const f32x4*>(PART);
             mine = (P[tid] + P[256 + tid]) + (P[512 + tid] + P[768 + tid]);    // this member's partial, 4 outputs per thread
         }
+        XSTAMP(3)
         }
+        if constexpr (ORDER == 1 && !ND) s8_prologue(s, wbase + (size_t)it * XRD * 64);   // the ring fills behind the exchange
         f32x4 total;
         if constexpr (SOLO) {
             total = mine;
-            s8_prologue(s, wbase + (size_t)it * XRD * 64);
+            if constexpr (ORDER == 0 && !ND) s8_prologue(s, wbase + (size_t)it * XRD * 64);
         } else {
             mine.x = (float)it;                                              // the tag (a product kernel packs 3 values + tag, or 128-bit LL)
             gdata[((size_t)(it & 1) * XG + member) * 256 + tid] = mine;
@@ -155,13 +169,26 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
                 timed_out |= cnt >= lim;
             }
             // the next layer's ring is requested behind the four data loads (loads return in order: the data first)
-            s8_prologue(s, wbase + (size_t)it * XRD * 64);
-            asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "n"(XRD - 1));
+            if constexpr (ORDER == 0 && !ND) {
+                s8_prologue(s, wbase + (size_t)it * XRD * 64);
+                asm volatile("s_waitcnt vmcnt(%4)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3) : "n"(XRD - 1));
+            } else if constexpr (ND) {                                       // the four data loads are the youngest requests
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3));
+            }
             total = (v0 + v1) + (v2 + v3);
+        }
+        XSTAMP(4)
+        if constexpr (ND) {                                                  // iteration 0 multiplied an empty ring: discard
+            const float keepf = it > 0 ? 1.f : 0.f;
+            total.y = it > 0 ? total.y : 0.f; total.z = it > 0 ? total.z : 0.f; total.w = it > 0 ? total.w : 0.f;
+            (void)keepf;
         }
         // "coupling": the next layer's input, one element per thread
         XA[(tid >> 4) * WS_A + (tid & 15)] = 0.5f * XA[(tid >> 4) * WS_A + (tid & 15)] + 1e-3f * (total.y + total.z + total.w) + 0.01f;
         s8_barrier();
+        XSTAMP(5)
     }
     fail = timed_out;
     const long long t1 = __builtin_amdgcn_s_memtime();
@@ -171,14 +198,15 @@ __global__ __launch_bounds__(256) void k_xcu_mlp(const float4* __restrict__ src,
         out[wg].cycles = t1 - t0;
         out[wg].xcc = __builtin_amdgcn_s_getreg(20 | (3 << 11));
         out[wg].fail = fail;
+        for (int i = 0; i < 6; ++i) out[wg].stage[i] = tl[i];
     }
 }
 
-template <int SOLO>
+template <int SOLO, int ORDER = 0, int TL = 0, int ND = 0>
 static void run(const char* name, const float4* src, size_t region, f32x4* xbuf, float* sink, XOut* out) {
     const size_t wave_bytes = region / 4;
     const int n_layers = (int)(wave_bytes / 1024 / XRD) - 2;
-    auto kern = k_xcu_mlp<SOLO>;
+    auto kern = k_xcu_mlp<SOLO, ORDER, TL, ND>;
     const size_t lds = 96 * 1024;                                            // one workgroup per CU
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     for (int rep = 0; rep < 2; ++rep) {
@@ -199,13 +227,20 @@ static void run(const char* name, const float4* src, size_t region, f32x4* xbuf,
     mean /= 256;
     printf("%-44s %3d layers: %7.0f cycles per forward layer of 16 chains (slowest WG %7.0f), %d WGs timed out\n", name, n_layers,
            mean / (n_layers + 1), mx / (n_layers + 1), failed);
+    if (TL) {
+        printf("    stage cycles per layer (WG 0): W1 %lld | W2 GEMM %lld | W2 sum %lld | W3 + partial %lld | exchange + ring request %lld | "
+               "update + barrier %lld\n", h[0].stage[0] / n_layers, h[0].stage[1] / n_layers, h[0].stage[2] / n_layers,
+               h[0].stage[3] / n_layers, h[0].stage[4] / n_layers, h[0].stage[5] / n_layers);
+    }
     fflush(stdout);
 }
 
 int main() {
     const size_t region = 10u << 20;
     float4* src; f32x4* xbuf; float* sink; XOut* out;
-    (void)hipMalloc((void**)&src, region + (2u << 20));
+    float4* src_alloc;
+    (void)hipMalloc((void**)&src_alloc, region + (3u << 20));
+    src = src_alloc + (1u << 20) / 16;                                       // 1 MiB of slack in front (ND reads one tile early)
     std::vector<float> hw((region + (2u << 20)) / 4);
     unsigned st = 12345u;
     for (auto& w : hw) { st = st * 1664525u + 1013904223u; w = ((float)(st >> 8) / 16777216.f - 0.5f) * 0.2f; }
@@ -213,9 +248,18 @@ int main() {
     (void)hipMalloc((void**)&xbuf, (size_t)64 * 2 * XG * 256 * 16);
     (void)hipMalloc((void**)&sink, 256 * 256 * 4);
     (void)hipMalloc((void**)&out, 256 * sizeof(XOut));
-    run<1>("one member alone (no exchange)", src, region, xbuf, sink, out);
-    run<0>("four members, tagged all-reduce per layer", src, region, xbuf, sink, out);
-    run<1>("one member alone (no exchange)", src, region, xbuf, sink, out);
-    run<0>("four members, tagged all-reduce per layer", src, region, xbuf, sink, out);
+    run<1, 0>("one member alone (no exchange)", src, region, xbuf, sink, out);
+    run<0, 0>("four members, ring requested after exchange", src, region, xbuf, sink, out);
+    run<0, 1>("four members, ring requested before exchange", src, region, xbuf, sink, out);
+    run<1, 0>("one member alone (no exchange)", src, region, xbuf, sink, out);
+    run<0, 0>("four members, ring requested after exchange", src, region, xbuf, sink, out);
+    run<0, 1>("four members, ring requested before exchange", src, region, xbuf, sink, out);
+    run<1, 0, 0, 1>("one member alone, never-drained ring", src, region, xbuf, sink, out);
+    run<0, 0, 0, 1>("four members, never-drained ring", src, region, xbuf, sink, out);
+    run<1, 0, 0, 1>("one member alone, never-drained ring", src, region, xbuf, sink, out);
+    run<0, 0, 0, 1>("four members, never-drained ring", src, region, xbuf, sink, out);
+    run<0, 0, 1, 1>("four members, never-drained, stage stamps", src, region, xbuf, sink, out);
+    run<1, 0, 1>("one member alone, stage stamps", src, region, xbuf, sink, out);
+    run<0, 0, 1>("four members, stage stamps", src, region, xbuf, sink, out);
     return 0;
 }
