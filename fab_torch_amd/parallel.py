@@ -212,6 +212,17 @@ class HipShardBackend:
                            st["log_w"], st["n_valid"], st["stats"], partials, None, None, None, None, None, None,
                            self._ops_mod.precision_of(self.ais.base_distribution))
 
+    def one_op_available(self, group=None) -> bool:
+        """Can `ais_sharded_tuned` find this process group from C++?  (It resolves the group by NAME in c10d's registry;
+        torch registers every group it creates.)  Checked once per sampler, BEFORE anything is enqueued and from state that
+        is the same on every rank, so that all ranks take the same form of the loop."""
+        try:
+            pg = group if group is not None else dist.distributed_c10d._get_default_group()
+            import torch._C._distributed_c10d as c10d
+            return hasattr(self.ops, "ais_sharded_tuned") and c10d._resolve_process_group(str(pg.group_name)) is not None
+        except Exception:                                  # noqa: BLE001 - any failure: the Python-stepped loop
+            return False
+
     def run_tuned(self, b, group=None, eps0=None, noise_a=None, noise_b=None):
         """The whole tuned call of this shard in ONE op (torch.ops.fabhip.ais_sharded_tuned, csrc/torch_ops.cpp): the loop
         `begin` / M x (`step`, slab all-gather, `adapt`) / `finish` with the collectives issued from C++ through the c10d
@@ -309,8 +320,21 @@ class ShardedAnnealedImportanceSampler:
         # tuned calls: one op per call (default) or the Python-stepped loop it replaced (FABHIP_SHARDED_ONE_OP=0: kept as
         # the reference implementation - tests/test_gpu_sharded.py compares the two bit for bit)
         self.one_op = (os.environ.get("FABHIP_SHARDED_ONE_OP", "1") != "0") if one_op is None else bool(one_op)
+        self._one_op_ok = None
         self.logging_info = None
         self.n_slab_gathers = 0                 # collectives issued by the last call besides the particle gather
+
+    def _use_one_op(self) -> bool:
+        if not (self.one_op and hasattr(self.backend, "run_tuned")):
+            return False
+        if self._one_op_ok is None:                        # once: the same answer on every rank (see one_op_available)
+            chk = getattr(self.backend, "one_op_available", None)
+            self._one_op_ok = bool(chk(self.group)) if chk is not None else True
+            if not self._one_op_ok:
+                import warnings
+                warnings.warn("fab_torch_amd: the process group cannot be resolved from C++ - tuned sharded AIS falls back to "
+                              "the Python-stepped loop (same values)")
+        return self._one_op_ok
 
     def local_batch(self, total_batch: int) -> int:
         world = _world(self.group)
@@ -330,7 +354,7 @@ class ShardedAnnealedImportanceSampler:
             pt, log_w, slab = be.run_metropolis_deferred(b, eps0, noise_a, noise_b)
             be.adapt_metropolis(all_gather_rows(slab.reshape(1, -1), self.group).reshape(-1), world, b)
             self.n_slab_gathers = 1
-        elif self.one_op and hasattr(be, "run_tuned"):     # the loop below, inside one op (collectives issued from C++)
+        elif self._use_one_op():                           # the loop below, inside one op (collectives issued from C++)
             pt, log_w, self.n_slab_gathers = be.run_tuned(b, self.group, eps0, noise_a, noise_b)
         else:
             st = be.begin(b, eps0, noise_a, noise_b)

@@ -138,6 +138,7 @@ def _worker(rank, world, port, total, out, one_op):
     torch.cuda.set_device(0)
     ais, hmc = _sampler(dev="cuda:0")
     sh = parallel.ShardedAnnealedImportanceSampler(ais, one_op=one_op)
+    assert sh._use_one_op() is bool(one_op)                 # the gloo group resolves from C++: the one-op form really runs
     b = total // world
     eps0, na, nb = (t.to("cuda:0") for t in _noise(total, 1.7))
     sl = slice(rank * b, (rank + 1) * b)

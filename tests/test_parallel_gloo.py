@@ -396,3 +396,23 @@ def test_two_rank_metropolis_run_adapts_on_all_chains_with_one_gather_per_call(t
     assert torch.equal(r0["x"], r1["x"]) and torch.equal(r0["lw"], r1["lw"])
     np.testing.assert_allclose(r0["x"].numpy(), pt.x.numpy(), rtol=1e-5, atol=1e-5)
     np.testing.assert_allclose(r0["lw"].numpy(), lw.numpy(), rtol=1e-4, atol=1e-4)
+
+
+def test_one_op_form_is_chosen_only_when_the_group_resolves_from_cxx():
+    """The tuned sharded call runs as ONE op only if c10d's registry knows the process group by name - decided once, before
+    anything is enqueued, from state every rank shares; otherwise (and for backends without the op) the Python-stepped loop."""
+    class _B:
+        hmc, tuning = True, True
+        def __init__(self, ok): self.ok, self.asked = ok, 0
+        def one_op_available(self, group=None): self.asked += 1; return self.ok
+        def run_tuned(self, *a): raise AssertionError("not reached in this test")
+    for ok in (True, False):
+        be = _B(ok)
+        sh = parallel.ShardedAnnealedImportanceSampler(backend=be, one_op=True)
+        import warnings
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            assert sh._use_one_op() is ok and sh._use_one_op() is ok and be.asked == 1      # asked once
+            assert (len(w) == 1) == (not ok)
+    assert parallel.ShardedAnnealedImportanceSampler(backend=_B(True), one_op=False)._use_one_op() is False
+    assert parallel.ShardedAnnealedImportanceSampler(backend=_OracleShardBackend(), one_op=True)._use_one_op() is False   # no run_tuned
