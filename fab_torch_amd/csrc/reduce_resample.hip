@@ -917,27 +917,31 @@ __global__ __launch_bounds__(256) void k_sample_systematic(ScanWs ws, long n, lo
 // reaches C", is K(C) = ceil(((C << F) - U) / S), evaluated as a float64 estimate + ONE exact integer correction step.
 //
 // Fused path (no CDF in HBM, no per-stratum search):
-//   pass T  k_emit_wave_sums : fixed-point weight sum of every 1024-weight wave tile + of every 8192-weight block
+//   pass T  k_emit_wave_sums : fixed-point weight sum of every 1024-weight wave tile + of every 4096-weight block (EM_NW waves)
 //           k_emit_prefix    : exclusive prefix over the block sums (one workgroup), total, (F, S, U)      (reads 4N)
 //   pass E  k_emit_systematic: every wave re-derives the CDF of its 1024 weights in registers (coalesced loads, LDS
 //           transpose so that a lane owns 16 consecutive weights, serial sums + one 6-step wave scan).  Weight j owns the
 //           CONTIGUOUS strata [K(C_{j-1}), K(C_j)): the resampled index array is an EXPANSION - weight j repeated
 //           K(C_j) - K(C_{j-1}) times.  Every weight with a non-empty run drops ONE marker (its id) at the first
-//           position of its run in a 2048-entry LDS window; an inclusive max-scan (ids grow with position) fills the
+//           position of its run in a 1536-entry LDS window; an inclusive max-scan (ids grow with position) fills the
 //           runs - no data-dependent loop, no divergence, a heavy weight costs nothing extra - and the window is
 //           flushed with coalesced 32-byte-per-lane stores.  Runs >= 32768 strata (all the mass on a few particles)
 //           are published and filled by a grid-wide kernel instead of one wave.                 (reads 4N, writes 8 ns)
 // Integer prefix sums and an exact inverse => bit-identical to the scan + search path and to the oracle.
 // HBM traffic 12N + 8 ns bytes instead of 4N + 12N + 16 ns.
 // ------------------------------------------------------------------------------------------------
-constexpr int EM_NW = 8;                                // waves per workgroup
+constexpr int EM_NW = 4;                                // waves per workgroup (r4: 4 x 7 KiB of LDS -> 5 workgroups = 20 waves per CU at <= 96
+                                                        // VGPRs, was 8 waves x 9 KiB -> 16 per CU: 402 -> 382 us end to end at 2^26)
 constexpr int EM_WAVE_ITEMS = 1024;                     // weights per wave: 16 consecutive per lane
 constexpr int EM_BLOCK = EM_WAVE_ITEMS * EM_NW;
 constexpr int EM_FSTRIDE = 20;                          // floats per lane row of the input staging (16 + 4 pad)
-constexpr int EM_WIN = 2048;                            // int32 marker window (entries) per wave: 32 per lane row
-constexpr int EM_WSTRIDE = 36;                          // dwords per lane row of the window (32 + 4 pad: conflict-free b128)
+constexpr int EM_WIN = 1536;                            // int32 marker window (entries) per wave: EM_ROW = 24 per lane row (a wave owns ~1024
+                                                        // strata when ns = N; 1024 entries: two passes for half the waves, 402 us)
+constexpr int EM_WSTRIDE = 28;                          // dwords per lane row of the window (24 + 4 pad: 28 i mod 64 distinct multiples of 4
+                                                        // over 16 lanes: conflict-free b128)
 constexpr int EM_WAVE_LDS = 64 * EM_WSTRIDE * 4;        // bytes per wave (>= 64 * EM_FSTRIDE * 4)
-__device__ __forceinline__ int em_waddr(int e) { return (e >> 5) * EM_WSTRIDE + (e & 31); }
+constexpr int EM_ROW = EM_WIN / 64;                     // window entries per lane row
+__device__ __forceinline__ int em_waddr(int e) { const int r = (int)((unsigned)e / (unsigned)EM_ROW); return r * EM_WSTRIDE + (e - r * EM_ROW); }
 constexpr int EM_GIANT = 32768;                         // runs at least this long are filled by a grid-wide kernel
 
 __global__ __launch_bounds__(64 * EM_NW) void k_emit_wave_sums(const float* __restrict__ lw, long n,
@@ -972,7 +976,7 @@ __global__ __launch_bounds__(64 * EM_NW) void k_emit_wave_sums(const float* __re
     }
 }
 
-// exclusive prefix over the block sums (nb = ceil(N / 8192)): one 1024-thread workgroup, a contiguous chunk per thread;
+// exclusive prefix over the block sums (nb = ceil(N / EM_BLOCK)): one 1024-thread workgroup, a contiguous chunk per thread;
 // also the stratum map {total, S, U, F} and the reset of the giant-run counter
 __global__ __launch_bounds__(1024) void k_emit_prefix(const unsigned long long* __restrict__ block_sum, long nb,
                                                       unsigned long long* __restrict__ block_excl, double u0, long ns,
@@ -1171,15 +1175,15 @@ __global__ __launch_bounds__(64 * EM_NW) void k_emit_systematic(const float* __r
         }
         __builtin_amdgcn_wave_barrier();
         // (c) inclusive max-scan: lane owns entries [32 lane, 32 lane + 32)
-        int v[32];
+        int v[EM_ROW];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < EM_ROW / 4; ++i) {
             const int4 q = *reinterpret_cast<const int4*>(win + EM_WSTRIDE * lane + 4 * i);
             v[4 * i] = q.x; v[4 * i + 1] = q.y; v[4 * i + 2] = q.z; v[4 * i + 3] = q.w;
         }
 #pragma unroll
-        for (int i = 1; i < 32; ++i) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
-        int mx_in = v[31];
+        for (int i = 1; i < EM_ROW; ++i) v[i] = v[i] > v[i - 1] ? v[i] : v[i - 1];
+        int mx_in = v[EM_ROW - 1];
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const int o = __shfl_up(mx_in, off);
@@ -1189,7 +1193,7 @@ __global__ __launch_bounds__(64 * EM_NW) void k_emit_systematic(const float* __r
         if (lane == 0) carry = 0;
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < EM_ROW / 4; ++i) {
             int4 q;
             q.x = (v[4 * i] > carry ? v[4 * i] : carry) - 1;
             q.y = (v[4 * i + 1] > carry ? v[4 * i + 1] : carry) - 1;
