@@ -925,7 +925,7 @@ int64_t ais_phase_core(const Tensor& packed, int64_t dim, int64_t n_layers, int6
     int64_t n_collectives = 0;
     for (int64_t j = 1; j <= M; ++j) {
         chk(fabhip_ais_phase(&a, 0, (int32_t)j, (int32_t)j, slab, st), "ais_sharded_tuned (transition)");
-        if (world > 1) {
+        if (world > 1 || device_collective) {          // (a one-rank RCCL group still runs the collective: the path a node takes)
             if (device_collective) {
                 pg->_allgather_base(gathered, *partials)->wait();
             } else {

@@ -77,12 +77,29 @@ def test_emulated_shards_reproduce_the_fused_single_device_run_bit_for_bit(total
     assert torch.equal(torch.cat([o[0].log_q for o in outs]), pt.log_q)
 
 
-def test_one_op_tuned_call_on_a_one_rank_group_is_the_fused_single_device_call(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_one_op_tuned_call_on_a_one_rank_group_is_the_fused_single_device_call(tmp_path, backend):
     """`ais_sharded_tuned` on a process group of ONE rank (its C++ loop: init, M x {transition with the adaptation deferred,
     slab "gather", rule on the slab}, finish) against the fused single-device call: particles, weights, step sizes, logging
-    slots bit for bit, two consecutive calls (the adapted step sizes carry over); a slab of the wrong size is refused."""
+    slots bit for bit, two consecutive calls (the adapted step sizes carry over); a slab of the wrong size is refused.
+    backend "nccl" = RCCL: a one-rank communicator on the box's GPU - the op then issues its M slab all-gathers through RCCL on
+    the compute stream (device tensors, `Work::wait()` ordering the stream, no host staging): the code path a multi-GPU node
+    takes, short of a second rank."""
+    import datetime
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
-    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        dist.init_process_group(backend, rank=0, world_size=1, timeout=datetime.timedelta(seconds=120),
+                                **({"device_id": torch.device("cuda:0")} if backend == "nccl" else {}))
+        if backend == "nccl":                                # the communicator is created by the first collective
+            probe = torch.ones(4, device=DEV)
+            out = torch.empty(4, device=DEV)
+            dist.all_gather_into_tensor(out, probe)
+            torch.cuda.synchronize()
+            assert torch.equal(out, probe)
+    except Exception as e:                                    # noqa: BLE001 - a box whose RCCL cannot start a communicator
+        if dist.is_initialized():
+            dist.destroy_process_group()
+        pytest.skip(f"no {backend} communicator on this box: {e}")
     try:
         total = 256
         eps0, na, nb = (t.to(DEV) for t in _noise(total, 1.7))
@@ -93,7 +110,7 @@ def test_one_op_tuned_call_on_a_one_rank_group_is_the_fused_single_device_call(t
             for it in range(2):
                 pt, lw = ais1.sample_and_log_weights(total, eps0=eps0, noise_a=na, noise_b=nb)
                 pt2, lw2, n_coll = be.run_tuned(total, None, eps0, na, nb)
-                assert n_coll == 0                                        # one rank: nothing to gather
+                assert n_coll == (M if backend == "nccl" else 0)        # one gloo rank: nothing to gather; RCCL: M real collectives
                 assert torch.equal(pt2.x, pt.x) and torch.equal(lw2, lw) and torch.equal(pt2.log_q, pt.log_q)
                 assert torch.equal(hmc2.epsilons, hmc1.epsilons) and torch.equal(hmc2.common_epsilon, hmc1.common_epsilon)
                 assert torch.equal(hmc2._p_accept_first, hmc1._p_accept_first)
