@@ -306,7 +306,7 @@ class ShardedAnnealedImportanceSampler:
     semantics of ONE device holding every chain: rank r runs chains [r b, (r + 1) b), the step sizes adapt on the
     acceptance of all chains (one slab all-gather per transition while tuning is on), the particles are joined by one
     all-gather at the end, ESS / log Z are those of the gathered set.  Returns (x, log_w, log_q) of all chains on every
-    rank (`compact=False`: fixed `world * b` rows, dropped chains as log_w = -inf rows; the fused rank-local call and the
+    rank (`compact=False`: fixed `world * max shard` rows, dropped chains - and the padding of an uneven split - as log_w = -inf rows; the fused rank-local call and the
     "chain end" filter each read their row counts once, the gather itself adds no host synchronisation).  A shard that loses all
     of its chains is an empty shard, not an error: "No valid points" is raised - on every rank - only when the GATHERED set is
     empty (compact=True; with compact=False `logging_info` shows it).  Bit-for-bit equality with one device holds when both
@@ -337,10 +337,15 @@ class ShardedAnnealedImportanceSampler:
         return self._one_op_ok
 
     def local_batch(self, total_batch: int) -> int:
+        """This rank's share of `total_batch` chains.  Even splits everywhere; an UNEVEN split (the first total % world ranks run
+        one chain more, `shard_sizes`) is taken where no slab travels - tuning frozen / one rank: the particle gather pads every
+        shard to the largest one with invalid rows.  With tuning on the slabs of all ranks must have one shape (and only shards
+        that are multiples of 16 chains reproduce one device bit for bit): refused."""
         world = _world(self.group)
-        if total_batch % world:
-            raise ValueError(f"sharded AIS: {total_batch} chains do not split evenly over {world} ranks")
-        return total_batch // world
+        if total_batch % world and world > 1 and self.backend.tuning:
+            raise ValueError(f"sharded AIS with step-size tuning on: {total_batch} chains do not split evenly over {world} ranks "
+                             "(the acceptance slabs of all ranks must have one shape); set_eval_mode(True) takes uneven splits")
+        return shard_sizes(total_batch, world)[_rank(self.group)]
 
     def sample_and_log_weights(self, total_batch: int, eps0=None, noise_a=None, noise_b=None, compact: bool = True,
                                logging: bool = True):
@@ -364,7 +369,8 @@ class ShardedAnnealedImportanceSampler:
                 self.n_slab_gathers += 1
                 be.adapt(st, j, gathered, world)
             pt, log_w = be.finish(st)
-        buf = all_gather_rows(pack_particles(pt.x, log_w, pt.log_q, b), self.group)
+        cap = max(shard_sizes(total_batch, world))         # (== b for an even split)
+        buf = all_gather_rows(pack_particles(pt.x, log_w, pt.log_q, cap), self.group)
         D = buf.shape[-1] - 3
         n_valid = buf[:, D + 2].sum()                      # device scalar: chains that survived on any rank
         if compact:                                        # (the boolean-mask indexing synchronises with the host anyway)

@@ -416,3 +416,50 @@ def test_one_op_form_is_chosen_only_when_the_group_resolves_from_cxx():
             assert (len(w) == 1) == (not ok)
     assert parallel.ShardedAnnealedImportanceSampler(backend=_B(True), one_op=False)._use_one_op() is False
     assert parallel.ShardedAnnealedImportanceSampler(backend=_OracleShardBackend(), one_op=True)._use_one_op() is False   # no run_tuned
+
+
+# ---- uneven splits (tuning frozen): the particle gather pads every shard to the largest one ---------------------------------
+class _FrozenStubBackend:
+    """Rank-local stand-in with tuning frozen: chains are rows [global index, rank], log_w = global index."""
+    tuning = False
+
+    def run_fused(self, b, eps0=None, noise_a=None, noise_b=None):
+        from fab_torch_amd.point import Point
+        r = dist.get_rank() if dist.is_initialized() else 0
+        first = sum(parallel.shard_sizes(self.total, dist.get_world_size() if dist.is_initialized() else 1)[:r])
+        idx = torch.arange(first, first + b, dtype=torch.float32)
+        x = torch.stack([idx, torch.full_like(idx, float(r))], dim=1)
+        return Point(x, -idx, idx, None, None), idx.clone()
+
+
+def _worker_uneven(rank, world, port, total, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    be = _FrozenStubBackend(); be.total = total
+    sh = parallel.ShardedAnnealedImportanceSampler(backend=be)
+    assert sh.local_batch(total) == parallel.shard_sizes(total, world)[rank]
+    x, lw, lq = sh.sample_and_log_weights(total)                      # compact: exactly the chains that exist
+    xf, lwf, _ = sh.sample_and_log_weights(total, compact=False)      # fixed size: world * largest shard, padding as -inf rows
+    be.tuning = True
+    try:
+        sh.local_batch(total)
+        refused = False
+    except ValueError:
+        refused = True
+    torch.save({"x": x, "lw": lw, "xf": xf, "lwf": lwf, "refused": refused, "ess": float(sh.logging_info["ess_ais"])}, out + str(rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uneven_split_with_tuning_frozen_pads_the_gather_and_is_refused_with_tuning_on(tmp_path):
+    world, total = 2, 7                                              # shards of 4 and 3 chains
+    out = str(tmp_path / "u")
+    mp.spawn(_worker_uneven, args=(world, _free_port(), total, out), nprocs=world, join=True)
+    r0, r1 = torch.load(out + "0"), torch.load(out + "1")
+    for r in (r0, r1):
+        assert r["x"].shape == (total, 2) and torch.equal(r["x"][:, 0], torch.arange(total, dtype=torch.float32))
+        assert torch.equal(r["x"][:, 1], torch.tensor([0., 0, 0, 0, 1, 1, 1])) and torch.equal(r["lw"], r["x"][:, 0])
+        assert r["xf"].shape == (8, 2) and torch.isinf(r["lwf"][7]) and r["lwf"][7] < 0 and torch.equal(r["lwf"][:7], r["lw"])
+        assert r["refused"]
+    w = torch.exp(r0["lw"].double())
+    assert abs(r0["ess"] - float(w.sum() ** 2 / (w ** 2).sum() / total)) < 1e-9        # normalised by the chains that exist
