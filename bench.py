@@ -45,11 +45,11 @@ def build_flow_state(seed=0):
 CPU_THREADS = 16                     # the thread count the oracle's eager CPU path is timed at (best of the 8/16/32/64 sweeps of r1-r3)
 
 
-def cpu_baseline(flow_state, n_calls=5):
+def cpu_baseline(flow_state, n_calls=20, n_warm=5):
     """The oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores on the same workload at a
-    FIXED thread count (CPU_THREADS): median of n_calls full AIS calls of 1024 chains after one warm-up call (SURVEY 8d;
-    VERDICT r3: rounds 1-3 reported 2 calls at whatever count a sweep picked).  A one-call-each sweep over other thread
-    counts is reported next to it as information, never as `value`."""
+    FIXED thread count (CPU_THREADS): median of n_calls = 20 full AIS calls of 1024 chains after n_warm = 5 warm-up calls
+    (SURVEY 8d's protocol; ~20 s of CPU work).  A one-call-each sweep over other thread counts is reported next to it as
+    information, never as `value`."""
     from oracle import ais as oais, flow as oflow, targets as otgt
     nf = oflow.make_realnvp(D, K_LAYERS, NODES)
     nf.load_state_dict(flow_state)
@@ -68,7 +68,8 @@ def cpu_baseline(flow_state, n_calls=5):
 
     threads = min(CPU_THREADS, os.cpu_count() or CPU_THREADS)
     torch.set_num_threads(threads)
-    call()                                                         # warm-up
+    for _ in range(n_warm):
+        call()
     dts = sorted(call() for _ in range(n_calls))
     dt = dts[n_calls // 2]
     sweep = {}
@@ -79,7 +80,7 @@ def cpu_baseline(flow_state, n_calls=5):
             sweep[str(nt)] = B_PER_GPU / call()
     torch.set_num_threads(threads)
     return {"value": B_PER_GPU / dt, "unit": "AIS samples/s", "cores": threads, "kind": "port",
-            "sample": f"median of {n_calls} calls of sample_and_log_weights({B_PER_GPU}) after one warm-up call, {threads} threads "
+            "sample": f"median of {n_calls} calls of sample_and_log_weights({B_PER_GPU}) after {n_warm} warm-up calls, {threads} threads "
                       f"(fixed), fp32, oracle/ = PyTorch-CPU eager + autograd per leapfrog",
             "sec_per_call": dt, "sec_per_call_min_max": [dts[0], dts[-1]], "host_cpus": os.cpu_count(),
             "thread_sweep_samples_per_s": sweep}
@@ -301,10 +302,20 @@ def main():
     if distributed:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+        # a rank that never arrives (dead GPU, wrong device mapping, RCCL bootstrap over xGMI failing) must end this run with an
+        # error line, not hold the node until the lease expires: bounded rendezvous + collective timeouts, asynchronous error
+        # handling that tears the process down (tools/scale_run.sh reads the exit codes)
+        import datetime
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+        tmo = datetime.timedelta(seconds=int(os.environ.get("FABHIP_BENCH_PG_TIMEOUT", "180")))
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev, timeout=tmo)
+            else:
+                dist.init_process_group(backend, timeout=tmo)
+        except Exception as e:                             # noqa: BLE001 - reported, then fatal
+            print(json.dumps({"error": f"init_process_group({backend}) failed on rank {rank}/{world}: {e!r}"}), flush=True)
+            raise SystemExit(3)
 
     def sync():
         if dev.type == "cuda":
@@ -395,6 +406,7 @@ def main():
         step()
     barrier()
     elapsed_eval = max_over_ranks(time.perf_counter() - t0)
+    slab_gathers_eval = sharded.n_slab_gathers if distributed else 0
     hmc.set_eval_mode(False)
     # the particle all-gather alone (the one data-path collective), HIP events on the collective's stream
     gather_us = None
@@ -419,22 +431,19 @@ def main():
     # ---- roofline of the dominant kernel (k_hmc_step): live HIP-event timing on the launch stream -----
     roof = None
     if rank == 0:
-        from fab_torch_amd.transition_operators import create_point
-        hmc.set_eval_mode(True)
+        # The kernel the timed step runs: M back-to-back launches of the transition kernel with the step-size rule in its last
+        # wave, enqueued by ONE op (torch.ops.fabhip.ais_phase = fabhip_ais_phase, the call `step` itself makes) and bracketed
+        # by HIP events on torch's current stream (= the stream handed to the C ABI).  Per launch = (chain initialisation +
+        # transitions 1 .. M) - (chain initialisation alone), medians of 10 calls each, / M  (rounds 1 - 4
+        # timed a stand-alone hmc.transition, which adds a k_hmc_adapt launch and a dispatch per transition).
+        saved_roof = {k: v.clone() for k, v in hmc.state_dict().items()}
+        shard = parallel.HipShardBackend(ais)
 
         def time_transition(n_chains, n_t=10):
-            x0, _ = flow.native_sample(torch.randn(n_chains, D, device=dev))
-            pt = create_point(x0, flow, target, with_grad=True)
-            for _ in range(3):
-                hmc.transition(pt, 4, float(ais.B_space[4]))
-            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_t + 1)]
-            ev[0].record()                                  # torch's current stream == the stream handed to the C ABI
-            for i in range(n_t):
-                hmc.transition(pt, 4, float(ais.B_space[4]))
-                ev[i + 1].record()
-            torch.cuda.synchronize()
-            ms = sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n_t))
-            return ms[n_t // 2] * 1e-3
+            st = shard._state(n_chains)
+            t_init = _event_time(lambda: shard._phase(st, 1, 1, 0), n=n_t, warm=3)
+            t_full = _event_time(lambda: shard._phase(st, 1, 1, M, tune=True), n=n_t, warm=3)
+            return (t_full - t_init) / M
 
         t_kernel = time_transition(B_PER_GPU)
         flop = B_PER_GPU * L * 2 * F_FWD                  # flow fwd + d/dx per leapfrog (target flops ignored)
@@ -445,12 +454,13 @@ def main():
         n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
         r8 = shape == 8 or (shape == 0 and 1152 < B_PER_GPU <= 8 * n_cu)    # 8-chain tiles (flow_r8.h) up to 8 chains per CU
         n_wg = (B_PER_GPU + 3) // 4 if r4 else ((B_PER_GPU + 7) // 8 if r8 else (B_PER_GPU + 15) // 16)
-        kname = "k_hmc_step_r4<5> (4 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r4 else \
-            ("k_hmc_step_r8<5> (8 chains per workgroup, v_mfma_f32_4x4x1; + k_hmc_adapt, ~2 us)" if r8 else
+        kname = "k_hmc_step_r4<5> (4 chains per workgroup, v_mfma_f32_4x4x1; step-size rule in its last wave)" if r4 else \
+            ("k_hmc_step_r8<5> (8 chains per workgroup, v_mfma_f32_4x4x1; step-size rule in its last wave)" if r8 else
              "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)")
         roof = {"bound": "mfma", "kernel": kname, "achieved": ach,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
                 "traffic": None, "ms_per_launch": t_kernel * 1e3, "flop_per_launch": flop,
+                "timing": "HIP events around fabhip_ais_phase(init + M transitions) minus (init), / M: the launches of the timed step",
                 "workgroups": n_wg, "frac_of_occupied_cus": ach / (PEAK_FP32_MFMA_TFLOPS * min(n_wg, 256) / 256)}
         # HBM traffic per launch: separate rocprofv3 --pmc passes of tools/prof_hmc.py (same kernel, same shape),
         # summarised by tools/pmc_summary.py and committed; not collectable from inside this process.
@@ -493,7 +503,7 @@ def main():
         ach_2k = 2048 * L * 2 * F_FWD / t_2k / 1e12
         roof["chains_2048"] = {"chains": 2048, "kernel": "k_hmc_step_r8<5> (8 chains per workgroup)", "ms_per_launch": t_2k * 1e3,
                                "achieved": ach_2k, "frac": ach_2k / PEAK_FP32_MFMA_TFLOPS}
-        hmc.set_eval_mode(False)
+        hmc.load_state_dict(saved_roof)
 
     # ---- second roofline: the resample scan + the whole systematic resampler at N = 2^26 (HBM-bound) ----
     roof_extra, ess_trained, ess_trained_fast = None, None, None
@@ -503,6 +513,7 @@ def main():
         ess_trained_fast = trained_flow_ess(dev, fast=True)
     spline3 = spline_cfg3(dev) if (rank == 0 and world == 1 and not custom and args.workload == "headline") else None
 
+    bad = []
     if rank == 0:
         total = world * B_PER_GPU * args.steps
         line = {
@@ -510,15 +521,17 @@ def main():
             "value": total / elapsed, "unit": "AIS samples/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s%s: ManyWell-32 AIS, RealNVP %dx(16-320-320-32)+InvAffine, HMC L=5 n_outer=1, "
-                                   "M=%d linear beta, alpha=2 (target p^2/q), step-size tuning on" %
-                                   (args.workload, " (modified)" if custom else "", K_LAYERS, M),
+            "config": {"workload": "%s%s: ManyWell-32 AIS, RealNVP %dx(16-320-320-32)+InvAffine (seeded default init, last coupling "
+                                   "Linears N(0, 0.01^2)), HMC L=5 n_outer=1, M=%d linear beta, alpha=2 (target p^2/q), "
+                                   "step-size tuning on" % (args.workload, " (modified)" if custom else "", K_LAYERS, M),
                        "chains_per_gpu": B_PER_GPU, "global_chains": world * B_PER_GPU,
                        "parallelism": (f"chains sharded x{world}: single-device step-size rule ({slab_gathers} acceptance-slab "
                                        "all-gathers per step) + one particle all-gather" if world > 1 else "single GPU")},
             "ranks": world, "backend": ("rccl" if backend == "nccl" else backend) if distributed else None,
             "rccl_ranks": (dist.get_world_size() if (distributed and backend == "nccl") else 0),
+            "process_group_ranks": (dist.get_world_size() if distributed else 1),
             "collectives_per_step": (slab_gathers + 1) if distributed else 0,
+            "collectives_per_step_eval_mode": (slab_gathers_eval + 1) if distributed else 0,
             "lib_srchash": _lib_srchash(),
             "gathered_rows": int(out[0].shape[0]), "particle_all_gather_us": gather_us,
             "slab_all_gathers_per_step": slab_gathers,
@@ -543,10 +556,26 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(flow_state)
             line["speedup_vs_cpu"] = line["value"] / line["cpu_baseline"]["value"]
-        print(json.dumps(line))
+        # N > 1: what the line claims about the collectives is checked, not assumed (a run that silently fell back to another
+        # backend, another loop form or rank-local step sizes fails here instead of producing a plausible number)
+        if distributed:
+            if backend == "nccl" and line["rccl_ranks"] != world:
+                bad.append(f"rccl_ranks {line['rccl_ranks']} != world {world}")
+            if line["process_group_ranks"] != world:
+                bad.append(f"process group holds {line['process_group_ranks']} ranks, launched {world}")
+            if line["collectives_per_step"] != M + 1:
+                bad.append(f"tuned step issued {line['collectives_per_step']} collectives, expected M + 1 = {M + 1}")
+            if line["collectives_per_step_eval_mode"] != 1:
+                bad.append(f"eval-mode step issued {line['collectives_per_step_eval_mode']} collectives, expected 1")
+            if line["gathered_rows"] != world * B_PER_GPU:
+                bad.append(f"gathered {line['gathered_rows']} rows, expected {world * B_PER_GPU}")
+        line["multi_gpu_checks"] = "ok" if not bad else bad
+        print(json.dumps(line), flush=True)
     if distributed:
         dist.barrier()                      # rank 0 measured the roofline leg alone; leave together
         dist.destroy_process_group()
+    if rank == 0 and bad:
+        raise SystemExit("bench.py: multi-GPU consistency checks failed: " + "; ".join(bad))
 
 
 if __name__ == "__main__":

@@ -14,7 +14,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 212          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+ABI_VERSION = 213          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
 TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2
@@ -178,8 +178,15 @@ def _read_small(t: torch.Tensor) -> torch.Tensor:
         ent = (torch.empty(t.numel(), dtype=t.dtype, pin_memory=True), torch.cuda.Event())
         cache[key] = ent
     buf, ev = ent
-    buf.copy_(t, non_blocking=True)
-    ev.record()
+    # copy and event on the current stream of t's DEVICE (the ops run under a device guard, so t may live on a device that
+    # is not the current one: an event recorded on the current device's stream would complete before the copy lands)
+    if t.device.index == torch.cuda.current_device():   # (the common case: no guard, no stream lookup on the call's host path)
+        buf.copy_(t, non_blocking=True)
+        ev.record()
+    else:
+        with torch.cuda.device(t.device):
+            buf.copy_(t, non_blocking=True)
+            ev.record(torch.cuda.current_stream(t.device))
     if POLL_READS:
         for _ in range(200000):
             if ev.query():

@@ -10,6 +10,7 @@
 #include "flow_device.h"
 #include "target_device.h"
 #include "flow_r4.h"
+#include "flow_r4f.h"
 #include "flow_r8.h"
 #include "launch.h"
 
@@ -398,7 +399,9 @@ static inline ExtraLds4 make_extra_lds4(const R4Lds& l, int D) {
     return e;
 }
 
-template <int NTWM, bool BIGD, bool STREAM>
+// MODE: 0 = per-stage weight requests (flow_log_prob_r4), 1 = one stream per wave (flow_log_prob_r4s), 2 = fused stages on
+// their own stream (flow_r4f.h: flow_log_prob_r4f; the bias blocks of all layers are copied to LDS once per launch)
+template <int NTWM, bool BIGD, int MODE>
 __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
                                                           const float* __restrict__ packed, TargetDev tg, HmcK a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -421,6 +424,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
     const bool active = ew && g < nv;
     const float eps = *a.eps_ptr + *a.ceps_ptr;
     for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
+    if constexpr (MODE == 2) r4f_load_bias(packed + f.o_r4fb, lds + l.o_BIAS, f.K * r4f_bias_stride(f.Wp), t.tid);
     float k0 = 0.f;
     if (ew) {
         for (int j = t.c; j < D; j += 16) {
@@ -457,7 +461,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
             lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
         }
         __syncthreads();
-        if constexpr (STREAM) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
+        if constexpr (MODE == 2) lq = flow_log_prob_r4f<NTWM>(f, l, packed, lds, t4, &goff);
+        else if constexpr (MODE == 1) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
         else lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 2 : 1>(f, rd, l, packed, lds, t4, &goff);
         if (ew) {
             lp = target_tile<true>(tg, XP, D, GP, D, t);
@@ -521,7 +526,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
 // (fabhip_flow_sample: no 4-chain tile code for that direction), this kernel re-evaluates log q + d/dx at the samples (the
 // reference does, base.py:65-68), the target and the initial log-weight - two of the three flow passes of k_ais_init on
 // 256 instead of 64 workgroups.
-template <int NTWM, bool STREAM>
+template <int NTWM, int MODE>
 __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
                                                           const float* __restrict__ packed, TargetDev tg,
                                                           const float* __restrict__ lq0, const float* __restrict__ eps0,
@@ -538,15 +543,19 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd,
     float* GP = lds + x.o_GP;
     float q0s = 0.f;                                   // log q of the sampling pass (eps0 given: the flow SAMPLE runs here as well)
     bool sampled = false;
-    if constexpr (STREAM) {
+    if constexpr (MODE >= 1) {
         if (eps0) {                                    // x, log q0 = flow.sample(eps0) on this tile (k_flow_sample_r4's work)
             for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) {
                 const int r = e / R4_DS, j = e % R4_DS;
                 lds[l.o_X0 + e] = (j < D && row0 + r < B) ? eps0[(row0 + r) * D + j] : 0.f;
             }
+            if constexpr (MODE == 2)                   // the sampling direction's bias blocks (K + 1 virtual layers)
+                r4f_load_bias(packed + f.o_r4fb + (size_t)f.K * r4f_bias_stride(f.Wp), lds + l.o_BIAS,
+                              (f.K + 1) * r4f_bias_stride(f.Wp), t.tid);
             __syncthreads();
             int xoff = 0;
-            q0s = flow_sample_r4s<NTWM>(f, rd, l, packed, lds, t4, &xoff);
+            if constexpr (MODE == 2) q0s = flow_sample_r4f<NTWM>(f, l, packed, lds, t4, &xoff);
+            else q0s = flow_sample_r4s<NTWM>(f, rd, l, packed, lds, t4, &xoff);
             for (int e = t.tid; e < R4 * D; e += NTHREADS) {
                 const int r = e / D, j = e % D;
                 const float v = lds[xoff + r * R4_DS + j];
@@ -566,10 +575,12 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd,
         lds[l.o_X0 + e] = v;
         if (j < D) XP[r * D + j] = v;
     }
+    if constexpr (MODE == 2) r4f_load_bias(packed + f.o_r4fb, lds + l.o_BIAS, f.K * r4f_bias_stride(f.Wp), t.tid);
     __syncthreads();
     int goff = 0;
     float lq;
-    if constexpr (STREAM) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
+    if constexpr (MODE == 2) lq = flow_log_prob_r4f<NTWM>(f, l, packed, lds, t4, &goff);
+    else if constexpr (MODE == 1) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
     else lq = flow_log_prob_r4<NTWM, 2, 2, 2, 1>(f, rd, l, packed, lds, t4, &goff);
     if (!ew) return;
     const float lp = target_tile<true>(tg, XP, D, GP, D, t);
@@ -1140,7 +1151,8 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
     FlowDims f = f0;
     f.timeline = debug_timeline(st);
     const R4Dims rd = make_r4_dims(f);
-    const R4Lds l = make_r4_lds(f);
+    const bool fused = use_r4_fused(f);
+    const R4Lds l = make_r4_lds(f, fused);
     const ExtraLds4 x = make_extra_lds4(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     // every row of the ceil(B / 16) sixteen-row blocks k_hmc_adapt sums is written by some workgroup (workgroups past
@@ -1149,13 +1161,17 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
     const bool stream = option(FABHIP_OPT_R4_STREAM) != 0;  // 0: per-stage request groups also where the stream image exists
     if constexpr (NTWM > 5) {
         return FABHIP_ENOTSUP;                              // (use_r4_tiles never selects it)
+    } else if (NTWM >= 2 && fused) {
+        constexpr int NS = NTWM >= 2 ? NTWM : 2;
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, 2>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NS, false, 2>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
     } else if (NTWM >= 2 && f.o_r4s >= 0 && (stream || NTWM >= 5)) {    // (the per-stage schedule spills at 5 tiles per wave)
         constexpr int NS = NTWM >= 2 ? NTWM : 2;           // (never instantiates the stream code for NTWM = 1)
-        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, true>, bytes));
-        hipLaunchKernelGGL((k_hmc_step_r4<NS, false, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, 1>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NS, false, 1>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
     } else if constexpr (NTWM < 5) {
-        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, false, false>, bytes));
-        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, false, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NTWM, false, 0>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NTWM, false, 0>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
     } else {
         return FABHIP_ENOTSUP;
     }
@@ -1166,21 +1182,27 @@ template <int NTWM>
 static int launch_ais_init_r4(const FlowDims& f, const float* packed, const TargetDev& tg, const float* lq0, const float* eps0,
                               const PointDev& pt, float* log_w, float* base_log_w, fabhip_anneal an, long B, hipStream_t st) {
     const R4Dims rd = make_r4_dims(f);
-    const R4Lds l = make_r4_lds(f);
+    const bool fused = use_r4_fused(f);
+    const R4Lds l = make_r4_lds(f, fused);
     const ExtraLds4 x = make_extra_lds4(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid((unsigned)((B + R4 - 1) / R4));
     if constexpr (NTWM > 5) {
         return FABHIP_ENOTSUP;
+    } else if (NTWM >= 2 && fused) {
+        constexpr int NS = NTWM >= 2 ? NTWM : 2;
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NS, 2>, bytes));
+        hipLaunchKernelGGL((k_ais_init_r4<NS, 2>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, eps0, pt,
+                           log_w, base_log_w, an, B);
     } else if (NTWM >= 2 && f.o_r4s >= 0) {
         constexpr int NS = NTWM >= 2 ? NTWM : 2;
-        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NS, true>, bytes));
-        hipLaunchKernelGGL((k_ais_init_r4<NS, true>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, eps0, pt,
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NS, 1>, bytes));
+        hipLaunchKernelGGL((k_ais_init_r4<NS, 1>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, eps0, pt,
                            log_w, base_log_w, an, B);
     } else if constexpr (NTWM < 5) {
-        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NTWM, false>, bytes));
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NTWM, 0>, bytes));
         if (eps0) return FABHIP_ENOTSUP;                    // (the sampling direction exists on the stream image only)
-        hipLaunchKernelGGL((k_ais_init_r4<NTWM, false>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0,
+        hipLaunchKernelGGL((k_ais_init_r4<NTWM, 0>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0,
                            (const float*)nullptr, pt, log_w, base_log_w, an, B);
     } else {
         return FABHIP_ENOTSUP;

@@ -1,6 +1,7 @@
 // RealNVP flow: parameter packing, log_prob (+ d/dx) and sampling kernels + their C ABI.
 #include "flow_device.h"
 #include "flow_r4.h"
+#include "flow_r4f.h"
 #include "flow_r8.h"
 #include "launch.h"
 #include <stdlib.h>
@@ -312,8 +313,9 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_sample(FlowDims f, FlowLds l,
     }
 }
 
-// the same on 4-chain tiles (flow_r4.h: flow_sample_r4s) - 256 workgroups for 1024 chains instead of 64
-template <int NTWM>
+// the same on 4-chain tiles (flow_r4.h: flow_sample_r4s; FUSED: flow_r4f.h: flow_sample_r4f) - 256 workgroups for 1024 chains
+// instead of 64
+template <int NTWM, bool FUSED>
 __global__ __launch_bounds__(NTHREADS) void k_flow_sample_r4(FlowDims f, R4Dims rd, R4Lds l, const float* __restrict__ packed,
                                                              const float* __restrict__ eps, float* __restrict__ x,
                                                              float* __restrict__ log_q, long B) {
@@ -325,9 +327,14 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_sample_r4(FlowDims f, R4Dims 
         const long g = row0 + r;
         lds[l.o_X0 + e] = (j < f.D && g < B) ? eps[g * f.D + j] : 0.f;
     }
+    if constexpr (FUSED)
+        r4f_load_bias(packed + f.o_r4fb + (size_t)f.K * r4f_bias_stride(f.Wp), lds + l.o_BIAS, (f.K + 1) * r4f_bias_stride(f.Wp),
+                      t4.tid);
     __syncthreads();
     int xoff = 0;
-    const float lq = flow_sample_r4s<NTWM>(f, rd, l, packed, lds, t4, &xoff);
+    float lq;
+    if constexpr (FUSED) lq = flow_sample_r4f<NTWM>(f, l, packed, lds, t4, &xoff);
+    else lq = flow_sample_r4s<NTWM>(f, rd, l, packed, lds, t4, &xoff);
     if (t4.tid < 64 && (t4.tid & 15) == 0 && row0 + (t4.tid >> 4) < B) log_q[row0 + (t4.tid >> 4)] = lq;
     for (int e = t4.tid; e < R4 * f.D; e += NTHREADS) {
         const int r = e / f.D, j = e % f.D;
@@ -516,6 +523,114 @@ __global__ __launch_bounds__(256) void k_pack_r4s(FlowDims f, R4Dims rd, float* 
     }
 }
 
+// Fused-stage stream image + bias blocks (flow_r4f.h), built from what the launches before this one have written: the r4 tiles
+// (k_pack_r4: W1, W2, W2^T, W3, W3^T in fp32, copied), the assembled D x D maps W' / W'^-1 (k_affine_assemble) and the layer
+// blocks' biases.  The fused matrices W1' = W'[:, :d] W1^T (density; sampling: W'^-1 of the layer before) and the fused biases
+// are float64 products rounded once.  Layout: see flow_r4f.h.
+__global__ __launch_bounds__(256) void k_pack_r4f(FlowDims f, R4Dims rd, float* __restrict__ packed) {
+    const int G = rd.G, K = f.K, D = f.D, d = f.d, Wp = f.Wp;
+    const int TL = r4f_tl(G), CR = 4 * G + 5, I_N = 4 * G + 3;
+    const long total4 = (long)(3 * K + 3) * TL * NWAVE * 64;
+    const float4* r4 = reinterpret_cast<const float4*>(packed + f.o_r4);
+    const long LS4 = rd.layer_stride / 4;
+    float4* dst = reinterpret_cast<float4*>(packed + f.o_r4f);
+    auto Wm = [&](int layer) { return packed + f.o_scratch + (size_t)layer * 2 * D * D; };           // W' (ActNorm folded)
+    auto Winv = [&](int layer) { return packed + f.o_scratch + (size_t)layer * 2 * D * D + (size_t)D * D; };
+    // W1[k][n] (k < 16: conditioner input, n < Wp: hidden column) of a layer, from its r4 tiles (zero beyond d / W)
+    auto W1 = [&](int layer, int k, int n) -> float {
+        return packed[f.o_r4 + (size_t)layer * rd.layer_stride + rd.o_W1 + ((size_t)(k >> 2) * G + (n >> 6)) * 256 + (n & 63) * 4 + (k & 3)];
+    };
+    // (M[r][:d] . W1[:, n]) in float64: the fused first Linear of `layer` behind the D x D map M
+    auto fusedW = [&](const float* M, int r, int layer, int n) -> float {
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) acc += (double)M[r * D + j] * (double)W1(layer, j, n);
+        return (float)acc;
+    };
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total4; e += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(e & 63);
+        const long tt = e >> 6;
+        const int slot = (int)(tt / (NWAVE * TL));
+        int r = (int)(tt % (NWAVE * TL));
+        int sec = -1, layer = 0;                           // 0 density forward, 1 density reverse, 2 sampling (virtual layer)
+        if (slot < K) { sec = 0; layer = K - 1 - slot; }
+        else if (slot < 2 * K) { sec = 1; layer = slot - K; }
+        else if (slot > 2 * K && slot <= 3 * K + 1) { sec = 2; layer = slot - (2 * K + 1); }
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (sec >= 0) {
+            int I, w, g;
+            if (r < 2 * NWAVE * G) { I = r / (NWAVE * G); r -= I * NWAVE * G; w = r / G; g = r % G; }
+            else if (r < 2 * NWAVE * G + NWAVE) { I = 2; w = r - 2 * NWAVE * G; g = 0; }
+            else { r -= 2 * NWAVE * G + NWAVE; I = 3 + r / (NWAVE * G); r %= NWAVE * G; w = r / G; g = r % G; }
+            const int sblk = lane >> 5, c = lane & 31;
+            long src = -1;                                 // float4 index inside the layer's r4 block
+            const int lsrc = layer < K ? layer : K - 1;    // (virtual sampling layer K has no coupling block)
+            const bool coupling = sec != 2 || layer < K;
+            if (I < 2) {                                   // S1: k-quad 2 w + I of the fused first Linear | S4: of W3^T
+                const int q = 2 * w + I, n = 64 * g + lane;
+                if (sec == 1) src = rd.o_W3T / 4 + ((long)q * G + g) * 64 + lane;
+                else if (coupling) {
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 4 * q + j;
+                        if (k >= D) continue;
+                        if (sec == 0) v[j] = fusedW(Wm(layer), k, layer, n);
+                        else if (layer == 0) v[j] = k < d ? W1(0, k, n) : 0.f;
+                        else v[j] = fusedW(Winv(layer - 1), k, layer, n);
+                    }
+                }
+            } else if (I == 2) {                           // dense D x D tile: k-quad 2 w + sblk, column c
+                for (int j = 0; j < 4; ++j) {
+                    const int k = 4 * (2 * w + sblk) + j;
+                    if (k >= D || c >= D) continue;
+                    if (sec == 0) v[j] = Wm(layer)[k * D + c];
+                    else if (sec == 1) v[j] = Wm(layer)[c * D + k];
+                    else if (layer == 0) v[j] = k == c ? 1.f : 0.f;
+                    else v[j] = Winv(layer - 1)[k * D + c];
+                }
+            } else if (I < I_N) {                          // W x W: k-quad 4 G w + (I - 3)
+                if (coupling) src = (sec == 1 ? rd.o_W2T : rd.o_W2) / 4 + ((long)(4 * G * w + (I - 3)) * G + g) * 64 + lane;
+            } else if (I < CR) {                           // dense narrow tiles: T = (I - I_N) G + g, k-quads 4 G w + 2 T + sblk
+                const int T = (I - I_N) * G + g;
+                if (sec == 1) {                            // (W1')^T: hidden row k, state column c
+                    for (int j = 0; j < 4; ++j) {
+                        const int k = 4 * (4 * G * w + 2 * T + sblk) + j;
+                        if (c < D && k < Wp) v[j] = fusedW(Wm(layer), c, layer, k);
+                    }
+                } else if (coupling) src = rd.o_W3 / 4 + ((long)(2 * G * w + T)) * 64 + lane;
+            }
+            if (src >= 0) { const float4 t4 = r4[(long)lsrc * LS4 + src]; v[0] = t4.x; v[1] = t4.y; v[2] = t4.z; v[3] = t4.w; }
+        }
+        dst[e] = make_float4(v[0], v[1], v[2], v[3]);
+    }
+    // bias blocks: K density (layer k), K + 1 sampling (virtual layer v: coupling of layer v behind the affine map of layer v - 1)
+    const int BS = r4f_bias_stride(Wp);
+    float* bdst = packed + f.o_r4fb;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < (long)(2 * K + 1) * BS; e += (long)gridDim.x * blockDim.x) {
+        const int blk = (int)(e / BS), o = (int)(e % BS);
+        const bool samp = blk >= K;
+        const int layer = samp ? blk - K : blk;            // density: layer; sampling: virtual layer v
+        const bool coupling = !samp || layer < K;
+        const float* Lp = packed + (size_t)(coupling ? layer : K - 1) * f.layer_stride;
+        // additive term of the D x D map in front of this block's first Linear, and its log-det
+        const float* add = nullptr;
+        float logS = 0.f;
+        if (!samp) { add = Lp + f.o_ac; logS = Lp[f.o_logS]; }
+        else if (layer > 0) { const float* Lq = packed + (size_t)(layer - 1) * f.layer_stride; add = Lq + f.o_at; logS = Lq[f.o_logS]; }
+        float val = 0.f;
+        if (o < Wp) {                                      // b1' = b1 + add[:d] . W1
+            if (coupling) {
+                double acc = (double)Lp[f.o_b1 + o];
+                if (add) for (int j = 0; j < d; ++j) acc += (double)add[j] * (double)W1(layer, j, o);
+                val = (float)acc;
+            }
+        } else if (o < 2 * Wp) { if (coupling) val = Lp[f.o_b2 + (o - Wp)]; }
+        else if (o < 2 * Wp + 32) { const int cc = o - 2 * Wp; if (add && cc < D) val = add[cc]; }
+        else if (o < 2 * Wp + 48) { if (coupling) val = Lp[f.o_b3 + (o - 2 * Wp - 32)]; }
+        else if (o < 2 * Wp + 64) { if (coupling) val = Lp[f.o_b3 + f.DOp + (o - 2 * Wp - 48)]; }
+        else if (o == 2 * Wp + 64) val = logS;
+        bdst[e] = val;
+    }
+}
+
 template <int NTWM>
 static int launch_sample(const FlowDims& f, const float* packed, const float* eps, float* x, float* log_q, long B,
                          hipStream_t st) {
@@ -523,11 +638,17 @@ static int launch_sample(const FlowDims& f, const float* packed, const float* ep
         // batches the transitions run on 4-chain tiles (<= 1152 chains): the sample on 4-chain tiles as well
         if (use_r4_tiles(f, B) && f.o_r4s >= 0 && option(FABHIP_OPT_R4_STREAM) != 0) {
             const R4Dims rd = make_r4_dims(f);
-            const R4Lds l4 = make_r4_lds(f);
+            const bool fused = use_r4_fused(f);
+            const R4Lds l4 = make_r4_lds(f, fused);
             const size_t bytes4 = (size_t)l4.total * 4;
-            FAB_TRY(set_max_lds((const void*)k_flow_sample_r4<NTWM>, bytes4));
-            hipLaunchKernelGGL((k_flow_sample_r4<NTWM>), dim3((unsigned)((B + R4 - 1) / R4)), dim3(NTHREADS), bytes4, st, f, rd, l4,
-                               packed, eps, x, log_q, B);
+            const dim3 grid4((unsigned)((B + R4 - 1) / R4));
+            if (fused) {
+                FAB_TRY(set_max_lds((const void*)k_flow_sample_r4<NTWM, true>, bytes4));
+                hipLaunchKernelGGL((k_flow_sample_r4<NTWM, true>), grid4, dim3(NTHREADS), bytes4, st, f, rd, l4, packed, eps, x, log_q, B);
+            } else {
+                FAB_TRY(set_max_lds((const void*)k_flow_sample_r4<NTWM, false>, bytes4));
+                hipLaunchKernelGGL((k_flow_sample_r4<NTWM, false>), grid4, dim3(NTHREADS), bytes4, st, f, rd, l4, packed, eps, x, log_q, B);
+            }
             return check_launch();
         }
     }
@@ -564,7 +685,7 @@ struct Options {
     int v[FABHIP_OPT_COUNT];
     Options() {
         static const struct { int key; const char* env; int dflt; } tab[FABHIP_OPT_COUNT] = {
-            {FABHIP_OPT_TILE_SHAPE, "FABHIP_TILE", 0},           {FABHIP_OPT_R4_STREAM, "FABHIP_R4_STREAM", 1},
+            {FABHIP_OPT_TILE_SHAPE, "FABHIP_TILE", 0},           {FABHIP_OPT_R4_STREAM, "FABHIP_R4_STREAM", 2},
             {FABHIP_OPT_SCAN_VARIANT, "FABHIP_SCAN_VARIANT", 3}, {FABHIP_OPT_SYSTEMATIC_VARIANT, "FABHIP_SYSTEMATIC_VARIANT", 1},
             {FABHIP_OPT_SPLINE_STAGED, "FABHIP_SPLINE_STAGED", 0}, {FABHIP_OPT_TIMELINE, "FABHIP_TIMELINE", 0},
             {FABHIP_OPT_SPLINE_MFMA, "FABHIP_SPLINE_MFMA", 0},   {FABHIP_OPT_SPLINE_LEAP, "FABHIP_SPLINE_LEAP", 1},
@@ -644,6 +765,8 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
     }
     if (f.o_r4s >= 0)
         hipLaunchKernelGGL(k_pack_r4s, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed);
+    if (f.o_r4f >= 0)
+        hipLaunchKernelGGL(k_pack_r4f, dim3(2048), dim3(256), 0, st, f, make_r4_dims(f), packed);
     hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();
 }

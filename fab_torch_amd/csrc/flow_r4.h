@@ -51,9 +51,10 @@ FAB_HD R4Dims make_r4_dims(const FlowDims& f) {
 struct R4Lds {
     int WS, PN;                        // leading dims: hidden activations, partial products
     int o_X0, o_X1, o_HA, o_HB, o_PRM, o_DP, o_PART, o_ES, o_V2, o_MASK, total;
+    int o_PZ, o_BIAS;                  // fused stages (flow_r4f.h): partials of the dense narrow products, bias blocks of all layers
 };
 
-FAB_HD R4Lds make_r4_lds(const FlowDims& f) {
+FAB_HD R4Lds make_r4_lds(const FlowDims& f, bool fused = false) {
     R4Lds l;
     l.WS = f.Wp + 4;                   // (Wp + 4) * 4 bytes = 16 mod 128: the 4 rows' 16-byte A reads hit 4 different bank groups
     l.PN = f.Wp;
@@ -68,6 +69,12 @@ FAB_HD R4Lds make_r4_lds(const FlowDims& f) {
     l.o_ES = o; o += f.K * R4 * f.DOp;
     l.o_V2 = o; o += f.K * R4 * f.DOp;
     l.o_MASK = o; o += f.K * 2 * NTHREADS;
+    l.o_PZ = l.o_BIAS = 0;
+    if (fused) {
+        o = (o + 3) & ~3;
+        l.o_PZ = o; o += 2 * NWAVE * R4 * 32;
+        l.o_BIAS = o; o += (f.K + 1) * r4f_bias_stride(f.Wp);
+    }
     l.total = (o + 3) & ~3;
     return l;
 }
@@ -193,6 +200,39 @@ __device__ __forceinline__ void r4_bias_load(float (&bv)[G], const float* __rest
     for (int i = 0; i < G; ++i) bv[i] = bias ? bias[(256 * i + t.tid) % N] : 0.f;
 }
 
+// The 4 partials of this thread's G outputs (output o = 256 i + tid; PN = 64 G, so partial w of output o sits at
+// part[w 4 PN + o]) summed as (P0 + P1) + (P2 + P3).  All 2 G reads are issued back to back from ONE address register
+// (ds_read2st64_b32: two dwords 64-dword strides apart) and waited for once: written as compiler-visible loads the epilogue
+// came out as G dependent LDS round trips (read 4, wait, add, read 4, ...: hipcc's scheduler at 255 live VGPRs), ~1 k cycles
+// per wide stage in the round-5 stage stamps.  The waits name the destination registers; "memory" clobbers keep the
+// compiler's own LDS accesses on their side of the block.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int O0, int O1>
+__device__ __forceinline__ f32x2 lds_read2st64(unsigned addr) {
+    f32x2 v;
+    asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(v) : "v"(addr), "n"(O0), "n"(O1) : "memory");
+    return v;
+}
+template <int G>
+__device__ __forceinline__ void r4_read_partials(const float* part, int PN, int tid, float (&v)[G]) {
+    (void)PN;                                              // (== 64 G: make_r4_lds)
+    const unsigned addr = (unsigned)(size_t)(part + tid);  // LDS byte address (low half of the generic pointer)
+    f32x2 r[2 * G];
+    static_for<0, G>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        r[2 * i] = lds_read2st64<4 * i, 4 * i + 8 * G>(addr);                // (P0, P2)
+        r[2 * i + 1] = lds_read2st64<4 * i + 4 * G, 4 * i + 12 * G>(addr);   // (P1, P3): r[2 i] + r[2 i + 1] = (P0 + P1, P2 + P3)
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int k = 0; k < 2 * G; ++k) asm volatile("" : "+v"(r[k]));
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const f32x2 h = r[2 * i] + r[2 * i + 1];
+        v[i] = h.x + h.y;
+    }
+}
+
 // epilogue: OUT[row][col] = f(bias[col] + ((P0 + P1) + (P2 + P3))) for this thread's G of the 4 x 64 G outputs
 // (row o / (64 G), col o % (64 G)).  EP 0: plain, 1: ReLU, sign bit i kept in *mask, 2: multiplied by sign bit i.
 struct R4NoPost {
@@ -207,14 +247,29 @@ __device__ __forceinline__ void r4_epilogue(const float* __restrict__ part, int 
                                             Post post = Post()) {
     constexpr int N = 64 * G;
     unsigned m = EP == 2 ? mask[t.tid] : 0u;
+    // every partial is read before the first output is written: `part` and `out` are both LDS, and hipcc keeps a read behind an
+    // earlier write it cannot prove disjoint - with the reads and writes of one output adjacent the epilogue was G dependent LDS
+    // round trips (~1 k cycles per wide stage, round 5 stage stamps); same sums, same order
+    float v[G];
+    if constexpr (G >= 2) {                                // (wide outputs: PN == 64 G)
+        r4_read_partials<G>(part, PN, t.tid, v);
+#pragma unroll
+        for (int i = 0; i < G; ++i) v[i] += bv[i];
+    } else {                                               // the D x D maps of the unfused variants: 64 columns, partials PN apart
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int o = 256 * i + t.tid, row = o / N, col = o - row * N;
+            const float* p = part + row * PN + col;
+            v[i] = ((p[0] + p[R4 * PN]) + (p[2 * R4 * PN] + p[3 * R4 * PN])) + bv[i];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int o = 256 * i + t.tid, row = o / N, col = o - row * N;
-        const float* p = part + row * PN + col;
-        float v = ((p[0] + p[R4 * PN]) + (p[2 * R4 * PN] + p[3 * R4 * PN])) + bv[i];
-        if (EP == 1) { const bool pos = v > 0.f; m |= (pos ? 1u : 0u) << i; v = pos ? v : 0.f; }
-        if (EP == 2) v = ((m >> i) & 1u) ? v : 0.f;
-        out[row * ldo + col] = post(row, col, v);
+        float w = v[i];
+        if (EP == 1) { const bool pos = w > 0.f; m |= (pos ? 1u : 0u) << i; w = pos ? w : 0.f; }
+        if (EP == 2) w = ((m >> i) & 1u) ? w : 0.f;
+        out[row * ldo + col] = post(row, col, w);
     }
     if (EP == 1) mask[t.tid] = m;
 }

@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 212
+#define FABHIP_ABI_VERSION 213
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -91,8 +91,10 @@ int fabhip_get_fast_mode(void);
                                             8 = flow_r8.h, 16 = flow_device.h tiles; a shape that does not exist for the flow
                                             falls back to 16) and of the 4x4x1 spline density kernel (8 / 16); 0 = by batch
                                             size (default) */
-#define FABHIP_OPT_R4_STREAM 1           /* FABHIP_R4_STREAM: 1 = continuous weight stream where its image exists (default),
-                                            0 = per-stage request groups */
+#define FABHIP_OPT_R4_STREAM 1           /* FABHIP_R4_STREAM: 4-chain tiles: 2 = fused stages on their own weight stream (flow_r4f.h: the
+                                            D x D map multiplied together with the first / last conditioner Linear, coupling in the
+                                            W3 epilogue; default where the image exists), 1 = the round-3 stream (one stage per
+                                            matrix), 0 = per-stage request groups */
 #define FABHIP_OPT_SCAN_VARIANT 2        /* FABHIP_SCAN_VARIANT: fixed-point CDF scan, 3 = LDS-transposed (default), 0-2 = A/B */
 #define FABHIP_OPT_SYSTEMATIC_VARIANT 3  /* FABHIP_SYSTEMATIC_VARIANT: 1 = fused systematic sampler (default), 0 = CDF in HBM */
 #define FABHIP_OPT_SPLINE_STAGED 4       /* FABHIP_SPLINE_STAGED: 1 = per-layer spline kernels instead of the one-launch kernel */

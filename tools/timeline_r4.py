@@ -21,13 +21,18 @@ torch.cuda.synchronize()
 buf = (C.c_int64 * 64)()
 _lib.check(_lib.load().fabhip_debug_timeline(buf, 64), "timeline")
 ts = list(buf)
+from fab_torch_amd import _ops
+fused = int(_ops.load().get_option(_ops.OPT_R4_STREAM)) >= 2
 names = {0: "fwd layer start", 1: "affine done", 2: "W1 (d -> W) done", 3: "W2 (W x W) done", 4: "W3 (W -> 64) done",
          5: "coupling done", 16: "rev layer start", 17: "d-params done", 18: "W3T (64 -> W) done", 19: "W2T (W x W) done",
          20: "W1T (W -> d) done", 21: "add + barrier", 22: "affine^T done"}
+if fused:                            # flow_r4f.h: six stages per layer pair
+    names = {0: "fwd layer start", 1: "S1 y -> h1, z (K = 32) done", 3: "S2 W2 (W x W) done", 5: "S3 W3 + coupling done",
+             16: "rev layer start", 18: "S4 W3T (32 -> W) done", 19: "S5 W2T (W x W) done", 22: "S6 [W1'T ; AT] (W + D -> D) done"}
 prev = None
-for i in sorted(names):
+for i in sorted(names, key=lambda i: ts[i]):
     if not ts[i]:
         continue
-    print(f"{i:2d} {names[i]:24s}", "" if prev is None or i in (0, 16) else f"+{ts[i] - prev:6d} ticks")
+    print(f"{i:2d} {names[i]:36s}", "" if prev is None or i in (0, 16) else f"+{ts[i] - prev:6d} ticks")
     prev = ts[i]
 print("fwd layer:", ts[5] - ts[0], "rev layer:", ts[22] - ts[16], "ticks")
