@@ -136,8 +136,8 @@ struct R4NoNext {
     __device__ __forceinline__ void operator()() const {}
 };
 
-template <int G>
-__device__ __forceinline__ void r4_quad(const float4& a, const float4 (&b)[G], f32x4 (&acc)[G]) {
+template <int G, class BT>
+__device__ __forceinline__ void r4_quad(const float4& a, const BT (&b)[G], f32x4 (&acc)[G]) {
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = mfma44(a.x, b[g].x, acc[g]);
 #pragma unroll

@@ -30,6 +30,7 @@
 // layer bodies).
 #pragma once
 #include "flow_r4.h"
+#include "stream_r8.h"
 
 namespace fab {
 
@@ -37,16 +38,54 @@ template <int NTWM>
 struct R4F {
     static constexpr int G = NTWM;
     static constexpr int CR = 4 * G + 5;                   // items with tiles per layer and direction
-#ifdef FAB_R4F_RD
-    static constexpr int RD = FAB_R4F_RD;                  // (timing experiments: tools/experiments/price)
-#else
-    static constexpr int RD = CR % 5 == 0 ? 5 : (CR % 7 == 0 ? 7 : (CR % 6 == 0 ? 6 : 7));
-#endif
-    static constexpr int C = (CR + RD - 1) / RD * RD;      // padded with empty items: the ring size divides the items per layer
     static constexpr int TL = (4 * G + 4) * G + 1;         // tiles per wave, layer and direction
     static constexpr int I_A = 2, I_W = 3, I_N = 4 * G + 3;
     static constexpr int ntiles(int I) { return I == I_A ? 1 : (I < CR ? G : 0); }
     static constexpr int toff(int I) { return I <= I_A ? I * G : (I - 1) * G + 1; }
+    // The ring (R4FRing) holds RD items in ACCUMULATION registers; its slots are compile-time constants when RD divides the
+    // items per layer, so a layer is padded to C = a multiple of RD with E EMPTY items (no tiles, no request).  They sit inside
+    // the W x W stage, one behind every STEP-th k-quad, where the extra request of the item behind them hides behind MFMAs
+    // (round-5 measurement: all of them at the layer's end = one burst of requests = +2 k cycles in S3 / S6).
+#ifdef FAB_R4F_RD
+    static constexpr int RD = FAB_R4F_RD;                  // (timing experiments: tools/experiments/price)
+#else
+    // G = 5: RD = 5 (C = 25), G = 4: RD = 7 (C = 21), G = 2: RD = 13 (C = 13): no empty items in the shipped shapes.  Measured at
+    // G = 5 (tools/experiments/price): RD = 9 (C = 27, two empty items) is 2 % SLOWER than RD = 5 - the W x W stages run at the
+    // rate the L2 -> CU path delivers (~46 B/clk per CU with 256 CUs streaming) whatever is in flight, and a deeper queue only
+    // delays the items of the short stages behind it
+    static constexpr int RD = G >= 5 ? 5 : (G == 4 ? 7 : 13);
+#endif
+    static constexpr int C = (CR + RD - 1) / RD * RD;
+    static constexpr int E = C - CR;
+    static constexpr int STEP = (4 * G) / (E + 1) > 0 ? (4 * G) / (E + 1) : 1;
+    // virtual position of item I in the padded sequence / the item at virtual position V (-1: empty)
+    static constexpr int vidx(int I) {
+        int q = I - I_W;
+        q = q < 0 ? 0 : (q > 4 * G ? 4 * G : q);
+        const int e = q / STEP;
+        return I + (e < E ? e : E);
+    }
+    static constexpr int item_at(int V) {
+        for (int I = 0; I < CR; ++I)
+            if (vidx(I) == V) return I;
+        return -1;
+    }
+    static constexpr int vtiles(int V) { return item_at(V % C) < 0 ? 0 : ntiles(item_at(V % C)); }
+    // Request schedule: while item I (position V) is consumed, every position up to V - 1 + RD that has not been requested yet
+    // is requested - i.e. the slot of the item consumed BEFORE I is re-filled (its last reader sits behind a scheduling
+    // barrier: the old and the new contents of a slot are never live together, so hipcc needs no copy of a ring register;
+    // stream_r8.h tops its ring up the same way).  RD - 1 items are in flight at most.
+    static constexpr int prev_pos(int I) { return I > 0 ? vidx(I - 1) : vidx(CR - 1) - C; }
+    static constexpr int req_hi(int I) { return vidx(I) - 1 + RD; }          // last position requested while item I is consumed
+    static constexpr int req_lo(int I) { return prev_pos(I) - 1 + RD + 1; }  // first one
+    // loads issued after the last tile of item I when its tiles are waited for (requests up to prev_pos(I) - 1 + RD are out)
+    static constexpr int inflight_behind(int I) {
+        int n = 0;
+        for (int J = vidx(I) + 1; J <= prev_pos(I) - 1 + RD; ++J) n += vtiles(J);
+        return n;
+    }
+    static_assert(E <= 4 * G / STEP, "every empty item needs a k-quad of the W x W stage to sit behind");
+    static_assert((RD - 1) * G < 64, "vmcnt is a 6-bit counter");
 };
 
 // bias block of one layer in LDS / in the image (r4f_bias_stride floats, fabhip_common.h):
@@ -60,8 +99,8 @@ struct R4FAcc {
 #pragma unroll
         for (int i = 0; i < 8; ++i) a[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
-    template <int T>
-    __device__ __forceinline__ void tile(const float4& x, const float4& w) {
+    template <int T, class WT>
+    __device__ __forceinline__ void tile(const float4& x, const WT& w) {
         constexpr int o = 4 * (T & 1);
         a[o + 0] = mfma44(x.x, w.x, a[o + 0]);
         a[o + 1] = mfma44(x.y, w.y, a[o + 1]);
@@ -100,40 +139,78 @@ __device__ __forceinline__ void r4f_load_bias(const float* __restrict__ src, flo
     for (int e = tid; e < nfloats / 4; e += NTHREADS) d4[e] = s4[e];
 }
 
-// ring of RD items over the fused stream; `sp` points at (layer slot, lane) of the section being consumed
+// Ring of RD items over the fused stream in ACCUMULATION registers (the structure of stream_r8.h): the tiles are requested by
+// inline-asm loads hipcc does not see ("=a" destinations: the MFMAs read their B operand from there directly) and waited for
+// with hand-counted s_waitcnt vmcnt(N) that name the registers - so the ring costs no architectural VGPR (round 5: with
+// compiler-tracked loads 100 of 255 VGPRs, 136 v_accvgpr moves in S1 alone) and can be RD = 10 items deep: the short stages'
+// idle memory pipe prefetches half of the next W x W stage.  Loads return in order, so an item is complete once at most
+// `inflight_behind` younger loads are outstanding; any other load in flight (stage stamps) only makes a wait conservative.
+// The build's ISA check (_isa_check.py) verifies on the generated code that no instruction touches a ring register whose
+// load may still be in flight.
 template <int NTWM>
 struct R4FRing {
     using S = R4F<NTWM>;
     static constexpr int G = S::G, RD = S::RD, C = S::C;
-    float4 r[RD][G];
-    const float4* sp;
-    int wG, w1;
-    __device__ __forceinline__ R4FRing(const float4* base, const Tid4& t) : sp(base + t.lane), wG(t.wave * G * 64), w1(t.wave * 64) {
-        static_for<0, RD>([&](auto ic) {
-            constexpr int I = decltype(ic)::value;
-            load<I, 0>(IC<I % RD>{});
-        });
+    f32x4 r[RD][G];
+    const float4 *spG, *sp1;           // (layer slot, wave) of the section being consumed: items of G tiles / of one tile
+    unsigned voff0, voff1;             // lane * 16 (+ 4096: the fifth tile of an item is past the 12-bit immediate offset)
+    __device__ __forceinline__ R4FRing(const float4* base, const Tid4& t)
+        : spG(base + (size_t)t.wave * G * 64), sp1(base + (size_t)t.wave * 64), voff0((unsigned)t.lane * 16u),
+          voff1((unsigned)t.lane * 16u + 4096u) {
+        static_for<0, RD - 1>([&](auto vc) { request<decltype(vc)::value>(); });
     }
-    // item J of the layer `LOFF` slots ahead -> ring slot SL
-    template <int J, int LOFF, int SL>
-    __device__ __forceinline__ void load(IC<SL>) {
-        constexpr int n = S::ntiles(J);
-        constexpr long off = ((long)LOFF * S::TL + S::toff(J)) * 4 * 64;
-#pragma unroll
-        for (int g = 0; g < n; ++g) r[SL][g] = sp[off + (n == G ? wG : w1) + g * 64];
+    // request the item at virtual position V (V >= C: of the next layer) into its slot
+    template <int V>
+    __device__ __forceinline__ void request() {
+        constexpr int I = S::item_at(V % C);
+        if constexpr (I >= 0) {
+            constexpr int n = S::ntiles(I), SL = V % RD;
+            const float4* b0 = (n == G ? spG : sp1) + ((size_t)(V / C) * S::TL + S::toff(I)) * 4 * 64;
+            // (wave-uniform by construction; made so explicitly: the "s" operand of the load must not end up in VGPRs)
+            const unsigned long long bu = (unsigned long long)b0;
+            const float4* b = reinterpret_cast<const float4*>(
+                ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu >> 32)) << 32) |
+                (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu & 0xffffffffull)));
+            static_for<0, n>([&](auto gc) {
+                constexpr int g = decltype(gc)::value;
+                if constexpr (g == 0) s8_load_first<0>(r[SL][0], voff0, b);
+                else if constexpr (g < 4) s8_load<g * 1024>(r[SL][g], voff0, b);
+                else s8_load<(g - 4) * 1024>(r[SL][g], voff1, b);
+            });
+        }
     }
-    // item I of the current layer has been consumed: request the item RD places further down the stream into its slot
+    template <int I>
+    static constexpr int slot(IC<I>) { return S::vidx(I) % RD; }
+    // the tiles of item I have landed (nothing below this line is scheduled above it)
+    template <int I>
+    __device__ __forceinline__ void wait(IC<I>) {
+        constexpr int SL = S::vidx(I) % RD, N = S::inflight_behind(I);
+        static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+        if constexpr (S::ntiles(I) == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+a"(r[SL][0]) : "n"(N));
+        else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+a"(r[SL][0]), "+a"(r[SL][1]) : "n"(N));
+        else if constexpr (G == 4)
+            asm volatile("s_waitcnt vmcnt(%4)" : "+a"(r[SL][0]), "+a"(r[SL][1]), "+a"(r[SL][2]), "+a"(r[SL][3]) : "n"(N));
+        else
+            asm volatile("s_waitcnt vmcnt(%5)"
+                         : "+a"(r[SL][0]), "+a"(r[SL][1]), "+a"(r[SL][2]), "+a"(r[SL][3]), "+a"(r[SL][4])
+                         : "n"(N));
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // called once while item I is consumed, between two scheduling barriers: top the ring up to position vidx(I) - 1 + RD
     template <int I>
     __device__ __forceinline__ void refill(IC<I>) {
-        constexpr int J = I + RD;
-        if constexpr (J < C) load<J, 0>(IC<I % RD>{});
-        else load<J - C, 1>(IC<I % RD>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<S::req_lo(I), S::req_hi(I) + 1>([&](auto pc) { request<decltype(pc)::value>(); });
+        __builtin_amdgcn_sched_barrier(0);
     }
-    // the empty items that pad a layer to a multiple of the ring size
-    __device__ __forceinline__ void skip_pad() {
-        static_for<S::CR, C>([&](auto ic) { refill(ic); });
+    __device__ __forceinline__ void next_layer() { spG += (size_t)S::TL * 4 * 64; sp1 += (size_t)S::TL * 4 * 64; }
+    // end of an evaluation: wait for the requests that ran past the end of the stream (into its padding slot)
+    __device__ __forceinline__ void drain() {
+        static_for<0, RD>([&](auto sc) {
+            constexpr int SL = decltype(sc)::value;
+            static_for<0, G>([&](auto gc) { asm volatile("s_waitcnt vmcnt(0)" : "+a"(r[SL][decltype(gc)::value])); });
+        });
     }
-    __device__ __forceinline__ void next_layer() { sp += (size_t)S::TL * 4 * 64; }
 };
 
 // S1 / S4: OUT[4][64 G] = epilogue(ACT[4][32] @ B) with the two k-quads of this wave in items I0, I0 + 1; separate accumulators
@@ -145,10 +222,12 @@ __device__ __forceinline__ void r4f_short_mma(const float4& a0, const float4& a1
     f32x4 acc0[G], acc1[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) { acc0[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[g] = acc0[g]; }
-    r4_quad<G>(a0, ring.r[I0 % RD], acc0);
+    ring.wait(IC<I0>{});
+    r4_quad<G>(a0, ring.r[ring.slot(IC<I0>{})], acc0);
     ring.refill(IC<I0>{});
     __builtin_amdgcn_sched_barrier(0);
-    r4_quad<G>(a1, ring.r[(I0 + 1) % RD], acc1);
+    ring.wait(IC<I0 + 1>{});
+    r4_quad<G>(a1, ring.r[ring.slot(IC<I0 + 1>{})], acc1);
     ring.refill(IC<I0 + 1>{});
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -169,7 +248,8 @@ __device__ __forceinline__ void r4f_dense_wide(const float* act, int lda, Ring& 
     static_for<0, NQ>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
-        r4_quad<G>(a, ring.r[(I0 + q) % RD], acc);
+        ring.wait(IC<I0 + q>{});
+        r4_quad<G>(a, ring.r[ring.slot(IC<I0 + q>{})], acc);
         ring.refill(IC<I0 + q>{});
         __builtin_amdgcn_sched_barrier(0);
     });
@@ -194,7 +274,8 @@ __device__ __forceinline__ void r4f_narrow_mma(const float* act, int lda, Ring& 
     static_for<0, 2 * G>([&](auto tc) {
         constexpr int T = decltype(tc)::value;
         const float4 a = *reinterpret_cast<const float4*>(arow + 8 * T);
-        p.template tile<T>(a, ring.r[(I0 + T / G) % RD][T % G]);
+        if constexpr (T % G == 0) ring.wait(IC<I0 + T / G>{});
+        p.template tile<T>(a, ring.r[ring.slot(IC<I0 + T / G>{})][T % G]);
         if constexpr (T % G == G - 1) {
             ring.refill(IC<I0 + T / G>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -225,6 +306,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
     const int sblk = t.lane >> 5;
     R4FRing<NTWM> ring(reinterpret_cast<const float4*>(packed + f.o_r4f), t);
     float logq = 0.f;
+#pragma unroll 1                       // (an unrolled copy gets other ring registers, joined by copies of in-flight slots: ISA check)
     for (int layer = f.K - 1; layer >= 0; --layer) {
         const float* bt = BT + (size_t)layer * BS;
         unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
@@ -235,7 +317,8 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
             const float4 a0 = *reinterpret_cast<const float4*>(xr), a1 = *reinterpret_cast<const float4*>(xr + 4);
             r4f_short_mma<NTWM, 0>(a0, a1, ring, PART, l.PN, t);
             R4FAcc z;
-            z.template tile<0>(sblk ? a1 : a0, ring.r[S::I_A % RD][0]);
+            ring.wait(IC<S::I_A>{});
+            z.template tile<0>(sblk ? a1 : a0, ring.r[ring.slot(IC<S::I_A>{})][0]);
             ring.refill(IC<S::I_A>{});
             z.store(PZ, t);
             float bv[G];
@@ -255,7 +338,6 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
             R4FAcc p;
             r4f_narrow_mma<NTWM>(HB, l.WS, ring, p, t);
             p.store(PZ, t);
-            ring.skip_pad();
             r4_barrier();
             if (ew) {
                 float ssum = 0.f;
@@ -300,16 +382,25 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
     }
     r4_barrier();
     // reverse sweep: g = d log q / d(state), layers 0 .. K-1
+#pragma unroll 1                       // (an unrolled copy gets other ring registers, joined by copies of in-flight slots: ISA check)
     for (int layer = 0; layer < f.K; ++layer) {
         unsigned* mk = reinterpret_cast<unsigned*>(lds + l.o_MASK) + (size_t)layer * 2 * NTHREADS;
         const bool tl = layer == 1;
         if (tl) FAB_TL(f, 16);
-        float4 atile;
+        f32x4 atile;
         {   // S4: (shift | scale) cotangents -> hidden (K = 32)
             const float* dr = DP + t.arow * R4_DS + 8 * t.wave;
             const float4 a0 = *reinterpret_cast<const float4*>(dr), a1 = *reinterpret_cast<const float4*>(dr + 4);
             r4f_short_mma<NTWM, 0>(a0, a1, ring, PART, l.PN, t);
-            atile = ring.r[S::I_A % RD][0];               // A^T: used by S6 (stays in registers over S5)
+            ring.wait(IC<S::I_A>{});
+            {   // A^T: used by S6.  Copied out of the ring into VGPRs - an opaque copy: if `atile` merely aliased the slot's register,
+                // the slot's next request would get ANOTHER register and hipcc would copy that in-flight register back at the
+                // loop latch (ISA check, G = 2)
+                const f32x4 tsrc = ring.r[ring.slot(IC<S::I_A>{})][0];
+                float ax = tsrc.x, ay = tsrc.y, az = tsrc.z, aw = tsrc.w;
+                asm volatile("" : "+v"(ax), "+v"(ay), "+v"(az), "+v"(aw));
+                atile = (f32x4){ax, ay, az, aw};
+            }
             ring.refill(IC<S::I_A>{});
             float bv[G];
 #pragma unroll
@@ -327,7 +418,6 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
             const float4 ag = *reinterpret_cast<const float4*>(X + t.arow * R4_DS + 8 * t.wave + 4 * sblk);
             p.template tile<0>(ag, atile);
             p.store(PZ, t);
-            ring.skip_pad();
             r4_barrier();
             if (t.tid < 128) {
                 float v = r4f_tree8(PZ, zrow, zc);
@@ -346,6 +436,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
         if (tl) FAB_TL(f, 22);
         ring.next_layer();
     }
+    ring.drain();
     *grad_off = l.o_X0;
     return logq;
 }
@@ -385,33 +476,37 @@ __device__ float flow_sample_r4f(const FlowDims& f, const R4Lds& l, const float*
         logq = -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
     }
     r4_barrier();
-    for (int v = 0; v <= f.K; ++v) {
-        const float* bt = BT + (size_t)v * BS;
-        {   // S1: h1 = relu(z W1'' + b1''), y = z W'^-1(layer v - 1) + at   (v = 0: y = z; v = K: the last affine map alone)
-            const float* xr = X + t.arow * R4_DS + 8 * t.wave;
-            const float4 a0 = *reinterpret_cast<const float4*>(xr), a1 = *reinterpret_cast<const float4*>(xr + 4);
-            r4f_short_mma<NTWM, 0>(a0, a1, ring, PART, l.PN, t);
-            R4FAcc z;
-            z.template tile<0>(sblk ? a1 : a0, ring.r[S::I_A % RD][0]);
-            ring.refill(IC<S::I_A>{});
-            z.store(PZ, t);
-            float bv[G];
-            r4f_bias<G>(bv, bt, t);
-            r4_barrier();
-            float zv = 0.f;                                // (read before the wide epilogue's writes: one LDS round trip less)
-            if (t.tid < 128) zv = r4f_tree8(PZ, zrow, zc) + bt[2 * f.Wp + zc];
-            r4_epilogue<G, 1>(PART, l.PN, bv, HA, l.WS, mk, t);
-            if (t.tid < 128) X[zrow * R4_DS + zc] = zv;
-            r4_barrier();
-        }
+    // S1 of virtual layer v: h1 = relu(z W1'' + b1''), y = z W'^-1(layer v - 1) + at   (v = 0: y = z; v = K: the last affine map
+    // alone, its h1 discarded).  Called from the loop and once behind it: a loop with an exit in the middle gets rotated by hipcc,
+    // and the copies of S1 then disagree about the ring's registers (found by the build's ISA check)
+    auto s1 = [&](const float* bt) {
+        const float* xr = X + t.arow * R4_DS + 8 * t.wave;
+        const float4 a0 = *reinterpret_cast<const float4*>(xr), a1 = *reinterpret_cast<const float4*>(xr + 4);
+        r4f_short_mma<NTWM, 0>(a0, a1, ring, PART, l.PN, t);
+        R4FAcc z;
+        ring.wait(IC<S::I_A>{});
+        z.template tile<0>(sblk ? a1 : a0, ring.r[ring.slot(IC<S::I_A>{})][0]);
+        ring.refill(IC<S::I_A>{});
+        z.store(PZ, t);
+        float bv[G];
+        r4f_bias<G>(bv, bt, t);
+        r4_barrier();
+        float zv = 0.f;                                // (read before the wide epilogue's writes: one LDS round trip less)
+        if (t.tid < 128) zv = r4f_tree8(PZ, zrow, zc) + bt[2 * f.Wp + zc];
+        r4_epilogue<G, 1>(PART, l.PN, bv, HA, l.WS, mk, t);
+        if (t.tid < 128) X[zrow * R4_DS + zc] = zv;
+        r4_barrier();
         logq -= -bt[2 * f.Wp + 64];
-        if (v == f.K) break;
+    };
+#pragma unroll 1                       // (an unrolled copy gets other ring registers, joined by copies of in-flight slots: ISA check)
+    for (int v = 0; v < f.K; ++v) {
+        const float* bt = BT + (size_t)v * BS;
+        s1(bt);
         r4f_dense_wide<NTWM, 1>(HA, l.WS, ring, bt + f.Wp, HB, l.WS, mk + NTHREADS, PART, l.PN, t);
         {   // S3 + AffineCoupling.forward: z2 <- z2 exp(s) + shift, log_det = sum(s)
             R4FAcc p;
             r4f_narrow_mma<NTWM>(HB, l.WS, ring, p, t);
             p.store(PZ, t);
-            ring.skip_pad();
             r4_barrier();
             if (ew) {
                 float ssum = 0.f;
@@ -427,6 +522,8 @@ __device__ float flow_sample_r4f(const FlowDims& f, const R4Lds& l, const float*
         }
         ring.next_layer();
     }
+    s1(BT + (size_t)f.K * BS);
+    ring.drain();
     *x_off = l.o_X0;
     return logq;
 }
