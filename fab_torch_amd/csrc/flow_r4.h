@@ -56,7 +56,9 @@ struct R4Lds {
 
 FAB_HD R4Lds make_r4_lds(const FlowDims& f, bool fused = false) {
     R4Lds l;
-    l.WS = f.Wp + 4;                   // (Wp + 4) * 4 bytes = 16 mod 128: the 4 rows' 16-byte A reads hit 4 different bank groups
+    // (Wp + 4) * 4 bytes = 16 mod 128: the 4 rows' 16-byte A reads hit 4 different bank groups; fused stages: Wp + 16 (64 bytes
+    // mod 256) - their epilogues store a wave's outputs as 16 columns x 4 rows, which then fall into 64 different banks
+    l.WS = fused ? f.Wp + 16 : f.Wp + 4;
     l.PN = f.Wp;
     int o = 0;
     l.o_X0 = o; o += R4 * R4_DS;
@@ -270,6 +272,38 @@ __device__ __forceinline__ void r4_epilogue(const float* __restrict__ part, int 
         if (EP == 1) { const bool pos = w > 0.f; m |= (pos ? 1u : 0u) << i; w = pos ? w : 0.f; }
         if (EP == 2) w = ((m >> i) & 1u) ? w : 0.f;
         out[row * ldo + col] = post(row, col, w);
+    }
+    if (EP == 1) mask[t.tid] = m;
+}
+
+// ---- row-fastest partials (fused stages, flow_r4f.h): PART[wave][col][row] - a lane's accumulator of a column group IS the
+// float4 (rows 0 .. 3) of its column, so the partial product goes out as G 16-byte stores instead of 4 G dword stores (and the
+// compiler does not first move 4 G accumulation registers into VGPRs).  Output o = 256 i + tid of a thread is then
+// (col = o / 4, row = o % 4); its partials still sit at part[w 4 N + o], so r4_read_partials applies unchanged.
+template <int G>
+__device__ __forceinline__ void r4_store_part_rf(const f32x4 (&acc)[G], float* __restrict__ part, const Tid4& t) {
+    f32x4* pw = reinterpret_cast<f32x4*>(part + (size_t)t.wave * R4 * 64 * G) + t.lane;
+#pragma unroll
+    for (int g = 0; g < G; ++g) pw[64 * g] = acc[g];
+}
+template <int G>
+__device__ __forceinline__ void r4_bias_rf(float (&bv)[G], const float* __restrict__ b, const Tid4& t) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) bv[i] = b[(256 * i + t.tid) >> 2];
+}
+template <int G, int EP>
+__device__ __forceinline__ void r4_epilogue_rf(const float* __restrict__ part, const float (&bv)[G], float* __restrict__ out, int ldo,
+                                               unsigned* mask, const Tid4& t) {
+    unsigned m = EP == 2 ? mask[t.tid] : 0u;
+    float v[G];
+    r4_read_partials<G>(part, 64 * G, t.tid, v);
+    const int row = t.tid & 3, col0 = t.tid >> 2;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        float w = v[i] + bv[i];
+        if (EP == 1) { const bool pos = w > 0.f; m |= (pos ? 1u : 0u) << i; w = pos ? w : 0.f; }
+        if (EP == 2) w = ((m >> i) & 1u) ? w : 0.f;
+        out[row * ldo + col0 + 64 * i] = w;
     }
     if (EP == 1) mask[t.tid] = m;
 }

@@ -125,13 +125,6 @@ __device__ __forceinline__ float r4f_tree8(const float* __restrict__ pz, int row
     return ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
 }
 
-template <int G>
-__device__ __forceinline__ void r4f_bias(float (&bv)[G], const float* __restrict__ b, const Tid4& t) {
-    constexpr int N = 64 * G;
-#pragma unroll
-    for (int i = 0; i < G; ++i) bv[i] = b[(256 * i + t.tid) % N];
-}
-
 // the bias blocks of `nblk` layers: image -> LDS (all threads; the caller synchronises)
 __device__ __forceinline__ void r4f_load_bias(const float* __restrict__ src, float* __restrict__ dst, int nfloats, int tid) {
     const float4* s4 = reinterpret_cast<const float4*>(src);
@@ -232,7 +225,8 @@ __device__ __forceinline__ void r4f_short_mma(const float4& a0, const float4& a1
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) acc0[g] += acc1[g];
-    r4_store_part<G>(acc0, part, PN, t);
+    (void)PN;
+    r4_store_part_rf<G>(acc0, part, t);
 }
 
 // S2 / S5: the W x W stage on the ring, quad q = item I0 + q
@@ -253,15 +247,16 @@ __device__ __forceinline__ void r4f_dense_wide(const float* act, int lda, Ring& 
         ring.refill(IC<I0 + q>{});
         __builtin_amdgcn_sched_barrier(0);
     });
-    r4_store_part<G>(acc, part, PN, t);
+    (void)PN;
+    r4_store_part_rf<G>(acc, part, t);
     float bv[G];
-    if (bias) r4f_bias<G>(bv, bias, t);
+    if (bias) r4_bias_rf<G>(bv, bias, t);
     else {
 #pragma unroll
         for (int g = 0; g < G; ++g) bv[g] = 0.f;
     }
     r4_barrier();
-    r4_epilogue<G, EP>(part, PN, bv, out, ldo, mask, t);
+    r4_epilogue_rf<G, EP>(part, bv, out, ldo, mask, t);
     r4_barrier();
 }
 
@@ -322,11 +317,11 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
             ring.refill(IC<S::I_A>{});
             z.store(PZ, t);
             float bv[G];
-            r4f_bias<G>(bv, bt, t);
+            r4_bias_rf<G>(bv, bt, t);
             r4_barrier();
             float zv = 0.f;                                // (read before the wide epilogue's writes: one LDS round trip less)
             if (t.tid < 128) zv = r4f_tree8(PZ, zrow, zc) + bt[2 * f.Wp + zc];
-            r4_epilogue<G, 1>(PART, l.PN, bv, HA, l.WS, mk, t);
+            r4_epilogue_rf<G, 1>(PART, bv, HA, l.WS, mk, t);
             if (t.tid < 128) X[zrow * R4_DS + zc] = zv;
             r4_barrier();
         }
@@ -406,7 +401,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
 #pragma unroll
             for (int g = 0; g < G; ++g) bv[g] = 0.f;
             r4_barrier();
-            r4_epilogue<G, 2>(PART, l.PN, bv, HA, l.WS, mk + NTHREADS, t);
+            r4_epilogue_rf<G, 2>(PART, bv, HA, l.WS, mk + NTHREADS, t);
             r4_barrier();
         }
         if (tl) FAB_TL(f, 18);
@@ -489,11 +484,11 @@ __device__ float flow_sample_r4f(const FlowDims& f, const R4Lds& l, const float*
         ring.refill(IC<S::I_A>{});
         z.store(PZ, t);
         float bv[G];
-        r4f_bias<G>(bv, bt, t);
+        r4_bias_rf<G>(bv, bt, t);
         r4_barrier();
         float zv = 0.f;                                // (read before the wide epilogue's writes: one LDS round trip less)
         if (t.tid < 128) zv = r4f_tree8(PZ, zrow, zc) + bt[2 * f.Wp + zc];
-        r4_epilogue<G, 1>(PART, l.PN, bv, HA, l.WS, mk, t);
+        r4_epilogue_rf<G, 1>(PART, bv, HA, l.WS, mk, t);
         if (t.tid < 128) X[zrow * R4_DS + zc] = zv;
         r4_barrier();
         logq -= -bt[2 * f.Wp + 64];
