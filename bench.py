@@ -543,9 +543,11 @@ def main():
             "ess_trained": ess_trained,
             "spline_cfg3": spline3,
             "fast_mode": {
-                "what": "NOT the parity path: the two 320x320 GEMMs of every coupling layer on the bf16 matrix cores "
-                        "(v_mfma_f32_16x16x32_bf16, fp32 accumulation) inside the transition kernels; log q deviates "
-                        "1e-3 .. 1e-2 from the fp32 kernels",
+                "what": "NOT the parity path: the two 320x320 GEMMs of every coupling layer with bf16 operands (weights rounded at pack "
+                        "time, activations as they are fetched; fp32 accumulation) inside the chain-initialisation and transition "
+                        "kernels - up to 1152 chains on the 4-chain tiles with fused stages (v_mfma_f32_4x4x4_16b_bf16, half the "
+                        "weight stream), above on the 16-chain tiles (v_mfma_f32_16x16x32_bf16); log q deviates 1e-3 .. 1e-2 from "
+                        "the fp32 kernels",
                 "value": total / elapsed_fast, "unit": "AIS samples/s", "ms_per_step": elapsed_fast / args.steps * 1e3,
                 "speedup_vs_value": elapsed / elapsed_fast, "ess_ais": info_fast["ess_ais"], "log_Z": info_fast["log_Z"],
                 "ess_trained": None if ess_trained_fast is None else

@@ -400,7 +400,8 @@ static inline ExtraLds4 make_extra_lds4(const R4Lds& l, int D) {
 }
 
 // MODE: 0 = per-stage weight requests (flow_log_prob_r4), 1 = one stream per wave (flow_log_prob_r4s), 2 = fused stages on
-// their own stream (flow_r4f.h: flow_log_prob_r4f; the bias blocks of all layers are copied to LDS once per launch)
+// their own stream (flow_r4f.h: flow_log_prob_r4f; the bias blocks of all layers are copied to LDS once per launch), 3 = the
+// fused stages in FAST mode (bf16 W x W tiles: never the parity path)
 template <int NTWM, bool BIGD, int MODE>
 __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
                                                           const float* __restrict__ packed, TargetDev tg, HmcK a) {
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
     const bool active = ew && g < nv;
     const float eps = *a.eps_ptr + *a.ceps_ptr;
     for (int e = t.tid; e < R4 * R4_DS; e += NTHREADS) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
-    if constexpr (MODE == 2) r4f_load_bias(packed + f.o_r4fb, lds + l.o_BIAS, f.K * r4f_bias_stride(f.Wp), t.tid);
+    if constexpr (MODE >= 2) r4f_load_bias(packed + f.o_r4fb, lds + l.o_BIAS, f.K * r4f_bias_stride(f.Wp), t.tid);
     float k0 = 0.f;
     if (ew) {
         for (int j = t.c; j < D; j += 16) {
@@ -461,7 +462,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
             lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
         }
         __syncthreads();
-        if constexpr (MODE == 2) lq = flow_log_prob_r4f<NTWM>(f, l, packed, lds, t4, &goff);
+        if constexpr (MODE == 3) lq = flow_log_prob_r4f<NTWM, true>(f, l, packed, lds, t4, &goff);
+        else if constexpr (MODE == 2) lq = flow_log_prob_r4f<NTWM>(f, l, packed, lds, t4, &goff);
         else if constexpr (MODE == 1) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
         else lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 2 : 1>(f, rd, l, packed, lds, t4, &goff);
         if (ew) {
@@ -549,12 +551,12 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd,
                 const int r = e / R4_DS, j = e % R4_DS;
                 lds[l.o_X0 + e] = (j < D && row0 + r < B) ? eps0[(row0 + r) * D + j] : 0.f;
             }
-            if constexpr (MODE == 2)                   // the sampling direction's bias blocks (K + 1 virtual layers)
+            if constexpr (MODE >= 2)                   // the sampling direction's bias blocks (K + 1 virtual layers)
                 r4f_load_bias(packed + f.o_r4fb + (size_t)f.K * r4f_bias_stride(f.Wp), lds + l.o_BIAS,
                               (f.K + 1) * r4f_bias_stride(f.Wp), t.tid);
             __syncthreads();
             int xoff = 0;
-            if constexpr (MODE == 2) q0s = flow_sample_r4f<NTWM>(f, l, packed, lds, t4, &xoff);
+            if constexpr (MODE >= 2) q0s = flow_sample_r4f<NTWM>(f, l, packed, lds, t4, &xoff);       // (the sample stays fp32)
             else q0s = flow_sample_r4s<NTWM>(f, rd, l, packed, lds, t4, &xoff);
             for (int e = t.tid; e < R4 * D; e += NTHREADS) {
                 const int r = e / D, j = e % D;
@@ -575,11 +577,12 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r4(FlowDims f, R4Dims rd,
         lds[l.o_X0 + e] = v;
         if (j < D) XP[r * D + j] = v;
     }
-    if constexpr (MODE == 2) r4f_load_bias(packed + f.o_r4fb, lds + l.o_BIAS, f.K * r4f_bias_stride(f.Wp), t.tid);
+    if constexpr (MODE >= 2) r4f_load_bias(packed + f.o_r4fb, lds + l.o_BIAS, f.K * r4f_bias_stride(f.Wp), t.tid);
     __syncthreads();
     int goff = 0;
     float lq;
-    if constexpr (MODE == 2) lq = flow_log_prob_r4f<NTWM>(f, l, packed, lds, t4, &goff);
+    if constexpr (MODE == 3) lq = flow_log_prob_r4f<NTWM, true>(f, l, packed, lds, t4, &goff);
+    else if constexpr (MODE == 2) lq = flow_log_prob_r4f<NTWM>(f, l, packed, lds, t4, &goff);
     else if constexpr (MODE == 1) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
     else lq = flow_log_prob_r4<NTWM, 2, 2, 2, 1>(f, rd, l, packed, lds, t4, &goff);
     if (!ew) return;
@@ -1161,6 +1164,10 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
     const bool stream = option(FABHIP_OPT_R4_STREAM) != 0;  // 0: per-stage request groups also where the stream image exists
     if constexpr (NTWM > 5) {
         return FABHIP_ENOTSUP;                              // (use_r4_tiles never selects it)
+    } else if (NTWM >= 2 && fused && f.fast) {
+        constexpr int NS = NTWM >= 2 ? NTWM : 2;
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, 3>, bytes));
+        hipLaunchKernelGGL((k_hmc_step_r4<NS, false, 3>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
     } else if (NTWM >= 2 && fused) {
         constexpr int NS = NTWM >= 2 ? NTWM : 2;
         FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, 2>, bytes));
@@ -1189,6 +1196,11 @@ static int launch_ais_init_r4(const FlowDims& f, const float* packed, const Targ
     const dim3 grid((unsigned)((B + R4 - 1) / R4));
     if constexpr (NTWM > 5) {
         return FABHIP_ENOTSUP;
+    } else if (NTWM >= 2 && fused && f.fast) {
+        constexpr int NS = NTWM >= 2 ? NTWM : 2;
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NS, 3>, bytes));
+        hipLaunchKernelGGL((k_ais_init_r4<NS, 3>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, lq0, eps0, pt,
+                           log_w, base_log_w, an, B);
     } else if (NTWM >= 2 && fused) {
         constexpr int NS = NTWM >= 2 ? NTWM : 2;
         FAB_TRY(set_max_lds((const void*)k_ais_init_r4<NS, 2>, bytes));

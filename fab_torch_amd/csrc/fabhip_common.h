@@ -22,6 +22,7 @@ FAB_HD int pad32(int a) { return ceil_div(a, 32) * 32; }
 // hidden width is padded to 64 * (column tiles per wave), tiles per wave in {1, 2, 4, 5, 8}
 // fused 4-chain stream (flow_r4f.h): tiles per wave, layer and direction / floats of one layer's bias block
 FAB_HD int r4f_tl(int G) { return (4 * G + 4) * G + 1; }
+FAB_HD int r4f_tl_fast(int G) { return (2 * G + 4) * G + 1; }   // bf16 W x W tiles: two k-quads per tile
 FAB_HD int r4f_bias_stride(int Wp) { return 2 * Wp + 80; }
 FAB_HD int ntw_variant(int W) { const int p = ceil_div(W, 64); return p <= 2 ? p : (p <= 4 ? 4 : (p <= 5 ? 5 : 8)); }
 
@@ -46,6 +47,7 @@ struct FlowDims {
     int o_r4s;                  // the same tiles in per-wave consumption order (flow_r4.h: R4Stream; D <= 32, Wp >= 128), else -1
     int o_r8;                   // 8-chain-tile weight image (flow_r8.h; D <= 32, Wp = 256 / 320), else -1
     int o_r4f, o_r4fb;          // 4-chain tiles, fused stages (flow_r4f.h): weight stream / bias blocks (where o_r4s exists), else -1
+    int o_r4fh;                 // the same stream with bf16 W x W tiles (fast mode; density direction only), else -1
     int total;                  // total floats
     long long* timeline;        // dev-only: s_memtime stamps of workgroup 0 (nullptr in production)
     int fast;                   // this call runs the fast-mode kernels (resolved from fabhip_flow::precision by the entry point)
@@ -110,13 +112,16 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
     }
     // fused-stage 4-chain stream (flow_r4f.h): [K density forward | K density reverse | 1 pad | K + 1 sampling | 1 pad] layer slots
     // of r4f_tl(G) tiles per wave, then the bias blocks (K density, K + 1 sampling)
-    f.o_r4f = -1; f.o_r4fb = -1;
+    f.o_r4f = -1; f.o_r4fb = -1; f.o_r4fh = -1;
     if (f.o_r4s >= 0 && f.DOp == 16) {
         const int G = f.Wp / 64;
         f.o_r4f = (f.total + 63) & ~63;
         f.total = f.o_r4f + (3 * K + 3) * r4f_tl(G) * NWAVE * 256;
         f.o_r4fb = f.total;
         f.total += (2 * K + 1) * r4f_bias_stride(f.Wp);
+        // fast mode: [K density forward | K density reverse | 1 pad] layer slots of r4f_tl_fast(G) tiles
+        f.o_r4fh = (f.total + 63) & ~63;
+        f.total = f.o_r4fh + (2 * K + 1) * r4f_tl_fast(G) * NWAVE * 256;
     }
     f.timeline = nullptr;
     f.fast = 0;

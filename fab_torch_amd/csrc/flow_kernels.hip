@@ -527,13 +527,15 @@ __global__ __launch_bounds__(256) void k_pack_r4s(FlowDims f, R4Dims rd, float* 
 // (k_pack_r4: W1, W2, W2^T, W3, W3^T in fp32, copied), the assembled D x D maps W' / W'^-1 (k_affine_assemble) and the layer
 // blocks' biases.  The fused matrices W1' = W'[:, :d] W1^T (density; sampling: W'^-1 of the layer before) and the fused biases
 // are float64 products rounded once.  Layout: see flow_r4f.h.
-__global__ __launch_bounds__(256) void k_pack_r4f(FlowDims f, R4Dims rd, float* __restrict__ packed) {
+__global__ __launch_bounds__(256) void k_pack_r4f(FlowDims f, R4Dims rd, float* __restrict__ packed, int fast) {
     const int G = rd.G, K = f.K, D = f.D, d = f.d, Wp = f.Wp;
-    const int TL = r4f_tl(G), CR = 4 * G + 5, I_N = 4 * G + 3;
-    const long total4 = (long)(3 * K + 3) * TL * NWAVE * 64;
+    // fast = 1: the bf16 image (density sections only; W x W items = two k-quads per tile)
+    const int NQW = fast ? 2 * G : 4 * G;
+    const int TL = fast ? r4f_tl_fast(G) : r4f_tl(G), CR = NQW + 5, I_N = NQW + 3;
+    const long total4 = (long)(fast ? 2 * K + 1 : 3 * K + 3) * TL * NWAVE * 64;
     const float4* r4 = reinterpret_cast<const float4*>(packed + f.o_r4);
     const long LS4 = rd.layer_stride / 4;
-    float4* dst = reinterpret_cast<float4*>(packed + f.o_r4f);
+    float4* dst = reinterpret_cast<float4*>(packed + (fast ? f.o_r4fh : f.o_r4f));
     auto Wm = [&](int layer) { return packed + f.o_scratch + (size_t)layer * 2 * D * D; };           // W' (ActNorm folded)
     auto Winv = [&](int layer) { return packed + f.o_scratch + (size_t)layer * 2 * D * D + (size_t)D * D; };
     // W1[k][n] (k < 16: conditioner input, n < Wp: hidden column) of a layer, from its r4 tiles (zero beyond d / W)
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(256) void k_pack_r4f(FlowDims f, R4Dims rd, float* 
         int sec = -1, layer = 0;                           // 0 density forward, 1 density reverse, 2 sampling (virtual layer)
         if (slot < K) { sec = 0; layer = K - 1 - slot; }
         else if (slot < 2 * K) { sec = 1; layer = slot - K; }
-        else if (slot > 2 * K && slot <= 3 * K + 1) { sec = 2; layer = slot - (2 * K + 1); }
+        else if (!fast && slot > 2 * K && slot <= 3 * K + 1) { sec = 2; layer = slot - (2 * K + 1); }
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         if (sec >= 0) {
             int I, w, g;
@@ -586,8 +588,18 @@ __global__ __launch_bounds__(256) void k_pack_r4f(FlowDims f, R4Dims rd, float* 
                     else if (layer == 0) v[j] = k == c ? 1.f : 0.f;
                     else v[j] = Winv(layer - 1)[k * D + c];
                 }
-            } else if (I < I_N) {                          // W x W: k-quad 4 G w + (I - 3)
-                if (coupling) src = (sec == 1 ? rd.o_W2T : rd.o_W2) / 4 + ((long)(4 * G * w + (I - 3)) * G + g) * 64 + lane;
+            } else if (I < I_N) {                          // W x W: k-quad 4 G w + (I - 3)   (fast: k-quads 4 G w + 2 (I - 3), + 1 as bf16)
+                if (!fast) {
+                    if (coupling) src = (sec == 1 ? rd.o_W2T : rd.o_W2) / 4 + ((long)(4 * G * w + (I - 3)) * G + g) * 64 + lane;
+                } else {
+                    const long b4 = (long)lsrc * LS4 + (sec == 1 ? rd.o_W2T : rd.o_W2) / 4;
+                    const int q0 = 4 * G * w + 2 * (I - 3);
+                    const float4 lo = r4[b4 + ((long)q0 * G + g) * 64 + lane], hi = r4[b4 + ((long)(q0 + 1) * G + g) * 64 + lane];
+                    v[0] = __uint_as_float(bf16_rne(lo.x) | (bf16_rne(lo.y) << 16));
+                    v[1] = __uint_as_float(bf16_rne(lo.z) | (bf16_rne(lo.w) << 16));
+                    v[2] = __uint_as_float(bf16_rne(hi.x) | (bf16_rne(hi.y) << 16));
+                    v[3] = __uint_as_float(bf16_rne(hi.z) | (bf16_rne(hi.w) << 16));
+                }
             } else if (I < CR) {                           // dense narrow tiles: T = (I - I_N) G + g, k-quads 4 G w + 2 T + sblk
                 const int T = (I - I_N) * G + g;
                 if (sec == 1) {                            // (W1')^T: hidden row k, state column c
@@ -601,6 +613,7 @@ __global__ __launch_bounds__(256) void k_pack_r4f(FlowDims f, R4Dims rd, float* 
         }
         dst[e] = make_float4(v[0], v[1], v[2], v[3]);
     }
+    if (fast) return;
     // bias blocks: K density (layer k), K + 1 sampling (virtual layer v: coupling of layer v behind the affine map of layer v - 1)
     const int BS = r4f_bias_stride(Wp);
     float* bdst = packed + f.o_r4fb;
@@ -765,8 +778,10 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
     }
     if (f.o_r4s >= 0)
         hipLaunchKernelGGL(k_pack_r4s, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed);
-    if (f.o_r4f >= 0)
-        hipLaunchKernelGGL(k_pack_r4f, dim3(2048), dim3(256), 0, st, f, make_r4_dims(f), packed);
+    if (f.o_r4f >= 0) {
+        hipLaunchKernelGGL(k_pack_r4f, dim3(2048), dim3(256), 0, st, f, make_r4_dims(f), packed, 0);
+        hipLaunchKernelGGL(k_pack_r4f, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed, 1);
+    }
     hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();
 }

@@ -34,12 +34,15 @@
 
 namespace fab {
 
-template <int NTWM>
+// FAST (fast mode, never the parity path): the W x W items hold bf16 tiles - 2 k-quads per 1-KiB tile (lane = column, 16 bytes =
+// 8 consecutive k), so a wave's W x W stage is 2 G items instead of 4 G and streams half the bytes; everything else as fp32.
+template <int NTWM, bool FAST = false>
 struct R4F {
     static constexpr int G = NTWM;
-    static constexpr int CR = 4 * G + 5;                   // items with tiles per layer and direction
-    static constexpr int TL = (4 * G + 4) * G + 1;         // tiles per wave, layer and direction
-    static constexpr int I_A = 2, I_W = 3, I_N = 4 * G + 3;
+    static constexpr int NQW = FAST ? 2 * G : 4 * G;       // items of a W x W stage
+    static constexpr int CR = NQW + 5;                     // items with tiles per layer and direction
+    static constexpr int TL = (NQW + 4) * G + 1;           // tiles per wave, layer and direction
+    static constexpr int I_A = 2, I_W = 3, I_N = NQW + 3;
     static constexpr int ntiles(int I) { return I == I_A ? 1 : (I < CR ? G : 0); }
     static constexpr int toff(int I) { return I <= I_A ? I * G : (I - 1) * G + 1; }
     // The ring (R4FRing) holds RD items in ACCUMULATION registers; its slots are compile-time constants when RD divides the
@@ -53,15 +56,15 @@ struct R4F {
     // G = 5 (tools/experiments/price): RD = 9 (C = 27, two empty items) is 2 % SLOWER than RD = 5 - the W x W stages run at the
     // rate the L2 -> CU path delivers (~46 B/clk per CU with 256 CUs streaming) whatever is in flight, and a deeper queue only
     // delays the items of the short stages behind it
-    static constexpr int RD = G >= 5 ? 5 : (G == 4 ? 7 : 13);
+    static constexpr int RD = G >= 5 ? 5 : (G == 4 ? 7 : (FAST ? 9 : 13));   // (FAST: CR = 15 / 13 / 9 -> C = 15 / 14 / 9)
 #endif
     static constexpr int C = (CR + RD - 1) / RD * RD;
     static constexpr int E = C - CR;
-    static constexpr int STEP = (4 * G) / (E + 1) > 0 ? (4 * G) / (E + 1) : 1;
+    static constexpr int STEP = NQW / (E + 1) > 0 ? NQW / (E + 1) : 1;
     // virtual position of item I in the padded sequence / the item at virtual position V (-1: empty)
     static constexpr int vidx(int I) {
         int q = I - I_W;
-        q = q < 0 ? 0 : (q > 4 * G ? 4 * G : q);
+        q = q < 0 ? 0 : (q > NQW ? NQW : q);
         const int e = q / STEP;
         return I + (e < E ? e : E);
     }
@@ -84,7 +87,7 @@ struct R4F {
         for (int J = vidx(I) + 1; J <= prev_pos(I) - 1 + RD; ++J) n += vtiles(J);
         return n;
     }
-    static_assert(E <= 4 * G / STEP, "every empty item needs a k-quad of the W x W stage to sit behind");
+    static_assert(E <= NQW / STEP, "every empty item needs an item of the W x W stage to sit behind");
     static_assert((RD - 1) * G < 64, "vmcnt is a 6-bit counter");
 };
 
@@ -140,9 +143,9 @@ __device__ __forceinline__ void r4f_load_bias(const float* __restrict__ src, flo
 // `inflight_behind` younger loads are outstanding; any other load in flight (stage stamps) only makes a wait conservative.
 // The build's ISA check (_isa_check.py) verifies on the generated code that no instruction touches a ring register whose
 // load may still be in flight.
-template <int NTWM>
+template <int NTWM, bool FAST = false>
 struct R4FRing {
-    using S = R4F<NTWM>;
+    using S = R4F<NTWM, FAST>;
     static constexpr int G = S::G, RD = S::RD, C = S::C;
     f32x4 r[RD][G];
     const float4 *spG, *sp1;           // (layer slot, wave) of the section being consumed: items of G tiles / of one tile
@@ -233,8 +236,8 @@ __device__ __forceinline__ void r4f_short_mma(const float4& a0, const float4& a1
 template <int NTWM, int EP, class Ring>
 __device__ __forceinline__ void r4f_dense_wide(const float* act, int lda, Ring& ring, const float* __restrict__ bias, float* out,
                                                int ldo, unsigned* mask, float* part, int PN, const Tid4& t) {
-    using S = R4F<NTWM>;
-    constexpr int G = NTWM, NQ = 4 * NTWM, RD = S::RD, I0 = S::I_W;
+    using S = typename Ring::S;
+    constexpr int G = NTWM, NQ = 4 * NTWM, I0 = S::I_W;
     f32x4 acc[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -260,10 +263,72 @@ __device__ __forceinline__ void r4f_dense_wide(const float* act, int lda, Ring& 
     r4_barrier();
 }
 
+// the same stage in FAST mode: item i = k-quads 2 i, 2 i + 1 of this wave as bf16 tiles; the activations are rounded to bf16 as
+// they are fetched (v_cvt_pk_bf16_f32, round to nearest even: what fast mode's 16-chain kernels do), one
+// v_mfma_f32_4x4x4_16b_bf16 per k-quad and column group (fp32 accumulation; even / odd quads on separate accumulators, added at
+// the end: 2 G chains of G dependent instructions)
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 r4f_bf16x4(const float4& a) {
+    union { unsigned u[2]; s16x4 v; } c;
+    c.u[0] = cvt_pk_bf16(a.x, a.y);
+    c.u[1] = cvt_pk_bf16(a.z, a.w);
+    return c.v;
+}
+template <int NTWM, int EP, class Ring>
+__device__ __forceinline__ void r4f_dense_wide_bf16(const float* act, int lda, Ring& ring, const float* __restrict__ bias, float* out,
+                                                    int ldo, unsigned* mask, float* part, const Tid4& t) {
+    using S = typename Ring::S;
+    constexpr int G = NTWM, NI = 2 * NTWM, I0 = S::I_W;
+    f32x4 acc0[G], acc1[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) { acc0[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[g] = acc0[g]; }
+    const float* arow = act + t.arow * lda + 16 * NTWM * t.wave;
+    static_for<0, NI>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        const s16x4 a0 = r4f_bf16x4(*reinterpret_cast<const float4*>(arow + 8 * i));
+        const s16x4 a1 = r4f_bf16x4(*reinterpret_cast<const float4*>(arow + 8 * i + 4));
+        ring.wait(IC<I0 + i>{});
+        constexpr int SL = Ring::slot(IC<I0 + i>{});
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const f32x4 w = ring.r[SL][g];
+            acc0[g] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a0, __builtin_bit_cast(s16x4, (f32x2v)__builtin_shufflevector(w, w, 0, 1)),
+                                                             acc0[g], 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const f32x4 w = ring.r[SL][g];
+            acc1[g] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(a1, __builtin_bit_cast(s16x4, (f32x2v)__builtin_shufflevector(w, w, 2, 3)),
+                                                             acc1[g], 0, 0, 0);
+        }
+        // the item's tiles stay allocated until its last MFMA has issued: hipcc otherwise makes a consumed tile the destination of
+        // the MFMA that reads its upper half (v_mfma a[68:71], v[..], a[70:71]), and on gfx950 the pipelined 4x4x4 bf16 MFMA then
+        // returns wrong sums (round 5: odd k-quads wrong exactly for the column groups allocated that way; the f32 4x4x1 form with
+        // the same overlap is fine, a single bf16 MFMA with it as well)
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" : : "a"(ring.r[SL][g]));
+        ring.refill(IC<I0 + i>{});
+        __builtin_amdgcn_sched_barrier(0);
+    });
+#pragma unroll
+    for (int g = 0; g < G; ++g) acc0[g] += acc1[g];
+    r4_store_part_rf<G>(acc0, part, t);
+    float bv[G];
+    if (bias) r4_bias_rf<G>(bv, bias, t);
+    else {
+#pragma unroll
+        for (int g = 0; g < G; ++g) bv[g] = 0.f;
+    }
+    r4_barrier();
+    r4_epilogue_rf<G, EP>(part, bv, out, ldo, mask, t);
+    r4_barrier();
+}
+
 // the 2 G dense tiles of items I_N, I_N + 1 against ACT[4][Wp] (this wave's K range: quads 4 G w + 2 T + sblk)
 template <int NTWM, class Ring>
 __device__ __forceinline__ void r4f_narrow_mma(const float* act, int lda, Ring& ring, R4FAcc& p, const Tid4& t) {
-    using S = R4F<NTWM>;
+    using S = typename Ring::S;
     constexpr int G = NTWM, RD = S::RD, I0 = S::I_N;
     const float* arow = act + t.arow * lda + 16 * NTWM * t.wave + 4 * (t.lane >> 5);
     static_for<0, 2 * G>([&](auto tc) {
@@ -282,10 +347,10 @@ __device__ __forceinline__ void r4f_narrow_mma(const float* act, int lda, Ring& 
 // log q(x) and d log q / dx for the 4 rows in X0 (columns >= D zero).  The gradient is left in X0 (*grad_off = l.o_X0, leading
 // dimension R4_DS); returns log q of row `tid >> 4` on wave 0.  The density bias table must be in LDS at l.o_BIAS.
 // ------------------------------------------------------------------------------------------------
-template <int NTWM>
+template <int NTWM, bool FAST = false>
 __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const float* __restrict__ packed, float* lds,
                                    const Tid4& t, int* grad_off) {
-    using S = R4F<NTWM>;
+    using S = R4F<NTWM, FAST>;
     constexpr int G = NTWM, RD = S::RD;
     float* X = lds + l.o_X0;
     float* HA = lds + l.o_HA;
@@ -299,7 +364,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
     const int row = t.tid >> 4, c = t.tid & 15;            // element-wise mapping of wave 0 (coupling, base distribution)
     const int zrow = t.tid >> 5, zc = t.tid & 31;          // (row, column) of the 4 x 32 outputs of a dense narrow product
     const int sblk = t.lane >> 5;
-    R4FRing<NTWM> ring(reinterpret_cast<const float4*>(packed + f.o_r4f), t);
+    R4FRing<NTWM, FAST> ring(reinterpret_cast<const float4*>(packed + (FAST ? f.o_r4fh : f.o_r4f)), t);
     float logq = 0.f;
 #pragma unroll 1                       // (an unrolled copy gets other ring registers, joined by copies of in-flight slots: ISA check)
     for (int layer = f.K - 1; layer >= 0; --layer) {
@@ -327,7 +392,8 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
         }
         logq += bt[2 * f.Wp + 64];
         if (tl) FAB_TL(f, 1);
-        r4f_dense_wide<NTWM, 1>(HA, l.WS, ring, bt + f.Wp, HB, l.WS, mk + NTHREADS, PART, l.PN, t);
+        if constexpr (FAST) r4f_dense_wide_bf16<NTWM, 1>(HA, l.WS, ring, bt + f.Wp, HB, l.WS, mk + NTHREADS, PART, t);
+        else r4f_dense_wide<NTWM, 1>(HA, l.WS, ring, bt + f.Wp, HB, l.WS, mk + NTHREADS, PART, l.PN, t);
         if (tl) FAB_TL(f, 3);
         {   // S3: (shift | s) = h2 W3 + b3, then AffineCoupling.inverse: z2 <- (z2 - shift) exp(-s), log_det = -sum(s)
             R4FAcc p;
@@ -405,7 +471,8 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
             r4_barrier();
         }
         if (tl) FAB_TL(f, 18);
-        r4f_dense_wide<NTWM, 2>(HA, l.WS, ring, nullptr, HB, l.WS, mk, PART, l.PN, t);
+        if constexpr (FAST) r4f_dense_wide_bf16<NTWM, 2>(HA, l.WS, ring, nullptr, HB, l.WS, mk, PART, t);
+        else r4f_dense_wide<NTWM, 2>(HA, l.WS, ring, nullptr, HB, l.WS, mk, PART, l.PN, t);
         if (tl) FAB_TL(f, 19);
         {   // S6: g_y = dh1 W1'^T + g_z A^T, then the coupling cotangents of layer + 1
             R4FAcc p;

@@ -75,7 +75,9 @@ int tail_small(const TailArgs& a, int* dest, hipStream_t st);
 // only (the other instantiations spill registers and are not compiled).  Used by the transitions, the chain initialisation and
 // the flow sample alike.
 static inline bool use_r4_tiles(const FlowDims& f, long B) {
-    if (f.fast || f.D > 32 || f.NTW / 4 > 5) return false;
+    if (f.D > 32 || f.NTW / 4 > 5) return false;
+    // fast mode: only where the fused-stage stream has its bf16 image (flow_r4f.h; round 5) - else the 16-chain fast kernels
+    if (f.fast && !(f.o_r4fh >= 0 && f.NTW / 4 >= 2 && option(FABHIP_OPT_R4_STREAM) >= 2)) return false;
     const int shape = option(FABHIP_OPT_TILE_SHAPE);
     if (shape == 16 || shape == 8) return false;
     if (shape == 4) return true;

@@ -78,6 +78,47 @@ def test_fast_mode_is_the_flow_with_bf16_rounded_inner_gemm_operands(D, K, nodes
     assert float(rel.median()) <= 2e-3 and float(rel.max()) <= 5e-2, f"grad vs emulation: {float(rel.max()):.2e}"
 
 
+@pytest.mark.parametrize("D,K,nodes,B,M", [(32, 10, 10, 1024, 2), (32, 10, 10, 37, 3), (6, 8, 40, 64, 2), (16, 3, 8, 100, 2)])
+def test_fast_mode_on_four_chain_tiles_is_the_same_flow_with_bf16_rounded_inner_gemm_operands(D, K, nodes, B, M):
+    """Round 5: up to 1152 chains fast mode runs on the 4-chain tiles with fused stages (flow_r4f.h, bf16 W x W tiles,
+    v_mfma_f32_4x4x4_16b_bf16) - chain initialisation and transitions of a fused AIS call.  log q and d log q / dx of the
+    returned points (written by those kernels) against the float64 emulation at the returned x; deterministic; the fp32
+    call on the same noise untouched by the switch."""
+    torch.manual_seed(D + K)
+    nf = oflow.make_realnvp(D, K, nodes)
+    oflow.randomize_last_layers(nf, 0.02, 5)
+    hf = fa.RealNVP(D, K, nodes)
+    hf._nf_model.load_state_dict(nf.state_dict())
+    hf = hf.to(DEV).requires_grad_(False)
+    target = fa.ManyWellEnergy(D)
+    g = torch.Generator(device=DEV).manual_seed(7)
+    eps0 = torch.randn(B, D, device=DEV, generator=g)
+    na = torch.randn(M, 1, B, D, device=DEV, generator=g)
+    nb = torch.empty(M, 1, B, device=DEV).exponential_(generator=g)
+
+    def call(fast):
+        hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05, L=3,
+                                       eval_mode=True).to(DEV)
+        ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, M)
+        with fa.fast_mode(fast):
+            pt, lw = ais.sample_and_log_weights(B, eps0=eps0, noise_a=na, noise_b=nb)
+        return pt.x.clone(), pt.log_q.clone(), pt.grad_log_q.clone(), lw.clone()
+
+    r32, rf, rf2, r32b = call(False), call(True), call(True), call(False)
+    assert all(torch.equal(a, b) for a, b in zip(r32, r32b))              # the fp32 path is untouched
+    assert all(torch.equal(a, b) for a, b in zip(rf, rf2))                # deterministic
+    assert not torch.equal(rf[1], r32[1])                                 # (and it is another computation)
+    x, lq, gq, _ = rf
+    em = emulation(nf)
+    xg = x.cpu().double().requires_grad_(True)
+    lq_e = em.log_prob(xg)
+    (g_e,) = torch.autograd.grad(lq_e.sum(), xg)
+    dev_em = float((lq.cpu().double() - lq_e.detach()).abs().max())
+    assert dev_em <= 2e-3, f"4-chain fast mode vs its emulation: {dev_em:.2e}"
+    rel = (gq.cpu().double() - g_e).norm(dim=1) / g_e.norm(dim=1)
+    assert float(rel.median()) <= 2e-3 and float(rel.max()) <= 5e-2, f"grad vs emulation: {float(rel.max()):.2e}"
+
+
 def test_fast_mode_ais_on_the_trained_flow_keeps_the_ess_within_one_percent():
     """g13: the committed trained ManyWell-6 flow and the reference's evaluation AIS call on it (captured noise).  The
     fp32 path reproduces the reference ESS to 1e-6 (test_gpu_workloads); the fast mode must stay within 1 % of it."""
