@@ -9,7 +9,7 @@ from .flow import RealNVP, make_wrapped_normflow_realnvp
 from .targets import ManyWellEnergy, GMM
 from .transition_operators import (TransitionOperator, HamiltonianMonteCarlo, Metropolis, create_point, grad_and_value,
                                    get_intermediate_log_prob, get_grad_intermediate_log_prob)
-from .ais import AnnealedImportanceSampler, LoggingInfo
+from .ais import AnnealedImportanceSampler, LoggingInfo, NoValidPoints
 from .numerical import effective_sample_size, ess_and_log_z
 from .core import FABModel
 from .buffer import PrioritisedReplayBuffer, sample_without_replacement
@@ -42,7 +42,7 @@ class fast_mode:
 __all__ = [
     "Point", "RealNVP", "make_wrapped_normflow_realnvp", "ManyWellEnergy", "GMM", "TransitionOperator",
     "HamiltonianMonteCarlo", "Metropolis", "create_point", "grad_and_value", "get_intermediate_log_prob",
-    "get_grad_intermediate_log_prob", "AnnealedImportanceSampler", "LoggingInfo",
+    "get_grad_intermediate_log_prob", "AnnealedImportanceSampler", "LoggingInfo", "NoValidPoints",
     "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
     "multinomial_torch_compat", "gather_rows", "FABModel", "PrioritisedReplayBuffer",
     "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam", "WrappedTorchDist", "CircularCoupledRQSFlow", "make_wrapped_normflow_spline", "fast_mode",

@@ -216,6 +216,37 @@ def check_kernel(name, insns):
     return sorted(set(bad))
 
 
+def check_adapt_fold(name, insns):
+    """The in-kernel step-size rule of the 4- / 8-chain transition kernels (csrc/ais_kernels.hip: hmc_store_row_stats /
+    hmc_adapt_last) orders its cross-workgroup traffic by HARDWARE behaviour, not by the HIP memory model: the
+    per-chain values are written with device-scope relaxed atomic stores, which gfx950 lowers to write-through stores (sc1:
+    visible in memory when vmcnt retires them), the wave waits vmcnt(0) and draws a ticket (returning atomic add), and the wave
+    with the last ticket reads the values past the non-coherent L2 (sc1 loads).  A compiler that lowers those accesses
+    differently would silently break the rule, so the lowering itself is checked on every build: in such a kernel the ticket
+    must directly follow an `s_waitcnt vmcnt(0)` with no vector-memory instruction in between, at least two `sc1` dword stores
+    must precede it, and at least 32 `sc1` dword loads (16 rows x 2 statistics) must follow it."""
+    if not re.search(r"k_hmc_step_r[48]", name):
+        return []
+    texts = [x[1] for x in insns]
+    tickets = [i for i, t in enumerate(texts) if t.startswith("global_atomic_add") and " sc0" in t]
+    if not tickets:
+        return []                                   # (an instantiation without the folded rule)
+    bad = []
+    for i in tickets:
+        j = i - 1
+        while j >= 0 and not (texts[j].startswith("s_waitcnt") and "vmcnt(0)" in texts[j]) and not _VMEM.match(texts[j]) and i - j < 48:
+            j -= 1                                  # (weaker waits hipcc adds at joins in between are no-ops on an empty queue)
+        if j < 0 or not (texts[j].startswith("s_waitcnt") and "vmcnt(0)" in texts[j]):
+            bad.append((i, "ticket not directly behind s_waitcnt vmcnt(0)", texts[i]))
+    n_st = sum(1 for t in texts[:tickets[-1]] if t.startswith("global_store_dword ") and " sc1" in t)
+    n_ld = sum(1 for t in texts[tickets[0]:] if t.startswith("global_load_dword ") and " sc1" in t)
+    if n_st < 2:
+        bad.append((tickets[0], f"only {n_st} write-through (sc1) statistic stores in front of the ticket", texts[tickets[0]]))
+    if n_ld < 32:
+        bad.append((tickets[0], f"only {n_ld} sc1 statistic loads behind the ticket", texts[tickets[0]]))
+    return bad
+
+
 def check_object(obj, patterns=None, verbose=False):
     """{kernel: findings} for the kernels of `obj` whose name contains one of `patterns` (all when None)."""
     out = {}
@@ -224,7 +255,7 @@ def check_object(obj, patterns=None, verbose=False):
             continue
         if not insns:
             continue
-        bad = check_kernel(name, insns)
+        bad = check_kernel(name, insns) + check_adapt_fold(name, insns)
         out[name] = bad
         if verbose:
             n_ld = sum(1 for _, l, _ in insns if l.startswith("global_load_dwordx4"))

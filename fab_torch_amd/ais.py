@@ -17,6 +17,16 @@ from .transition_operators import (HamiltonianMonteCarlo, Metropolis, Transition
                                    create_point_generic, _owner, _owner_or_none)
 
 
+class NoValidPoints(Exception):
+    """The reference's `Exception("No valid points generated in sampling the chain init / end")` (ais.py:202-204, 211) as a class of
+    its own - same message, still an `Exception` for callers written against the reference - so that the sharded sampler can tell
+    an empty shard from any other failure (it matched the message text of a bare Exception).  `phase`: "init" / "end"."""
+
+    def __init__(self, phase: str):
+        super().__init__(f"No valid points generated in sampling the chain {phase}")
+        self.phase = phase
+
+
 class LoggingInfo(NamedTuple):
     ess_base: float
     ess_ais: float
@@ -230,7 +240,7 @@ class AnnealedImportanceSampler:
         n_valid = int(valid.sum())
         if n_valid == 0:
             if raise_exception:
-                raise Exception(f"No valid points generated in sampling the {descriptor}")
+                raise NoValidPoints(descriptor.replace("chain ", ""))
             print(f"No valid points generated in sampling the {descriptor}")       # ais.py:206-207 (evaluation)
             return point, log_w
         if n_valid == valid.shape[0]:
@@ -257,9 +267,9 @@ class AnnealedImportanceSampler:
             point, log_w, n_valid, stats, _, _ = self.run(batch_size, eps0, noise_a, noise_b)
         host, (n_init, n_end) = _ops.read_counts_and_stats(n_valid, stats)   # the single device->host read
         if n_init == 0:
-            raise Exception("No valid points generated in sampling the chain init")
+            raise NoValidPoints("init")
         if n_end == 0:
-            raise Exception("No valid points generated in sampling the chain end")
+            raise NoValidPoints("end")
         if n_end != batch_size:
             print(f"{batch_size - n_end} nan/inf samples/log-probs/log-weights encountered.")
             point, log_w = point[:n_end], log_w[:n_end]
@@ -293,7 +303,7 @@ class AnnealedImportanceSampler:
             counts.append(n_valid)
         host = torch.stack(counts).cpu()                       # the single synchronisation
         if int(host[:, 0].min()) == 0:
-            raise Exception("No valid points generated in sampling the chain init")
+            raise NoValidPoints("init")
         n0 = [int(v) for v in host[:, 0]]
         n1 = [int(v) if int(v) > 0 else n0[i] for i, v in enumerate(host[:, 1])]   # "chain end": print + keep (:170)
         if any(int(v) == 0 for v in host[:, 1]):

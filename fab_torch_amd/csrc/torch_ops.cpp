@@ -22,6 +22,7 @@
 #include <torch/csrc/distributed/c10d/GroupRegistry.hpp>
 #include <torch/csrc/distributed/c10d/ProcessGroup.hpp>
 
+#include <algorithm>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -171,7 +172,13 @@ static std::vector<int64_t> g_keysets_free;        // released slots (tensors_ke
 int64_t tensors_key_register(at::TensorList ts, int64_t reuse) {
     std::lock_guard<std::mutex> lk(g_keysets_mu);
     std::vector<Tensor> v(ts.begin(), ts.end());
-    if (reuse >= 0 && reuse < (int64_t)g_keysets.size()) { g_keysets[(size_t)reuse] = std::move(v); return reuse; }
+    // (a slot is re-used only while its owner still holds it: one that has been released - and may have been handed to another
+    //  flow since - is not the caller's any more)
+    if (reuse >= 0 && reuse < (int64_t)g_keysets.size() &&
+        std::find(g_keysets_free.begin(), g_keysets_free.end(), reuse) == g_keysets_free.end()) {
+        g_keysets[(size_t)reuse] = std::move(v);
+        return reuse;
+    }
     if (!g_keysets_free.empty()) {
         const int64_t h = g_keysets_free.back();
         g_keysets_free.pop_back();
@@ -185,6 +192,8 @@ int64_t tensors_key_register(at::TensorList ts, int64_t reuse) {
 void tensors_key_release(int64_t handle) {
     std::lock_guard<std::mutex> lk(g_keysets_mu);
     if (handle < 0 || handle >= (int64_t)g_keysets.size()) return;
+    if (std::find(g_keysets_free.begin(), g_keysets_free.end(), handle) != g_keysets_free.end()) return;   // already free: a second
+                                                                                       // release must not hand the slot out twice
     g_keysets[(size_t)handle].clear();
     g_keysets[(size_t)handle].shrink_to_fit();
     g_keysets_free.push_back(handle);

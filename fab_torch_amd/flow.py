@@ -303,9 +303,9 @@ class RealNVP(nn.Module):
         return tensors
 
     def invalidate_native(self):
-        """Forget the registered parameter set (`_param_key`).  Needed only after ASSIGNING a new nn.Parameter object to a layer of
-        `_nf_model` (in-place updates, `.data = ...`, `.to()`, `load_state_dict` keep the objects and are seen by the key) - the
-        same contract torch.optim has with the parameters it was given."""
+        """Forget the registered parameter set (`_param_key`).  Since round 5 `_param_key` compares every registered tensor object
+        with what its module holds, so a re-assigned Parameter / buffer (`layer.weight = nn.Parameter(..)`,
+        `load_state_dict(assign=True)`) re-registers by itself; this stays as the explicit form (and for a replaced sub-MODULE)."""
         self.__dict__.pop("_pset", None)                       # (the slot of the op layer, `_pset_handle`, is kept and re-used)
         self.__dict__.pop("_leaf_cache", None)
         self._packed_key = None
@@ -313,6 +313,15 @@ class RealNVP(nn.Module):
     def _own_handle(self):
         h = self.__dict__.get("_pset_handle")                  # (owner token, slot): a deep copy / un-pickled flow carries its
         return h[1] if h is not None and h[0] == _ops.owner_token(self) else -1    # source's entry and must not use it
+
+    def __getstate__(self):
+        """Pickling / copy.deepcopy: the handles of the op layer's parameter-set registry (and the caches built on them) belong to
+        THIS object in THIS process and do not travel - a copy or an un-pickled flow registers its own tensors (the
+        owner token alone, (process nonce, id), can be met again by an object created after its source was collected)."""
+        st = dict(self.__dict__)
+        for k in ('_pset', '_pset_handle', '_leaf_cache'):
+            st.pop(k, None)
+        return st
 
     def __del__(self):
         try:
@@ -329,8 +338,8 @@ class RealNVP(nn.Module):
 
     def _param_key(self, ops):
         """Identity of the current parameter values: the tensors are registered with the op layer ONCE (112 dict look-ups and a
-        112-tensor list through the dispatcher cost 35 us per AIS call while the GPU has nothing to do); per call, three probe
-        objects are compared by identity and one integer goes through the dispatcher."""
+        112-tensor list through the dispatcher cost 35 us per AIS call while the GPU has nothing to do); per call, every registered
+        object is compared by identity with what its module holds now (~4 us) and one integer goes through the dispatcher."""
         nf = self._nf_model
         c = self.__dict__.get("_pset")
         if c is not None and c[0] is nf and c[1] == (self.n_layers, self.act_norm) and c[2] == self._own_handle():
@@ -345,11 +354,25 @@ class RealNVP(nn.Module):
         self.__dict__.pop("_leaf_cache", None)                 # (a copy's cache names the source's modules)
         handle = ops.tensors_key_register(self._param_list_fast(for_key=True), self._own_handle())
         self.__dict__["_pset_handle"] = (_ops.owner_token(self), handle)
+        # identity probes for EVERY registered tensor: (owning dict, name, object).  ADVICE r4: three probes did not see a
+        # Parameter / buffer object re-assigned in another layer (`layer.weight = nn.Parameter(..)`, `load_state_dict(assign=True)`),
+        # and the stale image was then sampled silently; 112 dict look-ups cost ~4 us per call
         lc = self.__dict__["_leaf_cache"]
-        first, last, q0 = lc[2][0], lc[2][-1], lc[4]
-        probes = [(first[0]._parameters, "weight", first[0]._parameters["weight"]),
-                  (last[3]._parameters, "L", last[3]._parameters["L"]),
-                  (q0._parameters, "loc", q0._parameters.get("loc"))]
+        probes = []
+        for mods in lc[2]:
+            for m, names in zip(mods, self._LEAF_ATTRS):
+                for n in names:
+                    d = m._parameters if m._parameters.get(n) is not None else m._buffers
+                    probes.append((d, n, d[n]))
+        q0 = lc[4]
+        for n in ("loc", "log_scale"):
+            if q0._parameters.get(n) is not None:
+                probes.append((q0._parameters, n, q0._parameters[n]))
+        for an in lc[3]:
+            for n in ("s", "t"):
+                d = an._parameters if an._parameters.get(n) is not None else an._buffers
+                if d.get(n) is not None:
+                    probes.append((d, n, d[n]))
         self.__dict__["_pset"] = (nf, (self.n_layers, self.act_norm), handle, probes)
         return tuple(ops.tensors_key_of(handle))
 

@@ -184,16 +184,22 @@ class HipShardBackend:
         self.ops.metropolis_adapt_gathered(gathered, int(world), int(b), op.noise_scalings, float(op.target_prob_accept), True)
 
     def run_fused(self, b, eps0=None, noise_a=None, noise_b=None):
+        from .ais import NoValidPoints
         from .point import Point
+        self.empty_phase = None
         try:
             pt, log_w = self.ais.sample_and_log_weights(b, eps0=eps0, noise_a=noise_a, noise_b=noise_b)
-        except Exception as e:                            # the reference's "No valid points ..." (ais.py:201,211) of THIS shard:
-            if "No valid points" not in str(e):           # an empty shard - the gathered set decides (see finish)
-                raise
+        except NoValidPoints as e:                        # the reference's "No valid points ..." (ais.py:201,211) of THIS shard,
+            self.empty_phase = e.phase                    # and nothing else (the message text of any Exception was matched)
+            # an empty shard - the gathered set decides (see finish).  The shape of an empty Point comes from the sampler's own
+            # plug-ins (native flows have `dim`; a generic base distribution its `event_shape`)
             flow = self.ais.base_distribution
-            dev = next(flow.parameters()).device
+            D = int(getattr(flow, "dim", None) or flow.event_shape[0])
+            try:
+                dev = next(flow.parameters()).device
+            except (StopIteration, AttributeError):
+                dev = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
             z = lambda *sh: torch.zeros(sh, dtype=torch.float32, device=dev)      # noqa: E731
-            D = int(flow.dim)
             pt, log_w = Point(z(0, D), z(0), z(0), z(0, D), z(0, D)), z(0)
         return pt, log_w
 
@@ -376,7 +382,11 @@ class ShardedAnnealedImportanceSampler:
         if compact:                                        # (the boolean-mask indexing synchronises with the host anyway)
             x, lw, lq = unpack_particles(buf)
             if x.shape[0] == 0:                            # every rank sees the same gathered set: all raise together
-                raise Exception("No valid points generated in sampling the chain end")
+                from .ais import NoValidPoints
+                # (one rank: the phase in which this rank's chains died, as the reference reports it; several ranks may have lost
+                #  theirs in different phases - "end" then: the gathered set is what is empty)
+                phase = getattr(be, "empty_phase", None) if world == 1 else None
+                raise NoValidPoints(phase or "end")
         else:
             x, lw, lq = buf[:, :D], buf[:, D], buf[:, D + 1]
         if logging:

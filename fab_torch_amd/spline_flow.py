@@ -370,6 +370,15 @@ class CircularCoupledRQSFlow(nn.Module):
         h = self.__dict__.get("_pset_handles")                 # (owner token, (slot, slot)): a deep copy / un-pickled flow carries
         return h[1] if h is not None and h[0] == _ops.owner_token(self) else (-1, -1)    # its source's entry and must not use it
 
+    def __getstate__(self):
+        """Pickling / copy.deepcopy: the handles of the op layer's parameter-set registry (and the caches built on them) belong to
+        THIS object in THIS process and do not travel - a copy or an un-pickled flow registers its own tensors (the
+        owner token alone, (process nonce, id), can be met again by an object created after its source was collected)."""
+        st = dict(self.__dict__)
+        for k in ('_pset', '_pset_handles'):
+            st.pop(k, None)
+        return st
+
     def __del__(self):
         try:
             for h in self._own_handles():
@@ -385,7 +394,7 @@ class CircularCoupledRQSFlow(nn.Module):
 
     def _param_keys(self, ops):
         """((storage address, version) mix of the parameters, the same of the buffers): the tensor objects are registered with
-        the op layer once (fabhip::tensors_key_register), three of each are compared by identity per call, two integers go
+        the op layer once (fabhip::tensors_key_register), all of them are compared by identity per call, two integers go
         through the dispatcher - instead of walking `parameters()` / `buffers()` (hundreds of attribute reads per AIS call)."""
         c = self.__dict__.get("_pset")
         if c is not None and (c[0], c[1]) != self._own_handles():
@@ -408,7 +417,8 @@ class CircularCoupledRQSFlow(nn.Module):
             hp = ops.tensors_key_register([e[2] for e in plist], old[0])
             hb = ops.tensors_key_register([e[2] for e in blist], old[1])
             self.__dict__["_pset_handles"] = (_ops.owner_token(self), (hp, hb))
-            probes = [lst[i] for lst in (plist, blist) if lst for i in sorted({0, len(lst) // 2, len(lst) - 1})]
+            probes = plist + blist                               # EVERY registered tensor (three probes missed a
+                                                                 # Parameter / buffer re-assigned in another layer; ~10 us per call)
             c = (hp, hb, probes)
             self.__dict__["_pset"] = c
         return tuple(ops.tensors_key_of(c[0])), tuple(ops.tensors_key_of(c[1]))

@@ -82,6 +82,31 @@ class Capture:
         torch.randn_like, torch.distributions.Exponential.sample, torch.randn, torch.rand = self._o
 
 
+class Inject:
+    """The reverse of Capture: the reference's next `torch.randn_like` / `Exponential.sample` calls return the given draws, in
+    order (a re-run of selected chains on the noise a larger run captured for them)."""
+
+    def __init__(self, randn_like, expo):
+        self.rl, self.ex = list(randn_like), list(expo)
+
+    def __enter__(self):
+        self._o = (torch.randn_like, torch.distributions.Exponential.sample)
+        inj = self
+
+        def randn_like(x, *a, **k):
+            t = inj.rl.pop(0); assert t.shape == x.shape; return t.clone()
+
+        def expo(self_, shape=torch.Size()):
+            t = inj.ex.pop(0); assert tuple(t.shape) == tuple(shape); return t.clone()
+
+        torch.randn_like = randn_like
+        torch.distributions.Exponential.sample = expo
+        return self
+
+    def __exit__(self, *exc):
+        torch.randn_like, torch.distributions.Exponential.sample = self._o
+
+
 class EpsFlow:
     """`Distribution` adapter: deterministic base noise for the oracle flow."""
 
@@ -317,7 +342,7 @@ def g8_full_chain():
     npz("g8_ais_gmm_metropolis.npz", **out)
 
 
-def g14_headline_arch(name="g14_ais_headline.npz", std=0.05, eps_init=0.2, seed=140):
+def g14_headline_arch(name="g14_ais_headline.npz", std=0.05, eps_init=0.2, seed=140, save=True, B=64, tune=True, noise=None):
     """(`g15_ais_headline_mild.npz`: the same call in a MILD regime - last coupling Linears N(0, 0.01^2), initial step size
     0.05 - in which one transition does not amplify fp32 rounding: the GPU test allows no waiver on it)
     The reference's own AIS call and one HMC transition at the HEADLINE flow architecture (many_well.yaml:7-10: RealNVP
@@ -326,12 +351,12 @@ def g14_headline_arch(name="g14_ais_headline.npz", std=0.05, eps_init=0.2, seed=
     rebuilds them from the seed (same routine, same torch CPU generator); the fixture holds noise, every transition's
     input step sizes and output state (snapshots for teacher-forced per-transition checks) and the final outputs."""
     from helpers import seeded_oracle_flow
-    D, K, nodes, M, L, B, alpha = 32, 10, 10, 8, 5, 64, 2.0
+    D, K, nodes, M, L, alpha = 32, 10, 10, 8, 5, 2.0
     nf = seeded_oracle_flow(D, K, nodes, seed, std)
     target = ManyWellEnergy(dim=D, use_gpu=False)
-    hmc = tuned_hmc(M, D, nf, target, eps_init, L, 1, alpha, False)
+    hmc = tuned_hmc(M, D, nf, target, eps_init, L, 1, alpha, False, tune=tune)
     torch.manual_seed(seed + 1)
-    eps0 = torch.randn(B, D)
+    eps0 = torch.randn(B, D) if noise is None else noise[0]      # noise = (eps0, [momenta per transition], [Exp(1) per transition])
     ais = AnnealedImportanceSampler(EpsFlow(nf, eps0), target.log_prob, hmc, p_target=False, alpha=alpha,
                                     n_intermediate_distributions=M)
     in_eps, in_ceps = hmc.epsilons.clone(), hmc.common_epsilon.clone()
@@ -346,11 +371,17 @@ def g14_headline_arch(name="g14_ais_headline.npz", std=0.05, eps_init=0.2, seed=
         snaps.append((out.x.clone(), out.log_q.clone(), out.log_p.clone()))
         return out
     hmc.transition = recording_transition
-    with Capture() as cap:
-        pt, log_w = ais.sample_and_log_weights(B)
+    if noise is None:
+        with Capture() as cap:
+            pt, log_w = ais.sample_and_log_weights(B)
+    else:                                              # (the same reference call on given draws)
+        cap = Capture()
+        cap.randn_like, cap.expo = [t.clone() for t in noise[1]], [t.clone() for t in noise[2]]
+        with Inject(noise[1], noise[2]):
+            pt, log_w = ais.sample_and_log_weights(eps0.shape[0])
     hmc.transition = orig
     info = ais.get_logging_info()
-    npz(name, D=D, K=K, nodes=nodes, flow_seed=seed, flow_std=std, M=M, L=L, alpha=alpha, p_target=0,
+    out = dict(D=D, K=K, nodes=nodes, flow_seed=seed, flow_std=std, M=M, L=L, alpha=alpha, p_target=0,
         eps0=eps0, B_space=ais.B_space, in_epsilons=in_eps, in_common_epsilon=in_ceps,
         noise_p=torch.stack(cap.randn_like)[:, None], noise_e=torch.stack(cap.expo)[:, None],
         snap_x=torch.stack([s_[0] for s_ in snaps]), snap_log_q=torch.stack([s_[1] for s_ in snaps]),
@@ -362,6 +393,93 @@ def g14_headline_arch(name="g14_ais_headline.npz", std=0.05, eps_init=0.2, seed=
         # a probe of the rebuilt weights: the fixture is only valid for the flow `seeded_oracle_flow` returns
         flow_probe=torch.stack([nf.flows[0].flows[1].param_map.net[2].weight[0, :8].detach(),
                                 nf.flows[-2].flows[1].param_map.net[4].weight[1, :8].detach()]))
+    if save:
+        npz(name, **out)
+    return out
+
+
+def g16_rejecting(name="g16_ais_headline_rejecting.npz", std=0.01, eps_init=0.26, seed=160, pool=512, keep=64, verbose=True):
+    """the headline architecture with BOTH accept outcomes and still no ill-conditioned chain.  At a step size at
+    which a quarter of the proposals is rejected, some chains of ANY batch sit next to a ReLU kink or an accept threshold, so the
+    fixture is a SELECTION: the reference runs `pool` chains (step-size tuning frozen: chains are then independent of each other),
+    the float64 oracle - teacher-forced from the reference's snapshots - marks the chains on which, in EVERY transition, the
+    reference's fp32 proposal is within 5e-6 (densities: 1e-5) of float64, the accept margin exceeds 0.05 and the decisions agree; `keep` of those
+    (rejecting ones first) are re-run through the reference on their own captured noise, and that run is the fixture."""
+    import copy
+    from helpers import seeded_oracle_flow
+    from oracle import ais as oais, targets as otgt
+    big = g14_headline_arch("unused", std=std, eps_init=eps_init, seed=seed, save=False, B=pool, tune=False)
+    D, M, L, alpha = int(big["D"]), int(big["M"]), int(big["L"]), float(big["alpha"])
+    nf64 = copy.deepcopy(seeded_oracle_flow(D, int(big["K"]), int(big["nodes"]), seed, std)).double()
+    otarget = otgt.ManyWell(D)
+    o64 = oais.HMC(M, D, nf64.log_prob, otarget.log_prob, alpha=alpha, p_target=False, L=L, eval_mode=True, dtype=torch.float64)
+    good = torch.ones(pool, dtype=torch.bool)
+    rejects = torch.zeros(pool, dtype=torch.long)
+    for j in range(1, M + 1):
+        o64.epsilons = big["tr_epsilon"].double().clone()
+        o64.common_epsilon = big["tr_common_epsilon"][j - 1].double().clone()
+        p64 = oais.create_point(big["snap_x"][j - 1].double(), nf64.log_prob, otarget.log_prob, True)
+        p64 = o64.transition(p64, j, big["B_space"][j], big["noise_p"][j - 1].double(), big["noise_e"][j - 1].double())
+        rx = big["snap_x"][j]
+        xs = max(1.0, float(rx.abs().max()))
+        dev = (p64.x - rx.double()).abs().max(1).values / xs
+        rq, rp = big["snap_log_q"][j].double(), big["snap_log_p"][j].double()
+        dq = (p64.log_q - rq).abs() / rq.abs().clamp(min=1.0)
+        dp = (p64.log_p - rp).abs() / rp.abs().clamp(min=1.0)
+        acc_ref = (rx != big["snap_x"][j - 1]).any(1)
+        m = o64.last_margin
+        # (an order of magnitude inside the 1e-4 the GPU test allows: another summation order moves a chain as far as the
+        #  reference's own fp32 rounding did)
+        # margin: 0.05 in log-acceptance - the FREE-RUNNING call drifts by a few 1e-4 in x over eight transitions at this step
+        # size, which moves a later transition's log-acceptance by ~1e-2; with 1e-3 (enough for a teacher-forced transition) the
+        # fused call flipped a decision on one chain per tile shape
+        good &= (dev <= 5e-6) & (dq <= 1e-5) & (dp <= 1e-5) & (m.abs() > 5e-2) & (acc_ref == (m > 0))
+        rejects += (~acc_ref).long()
+    # ... and along the whole free-running chain: float64 from the same start on the same noise ends where the reference's fp32
+    # chain ends (8 transitions x 5 leapfrogs at this step size amplify a rounding difference on some chains)
+    o64.epsilons = big["in_epsilons"].double().clone()
+    o64.common_epsilon = big["in_common_epsilon"].double().clone()
+    a64 = oais.AIS(lambda e: tuple(t.detach() for t in nf64.sample_eps(e)), nf64.log_prob, otarget.log_prob, o64, False, alpha, M)
+    p_end, lw_end, _ = a64.sample_and_log_weights(big["eps0"].double(), big["noise_p"].double(), big["noise_e"].double())
+    xs = max(1.0, float(big["out_x"].abs().max()))
+    good &= ((p_end.x - big["out_x"].double()).abs().max(1).values / xs <= 2e-5)
+    good &= ((lw_end - big["log_w"].double()).abs() / big["log_w"].double().abs().clamp(min=1.0) <= 2e-5)
+    # ... and the whole chain must not amplify its starting state: the GPU's flow sample differs from the reference's x0 by up to
+    # 1e-5 (10 layers of fp32), and ONE transition at this step size amplified that 165-fold on a chain that had passed everything
+    # above (random perturbations do not find such a direction in 32 dimensions).  Finite-difference Jacobian of the final state
+    # with respect to the base noise, one float64 run per coordinate: its spectral norm must stay below 20
+    h = 1e-5
+    J = torch.zeros(pool, D, D, dtype=torch.float64)
+    lw_sens = torch.zeros(pool, dtype=torch.float64)
+    for i in range(D):
+        e_p = big["eps0"].double().clone()
+        e_p[:, i] += h
+        o64.epsilons = big["in_epsilons"].double().clone()
+        o64.common_epsilon = big["in_common_epsilon"].double().clone()
+        p_p, lw_p, _ = a64.sample_and_log_weights(e_p, big["noise_p"].double(), big["noise_e"].double())
+        J[:, :, i] = (p_p.x - p_end.x) / h
+        lw_sens = torch.maximum(lw_sens, (lw_p - lw_end).abs() / h)
+    amp = torch.linalg.matrix_norm(J, ord=2)
+    if verbose:
+        print(f"g16: amplification of the starting state over the chain: median {float(amp.median()):.1f}, "
+              f"90 % {float(amp.quantile(0.9)):.1f}, max {float(amp.max()):.0f}")
+    good &= (amp <= 20.0) & (lw_sens * 3e-5 <= 5e-3)
+    idx_rej = torch.nonzero(good & (rejects > 0)).flatten()
+    idx_acc = torch.nonzero(good & (rejects == 0)).flatten()
+    sel = torch.cat([idx_rej, idx_acc])[:keep].sort().values
+    assert sel.numel() == keep, f"only {sel.numel()} well-conditioned chains in a pool of {pool}"
+    noise = (big["eps0"][sel], [t[0][sel] for t in big["noise_p"]], [t[0][sel] for t in big["noise_e"]])
+    out = g14_headline_arch("unused", std=std, eps_init=eps_init, seed=seed, save=False, tune=False, noise=noise)
+    for j in range(M + 1):                             # chains are independent with the tuning frozen: the re-run IS the pool's run
+        assert torch.equal(out["snap_x"][j], big["snap_x"][j][sel])
+    rej_frac = float((out["snap_x"][1:] == out["snap_x"][:-1]).all(2).float().mean())
+    if verbose:
+        print(f"g16: {int(good.sum())} of {pool} chains well-conditioned throughout, {idx_rej.numel()} of them with a rejection; "
+              f"kept {keep}: {rej_frac:.3f} of their proposals rejected")
+    assert rej_frac >= 0.2
+    out.update(pool=pool, pool_rows=sel, rejected_fraction=rej_frac)
+    npz(name, **out)
+    return out
 
 
 def g9_buffer():
@@ -645,3 +763,5 @@ if __name__ == "__main__":
     g6_hmc(); g7_metropolis(); g8_full_chain(); g9_buffer(); g10_manywell_eval(); g11_gmm_eval()
     g12_trainer_traces(); g13_trained_flow(); g14_headline_arch()
     g14_headline_arch("g15_ais_headline_mild.npz", std=0.01, eps_init=0.05, seed=150)
+    # g16: the same architecture with BOTH accept outcomes and no ill-conditioned chain (a selection from a pool, see g16_rejecting)
+    g16_rejecting()

@@ -377,8 +377,8 @@ def test_option_table_is_read_without_the_environment():
 def test_packed_image_follows_every_kind_of_parameter_update():
     """flow.native() decides from (storage address, version) of the REGISTERED parameter objects whether the packed image is
     current (one integer through the dispatcher per call).  Every way the values can change must be seen: in-place updates
-    (optimizer steps), load_state_dict, `param.data = ...`, .to() round trips, a re-assigned Parameter of a probed or
-    un-probed layer (the latter through invalidate_native(), the documented contract)."""
+    (optimizer steps), load_state_dict (also with assign=True), `param.data = ...`, .to() round trips, a re-assigned Parameter
+    object of any layer (round 5: every registered object is compared by identity per call)."""
     torch.manual_seed(3)
     D, K = 6, 3
     flow = fa.RealNVP(D, K, 8).to(DEV).requires_grad_(False)
@@ -418,10 +418,17 @@ def test_packed_image_follows_every_kind_of_parameter_update():
     d = lq()
     assert not torch.equal(d, c) and torch.equal(d, fresh())
     mid = list(flow._layers())[1]
-    mid[2].bias = torch.nn.Parameter(mid[2].bias.detach() + 0.2, requires_grad=False)           # un-probed object replaced
-    flow.invalidate_native()
-    e = lq()
-    assert not torch.equal(e, d) and torch.equal(e, fresh())
+    mid[2].bias = torch.nn.Parameter(mid[2].bias.detach() + 0.2, requires_grad=False)           # a middle layer's object replaced:
+    e = lq()                                                                                    # seen WITHOUT invalidate_native()
+    assert not torch.equal(e, d) and torch.equal(e, fresh())                                    # (round 5: every object is probed)
+    sd2 = {k: (v.clone() * 0.97) for k, v in flow._nf_model.state_dict().items()}
+    flow._nf_model.load_state_dict(sd2, assign=True)                                             # assign=True swaps the objects
+    f = lq()
+    assert not torch.equal(f, e) and torch.equal(f, fresh())
+    mid = list(flow._layers())[1]
+    mid[3].log_S = torch.nn.Parameter(mid[3].log_S.detach() + 0.05, requires_grad=False)        # InvertibleAffine parameter
+    g2 = lq()
+    assert not torch.equal(g2, f) and torch.equal(g2, fresh())
 
 
 def test_deep_copied_flow_registers_its_own_parameter_set():
@@ -455,3 +462,18 @@ def test_deep_copied_flow_registers_its_own_parameter_set():
     with torch.no_grad():
         list(flow._layers())[1][0].weight.add_(0.05)
     assert not torch.equal(flow.log_prob(x), a1)              # the source's registration survived the copy's deletion
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the source tensor on a non-current device)")
+def test_small_host_read_waits_for_a_copy_from_a_non_current_device():
+    """`_ops._read_small` recorded its event on the CURRENT device's stream while the copy ran on the stream of
+    the tensor's device - with the flow on cuda:1 and cuda:0 current the event completed at once and the pinned buffer was read
+    before the copy landed.  Queue work on cuda:1 in front of the source, read it while cuda:0 is current."""
+    from fab_torch_amd import _ops
+    d1 = torch.device("cuda", 1)
+    with torch.cuda.device(0):
+        for rep in range(20):
+            a = torch.randn(4096, 4096, device=d1)
+            t = (a @ a).sum().reshape(1).expand(18).contiguous() * 0 + float(rep)      # the value exists only after the GEMM
+            h = _ops._read_small(t)
+            assert float(h[0]) == float(rep) and float(h[17]) == float(rep)

@@ -454,15 +454,25 @@ def test_trainer_iterations_from_the_reference_state_at_the_north_star_tolerance
             ref = float(g[f"it{it}_{key}"])
             assert abs(info[key] - ref) <= RTOL * max(1.0, abs(ref)), (it, key, info[key], ref)
         # the adjusted entries moved by log q_new - log q_old after the iteration's own Adam steps, on samples all over the
-        # buffer (one Adam step moves a sample next to a ReLU kink by more than it moves the others): at most 1 entry in
-        # 200 outside the north-star 1e-4, none outside 1e-3
+        # buffer (one Adam step moves a sample next to a ReLU kink by more than it moves the others): none outside 1e-3, and
+        # outside the north-star 1e-4 only the one entry named below
         for got, key in ((buf.buffer.log_w, "buf_log_w"), (buf.buffer.log_q_old, "buf_log_q_old")):
             ref = torch.tensor(g[f"it{it}_{key}"])
             assert close(got, ref, 10 * RTOL), (it, key, worst(got, ref, 10 * RTOL))
             fin = torch.isfinite(ref)
             err = (got.cpu()[fin] - ref[fin]).abs()
             tol = 2e-6 * max(1.0, float(ref[fin].abs().max())) + RTOL * ref[fin].abs()
-            assert int((err > tol).sum()) <= max(1, int(fin.sum()) // 200), (it, key, int((err > tol).sum()))
+            if os.environ.get("FABHIP_TEST_REPORT"):
+                with open(os.environ["FABHIP_TEST_REPORT"], "a") as fh:      # (dev: where the clause below stands)
+                    fh.write(f"REPLAY seed={seed} opt={optimiser} it={it} {key}: {int((err > tol).sum())} of {int(fin.sum())} entries "
+                             f"outside 1e-4, worst {float((err / tol).max()):.2f} x tol\n")
+            # measured on the round-5 library over all 60 (seed, optimiser, iteration, buffer) combinations: 59 have NO entry outside
+            # 1e-4; one (seed 1, iteration 1, log_q_old) has ONE of 512 at 1.85 x the tolerance with both optimisers - a sample
+            # whose pre-activation changes sign under that iteration's Adam step in one of the two arithmetics (VERDICT r4 6b:
+            # the clause was "1 in 200" for every combination)
+            allowed = 1 if (seed == 1 and it == 1 and key == "buf_log_q_old") else 0
+            assert int((err > tol).sum()) <= allowed and float((err / tol).max()) <= 2.5, (it, key, int((err > tol).sum()),
+                                                                                          float((err / tol).max()))
         nxt = ({k[len(f"it{it + 1}_param."):]: v for k, v in gs.items() if k.startswith(f"it{it + 1}_param.")}
                if it + 1 < n_iter else {k[len("final."):]: v for k, v in g.items() if k.startswith("final.")})
         for k, v in hf._nf_model.state_dict().items():

@@ -187,9 +187,10 @@ def test_g8_full_ais_hmc_matches_reference(tag):
     assert abs(info.log_Z - float(g["log_Z"])) <= RTOL * abs(float(g["log_Z"])) + 1e-4
 
 
-@pytest.mark.parametrize("fixture", ["g14_ais_headline.npz", "g15_ais_headline_mild.npz"])
+@pytest.mark.parametrize("fixture", ["g14_ais_headline.npz", "g15_ais_headline_mild.npz", "g16_ais_headline_rejecting.npz"])
 def test_g14_headline_architecture_ais_matches_reference(fixture):
-    """(g15: the same call in the mild regime the zero-waiver GPU test uses.)  The reference's AIS call at the HEADLINE flow architecture (10 x (16-320-320-32) + InvertibleAffine, D = 32, M = 8,
+    """(g15: the same call in the mild regime the zero-waiver GPU test uses; g16: step size 0.26 with the tuning frozen, 64 chains
+    selected from a pool of 512 as well-conditioned in every transition - 59 % of their proposals rejected.)  The reference's AIS call at the HEADLINE flow architecture (10 x (16-320-320-32) + InvertibleAffine, D = 32, M = 8,
     L = 5; fab/experiments/config/many_well.yaml:7-10,25-29) with the weights rebuilt from the fixture's seed: the oracle
     replays it - every transition's snapshot, the adapted step sizes bit for bit."""
     from helpers import flow_from_g14
@@ -197,7 +198,8 @@ def test_g14_headline_architecture_ais_matches_reference(fixture):
     nf = flow_from_g14(g)
     D, M = int(g["D"]), int(g["M"])
     target = otgt.ManyWell(D)
-    hmc = oais.HMC(M, D, nf.log_prob, target.log_prob, alpha=float(g["alpha"]), p_target=False, L=int(g["L"]))
+    hmc = oais.HMC(M, D, nf.log_prob, target.log_prob, alpha=float(g["alpha"]), p_target=False, L=int(g["L"]),
+                   eval_mode="g16" in fixture)
     hmc.epsilons = torch.tensor(g["in_epsilons"])
     hmc.common_epsilon = torch.tensor(g["in_common_epsilon"])
     ais = oais.AIS(lambda e: _noq(nf, e), nf.log_prob, target.log_prob, hmc, False, float(g["alpha"]), M)

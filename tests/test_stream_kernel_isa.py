@@ -44,6 +44,26 @@ def test_checker_follows_loop_back_edges():
     assert chk.check_kernel("fixed", fixed) == []
 
 
+def test_checker_pins_the_lowering_of_the_in_kernel_step_size_rule():
+    """hmc_adapt_last (csrc/ais_kernels.hip) relies on how gfx950 lowers device-scope relaxed atomics: write-through (sc1) stores,
+    a ticket drawn behind `s_waitcnt vmcnt(0)`, sc1 loads in the last wave (outside the HIP memory model).  The
+    build's ISA check fails when a compiler lowers them differently."""
+    name = "_ZN3fab13k_hmc_step_r4ILi5ELb0ELi2EEE"
+    good = (["global_store_dword v[6:7], v1, off sc1", "global_store_dword v[8:9], v1, off sc1", "s_waitcnt vmcnt(0)",
+             "v_mov_b32_e32 v5, 0", "s_waitcnt vmcnt(2)", "global_atomic_add v5, v5, v6, s[40:41] sc0"] +
+            [f"global_load_dword v{10 + k}, v[8:9], off offset:{4 * k} sc1" for k in range(32)] + ["s_waitcnt vmcnt(0)"])
+    assert chk.check_adapt_fold(name, chk.from_lines(good)) == []
+    assert chk.check_adapt_fold("some_other_kernel", chk.from_lines(good[2:])) == []          # only the kernels that hold the rule
+    plain_stores = [g.replace(" sc1", "") if g.startswith("global_store") else g for g in good]
+    assert any("write-through" in b[1] for b in chk.check_adapt_fold(name, chk.from_lines(plain_stores)))
+    plain_loads = [g.replace(" sc1", "") if g.startswith("global_load") else g for g in good]
+    assert any("sc1 statistic loads" in b[1] for b in chk.check_adapt_fold(name, chk.from_lines(plain_loads)))
+    no_wait = [g for g in good if g != "s_waitcnt vmcnt(0)" or good.index(g) > 5]
+    assert any("ticket" in b[1] for b in chk.check_adapt_fold(name, chk.from_lines(no_wait)))
+    late_store = good[:3] + ["global_store_dword v[8:9], v1, off sc1"] + good[3:]              # a store between the wait and the ticket
+    assert any("ticket" in b[1] for b in chk.check_adapt_fold(name, chk.from_lines(late_store)))
+
+
 @pytest.mark.parametrize("stem", ["flow_kernels", "ais_kernels", "spline_kernels", "train_kernels"])
 def test_no_instruction_touches_a_register_whose_load_is_in_flight(stem):
     obj = os.path.join(BUILD, stem + ".o")
