@@ -45,6 +45,9 @@ struct SplineDims {
     int layer_stride, o_base, total;
     // 8-chain-tile image (spline_r8.h; Wp == 256 only, else o_r8 == 0): per layer [head | forward tiles | reverse tiles]
     int o_r8, r8_head, r8_tpl, r8_layer; // head floats, 1-KiB tiles per wave and direction, floats per layer
+    int r8_trim;                         // round 5: the r8 stream without its zero tiles (D <= 32 with two output chunks: <= 16 identity
+                                         // features -> W0 is 4 k-quads, not 16; <= 400 conditioner outputs -> WfT is 100 k-quads, not
+                                         // 128; W0T as 4 dense tiles, not 16): 260 + 232 instead of 272 + 272 tiles per wave and layer
 };
 
 FAB_HD SplineDims make_spline_dims(int D, int L, int W) {
@@ -79,6 +82,7 @@ FAB_HD SplineDims make_spline_dims(int D, int L, int W) {
     f.o_r8 = 0;
     f.r8_head = ((SP_META_ROWS + 2) * 64 + 1664 + 128) + 3 * 256 + 128 + f.NFP;   // spline_r8.h: S8H_*
     f.r8_tpl = 16 + 64 * (2 + f.NCH);
+    f.r8_trim = (f.NCH == 2 && (D + 1) / 2 <= 16) ? 1 : 0;
     f.r8_layer = f.r8_head + 2 * NWAVE * f.r8_tpl * 256;
     if (f.NTWM == 4) {
         f.o_r8 = (f.total + 255) & ~255;
@@ -1206,19 +1210,19 @@ static int r8_row_blocks(const SplineDims& f, long B, int fast, bool grad) {
     return rb;
 }
 
-template <int NCH, int RB>
+template <int NCH, int RB, bool TRIM = false>
 static int launch_logprob_r8(const SplineDims& f, const float* packed, const float* x, float* log_q, float* grad_x, long B,
                              float* Zsave, float* Psave, hipStream_t st, const SplineLeapDev& lp = SplineLeapDev{}) {
     const dim3 grid((unsigned)ceil_div((int)B, 4 * RB)), block(NTHREADS);
     const S8Lds l = make_s8_lds(f, grad_x != nullptr, 4 * RB);
     const size_t bytes = (size_t)l.total * 4;
     if (grad_x) {
-        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, true>, bytes));
-        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, true>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, true, TRIM>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, true, TRIM>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
                            Psave, sp_timeline(st), lp);
     } else {
-        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, false>, bytes));
-        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, false>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
+        FAB_TRY(set_max_lds((const void*)k_spline_logprob_r8<NCH, RB, false, TRIM>, bytes));
+        hipLaunchKernelGGL((k_spline_logprob_r8<NCH, RB, false, TRIM>), grid, block, bytes, st, f, l, packed, x, log_q, grad_x, B, Zsave,
                            Psave, sp_timeline(st), SplineLeapDev{});
     }
     return check_launch();
@@ -1229,7 +1233,8 @@ static int launch_logprob_r8_nch(const SplineDims& f, const float* packed, const
                                  float* Zsave, float* Psave, hipStream_t st, const SplineLeapDev& lp = SplineLeapDev{}) {
     switch (f.NCH) {
         case 1: return launch_logprob_r8<1, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
-        case 2: return launch_logprob_r8<2, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
+        case 2: return f.r8_trim ? launch_logprob_r8<2, RB, true>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp)
+                                 : launch_logprob_r8<2, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
         case 3: return launch_logprob_r8<3, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
         case 4: return launch_logprob_r8<4, RB>(f, packed, x, log_q, grad_x, B, Zsave, Psave, st, lp);
         default: return FABHIP_ENOTSUP;

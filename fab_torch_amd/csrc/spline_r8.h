@@ -138,28 +138,34 @@ __global__ __launch_bounds__(256) void k_spline_pack_r8(SplineDims f, SplineSrc 
             const long tl = e >> 8;
             const int tile = (int)(tl % TPL), wave = (int)((tl / TPL) % NWAVE), dir = (int)(tl / ((long)TPL * NWAVE));
             const int n = 64 * wave + lane;
+            // round 5 (f.r8_trim): the stream without zero tiles - W0 as K0Q = 4 k-quads, WfT as KFQ = 100, W0T as 4 dense tiles
+            const int K0Q = f.r8_trim ? 4 : 16, KFQ = f.r8_trim ? 100 : 64 * f.NCH;
             if (dir == 0) {
-                if (tile < 16) {                                               // W0: B[k][n] = w0[n][k]
+                if (tile < K0Q) {                                              // W0: B[k][n] = w0[n][k]
                     const int k = 4 * tile + kk;
                     if (k < n_id && n < W) v = s.w0[n * n_id + k];
-                } else {
-                    const int t2 = tile - 16, m = t2 >> 6, k = 4 * (t2 & 63) + kk;
+                } else if (tile < K0Q + 64 * (2 + f.NCH)) {
+                    const int t2 = tile - K0Q, m = t2 >> 6, k = 4 * (t2 & 63) + kk;
                     if (m == 0) { if (k < W && n < W) v = s.wa[n * W + k]; }
                     else if (m == 1) { if (k < W && n < W) v = s.wb[n * W + k]; }
                     else { const int col = (m - 2) * 256 + n; if (k < W && col < nout) v = s.wf[col * W + k]; }
                 }
             } else {
-                const int nwf = 64 * f.NCH;
-                if (tile < nwf) {                                              // WfT: B[k][n] = wf[k][n]
+                if (tile < KFQ) {                                              // WfT: B[k][n] = wf[k][n]
                     const int k = 4 * tile + kk;
                     if (k < nout && n < W) v = s.wf[k * W + n];
                 } else {
-                    const int t2 = tile - nwf;
+                    const int t2 = tile - KFQ;
                     if (t2 < 64) { const int k = 4 * t2 + kk; if (k < W && n < W) v = s.wb[k * W + n]; }
                     else if (t2 < 128) { const int k = 4 * (t2 - 64) + kk; if (k < W && n < W) v = s.wa[k * W + n]; }
-                    else {                                                     // W0T, K split over the waves: B[k][i] = w0[k][i]
-                        const int k = 64 * wave + 4 * (t2 - 128) + kk;
-                        if (k < W && lane < n_id) v = s.w0[k * n_id + lane];
+                    else if (!f.r8_trim) {                                     // W0T, K split over the waves: B[k][i] = w0[k][i]
+                        if (t2 < 144) {
+                            const int k = 64 * wave + 4 * (t2 - 128) + kk;
+                            if (k < W && lane < n_id) v = s.w0[k * n_id + lane];
+                        }
+                    } else if (t2 < 132) {                                     // ... as dense tiles: 4 k-quads x 16 identity features
+                        const int k = 64 * wave + 4 * (4 * (t2 - 128) + (lane >> 4)) + kk, c = lane & 15;
+                        if (k < W && c < n_id) v = s.w0[k * n_id + c];
                     }
                 }
             }
@@ -180,7 +186,8 @@ struct SplineLeapDev {
 __device__ __forceinline__ float g_clamp_nan0_s8(float g, float mg) { return (g != g) ? 0.f : fminf(fmaxf(g, -mg), mg); }   // hmc.py:194-199
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
-template <int NCH, int RB, bool GRAD>
+// TRIM (SplineDims::r8_trim: D <= 32, two output chunks): the layer's stream without its zero tiles - see k_spline_pack_r8
+template <int NCH, int RB, bool GRAD, bool TRIM = false>
 __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8Lds l, const float* __restrict__ packed,
                                                                 const float* __restrict__ x, float* __restrict__ log_q,
                                                                 float* __restrict__ grad_x, long B, float* __restrict__ Zsave,
@@ -188,6 +195,10 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid8 t;
     constexpr int R8 = 4 * RB;                                                 // chains of this workgroup
+    constexpr int K0Q = TRIM ? 4 : 16;                                         // k-quads of W0 (identity features / 4)
+    constexpr int KFQ = TRIM ? 100 : 64 * NCH;                                 // k-quads of WfT (conditioner outputs / 4)
+    constexpr int PHF = K0Q % S8_RD, PHR = KFQ % S8_RD;                        // ring phase behind W0 / behind WfT
+    static_assert(!TRIM || NCH == 2, "the trimmed stream exists for two output chunks");
 #define S8_TL(idx) do { if (tlp && blockIdx.x == 0 && threadIdx.x == 0) tlp[idx] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     const long row0 = (long)blockIdx.x * R8;
     float* A0 = lds + l.o_A0; float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* T = lds + l.o_T;
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         {   // h0 = A0 W0 + b0; X2 = relu(h0)
             S8Acc<RB> acc;
             s8_zero(acc);
-            s8_iter<16, 16, 0, S8_INF>(s, A0 + t.arow * S8_AS, 4 * S8_AS, acc);
+            s8_iter<K0Q, K0Q, 0, S8_INF>(s, A0 + t.arow * S8_AS, 4 * S8_AS, acc);
             s8_fold(acc, o);
             const float bv = HD[S8H_B0 + col];
 #pragma unroll
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         s8_barrier();
         {   // t = relu(h0) Wa + ba; X1 = relu(t)
             if (layer > 0) head_fetch(Lr - lfl);
-            s8_gemm64<16, RB>(s, X2, S8_WS, t, o);
+            s8_gemm64<PHF, RB>(s, X2, S8_WS, t, o);
             const float bv = HD[S8H_BA + col];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -352,7 +363,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         }
         s8_barrier();
         {   // h1 = h0 + relu(t) Wb + bb -> T
-            s8_gemm64<16, RB>(s, X1, S8_WS, t, o);
+            s8_gemm64<PHF, RB>(s, X1, S8_WS, t, o);
             const float bv = HD[S8H_BB + col];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -363,8 +374,8 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         if (tl) S8_TL(2);
         s8_for<0, NCH>([&](auto cc) {                                          // P = h1 Wf + bf, chunks of 256 outputs
             constexpr int c = decltype(cc)::value;
-            if constexpr (c + 1 < NCH) s8_gemm64<16, RB>(s, T, S8_WS, t, o);
-            else s8_gemm64<16, RB, 31>(s, T, S8_WS, t, o);                         // the layer's last tiles: the ring drains
+            if constexpr (c + 1 < NCH) s8_gemm64<PHF, RB>(s, T, S8_WS, t, o);
+            else s8_gemm64<PHF, RB, 31>(s, T, S8_WS, t, o);                        // the layer's last tiles: the ring drains
             const float bv = HD[S8H_BF + c * 256 + col];
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
@@ -473,7 +484,8 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                 S8Acc<RB> acc;
                 s8_zero(acc);
                 const float* ap = PT + t.arow * l.PS;
-                s8_for<0, 2 * NCH>([&](auto ic) { s8_iter<32, 32, 0, S8_INF>(s, ap + 128 * decltype(ic)::value, 4 * l.PS, acc); });
+                s8_for<0, KFQ / 32>([&](auto ic) { s8_iter<32, 32, 0, S8_INF>(s, ap + 128 * decltype(ic)::value, 4 * l.PS, acc); });
+                if constexpr (KFQ % 32 != 0) s8_iter<KFQ % 32, KFQ % 32, 0, S8_INF>(s, ap + 128 * (KFQ / 32), 4 * l.PS, acc);
                 s8_fold(acc, o);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
@@ -484,7 +496,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             if (tl) S8_TL(11);
             {   // d relu(t) = dh1 WbT, masked by t > 0
                 if (layer + 1 < f.L) { head_fetch(Lr + lfl); tile_fetch(layer + 1); }
-                s8_gemm64<0, RB>(s, X1, S8_WS, t, o);
+                s8_gemm64<PHR, RB>(s, X1, S8_WS, t, o);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -493,7 +505,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             }
             s8_barrier();
             {   // dh0 = dh1 + (d t WaT masked by h0 > 0)
-                s8_gemm64<0, RB, 47>(s, X2, S8_WS, t, o);
+                s8_gemm64<PHR, RB, (TRIM ? 4 : 16) + 31>(s, X2, S8_WS, t, o);
 #pragma unroll
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -505,20 +517,43 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             {   // dA0 = dh0 W0T: K split over the waves (wave w: k = 64 w .. 64 w + 63), partial [8][64] products through LDS
                 S8Acc<RB> acc;
                 s8_zero(acc);
-                s8_iter<16, 16, 0, 15>(s, T + t.arow * S8_WS + 64 * t.wave, 4 * S8_WS, acc);
-                s8_fold(acc, o);
+                if constexpr (!TRIM) {
+                    s8_iter<16, 16, 0, 15>(s, T + t.arow * S8_WS + 64 * t.wave, 4 * S8_WS, acc);
+                    s8_fold(acc, o);
 #pragma unroll
-                for (int rb = 0; rb < RB; ++rb)
+                    for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * S8_AS + t.lane] = o[rb][r];
+                        for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * S8_AS + t.lane] = o[rb][r];
+                } else {        // dense tiles: lane quarter h4 multiplies k-quad 4 T + h4 of the wave's 16; 16 partials per output
+                    const int h4 = t.lane >> 4;
+                    s8_iter_k<16, 4, 4, PHR, 3>(s, T + t.arow * S8_WS + 64 * t.wave + 4 * h4, 4 * S8_WS, acc);
+                    s8_fold(acc, o);
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) PART[((4 * t.wave + h4) * R8 + 4 * rb + r) * 16 + (t.lane & 15)] = o[rb][r];
+                }
             }
             s8_barrier();
             if (tl) S8_TL(13);
             for (int e = t.tid; e < R8 * 64; e += NTHREADS) {
                 const int r = e >> 6, i = e & 63;
                 if (i < n_id) {
-                    const float* pp = PART + r * S8_AS + i;
-                    float d = (pp[0] + pp[R8 * S8_AS]) + (pp[2 * R8 * S8_AS] + pp[3 * R8 * S8_AS]);
+                    float d;
+                    if constexpr (!TRIM) {
+                        const float* pp = PART + r * S8_AS + i;
+                        d = (pp[0] + pp[R8 * S8_AS]) + (pp[2 * R8 * S8_AS] + pp[3 * R8 * S8_AS]);
+                    } else {                                                   // (n_id <= 16) fixed balanced tree over the 16 partials
+                        const float* pp = PART + r * 16 + i;
+                        float v16[16];
+#pragma unroll
+                        for (int q = 0; q < 16; ++q) v16[q] = pp[q * R8 * 16];
+#pragma unroll
+                        for (int w = 1; w < 16; w *= 2)
+#pragma unroll
+                            for (int q = 0; q < 16; q += 2 * w) v16[q] = v16[q] + v16[q + w];
+                        d = v16[0];
+                    }
                     const int feat = (int)meta[M_IDF * 64 + i];
                     if (meta[M_PFON * 64 + i] != 0.f) {
                         const int k = (int)meta[M_PFK * 64 + i];
