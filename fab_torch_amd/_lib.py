@@ -106,7 +106,7 @@ SYMBOLS = [
     "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_tape_gemm", "fabhip_debug_spline_timeline",
     "fabhip_metropolis_partials_floats", "fabhip_metropolis_adapt_gathered",
 ]
-ABI_VERSION = 213          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 214          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):

@@ -621,7 +621,7 @@ static inline ExtraLds8 make_extra_lds8(const R8Lds& l, int D) {
     return e;
 }
 
-template <int G>
+template <int G, bool FUSED>
 __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, ExtraLds8 x, const float* __restrict__ packed,
                                                         TargetDev tg, HmcK a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -644,9 +644,10 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
     float* GP = lds + x.o_GP;
     const bool active = ew && g < nv;
     const float eps = *a.eps_ptr + *a.ceps_ptr;
-    r8_load_heads(f, l, packed, lds, t.tid, NT);
+    if constexpr (FUSED) r8f_load_heads(f, l, packed, lds, t.tid, NT);
+    else r8_load_heads(f, l, packed, lds, t.tid, NT);
     for (int e = t.tid; e < R8 * R4_DS; e += NT) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
-    R8Stream s;
+    std::conditional_t<FUSED, R8FStream, R8Stream> s;
     s8_stream_init(s, t8.lane);
     float k0 = 0.f;
     if (ew) {
@@ -684,7 +685,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
             lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
         }
         __syncthreads();
-        lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
+        lq = flow_log_prob_r8<G, FUSED>(f, l, packed, lds, t8, s, &goff);
         if (ew) {
             lp = target_tile<true>(tg, XP, D, GP, D, t);
             for (int j = t.c; j < D; j += 16) {
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r8(FlowDims f, R8Lds l, E
 }
 
 // Chain initialisation on 8-chain tiles (as k_ais_init_r4: the flow SAMPLE stays on the 16-chain kernel)
-template <int G>
+template <int G, bool FUSED>
 __global__ __launch_bounds__(NTHREADS) void k_ais_init_r8(FlowDims f, R8Lds l, ExtraLds8 x, const float* __restrict__ packed,
                                                         TargetDev tg, const float* __restrict__ lq0, PointDev pt,
                                                         float* __restrict__ log_w, float* __restrict__ base_log_w,
@@ -759,7 +760,8 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r8(FlowDims f, R8Lds l, E
     const long g = row0 + t.row;
     float* XP = lds + x.o_XP;
     float* GP = lds + x.o_GP;
-    r8_load_heads(f, l, packed, lds, t.tid, NT);
+    if constexpr (FUSED) r8f_load_heads(f, l, packed, lds, t.tid, NT);
+    else r8_load_heads(f, l, packed, lds, t.tid, NT);
     for (int e = t.tid; e < R8 * R4_DS; e += NT) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
     for (int e = t.tid; e < R8 * R4_DS; e += NT) {
         const int r = e / R4_DS, j = e % R4_DS;
@@ -767,11 +769,11 @@ __global__ __launch_bounds__(NTHREADS) void k_ais_init_r8(FlowDims f, R8Lds l, E
         lds[l.o_X0 + e] = v;
         if (j < D) XP[r * D + j] = v;
     }
-    R8Stream s;
+    std::conditional_t<FUSED, R8FStream, R8Stream> s;
     s8_stream_init(s, t8.lane);
     __syncthreads();
     int goff = 0;
-    const float lq = flow_log_prob_r8<G>(f, l, packed, lds, t8, s, &goff);
+    const float lq = flow_log_prob_r8<G, FUSED>(f, l, packed, lds, t8, s, &goff);
     if (!ew) return;
     const float lp = target_tile<true>(tg, XP, D, GP, D, t);
     if (g < B) {
@@ -1229,13 +1231,14 @@ static int launch_hmc_step_r8(const FlowDims& f0, const float* packed, const Tar
     const ExtraLds8 x = make_extra_lds8(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid((unsigned)(nblk_of(a.B) * (ROWS / R8)));      // every row of the 16-row blocks k_hmc_adapt sums gets written
-#define FAB_R8_STEP(G)                                                                                            \
+    const bool fused = use_r8_fused(f);
+#define FAB_R8_STEP(G, FU)                                                                                        \
     do {                                                                                                          \
-        FAB_TRY(set_max_lds((const void*)k_hmc_step_r8<G>, bytes));                                               \
-        hipLaunchKernelGGL((k_hmc_step_r8<G>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);          \
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r8<G, FU>, bytes));                                           \
+        hipLaunchKernelGGL((k_hmc_step_r8<G, FU>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, a);      \
     } while (0)
-    if (f.Wp == 320) FAB_R8_STEP(5);
-    else if (f.Wp == 256) FAB_R8_STEP(4);
+    if (f.Wp == 320) { if (fused) FAB_R8_STEP(5, true); else FAB_R8_STEP(5, false); }
+    else if (f.Wp == 256) { if (fused) FAB_R8_STEP(4, true); else FAB_R8_STEP(4, false); }
     else return FABHIP_ENOTSUP;
 #undef FAB_R8_STEP
     return check_launch();
@@ -1247,14 +1250,15 @@ static int launch_ais_init_r8(const FlowDims& f, const float* packed, const Targ
     const ExtraLds8 x = make_extra_lds8(l, f.D);
     const size_t bytes = (size_t)x.total * 4;
     const dim3 grid((unsigned)((B + R8 - 1) / R8));
-#define FAB_R8_INIT(G)                                                                                            \
+    const bool fused = use_r8_fused(f);
+#define FAB_R8_INIT(G, FU)                                                                                        \
     do {                                                                                                          \
-        FAB_TRY(set_max_lds((const void*)k_ais_init_r8<G>, bytes));                                               \
-        hipLaunchKernelGGL((k_ais_init_r8<G>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, lq0, pt, log_w, \
+        FAB_TRY(set_max_lds((const void*)k_ais_init_r8<G, FU>, bytes));                                           \
+        hipLaunchKernelGGL((k_ais_init_r8<G, FU>), grid, dim3(NTHREADS), bytes, st, f, l, x, packed, tg, lq0, pt, log_w, \
                            base_log_w, an, B);                                                                    \
     } while (0)
-    if (f.Wp == 320) FAB_R8_INIT(5);
-    else if (f.Wp == 256) FAB_R8_INIT(4);
+    if (f.Wp == 320) { if (fused) FAB_R8_INIT(5, true); else FAB_R8_INIT(5, false); }
+    else if (f.Wp == 256) { if (fused) FAB_R8_INIT(4, true); else FAB_R8_INIT(4, false); }
     else return FABHIP_ENOTSUP;
 #undef FAB_R8_INIT
     return check_launch();

@@ -46,6 +46,7 @@ struct FlowDims {
     int o_r4;                   // 4-chain-tile weight image (flow_r4.h: R4Dims), K layer blocks
     int o_r4s;                  // the same tiles in per-wave consumption order (flow_r4.h: R4Stream; D <= 32, Wp >= 128), else -1
     int o_r8;                   // 8-chain-tile weight image (flow_r8.h; D <= 32, Wp = 256 / 320), else -1
+    int o_r8f;                  // 8-chain tiles, fused stages (flow_r8.h: W1' = W'[:, :d] W1^T; needs o_r8 and o_r4fb), else -1
     int o_r4f, o_r4fb;          // 4-chain tiles, fused stages (flow_r4f.h): weight stream / bias blocks (where o_r4s exists), else -1
     int o_r4fh;                 // the same stream with bf16 W x W tiles (fast mode; density direction only), else -1
     int total;                  // total floats
@@ -122,6 +123,13 @@ FAB_HD FlowDims make_flow_dims(int D, int K, int W) {
         // fast mode: [K density forward | K density reverse | 1 pad] layer slots of r4f_tl_fast(G) tiles
         f.o_r4fh = (f.total + 63) & ~63;
         f.total = f.o_r4fh + (2 * K + 1) * r4f_tl_fast(G) * NWAVE * 256;
+    }
+    // 8-chain tiles with fused stages: per wave K layers x 2 directions x (84 / 126 tiles = 2 / 3 ring depths of 42) + 64 tiles of tail
+    f.o_r8f = -1;
+    if (f.o_r8 >= 0 && f.o_r4fb >= 0) {
+        const int G = f.Wp / 64;
+        f.o_r8f = (f.total + 63) & ~63;
+        f.total = f.o_r8f + NWAVE * (2 * K * (G == 5 ? 126 : 84) + 64) * 256;
     }
     f.timeline = nullptr;
     f.fast = 0;

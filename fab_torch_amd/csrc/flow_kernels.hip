@@ -465,6 +465,67 @@ __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0,
     }
 }
 
+// 8-chain-tile image with fused stages (flow_r8.h, FlowDims::o_r8f): the same per-wave stream, per layer forward [AW 4 | W1' 8 (+2) |
+// W2 16 G (+4 G) | W3 2 G], reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1'T 2 G | AWT 1], padded to r8f_tiles_p(G).  W1' = W'[:, :d] W1^T
+// is a float64 product rounded once (the bias b1' comes from k_pack_r4f's density blocks); W1'T: this wave's quarter of the hidden
+// rows as dense tiles (2 k-quads x 32 state columns); AWT: ONE dense tile per wave - rows 8 w .. 8 w + 7 of W'^T.
+__global__ __launch_bounds__(256) void k_pack_r8f(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed) {
+    const int D = f.D, d = f.d, DO = f.DO, W = f.W, G = f.Wp / 64, EX = G - 4, K = f.K;
+    const int TF = r8f_tiles_fwd(G), TR = r8f_tiles_rev(G), TP = r8f_tiles_p(G);
+    const int NQW = 16 * G, NQK = 4 * G, NQ1 = R8_KD4;
+    const int y = blockIdx.y, layer = k0 + y;
+    float* __restrict__ img = packed + f.o_r8f;
+    const long WT = r8f_wave_tiles(G, K);
+    const float* Wm = packed + f.o_scratch + (size_t)layer * 2 * D * D;       // W' (assembled, ActNorm folded)
+    const float *w1 = tab.w1[y], *w2 = tab.w2[y], *w3 = tab.w3[y];
+    auto fusedW = [&](int r, int n) -> float {                                 // W1'[r][n] = sum_j W'[r][j] W1[n][j]
+        if (r >= D || n >= W) return 0.f;
+        double acc = 0.0;
+        for (int j = 0; j < d; ++j) acc += (double)Wm[r * D + j] * (double)w1[n * d + j];
+        return (float)acc;
+    };
+    const int LT = NWAVE * 2 * TP * 256;                                        // floats of this layer, over waves and directions
+    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < LT; off += gridDim.x * blockDim.x) {
+        const int kk = off & 3, lane = (off >> 2) & 63;
+        int tl = off >> 8;
+        const int wave = tl / (2 * TP);
+        tl -= wave * 2 * TP;
+        const bool fwd = tl < TP;
+        int ti = fwd ? tl : tl - TP;
+        const long pos = fwd ? (long)(K - 1 - layer) * TP + ti : (long)(K + layer) * TP + ti;
+        float* dstp = img + ((size_t)wave * WT + pos) * 256 + ((size_t)lane << 2) + kk;
+        if (ti >= (fwd ? TF : TR)) { *dstp = 0.f; continue; }                  // the padding tiles
+        float v = 0.f;
+        int mat, q, n;                                                          // mat 0 AW / AWT, 1 W1' / W1'T, 2 W2 / W2T, 3 W3 / W3T
+        if (fwd) {
+            if (ti < R8_TD) { mat = 0; q = 2 * ti + (lane >> 5); n = lane & 31; }
+            else if ((ti -= R8_TD) < NQ1) { mat = 1; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= NQ1) < EX * (NQ1 / 4)) { mat = 1; q = (NQ1 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= EX * (NQ1 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else { ti -= EX * NQK; mat = 3; q = NQK * wave + 2 * ti + (lane >> 5); n = lane & 31; }
+            const int k = 4 * q + kk;
+            if (mat == 0) { if (k < D && n < D) v = Wm[k * D + n]; }
+            else if (mat == 1) v = fusedW(k, n);
+            else if (mat == 2) { if (k < W && n < W) v = w2[n * W + k]; }
+            else { const int o = prm_orig(n, DO, f.DOp); if (k < W && n < 2 * f.DOp && o >= 0) v = w3[o * W + k]; }
+        } else {
+            if (ti < R8_Ko4) { mat = 3; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= R8_Ko4) < EX * (R8_Ko4 / 4)) { mat = 3; q = (R8_Ko4 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= EX * (R8_Ko4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else if ((ti -= EX * NQK) < NQK / 2) { mat = 1; q = NQK * wave + 2 * ti + (lane >> 5); n = lane & 31; }   // dense: 2 k-quads x 32
+            else { mat = 0; q = 2 * wave + (lane >> 5); n = lane & 31; }
+            const int k = 4 * q + kk;
+            if (mat == 3) { const int o = prm_orig(k, DO, f.DOp); if (k < 2 * f.DOp && o >= 0 && n < W) v = w3[o * W + n]; }
+            else if (mat == 2) { if (k < W && n < W) v = w2[k * W + n]; }
+            else if (mat == 1) v = fusedW(n, k);                                // (W1')^T[k][n]: hidden row k, state column n
+            else { if (k < D && n < D) v = Wm[n * D + k]; }
+        }
+        *dstp = v;
+    }
+}
+
 // Stream image (flow_r4.h: R4Stream): the r4 tiles copied into the order a wave consumes them.  float4 index of a
 // stream element = ((item * 4 + wave) * G + g) * 64 + lane, item = global item number (forward layers K-1 .. 0, then
 // reverse layers 0 .. K-1, C = 4 G + 4 items each).  Source tiles come from the r4 image k_pack_r4 has just written.
@@ -775,6 +836,8 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
         hipLaunchKernelGGL(k_pack_r4, dim3(ceil_div(rd.layer_stride, 256 * 8), nl), dim3(256), 0, st, f, rd, mt, k0, packed);
         if (f.o_r8 >= 0)
             hipLaunchKernelGGL(k_pack_r8, dim3(ceil_div(NWAVE * 2 * r8_tiles_p(f.Wp / 64) * 256, 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
+        if (f.o_r8f >= 0)
+            hipLaunchKernelGGL(k_pack_r8f, dim3(ceil_div(NWAVE * 2 * r8f_tiles_p(f.Wp / 64) * 256, 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
     }
     if (f.o_r4s >= 0)
         hipLaunchKernelGGL(k_pack_r4s, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed);

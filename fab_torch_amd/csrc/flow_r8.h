@@ -45,6 +45,26 @@ FAB_HD int r8_tiles_p(int G) { return r8_tiles_fwd(G) + r8_tiles_pad(G); }   // 
 FAB_HD long r8_wave_tiles(int G, int K) { return 2L * K * r8_tiles_p(G) + R8_TAIL; }   // one wave's stream
 FAB_HD long r8_image_floats(int G, int K) { return (long)NWAVE * r8_wave_tiles(G, K) * 256; }
 
+// ---- fused stages (r5; the 8-chain form of flow_r4f.h) ----------------------------------------------------------------
+// The InvertibleAffine of a layer is multiplied INTO the conditioner's first Linear at pack time (k_pack_r8f: W1' = W'[:, :d] W1^T,
+// b1' = b1 + ac[:d] W1^T, float64 products rounded once), so that
+//   forward: ONE stage reads y and makes z = y W' + ac (every wave, 4 dense tiles; needed by the coupling three stages later)
+//            AND h1 = relu(y W1' + b1') (N-split, K = 32: 8 k-quads) - no stage and no barrier for the D x D map alone;
+//   reverse: ONE K-split stage makes g_y = dh1 W1'^T + g_z W'^T (2 G dense tiles of this wave's quarter of K = Wp plus ONE dense
+//            tile of the D x D map: this wave's 8 rows of it) and its consumer - the sum of the 8 partial products - forms the next
+//            layer's coupling cotangents: three stages instead of five, the "+=" stage and the every-wave D x D product gone.
+// Stream per wave and layer: forward [AW 4 | W1' 8 (+2) | W2 16 G (+4 G) | W3 2 G], reverse [W3T 8 (+2) | W2T 16 G (+4 G) |
+// W1'T 2 G | AWT 1], padded to r8f_tiles_p (84 / 126 = 2 / 3 ring depths of 42).  Biases: the density blocks of flow_r4f.h's
+// image (FlowDims::o_r4fb: b1' | b2 | ac | shift | scale | logS), copied into the head blocks' layout.
+constexpr int R8F_RD = 42;
+using R8FStream = S8StreamT<R8F_RD>;
+FAB_HD int r8f_tiles_fwd(int G) { const int EX = G - 4; return R8_TD + R8_KD4 + EX * (R8_KD4 / 4) + 16 * G + 4 * G * EX + 2 * G; }
+FAB_HD int r8f_tiles_rev(int G) { const int EX = G - 4; return R8_Ko4 + 2 * EX + 16 * G + 4 * G * EX + 2 * G + 1; }
+FAB_HD int r8f_tiles_p(int G) { return G == 5 ? 3 * R8F_RD : 2 * R8F_RD; }                  // >= 124 / 84 forward, 121 / 81 reverse
+FAB_HD long r8f_wave_tiles(int G, int K) { return 2L * K * r8f_tiles_p(G) + R8_TAIL; }
+FAB_HD long r8f_image_floats(int G, int K) { return (long)NWAVE * r8f_wave_tiles(G, K) * 256; }
+FAB_HD bool r8f_shape_ok(const FlowDims& f) { return f.o_r8f >= 0; }
+
 // LDS plan of an r8 workgroup (floats)
 struct R8Lds {
     int WS, HF;                        // leading dim of the hidden tiles; floats per layer of the head block
@@ -100,6 +120,22 @@ __device__ __forceinline__ void r8_load_heads(const FlowDims& f, const R8Lds& l,
     }
 }
 
+// fused stages: the same head layout from the density bias blocks of the fused 4-chain image (b1' instead of b1)
+__device__ __forceinline__ void r8f_load_heads(const FlowDims& f, const R8Lds& l, const float* __restrict__ packed, float* lds,
+                                               int tid, int nthreads) {
+    const int BS = r4f_bias_stride(f.Wp);
+    for (int e = tid; e < f.K * l.HF; e += nthreads) {
+        const int layer = e / l.HF, i = e - layer * l.HF;
+        const float* Bp = packed + f.o_r4fb + (size_t)layer * BS;            // b1'[Wp] | b2[Wp] | ac[32] | shift[16] | scale[16] | logS
+        float v = 0.f;
+        if (i < 64) { if (i < 32) v = Bp[2 * f.Wp + i]; }
+        else if (i < 64 + 2 * f.Wp) v = Bp[i - 64];
+        else if (i < 128 + 2 * f.Wp) { const int j = i - 64 - 2 * f.Wp; if (j < 2 * f.DOp) v = Bp[2 * f.Wp + 32 + j]; }   // (DOp == 16)
+        else if (i == 128 + 2 * f.Wp) v = Bp[2 * f.Wp + 64];
+        lds[l.o_HEAD + e] = v;
+    }
+}
+
 // An opaque zero, re-made in every layer iteration and added to the LDS base: hipcc otherwise hoists every LDS address of the
 // (large) layer body out of the loop - several hundred registers, spilled to scratch (G = 5: 500 VGPRs).
 __device__ __forceinline__ int r8_opaque_zero() {
@@ -138,8 +174,8 @@ __device__ __forceinline__ float r8_sum_halves(float v) {
 // mk: ballots of this layer and stage, [column group][chain].  Ends with a workgroup barrier.
 // (leading dimensions are template parameters: with run-time strides hipcc hoists one address register per LDS access out of
 // the layer loop - several hundred of them - and spills)
-template <int G, int T0, int NQ, int TOTAL, int EP, int lda, int ldo, class Bias>
-__device__ __forceinline__ void r8_dense_wide(R8Stream& s, const float* act, float* out, float* PART,
+template <int G, int T0, int NQ, int TOTAL, int EP, int lda, int ldo, class ST, class Bias>
+__device__ __forceinline__ void r8_dense_wide(ST& s, const float* act, float* out, float* PART,
                                               unsigned long long* mk, const Tid8f& t, Bias bias) {
     constexpr int EX = G - 4;
     f32x4 o[2];
@@ -206,19 +242,21 @@ __device__ __forceinline__ void r8_dense_wide(R8Stream& s, const float* act, flo
 // log q(x) and d log q / dx for the 8 rows in X0 (columns >= D zero; DP and PRM zeroed by the caller); the gradient is left
 // in the state buffer whose offset is returned through *grad_off.  Returns log q of row `tid >> 4` on threads < 128.
 // All 256 threads of the workgroup must call it; it ends with a workgroup barrier.
-template <int G>
+template <int G, bool FUSED = false, class ST>
 __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds& l, const float* __restrict__ packed, float* lds,
-                                  const Tid8f& t, R8Stream& s, int* grad_off) {
+                                  const Tid8f& t, ST& s, int* grad_off) {
     constexpr int EX = G - 4, NQW = 16 * G, NQK = 4 * G;                  // k-quads of K = Wp; of a wave's quarter of it
-    constexpr int F_AW = 0, F_W1 = R8_TD, F_W2 = F_W1 + R8_Kd4 + EX * (R8_Kd4 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK / 2;
-    constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK, B_AWT = B_W1T + NQK / 4,
-                  TR = B_AWT + R8_TD;
-    static_assert(TF == TR && (TF + EX) % R8_RD == 0, "a layer's padded tile count must be a multiple of the ring depth");
-    constexpr int TP = TF + EX;                                             // padded tiles per layer and direction (EX: one zero tile)
+    constexpr int NQ1 = FUSED ? R8_KD4 : R8_Kd4;                            // k-quads of the first Linear's K (fused: the whole state)
+    constexpr int F_AW = 0, F_W1 = R8_TD, F_W2 = F_W1 + NQ1 + EX * (NQ1 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK / 2;
+    constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK,
+                  B_AWT = B_W1T + (FUSED ? NQK / 2 : NQK / 4), TR = B_AWT + (FUSED ? 1 : R8_TD);
+    constexpr int TP = FUSED ? (G == 5 ? 3 : 2) * R8F_RD : TF + EX;         // padded tiles per layer and direction (zero tiles behind)
+    static_assert(ST::RD == (FUSED ? R8F_RD : R8_RD) && TP % ST::RD == 0 && TP >= TF && TP >= TR && (FUSED || TF == TR),
+                  "a layer's padded tile count must be a multiple of the ring depth");
     constexpr int CONT = S8_INF;                                            // "tiles left in the stream": never drained
     const int h2 = t.lane >> 5, h4 = t.lane >> 4;                           // this lane's k-quad inside a dense tile of 2 / 4
     constexpr int WS = 64 * G + 4;                                          // = l.WS, as a constant (see r8_dense_wide)
-    const float* img = packed + f.o_r8;
+    const float* img = packed + (FUSED ? f.o_r8f : f.o_r8);
     int cur = l.o_X0, nxt = l.o_X1;
     float* const lds0 = lds;
     const bool ew = t.tid < 128;
@@ -226,11 +264,12 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
     const int DOp = f.DOp;
     float logq = 0.f;
     // this wave's stream: [layers K-1 .. 0 forward | layers 0 .. K-1 reverse | tail], TP tiles per layer and direction
-    s8_prologue(s, reinterpret_cast<const float4*>(img) + (size_t)t.wave * r8_wave_tiles(G, f.K) * 64);
-    auto pad_tile = [&](float* lds) {                                       // the zero tile that rounds a layer up to TP (G = 5)
-        if constexpr (EX) {
+    s8_prologue(s, reinterpret_cast<const float4*>(img) + (size_t)t.wave * (FUSED ? r8f_wave_tiles(G, f.K) : r8_wave_tiles(G, f.K)) * 64);
+    auto pad_tiles = [&](float* lds, auto tc) {                             // the zero tiles that round a layer up to TP
+        constexpr int T = decltype(tc)::value;
+        if constexpr (T < TP) {
             S8Acc<2> acc;
-            s8_iter_k<4, 1, 0, TF % R8_RD, CONT>(s, lds + l.o_X0 + t.arow * R4_DS, 4 * R4_DS, acc);
+            s8_iter_k<4, TP - T, 0, T % ST::RD, CONT>(s, lds + l.o_X0 + t.arow * R4_DS, 4 * R4_DS, acc);
         }
     };
     for (int layer = f.K - 1; layer >= 0; --layer) {
@@ -263,10 +302,13 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         }
         logq += HD[128 + 2 * f.Wp];
         float* Z = lds + nxt;
-        s8_barrier();
-        if (tl) FAB_TL(f, 1);
-        // conditioner: HA = relu(z[:, :d] W1 + b1), HB = relu(HA W2 + b2)
-        r8_dense_wide<G, F_W1, R8_Kd4, CONT + TP, 1, R4_DS, WS>(s, Z, HA, PART, mk, t, [&](int col) { return HD[64 + col]; });
+        if constexpr (!FUSED) {
+            s8_barrier();
+            if (tl) FAB_TL(f, 1);
+        }
+        // conditioner: HA = relu(z[:, :d] W1 + b1), HB = relu(HA W2 + b2)   (fused: HA = relu(y W1' + b1') from the layer's INPUT: z is
+        // first read by the coupling, three barriers from here)
+        r8_dense_wide<G, F_W1, NQ1, CONT + TP, 1, R4_DS, WS>(s, FUSED ? lds + cur : Z, HA, PART, mk, t, [&](int col) { return HD[64 + col]; });
         if (tl) FAB_TL(f, 2);
         r8_dense_wide<G, F_W2, NQW, CONT + TP, 1, WS, WS>(s, HA, HB, PART, mk + G * R8, t, [&](int col) { return HD[64 + f.Wp + col]; });
         if (tl) FAB_TL(f, 3);
@@ -281,7 +323,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
 #pragma unroll
                 for (int r = 0; r < 4; ++r) PART[((2 * t.wave + h2) * R8 + 4 * rb + r) * 32 + (t.lane & 31)] = o[rb][r];
         }
-        pad_tile(lds);                 // (the stream runs on into the next layer: nothing to request here)
+        pad_tiles(lds, std::integral_constant<int, TF>{});   // (the stream runs on into the next layer: nothing to request here)
         s8_barrier();
         if (tl) FAB_TL(f, 4);
         // AffineCoupling.inverse: z2 <- (z2 - shift) exp(-s), log_det = -sum(s)
@@ -348,6 +390,38 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         if (tl) FAB_TL(f, 17);
         r8_dense_wide<G, B_W2T, NQW, CONT + TP, 2, WS, WS>(s, HA, HB, PART, mk, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 18);
+        if constexpr (FUSED) {
+            {   // g_y = dh1 W1'^T + g_z W'^T: K split over the waves (this wave's quarter of the hidden width + 8 columns of g_z)
+                f32x4 o[2];
+                S8Acc<2> acc;
+                s8_zero(acc);
+                s8_run_k<8, B_W1T, NQK / 2, CONT + B_W1T>(s, HB + t.arow * WS + 4 * NQK * t.wave + 4 * h2, 4 * WS, acc);
+                s8_run_k<8, B_AWT, 1, CONT + B_AWT>(s, Gs + t.arow * R4_DS + 8 * t.wave + 4 * h2, 4 * R4_DS, acc);
+                s8_fold(acc, o);
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) PART[((2 * t.wave + h2) * R8 + 4 * rb + r) * 32 + (t.lane & 31)] = o[rb][r];
+            }
+            pad_tiles(lds, std::integral_constant<int, TR>{});
+            s8_barrier();
+            if (tl) FAB_TL(f, 19);
+            if (ew) {   // the sum of the 8 partial products; where the NEXT layer's g2 appears, its coupling cotangents
+#pragma unroll
+                for (int it = 0; it < 2; ++it) {
+                    const int col = c + 16 * it, j = col - f.d;
+                    float v = col < f.D ? r8_part_sum_n<8>(PART + row * 32 + col, R8 * 32) : 0.f;
+                    if (layer + 1 < f.K && j >= 0 && j < f.DO) {
+                        const float es = lds[l.o_ES + ((size_t)(layer + 1) * R8 + row) * DOp + j];
+                        const float v2 = lds[l.o_V2 + ((size_t)(layer + 1) * R8 + row) * DOp + j];
+                        DP[row * R4_DS + j] = -(v * es);
+                        DP[row * R4_DS + DOp + j] = -(v * v2) - 1.f;
+                        v = v * es;
+                    }
+                    lds[nxt + row * R4_DS + col] = v;
+                }
+            }
+        } else {
         {   // conditioner input gradient = HB W1T: K split over the waves
             f32x4 o[2];
             S8Acc<2> acc;
@@ -370,7 +444,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             s8_zero(acc);
             s8_run_k<8, B_AWT, R8_TD, CONT + B_AWT>(s, Gs + t.arow * R4_DS + 4 * h2, 4 * R4_DS, acc);
             s8_fold(acc, o);
-            pad_tile(lds);
+            pad_tiles(lds, std::integral_constant<int, TR>{});
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
@@ -396,6 +470,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
                     }
             }
         }
+        }
         s8_barrier();
         if (tl) FAB_TL(f, 21);
         const int tmp = cur; cur = nxt; nxt = tmp;
@@ -404,5 +479,9 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
     *grad_off = cur;
     return logq;
 }
+
+// host side: fused stages where the image exists and FABHIP_OPT_R4_STREAM >= 2 (the switch of the 4-chain kernel: one A/B for both)
+int option(int key);                                   // (launch.h)
+static inline bool use_r8_fused(const FlowDims& f) { return r8f_shape_ok(f) && option(FABHIP_OPT_R4_STREAM) >= 2; }
 
 }  // namespace fab

@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 213
+#define FABHIP_ABI_VERSION 214
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -94,7 +94,8 @@ int fabhip_get_fast_mode(void);
 #define FABHIP_OPT_R4_STREAM 1           /* FABHIP_R4_STREAM: 4-chain tiles: 2 = fused stages on their own weight stream (flow_r4f.h: the
                                             D x D map multiplied together with the first / last conditioner Linear, coupling in the
                                             W3 epilogue; default where the image exists), 1 = the round-3 stream (one stage per
-                                            matrix), 0 = per-stage request groups */
+                                            matrix), 0 = per-stage request groups.  The 8-chain tiles follow the same switch: >= 2 =
+                                            their fused-stage stream (flow_r8.h, default), below = one stage per matrix */
 #define FABHIP_OPT_SCAN_VARIANT 2        /* FABHIP_SCAN_VARIANT: fixed-point CDF scan, 3 = LDS-transposed (default), 0-2 = A/B */
 #define FABHIP_OPT_SYSTEMATIC_VARIANT 3  /* FABHIP_SYSTEMATIC_VARIANT: 1 = fused systematic sampler (default), 0 = CDF in HBM */
 #define FABHIP_OPT_SPLINE_STAGED 4       /* FABHIP_SPLINE_STAGED: 1 = per-layer spline kernels instead of the one-launch kernel */

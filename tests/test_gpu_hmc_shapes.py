@@ -270,6 +270,56 @@ def test_fused_stage_four_chain_kernels_match_the_stream_kernels_and_sixteen_cha
             assert torch.equal(ea, eb)
 
 
+@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 2048), (32, 10, 8, 37), (6, 3, 40, 70), (16, 3, 20, 257), (10, 2, 30, 9)])
+def test_fused_stage_eight_chain_kernels_match_the_unfused_ones_and_sixteen_chain_tiles(D, K, nodes, B):
+    """flow_r8.h with fused stages (FABHIP_OPT_R4_STREAM >= 2, the default; hidden widths 256 / 320): y -> z and y -> h1 in ONE
+    stage (W1' = W'[:, :d] W1^T in float64 at pack time), dh1 W1'^T + g_z W'^T as ONE K-split stage.  One HMC transition (two outer
+    steps) agrees with the unfused 8-chain kernel (option 1) and the 16-chain tiles to 1e-5 of the scale wherever no accept decision
+    flipped; bit-reproducible; the initial density of a chain (k_ais_init_r8, through the fused AIS call) is covered by the fixture
+    tests at tile shape 8."""
+    torch.manual_seed(D + K + 1)
+    flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)           # hidden width nodes x D in (192, 320]: the widths the 8-chain tiles exist for
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.03 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    eps = torch.randn(B, D, device=DEV, generator=g)
+    ops = _ops.load()
+    res = {}
+    x0, _ = flow.native_sample(eps)
+    try:
+        for mode, shape in ((2, 8), (2, 8), (1, 8), (2, 16)):
+            ops.set_option(_ops.OPT_R4_STREAM, mode)
+            ops.set_option(_ops.OPT_TILE_SHAPE, shape)
+            hmc = fa.HamiltonianMonteCarlo(3, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
+                                           n_outer=2, L=4).to(DEV)
+            pt = fa.create_point(x0.clone(), flow, target, with_grad=True)
+            torch.manual_seed(7)
+            out = hmc.transition(pt, 1, 0.3)
+            res.setdefault((mode, shape), []).append((out.x.clone(), out.log_q.clone(), out.grad_log_q.clone(), hmc.epsilons.clone()))
+    finally:
+        ops.set_option(_ops.OPT_R4_STREAM, 2)
+        ops.set_option(_ops.OPT_TILE_SHAPE, 0)
+    for a, b in zip(res[(2, 8)][0], res[(2, 8)][1]):
+        assert torch.equal(a, b)
+    for other in ((1, 8), (2, 16)):
+        xa, lqa, ga, ea = res[(2, 8)][0]
+        xb, lqb, gb, eb = res[other][0]
+        sc = max(1.0, float(xb.abs().max()))
+        err = (xa - xb).abs().max(1).values / sc
+        ok = err <= 1e-5
+        assert int((~ok).sum()) <= max(1, B // 200), (other, int((~ok).sum()), float(err.max()))
+        assert float((lqa[ok] - lqb[ok]).abs().max()) <= 2e-5 * max(1.0, float(lqb.abs().max()))
+        gerr = (ga - gb).abs().max(1).values / max(1.0, float(gb.abs().max()))
+        assert int(((gerr > 1e-4) & ok).sum()) <= max(1, B // 100), (other, int(((gerr > 1e-4) & ok).sum()), float(gerr.max()))
+        if bool(ok.all()):
+            assert torch.equal(ea, eb)
+    # the fused and the unfused kernel are different roundings of the same function, not the same bits
+    assert not torch.equal(res[(2, 8)][0][1], res[(1, 8)][0][1]) or B < 16
+
+
 def _poisoned_noise(B, D, M, dev, rows, seed):
     """AIS noise of a run in which the chains `rows` die at "chain init" (NaN base noise: the compaction has rows to move) and two
     proposals of the last transition are NaN (rejected: a chain cannot die inside a transition)."""
