@@ -401,7 +401,9 @@ static inline ExtraLds4 make_extra_lds4(const R4Lds& l, int D) {
 
 // MODE: 0 = per-stage weight requests (flow_log_prob_r4), 1 = one stream per wave (flow_log_prob_r4s), 2 = fused stages on
 // their own stream (flow_r4f.h: flow_log_prob_r4f; the bias blocks of all layers are copied to LDS once per launch), 3 = the
-// fused stages in FAST mode (bf16 W x W tiles: never the parity path)
+// fused stages in FAST mode (bf16 W x W tiles: never the parity path), 4 = the fused stages with the last R4F_NS items of every
+// W x W stage prefetched into LDS during the short stages (flow_r4f.h "stash": same arithmetic, bit-identical to MODE 2)
+constexpr int R4F_NS = 3;
 template <int NTWM, bool BIGD, int MODE>
 __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd, R4Lds l, ExtraLds4 x,
                                                           const float* __restrict__ packed, TargetDev tg, HmcK a) {
@@ -462,7 +464,8 @@ __global__ __launch_bounds__(NTHREADS) void k_hmc_step_r4(FlowDims f, R4Dims rd,
             lds[l.o_X0 + e] = j < D ? XP[r * D + j] : 0.f;
         }
         __syncthreads();
-        if constexpr (MODE == 3) lq = flow_log_prob_r4f<NTWM, true>(f, l, packed, lds, t4, &goff);
+        if constexpr (MODE == 4) lq = flow_log_prob_r4f<NTWM, false, R4F_NS>(f, l, packed, lds, t4, &goff, lds + x.total);
+        else if constexpr (MODE == 3) lq = flow_log_prob_r4f<NTWM, true>(f, l, packed, lds, t4, &goff);
         else if constexpr (MODE == 2) lq = flow_log_prob_r4f<NTWM>(f, l, packed, lds, t4, &goff);
         else if constexpr (MODE == 1) lq = flow_log_prob_r4s<NTWM>(f, rd, l, packed, lds, t4, &goff);
         else lq = flow_log_prob_r4<NTWM, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 4 : 2, BIGD ? 2 : 1>(f, rd, l, packed, lds, t4, &goff);
@@ -1170,6 +1173,11 @@ static int launch_hmc_step_r4(const FlowDims& f0, const float* packed, const Tar
         constexpr int NS = NTWM >= 2 ? NTWM : 2;
         FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, 3>, bytes));
         hipLaunchKernelGGL((k_hmc_step_r4<NS, false, 3>), grid, dim3(NTHREADS), bytes, st, f, rd, l, x, packed, tg, a);
+    } else if (NTWM >= 4 && fused && option(FABHIP_OPT_R4_STREAM) >= 3 && bytes + (size_t)R4F_NS * NTWM * NWAVE * 1024 <= 160 * 1024) {
+        constexpr int NS = NTWM >= 4 ? NTWM : 4;           // (the stash exists where a layer has no empty ring items: 4 / 5 tiles per wave)
+        const size_t bytes_s = bytes + (size_t)R4F_NS * NS * NWAVE * 1024;
+        FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, 4>, bytes_s));
+        hipLaunchKernelGGL((k_hmc_step_r4<NS, false, 4>), grid, dim3(NTHREADS), bytes_s, st, f, rd, l, x, packed, tg, a);
     } else if (NTWM >= 2 && fused) {
         constexpr int NS = NTWM >= 2 ? NTWM : 2;
         FAB_TRY(set_max_lds((const void*)k_hmc_step_r4<NS, false, 2>, bytes));

@@ -36,14 +36,42 @@ namespace fab {
 
 // FAST (fast mode, never the parity path): the W x W items hold bf16 tiles - 2 k-quads per 1-KiB tile (lane = column, 16 bytes =
 // 8 consecutive k), so a wave's W x W stage is 2 G items instead of 4 G and streams half the bytes; everything else as fp32.
-template <int NTWM, bool FAST = false>
+// NS > 0 (round 5, "stash"): the LAST NS items of a W x W stage are not ring items - they are copied into LDS by
+// global_load_lds_dwordx4 (no register, one instruction per 1-KiB tile and wave) while the SHORT stages in front of that W x W
+// stage run, and read back with ds_read_b128 when their turn comes.  Why: the W x W stages run at the rate the L2 -> CU path
+// delivers; in the short stages the same path idles (five items consumed in ~3.9 k cycles: 42 % of what it could carry), because
+// the ring can only hold RD - 1 items ahead.  The CU's free LDS is the one place where more of the stream can wait: NS G KiB per
+// wave.  Same tiles, same MFMA order: bit-identical results.  MEASURED (profiles/r5/hmc_r4f_stash_timeline.txt, NS = 3): the W x W
+// stages of a layer pair lose 1.9 k cycles, the short stages gain 1.7 k - ~55 cycles per copied tile and wave wherever the copy
+// is issued: a 1-KiB vector-memory instruction occupies the CU's address path for 16 cycles, the four waves reach their request
+// sites together (a barrier apart at most) and an in-order wave cannot do anything else while it waits its turn.  Level with the
+// ring alone, so it is NOT the default (FABHIP_OPT_R4_STREAM = 3 selects it).  One stash PIECE (= one item, G tiles) is requested behind the
+// ring's own requests while items I_N, I_N + 1 (S3 / S6: for the NEXT layer slot), 0, 1, 2 (S1 / S4: this slot) are consumed -
+// the first NS of those; loads return in order, so the hand-counted waits simply count the pieces' loads as well.
+template <int NTWM, bool FAST = false, int NS_ = 0>
 struct R4F {
     static constexpr int G = NTWM;
+    static constexpr int NS = NS_;
     static constexpr int NQW = FAST ? 2 * G : 4 * G;       // items of a W x W stage
     static constexpr int CR = NQW + 5;                     // items with tiles per layer and direction
     static constexpr int TL = (NQW + 4) * G + 1;           // tiles per wave, layer and direction
     static constexpr int I_A = 2, I_W = 3, I_N = NQW + 3;
-    static constexpr int ntiles(int I) { return I == I_A ? 1 : (I < CR ? G : 0); }
+    // stash item k = k-quad SQ0 + k SQD of the W x W stage: spread over its front - a stash item is consumed ~3 x faster than a
+    // ring item, and the RD - 1 items behind one lose that much lead time; at the stage's END that starved S3 / S6 and S1 / S4 of
+    // their tiles (measured: short stages + 2.3 k cycles per layer pair, more than the W x W stages gained)
+    static constexpr int SQ0 = 1, SQD = NS > 0 ? (NQW - 5) / NS : 1;
+    static constexpr int stash_k(int I) { return (I - I_W - SQ0) / SQD; }
+    static constexpr bool is_stash(int I) {
+        return NS > 0 && I >= I_W + SQ0 && I < I_N && (I - I_W - SQ0) % SQD == 0 && stash_k(I) < NS;
+    }
+    static constexpr int stash_item(int k) { return I_W + SQ0 + k * SQD; }
+    static constexpr int ntiles(int I) { return I == I_A ? 1 : (I < CR && !is_stash(I) ? G : 0); }   // tiles the RING holds of item I
+    // the stash piece requested while item I is consumed (-1: none), and whether it belongs to the next layer slot
+    static constexpr int dma_piece(int I) {
+        const int k = I >= I_N ? I - I_N : (I <= I_A ? I + 2 : -1);
+        return k >= 0 && k < NS ? k : -1;
+    }
+    static constexpr bool dma_next_slot(int I) { return I >= I_N; }
     static constexpr int toff(int I) { return I <= I_A ? I * G : (I - 1) * G + 1; }
     // The ring (R4FRing) holds RD items in ACCUMULATION registers; its slots are compile-time constants when RD divides the
     // items per layer, so a layer is padded to C = a multiple of RD with E EMPTY items (no tiles, no request).  They sit inside
@@ -83,12 +111,33 @@ struct R4F {
     static constexpr int req_lo(int I) { return prev_pos(I) - 1 + RD + 1; }  // first one
     // loads issued after the last tile of item I when its tiles are waited for (requests up to prev_pos(I) - 1 + RD are out)
     static constexpr int inflight_behind(int I) {
+        if (NS > 0) return younger(I);
         int n = 0;
         for (int J = vidx(I) + 1; J <= prev_pos(I) - 1 + RD; ++J) n += vtiles(J);
         return n;
     }
+    // NS > 0 (E == 0: positions are items): loads issued behind the tiles of item I - ring item: its request, stash item: its
+    // piece - when they are waited for, i.e. after the refill of the item consumed before I.  The issue order is replayed
+    // backwards: the item consumed `step` items before I requested ring position (that item) - 1 + RD and then its piece.
+    static constexpr int younger(int I) {
+        int n = 0;
+        for (int step = 1; step <= C; ++step) {
+            const int J = ((I - step) % C + C) % C;
+            const int pk = dma_piece(J);
+            if (pk >= 0) {
+                if (is_stash(I) && pk == stash_k(I)) return n;
+                n += G;
+            }
+            const int V = (I - step) - 1 + RD;                 // position relative to I's layer (may be < 0 or >= C)
+            if (!is_stash(I) && V == I) return n;
+            n += vtiles(((V % C) + C) % C);
+        }
+        return 63;
+    }
     static_assert(E <= NQW / STEP, "every empty item needs an item of the W x W stage to sit behind");
     static_assert((RD - 1) * G < 64, "vmcnt is a 6-bit counter");
+    static_assert(NS == 0 || (E == 0 && !FAST && NS <= 5 && SQD >= 2 && stash_item(NS - 1) + RD - 1 < I_N),
+                  "the stash needs a layer without empty items; no stash item within the ring's reach of the short stages");
 };
 
 // bias block of one layer in LDS / in the image (r4f_bias_stride floats, fabhip_common.h):
@@ -143,17 +192,70 @@ __device__ __forceinline__ void r4f_load_bias(const float* __restrict__ src, flo
 // `inflight_behind` younger loads are outstanding; any other load in flight (stage stamps) only makes a wait conservative.
 // The build's ISA check (_isa_check.py) verifies on the generated code that no instruction touches a ring register whose
 // load may still be in flight.
-template <int NTWM, bool FAST = false>
+template <int NTWM, bool FAST = false, int NS = 0>
 struct R4FRing {
-    using S = R4F<NTWM, FAST>;
+    using S = R4F<NTWM, FAST, NS>;
     static constexpr int G = S::G, RD = S::RD, C = S::C;
     f32x4 r[RD][G];
     const float4 *spG, *sp1;           // (layer slot, wave) of the section being consumed: items of G tiles / of one tile
     unsigned voff0, voff1;             // lane * 16 (+ 4096: the fifth tile of an item is past the 12-bit immediate offset)
-    __device__ __forceinline__ R4FRing(const float4* base, const Tid4& t)
+    unsigned stash_m0;                 // LDS byte address of this wave's stash (NS G tiles of 1 KiB)
+    const float4* stash_rd;            // the same place for this lane's ds_read_b128: + (k G + g) 64 float4
+    __device__ __forceinline__ R4FRing(const float4* base, const Tid4& t, float* stash = nullptr)
         : spG(base + (size_t)t.wave * G * 64), sp1(base + (size_t)t.wave * 64), voff0((unsigned)t.lane * 16u),
-          voff1((unsigned)t.lane * 16u + 4096u) {
-        static_for<0, RD - 1>([&](auto vc) { request<decltype(vc)::value>(); });
+          voff1((unsigned)t.lane * 16u + 4096u),
+          stash_m0((unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)stash + t.wave * (NS * G * 1024))),
+          stash_rd(reinterpret_cast<const float4*>(stash) + (size_t)t.wave * (NS * G * 64) + t.lane) {
+        if constexpr (NS == 0) static_for<0, RD - 1>([&](auto vc) { request<decltype(vc)::value>(); });
+        else {
+            // what the last RD - 1 items of a layer in front of this one would have requested, in their order (the waits count on it)
+            static_for<0, RD - 1>([&](auto pc) {
+                constexpr int P = decltype(pc)::value - (RD - 1);        // consumed position, < 0: item P + C of the slot before
+                request<P - 1 + RD>();
+                constexpr int I = P + C;
+                if constexpr (S::dma_piece(I) >= 0) request_dma<S::dma_piece(I), false>();
+            });
+        }
+    }
+    // stash piece k of this layer slot (NEXT: of the one behind it): G tiles -> LDS
+    template <int K, bool NEXT>
+    __device__ __forceinline__ void request_dma() {
+        constexpr int I = S::stash_item(K);
+        const float4* b0 = spG + ((size_t)(NEXT ? 1 : 0) * S::TL + S::toff(I)) * 4 * 64;
+        const unsigned long long bu = (unsigned long long)b0;
+        const float4* b = reinterpret_cast<const float4*>(
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu >> 32)) << 32) |
+            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu & 0xffffffffull)));
+        const unsigned dst = stash_m0 + K * G * 1024;
+        // M0 = LDS byte address of the first tile; the immediate offset moves the global AND the LDS address (lane l -> + 16 l)
+        static_assert(G >= 2 && G <= 5, "");
+        if constexpr (G == 2)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(voff0), "s"(b), "s"(dst) : "memory");
+        else if constexpr (G == 3)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
+                         :: "v"(voff0), "s"(b), "s"(dst) : "memory");
+        else
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
+                         "global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(voff0), "s"(b), "s"(dst) : "memory");
+        if constexpr (G == 5)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:0"
+                         :: "v"(voff1), "s"(b), "s"(dst + 4096u) : "memory");
+    }
+    // the tiles of stash item I have landed in LDS (loads return in order: at most `inflight_behind` younger ones are outstanding)
+    template <int I>
+    __device__ __forceinline__ void wait_stash(IC<I>) {
+        constexpr int N = S::inflight_behind(I);
+        static_assert(S::is_stash(I) && N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+    }
+    template <int I>
+    __device__ __forceinline__ void read_stash(IC<I>, float4 (&w)[G]) const {
+        constexpr int K = S::stash_k(I);
+#pragma unroll
+        for (int g = 0; g < G; ++g) w[g] = stash_rd[(K * G + g) * 64];
     }
     // request the item at virtual position V (V >= C: of the next layer) into its slot
     template <int V>
@@ -181,7 +283,7 @@ struct R4FRing {
     template <int I>
     __device__ __forceinline__ void wait(IC<I>) {
         constexpr int SL = S::vidx(I) % RD, N = S::inflight_behind(I);
-        static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+        static_assert(!S::is_stash(I) && N >= 0 && N < 64, "vmcnt is a 6-bit counter");
         if constexpr (S::ntiles(I) == 1) asm volatile("s_waitcnt vmcnt(%1)" : "+a"(r[SL][0]) : "n"(N));
         else if constexpr (G == 2) asm volatile("s_waitcnt vmcnt(%2)" : "+a"(r[SL][0]), "+a"(r[SL][1]) : "n"(N));
         else if constexpr (G == 4)
@@ -197,6 +299,7 @@ struct R4FRing {
     __device__ __forceinline__ void refill(IC<I>) {
         __builtin_amdgcn_sched_barrier(0);
         static_for<S::req_lo(I), S::req_hi(I) + 1>([&](auto pc) { request<decltype(pc)::value>(); });
+        if constexpr (S::dma_piece(I) >= 0) request_dma<S::dma_piece(I), S::dma_next_slot(I)>();
         __builtin_amdgcn_sched_barrier(0);
     }
     __device__ __forceinline__ void next_layer() { spG += (size_t)S::TL * 4 * 64; sp1 += (size_t)S::TL * 4 * 64; }
@@ -242,12 +345,21 @@ __device__ __forceinline__ void r4f_dense_wide(const float* act, int lda, Ring& 
 #pragma unroll
     for (int g = 0; g < G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* arow = act + t.arow * lda + 16 * NTWM * t.wave;
+    float4 ws[2][G];                   // stash tiles out of LDS, read one item ahead of their MFMAs
     static_for<0, NQ>([&](auto qc) {
         constexpr int q = decltype(qc)::value;
         const float4 a = *reinterpret_cast<const float4*>(arow + 4 * q);
-        ring.wait(IC<I0 + q>{});
-        r4_quad<G>(a, ring.r[ring.slot(IC<I0 + q>{})], acc);
+        if constexpr (S::is_stash(I0 + q)) {
+            r4_quad<G>(a, ws[S::stash_k(I0 + q) & 1], acc);
+        } else {
+            ring.wait(IC<I0 + q>{});
+            r4_quad<G>(a, ring.r[ring.slot(IC<I0 + q>{})], acc);
+        }
         ring.refill(IC<I0 + q>{});
+        if constexpr (q + 1 < NQ && S::is_stash(I0 + q + 1)) {
+            ring.wait_stash(IC<I0 + q + 1>{});
+            ring.read_stash(IC<I0 + q + 1>{}, ws[S::stash_k(I0 + q + 1) & 1]);
+        }
         __builtin_amdgcn_sched_barrier(0);
     });
     (void)PN;
@@ -347,10 +459,10 @@ __device__ __forceinline__ void r4f_narrow_mma(const float* act, int lda, Ring& 
 // log q(x) and d log q / dx for the 4 rows in X0 (columns >= D zero).  The gradient is left in X0 (*grad_off = l.o_X0, leading
 // dimension R4_DS); returns log q of row `tid >> 4` on wave 0.  The density bias table must be in LDS at l.o_BIAS.
 // ------------------------------------------------------------------------------------------------
-template <int NTWM, bool FAST = false>
+template <int NTWM, bool FAST = false, int NS = 0>
 __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const float* __restrict__ packed, float* lds,
-                                   const Tid4& t, int* grad_off) {
-    using S = R4F<NTWM, FAST>;
+                                   const Tid4& t, int* grad_off, float* stash = nullptr) {
+    using S = R4F<NTWM, FAST, NS>;
     constexpr int G = NTWM, RD = S::RD;
     float* X = lds + l.o_X0;
     float* HA = lds + l.o_HA;
@@ -364,7 +476,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
     const int row = t.tid >> 4, c = t.tid & 15;            // element-wise mapping of wave 0 (coupling, base distribution)
     const int zrow = t.tid >> 5, zc = t.tid & 31;          // (row, column) of the 4 x 32 outputs of a dense narrow product
     const int sblk = t.lane >> 5;
-    R4FRing<NTWM, FAST> ring(reinterpret_cast<const float4*>(packed + (FAST ? f.o_r4fh : f.o_r4f)), t);
+    R4FRing<NTWM, FAST, NS> ring(reinterpret_cast<const float4*>(packed + (FAST ? f.o_r4fh : f.o_r4f)), t, stash);
     float logq = 0.f;
 #pragma unroll 1                       // (an unrolled copy gets other ring registers, joined by copies of in-flight slots: ISA check)
     for (int layer = f.K - 1; layer >= 0; --layer) {

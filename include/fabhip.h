@@ -93,8 +93,10 @@ int fabhip_get_fast_mode(void);
                                             size (default) */
 #define FABHIP_OPT_R4_STREAM 1           /* FABHIP_R4_STREAM: 4-chain tiles: 2 = fused stages on their own weight stream (flow_r4f.h: the
                                             D x D map multiplied together with the first / last conditioner Linear, coupling in the
-                                            W3 epilogue; default where the image exists), 1 = the round-3 stream (one stage per
-                                            matrix), 0 = per-stage request groups.  The 8-chain tiles follow the same switch: >= 2 =
+                                            W3 epilogue; default where the image exists), 3 = the same with three items of every W x W
+                                            stage prefetched into LDS during the short stages (opt-in: bit-identical to 2 and, measured,
+                                            no faster - the copies' issue time lands on the short stages),
+                                            1 = the round-3 stream (one stage per matrix), 0 = per-stage request groups.  The 8-chain tiles follow the same switch: >= 2 =
                                             their fused-stage stream (flow_r8.h, default), below = one stage per matrix */
 #define FABHIP_OPT_SCAN_VARIANT 2        /* FABHIP_SCAN_VARIANT: fixed-point CDF scan, 3 = LDS-transposed (default), 0-2 = A/B */
 #define FABHIP_OPT_SYSTEMATIC_VARIANT 3  /* FABHIP_SYSTEMATIC_VARIANT: 1 = fused systematic sampler (default), 0 = CDF in HBM */

@@ -320,6 +320,43 @@ def test_fused_stage_eight_chain_kernels_match_the_unfused_ones_and_sixteen_chai
     assert not torch.equal(res[(2, 8)][0][1], res[(1, 8)][0][1]) or B < 16
 
 
+@pytest.mark.parametrize("D,K,nodes,B", [(32, 10, 10, 1024), (32, 10, 8, 37), (16, 3, 20, 257), (6, 3, 40, 70)])
+def test_lds_prefetch_of_the_fused_four_chain_kernel_is_bit_identical_to_the_ring_alone(D, K, nodes, B):
+    """FABHIP_OPT_R4_STREAM = 3 (opt-in: measured level with option 2): three items of every W x W stage of
+    the fused 4-chain transition kernel reach the MFMAs through LDS (global_load_lds_dwordx4 issued during the short stages,
+    ds_read_b128 when their turn comes) instead of the register ring.  Same tiles, same order of MFMAs: everything a transition
+    returns is bit-identical to option 2, over two transitions from the same start, and repeated runs agree (a tile read before
+    its copy has landed would show here)."""
+    torch.manual_seed(D + K + 2)
+    flow = fa.RealNVP(D, K, nodes).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in flow.parameters():
+            if p.dim() == 2 and p.shape[0] != p.shape[1]:
+                p.add_(0.03 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x0, _ = flow.native_sample(torch.randn(B, D, device=DEV, generator=g))
+    ops = _ops.load()
+    res = {}
+    try:
+        for mode in (3, 2, 3, 3):
+            ops.set_option(_ops.OPT_R4_STREAM, mode)
+            ops.set_option(_ops.OPT_TILE_SHAPE, 4)
+            hmc = fa.HamiltonianMonteCarlo(3, D, flow.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.05,
+                                           n_outer=2, L=5).to(DEV)
+            pt = fa.create_point(x0.clone(), flow, target, with_grad=True)
+            torch.manual_seed(7)
+            out = hmc.transition(pt, 1, 0.3)
+            out = hmc.transition(out, 2, 0.6)
+            res.setdefault(mode, []).append((out.x.clone(), out.log_q.clone(), out.grad_log_q.clone(), hmc.epsilons.clone()))
+    finally:
+        ops.set_option(_ops.OPT_R4_STREAM, 2)
+        ops.set_option(_ops.OPT_TILE_SHAPE, 0)
+    for other in (res[2][0], res[3][1], res[3][2]):
+        for a, b in zip(res[3][0], other):
+            assert torch.equal(a, b)
+
+
 def _poisoned_noise(B, D, M, dev, rows, seed):
     """AIS noise of a run in which the chains `rows` die at "chain init" (NaN base noise: the compaction has rows to move) and two
     proposals of the last transition are NaN (rejected: a chain cannot die inside a transition)."""
