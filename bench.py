@@ -219,7 +219,7 @@ def spline_cfg3(dev):
     return {"workload": "cfg3: ManyWell-32, spline flow 12 x (hidden 256, 8 bins), 2048 chains, M = 12, HMC L = 5",
             "value": B / t_call, "unit": "AIS samples/s", "ms_per_call": t_call * 1e3,
             "density_grad_evals_per_call": M * LF + 1, "ms_per_density_grad": t_eval * 1e3,
-            "kernel": "k_spline_logprob_r8<2, 2, true> (8 chains per workgroup, v_mfma_f32_4x4x1, 256 workgroups)",
+            "kernel": "k_spline_logprob_r8<2, 2, true, true> (8 chains per workgroup, stream without zero tiles, v_mfma_f32_4x4x1, 256 workgroups)",
             "achieved_TFLOPs": flop_alg / t_eval / 1e12, "frac_fp32_mfma_peak": flop_alg / t_eval / 1e12 / PEAK_FP32_MFMA_TFLOPS,
             "flop_per_eval_algorithmic": flop_alg, "flop_per_eval_as_executed": flop,
             "as_executed": {"achieved_TFLOPs": flop / t_eval / 1e12, "frac_fp32_mfma_peak": flop / t_eval / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -455,7 +455,7 @@ def main():
         r8 = shape == 8 or (shape == 0 and 1152 < B_PER_GPU <= 8 * n_cu)    # 8-chain tiles (flow_r8.h) up to 8 chains per CU
         n_wg = (B_PER_GPU + 3) // 4 if r4 else ((B_PER_GPU + 7) // 8 if r8 else (B_PER_GPU + 15) // 16)
         kname = "k_hmc_step_r4<5> (4 chains per workgroup, v_mfma_f32_4x4x1; step-size rule in its last wave)" if r4 else \
-            ("k_hmc_step_r8<5> (8 chains per workgroup, v_mfma_f32_4x4x1; step-size rule in its last wave)" if r8 else
+            ("k_hmc_step_r8<5, true> (8 chains per workgroup, fused stages, v_mfma_f32_4x4x1; step-size rule in its last wave)" if r8 else
              "k_hmc_step<5> (+ k_hmc_adapt, ~2 us)")
         roof = {"bound": "mfma", "kernel": kname, "achieved": ach,
                 "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
@@ -501,7 +501,7 @@ def main():
         # 8-chain tiles (k_hmc_step_r8<5>) with one workgroup per CU (2048 chains: the shape of BASELINE cfg 4 per GPU):
         t_2k = time_transition(2048)
         ach_2k = 2048 * L * 2 * F_FWD / t_2k / 1e12
-        roof["chains_2048"] = {"chains": 2048, "kernel": "k_hmc_step_r8<5> (8 chains per workgroup)", "ms_per_launch": t_2k * 1e3,
+        roof["chains_2048"] = {"chains": 2048, "kernel": "k_hmc_step_r8<5, true> (8 chains per workgroup, fused stages)", "ms_per_launch": t_2k * 1e3,
                                "achieved": ach_2k, "frac": ach_2k / PEAK_FP32_MFMA_TFLOPS}
         hmc.load_state_dict(saved_roof)
 

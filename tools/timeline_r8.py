@@ -23,9 +23,14 @@ torch.cuda.synchronize()
 buf = (C.c_int64 * 64)()
 _lib.check(_lib.load().fabhip_debug_timeline(buf, 64), "timeline")
 ts = list(buf)
+from fab_torch_amd import _ops
+fused = int(_ops.load().get_option(_ops.OPT_R4_STREAM)) >= 2
 names = {0: "fwd layer start", 1: "affine (every wave, 4 dense tiles)", 2: "W1 (d -> W, 4 tiles)", 3: "W2 (W x W, 16 G tiles)",
          4: "W3 (K split, 2 G dense tiles) + next ring", 5: "coupling", 16: "rev layer start", 17: "W3T (8 tiles)",
          18: "W2T (16 G tiles)", 19: "W1T (K split, G dense tiles)", 20: "add", 21: "affine^T (4 dense tiles) + next ring"}
+if fused:       # flow_r8.h FUSED: y -> z and y -> h1 in one stage; dh1 W1'^T + g_z W'^T in one K-split stage + its consumer
+    names.update({2: "S1: z = y W' + ac | h1 = relu(y W1' + b1')", 19: "S6: dh1 W1'^T + g_z W'^T (K split)",
+                  21: "S6 consumer: 8 partials + next cotangents"})
 prev = None
 for i in sorted(names):
     if not ts[i]:
