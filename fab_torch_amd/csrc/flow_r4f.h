@@ -487,15 +487,50 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
         {   // S1: h1 = relu(y W1' + b1'), z = y A + ac   (K = 32: k in [8 w, 8 w + 8) on this wave)
             const float* xr = X + t.arow * R4_DS + 8 * t.wave;
             const float4 a0 = *reinterpret_cast<const float4*>(xr), a1 = *reinterpret_cast<const float4*>(xr + 4);
+#ifdef FAB_R4F_WAVETL                  // dev-only (tools/experiments/dephase): per-wave stamps around the refills of S1
+            long long wt[8];
+#define FAB_WT(k) do { __builtin_amdgcn_sched_barrier(0); wt[k] = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+            FAB_WT(0);
+            {
+                f32x4 acc0[G], acc1[G];
+#pragma unroll
+                for (int g = 0; g < G; ++g) { acc0[g] = (f32x4){0.f, 0.f, 0.f, 0.f}; acc1[g] = acc0[g]; }
+                ring.wait(IC<0>{});
+                FAB_WT(1);
+                r4_quad<G>(a0, ring.r[ring.slot(IC<0>{})], acc0);
+                FAB_WT(2);
+                ring.refill(IC<0>{});
+                FAB_WT(3);
+                ring.wait(IC<1>{});
+                r4_quad<G>(a1, ring.r[ring.slot(IC<1>{})], acc1);
+                FAB_WT(4);
+                ring.refill(IC<1>{});
+                FAB_WT(5);
+#pragma unroll
+                for (int g = 0; g < G; ++g) acc0[g] += acc1[g];
+                r4_store_part_rf<G>(acc0, PART, t);
+            }
+#else
             r4f_short_mma<NTWM, 0>(a0, a1, ring, PART, l.PN, t);
+#endif
             R4FAcc z;
             ring.wait(IC<S::I_A>{});
             z.template tile<0>(sblk ? a1 : a0, ring.r[ring.slot(IC<S::I_A>{})][0]);
             ring.refill(IC<S::I_A>{});
+#ifdef FAB_R4F_WAVETL
+            FAB_WT(6);
+#endif
             z.store(PZ, t);
             float bv[G];
             r4_bias_rf<G>(bv, bt, t);
             r4_barrier();
+#ifdef FAB_R4F_WAVETL
+            FAB_WT(7);
+            if (tl && f.timeline && blockIdx.x == 0 && t.lane == 0) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) f.timeline[32 + 8 * t.wave + k] = wt[k];
+            }
+#endif
             float zv = 0.f;                                // (read before the wide epilogue's writes: one LDS round trip less)
             if (t.tid < 128) zv = r4f_tree8(PZ, zrow, zc) + bt[2 * f.Wp + zc];
             r4_epilogue_rf<G, 1>(PART, bv, HA, l.WS, mk, t);

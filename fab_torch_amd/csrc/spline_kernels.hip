@@ -539,6 +539,11 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_net_bwd(SplineDims f, NetLd
 // The spline arithmetic below uses the hardware transcendental forms (__expf = v_exp_f32 on a scaled argument, __logf =
 // v_log_f32 scaled: ~1-2 ulp) - the dependent exp / log chains of a coordinate are what bounds the element-wise part
 // of the kernels, and 2e-7 relative is far inside the 1e-4 parity bar (softplus keeps log1pf where exp(u) is tiny).
+// Round 5: quotients by a shared denominator are products with its hardware reciprocal (v_rcp_f32, 1 ulp; every
+// denominator here is a softmax sum >= 1, a bin width / height >= 2 tb MIN, or a positive rational-quadratic term): an IEEE
+// fp32 division is ~10 dependent instructions, a coordinate had 17 in the forward and 29 in the reverse pass - 2 + 2 and 2 + 6
+// reciprocals now.  Shared by every spline kernel (16- / 8-chain tiles, sampling, tape), so they stay bit-compatible.
+__device__ __forceinline__ float sp_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 struct Rqs {
     float cw[SP_K + 1], ch[SP_K + 1];                    // knot positions / values
     float ud[SP_K + 1];                                  // effective unnormalised knot derivatives (end knots fixed / tied)
@@ -557,8 +562,8 @@ __device__ __forceinline__ void rqs_knot_pair(const Rqs& s, int b, float& d0, fl
     d1 = SP_MIN_D + sp_softplus(u1);
     if (sg0) {
         const bool f0 = !s.circ && b == 0, f1 = !s.circ && b == SP_K - 1;
-        *sg0 = f0 ? 0.f : 1.f / (1.f + __expf(-u0));
-        *sg1 = f1 ? 0.f : 1.f / (1.f + __expf(-u1));
+        *sg0 = f0 ? 0.f : sp_rcp(1.f + __expf(-u0));
+        *sg1 = f1 ? 0.f : sp_rcp(1.f + __expf(-u1));
     }
 }
 
@@ -574,9 +579,10 @@ __device__ __forceinline__ void rqs_setup(const float* p, bool circ, float tb, R
     for (int j = 0; j < SP_K; ++j) { s.pw[j] = __expf(p[j] - mw); sw += s.pw[j]; s.ph[j] = __expf(p[SP_K + j] - mh); sh += s.ph[j]; }
     float cw = 0.f, chh = 0.f;
     s.cw[0] = -tb; s.ch[0] = -tb;
+    const float isw = sp_rcp(sw), ish = sp_rcp(sh);
 #pragma unroll
     for (int j = 0; j < SP_K; ++j) {
-        s.pw[j] = s.pw[j] / sw; s.ph[j] = s.ph[j] / sh;
+        s.pw[j] = s.pw[j] * isw; s.ph[j] = s.ph[j] * ish;
         cw += SP_MIN_W + (1.f - SP_MIN_W * SP_K) * s.pw[j];
         chh += SP_MIN_H + (1.f - SP_MIN_H * SP_K) * s.ph[j];
         s.cw[j + 1] = (2.f * tb) * cw + (-tb);
@@ -610,10 +616,11 @@ __device__ __forceinline__ void rqs_forward(const Rqs& s, float x, float tb, flo
     for (int j = 0; j < SP_K; ++j)
         if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; }
     rqs_knot_pair(s, b, d0, d1, nullptr, nullptr);
-    const float th = (x - xk) / w, t1 = th * (1.f - th), dl = h / w;
+    const float iw = sp_rcp(w);
+    const float th = (x - xk) * iw, t1 = th * (1.f - th), dl = h * iw;
     const float num = h * (dl * (th * th) + d0 * t1);
     const float den = dl + (d0 + d1 - 2.f * dl) * t1;
-    y = yk + num / den;
+    y = yk + num * sp_rcp(den);
     const float dn = (dl * dl) * (d1 * (th * th) + 2.f * dl * t1 + d0 * ((1.f - th) * (1.f - th)));
     ld = __logf(dn) - 2.f * __logf(den);
 }
@@ -627,12 +634,12 @@ __device__ __forceinline__ void rqs_inverse(const Rqs& s, float y, float tb, flo
     for (int j = 0; j < SP_K; ++j)
         if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; yk = s.ch[j]; h = s.ch[j + 1] - s.ch[j]; }
     rqs_knot_pair(s, b, d0, d1, nullptr, nullptr);
-    const float dl = h / w, dy = y - yk, A = d0 + d1 - 2.f * dl;
+    const float dl = h * sp_rcp(w), dy = y - yk, A = d0 + d1 - 2.f * dl;
     const float a = dy * A + h * (dl - d0);
     const float bq = h * d0 - dy * A;
     const float c = -dl * dy;
     const float disc = bq * bq - 4.f * a * c;
-    const float root = (2.f * c) / (-bq - sqrtf(disc));
+    const float root = (2.f * c) * sp_rcp(-bq - sqrtf(disc));
     x = root * w + xk;
     const float t1 = root * (1.f - root);
     const float den = dl + A * t1;
@@ -655,21 +662,23 @@ __device__ __forceinline__ float rqs_backward(const Rqs& s, const float* p, bool
     for (int j = 0; j < SP_K; ++j)
         if (j == b) { xk = s.cw[j]; w = s.cw[j + 1] - s.cw[j]; h = s.ch[j + 1] - s.ch[j]; }
     rqs_knot_pair(s, b, d0, d1, dp ? &sg0 : nullptr, dp ? &sg1 : nullptr);
-    const float th = (x - xk) / w, t1 = th * (1.f - th), dl = h / w, A = d0 + d1 - 2.f * dl;
+    const float iw = sp_rcp(w), ih = sp_rcp(h);
+    const float th = (x - xk) * iw, t1 = th * (1.f - th), dl = h * iw, A = d0 + d1 - 2.f * dl;
     const float num = h * (dl * (th * th) + d0 * t1);
     const float den = dl + A * t1;
     const float e = d1 * (th * th) + 2.f * dl * t1 + d0 * ((1.f - th) * (1.f - th));
-    const float nb = gy / den;                                     // cotangent of num
-    const float db = -gy * num / (den * den) - 2.f / den;          // of den
-    const float eb = 1.f / e;                                      // of e
-    const float sb = 2.f / dl + eb * 2.f * t1 + db * (1.f - 2.f * t1) + nb * h * (th * th);
+    const float iden = sp_rcp(den);
+    const float nb = gy * iden;                                    // cotangent of num
+    const float db = -gy * num * (iden * iden) - 2.f * iden;       // of den
+    const float eb = sp_rcp(e);                                    // of e
+    const float sb = 2.f * (w * ih) + eb * 2.f * t1 + db * (1.f - 2.f * t1) + nb * h * (th * th);   // (2 / dl = 2 w / h)
     const float t1b = eb * 2.f * dl + db * A + nb * h * d0;
     const float d0b = eb * ((1.f - th) * (1.f - th)) + db * t1 + nb * h * t1;
     const float d1b = eb * (th * th) + db * t1;
     const float thb = eb * (2.f * d1 * th - 2.f * d0 * (1.f - th)) + nb * 2.f * h * dl * th + t1b * (1.f - 2.f * th);
-    const float hb = nb * (num / h) + sb / w;
-    const float wb = -sb * h / (w * w) - thb * th / w;
-    const float xb = thb / w;
+    const float hb = nb * (num * ih) + sb * iw;
+    const float wb = -sb * h * (iw * iw) - thb * th * iw;
+    const float xb = thb * iw;
     if (dp) {
         // knots: W_b += -xb - wb, W_{b+1} += wb ; H_b += gy - hb, H_{b+1} += hb ; D_b += d0b, D_{b+1} += d1b
         const float cWb = -xb - wb, cW1 = wb, cHb = gy - hb, cH1 = hb;

@@ -36,3 +36,10 @@ for i in sorted(names, key=lambda i: ts[i]):
     print(f"{i:2d} {names[i]:36s}", "" if prev is None or i in (0, 16) else f"+{ts[i] - prev:6d} ticks")
     prev = ts[i]
 print("fwd layer:", ts[5] - ts[0], "rev layer:", ts[22] - ts[16], "ticks")
+if any(ts[32:64]):                   # -DFAB_R4F_WAVETL (dev build): per-wave stamps inside S1, relative to wave 0's stage start
+    lab = ["start", "item 0 landed", "quad 0 issued", "refill 0 issued", "item 1 + quad 1", "refill 1 issued",
+           "A tile + refill 2", "barrier passed"]
+    t0 = min(ts[32 + 8 * w] for w in range(4))
+    print("S1 per wave (ticks since the first wave's start): " + " | ".join(lab))
+    for w in range(4):
+        print(f"  wave {w}: " + " ".join(f"{ts[32 + 8 * w + k] - t0:6d}" for k in range(8)))
