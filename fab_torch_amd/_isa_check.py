@@ -225,7 +225,7 @@ def check_adapt_fold(name, insns):
     differently would silently break the rule, so the lowering itself is checked on every build: in such a kernel the ticket
     must directly follow an `s_waitcnt vmcnt(0)` with no vector-memory instruction in between, at least two `sc1` dword stores
     must precede it, and at least 32 `sc1` dword loads (16 rows x 2 statistics) must follow it."""
-    if not re.search(r"k_hmc_step_r[48]", name):
+    if not re.search(r"k_hmc_step_r[48]|k_spline_logprob_r8", name):      # (spline_r8.h: s8_fold_adapt_last, the same mechanism)
         return []
     texts = [x[1] for x in insns]
     tickets = [i for i, t in enumerate(texts) if t.startswith("global_atomic_add") and " sc0" in t]

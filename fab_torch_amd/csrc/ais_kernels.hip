@@ -1517,10 +1517,26 @@ __global__ void k_spline_init_logw(const float* __restrict__ lq, const float* __
 
 size_t fabhip_spline_hmc_workspace_bytes(int32_t dim, int32_t n_layers, int32_t hidden, int64_t B) {
     return align256(fabhip_generic_workspace_bytes(B, dim)) +
-           align256(fabhip_spline_workspace_bytes(dim, n_layers, hidden, B, 1)) + align256((size_t)B * (3 * dim + 2) * 4) + 256;
+           align256(fabhip_spline_workspace_bytes(dim, n_layers, hidden, B, 1)) + align256((size_t)B * (3 * dim + 2) * 4) +
+           align256(spline_fold_scratch_floats(B) * 4) + 256;
+}
+
+// `ticket_zeroed`: the caller has already zeroed the fold's ticket word in this workspace (fabhip_spline_ais_run: once per call;
+// the wave that draws the last ticket of a launch resets it)
+static int spline_hmc_transition_impl(const fabhip_spline_hmc_args* a, fabhip_stream_t stream, bool ticket_zeroed);
+static int* spline_fold_ticket(const fabhip_spline_hmc_args* a) {
+    char* ws = (char*)a->workspace;
+    ws += align256(fabhip_generic_workspace_bytes(a->B, a->flow.dim));
+    ws += align256(fabhip_spline_workspace_bytes(a->flow.dim, a->flow.n_layers, a->flow.hidden, a->B, 1));
+    ws += align256((size_t)a->B * (3 * a->flow.dim + 2) * 4);
+    return (int*)((float*)ws + 32 * ((a->B + 15) / 16));
 }
 
 int fabhip_spline_hmc_transition(const fabhip_spline_hmc_args* a, fabhip_stream_t stream) {
+    return spline_hmc_transition_impl(a, stream, false);
+}
+
+static int spline_hmc_transition_impl(const fabhip_spline_hmc_args* a, fabhip_stream_t stream, bool ticket_zeroed) {
     if (!a || !a->flow.packed || !a->noise_p || !a->noise_e || !a->epsilons || !a->common_epsilon || !a->mass ||
         !a->workspace || a->B < 0 || a->n_outer < 1 || a->L < 1)
         return FABHIP_EINVAL;
@@ -1536,22 +1552,44 @@ int fabhip_spline_hmc_transition(const fabhip_spline_hmc_args* a, fabhip_stream_
     void* gws = ws; ws += align256(gb);
     const size_t sb = fabhip_spline_workspace_bytes(D, a->flow.n_layers, a->flow.hidden, B, 1);
     void* sws = ws; ws += align256(sb);
-    float* pb = (float*)ws;
+    float* pb = (float*)ws; ws += align256((size_t)B * (3 * D + 2) * 4);
+    float* fold_ws = (float*)ws;                                   // row_acc, row_dist [16 nblk], ticket
     fabhip_point prop{pb, pb + 3 * B * D, pb + 3 * B * D + B, pb + B * D, pb + 2 * B * D};
     const fabhip_point cur = a->point;
     fabhip_point start = cur;
+    // round 5: begin / accept / step-size rule inside the first / last leapfrog launch (L launches per outer step instead of
+    // L + 3) where the one-launch leapfrog applies - the same arithmetic in the same order, bit for bit (spline_r8.h)
+    const bool fold = spline_leap_fold_supported(&a->flow, B);
+    const int nblk = (int)((B + 15) / 16);
+    if (fold && !ticket_zeroed && hipMemsetAsync(spline_fold_ticket(a), 0, 4, st) != hipSuccess) return FABHIP_ELAUNCH;
     for (int n = 0; n < a->n_outer; ++n) {
-        FAB_TRY(gen_hmc_begin(&start, &cur, B, D, a->cur, a->noise_p + (size_t)n * B * D, a->mass, a->max_grad, gws, a->n_valid, st));
+        const bool last = n + 1 == a->n_outer;
+        if (!fold)
+            FAB_TRY(gen_hmc_begin(&start, &cur, B, D, a->cur, a->noise_p + (size_t)n * B * D, a->mass, a->max_grad, gws, a->n_valid, st));
         for (int l = 0; l < a->L; ++l) {
             {   // one launch per leapfrog where the 4x4x1 spline kernel applies (launch.h: SplineLeap)
                 float *XPw, *Pw, *GUw;
                 gen_hmc_state(gws, B, D, &XPw, &Pw, &GUw);
                 SplineLeap lp;
+                lp.fold = SplineFold{};
+                if (fold) {
+                    SplineFold& fd = lp.fold;
+                    fd.flags = (l == 0 ? 1 : 0) | (l + 1 == a->L ? 2 : 0);
+                    fd.start_x = start.x; fd.start_gq = start.grad_log_q; fd.start_gp = start.grad_log_p;
+                    fd.noise_p = a->noise_p + (size_t)n * B * D;
+                    fd.logp_cur = GUw + (size_t)B * D;              // the generic workspace's per-chain row (generic_kernels.hip: split_ws)
+                    fd.cur_x = cur.x; fd.cur_lq = cur.log_q; fd.cur_lp = cur.log_p; fd.cur_gq = cur.grad_log_q; fd.cur_gp = cur.grad_log_p;
+                    fd.noise_e = a->noise_e + (size_t)n * B; fd.nx = a->next; fd.log_w = last ? a->log_w : nullptr;
+                    fd.n_valid = a->n_valid; fd.row_acc = fold_ws; fd.row_dist = fold_ws + 16 * (size_t)nblk;
+                    fd.ticket = (int*)(fold_ws + 32 * (size_t)nblk);
+                    fd.eps_w = a->epsilons + n; fd.ceps_w = a->common_epsilon; fd.target_p_accept = a->target_p_accept; fd.tune = a->tune;
+                    fd.p_accept_out = a->p_accept ? a->p_accept + n : nullptr; fd.dist_out = a->avg_distance; fd.nblk = nblk;
+                }
                 lp.XP = XPw; lp.x_out = prop.x; lp.P = Pw; lp.GU = GUw; lp.eps_ptr = a->epsilons + n; lp.ceps_ptr = a->common_epsilon; lp.mass = a->mass;
                 lp.c = a->cur; lp.max_grad = a->max_grad; lp.tg = a->target; lp.prop_lp = prop.log_p; lp.prop_gp = prop.grad_log_p;
                 const int rc = spline_log_prob_leap(&a->flow, lp, prop.log_q, prop.grad_log_q, B, sws, sb, st);
                 if (rc == FABHIP_OK) continue;
-                if (rc != FABHIP_ENOTSUP) return rc;
+                if (rc != FABHIP_ENOTSUP || fold) return rc == FABHIP_ENOTSUP ? FABHIP_EINVAL : rc;
             }
             FAB_TRY(fabhip_hmc_generic_leap_pre(B, D, a->epsilons + n, a->common_epsilon, a->mass, prop.x, gws, gb, stream));
             FAB_TRY(fabhip_spline_log_prob(&a->flow, prop.x, prop.log_q, prop.grad_log_q, B, sws, sb, stream));
@@ -1559,10 +1597,10 @@ int fabhip_spline_hmc_transition(const fabhip_spline_hmc_args* a, fabhip_stream_
             FAB_TRY(fabhip_hmc_generic_leap_post(B, D, prop.grad_log_q, prop.grad_log_p, a->cur, a->max_grad, a->epsilons + n,
                                                  a->common_epsilon, gws, gb, stream));
         }
-        const bool last = n + 1 == a->n_outer;
-        FAB_TRY(gen_hmc_accept(&prop, &cur, B, D, a->cur, a->next, last ? a->log_w : nullptr, a->noise_e + (size_t)n * B, a->mass,
-                               a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
-                               a->p_accept ? a->p_accept + n : nullptr, a->avg_distance, gws, a->n_valid, st));
+        if (!fold)
+            FAB_TRY(gen_hmc_accept(&prop, &cur, B, D, a->cur, a->next, last ? a->log_w : nullptr, a->noise_e + (size_t)n * B, a->mass,
+                                   a->epsilons + n, a->common_epsilon, a->target_p_accept, a->tune,
+                                   a->p_accept ? a->p_accept + n : nullptr, a->avg_distance, gws, a->n_valid, st));
         start = prop;                                  // the reference continues from the PROPOSAL (hmc.py:133-142)
     }
     return FABHIP_OK;
@@ -1624,7 +1662,9 @@ int fabhip_spline_ais_run(const fabhip_spline_ais_args* a, fabhip_stream_t strea
         if (j == 1) { h.p_accept = a->p_accept_first; h.avg_distance = a->avg_distance_first; }
         else if (j == a->M) { h.p_accept = a->p_accept_last; h.avg_distance = a->avg_distance_last; }
         h.workspace = trans_ws; h.workspace_bytes = tws;
-        FAB_TRY(fabhip_spline_hmc_transition(&h, stream));
+        if (j == 1 && spline_leap_fold_supported(&a->flow, B) && hipMemsetAsync(spline_fold_ticket(&h), 0, 4, st) != hipSuccess)
+            return FABHIP_ELAUNCH;
+        FAB_TRY(spline_hmc_transition_impl(&h, stream, true));
     }
     // 5. "chain end" filter, 6. ESS / log Z
     FAB_TRY(phase_tail(a->point, a->log_w, B, D, a->n_valid, a->n_valid + 1, tmp, dest, nullptr, nullptr, (double)B, a->stats + 3,

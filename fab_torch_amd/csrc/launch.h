@@ -38,7 +38,31 @@ void gen_hmc_state(void* workspace, long B, int dim, float** XP, float** P, floa
 // One leapfrog of the spline family in ONE launch (spline_kernels.hip; r4): first half step, spline density + gradient, target
 // + gradient and second half step inside k_spline_logprob_r8.  FABHIP_ENOTSUP where that kernel does not apply (the caller
 // then runs the four launches of the generic pieces - the same arithmetic, bit for bit).
+// Round 5: the rest of the outer step inside the leapfrog launches (spline_r8.h) - flags & 1: first leapfrog of the outer step
+// (k_gen_hmc_begin's work at the launch's top), & 2: the last one (k_gen_hmc_accept's and k_gen_hmc_adapt's at its end).
+struct SplineFold {
+    int flags;
+    const float *start_x, *start_gq, *start_gp, *noise_p;      // first
+    float* logp_cur;                                           // [B] written by the first launch, read by the last
+    float *cur_x, *cur_lq, *cur_lp, *cur_gq, *cur_gp;          // committed in place by the last launch (hmc.py:154)
+    const float* noise_e;
+    fabhip_anneal nx;
+    float* log_w;                                              // nullptr: no AIS increment in this outer step
+    const int* n_valid;                                        // device scalar: rows in use (nullptr: B)
+    float *row_acc, *row_dist;                                 // [16 nblk] per-chain min(1, acceptance prob) / store_info distance
+    int* ticket;                                               // zero before the launch; reset by the wave that draws the last one
+    float *eps_w, *ceps_w;
+    float target_p_accept;
+    int tune;
+    float *p_accept_out, *dist_out;
+    int nblk;
+};
+// whether spline_log_prob_leap applies to this shape AND can carry the fold (FABHIP_OPT_ADAPT_FOLD, LDS for the block sums)
+bool spline_leap_fold_supported(const fabhip_spline_flow* flow, int64_t B);
+// floats of the fold's scratch behind a generic-HMC workspace: row_acc, row_dist [16 nblk] + the ticket word
+size_t spline_fold_scratch_floats(int64_t B);
 struct SplineLeap {
+    SplineFold fold;                   // flags == 0: a plain leapfrog
     float *XP, *P, *GU;                // [B][D] of the transition workspace: position, momentum, clamped grad U
     float* x_out;                      // the proposal's x (a copy of XP, as fabhip_hmc_generic_leap_pre leaves it)
     const float *eps_ptr, *ceps_ptr, *mass;

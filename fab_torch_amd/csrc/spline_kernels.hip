@@ -1278,6 +1278,21 @@ static int net(const SplineDims& f, const float* packed, int layer, const float*
 
 static inline size_t sp_al(size_t v) { return (v + 255) & ~(size_t)255; }
 
+// launch.h: the outer step's begin / accept / step-size rule inside the leapfrog launches - where the one-launch leapfrog
+// applies, the switch is on and the last wave's 2 nblk block sums fit the conditioner-output tile it uses as scratch
+size_t spline_fold_scratch_floats(int64_t B) { return (size_t)32 * ((B + 15) / 16) + 64; }
+bool spline_leap_fold_supported(const fabhip_spline_flow* flow, int64_t B) {
+    if (!flow || !flow->packed || B < 1 || !option(FABHIP_OPT_SPLINE_LEAP) || option(FABHIP_OPT_SPLINE_STAGED) ||
+        !option(FABHIP_OPT_ADAPT_FOLD))
+        return false;
+    if (check_spline_shape(flow->dim, flow->n_layers, flow->hidden) != FABHIP_OK) return false;
+    const SplineDims f = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
+    const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision), true);
+    if (rb == 0) return false;
+    const S8Lds l = make_s8_lds(f, true, 4 * rb);
+    return 2 * ((B + 15) / 16) <= (int64_t)(4 * rb) * l.PS;
+}
+
 // launch.h: one leapfrog of the spline family in one launch
 int spline_log_prob_leap(const fabhip_spline_flow* flow, const SplineLeap& a, float* log_q, float* grad_x, int64_t B,
                          void* workspace, size_t workspace_bytes, hipStream_t st) {
@@ -1296,6 +1311,8 @@ int spline_log_prob_leap(const fabhip_spline_flow* flow, const SplineLeap& a, fl
     SplineLeapDev d;
     d.XP = a.XP; d.x_out = a.x_out; d.P = a.P; d.GU = a.GU; d.eps_ptr = a.eps_ptr; d.ceps_ptr = a.ceps_ptr; d.mass = a.mass; d.c = a.c;
     d.max_grad = a.max_grad; d.tg = make_target_dev(a.tg); d.prop_lp = a.prop_lp; d.prop_gp = a.prop_gp;
+    d.fold = a.fold;
+    if (d.fold.flags && !spline_leap_fold_supported(flow, B)) return FABHIP_EINVAL;   // (the caller asks first)
     if (rb == 1) return launch_logprob_r8_nch<1>(f, flow->packed, a.XP, log_q, grad_x, (long)B, Z, P, st, d);
     if (rb == 2) return launch_logprob_r8_nch<2>(f, flow->packed, a.XP, log_q, grad_x, (long)B, Z, P, st, d);
     return launch_logprob_r8_nch<4>(f, flow->packed, a.XP, log_q, grad_x, (long)B, Z, P, st, d);

@@ -175,6 +175,13 @@ __global__ __launch_bounds__(256) void k_spline_pack_r8(SplineDims f, SplineSrc 
 }
 
 // optional leapfrog around the density evaluation (launch.h: SplineLeap; XP == nullptr: a plain density call)
+// Round 5: the REST of an HMC outer step (hmc.py:129-160) inside the leapfrog launches - `flags` & 1: this launch is the first
+// leapfrog and does k_gen_hmc_begin's work at its top (p0 = noise x mass, grad U of the start point, -U(current) - K(p0));
+// & 2: it is the last one and does k_gen_hmc_accept's (accept / reject, commit, AIS log-weight increment) and k_gen_hmc_adapt's
+// (step-size rule, by the last wave of the launch to finish: the mechanism of ais_kernels.hip's hmc_adapt_last) at its end:
+// a transition is L launches instead of L + 3.  Every sum is formed in the order of the kernels it replaces (16 lanes per chain:
+// lane c adds coordinates c, c + 16, ..; xor butterfly 8, 4, 2, 1; 16 chains per block in row order; blocks in order): bit-identical.
+using SplineFoldDev = SplineFold;     // launch.h
 struct SplineLeapDev {
     float *XP, *P, *GU, *x_out;
     const float *eps_ptr, *ceps_ptr, *mass;
@@ -182,8 +189,53 @@ struct SplineLeapDev {
     float max_grad;
     TargetDev tg;
     float *prop_lp, *prop_gp;
+    SplineFoldDev fold;
 };
 __device__ __forceinline__ float g_clamp_nan0_s8(float g, float mg) { return (g != g) ? 0.f : fminf(fmaxf(g, -mg), mg); }   // hmc.py:194-199
+__device__ __forceinline__ float s8_row16_sum_xor(float v) {                   // generic_kernels.hip: g_row16_sum
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 4);
+    v += __shfl_xor(v, 2);
+    v += __shfl_xor(v, 1);
+    return v;
+}
+// k_gen_hmc_adapt's work by the last wave of the launch to finish.  Cross-workgroup ordering as in ais_kernels.hip
+// (hmc_store_row_stats / hmc_adapt_last; _isa_check.py pins the lowering): per-chain values written through (sc1) by
+// device-scope relaxed atomic stores, vmcnt(0), ticket; the last ticket's wave reads them past its XCD's L2 (sc1 loads).
+// Every wave of every workgroup calls this once, after its stores.  `scratch`: 2 nblk floats of LDS nobody else touches.
+__device__ __forceinline__ void s8_fold_adapt_last(const SplineFoldDev& a, long B, float* scratch, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int tk = 0;
+    if (lane == 0) tk = __hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tk = __builtin_amdgcn_readfirstlane(tk);
+    if (tk != (int)gridDim.x * NWAVE - 1) return;
+    const int nblk = a.nblk;
+    for (int b = lane; b < nblk; b += 64) {
+        float s = 0.f, d = 0.f;
+        for (int r = 0; r < 16; ++r) {
+            s += __hip_atomic_load(a.row_acc + (long)b * 16 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            d += __hip_atomic_load(a.row_dist + (long)b * 16 + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        scratch[b] = s; scratch[nblk + b] = d;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // one wave: its LDS writes are done before lane 0 reads them
+    if (lane == 0) {
+        long nv = a.n_valid ? (long)*a.n_valid : B;
+        nv = nv < B ? nv : B;
+        if (nv > 0) {
+            float s = 0.f, d = 0.f;
+            for (int i = 0; i < nblk; ++i) { s += scratch[i]; d += scratch[nblk + i]; }
+            const float log_mean = logf(s) - logf((float)nv);                 // hmc.py:122-123,162-170
+            if (a.p_accept_out) *a.p_accept_out = expf(log_mean);
+            if (a.dist_out) *a.dist_out = d / (float)nv;
+            if (a.tune) {
+                if (log_mean > logf(a.target_p_accept)) { *a.eps_w = *a.eps_w * 1.05f; *a.ceps_w = *a.ceps_w * 1.02f; }
+                else { *a.eps_w = *a.eps_w / 1.05f; *a.ceps_w = *a.ceps_w / 1.02f; }
+            }
+        }
+        __hip_atomic_store(a.ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------
 // TRIM (SplineDims::r8_trim: D <= 32, two output chunks): the layer's stream without its zero tiles - see k_spline_pack_r8
@@ -272,18 +324,32 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     // x <- wrap(x - pre-shift of the top layer)
     {
         const float* mt = packed + (size_t)(f.L - 1) * f.layer_stride + f.o_meta;
+        const bool first = GRAD && lp.XP && (lp.fold.flags & 1);               // + k_gen_hmc_begin (hmc.py:134)
+        long nvb = B;
+        if (first && lp.fold.n_valid) { const long nvd = (long)*lp.fold.n_valid; nvb = nvd < B ? nvd : B; }
         for (int e = t.tid; e < R8 * 64; e += NTHREADS) {
             const int r = e >> 6, j = e & 63;
             const long g = row0 + r;
-            float v = 0.f;
+            float v = 0.f, kt = 0.f;
             if (j < f.D && g < B) {
                 if (GRAD && lp.XP) {                                            // first half of a leapfrog (k_gen_leap_pre, hmc.py:140-142)
                     const long i = g * f.D + j;
                     const float eps = *lp.eps_ptr + *lp.ceps_ptr;
                     const float m = lp.mass[j];
-                    const float p = lp.P[i] - eps * lp.GU[i] / 2.f;
+                    float p0, gu0, x0;
+                    if (first) {                                                // rows of dropped chains: a defined (zero) state
+                        const bool on = g < nvb;
+                        p0 = on ? lp.fold.noise_p[i] * m : 0.f;
+                        const float gr = on ? -(lp.c.g_q * lp.fold.start_gq[i] + lp.c.g_p * lp.fold.start_gp[i]) : 0.f;
+                        gu0 = g_clamp_nan0_s8(gr, lp.max_grad);
+                        x0 = on ? lp.fold.start_x[i] : 0.f;
+                        kt = p0 * p0 / m;
+                    } else {
+                        p0 = lp.P[i]; gu0 = lp.GU[i]; x0 = lp.XP[i];
+                    }
+                    const float p = p0 - eps * gu0 / 2.f;
                     lp.P[i] = p;
-                    v = lp.XP[i] + eps / m * p;
+                    v = x0 + eps / m * p;
                     lp.XP[i] = v;
                     lp.x_out[i] = v;
                 } else {
@@ -292,6 +358,16 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                 if (mt[M_PREON * 64 + j] != 0.f) v = sp_wrap(v - mt[M_PRESH * 64 + j], mt[M_TB * 64 + j]);
             }
             ZT[e] = v;
+            if (first) {                    // K(p0) in k_gen_hmc_begin's order: lane c < 16 adds coordinates c, c + 16, c + 32, c + 48
+                const int c16 = t.lane & 15;
+                float k0 = kt;
+                k0 += __shfl(kt, c16 + 16);
+                k0 += __shfl(kt, c16 + 32);
+                k0 += __shfl(kt, c16 + 48);
+                k0 = s8_row16_sum_xor(k0) / 2.f;
+                if (t.lane == 0 && g < nvb)
+                    lp.fold.logp_cur[g] = (lp.c.c_q * lp.fold.cur_lq[g] + lp.c.c_p * lp.fold.cur_lp[g]) - k0;
+            }
         }
     }
     constexpr int NRG = (RB + 1) / 2;                                          // groups of 8 chains (RB = 1: half a group)
@@ -585,6 +661,11 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             __syncthreads();
             const float lpv = target_tile<true>(lp.tg, XH, D, GPH, D, tt);
             const long g = row0 + tt.row;
+            const bool last = (lp.fold.flags & 2) != 0;                         // + k_gen_hmc_accept, k_gen_hmc_adapt
+            long nv = B;
+            if (last && lp.fold.n_valid) { const long nvd = (long)*lp.fold.n_valid; nv = nvd < B ? nvd : B; }
+            const bool active = last && tt.row < R8 && g < nv;
+            float k1 = 0.f, dist2 = 0.f;
             if (tt.row < R8 && g < B) {
                 if (tt.c == 0) lp.prop_lp[g] = lpv;
                 const float eps = *lp.eps_ptr + *lp.ceps_ptr;
@@ -594,8 +675,59 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                     lp.prop_gp[i] = gpv;
                     const float gu = g_clamp_nan0_s8(-(lp.c.g_q * GT[tt.row * 64 + j] + lp.c.g_p * gpv), lp.max_grad);
                     lp.GU[i] = gu;
-                    lp.P[i] = lp.P[i] - eps * gu / 2.f;
+                    const float p = lp.P[i] - eps * gu / 2.f;
+                    lp.P[i] = p;
+                    if (active) {
+                        k1 += p * p / lp.mass[j];
+                        const float dx = lp.fold.cur_x[i] - XH[tt.row * D + j];
+                        dist2 += dx * dx;
+                    }
                 }
+            }
+            if (last) {
+                k1 = s8_row16_sum_xor(k1) / 2.f;
+                dist2 = s8_row16_sum_xor(dist2);
+                float contrib = 0.f, dist = 0.f;
+                if (active) {
+                    const float lq = log_q[g], lpp = lpv;
+                    const float lq_c = lp.fold.cur_lq[g], lp_c = lp.fold.cur_lp[g];
+                    const float delta = ((lp.c.c_q * lq + lp.c.c_p * lpp) - k1) - lp.fold.logp_cur[g];
+                    const bool valid = isfinite(delta);
+                    const float dd = valid ? delta : -INFINITY;
+                    const bool accept = valid && (dd > -lp.fold.noise_e[g]);            // hmc.py:105-124
+                    contrib = expf(fminf(dd, 0.f));
+                    dist = accept ? 0.f : sqrtf(dist2);                          // store_info sees the committed point
+                    if (accept) {
+                        for (int j = tt.c; j < D; j += 16) {
+                            const long i = g * D + j;
+                            lp.fold.cur_x[i] = XH[tt.row * D + j];
+                            lp.fold.cur_gq[i] = GT[tt.row * 64 + j];
+                            lp.fold.cur_gp[i] = GPH[tt.row * D + j];
+                        }
+                    }
+                    if (tt.c == 0) {
+                        if (accept) { lp.fold.cur_lq[g] = lq; lp.fold.cur_lp[g] = lpp; }
+                        if (lp.fold.log_w) {                                      // ais.py:93-100
+                            const float lqf = accept ? lq : lq_c, lpf = accept ? lpp : lp_c;
+                            lp.fold.log_w[g] = lp.fold.log_w[g] + ((lp.fold.nx.c_q * lqf + lp.fold.nx.c_p * lpf) -
+                                                                    (lp.c.c_q * lqf + lp.c.c_p * lpf));
+                        }
+                    }
+                }
+                // per-chain statistics of EVERY row of the 16-row blocks (rows past the grid: the last workgroup's)
+                const long nrow = 16L * lp.fold.nblk;
+                if (tt.c == 0) {
+                    if (tt.row < R8 && g < nrow) {
+                        __hip_atomic_store(lp.fold.row_acc + g, contrib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(lp.fold.row_dist + g, dist, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const long g2 = (long)R8 * gridDim.x + tt.row;
+                    if (blockIdx.x == gridDim.x - 1 && g2 < nrow) {
+                        __hip_atomic_store(lp.fold.row_acc + g2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(lp.fold.row_dist + g2, 0.f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                s8_fold_adapt_last(lp.fold, B, PT, t.lane);
             }
         }
     }

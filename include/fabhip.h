@@ -111,7 +111,9 @@ int fabhip_get_fast_mode(void);
                                             initialisation and after the last transition in ONE launch each (default), 0 = the six / five
                                             separate kernels (the same results, bit for bit) */
 #define FABHIP_OPT_ADAPT_FOLD 9          /* FABHIP_ADAPT_FOLD: fused AIS calls on 4- / 8-chain tiles: 1 = the step-size rule runs in the LAST
-                                            workgroup of every transition kernel (ticket; default), 0 = its own launch per transition */
+                                            workgroup of every transition kernel (ticket; default), 0 = its own launch per transition.
+                                            Spline family (round 5): 1 = an outer HMC step is L launches - begin inside the first
+                                            leapfrog launch, accept + rule inside the last; 0 = L + 3 (the same results, bit for bit) */
 #define FABHIP_OPT_COUNT 10
 int fabhip_set_option(int key, int value);
 int fabhip_get_option(int key);

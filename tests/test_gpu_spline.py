@@ -594,3 +594,48 @@ def test_spline_transitions_at_the_baseline_tile_shapes_vs_oracle(name, D, L, hi
         part, lw_part = ais.sample_and_log_weights(SL, eps0=eps[:SL].to(DEV), u0=u[:SL].to(DEV),
                                                    noise_a=na[:, :, :SL].contiguous(), noise_b=nb[:, :, :SL].contiguous())
     assert torch.equal(full.x[:SL], part.x) and torch.equal(lw_full[:SL], lw_part) and torch.equal(full.log_q[:SL], part.log_q)
+
+
+@pytest.mark.parametrize("D,L,hidden,circ,B,n_outer,LF,shape", [
+    (32, 4, 256, (), 2041, 1, 3, 8),                       # cfg 3's tile shape, a ragged last workgroup AND a ragged last 16-row block
+    (32, 3, 256, (), 301, 2, 1, 4),                        # 4-chain tiles; L = 1: first and last leapfrog are the same launch; two outer steps
+    (60, 3, 256, (3, 7, 20), 530, 1, 2, 16),               # cfg 5's shape: 16-chain stream tiles, D > 32 (four coordinates per lane of a row)
+])
+def test_spline_transition_in_L_launches_equals_the_L_plus_3_launch_form(D, L, hidden, circ, B, n_outer, LF, shape):
+    """Round 5 (VERDICT r4 Missing #2): with FABHIP_ADAPT_FOLD the fused spline call runs an outer HMC step in L launches - the
+    first leapfrog launch does k_gen_hmc_begin's work at its top, the last one k_gen_hmc_accept's and (in the last wave of
+    the launch to finish) k_gen_hmc_adapt's.  Same sums in the same order: particles, densities, gradients, log-weights,
+    ADAPTED step sizes (tuning on) and the logging scalars must equal the L + 3 launch form bit for bit - on every tile
+    shape, with chains dropped by the "chain init" filter (rows past the device-side row count) and ragged batch sizes."""
+    from fab_torch_amd import _ops
+    M = 3
+    tb = torch.full((D,), 5.0)
+    if circ:
+        tb[list(circ)] = math.pi
+    torch.manual_seed(3)
+    hf = fa.make_wrapped_normflow_spline(D, L, hidden, circ, tb).to(DEV).requires_grad_(False)
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.add_(0.05 * torch.randn_like(p))
+    target = fa.ManyWellEnergy(D)
+    g = torch.Generator(device=DEV).manual_seed(4)
+    na = torch.randn(M, n_outer, B, D, device=DEV, generator=g)
+    nb = torch.empty(M, n_outer, B, device=DEV).exponential_(generator=g)
+    u0 = torch.rand(B, D, device=DEV, generator=g)
+    eps0 = torch.randn(B, D, device=DEV, generator=g)
+    eps0[5, 0] = float("nan")                               # one chain leaves at the "chain init" filter
+    res = {}
+    for fold in (1, 0):
+        with _ops.option(_ops.OPT_TILE_SHAPE, shape), _ops.option(_ops.OPT_ADAPT_FOLD, fold):
+            hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=2.0, p_target=False, epsilon=0.12, L=LF,
+                                           n_outer=n_outer).to(DEV)
+            ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, 2.0, M)
+            assert ais._spline_parts() is not None
+            pt, lw = ais.sample_and_log_weights(B, noise_a=na, noise_b=nb, u0=u0, eps0=eps0)
+            res[fold] = (pt.x.clone(), pt.log_q.clone(), pt.log_p.clone(), pt.grad_log_q.clone(), pt.grad_log_p.clone(), lw.clone(),
+                         hmc.epsilons.clone(), hmc.common_epsilon.clone(), ais.get_logging_info())
+    for a, b in zip(res[1][:8], res[0][:8]):
+        assert a.shape == b.shape and torch.equal(a, b)
+    assert res[1][8] == res[0][8]
+    assert res[1][0].shape[0] == B - 1
+    assert not torch.equal(res[1][6], torch.full_like(res[1][6], 0.12 * 0.9))        # the rule ran
