@@ -16,6 +16,7 @@ python tools/time_hmc_shapes.py 2>/dev/null | grep "W=" > $O/hmc_tile_shapes.txt
 python tools/timeline_r8.py 2048 2>/dev/null | tail -11 > $O/hmc_r8f_stage_timeline.txt
 (echo "--- unfused (FABHIP_R4_STREAM=1) ---"; FABHIP_R4_STREAM=1 python tools/timeline_r8.py 2048 2>/dev/null | tail -13) >> $O/hmc_r8f_stage_timeline.txt
 timeout 300 python tools/bench_spline.py 2>/dev/null | tail -1 > $O/spline_cfg3.json
+timeout 300 python tools/timeline_spline.py 2>/dev/null | tail -13 > $O/spline_r8_stage_timeline.txt
 CFG=5 N=3 timeout 300 python tools/bench_spline.py 2>/dev/null | tail -1 > $O/spline_cfg5_shape.json
 bash tools/pmc_stream_kernels.sh > $O/pmc_stream.log 2>&1
 cp gpurun_out/pmc_stream_hmc/summary.json $O/hmc_step_r8_pmc_summary.json; cp gpurun_out/pmc_stream_spline/summary.json $O/spline_r8_pmc_summary.json
