@@ -7,6 +7,7 @@
 // region) or interleaved tile by tile, 0 or 2 workgroup barriers per stage of NT tiles.
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -135,6 +136,15 @@ static void run(const char* src, size_t region, int n_wg, float* sink, long long
     }
     mean /= n_wg;
     const double tiles_simd = (double)n_stages * NT * (NW / 4);
+    if (getenv("PER_WAVE")) {            // round 5: is the L2 -> CU service of the waves of a workgroup systematically uneven?
+        printf("   per-wave cycles / 1000 (mean over workgroups; min .. max over workgroups):");
+        for (int w = 0; w < NW; ++w) {
+            double m = 0; long long lo = h[w], hi = h[w];
+            for (int g = 0; g < n_wg; ++g) { const long long v = h[(size_t)g * NW + w]; m += (double)v; lo = v < lo ? v : lo; hi = v > hi ? v : hi; }
+            printf("  w%d %.0f (%.0f..%.0f)", w, m / n_wg / 1e3, lo / 1e3, hi / 1e3);
+        }
+        printf("\n");
+    }
     printf("NW=%d RD=%2d burst=%d%s RB=%d dst=%s addr=%s layout=%s sync=%d NT=%3d: %6.1f cycles per tile and SIMD  %5.1f B/clk/CU  (MFMA floor %d)\n",
            NW, RD, B, ILV ? " (1/tile)" : "", RB, AREG ? "a" : "v", VADDR ? "vaddr" : "saddr", LAYOUT ? "interleaved" : "apart", SYNC, NT,
            mean / tiles_simd, tiles_simd * 4 * 1024 / mean, 32 * RB);
@@ -170,6 +180,15 @@ int main() {
     run<8, 24, 8, 1, 1, 0, 0, 2, 48, 1>(src, region, W, sink, cyc);
     run<8, 24, 8, 1, 1, 0, 0, 2, 48, 0>(src, region, W, sink, cyc);
     run<8, 16, 8, 1, 1, 0, 0, 0, 48, 1>(src, region, W, sink, cyc);
+    printf("-- round 5: the free-running winners WITH two workgroup barriers per stage (a product stage ends in a partial-sum exchange)\n");
+    run<4, 32, 1, 1, 1, 0, 0, 2, 96, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 0, 0, 0, 2, 96, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 1, 0, 0, 2, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 2, 48, 0>(src, region, W, sink, cyc);
+    run<8, 16, 1, 1, 0, 0, 0, 2, 48, 0>(src, region, W, sink, cyc);
+    run<8, 12, 1, 1, 0, 0, 0, 2, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 2, 24, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 0, 48, 0>(src, region, W, sink, cyc);
     printf("-- 8 chains (RB 2)\n");
     run<4, 32, 1, 2, 1, 0, 0, 0, 96, 0>(src, region, W, sink, cyc);
     run<4, 32, 8, 2, 1, 0, 0, 0, 96, 0>(src, region, W, sink, cyc);
