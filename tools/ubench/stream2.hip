@@ -33,15 +33,48 @@ template <int AREG, int N> __device__ __forceinline__ void wait_for(f32x4& r) {
 }
 
 template <int NW, int RD, int B, int RB, int AREG, int VADDR, int ILV, int SYNC, int NT, int LAYOUT>
-__global__ __launch_bounds__(64 * NW) void k_stream2(const char* __restrict__ src, size_t wave_off, int n_stages,
-                                                      float* __restrict__ sink, long long* __restrict__ cycles) {
+__global__ __launch_bounds__(64 * (NW + (SYNC >= 20 ? 1 : 0))) void k_stream2(const char* __restrict__ src, size_t wave_off, int n_stages,
+                                                      float* __restrict__ sink, long long* __restrict__ cycles, int getwait = 0, int wrap_stages = 0, int pf_ahead = 1, int pf_on = 1) {
     static_assert(RD % B == 0 && NT % RD == 0 && RD <= 63, "static slots");
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int WS = 4 * NT + 4;
     constexpr size_t tile_stride = LAYOUT ? (size_t)NW * 1024 : 1024;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     for (int e = tid; e < 8 * WS; e += 64 * NW) lds[e] = 0.001f * (float)(e % 97);
+    if (tid < 8) reinterpret_cast<int*>(lds + 8 * WS)[tid] = 0;
     __syncthreads();
+    // SYNC 20 / 21 / 22 (round 5): two barriers per stage AND one more wave per workgroup that only PREFETCHES - it touches the
+    // 128-byte lines the compute waves will request one stage later (one dword per line and lane: 8 KiB of lines per
+    // instruction; nothing is waited for), 1 / 32, 1 / 8 or all of them (the 32 CUs of an XCD share its L2 and run in step),
+    // and joins the stage's barriers, which is all the pacing it needs
+    if constexpr (SYNC >= 20) {
+        if (wave == NW) {
+            constexpr int S = SYNC == 20 ? 32 : (SYNC == 21 ? 8 : 1);
+            constexpr int CH = NW * NT / 8;                         // chunks of 64 lines per stage
+            const int share = (blockIdx.x >> 3) % S;
+            constexpr int CW = (CH + S - 1) / S;                    // chunks of this workgroup per stage
+            float pend[CW], keep = 0.f;                             // compiler-tracked loads, consumed one stage later (long landed)
+#pragma unroll
+            for (int i = 0; i < CW; ++i) pend[i] = 0.f;
+            for (int st = 0; st < n_stages; ++st) {
+#pragma unroll
+                for (int i = 0; i < CW; ++i) keep += pend[i];
+#pragma unroll
+                for (int i = 0; i < CW; ++i) {
+                    const int c = share + i * S;
+                    const int cl = c < CH ? c : CH - 1;
+                    const int w = cl / (NT / 8), cc = cl % (NT / 8);
+                    const char* p = src + (size_t)w * wave_off + ((size_t)RD + (size_t)(st + pf_ahead) * NT) * 1024 + (size_t)cc * 8192 + lane * 128;
+                    if (pf_on) pend[i] = *reinterpret_cast<const float*>(p);
+                }
+                lds_barrier(); lds_barrier();
+            }
+#pragma unroll
+            for (int i = 0; i < CW; ++i) keep += pend[i];
+            sink[blockIdx.x * 64 * (NW + 1) + tid] = keep;
+            return;
+        }
+    }
     const char* sb = src + (size_t)wave * wave_off;                 // tile t of this wave: sb + t * tile_stride (+ lane * 16)
     const unsigned voff = lane * 16;
     f32x4 ring[RD];
@@ -56,6 +89,8 @@ __global__ __launch_bounds__(64 * NW) void k_stream2(const char* __restrict__ sr
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) acc[k][rb] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const float* ap = lds + (lane & 3) * WS;
+    long long twait = 0;
+    if constexpr (SYNC == 13) { if (wave >= 4) __builtin_amdgcn_s_setprio(3); }   // the second wave of every SIMD at the highest priority
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int st = 0; st < n_stages; ++st) {
         float4 an[RB];
@@ -100,7 +135,48 @@ __global__ __launch_bounds__(64 * NW) void k_stream2(const char* __restrict__ sr
             }
         });
         sb += (size_t)NT * tile_stride;
+        // WRAP_STAGES (round 5): the wave re-reads the same few stages - a working set that stays in the XCD's L2 (no first-touch misses)
+        if (wrap_stages && (st + 1) % wrap_stages == 0) sb -= (size_t)wrap_stages * NT * tile_stride;
         if constexpr (SYNC == 2) { lds_barrier(); lds_barrier(); }
+        if constexpr (SYNC >= 20) { lds_barrier(); lds_barrier(); }
+        if constexpr (SYNC == 3) { lds_barrier(); }                                            // one barrier per stage
+        if constexpr (SYNC == 4) { lds_barrier(); lds_barrier(); if (wave >= 4) __builtin_amdgcn_s_sleep(1); }   // partner waves restart 64 cycles later
+        if constexpr (SYNC == 5) {                                                             // two barriers, time spent in them accounted
+            const long long b0 = __builtin_amdgcn_s_memtime();
+            lds_barrier(); lds_barrier();
+            twait += __builtin_amdgcn_s_memtime() - b0;
+        }
+        if constexpr (SYNC == 7) {                                                             // software barrier (LDS counter + s_sleep) instead of s_barrier
+            volatile int* bar = reinterpret_cast<volatile int*>(lds + 8 * WS);
+            if (lane == 0) {
+                __hip_atomic_fetch_add((int*)bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (*bar < NW * (st + 1)) __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (SYNC == 8 || SYNC == 9) {                                                // software barriers over SUBSETS of the waves:
+            // 8: the two waves of a SIMD {w, w + 4}; 9: the first waves of the SIMDs {0..3} and the second waves {4..7} separately
+            volatile int* bar = reinterpret_cast<volatile int*>(lds + 8 * WS) + 1 + (SYNC == 8 ? (wave & 3) : (wave >> 2));
+            constexpr int NMEM = SYNC == 8 ? 2 : 4;
+            if (lane == 0) {
+                __hip_atomic_fetch_add((int*)bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                while (*bar < NMEM * (st + 1)) __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if constexpr (SYNC == 12) {                                                            // two barriers, arrival / departure stamps of workgroup 0
+            const long long b0 = __builtin_amdgcn_s_memtime();
+            lds_barrier(); lds_barrier();
+            const long long b1 = __builtin_amdgcn_s_memtime();
+            if (blockIdx.x == 0 && lane == 0 && st < 16) { cycles[4096 + (st * 8 + wave) * 2] = b0 - t0; cycles[4096 + (st * 8 + wave) * 2 + 1] = b1 - t0; }
+        }
+        if constexpr (SYNC == 13 || SYNC == 14) {                                              // two barriers + s_setprio
+            lds_barrier(); lds_barrier();
+            if constexpr (SYNC == 14) {                                                        // the favoured wave of a SIMD alternates per stage
+                if (((st & 1) ^ (wave >> 2)) != 0) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+            }
+        }
+        if constexpr (SYNC == 6) { lds_barrier(); lds_barrier(); if (wave >= 4) __builtin_amdgcn_s_sleep(8); }   // ... 512 cycles later
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
     float s = 0.f;
@@ -110,7 +186,7 @@ __global__ __launch_bounds__(64 * NW) void k_stream2(const char* __restrict__ sr
 #pragma unroll
         for (int rb = 0; rb < RB; ++rb) s += acc[k][rb][0] + acc[k][rb][1] + acc[k][rb][2] + acc[k][rb][3];
     sink[blockIdx.x * 64 * NW + tid] = s;
-    if (lane == 0) cycles[blockIdx.x * NW + wave] = t1 - t0;
+    if (lane == 0) cycles[blockIdx.x * NW + wave] = SYNC == 5 && getwait ? twait : t1 - t0;
 }
 
 // LAYOUT 0: every wave its own contiguous region; 1: the waves' tiles interleaved (tile t of wave w at (t NW + w) KiB)
@@ -119,11 +195,12 @@ static void run(const char* src, size_t region, int n_wg, float* sink, long long
     const size_t wave_bytes = region / NW;
     const int n_stages = (int)(wave_bytes / 1024 / NT) - 1;
     auto kern = k_stream2<NW, RD, B, RB, AREG, VADDR, ILV, SYNC, NT, LAYOUT>;
-    const size_t lds = (size_t)8 * (4 * NT + 4) * 4;
+    const size_t lds = (size_t)8 * (4 * NT + 4) * 4 + 64;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const size_t wave_off = LAYOUT ? 1024 : wave_bytes;
     for (int rep = 0; rep < 3; ++rep)
-        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64 * NW), lds, 0, src, wave_off, n_stages, sink, cyc);
+        hipLaunchKernelGGL(kern, dim3(n_wg), dim3(64 * (NW + (SYNC >= 20 ? 1 : 0))), lds, 0, src, wave_off, n_stages, sink, cyc, getenv("GETWAIT") ? 1 : 0, getenv("WRAP_STAGES") ? atoi(getenv("WRAP_STAGES")) : 0,
+                           getenv("PF_AHEAD") ? atoi(getenv("PF_AHEAD")) : 1, getenv("PF_OFF") ? 0 : 1);
     hipError_t e = hipDeviceSynchronize();
     if (e != hipSuccess) { printf("failed: %s\n", hipGetErrorString(e)); return; }
     std::vector<long long> h((size_t)n_wg * NW);
@@ -136,6 +213,16 @@ static void run(const char* src, size_t region, int n_wg, float* sink, long long
     }
     mean /= n_wg;
     const double tiles_simd = (double)n_stages * NT * (NW / 4);
+    if (SYNC == 12) {
+        std::vector<long long> st((size_t)16 * 8 * 2);
+        (void)hipMemcpy(st.data(), cyc + 4096, st.size() * 8, hipMemcpyDeviceToHost);
+        printf("   workgroup 0, per stage: arrival at / departure from the barriers (cycles since start), waves 0 1 | 4 5\n");
+        for (int s_ = 0; s_ < 8; ++s_) {
+            printf("   stage %d:", s_);
+            for (int w : {0, 1, 4, 5}) if (w < NW) printf("  w%d %lld/%lld", w, st[(s_ * 8 + w) * 2], st[(s_ * 8 + w) * 2 + 1]);
+            printf("\n");
+        }
+    }
     if (getenv("PER_WAVE")) {            // round 5: is the L2 -> CU service of the waves of a workgroup systematically uneven?
         printf("   per-wave cycles / 1000 (mean over workgroups; min .. max over workgroups):");
         for (int w = 0; w < NW; ++w) {
@@ -189,6 +276,37 @@ int main() {
     run<8, 12, 1, 1, 0, 0, 0, 2, 48, 0>(src, region, W, sink, cyc);
     run<8, 24, 1, 1, 0, 0, 0, 2, 24, 0>(src, region, W, sink, cyc);
     run<8, 24, 1, 1, 0, 0, 0, 0, 48, 0>(src, region, W, sink, cyc);
+    printf("-- one barrier per stage / partner waves delayed after the barriers / time inside the barriers (GETWAIT=1: the per-wave figures are that time)\n");
+    run<8, 24, 1, 1, 0, 0, 0, 3, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 4, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 6, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 5, 48, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 1, 0, 0, 5, 96, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 2, 192, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 7, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 12, 48, 0>(src, region, W, sink, cyc);
+    printf("-- a prefetch wave (sync 20 / 21 / 22: it touches 1/32, 1/8, all of next stage's lines)\n");
+    run<4, 24, 1, 1, 1, 0, 0, 2, 96, 0>(src, region, W, sink, cyc);      // (ring of 24: five waves of <= 256 registers without spills)
+    run<4, 24, 1, 1, 1, 0, 0, 20, 96, 0>(src, region, W, sink, cyc);
+    run<4, 24, 1, 1, 1, 0, 0, 21, 96, 0>(src, region, W, sink, cyc);
+    run<4, 16, 1, 1, 1, 0, 0, 2, 96, 0>(src, region, W, sink, cyc);
+    run<4, 16, 1, 1, 1, 0, 0, 20, 96, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 1, 0, 0, 20, 96, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 1, 0, 0, 21, 96, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 1, 0, 0, 22, 96, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 1, 0, 0, 2, 96, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 21, 48, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 2, 1, 0, 0, 21, 96, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 2, 1, 0, 0, 2, 96, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 2, 48, 1>(src, region, W, sink, cyc);     // interleaved layout with barriers
+    run<8, 24, 1, 1, 0, 0, 0, 0, 48, 1>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 1, 0, 0, 2, 96, 1>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 13, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 14, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 8, 48, 0>(src, region, W, sink, cyc);
+    run<8, 24, 1, 1, 0, 0, 0, 9, 48, 0>(src, region, W, sink, cyc);
+    run<4, 32, 1, 1, 1, 0, 0, 7, 96, 0>(src, region, W, sink, cyc);
+    if (getenv("ONLY_R5")) return 0;
     printf("-- 8 chains (RB 2)\n");
     run<4, 32, 1, 2, 1, 0, 0, 0, 96, 0>(src, region, W, sink, cyc);
     run<4, 32, 8, 2, 1, 0, 0, 0, 96, 0>(src, region, W, sink, cyc);
