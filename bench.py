@@ -472,11 +472,13 @@ def main():
             stream = per_pair * K_LAYERS * L
             clk = 2.09e9                                     # shader clock under this kernel (s_memtime stamps against HIP events)
             roof["weight_stream"] = {"bytes_per_workgroup_per_launch": stream, "GBps_per_cu": stream / t_kernel / 1e9,
-                                     "B_per_clk_per_cu": stream / t_kernel / clk, "path_B_per_clk_per_cu": 52.0,
-                                     "frac_of_path": stream / t_kernel / clk / 52.0,
-                                     "note": "tools/ubench/nsplit.hip: the L2 -> CU path delivers ~52 B/clk per CU to 256 workgroups "
-                                             "streaming the same image (~110 GB/s at the ~2.1 GHz the kernel runs at); "
-                                             "DESIGN.md section 4"}
+                                     "B_per_clk_per_cu": stream / t_kernel / clk, "path_B_per_clk_per_cu": 58.0,
+                                     "frac_of_path": stream / t_kernel / clk / 58.0,
+                                     "note": "tools/ubench/stream2.hip (profiles/r5/ubench_stream2_prefetch.txt): a stage-synchronised "
+                                             "4-wave stream of this shape pulls 58 B/clk per CU from a resident L2 and 46.5 when "
+                                             "every line is its XCD's first touch, as in this kernel (47.9 MB through a 4 MB L2 "
+                                             "per evaluation); the kernel prefetches its stream into the L2 (DESIGN.md section 9 "
+                                             "item 1); over the whole launch incl. the short stages"}
         # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes restricted to this kernel
         # (tools/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed summary
         for path in ((os.path.join("profiles", "r5", "hmc_step_r4_traffic_pmc_summary.json"),) if r4 else

@@ -306,6 +306,9 @@ int main() {
     run<8, 24, 1, 1, 0, 0, 0, 8, 48, 0>(src, region, W, sink, cyc);
     run<8, 24, 1, 1, 0, 0, 0, 9, 48, 0>(src, region, W, sink, cyc);
     run<4, 32, 1, 1, 1, 0, 0, 7, 96, 0>(src, region, W, sink, cyc);
+    printf("-- 16 chains per workgroup (RB 4), with two barriers per stage: is the 16-chain shape sensitive to L2 first touches? (WRAP_STAGES)\n");
+    run<4, 24, 1, 4, 1, 0, 0, 2, 96, 0>(src, region, W, sink, cyc);
+    run<4, 24, 1, 4, 1, 0, 0, 0, 96, 0>(src, region, W, sink, cyc);
     if (getenv("ONLY_R5")) return 0;
     printf("-- 8 chains (RB 2)\n");
     run<4, 32, 1, 2, 1, 0, 0, 0, 96, 0>(src, region, W, sink, cyc);
