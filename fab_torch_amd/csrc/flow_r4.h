@@ -52,6 +52,7 @@ struct R4Lds {
     int WS, PN;                        // leading dims: hidden activations, partial products
     int o_X0, o_X1, o_HA, o_HB, o_PRM, o_DP, o_PART, o_ES, o_V2, o_MASK, total;
     int o_PZ, o_BIAS;                  // fused stages (flow_r4f.h): partials of the dense narrow products, bias blocks of all layers
+    int o_PF;                          // ... and 256 bytes per wave that the L2 prefetch's LDS-DMA loads land in (never read)
 };
 
 FAB_HD R4Lds make_r4_lds(const FlowDims& f, bool fused = false) {
@@ -71,11 +72,13 @@ FAB_HD R4Lds make_r4_lds(const FlowDims& f, bool fused = false) {
     l.o_ES = o; o += f.K * R4 * f.DOp;
     l.o_V2 = o; o += f.K * R4 * f.DOp;
     l.o_MASK = o; o += f.K * 2 * NTHREADS;
-    l.o_PZ = l.o_BIAS = 0;
+    l.o_PZ = l.o_BIAS = l.o_PF = 0;
     if (fused) {
         o = (o + 3) & ~3;
         l.o_PZ = o; o += 2 * NWAVE * R4 * 32;
         l.o_BIAS = o; o += (f.K + 1) * r4f_bias_stride(f.Wp);
+        o = (o + 3) & ~3;
+        l.o_PF = o; o += NWAVE * 64;
     }
     l.total = (o + 3) & ~3;
     return l;

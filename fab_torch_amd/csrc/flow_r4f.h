@@ -459,27 +459,36 @@ __device__ __forceinline__ void r4f_narrow_mma(const float* act, int lda, Ring& 
 // launch streams pass through every XCD's 4 MB L2 once per evaluation: the 32 workgroups of an XCD run in step, the first one
 // to ask for a line misses (MALL / HBM, ~1.3 us) and the other 31 queue on that pending fill - a stage-synchronised 4-wave
 // stream of this shape runs at 88 cycles per 1-KiB tile and SIMD on such data and at 70.5 when the data already sits in the L2.
-// So each workgroup TOUCHES its share of the lines of a layer slot AHEAD slots before the stream gets there: one
-// global_load_dword per wave and slot, lane -> one 128-byte line (line j + 16 (64 wave + lane) of the slot, j = the workgroup's
-// index on its XCD mod 16: every line has two workgroups that ask for it), destination a register nobody reads - in the
-// micro-benchmark 88.2 -> 75.7 cycles per tile with a fifth wave doing it; here the four waves do it themselves, right behind
-// the last request of the slot's first short stage: loads return in order, so the ring items requested behind a prefetch
-// wait for it, and at that point the next ring item is not needed for ~3 k cycles (the stage's epilogue + four W x W items).
-// The hand-counted waits stay valid: another load in the queue only makes them conservative.
+// So each workgroup TOUCHES its share of the lines of a layer slot AHEAD slots before the stream gets there: one load per
+// wave and slot, lane -> one 128-byte line (line j + 32 (64 wave + lane) of the slot, j = the workgroup's index on its XCD:
+// the 32 workgroups of an XCD cover every line once; waves whose lines all lie past the slot's end skip it) - in the
+// micro-benchmark 88.2 -> 75.7 cycles per tile with a fifth wave doing it; here the waves do it themselves, right behind the
+// last request of the slot's first short stage: loads return in order, so the ring items requested behind a prefetch wait
+// for it, and at that point the next ring item is not needed for ~3 k cycles (the stage's epilogue + four W x W items).
+// The load is an LDS-DMA (global_load_lds_dword: the dwords land in 256 bytes of junk LDS of this wave): it has NO destination
+// register.  (First version: a global_load_dword into an accumulation register nobody reads - measured the same, but hipcc is
+// free to move such a register while the load is in flight, and did so in two other instantiations: the build's ISA check
+// refused them.)  The hand-counted waits stay valid: another load in the queue only makes them conservative.
 #ifndef FAB_R4F_PF_AHEAD
 #define FAB_R4F_PF_AHEAD 2             // slots ahead (1 and 2 measure alike: 0.511 ms per transition against 0.570 without; 2 leaves
                                        // more room for workgroups of an XCD that have drifted apart); 0 = no prefetch
 #endif
 template <int TL>
-__device__ __forceinline__ void r4f_prefetch_l2(float& sink, const char* img, int slot, int nslots, const Tid4& t) {
+__device__ __forceinline__ void r4f_prefetch_l2(const float* junk, const char* img, int slot, int nslots, const Tid4& t) {
     if constexpr (FAB_R4F_PF_AHEAD > 0) {
         constexpr unsigned NL = (unsigned)TL * 32u;                // 128-byte lines of a slot (TL tiles x 4 waves x 1 KiB)
+        if (2048u * (unsigned)t.wave >= NL) return;                // (wave-uniform)
         int ts = slot + FAB_R4F_PF_AHEAD;
         ts = ts >= nslots ? ts - nslots : ts;                      // (the next evaluation starts at slot 0 again)
-        unsigned line = ((blockIdx.x >> 3) & 15u) + 16u * (unsigned)(64 * t.wave + t.lane);
+        unsigned line = ((blockIdx.x >> 3) & 31u) + 32u * (unsigned)(64 * t.wave + t.lane);
         line = line < NL ? line : NL - 1u;
-        const char* p = img + (size_t)ts * ((size_t)TL * 4096) + (size_t)line * 128;
-        asm volatile("global_load_dword %0, %1, off" : "+a"(sink) : "v"(p));
+        const unsigned voff = line * 128u;
+        const unsigned long long bu = (unsigned long long)(img + (size_t)ts * ((size_t)TL * 4096));
+        const char* b = reinterpret_cast<const char*>(
+            ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu >> 32)) << 32) |
+            (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu & 0xffffffffull)));
+        const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)junk);
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(b), "s"(m0v) : "memory");
     }
 }
 
@@ -506,7 +515,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
     const int sblk = t.lane >> 5;
     R4FRing<NTWM, FAST, NS> ring(reinterpret_cast<const float4*>(packed + (FAST ? f.o_r4fh : f.o_r4f)), t, stash);
     const char* pf_img = reinterpret_cast<const char*>(packed + (FAST ? f.o_r4fh : f.o_r4f));
-    float pf_sink = 0.f;               // (an accumulation register of its own, never read: r4f_prefetch_l2)
+    const float* pf_junk = lds + l.o_PF + 64 * t.wave;             // (r4f_prefetch_l2)
     int pf_slot = 0;
     float logq = 0.f;
 #pragma unroll 1                       // (an unrolled copy gets other ring registers, joined by copies of in-flight slots: ISA check)
@@ -548,7 +557,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
             ring.wait(IC<S::I_A>{});
             z.template tile<0>(sblk ? a1 : a0, ring.r[ring.slot(IC<S::I_A>{})][0]);
             ring.refill(IC<S::I_A>{});
-            r4f_prefetch_l2<S::TL>(pf_sink, pf_img, pf_slot++, 2 * f.K, t);
+            r4f_prefetch_l2<S::TL>(pf_junk, pf_img, pf_slot++, 2 * f.K, t);
 #ifdef FAB_R4F_WAVETL
             FAB_WT(6);
 #endif
@@ -642,7 +651,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
                 atile = (f32x4){ax, ay, az, aw};
             }
             ring.refill(IC<S::I_A>{});
-            r4f_prefetch_l2<S::TL>(pf_sink, pf_img, pf_slot++, 2 * f.K, t);
+            r4f_prefetch_l2<S::TL>(pf_junk, pf_img, pf_slot++, 2 * f.K, t);
             float bv[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) bv[g] = 0.f;
@@ -679,7 +688,6 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
         ring.next_layer();
     }
     ring.drain();
-    asm volatile("s_waitcnt vmcnt(0)" : "+a"(pf_sink));             // (the last prefetches have landed before the register dies)
     *grad_off = l.o_X0;
     return logq;
 }
