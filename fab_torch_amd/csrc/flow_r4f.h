@@ -460,8 +460,8 @@ __device__ __forceinline__ void r4f_narrow_mma(const float* act, int lda, Ring& 
 // to ask for a line misses (MALL / HBM, ~1.3 us) and the other 31 queue on that pending fill - a stage-synchronised 4-wave
 // stream of this shape runs at 88 cycles per 1-KiB tile and SIMD on such data and at 70.5 when the data already sits in the L2.
 // So each workgroup TOUCHES its share of the lines of a layer slot AHEAD slots before the stream gets there: one load per
-// wave and slot, lane -> one 128-byte line (line j + 32 (64 wave + lane) of the slot, j = the workgroup's index on its XCD:
-// the 32 workgroups of an XCD cover every line once; waves whose lines all lie past the slot's end skip it) - in the
+// wave and slot, lane -> one 128-byte line (line j + n (64 wave + lane) of the slot, j = the workgroup's index on its XCD, n = the
+// launch's workgroups per XCD, 32 at most: they cover every line once; waves whose lines all lie past the slot's end skip it) - in the
 // micro-benchmark 88.2 -> 75.7 cycles per tile with a fifth wave doing it; here the waves do it themselves, right behind the
 // last request of the slot's first short stage: loads return in order, so the ring items requested behind a prefetch wait
 // for it, and at that point the next ring item is not needed for ~3 k cycles (the stage's epilogue + four W x W items).
@@ -473,16 +473,25 @@ __device__ __forceinline__ void r4f_narrow_mma(const float* act, int lda, Ring& 
 #define FAB_R4F_PF_AHEAD 2             // slots ahead (1 and 2 measure alike: 0.511 ms per transition against 0.570 without; 2 leaves
                                        // more room for workgroups of an XCD that have drifted apart); 0 = no prefetch
 #endif
+// this lane's line of a slot (byte offset; ~0u: this wave has none) - once per evaluation: it takes an integer division
 template <int TL>
-__device__ __forceinline__ void r4f_prefetch_l2(const float* junk, const char* img, int slot, int nslots, const Tid4& t) {
+__device__ __forceinline__ unsigned r4f_prefetch_line(const Tid4& t) {
+    constexpr unsigned NL = (unsigned)TL * 32u;                    // 128-byte lines of a slot (TL tiles x 4 waves x 1 KiB)
+    // shares = the workgroups this launch has on an XCD (workgroup b runs on XCD b mod 8), 32 at most: with fewer than 16 a
+    // workgroup's 256 lanes no longer reach every line of its share - what they reach is still prefetched
+    unsigned nsh = (gridDim.x + 7u) >> 3;
+    nsh = nsh > 32u ? 32u : nsh;
+    if (nsh * 64u * (unsigned)t.wave >= NL) return ~0u;            // (wave-uniform: all of this wave's lines lie past the slot's end)
+    unsigned line = (blockIdx.x >> 3) % nsh + nsh * (unsigned)(64 * t.wave + t.lane);
+    line = line < NL ? line : NL - 1u;
+    return line * 128u;
+}
+template <int TL>
+__device__ __forceinline__ void r4f_prefetch_l2(const float* junk, unsigned voff, const char* img, int slot, int nslots) {
     if constexpr (FAB_R4F_PF_AHEAD > 0) {
-        constexpr unsigned NL = (unsigned)TL * 32u;                // 128-byte lines of a slot (TL tiles x 4 waves x 1 KiB)
-        if (2048u * (unsigned)t.wave >= NL) return;                // (wave-uniform)
+        if (voff == ~0u) return;                                   // (wave-uniform)
         int ts = slot + FAB_R4F_PF_AHEAD;
         ts = ts >= nslots ? ts - nslots : ts;                      // (the next evaluation starts at slot 0 again)
-        unsigned line = ((blockIdx.x >> 3) & 31u) + 32u * (unsigned)(64 * t.wave + t.lane);
-        line = line < NL ? line : NL - 1u;
-        const unsigned voff = line * 128u;
         const unsigned long long bu = (unsigned long long)(img + (size_t)ts * ((size_t)TL * 4096));
         const char* b = reinterpret_cast<const char*>(
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu >> 32)) << 32) |
@@ -516,6 +525,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
     R4FRing<NTWM, FAST, NS> ring(reinterpret_cast<const float4*>(packed + (FAST ? f.o_r4fh : f.o_r4f)), t, stash);
     const char* pf_img = reinterpret_cast<const char*>(packed + (FAST ? f.o_r4fh : f.o_r4f));
     const float* pf_junk = lds + l.o_PF + 64 * t.wave;             // (r4f_prefetch_l2)
+    const unsigned pf_voff = r4f_prefetch_line<S::TL>(t);
     int pf_slot = 0;
     float logq = 0.f;
 #pragma unroll 1                       // (an unrolled copy gets other ring registers, joined by copies of in-flight slots: ISA check)
@@ -557,7 +567,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
             ring.wait(IC<S::I_A>{});
             z.template tile<0>(sblk ? a1 : a0, ring.r[ring.slot(IC<S::I_A>{})][0]);
             ring.refill(IC<S::I_A>{});
-            r4f_prefetch_l2<S::TL>(pf_junk, pf_img, pf_slot++, 2 * f.K, t);
+            r4f_prefetch_l2<S::TL>(pf_junk, pf_voff, pf_img, pf_slot++, 2 * f.K);
 #ifdef FAB_R4F_WAVETL
             FAB_WT(6);
 #endif
@@ -651,7 +661,7 @@ __device__ float flow_log_prob_r4f(const FlowDims& f, const R4Lds& l, const floa
                 atile = (f32x4){ax, ay, az, aw};
             }
             ring.refill(IC<S::I_A>{});
-            r4f_prefetch_l2<S::TL>(pf_junk, pf_img, pf_slot++, 2 * f.K, t);
+            r4f_prefetch_l2<S::TL>(pf_junk, pf_voff, pf_img, pf_slot++, 2 * f.K);
             float bv[G];
 #pragma unroll
             for (int g = 0; g < G; ++g) bv[g] = 0.f;
