@@ -12,7 +12,7 @@ CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libfabhip.so")
 SOURCES = ["flow_kernels.hip", "ais_kernels.hip", "reduce_resample.hip", "train_kernels.hip", "topk.hip",
-           "generic_kernels.hip", "spline_kernels.hip"]
+           "generic_kernels.hip", "spline_kernels.hip", "train_step.hip"]
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-Wno-unused-result", "-Wno-pass-failed",
          "-Rpass-analysis=kernel-resource-usage"] + os.environ.get("FABHIP_EXTRA_FLAGS", "").split()

@@ -32,7 +32,7 @@ def precision_of(flow) -> int:
     raise FabhipError(f"flow.precision must be None, 'fp32' or 'fast' (got {p!r})")
 # developer / test switches of include/fabhip.h (fabhip_set_option)
 (OPT_TILE_SHAPE, OPT_R4_STREAM, OPT_SCAN_VARIANT, OPT_SYSTEMATIC_VARIANT, OPT_SPLINE_STAGED, OPT_TIMELINE,
- OPT_SPLINE_MFMA, OPT_SPLINE_LEAP, OPT_FUSED_TAIL, OPT_ADAPT_FOLD) = range(10)
+ OPT_SPLINE_MFMA, OPT_SPLINE_LEAP, OPT_FUSED_TAIL, OPT_ADAPT_FOLD, OPT_PGRAD, OPT_TAPE_TILES) = range(12)
 
 
 class FabhipError(RuntimeError):

@@ -763,7 +763,8 @@ struct Options {
             {FABHIP_OPT_SCAN_VARIANT, "FABHIP_SCAN_VARIANT", 3}, {FABHIP_OPT_SYSTEMATIC_VARIANT, "FABHIP_SYSTEMATIC_VARIANT", 1},
             {FABHIP_OPT_SPLINE_STAGED, "FABHIP_SPLINE_STAGED", 0}, {FABHIP_OPT_TIMELINE, "FABHIP_TIMELINE", 0},
             {FABHIP_OPT_SPLINE_MFMA, "FABHIP_SPLINE_MFMA", 0},   {FABHIP_OPT_SPLINE_LEAP, "FABHIP_SPLINE_LEAP", 1},
-            {FABHIP_OPT_FUSED_TAIL, "FABHIP_FUSED_TAIL", 1},     {FABHIP_OPT_ADAPT_FOLD, "FABHIP_ADAPT_FOLD", 1}};
+            {FABHIP_OPT_FUSED_TAIL, "FABHIP_FUSED_TAIL", 1},     {FABHIP_OPT_ADAPT_FOLD, "FABHIP_ADAPT_FOLD", 1},
+            {FABHIP_OPT_PGRAD, "FABHIP_PGRAD", 1},               {FABHIP_OPT_TAPE_TILES, "FABHIP_TAPE_TILES", 0}};
         for (const auto& t : tab) {
             const char* e = getenv(t.env);
             v[t.key] = (e && e[0]) ? atoi(e) : t.dflt;

@@ -12,35 +12,9 @@
 //   k_affine_grads         InvertibleAffine: dW -> (dL, dU, dlog_S) through W = P (tril(L,-1)+I)(triu(U,1)+diag(s e^logS))
 #include "flow_device.h"
 #include "launch.h"
+#include "train_common.h"
 
 namespace fab {
-
-// ---- flat gradient image: per layer [w1 | b1 | w2 | b2 | w3 | b3 | L | U | log_S], then loc, log_scale; flows with
-// ActNorm layers: then per layer [an_s | an_t] from `an_base` (= total without ActNorm) on
-struct GradLayout {
-    long layer_stride, w1, b1, w2, b2, w3, b3, L, U, logS, loc, log_scale, total, an_base, total_an;
-};
-
-FAB_HD GradLayout make_grad_layout(const FlowDims& f) {
-    GradLayout g;
-    long o = 0;
-    g.w1 = o; o += (long)f.W * f.d;
-    g.b1 = o; o += f.W;
-    g.w2 = o; o += (long)f.W * f.W;
-    g.b2 = o; o += f.W;
-    g.w3 = o; o += (long)2 * f.DO * f.W;
-    g.b3 = o; o += 2 * f.DO;
-    g.L = o; o += (long)f.D * f.D;
-    g.U = o; o += (long)f.D * f.D;
-    g.logS = o; o += f.D;
-    g.layer_stride = o;
-    g.loc = (long)f.K * o;
-    g.log_scale = g.loc + f.D;
-    g.total = g.log_scale + f.D;
-    g.an_base = g.total;
-    g.total_an = g.total + (long)f.K * 2 * f.D;
-    return g;
-}
 
 template <int NTWM>
 __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape(FlowDims f, FlowLds l, TapeDims td,
@@ -439,14 +413,6 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
 // ------------------------------------------------------------------------------------------------
 // blocks 0 .. K-1: InvertibleAffine layer `blockIdx.x`; block K: DiagGaussian base.
 // ------------------------------------------------------------------------------------------------
-constexpr int LBATCH = 16;
-struct AffineSrc {
-    const float *L, *U, *logS, *signS, *P, *an_s, *an_t;
-};
-struct AffineSrcTab {
-    const float *L[LBATCH], *U[LBATCH], *logS[LBATCH], *signS[LBATCH], *P[LBATCH], *an_s[LBATCH], *an_t[LBATCH];
-};
-
 // one workgroup per InvertibleAffine layer: (dL, dU, dlog_S) from dW = ga_ws[layer]; everything staged in LDS.
 // With an ActNorm after the map (density direction z = a @ W, a = (x - t) e^-s, log_det -= sum(s)) ga_ws holds
 // dW' = sum_b c_b x_b^T g_b for the FOLDED map W' = diag(e^-s) W.  With dc = sum_b c_b g_b (reduced here from the
@@ -547,8 +513,26 @@ static int launch_sample_bwd(const FlowDims& f, const TapeDims& td, const float*
     return check_launch();
 }
 
-static size_t tape_floats(const FlowDims& f, const TapeDims& td) {
-    return (size_t)td.total + (size_t)f.K * td.wz * td.wz + 16;     // + per-layer affine dW scratch + sum(coef)
+int launch_affine_grads(const FlowDims& f, const TapeDims& td, const GradLayout& gl, const fabhip_flow_params* params,
+                        const float* ga, float* grads, const float* tp, const float* coef, long B, hipStream_t st) {
+    const size_t smem = ((size_t)6 * f.D * f.D + 256) * 4;
+    FAB_TRY(set_max_lds((const void*)k_affine_grads, smem));
+    for (int k = 0; k < f.K; ++k)
+        if (!params->lu_L[k] || !params->lu_U[k] || !params->log_S[k] || !params->sign_S[k] || !params->perm_P[k] ||
+            (!params->an_s[k] != !params->an_t[k]))
+            return FABHIP_EINVAL;
+    for (int k0 = 0; k0 < f.K; k0 += LBATCH_T) {
+        const int nl = f.K - k0 < LBATCH_T ? f.K - k0 : LBATCH_T;
+        AffineSrcTab tab;
+        for (int y = 0; y < LBATCH_T; ++y) {
+            const int k = k0 + (y < nl ? y : 0);
+            tab.L[y] = params->lu_L[k]; tab.U[y] = params->lu_U[k]; tab.logS[y] = params->log_S[k];
+            tab.signS[y] = params->sign_S[k]; tab.P[y] = params->perm_P[k];
+            tab.an_s[y] = params->an_s[k]; tab.an_t[y] = params->an_t[k];
+        }
+        hipLaunchKernelGGL(k_affine_grads, dim3(nl), dim3(256), smem, st, f, td, gl, tab, k0, ga, grads, tp, coef, B);
+    }
+    return check_launch();
 }
 
 }  // namespace fab
@@ -623,30 +607,18 @@ int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* 
     if (tape_bytes < tape_floats(f, td) * sizeof(float)) return FABHIP_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     const GradLayout gl = make_grad_layout(f);
-    const GemmBlocks gb = make_gemm_blocks(f, td);
     const float* tp = (const float*)tape;
-    float* ga = const_cast<float*>(tp) + td.total;
-    const int nbase = ceil_div(td.wb, 64) * gb.q1;               // base-distribution blocks after the K layers
-    hipLaunchKernelGGL(k_param_grad, dim3((unsigned)(f.K * gb.per_layer + nbase)), dim3(256), 0, st, f, td, gb, gl,
-                       tp, coef, (long)B, grads, ga);
-    const size_t smem = ((size_t)6 * f.D * f.D + 256) * 4;
-    FAB_TRY(set_max_lds((const void*)k_affine_grads, smem));
-    for (int k = 0; k < f.K; ++k)
-        if (!params->lu_L[k] || !params->lu_U[k] || !params->log_S[k] || !params->sign_S[k] || !params->perm_P[k] ||
-            (!params->an_s[k] != !params->an_t[k]))
-            return FABHIP_EINVAL;
-    for (int k0 = 0; k0 < f.K; k0 += LBATCH) {
-        const int nl = f.K - k0 < LBATCH ? f.K - k0 : LBATCH;
-        AffineSrcTab tab;
-        for (int y = 0; y < LBATCH; ++y) {
-            const int k = k0 + (y < nl ? y : 0);
-            tab.L[y] = params->lu_L[k]; tab.U[y] = params->lu_U[k]; tab.logS[y] = params->log_S[k];
-            tab.signS[y] = params->sign_S[k]; tab.P[y] = params->perm_P[k];
-            tab.an_s[y] = params->an_s[k]; tab.an_t[y] = params->an_t[k];
-        }
-        hipLaunchKernelGGL(k_affine_grads, dim3(nl), dim3(256), smem, st, f, td, gl, tab, k0, ga, grads, tp, coef, (long)B);
+    float* ga = const_cast<float*>(tp) + tape_ga_offset(td);
+    if (option(FABHIP_OPT_PGRAD) != 0) {
+        // one workgroup per output tile, operands straight from the tape into the matrix cores (train_step.hip)
+        FAB_TRY(launch_param_grad_tiles(f, td, gl, tp, coef, (long)B, grads, ga, st));
+    } else {
+        const GemmBlocks gb = make_gemm_blocks(f, td);
+        const int nbase = ceil_div(td.wb, 64) * gb.q1;               // base-distribution blocks after the K layers
+        hipLaunchKernelGGL(k_param_grad, dim3((unsigned)(f.K * gb.per_layer + nbase)), dim3(256), 0, st, f, td, gb, gl,
+                           tp, coef, (long)B, grads, ga);
     }
-    return check_launch();
+    return launch_affine_grads(f, td, gl, params, ga, grads, tp, coef, (long)B, st);
 }
 
 }  // extern "C"

@@ -114,7 +114,12 @@ int fabhip_get_fast_mode(void);
                                             workgroup of every transition kernel (ticket; default), 0 = its own launch per transition.
                                             Spline family (round 5): 1 = an outer HMC step is L launches - begin inside the first
                                             leapfrog launch, accept + rule inside the last; 0 = L + 3 (the same results, bit for bit) */
-#define FABHIP_OPT_COUNT 10
+#define FABHIP_OPT_PGRAD 10              /* FABHIP_PGRAD: parameter gradients from a RealNVP tape: 1 = the stream-K GEMM over all products of all
+                                            layers (default; dense 64 x 64 / narrow tiles straight from HBM into the matrix cores, work cut
+                                            into equal shares), 0 = the round-1 64 x 64 block kernel (A/B; other summation order) */
+#define FABHIP_OPT_TAPE_TILES 11         /* FABHIP_TAPE_TILES: fabhip_flow_log_prob_tape: 0 = 8-chain stream tiles (flow_r8.h) where the flow has
+                                            that image (default), 16 = always the 16-chain kernel (A/B; other summation order) */
+#define FABHIP_OPT_COUNT 12
 int fabhip_set_option(int key, int value);
 int fabhip_get_option(int key);
 

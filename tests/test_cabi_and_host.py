@@ -43,10 +43,10 @@ def test_abi_revision_and_developer_switches_without_gpu():
     assert lib.fabhip_version() == rev == _lib.ABI_VERSION == _ops.ABI_VERSION
     keys = dict(re.findall(r"#define (FABHIP_OPT_[A-Z0-9_]+) (\d+)", txt))
     count = int(keys.pop("FABHIP_OPT_COUNT"))
-    assert sorted(int(v) for v in keys.values()) == list(range(count)) == list(range(10))
+    assert sorted(int(v) for v in keys.values()) == list(range(count)) == list(range(12))
     defaults = {"FABHIP_OPT_TILE_SHAPE": 0, "FABHIP_OPT_R4_STREAM": 2, "FABHIP_OPT_SCAN_VARIANT": 3, "FABHIP_OPT_SYSTEMATIC_VARIANT": 1,
                 "FABHIP_OPT_SPLINE_STAGED": 0, "FABHIP_OPT_TIMELINE": 0, "FABHIP_OPT_SPLINE_MFMA": 0, "FABHIP_OPT_SPLINE_LEAP": 1,
-                "FABHIP_OPT_FUSED_TAIL": 1, "FABHIP_OPT_ADAPT_FOLD": 1}
+                "FABHIP_OPT_FUSED_TAIL": 1, "FABHIP_OPT_ADAPT_FOLD": 1, "FABHIP_OPT_PGRAD": 1, "FABHIP_OPT_TAPE_TILES": 0}
     for name, key in keys.items():
         env = name.replace("FABHIP_OPT_", "FABHIP_").replace("TILE_SHAPE", "TILE")
         if env in os.environ:

@@ -1,0 +1,111 @@
+"""One FAB training iteration with the prioritised buffer on the reference's ManyWell-32 recipe, timed end to end and by phase.
+
+Recipe (`/root/reference/experiments/config/many_well.yaml`: flow 10 x (16-320-320-32 + InvertibleAffine), batch 2048, M = 4,
+HMC L = 5, alpha = 2, 8 minibatches per iteration (`n_batches_buffer_sampling`), buffer 512 000 / min 65 536, lr 3e-4,
+max_grad_norm 100, no weight clipping) through `fab_torch_amd.PrioritisedBufferTrainer.step` =
+`fab/train_with_prioritised_buffer.py:138-216`.  Timing: `iteration_ms` = N back-to-back `trainer.step` calls between two
+device synchronisations (every step ends with the reference's own `.item()` reads, so nothing is hidden behind the host);
+`ais_ms` / `train_ms` = HIP events around the AIS call and around everything after it (buffer add, sampling, 8 minibatch steps)
+inside the same steps.  `measure()` is what bench.py's `trainer_iteration` row calls; run stand-alone it prints one JSON object
+(and under `rocprofv3 --kernel-trace --stats` gives the per-kernel rows of profiles/r6/)."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+D, K_LAYERS, NODES, BATCH, M, L, NB, ALPHA = 32, 10, 10, 2048, 4, 5, 8, 2.0
+BUFFER, MIN_BUFFER, LR, MAX_GRAD_NORM = 512000, 65536, 3e-4, 100.0
+F_FWD = K_LAYERS * 2 * (16 * 320 + 320 * 320 + 2 * 320 * 16) + 2 * K_LAYERS * D * D      # flop per sample and sweep
+# parameter gradients: per layer dW1 (320 x 16), dW2 (320 x 320), dW3 (32 x 320), dW' (32 x 32), 2 flop per sample and entry
+F_PGRAD = K_LAYERS * 2 * (320 * 16 + 320 * 320 + 32 * 320 + 32 * 32)
+PEAK_FP32_MFMA_TFLOPS = 157.3
+
+
+def build(dev, seed=0, eps_init=0.2):
+    import fab_torch_amd as fa
+    from fab_torch_amd.buffer import PrioritisedReplayBuffer
+    torch.manual_seed(seed)
+    flow = fa.make_wrapped_normflow_realnvp(D, n_flow_layers=K_LAYERS, layer_nodes_per_dim=NODES, act_norm=False).to(dev)
+    target = fa.ManyWellEnergy(D)
+    hmc = fa.HamiltonianMonteCarlo(M, D, flow.log_prob, target.log_prob, alpha=ALPHA, p_target=False,
+                                   epsilon=eps_init, n_outer=1, L=L).to(dev)
+    model = fa.FABModel(flow, target, M, alpha=ALPHA, transition_operator=hmc, loss_type="fab_alpha_div")
+    ais = model.annealed_importance_sampler
+    opt = fa.FlatAdam(flow, lr=LR)
+
+    def init_sampler():
+        pt, lw = ais.sample_and_log_weights(BATCH, logging=False)
+        return pt.x, lw, pt.log_q
+
+    buf = PrioritisedReplayBuffer(D, BUFFER, MIN_BUFFER, init_sampler, device=dev)
+    trainer = fa.PrioritisedBufferTrainer(model, opt, buf, alpha=ALPHA, n_batches_buffer_sampling=NB,
+                                          max_gradient_norm=MAX_GRAD_NORM, w_adjust_max_clip=None)
+    return trainer
+
+
+def measure(dev, iters=20, warm=5):
+    trainer = build(dev)
+    ais = trainer.model.annealed_importance_sampler
+    for i in range(warm):
+        trainer.step(i + 1, BATCH)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for i in range(iters):
+        info = trainer.step(warm + i + 1, BATCH)
+    torch.cuda.synchronize(dev)
+    it_ms = (time.perf_counter() - t0) / iters * 1e3
+    # the AIS call of the iteration alone (same sampler, same state), HIP events on the ops' stream
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2 * iters)]
+    for i in range(iters):
+        ev[2 * i].record()
+        ais.sample_and_log_weights(BATCH)
+        ev[2 * i + 1].record()
+    torch.cuda.synchronize(dev)
+    ais_ms = sorted(ev[2 * i].elapsed_time(ev[2 * i + 1]) for i in range(iters))[iters // 2]
+    out = {"workload": "trainer_iteration: ManyWell-32, RealNVP 10x(16-320-320-32)+InvAffine, batch 2048, M = 4, HMC L = 5, "
+                       "8 minibatches of 2048 from a 512 000-entry prioritised buffer, alpha = 2, FlatAdam lr 3e-4, max_grad_norm 100 "
+                       "(experiments/config/many_well.yaml through fab/train_with_prioritised_buffer.py:138-216)",
+           "iteration_ms": it_ms, "ais_ms": ais_ms, "train_ms": it_ms - ais_ms, "iterations_per_s": 1e3 / it_ms,
+           "minibatch_us": (it_ms - ais_ms) / NB * 1e3, "loss": info["loss"], "grad_norm": info["grad_norm"],
+           "ess_ais": info.get("ess_ais"),
+           "flop_per_minibatch": {"tape_forward_reverse": 2 * BATCH * F_FWD, "param_grad": BATCH * F_PGRAD}}
+    return out, trainer
+
+
+def kernel_rows(trainer, dev, n=20):
+    """Stand-alone HIP-event timings of the two training kernels on a 2048-row minibatch (medians of n)."""
+    flow = trainer.model.flow
+    x = torch.randn(BATCH, D, device=dev)
+    coef = torch.full((BATCH,), -1.0 / BATCH, device=dev)
+
+    def ev_time(fn):
+        for _ in range(3):
+            fn()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            fn()
+            ev[i + 1].record()
+        torch.cuda.synchronize(dev)
+        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))[n // 2] * 1e-3
+
+    t_tape = ev_time(lambda: flow.log_prob_with_tape(x))
+    _, tape = flow.log_prob_with_tape(x)
+    t_pg = ev_time(lambda: flow.param_grad_flat(tape, coef))
+    rows = {}
+    for name, t, flop in (("tape_forward_reverse", t_tape, 2 * BATCH * F_FWD), ("param_grad", t_pg, BATCH * F_PGRAD)):
+        ach = flop / t / 1e12
+        rows[name] = {"us_per_call": t * 1e6, "flop": flop, "achieved_TFLOPs": ach, "frac_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
+    return rows
+
+
+if __name__ == "__main__":
+    dev = torch.device("cuda", 0)
+    iters = int(os.environ.get("ITERS", "20"))
+    out, trainer = measure(dev, iters=iters)
+    out["kernels"] = kernel_rows(trainer, dev)
+    print(json.dumps(out))
