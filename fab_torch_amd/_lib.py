@@ -105,8 +105,10 @@ SYMBOLS = [
     "fabhip_hmc_adapt_gathered", "fabhip_spline_hmc_workspace_bytes", "fabhip_spline_hmc_transition",
     "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_tape_gemm", "fabhip_debug_spline_timeline",
     "fabhip_metropolis_partials_floats", "fabhip_metropolis_adapt_gathered",
+    "fabhip_flow_pack_train", "fabhip_flow_log_prob_tape_rows", "fabhip_train_step_workspace_bytes", "fabhip_buffer_train_step",
+    "fabhip_buffer_add", "fabhip_buffer_sample_workspace_bytes", "fabhip_buffer_sample",
 ]
-ABI_VERSION = 214          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 215          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):

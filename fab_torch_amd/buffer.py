@@ -33,6 +33,10 @@ def sample_without_replacement(logits: torch.Tensor, n: int, gumbel: torch.Tenso
     (fab/utils/prioritised_replay_buffer.py:10-17).  `gumbel [len(logits)]` / `perm [n]` may be supplied (explicit
     noise, as everywhere in this package: parity replays of the reference's draws); otherwise they come from the
     device generator."""
+    if gumbel is None and perm is None and logits.is_cuda and logits.dtype == torch.float32:
+        # both draws, the Gumbel keys, the selection and its random order in ONE op (fabhip::buffer_sample_indices): the
+        # expressions below launch ~45 small kernels from Python
+        return _ops.load().buffer_sample_indices(logits.detach().contiguous(), int(n))
     if gumbel is None:
         u = torch.rand(logits.shape, device=logits.device, dtype=logits.dtype).clamp_(min=torch.finfo(logits.dtype).tiny)
         gumbel = -torch.log(-torch.log(u))
@@ -75,10 +79,16 @@ class PrioritisedReplayBuffer:
     @torch.no_grad()
     def add(self, x: torch.Tensor, log_w: torch.Tensor, log_q_old: torch.Tensor) -> None:
         n = x.shape[0]
-        idx = (torch.arange(n, device=self.device) + self.current_index) % self.max_length
-        self.buffer.x[idx] = x.to(self.device)
-        self.buffer.log_w[idx] = log_w.to(self.device)
-        self.buffer.log_q_old[idx] = log_q_old.to(self.device)
+        if self.buffer.x.is_cuda and n <= self.max_length:
+            dev = self.buffer.x.device                     # one launch (fabhip::buffer_add) instead of arange / % / three index_puts
+            _ops.load().buffer_add(x.detach().to(dev).float().contiguous(), log_w.detach().to(dev).float().contiguous(),
+                                   log_q_old.detach().to(dev).float().contiguous(), int(self.current_index), self.buffer.x,
+                                   self.buffer.log_w, self.buffer.log_q_old)
+        else:
+            idx = (torch.arange(n, device=self.device) + self.current_index) % self.max_length
+            self.buffer.x[idx] = x.to(self.device)
+            self.buffer.log_w[idx] = log_w.to(self.device)
+            self.buffer.log_q_old[idx] = log_q_old.to(self.device)
         new_index = self.current_index + n
         if not self.is_full:
             self.is_full = new_index >= self.max_length
@@ -96,6 +106,18 @@ class PrioritisedReplayBuffer:
         else:
             indices = sample_without_replacement(self.buffer.log_w[:max_index], batch_size, gumbel, perm)
         return self.buffer.x[indices], self.buffer.log_w[indices], self.buffer.log_q_old[indices], indices
+
+    @torch.no_grad()
+    def sample_indices(self, batch_size: int, gumbel: torch.Tensor = None, perm: torch.Tensor = None) -> torch.Tensor:
+        """The row indices `sample(batch_size)` would gather (:88-97), without gathering: the fused minibatch step
+        (`fabhip::buffer_train_step`) reads x and log_q_old in place."""
+        if not self.can_sample:
+            raise Exception("Buffer must be at minimum length before calling sample")
+        max_index = self.max_length if self.is_full else self.current_index
+        if self.sample_with_replacement:
+            from .resample import multinomial_indices
+            return multinomial_indices(self.buffer.log_w[:max_index], batch_size)
+        return sample_without_replacement(self.buffer.log_w[:max_index], batch_size, gumbel, perm)
 
     def sample_n_batches(self, batch_size: int, n_batches: int, gumbel: torch.Tensor = None,
                          perm: torch.Tensor = None) -> Iterable[Tuple[torch.Tensor, ...]]:

@@ -24,7 +24,7 @@ struct MlpTab {
 };
 
 // workgroup y handles layer k0 + y: W / Winv to the scratch area of the packed image, sum(log_S) to the layer block
-__global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab tab, int k0, float* __restrict__ packed,
+__global__ __launch_bounds__(1024) void k_affine_assemble(FlowDims f, AffineTab tab, int k0, float* __restrict__ packed,
                                                          int with_inverse) {
     const int D = f.D, layer = k0 + blockIdx.x;
     const float* __restrict__ Lraw = tab.L[blockIdx.x];
@@ -103,6 +103,7 @@ __global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab t
     for (int e = tid; e < D * D; e += blockDim.x) {           // Li <- P @ Lm
         const int i = e / D, j = e % D;
         float s = 0.f;
+#pragma unroll 8
         for (int k = 0; k < D; ++k) s = fmaf(Ps[i * D + k], Lm(k, j), s);
         Li[e] = s;
     }
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(256) void k_affine_assemble(FlowDims f, AffineTab t
     for (int e = tid; e < D * D; e += blockDim.x) {           // W = (P Lm) @ Um
         const int i = e / D, j = e % D;
         float s = 0.f;
+#pragma unroll 8
         for (int k = 0; k < D; ++k) s = fmaf(Li[i * D + k], Um(k, j), s);
         Wout[e] = an_s ? expf(-an_s[i]) * s : s;              // ActNorm.inverse before the map: diag(e^-s) W
     }
@@ -151,13 +153,21 @@ __device__ __forceinline__ int prm_orig(int p, int DO, int DOp) {
     return j < DO ? 2 * j + 1 : -1;
 }
 
-__global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed) {
+// off_begin > 0 (the training image of a flow whose tape forward runs on the 8-chain stream tiles): only the bias blocks
+// [o_b1, o_logS) - what r8_load_heads reads - and, from block (0, 0), the base distribution (one launch fewer)
+__global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed, int off_begin,
+                                                    const float* __restrict__ loc, const float* __restrict__ log_scale) {
     const int D = f.D, d = f.d, DO = f.DO, W = f.W;
     const int y = blockIdx.y, layer = k0 + y;
+    if (loc && blockIdx.x == 0 && y == 0 && (int)threadIdx.x < f.Dp) {
+        const int j = threadIdx.x;
+        packed[f.o_base + j] = j < f.D ? loc[j] : 0.f;
+        packed[f.o_base + f.Dp + j] = j < f.D ? log_scale[j] : 0.f;
+    }
     float* __restrict__ dst = packed + (size_t)layer * f.layer_stride;
     const float* Wm = packed + f.o_scratch + (size_t)layer * 2 * D * D;
     const LayerSrc s{tab.w1[y], tab.b1[y], tab.w2[y], tab.b2[y], tab.w3[y], tab.b3[y], Wm, Wm + D * D};
-    for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.o_logS; off += gridDim.x * blockDim.x) {
+    for (int off = off_begin + blockIdx.x * blockDim.x + threadIdx.x; off < f.o_logS; off += gridDim.x * blockDim.x) {
         float v = 0.f;
         int k, n;
         if (off < f.o_AWT) {                       // AW: B[k][n] = W[k][n]
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(256) void k_pack_layer(FlowDims f, MlpTab tab, int 
         }
         dst[off] = v;
     }
+    if (off_begin > 0) return;
     // (W'^-1)^T, appended after the bf16 images: B[k][n] = Winv[n][k]
     for (int off = blockIdx.x * blockDim.x + threadIdx.x; off < f.KBD * f.NTD * 256; off += gridDim.x * blockDim.x) {
         int k, n;
@@ -817,6 +828,7 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
         if (!p->w1[k] || !p->b1[k] || !p->w2[k] || !p->b2[k] || !p->w3[k] || !p->b3[k] || !p->lu_L[k] ||
             !p->lu_U[k] || !p->log_S[k] || !p->sign_S[k] || !p->perm_P[k] || (!p->an_s[k] != !p->an_t[k]))
             return FABHIP_EINVAL;
+    bool base_done = false;
     for (int k0 = 0; k0 < f.K; k0 += LBATCH) {             // all layers of a batch in one launch each
         const int nl = f.K - k0 < LBATCH ? f.K - k0 : LBATCH;
         AffineTab at;
@@ -829,24 +841,30 @@ static int flow_pack_impl(const fabhip_flow_params* p, float* packed, int with_i
             mt.w1[y] = p->w1[k]; mt.b1[y] = p->b1[k]; mt.w2[y] = p->w2[k]; mt.b2[y] = p->b2[k];
             mt.w3[y] = p->w3[k]; mt.b3[y] = p->b3[k];
         }
-        hipLaunchKernelGGL(k_affine_assemble, dim3(nl), dim3(256), smem, st, f, at, k0, packed, with_inverse);
-        const int nblk = ceil_div(f.o_logS, 256 * 4);
-        hipLaunchKernelGGL(k_pack_layer, dim3(nblk, nl), dim3(256), 0, st, f, mt, k0, packed);
+        hipLaunchKernelGGL(k_affine_assemble, dim3(nl), dim3(f.D <= 32 ? 1024 : 256), smem, st, f, at, k0, packed, with_inverse == 1 ? 1 : 0);
+        // training image + 8-chain tape tiles: the bias blocks only, with the base distribution in the same launch
+        const bool heads_only = with_inverse == 2 && f.o_r8 >= 0 && option(FABHIP_OPT_TAPE_TILES) != 16;
+        const int off_begin = heads_only ? f.o_b1 : 0;
+        const int nblk = ceil_div(f.o_logS - off_begin, 256 * 4);
+        hipLaunchKernelGGL(k_pack_layer, dim3(nblk, nl), dim3(256), 0, st, f, mt, k0, packed, off_begin,
+                           heads_only && k0 == 0 ? p->loc : (const float*)nullptr, p->log_scale);
+        base_done = base_done || (heads_only && k0 == 0);
+        if (f.o_r8 >= 0)
+            hipLaunchKernelGGL(k_pack_r8, dim3(ceil_div(NWAVE * 2 * r8_tiles_p(f.Wp / 64) * 256, 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
+        if (with_inverse == 2) continue;                  // training image: what fabhip_flow_log_prob_tape reads, nothing else
         hipLaunchKernelGGL(k_pack_bf16, dim3(ceil_div(f.Wp * f.Wp, 256 * 4), nl), dim3(256), 0, st, f, mt, k0, packed);
         const R4Dims rd = make_r4_dims(f);
         hipLaunchKernelGGL(k_pack_r4, dim3(ceil_div(rd.layer_stride, 256 * 8), nl), dim3(256), 0, st, f, rd, mt, k0, packed);
-        if (f.o_r8 >= 0)
-            hipLaunchKernelGGL(k_pack_r8, dim3(ceil_div(NWAVE * 2 * r8_tiles_p(f.Wp / 64) * 256, 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
         if (f.o_r8f >= 0)
             hipLaunchKernelGGL(k_pack_r8f, dim3(ceil_div(NWAVE * 2 * r8f_tiles_p(f.Wp / 64) * 256, 256 * 8), nl), dim3(256), 0, st, f, mt, k0, packed);
     }
-    if (f.o_r4s >= 0)
+    if (f.o_r4s >= 0 && with_inverse != 2)
         hipLaunchKernelGGL(k_pack_r4s, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed);
-    if (f.o_r4f >= 0) {
+    if (f.o_r4f >= 0 && with_inverse != 2) {
         hipLaunchKernelGGL(k_pack_r4f, dim3(2048), dim3(256), 0, st, f, make_r4_dims(f), packed, 0);
         hipLaunchKernelGGL(k_pack_r4f, dim3(1024), dim3(256), 0, st, f, make_r4_dims(f), packed, 1);
     }
-    hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
+    if (!base_done) hipLaunchKernelGGL(k_pack_base, dim3(1), dim3(64), 0, st, f, p->loc, p->log_scale, packed);
     return check_launch();
 }
 
@@ -856,6 +874,10 @@ int fabhip_flow_pack(const fabhip_flow_params* p, float* packed, fabhip_stream_t
 
 int fabhip_flow_pack_density(const fabhip_flow_params* p, float* packed, fabhip_stream_t stream) {
     return flow_pack_impl(p, packed, 0, stream);
+}
+
+int fabhip_flow_pack_train(const fabhip_flow_params* p, float* packed, fabhip_stream_t stream) {
+    return flow_pack_impl(p, packed, 2, stream);
 }
 
 int fabhip_flow_log_prob(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,

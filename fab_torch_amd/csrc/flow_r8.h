@@ -239,12 +239,43 @@ __device__ __forceinline__ void r8_dense_wide(ST& s, const float* act, float* ou
     s8_barrier();
 }
 
+// The training tape of an 8-chain tile (TapeDims layout, rows row0 .. row0 + 7; fabhip_flow_log_prob_tape): every matrix the
+// parameter-gradient GEMMs read is copied from LDS to HBM by all 256 threads right behind the barrier that completes it.  The
+// stores are compiler-tracked vector-memory operations issued while the weight ring is in flight: they only make the ring's
+// hand-counted waits conservative (gfx9 retires loads and stores of a wave in issue order; stream_r8.h).
+struct R8Tape {
+    const TapeDims* td;
+    float* tape;
+    long row0;
+};
+// 8 rows x 64 G floats (a hidden tile, leading dimension 64 G + 4) to tape rows `dld` floats apart: 16 G float4 per row, thread
+// (row = tid >> 5, c = tid & 31) takes columns c, c + 32, c + 64 - no division by a run-time width
+template <int G>
+__device__ __forceinline__ void r8_tape_wide(float* __restrict__ dst, int dld, const float* src, int tid) {
+    constexpr int WS = 64 * G + 4, W4 = 16 * G;
+    const int r = tid >> 5, c0 = tid & 31;
+    const float* sp = src + r * WS;
+    float* dp = dst + (long)r * dld;
+#pragma unroll
+    for (int c = 0; c < W4; c += 32)
+        if (c + c0 < W4) *reinterpret_cast<float4*>(dp + 4 * (c + c0)) = *reinterpret_cast<const float4*>(sp + 4 * (c + c0));
+}
+// 8 rows x w floats (w = 16 or 32) of a state-shaped buffer (leading dimension R4_DS) to tape rows w floats apart
+__device__ __forceinline__ void r8_tape_narrow(float* __restrict__ dst, int w, const float* src, int tid) {
+    const int sh = w == 32 ? 3 : 2;                                  // float4 per row: 8 / 4
+    if (tid < (R8 << sh)) {
+        const int r = tid >> sh, c = tid & ((1 << sh) - 1);
+        *reinterpret_cast<float4*>(dst + (long)r * w + 4 * c) = *reinterpret_cast<const float4*>(src + r * R4_DS + 4 * c);
+    }
+}
+
 // log q(x) and d log q / dx for the 8 rows in X0 (columns >= D zero; DP and PRM zeroed by the caller); the gradient is left
 // in the state buffer whose offset is returned through *grad_off.  Returns log q of row `tid >> 4` on threads < 128.
 // All 256 threads of the workgroup must call it; it ends with a workgroup barrier.
-template <int G, bool FUSED = false, class ST>
+template <int G, bool FUSED = false, bool TAPE = false, class ST>
 __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds& l, const float* __restrict__ packed, float* lds,
-                                  const Tid8f& t, ST& s, int* grad_off) {
+                                  const Tid8f& t, ST& s, int* grad_off, const R8Tape* tp = nullptr) {
+    static_assert(!(TAPE && FUSED), "the tape holds z and the full cotangent of z: one stage per matrix");
     constexpr int EX = G - 4, NQW = 16 * G, NQK = 4 * G;                  // k-quads of K = Wp; of a wave's quarter of it
     constexpr int NQ1 = FUSED ? R8_KD4 : R8_Kd4;                            // k-quads of the first Linear's K (fused: the whole state)
     constexpr int F_AW = 0, F_W1 = R8_TD, F_W2 = F_W1 + NQ1 + EX * (NQ1 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK / 2;
@@ -281,6 +312,11 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * G * R8;
         const bool tl = layer == f.K - 2;
         if (tl) FAB_TL(f, 0);
+        float* tl_layer = nullptr;
+        if constexpr (TAPE) {
+            tl_layer = tp->tape + (size_t)layer * tp->td->layer_stride;
+            r8_tape_narrow(tl_layer + tp->td->o_ZA + tp->row0 * tp->td->wz, tp->td->wz, lds + cur, t.tid);
+        }
         {   // InvertibleAffine.inverse (+ folded ActNorm): z <- z @ W' + ac   (every wave; wave 0 stores)
             f32x4 o[2];
             S8Acc<2> acc;
@@ -347,6 +383,24 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         }
         s8_barrier();
         if (tl) FAB_TL(f, 5);
+        if constexpr (TAPE) {
+            // ONE burst of stores per layer (a store sits in the wave's vmcnt queue until it is acknowledged, and the ring's waits
+            // count it): z1 | ones column, h1 = HA, h2 = HB (both intact until the next layer's conditioner) and their ones columns.
+            // (the layer's input went out at the layer's top: the next affine stage overwrites its buffer without a barrier)
+            const TapeDims& td = *tp->td;
+            {
+                const int r = t.tid >> 5, j = t.tid & 31;            // w1 = 32 (d <= 16)
+                tl_layer[td.o_Z1 + (tp->row0 + r) * td.w1 + j] = j < f.d ? Z[r * R4_DS + j] : (j == td.w1 - 16 ? 1.f : 0.f);
+            }
+            if (t.tid < R8 * 16) {
+                const int r = t.tid >> 4, j = t.tid & 15;
+                const float one = j == 0 ? 1.f : 0.f;
+                tl_layer[td.o_H1 + (tp->row0 + r) * td.wh + f.Wp + j] = one;
+                tl_layer[td.o_H2 + (tp->row0 + r) * td.wh + f.Wp + j] = one;
+            }
+            r8_tape_wide<G>(tl_layer + td.o_H1 + tp->row0 * td.wh, td.wh, HA, t.tid);
+            r8_tape_wide<G>(tl_layer + td.o_H2 + tp->row0 * td.wh, td.wh, HB, t.tid);
+        }
         const int tmp = cur; cur = nxt; nxt = tmp;
     }
     // DiagGaussian.log_prob, the seed of the reverse sweep, and the first layer's coupling cotangents
@@ -360,8 +414,14 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             const float sc = expf(ls);
             const float zn = (Zc[row * R4_DS + j] - base[j]) / sc;
             bsum += ls + 0.5f * (zn * zn);
+            if constexpr (TAPE) {                         // what d/dloc and d/dlog_scale reduce over the batch
+                float* TB = tp->tape + tp->td->o_TB + (tp->row0 + row) * tp->td->wb;
+                TB[j] = zn / sc;
+                TB[tp->td->wz + j] = zn * zn - 1.f;
+            }
             Zc[row * R4_DS + j] = -(zn / sc);
         }
+        if constexpr (TAPE) tp->tape[tp->td->o_TB + (tp->row0 + row) * tp->td->wb + 2 * tp->td->wz + c] = c == 0 ? 1.f : 0.f;
         logq += -0.5f * (float)f.D * 1.8378770664093453f - row16_sum(bsum);
         // (the 16 lanes of a row wrote the whole row: same wave, program order)
         for (int j = c; j < f.DO; j += 16) {
@@ -385,6 +445,11 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         float* Gs = lds + cur;
         const bool tl = layer == 1;
         if (tl) FAB_TL(f, 16);
+        float* tl_layer = nullptr;
+        if constexpr (TAPE) {
+            tl_layer = tp->tape + (size_t)layer * tp->td->layer_stride;
+            r8_tape_narrow(tl_layer + tp->td->o_DP + tp->row0 * tp->td->wp, tp->td->wp, DP, t.tid);
+        }
         // d relu(h2) = DP W3T masked by h2 > 0 -> HA;  d relu(h1) = HA W2T masked by h1 > 0 -> HB
         r8_dense_wide<G, B_W3T, R8_Ko4, CONT + TP, 2, R4_DS, WS>(s, DP, HA, PART, mk + G * R8, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 17);
@@ -438,6 +503,11 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         if (ew && c < f.d) Gs[row * R4_DS + c] += r8_part_sum_n<16>(PART + row * 16 + c, R8 * 16);   // g[:, :d] += ...   (d <= 16)
         s8_barrier();
         if (tl) FAB_TL(f, 20);
+        if constexpr (TAPE) {                             // the reverse sweep's burst: d relu(h2) = HA, d relu(h1) = HB, the cotangent of z
+            r8_tape_wide<G>(tl_layer + tp->td->o_E2 + tp->row0 * tp->td->we, tp->td->we, HA, t.tid);
+            r8_tape_wide<G>(tl_layer + tp->td->o_E1 + tp->row0 * tp->td->we, tp->td->we, HB, t.tid);
+            r8_tape_narrow(tl_layer + tp->td->o_GZ + tp->row0 * tp->td->wz, tp->td->wz, Gs, t.tid);
+        }
         {   // g <- g W'^T (every wave; wave 0 stores, and forms the NEXT layer's coupling cotangents where its g2 appears)
             f32x4 o[2];
             S8Acc<2> acc;

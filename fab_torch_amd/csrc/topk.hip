@@ -216,6 +216,61 @@ __global__ __launch_bounds__(1024) void k_topk_sort(const unsigned long long* __
     }
 }
 
+// Gumbel-max keys of the buffer's sampling without replacement (fab/utils/prioritised_replay_buffer.py:10-13):
+// key = logit - log(-log(u)), u ~ U(0, 1) clamped away from 0 (torch.finfo(float32).tiny) as the host expression does
+__global__ __launch_bounds__(256) void k_gumbel_keys(const float* __restrict__ logits, const float* __restrict__ u, long n,
+                                                     float* __restrict__ keys) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float uu = fmaxf(u[i], 1.17549435e-38f);
+    keys[i] = -logf(-logf(uu)) + logits[i];
+}
+
+// A pseudo-random order of the k selected rows - what `indices[torch.randperm(n)]` of :14-16 draws - without a sort: a keyed
+// bijection of [0, k), four Feistel rounds on the next power of two with cycle walking back into range (format-preserving
+// permutation), the round keys from four uniform draws of torch's generator.  O(1) per row, any k; sorting 16 384 random keys in
+// one workgroup's LDS (tried first) took 178 us.
+__device__ __forceinline__ unsigned tk_mix(unsigned x) {               // (murmur3 finaliser)
+    x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void k_random_order(const long long* __restrict__ idx_in, const float* __restrict__ u4, long k,
+                                                      long long* __restrict__ idx_out) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    int bits = 2;
+    while ((1l << bits) < k) ++bits;
+    const int lb = bits >> 1, rb = bits - lb;                            // left / right half widths
+    const unsigned lm = (1u << lb) - 1u, rm = (1u << rb) - 1u;
+    unsigned key[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) key[j] = tk_mix(__float_as_uint(u4[j]) * 0x9E3779B9u + (unsigned)j);
+    unsigned long v = (unsigned long)i;
+    do {                                                                 // cycle walking: expected < 2 trips (2^bits < 2 k... 4 k)
+        unsigned l = (unsigned)(v >> rb) & lm, r = (unsigned)v & rm;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j & 1) r ^= tk_mix(l ^ key[j]) & rm;                    // alternate the halves: each round is an involution
+            else l ^= tk_mix(r ^ key[j]) & lm;
+        }
+        v = ((unsigned long)l << rb) | r;
+    } while ((long)v >= k);
+    idx_out[i] = idx_in[v];
+}
+
+// PrioritisedReplayBuffer.add (fab/utils/prioritised_replay_buffer.py:71-85): rows (start + i) mod max_length of the ring
+__global__ __launch_bounds__(256) void k_buffer_add(const float* __restrict__ x, const float* __restrict__ log_w,
+                                                    const float* __restrict__ log_q, long n, int dim, long start, long max_length,
+                                                    float* __restrict__ bx, float* __restrict__ blw, float* __restrict__ blq) {
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * dim) return;
+    const long i = e / dim;
+    const int j = (int)(e - i * dim);
+    const long row = (start + i) % max_length;
+    bx[row * dim + j] = x[e];
+    if (j == 0) { blw[row] = log_w[i]; blq[row] = log_q[i]; }
+}
+
 static inline size_t tk_al(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline long tk_blocks(long n) { return (n + TK_TILE - 1) / TK_TILE; }
 
@@ -262,6 +317,38 @@ int fabhip_topk(const float* keys, int64_t n, int64_t k, int32_t sorted, int64_t
     const size_t lds = (size_t)np2 * 8;
     FAB_TRY(set_max_lds((const void*)k_topk_sort, lds));
     hipLaunchKernelGGL(k_topk_sort, dim3(1), dim3(1024), lds, st, ws.sel, (long)k, (long long*)idx_out, key_out);
+    return check_launch();
+}
+
+int fabhip_buffer_add(const float* x, const float* log_w, const float* log_q_old, int64_t n, int32_t dim, int64_t start,
+                      int64_t max_length, float* buf_x, float* buf_log_w, float* buf_log_q_old, fabhip_stream_t stream) {
+    if (!x || !log_w || !log_q_old || !buf_x || !buf_log_w || !buf_log_q_old || n < 0 || dim < 1 || max_length < 1 || start < 0 ||
+        n > max_length)
+        return FABHIP_EINVAL;
+    if (n == 0) return FABHIP_OK;
+    const long tot = (long)n * dim;
+    hipLaunchKernelGGL(k_buffer_add, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, log_w, log_q_old,
+                       (long)n, (int)dim, (long)start, (long)max_length, buf_x, buf_log_w, buf_log_q_old);
+    return check_launch();
+}
+
+size_t fabhip_buffer_sample_workspace_bytes(int64_t n, int64_t k) {
+    const size_t t = fabhip_topk_workspace_bytes(n, k);
+    return t ? t + tk_al((size_t)n * 4) + tk_al((size_t)k * 8) : 0;      // + the keys, the selection in index order
+}
+
+int fabhip_buffer_sample(const float* log_w, const float* u_gumbel, const float* u_order, int64_t n, int64_t k, int64_t* idx_out,
+                         void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!log_w || !u_gumbel || !u_order || !idx_out || !workspace || n < 1 || k < 1 || k > n) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_buffer_sample_workspace_bytes(n, k)) return FABHIP_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    char* p = (char*)workspace;
+    float* keys = (float*)p; p += tk_al((size_t)n * 4);
+    long long* sel = (long long*)p; p += tk_al((size_t)k * 8);
+    hipLaunchKernelGGL(k_gumbel_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, log_w, u_gumbel, (long)n, keys);
+    FAB_TRY(fabhip_topk(keys, n, k, 0, (int64_t*)sel, nullptr, p, workspace_bytes - (size_t)(p - (char*)workspace), stream));
+    hipLaunchKernelGGL(k_random_order, dim3((unsigned)((k + 255) / 256)), dim3(256), 0, st, (const long long*)sel, u_order, (long)k,
+                       (long long*)idx_out);
     return check_launch();
 }
 

@@ -350,6 +350,64 @@ void adam_clip_step(Tensor theta, const Tensor& grad, Tensor m, Tensor v, double
         "adam_clip_step");
 }
 
+// One gradient step on one minibatch of the prioritised replay buffer (fab/train_with_prioritised_buffer.py:158-185) as ONE op:
+// training pack, log q with the tape (the minibatch read in place from the buffer through `rows`), loss weights + buffer.adjust,
+// parameter gradients, clipped Adam - nine launches, no host synchronisation, no autograd graph.  `pset`: the flow's registered
+// parameter set (tensors_key_register: the order of fabhip_flow_params), whose tensors live inside `theta` (FlatAdam).
+std::tuple<Tensor, Tensor, Tensor> buffer_train_step(int64_t pset, Tensor packed, int64_t dim, int64_t n_layers, int64_t width,
+                                                     bool repack, const Tensor& x, const optional<Tensor>& rows,
+                                                     const Tensor& log_q_old, bool log_q_old_rows, double alpha, double w_clip,
+                                                     optional<Tensor> buf_log_w, optional<Tensor> buf_log_q_old, Tensor theta,
+                                                     Tensor m, Tensor v, double lr, double beta1, double beta2, double eps,
+                                                     Tensor step_count, double max_norm) {
+    c10::DeviceGuard g(theta.device());
+    fabhip_flow_params p;
+    {
+        std::lock_guard<std::mutex> lk(g_keysets_mu);
+        TORCH_CHECK(pset >= 0 && pset < (int64_t)g_keysets.size() && !g_keysets[(size_t)pset].empty(),
+                    "fabhip: unknown parameter-set handle ", pset);
+        fill_params(p, g_keysets[(size_t)pset], dim, n_layers, width);
+    }
+    make_flow(packed, dim, n_layers, width);
+    TORCH_CHECK(x.dim() == 2 && x.size(1) == dim, "fabhip: x must be [rows, dim]");
+    const int64_t B = rows.has_value() ? rows->numel() : x.size(0);
+    TORCH_CHECK(B >= 1, "fabhip: empty minibatch");
+    if (rows.has_value()) need(*rows, at::kLong, "rows");
+    TORCH_CHECK(buf_log_w.has_value() == buf_log_q_old.has_value(), "fabhip: buf_log_w and buf_log_q_old go together");
+    TORCH_CHECK(!(buf_log_w.has_value() || log_q_old_rows) || rows.has_value(), "fabhip: in-place buffer access needs `rows`");
+    const int64_t n_rows = x.size(0);
+    if (log_q_old_rows) need_n(log_q_old, n_rows, theta, "log_q_old (the buffer's)");
+    else need_n(log_q_old, B, theta, "log_q_old");
+    const int64_t n = theta.numel();
+    TORCH_CHECK(m.numel() == n && v.numel() == n, "fabhip: adam image sizes differ");
+    need(step_count, at::kInt, "step_count");
+    int64_t lay[15];
+    chk(fabhip_flow_grad_layout((int32_t)dim, (int32_t)n_layers, (int32_t)width, lay), "flow_grad_layout");
+    TORCH_CHECK(n == (p.an_s[0] ? lay[14] : lay[12]), "fabhip: theta has ", n, " floats, the flow's flat layout ", lay[12]);
+    // (the parameters must be views of theta: the gradient image and the Adam step use its layout)
+    TORCH_CHECK(p.w1[0] == theta.data_ptr<float>() + lay[1], "fabhip: the flow's parameters do not live inside theta (FlatAdam)");
+    Tensor log_q = fempty({B}, theta), adj = fempty({B}, theta), coef = fempty({B}, theta), grads = fempty({n}, theta),
+           stats = fempty({8}, theta);                      // (every entry is written by the step's kernels)
+    const size_t nb = fabhip_train_step_workspace_bytes((int32_t)dim, (int32_t)n_layers, (int32_t)width, B, n);
+    TORCH_CHECK(nb > 0, "fabhip: flow shape not supported");
+    Tensor ws = scratch(nb, theta);
+    fabhip_train_step_args a;
+    a.struct_bytes = sizeof(a);
+    a.params = &p; a.packed = packed.data_ptr<float>(); a.repack = repack ? 1 : 0; a.log_q_old_rows = log_q_old_rows ? 1 : 0;
+    a.x = fp(x, "x"); a.rows = rows.has_value() ? rows->data_ptr<int64_t>() : nullptr; a.log_q_old = fp(log_q_old, "log_q_old");
+    a.B = B; a.alpha = (float)alpha; a.w_adjust_max_clip = (float)w_clip;
+    a.buf_log_w = buf_log_w.has_value() ? fpmn(*buf_log_w, n_rows, theta, "buffer log_w") : nullptr;
+    a.buf_log_q_old = buf_log_q_old.has_value() ? fpmn(*buf_log_q_old, n_rows, theta, "buffer log_q_old") : nullptr;
+    a.log_q = log_q.data_ptr<float>(); a.log_w_adjust = adj.data_ptr<float>(); a.coef = coef.data_ptr<float>();
+    a.grads = grads.data_ptr<float>(); a.stats = stats.data_ptr<float>();
+    a.theta = fpm(theta, "theta"); a.m = fpm(m, "m"); a.v = fpm(v, "v"); a.n_params = n;
+    a.lr = (float)lr; a.beta1 = (float)beta1; a.beta2 = (float)beta2; a.eps = (float)eps; a.max_grad_norm = (float)max_norm;
+    a.step_count = step_count.data_ptr<int32_t>();
+    a.workspace = aligned(ws); a.workspace_bytes = nb;
+    chk(fabhip_buffer_train_step(&a, stream_of(theta)), "buffer_train_step");
+    return {log_q, adj, stats};
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // RQ-spline coupling flow.  `Tensor[] params`: per layer {meta, w0, b0, wa, ba, wb, bb, wf, bf, pfw, uw, uh, ud}
 // (pfw may be an empty tensor), then {base_scale, base_circ}.
@@ -1122,6 +1180,34 @@ Tensor gather_rows(const Tensor& src, const Tensor& idx) {
     return out;
 }
 
+// PrioritisedReplayBuffer.add / the row selection of .sample as one op each (the draws come from torch's device generator)
+void buffer_add(const Tensor& x, const Tensor& log_w, const Tensor& log_q_old, int64_t start, Tensor buf_x, Tensor buf_log_w,
+                Tensor buf_log_q_old) {
+    c10::DeviceGuard g(buf_x.device());
+    TORCH_CHECK(x.dim() == 2 && buf_x.dim() == 2 && x.size(1) == buf_x.size(1), "fabhip: x must be [n, dim] like the buffer");
+    const int64_t n = x.size(0), dim = x.size(1), L = buf_x.size(0);
+    need_n(log_w, n, buf_x, "log_w"); need_n(log_q_old, n, buf_x, "log_q_old");
+    need_n(buf_log_w, L, buf_x, "buffer log_w"); need_n(buf_log_q_old, L, buf_x, "buffer log_q_old");
+    need_n(x, n * dim, buf_x, "x");
+    chk(fabhip_buffer_add(fp(x, "x"), fp(log_w, "log_w"), fp(log_q_old, "log_q_old"), n, (int32_t)dim, start, L, fpm(buf_x, "buffer x"),
+                          fpm(buf_log_w, "buffer log_w"), fpm(buf_log_q_old, "buffer log_q_old"), stream_of(buf_x)),
+        "buffer_add");
+}
+
+Tensor buffer_sample_indices(const Tensor& log_w, int64_t k) {
+    c10::DeviceGuard g(log_w.device());
+    const int64_t n = log_w.numel();
+    Tensor u = at::rand({n}, log_w.options().dtype(at::kFloat)), r = at::rand({4}, log_w.options().dtype(at::kFloat));
+    Tensor idx = at::empty({k}, log_w.options().dtype(at::kLong));
+    const size_t nb = fabhip_buffer_sample_workspace_bytes(n, k);
+    TORCH_CHECK(nb > 0, "fabhip: buffer_sample_indices needs 1 <= k <= n");
+    Tensor ws = scratch(nb, log_w);
+    chk(fabhip_buffer_sample(fp(log_w, "log_w"), u.data_ptr<float>(), r.data_ptr<float>(), n, k, idx.data_ptr<int64_t>(), aligned(ws),
+                             nb, stream_of(log_w)),
+        "buffer_sample");
+    return idx;
+}
+
 Tensor topk(const Tensor& keys, int64_t k, bool sorted) {
     c10::DeviceGuard g(keys.device());
     const int64_t n = keys.numel();
@@ -1164,6 +1250,10 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("realnvp_sample_tape(Tensor theta, Tensor eps, Tensor packed, Tensor[] params, int dim, int n_layers, "
           "int width) -> (Tensor, Tensor)");
     m.def("realnvp_sample_grad_tape(" FLW ", Tensor x, Tensor grad_x, Tensor grad_log_q) -> (Tensor, Tensor)");
+    m.def("buffer_train_step(int pset, Tensor(a!) packed, int dim, int n_layers, int width, bool repack, Tensor x, Tensor? rows, "
+          "Tensor log_q_old, bool log_q_old_rows, float alpha, float w_clip, Tensor(b!)? buf_log_w, Tensor(c!)? buf_log_q_old, "
+          "Tensor(d!) theta, Tensor(e!) m, Tensor(f!) v, float lr, float beta1, float beta2, float eps, Tensor(g!) step_count, "
+          "float max_norm) -> (Tensor, Tensor, Tensor)");
     m.def("adam_clip_step(Tensor(a!) theta, Tensor grad, Tensor(b!) m, Tensor(c!) v, float lr, float beta1, float beta2, "
           "float eps, Tensor(d!) step_count, float max_norm, Tensor(e!) grad_norm) -> ()");
 
@@ -1247,6 +1337,9 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("multinomial_torch(Tensor probs, Tensor u) -> Tensor");
     m.def("gather_rows(Tensor src, Tensor idx) -> Tensor");
     m.def("topk(Tensor keys, int k, bool sorted) -> Tensor");
+    m.def("buffer_add(Tensor x, Tensor log_w, Tensor log_q_old, int start, Tensor(a!) buf_x, Tensor(b!) buf_log_w, "
+          "Tensor(c!) buf_log_q_old) -> ()");
+    m.def("buffer_sample_indices(Tensor log_w, int k) -> Tensor");
 }
 
 TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; deliberately no CPU registration
@@ -1258,6 +1351,7 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("realnvp_sample_tape", realnvp_sample_tape);
     m.impl("realnvp_sample_grad_tape", realnvp_sample_grad_tape);
     m.impl("adam_clip_step", adam_clip_step);
+    m.impl("buffer_train_step", buffer_train_step);
     m.impl("spline_pack", spline_pack);
     m.impl("spline_logprob_grad", spline_logprob_grad);
     m.impl("spline_logprob_tape", spline_logprob_tape);
@@ -1292,4 +1386,6 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("multinomial_torch", multinomial_torch);
     m.impl("gather_rows", gather_rows);
     m.impl("topk", topk);
+    m.impl("buffer_add", buffer_add);
+    m.impl("buffer_sample_indices", buffer_sample_indices);
 }

@@ -21,7 +21,8 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape(FlowDims f, Flo
                                                                  const float* __restrict__ packed,
                                                                  const float* __restrict__ x,
                                                                  float* __restrict__ log_q, float* __restrict__ grad,
-                                                                 float* __restrict__ tape, long B) {
+                                                                 float* __restrict__ tape, long B,
+                                                                 const int64_t* __restrict__ rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     Tid t;
     const long row0 = (long)blockIdx.x * ROWS;
@@ -29,7 +30,7 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape(FlowDims f, Flo
     for (int e = t.tid; e < ROWS * l.DS; e += NTHREADS) {
         const int r = e / l.DS, j = e % l.DS;
         const long g = row0 + r;
-        lds[l.o_U0 + e] = (j < f.D && g < B) ? x[g * f.D + j] : 0.f;
+        lds[l.o_U0 + e] = (j < f.D && g < B) ? x[(rows ? (long)rows[g] : g) * f.D + j] : 0.f;
         lds[l.o_U1 + e] = 0.f;
     }
     __syncthreads();
@@ -413,11 +414,12 @@ __global__ __launch_bounds__(256) void k_param_grad(FlowDims f, TapeDims td, Gem
 // ------------------------------------------------------------------------------------------------
 // blocks 0 .. K-1: InvertibleAffine layer `blockIdx.x`; block K: DiagGaussian base.
 // ------------------------------------------------------------------------------------------------
+constexpr int AFF_THREADS = 1024;      // one output entry per thread and D x D product for D <= 32 (the products are latency chains)
 // one workgroup per InvertibleAffine layer: (dL, dU, dlog_S) from dW = ga_ws[layer]; everything staged in LDS.
 // With an ActNorm after the map (density direction z = a @ W, a = (x - t) e^-s, log_det -= sum(s)) ga_ws holds
 // dW' = sum_b c_b x_b^T g_b for the FOLDED map W' = diag(e^-s) W.  With dc = sum_b c_b g_b (reduced here from the
 // tape's GZ rows):  dW = diag(e^-s) (dW' - t (x) dc),  ds_i = -sum_j W_ij dW_ij - sum_b c_b,  dt_i = -e^-s_i (W dc)_i.
-__global__ __launch_bounds__(256) void k_affine_grads(FlowDims f, TapeDims td, GradLayout gl, AffineSrcTab tab,
+__global__ __launch_bounds__(AFF_THREADS) void k_affine_grads(FlowDims f, TapeDims td, GradLayout gl, AffineSrcTab tab,
                                                       int k0, const float* __restrict__ ga_ws,
                                                       float* __restrict__ grads, const float* __restrict__ tape,
                                                       const float* __restrict__ coef, long B) {
@@ -427,8 +429,9 @@ __global__ __launch_bounds__(256) void k_affine_grads(FlowDims f, TapeDims td, G
     const AffineSrc src{tab.L[y], tab.U[y], tab.logS[y], tab.signS[y], tab.P[y], tab.an_s[y], tab.an_t[y]};
     float* dW = sm;                 // [D][D] each
     float* Lm = dW + DD;
-    float* Um = Lm + DD;
-    float* Ps = Um + DD;
+    float* Um = Lm + DD;            // rows D + 1 floats apart: T = dW Um^T reads a COLUMN of lanes (j) per k - with rows D apart
+    const int US = D + 1;           // (D = 32) all 32 lanes of a row hit one bank, 32 times per output entry
+    float* Ps = Um + DD + D;
     float* PL = Ps + DD;            // P @ Lm
     float* T = PL + DD;             // dW @ Um^T
     float* dc = T + DD;             // [4][64] partial column sums of c_b g_b, then [64] (ActNorm only)
@@ -437,29 +440,32 @@ __global__ __launch_bounds__(256) void k_affine_grads(FlowDims f, TapeDims td, G
     if (an) {
         const float* GZ = tape + (size_t)layer * td.layer_stride + td.o_GZ;
         const int j = tid & 63, r = tid >> 6;
-        float s = 0.f;
-        if (j < D)
-            for (long b = r; b < B; b += 4) s = fmaf(coef[b], GZ[b * td.wz + j], s);
-        dc[r * 64 + j] = s;
+        if (tid < 256) {
+            float s = 0.f;
+            if (j < D)
+                for (long b = r; b < B; b += 4) s = fmaf(coef[b], GZ[b * td.wz + j], s);
+            dc[r * 64 + j] = s;
+        }
         __syncthreads();
         if (tid < 64) dc[tid] = (dc[tid] + dc[64 + tid]) + (dc[128 + tid] + dc[192 + tid]);
         __syncthreads();
     }
-    for (int e = tid; e < DD; e += 256) {
+    for (int e = tid; e < DD; e += AFF_THREADS) {
         const int i = e / D, j = e - i * D;
         const float raw = ga_ws[((size_t)layer * td.wz + i) * td.wz + j];
         dW[e] = an ? expf(-src.an_s[i]) * (raw - src.an_t[i] * dc[j]) : raw;
         Lm[e] = i == j ? 1.f : (i > j ? src.L[e] : 0.f);
-        Um[e] = i == j ? src.signS[i] * expf(src.logS[i]) : (i < j ? src.U[e] : 0.f);
+        Um[i * US + j] = i == j ? src.signS[i] * expf(src.logS[i]) : (i < j ? src.U[e] : 0.f);
         Ps[e] = src.P[e];
     }
     __syncthreads();
-    for (int e = tid; e < DD; e += 256) {
+    for (int e = tid; e < DD; e += AFF_THREADS) {
         const int i = e / D, j = e - i * D;
         float s = 0.f, st = 0.f;
+#pragma unroll 8
         for (int k = 0; k < D; ++k) {
             s = fmaf(Ps[i * D + k], Lm[k * D + j], s);
-            st = fmaf(dW[i * D + k], Um[j * D + k], st);            // T = dW Um^T
+            st = fmaf(dW[i * D + k], Um[j * US + k], st);            // T = dW Um^T
         }
         PL[e] = s;
         T[e] = st;
@@ -471,34 +477,35 @@ __global__ __launch_bounds__(256) void k_affine_grads(FlowDims f, TapeDims td, G
         const int i = tid;
         for (int j = 0; j < D; ++j) {
             float w = 0.f;
-            for (int k = 0; k < D; ++k) w = fmaf(PL[i * D + k], Um[k * D + j], w);          // W_ij = (P Lm Um)_ij
+            for (int k = 0; k < D; ++k) w = fmaf(PL[i * D + k], Um[k * US + j], w);          // W_ij = (P Lm Um)_ij
             gs = fmaf(-w, dW[i * D + j], gs);
             gt = fmaf(w, dc[j], gt);
         }
         grads[gl.an_base + (long)layer * 2 * D + i] = gs - csum;
         grads[gl.an_base + (long)layer * 2 * D + D + i] = -expf(-src.an_s[i]) * gt;
     }
-    for (int e = tid; e < DD; e += 256) {
+    for (int e = tid; e < DD; e += AFF_THREADS) {
         const int i = e / D, j = e - i * D;
         float su = 0.f, sl = 0.f;
+#pragma unroll 8
         for (int k = 0; k < D; ++k) {
             su = fmaf(PL[k * D + i], dW[k * D + j], su);            // dUm = (P Lm)^T dW
             sl = fmaf(Ps[k * D + i], T[k * D + j], sl);             // dLm = P^T (dW Um^T)
         }
         G[gl.U + e] = i < j ? su : 0.f;
         G[gl.L + e] = i > j ? sl : 0.f;
-        if (i == j) G[gl.logS + i] = su * Um[e] + csum;             // d/dlog_S of s e^{log_S} (+ the +sum(log_S) log-det)
+        if (i == j) G[gl.logS + i] = su * Um[i * US + j] + csum;             // d/dlog_S of s e^{log_S} (+ the +sum(log_S) log-det)
     }
 }
 
 template <int NTWM>
 static int launch_log_prob_tape(const FlowDims& f, const TapeDims& td, const float* packed, const float* x,
-                                float* log_q, float* grad, float* tape, long B, hipStream_t st) {
+                                float* log_q, float* grad, float* tape, long B, const int64_t* rows, hipStream_t st) {
     const dim3 grid((unsigned)ceil_div((int)B, ROWS)), block(NTHREADS);
     const FlowLds l = make_flow_lds(f, true);
     const size_t bytes = (size_t)l.total * 4;
     FAB_TRY(set_max_lds((const void*)k_flow_log_prob_tape<NTWM>, bytes));
-    hipLaunchKernelGGL((k_flow_log_prob_tape<NTWM>), grid, block, bytes, st, f, l, td, packed, x, log_q, grad, tape, B);
+    hipLaunchKernelGGL((k_flow_log_prob_tape<NTWM>), grid, block, bytes, st, f, l, td, packed, x, log_q, grad, tape, B, rows);
     return check_launch();
 }
 
@@ -515,7 +522,7 @@ static int launch_sample_bwd(const FlowDims& f, const TapeDims& td, const float*
 
 int launch_affine_grads(const FlowDims& f, const TapeDims& td, const GradLayout& gl, const fabhip_flow_params* params,
                         const float* ga, float* grads, const float* tp, const float* coef, long B, hipStream_t st) {
-    const size_t smem = ((size_t)6 * f.D * f.D + 256) * 4;
+    const size_t smem = ((size_t)6 * f.D * f.D + f.D + 256) * 4;
     FAB_TRY(set_max_lds((const void*)k_affine_grads, smem));
     for (int k = 0; k < f.K; ++k)
         if (!params->lu_L[k] || !params->lu_U[k] || !params->log_S[k] || !params->sign_S[k] || !params->perm_P[k] ||
@@ -530,7 +537,7 @@ int launch_affine_grads(const FlowDims& f, const TapeDims& td, const GradLayout&
             tab.signS[y] = params->sign_S[k]; tab.P[y] = params->perm_P[k];
             tab.an_s[y] = params->an_s[k]; tab.an_t[y] = params->an_t[k];
         }
-        hipLaunchKernelGGL(k_affine_grads, dim3(nl), dim3(256), smem, st, f, td, gl, tab, k0, ga, grads, tp, coef, B);
+        hipLaunchKernelGGL(k_affine_grads, dim3(nl), dim3(AFF_THREADS), smem, st, f, td, gl, tab, k0, ga, grads, tp, coef, B);
     }
     return check_launch();
 }
@@ -572,7 +579,8 @@ int fabhip_flow_tape_layout(int32_t dim, int32_t n_layers, int32_t width, int64_
     return FABHIP_OK;
 }
 
-int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+// rows != nullptr: batch row g is row rows[g] of x (fabhip_flow_log_prob_tape_rows)
+static int log_prob_tape_impl(const fabhip_flow* flow, const float* x, const int64_t* rows, float* log_q, float* grad_x, int64_t B,
                               void* tape, size_t tape_bytes, fabhip_stream_t stream) {
     if (!flow || !flow->packed || !x || !log_q || !tape || B < 0) return FABHIP_EINVAL;
     FAB_TRY(check_flow_shape(flow->dim, flow->n_layers, flow->width));
@@ -580,8 +588,23 @@ int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* lo
     const FlowDims f = make_flow_dims(flow->dim, flow->n_layers, flow->width);
     const TapeDims td = make_tape_dims(f, (long)B);
     if (tape_bytes < tape_floats(f, td) * sizeof(float)) return FABHIP_ENOSPC;
-    FAB_DISPATCH_NTW(f, launch_log_prob_tape, f, td, flow->packed, x, log_q, grad_x, (float*)tape, (long)B,
+    // 8-chain stream tiles where the flow has that image (D <= 32, hidden width padded to 256 / 320): twice the workgroups of the
+    // 16-chain kernel on the same batch - a 2048-row minibatch fills the chip
+    if (option(FABHIP_OPT_TAPE_TILES) != 16 && f.o_r8 >= 0)
+        return launch_log_prob_tape_r8(f, td, flow->packed, x, rows, log_q, grad_x, (float*)tape, (long)B, (hipStream_t)stream);
+    FAB_DISPATCH_NTW(f, launch_log_prob_tape, f, td, flow->packed, x, log_q, grad_x, (float*)tape, (long)B, rows,
                      (hipStream_t)stream);
+}
+
+int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
+                              void* tape, size_t tape_bytes, fabhip_stream_t stream) {
+    return log_prob_tape_impl(flow, x, nullptr, log_q, grad_x, B, tape, tape_bytes, stream);
+}
+
+int fabhip_flow_log_prob_tape_rows(const fabhip_flow* flow, const float* x, const int64_t* rows, float* log_q, float* grad_x,
+                                   int64_t B, void* tape, size_t tape_bytes, fabhip_stream_t stream) {
+    if (!rows) return FABHIP_EINVAL;
+    return log_prob_tape_impl(flow, x, rows, log_q, grad_x, B, tape, tape_bytes, stream);
 }
 
 int fabhip_flow_sample_grad_tape(const fabhip_flow* flow, const float* x, const float* grad_x, const float* grad_log_q,
@@ -633,9 +656,13 @@ namespace fab {
 
 constexpr int ADAM_BLOCKS = 512;
 
-__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, long n, double* __restrict__ part) {
+__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, long n, double* __restrict__ part,
+                                                        int* __restrict__ steps_copy, const int* __restrict__ step_count) {
     __shared__ double red[256];
     const int tid = threadIdx.x;
+    // the step counter as k_adam_clip (the launch behind this one) sees it: its blocks read this copy, its block 0 writes the
+    // counter itself - no third launch and no block reads what another one writes
+    if (blockIdx.x == 0 && tid == 0) *steps_copy = *step_count;
     double s = 0.0;
     const long n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -657,71 +684,105 @@ struct AdamK {
     float lr, beta1, beta2, eps, max_norm;
 };
 
-__global__ __launch_bounds__(256) void k_adam_clip(float* __restrict__ theta, const float* __restrict__ g,
-                                                   float* __restrict__ m, float* __restrict__ v, long n, AdamK a,
-                                                   const double* __restrict__ part, int nparts,
-                                                   const int* __restrict__ step_count, float* __restrict__ norm_out) {
-    __shared__ double red[256];
-    const int tid = threadIdx.x;
-    double s = 0.0;
-    for (int i = tid; i < nparts; i += 256) s += part[i];
-    red[tid] = s;
-    __syncthreads();
-    for (int k = 128; k > 0; k >>= 1) {
-        if (tid < k) red[tid] += red[tid + k];
-        __syncthreads();
-    }
-    const float total = (float)sqrt(red[0]);
-    if (blockIdx.x == 0 && tid == 0) *norm_out = total;
-    if (!isfinite(total)) return;                               // "nan grad norm": no step
-    float coef = 1.f;
-    if (a.max_norm > 0.f) { coef = a.max_norm / (total + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
-    // t = applied steps so far + 1 (a skipped step does not advance the bias correction, like the reference,
-    // which simply does not call optimizer.step()); bias corrections in double as torch computes them on the host
-    const double t = (double)(*step_count + 1);
-    const float step_size = (float)((double)a.lr / (1.0 - pow((double)a.beta1, t)));
-    const float bc2_sqrt = (float)sqrt(1.0 - pow((double)a.beta2, t));
-    for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256) {
-        const float gi = g[i] * coef;
-        const float mi = m[i] + (gi - m[i]) * (1.f - a.beta1);               // exp_avg.lerp_(grad, 1 - beta1)
-        const float vi = v[i] * a.beta2 + (1.f - a.beta2) * (gi * gi);       // mul_(beta2).addcmul_(g, g, 1 - beta2)
-        m[i] = mi;
-        v[i] = vi;
-        const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
-        theta[i] = theta[i] - step_size * (mi / denom);                      // addcdiv_(exp_avg, denom, -step_size)
-    }
+__device__ __forceinline__ void adam_one(float& th, float gi, float& mi, float& vi, float coef, const AdamK& a, float step_size,
+                                         float bc2_sqrt) {
+    gi *= coef;
+    mi = mi + (gi - mi) * (1.f - a.beta1);                    // exp_avg.lerp_(grad, 1 - beta1)
+    vi = vi * a.beta2 + (1.f - a.beta2) * (gi * gi);          // mul_(beta2).addcmul_(g, g, 1 - beta2)
+    const float denom = sqrtf(vi) / bc2_sqrt + a.eps;
+    th = th - step_size * (mi / denom);                       // addcdiv_(exp_avg, denom, -step_size)
 }
 
-__global__ void k_adam_commit(const float* __restrict__ norm, int* __restrict__ step_count) {
-    if (isfinite(*norm)) *step_count += 1;
+// VEC: all four images 16-byte aligned (float4 accesses; the tail of n mod 4 by block 0).  Block 0 advances the step counter (the
+// blocks read k_sqnorm_partial's copy of it).
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_adam_clip(float* __restrict__ theta, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n, AdamK a,
+                                                   const double* __restrict__ part, int nparts, int* __restrict__ step_count,
+                                                   float* __restrict__ norm_out, const int* __restrict__ steps_copy) {
+    // the norm from the block partials (one wave, fixed order), the clip coefficient and Adam's bias corrections: once per block
+    __shared__ float bc[4];
+    const int tid = threadIdx.x;
+    if (tid < 64) {
+        double s = 0.0;
+        for (int i = tid; i < nparts; i += 64) s += part[i];
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_down(s, o);
+        if (tid == 0) {
+            const float total = (float)sqrt(s);
+            float coef = 1.f;
+            if (a.max_norm > 0.f) { coef = a.max_norm / (total + 1e-6f); coef = coef > 1.f ? 1.f : coef; }
+            // t = applied steps so far + 1 (a skipped step does not advance the bias correction, like the reference, which simply
+            // does not call optimizer.step()); bias corrections in double as torch computes them on the host
+            const double t = (double)(*steps_copy + 1);
+            bc[0] = total; bc[1] = coef;
+            bc[2] = (float)((double)a.lr / (1.0 - pow((double)a.beta1, t)));
+            bc[3] = (float)sqrt(1.0 - pow((double)a.beta2, t));
+        }
+    }
+    __syncthreads();
+    const float total = bc[0];
+    if (blockIdx.x == 0 && tid == 0) *norm_out = total;
+    const bool apply = isfinite(total);                         // "nan grad norm": no step
+    if (apply) {
+        const float coef = bc[1], step_size = bc[2], bc2_sqrt = bc[3];
+        if constexpr (VEC) {
+            const long n4 = n >> 2;
+            float4* th4 = reinterpret_cast<float4*>(theta);
+            const float4* g4 = reinterpret_cast<const float4*>(g);
+            float4* m4 = reinterpret_cast<float4*>(m);
+            float4* v4 = reinterpret_cast<float4*>(v);
+            for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+                float4 th = th4[i], mi = m4[i], vi = v4[i];
+                const float4 gi = g4[i];
+                adam_one(th.x, gi.x, mi.x, vi.x, coef, a, step_size, bc2_sqrt);
+                adam_one(th.y, gi.y, mi.y, vi.y, coef, a, step_size, bc2_sqrt);
+                adam_one(th.z, gi.z, mi.z, vi.z, coef, a, step_size, bc2_sqrt);
+                adam_one(th.w, gi.w, mi.w, vi.w, coef, a, step_size, bc2_sqrt);
+                th4[i] = th; m4[i] = mi; v4[i] = vi;
+            }
+            if (blockIdx.x == 0 && tid < (int)(n & 3)) {
+                const long i = (n4 << 2) + tid;
+                adam_one(theta[i], g[i], m[i], v[i], coef, a, step_size, bc2_sqrt);
+            }
+        } else {
+            for (long i = (long)blockIdx.x * 256 + tid; i < n; i += (long)gridDim.x * 256)
+                adam_one(theta[i], g[i], m[i], v[i], coef, a, step_size, bc2_sqrt);
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0 && apply) *step_count = *steps_copy + 1;
 }
 
 }  // namespace fab
 
 extern "C" {
 
-size_t fabhip_adam_workspace_bytes(int64_t n) { (void)n; return (size_t)fab::ADAM_BLOCKS * sizeof(double) + 16; }
+size_t fabhip_adam_workspace_bytes(int64_t n) { (void)n; return (size_t)fab::ADAM_BLOCKS * sizeof(double) + 32; }
 
 int fabhip_adam_clip_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                           float beta2, float eps, int32_t* step_count, float max_norm, float* grad_norm_out,
                           void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
     if (!theta || !grad || !m || !v || n < 1 || !step_count || !workspace) return FABHIP_EINVAL;
     if (workspace_bytes < fabhip_adam_workspace_bytes(n)) return FABHIP_ENOSPC;
-    if (((uintptr_t)grad & 15) != 0) return FABHIP_EINVAL;
+    if (((uintptr_t)grad & 15) != 0 || ((uintptr_t)workspace & 7) != 0) return FABHIP_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     double* part = (double*)workspace;
+    int* steps_copy = (int*)(part + fab::ADAM_BLOCKS);
     const long per = 256 * 4;
     int nb = (int)((n + per - 1) / per);
     if (nb > fab::ADAM_BLOCKS) nb = fab::ADAM_BLOCKS;
-    hipLaunchKernelGGL(fab::k_sqnorm_partial, dim3(nb), dim3(256), 0, st, grad, (long)n, part);
+    hipLaunchKernelGGL(fab::k_sqnorm_partial, dim3(nb), dim3(256), 0, st, grad, (long)n, part, steps_copy, (const int*)step_count);
     fab::AdamK a;
     a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
-    float* norm = grad_norm_out ? grad_norm_out : (float*)(part + fab::ADAM_BLOCKS);
-    int nb2 = (int)((n + 255) / 256);
-    if (nb2 > 2048) nb2 = 2048;
-    hipLaunchKernelGGL(fab::k_adam_clip, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
-                       (const int*)step_count, norm);
-    hipLaunchKernelGGL(fab::k_adam_commit, dim3(1), dim3(1), 0, st, (const float*)norm, (int*)step_count);
+    float* norm = grad_norm_out ? grad_norm_out : (float*)(steps_copy + 2);
+    const bool vec = (((uintptr_t)theta | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    int nb2 = (int)((n + per - 1) / per);          // one float4 per thread (a second trip of a few threads doubles the launch)
+    if (nb2 > 8192) nb2 = 8192;
+    if (vec)
+        hipLaunchKernelGGL(fab::k_adam_clip<true>, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
+                           (int*)step_count, norm, (const int*)steps_copy);
+    else
+        hipLaunchKernelGGL(fab::k_adam_clip<false>, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
+                           (int*)step_count, norm, (const int*)steps_copy);
     return fab::check_launch();
 }
 

@@ -340,4 +340,216 @@ int launch_param_grad_tiles(const FlowDims& f, const TapeDims& td, const GradLay
     return check_launch();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// tape forward on the 8-chain stream tiles (flow_r8.h, one stage per matrix: the tape needs z and the full cotangent of z, which the
+// fused stages never form).  `rows` != nullptr: row g of the batch is row rows[g] of `x` (a minibatch of the replay buffer read in
+// place, fab/utils/prioritised_replay_buffer.py:88-99 `self.buffer.x[indices]`).
+// ---------------------------------------------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape_r8(FlowDims f, R8Lds l, TapeDims td, const float* __restrict__ packed,
+                                                                    const float* __restrict__ x, const int64_t* __restrict__ rows,
+                                                                    float* __restrict__ log_q, float* __restrict__ grad,
+                                                                    float* __restrict__ tape, long B) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int NT = NTHREADS;
+    Tid8f t8;
+    const int D = f.D;
+    const long row0 = (long)blockIdx.x * R8;
+    r8_load_heads(f, l, packed, lds, t8.tid, NT);
+    for (int e = t8.tid; e < R8 * R4_DS; e += NT) { lds[l.o_DP + e] = 0.f; lds[l.o_PRM + e] = 0.f; }
+    for (int e = t8.tid; e < R8 * R4_DS; e += NT) {
+        const int r = e / R4_DS, j = e % R4_DS;
+        const long g = row0 + r;
+        float v = 0.f;
+        if (j < D && g < B) v = x[(rows ? (long)rows[g] : g) * D + j];
+        lds[l.o_X0 + e] = v;
+    }
+    R8Stream s;
+    s8_stream_init(s, t8.lane);
+    __syncthreads();
+    const R8Tape tp{&td, tape, row0};
+    int goff = 0;
+    const float lq = flow_log_prob_r8<G, false, true>(f, l, packed, lds, t8, s, &goff, &tp);
+    if (t8.tid >= 16 * R8) return;
+    const long g = row0 + t8.row;
+    if (g < B) {
+        if (t8.c == 0) log_q[g] = lq;
+        if (grad)
+            for (int j = t8.c; j < D; j += 16) grad[g * D + j] = lds[goff + t8.row * R4_DS + j];
+    }
+}
+
+int launch_log_prob_tape_r8(const FlowDims& f, const TapeDims& td, const float* packed, const float* x, const int64_t* rows,
+                            float* log_q, float* grad, float* tape, long B, hipStream_t st) {
+    if (!r8_shape_ok(f)) return FABHIP_ENOTSUP;
+    const R8Lds l = make_r8_lds(f);
+    const size_t bytes = (size_t)l.total * 4;
+    const dim3 grid((unsigned)(td.Bp / R8));                  // every row of the tape (Bp: a multiple of 16) is written
+#define FAB_R8_TAPE(G)                                                                                              \
+    do {                                                                                                            \
+        FAB_TRY(set_max_lds((const void*)k_flow_log_prob_tape_r8<G>, bytes));                                       \
+        hipLaunchKernelGGL((k_flow_log_prob_tape_r8<G>), grid, dim3(NTHREADS), bytes, st, f, l, td, packed, x, rows, log_q, grad, \
+                           tape, B);                                                                                \
+    } while (0)
+    if (f.Wp == 320) FAB_R8_TAPE(5);
+    else if (f.Wp == 256) FAB_R8_TAPE(4);
+    else return FABHIP_ENOTSUP;
+#undef FAB_R8_TAPE
+    return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The arithmetic between `log_q_x = flow.log_prob(x)` and `loss.backward()` of one replay-buffer minibatch
+// (fab/train_with_prioritised_buffer.py:162-172) and the buffer's `adjust` (fab/utils/prioritised_replay_buffer.py:117-131), one
+// workgroup:   log_w_adjust = (1 - alpha) (log_q - log_q_old);  w = clip(exp(log_w_adjust), max = w_clip);  loss = -mean(w log_q);
+//   coef_b = d loss / d log_q_b = w_b * (-1 / B)   (w is detached in the reference's loss), times NaN when the loss is not finite
+//   (the update is then skipped by the optimiser's finite-norm test: the reference's two host-side checks, :172-181);
+//   buffer: log_w[idx] += log_w_adjust, log_q_old[idx] = log_q where both are finite, log_w[idx] = -inf elsewhere.
+// stats: [0] loss, [1] mean(w before the clip), [2] min, [3] max, [4] mean(log_q)   (the reference's logging keys, :188-196)
+// ---------------------------------------------------------------------------------------------------------------------------------
+struct MinibatchK {
+    const float* log_q;
+    const float* log_q_old;            // [B], or the buffer's log_q_old when `rows` is set
+    const int64_t* rows;               // buffer rows of the minibatch (nullptr: no gather, no adjust)
+    float one_minus_alpha, w_clip, neg_inv_B;
+    float* coef;                       // [B] out
+    float* log_w_adjust;               // [B] out
+    float* buf_log_w;                  // adjusted in place at `rows` (nullptr: no adjust)
+    float* buf_log_q_old;
+    float* stats;                      // [8] out
+    long B;
+};
+
+__global__ __launch_bounds__(1024) void k_buffer_minibatch(MinibatchK a) {
+    __shared__ float red[5][16];
+    __shared__ float poison_s;
+    constexpr int KEEP = 4;                                 // weights kept in registers between the two passes (B <= 4096)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float s_wl = 0.f, s_w = 0.f, s_l = 0.f, mn = INFINITY, mx = -INFINITY;
+    bool nan_w = false;
+    float wk[KEEP];
+    // the first KEEP trips as three rounds of independent loads (row -> its stored values -> arithmetic): one memory latency per
+    // round instead of one per dependent access
+    long rowk[KEEP];
+    float lqk[KEEP], lqok[KEEP], blwk[KEEP];
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it) {
+        const long b = tid + 1024l * it;
+        rowk[it] = b < a.B ? (a.rows ? (long)a.rows[b] : b) : 0;
+        lqk[it] = b < a.B ? a.log_q[b] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it) {
+        const long b = tid + 1024l * it;
+        lqok[it] = b < a.B ? a.log_q_old[rowk[it]] : 0.f;
+        blwk[it] = (b < a.B && a.buf_log_w) ? a.buf_log_w[rowk[it]] : 0.f;
+    }
+    auto one = [&](long b, long row, float lq, float lqo, float blw, float& w_out) {
+        const float adj = a.one_minus_alpha * (lq - lqo);
+        const float wp = expf(adj);
+        const float w = (a.w_clip > 0.f && wp > a.w_clip) ? a.w_clip : wp;       // torch.clip(max=): NaN stays NaN
+        a.log_w_adjust[b] = adj;
+        w_out = w;
+        s_wl += w * lq; s_w += wp; s_l += lq;
+        nan_w = nan_w || (wp != wp);
+        mn = fminf(mn, wp); mx = fmaxf(mx, wp);
+        if (a.buf_log_w) {
+            const bool valid = isfinite(adj) && isfinite(lq);
+            a.buf_log_w[row] = valid ? blw + adj : -INFINITY;
+            if (valid) a.buf_log_q_old[row] = lq;
+        }
+    };
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it) {
+        const long b = tid + 1024l * it;
+        wk[it] = 0.f;
+        if (b < a.B) one(b, rowk[it], lqk[it], lqok[it], blwk[it], wk[it]);
+    }
+    for (long b = tid + 1024l * KEEP; b < a.B; b += 1024) {
+        const long row = a.rows ? (long)a.rows[b] : b;
+        float w;
+        one(b, row, a.log_q[b], a.log_q_old[row], a.buf_log_w ? a.buf_log_w[row] : 0.f, w);
+        a.coef[b] = w;
+    }
+    if (nan_w) { mn = NAN; mx = NAN; }                                           // torch.min / max propagate NaN
+    // fixed-order sums: the lanes of a wave by shuffles, then the 16 waves in order
+    for (int o = 32; o >= 1; o >>= 1) {
+        s_wl += __shfl_down(s_wl, o); s_w += __shfl_down(s_w, o); s_l += __shfl_down(s_l, o);
+        const float m1 = __shfl_down(mn, o), m2 = __shfl_down(mx, o);
+        mn = (mn != mn || m1 != m1) ? NAN : fminf(mn, m1);
+        mx = (mx != mx || m2 != m2) ? NAN : fmaxf(mx, m2);
+    }
+    if (lane == 0) { red[0][wave] = s_wl; red[1][wave] = s_w; red[2][wave] = s_l; red[3][wave] = mn; red[4][wave] = mx; }
+    __syncthreads();
+    if (tid == 0) {
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = INFINITY, t4 = -INFINITY;
+        for (int w = 0; w < 16; ++w) {
+            t0 += red[0][w]; t1 += red[1][w]; t2 += red[2][w];
+            t3 = (t3 != t3 || red[3][w] != red[3][w]) ? NAN : fminf(t3, red[3][w]);
+            t4 = (t4 != t4 || red[4][w] != red[4][w]) ? NAN : fmaxf(t4, red[4][w]);
+        }
+        const float Bf = (float)a.B;
+        const float loss = -(t0 / Bf);
+        a.stats[0] = loss; a.stats[1] = t1 / Bf; a.stats[2] = t3; a.stats[3] = t4; a.stats[4] = t2 / Bf;
+        a.stats[6] = 0.f; a.stats[7] = 0.f;                 // ([5]: the gradient norm, written by the optimiser step)
+        poison_s = isfinite(loss) ? 1.f : NAN;
+    }
+    __syncthreads();
+    const float poison = poison_s;
+#pragma unroll
+    for (int it = 0; it < KEEP; ++it) {
+        const long b = tid + 1024l * it;
+        if (b < a.B) a.coef[b] = wk[it] * a.neg_inv_B * poison;
+    }
+    for (long b = tid + 1024l * KEEP; b < a.B; b += 1024) a.coef[b] = a.coef[b] * a.neg_inv_B * poison;
+}
+
 }  // namespace fab
+
+using namespace fab;
+
+extern "C" {
+
+size_t fabhip_train_step_workspace_bytes(int32_t dim, int32_t n_layers, int32_t width, int64_t B, int64_t n_params) {
+    const size_t tape = fabhip_flow_tape_bytes(dim, n_layers, width, B);
+    if (tape == 0 || B < 1 || n_params < 1) return 0;
+    return ((tape + 255) & ~(size_t)255) + ((fabhip_adam_workspace_bytes(n_params) + 255) & ~(size_t)255);
+}
+
+int fabhip_buffer_train_step(const fabhip_train_step_args* a, fabhip_stream_t stream) {
+    if (!a || a->struct_bytes != sizeof(fabhip_train_step_args)) return FABHIP_EINVAL;
+    if (!a->params || !a->packed || !a->x || !a->log_q_old || !a->log_q || !a->log_w_adjust || !a->coef || !a->grads ||
+        !a->stats || !a->theta || !a->m || !a->v || !a->step_count || !a->workspace || a->B < 1 || a->n_params < 1)
+        return FABHIP_EINVAL;
+    if ((a->buf_log_w != nullptr) != (a->buf_log_q_old != nullptr)) return FABHIP_EINVAL;
+    if ((a->buf_log_w || a->log_q_old_rows) && !a->rows) return FABHIP_EINVAL;
+    const fabhip_flow_params* p = a->params;
+    FAB_TRY(check_flow_shape(p->dim, p->n_layers, p->width));
+    const size_t tape_bytes = fabhip_flow_tape_bytes(p->dim, p->n_layers, p->width, a->B);
+    const size_t tape_al = (tape_bytes + 255) & ~(size_t)255;
+    if (a->workspace_bytes < fabhip_train_step_workspace_bytes(p->dim, p->n_layers, p->width, a->B, a->n_params)) return FABHIP_ENOSPC;
+    if (((uintptr_t)a->workspace & 255) != 0) return FABHIP_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    // 1. the image of the current parameters (the optimiser step of the previous minibatch changed them)
+    if (a->repack) FAB_TRY(fabhip_flow_pack_train(p, a->packed, stream));
+    // 2. log q(x) with the tape, the minibatch read in place from the buffer
+    fabhip_flow fl;
+    fl.dim = p->dim; fl.n_layers = p->n_layers; fl.width = p->width; fl.precision = FABHIP_PRECISION_FP32; fl.packed = a->packed;
+    if (a->rows) FAB_TRY(fabhip_flow_log_prob_tape_rows(&fl, a->x, a->rows, a->log_q, nullptr, a->B, a->workspace, tape_bytes, stream));
+    else FAB_TRY(fabhip_flow_log_prob_tape(&fl, a->x, a->log_q, nullptr, a->B, a->workspace, tape_bytes, stream));
+    // 3. weights of the loss, its value, the buffer's adjustment
+    MinibatchK k;
+    k.log_q = a->log_q; k.log_q_old = a->log_q_old; k.rows = (a->log_q_old_rows || a->buf_log_w) ? a->rows : nullptr;
+    if (!a->log_q_old_rows && a->buf_log_w) return FABHIP_EINVAL;       // (adjusting in place needs the buffer's own log_q_old)
+    k.one_minus_alpha = 1.f - a->alpha; k.w_clip = a->w_adjust_max_clip; k.neg_inv_B = -1.f / (float)a->B;
+    k.coef = a->coef; k.log_w_adjust = a->log_w_adjust; k.buf_log_w = a->buf_log_w; k.buf_log_q_old = a->buf_log_q_old;
+    k.stats = a->stats; k.B = (long)a->B;
+    hipLaunchKernelGGL(k_buffer_minibatch, dim3(1), dim3(1024), 0, st, k);
+    // 4. d loss / d theta, 5. clipped Adam step (skipped on the device when the norm is not finite)
+    FAB_TRY(fabhip_flow_param_grad(p, &fl, a->workspace, tape_bytes, a->coef, a->B, a->grads, stream));
+    return fabhip_adam_clip_step(a->theta, a->grads, a->m, a->v, a->n_params, a->lr, a->beta1, a->beta2, a->eps, a->step_count,
+                                 a->max_grad_norm, a->stats + 5, (char*)a->workspace + tape_al,
+                                 a->workspace_bytes - tape_al, stream);
+}
+
+}  // extern "C"

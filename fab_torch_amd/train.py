@@ -102,6 +102,8 @@ class PrioritisedBufferTrainer:
         point_ais, log_w_ais = model.annealed_importance_sampler.sample_and_log_weights(
             batch_size, eps0=noise.get("eps0"), noise_a=noise.get("noise_a"), noise_b=noise.get("noise_b"))
         buf.add(point_ais.x.detach(), log_w_ais.detach(), point_ais.log_q.detach())
+        if self._fused and self._one_op_minibatch():
+            return self._step_fused(i, batch_size, noise)
         info = model.get_iter_info()
         mini_dataset = buf.sample_n_batches(batch_size=batch_size, n_batches=self.n_batches_buffer_sampling,
                                             gumbel=noise.get("gumbel"), perm=noise.get("perm"))
@@ -164,6 +166,52 @@ class PrioritisedBufferTrainer:
                     buf.adjust((1 - self.alpha) * (log_q_new - log_q_old), log_q_new, indices)
         # NB: like the reference, this trainer never steps `optim_schedular` (it is only checkpointed, :59-68);
         # fab/train.py:110-111 is the loop that steps it.
+        return info
+
+    def _one_op_minibatch(self) -> bool:
+        """The whole minibatch body as ONE op (fabhip::buffer_train_step): RealNVP + FlatAdam, the buffer on the flow's device and
+        sampled WITHOUT replacement (the op reads x / log_q_old in place and adjusts the buffer before the next minibatch reads it,
+        which equals the reference's gather-everything-first only when no row is drawn twice), weights adjusted on the fly."""
+        buf = self.buffer
+        return (not buf.sample_with_replacement and not self.w_adjust_in_buffer_after_update and buf.buffer.x.is_cuda
+                and buf.buffer.x.device == self.optimizer.theta.device and getattr(self, "one_op_minibatch", True))
+
+    def _step_fused(self, i: int, batch_size: int, noise: Dict) -> Dict:
+        """train_with_prioritised_buffer.py:153-198 with every minibatch as one `fabhip::buffer_train_step` call: no gathered copies
+        of the minibatches, no autograd graph, no host synchronisation until the iteration's logging values are read (once)."""
+        from . import _ops
+        model, buf, opt = self.model, self.buffer, self.optimizer
+        ops = _ops.load()
+        flow = model.flow
+        nb = self.n_batches_buffer_sampling
+        indices = buf.sample_indices(batch_size * nb, gumbel=noise.get("gumbel"), perm=noise.get("perm"))
+        self.last_indices = indices
+        chunks = torch.chunk(indices, nb)
+        log_w_last = buf.buffer.log_w[chunks[-1]]               # (logging: the last minibatch's weights as sampled, :190-191)
+        packed, D, K, W = flow.native(need_inverse=False)       # registers the parameter set / makes the image current
+        opt._check_alias()
+        handle = flow._own_handle()
+        grp = opt.param_groups[0]
+        clip = float(self.max_adjust_w_clip) if self.max_adjust_w_clip is not None else 0.0
+        mx = 0.0 if self.max_gradient_norm == float("inf") else float(self.max_gradient_norm)
+        stats = None
+        with torch.no_grad():
+            theta = opt.theta.detach()
+            for j, rows in enumerate(chunks):
+                _, _, stats = ops.buffer_train_step(
+                    handle, packed, D, K, W, j > 0, buf.buffer.x, rows.contiguous(), buf.buffer.log_q_old, True, float(self.alpha),
+                    clip, buf.buffer.log_w, buf.buffer.log_q_old, theta, opt.m, opt.v, float(grp["lr"]),
+                    float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]), opt.steps, mx)
+        flow._packed_key = None                                 # the parameters moved behind autograd's version counters (and the
+        flow._packed_has_inverse = False                        # image holds the training tiles of the last-but-one parameters)
+        opt.grad_norm.copy_(stats[5:6])
+        # the AIS call's logging values (:150; they do not change after the call): read here, behind the enqueued minibatches, so
+        # that the device-to-host read of the transition operator's statistics does not stall the queue in front of them
+        info = model.get_iter_info()
+        lw = torch.stack([torch.std(log_w_last), torch.mean(log_w_last)])
+        host = torch.cat([stats[:6], lw]).tolist()              # ONE device-to-host read for the iteration's logging values
+        info.update(loss=host[0], step=i, grad_norm=host[5], sampled_log_w_std=host[6], sampled_log_w_mean=host[7],
+                    w_adjust_mean=host[1], w_adjust_min=host[2], w_adjust_max=host[3], log_q_x_mean=host[4])
         return info
 
     def save_checkpoint(self, i: int):

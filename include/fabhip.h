@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 214
+#define FABHIP_ABI_VERSION 215
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -133,6 +133,11 @@ int fabhip_flow_pack(const fabhip_flow_params* params, float* packed, fabhip_str
  * fabhip_flow_log_prob / _log_prob_tape / the transition kernels between two optimiser steps of a minibatch loop;
  * fabhip_flow_sample and fabhip_ais_run need a full fabhip_flow_pack first. */
 int fabhip_flow_pack_density(const fabhip_flow_params* params, float* packed, fabhip_stream_t stream);
+/* The image for the TRAINING forward only (round 6): what fabhip_flow_log_prob_tape reads - the assembled affine maps, the 16-chain
+ * tiles with the biases and, where the flow has them, the 8-chain stream tiles; ~1/4 of the launches of a density pack.  Used between
+ * the optimiser steps of the replay-buffer minibatches (fabhip_buffer_train_step); any other consumer needs fabhip_flow_pack /
+ * fabhip_flow_pack_density afterwards. */
+int fabhip_flow_pack_train(const fabhip_flow_params* params, float* packed, fabhip_stream_t stream);
 
 /* `precision`: per CALL choice between the fp32 parity kernels and fast mode (below) for the entry points that have both -
  * FABHIP_PRECISION_DEFAULT (0, what a zero-initialised struct gets) follows the process default of fabhip_set_fast_mode,
@@ -263,6 +268,10 @@ size_t fabhip_flow_tape_bytes(int32_t dim, int32_t n_layers, int32_t width, int6
 int fabhip_flow_tape_layout(int32_t dim, int32_t n_layers, int32_t width, int64_t B, int64_t* out18);
 int fabhip_flow_log_prob_tape(const fabhip_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
                               void* tape, size_t tape_bytes, fabhip_stream_t stream);
+/* The same with the batch read in place from a larger matrix: batch row g is row rows[g] of x (`self.buffer.x[indices]` of
+ * fab/utils/prioritised_replay_buffer.py:98 without materialising the gather). */
+int fabhip_flow_log_prob_tape_rows(const fabhip_flow* flow, const float* x, const int64_t* rows, float* log_q, float* grad_x,
+                                   int64_t B, void* tape, size_t tape_bytes, fabhip_stream_t stream);
 int fabhip_flow_param_grad(const fabhip_flow_params* params, const fabhip_flow* flow, const void* tape,
                            size_t tape_bytes, const float* coef, int64_t B, float* grads, fabhip_stream_t stream);
 /* Backward of the SAMPLING direction - `loss.backward()` through `flow.sample_and_log_prob` for the reparameterised
@@ -284,6 +293,53 @@ size_t fabhip_adam_workspace_bytes(int64_t n);
 int fabhip_adam_clip_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                           float beta2, float eps, int32_t* step_count, float max_norm, float* grad_norm_out,
                           void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+
+/* ONE gradient step on ONE minibatch of the prioritised replay buffer - the body of the minibatch loop of
+ * fab/train_with_prioritised_buffer.py:158-185 with the buffer's `adjust` (fab/utils/prioritised_replay_buffer.py:117-131),
+ * enqueued without a host synchronisation:
+ *   (repack != 0) the training image of the current parameters (fabhip_flow_pack_train);
+ *   log_q = flow.log_prob(x) with the tape - x either [B][dim] (rows == NULL) or the buffer's x with the minibatch's row indices;
+ *   log_w_adjust = (1 - alpha) (log_q - log_q_old), w = clip(exp(log_w_adjust), max = w_adjust_max_clip) (<= 0: no clip),
+ *   loss = -mean(w log_q), coef = -w / B (w is detached in the reference's loss; NaN-poisoned when the loss is not finite, which the
+ *   optimiser's finite-norm test turns into the reference's skipped update, :172-181);
+ *   (buf_log_w != NULL) buffer.adjust on the minibatch's rows: log_w += log_w_adjust and log_q_old = log_q where both are finite,
+ *   log_w = -inf elsewhere (the reference adjusts after the optimiser step with the same values, :184-185; needs unique rows:
+ *   sampling without replacement);
+ *   grads = sum_b coef_b d log q(x_b) / d theta (fabhip_flow_param_grad), then fabhip_adam_clip_step on (theta, m, v).
+ * `params` point INTO theta (the flat layout of fabhip_flow_grad_layout: FlatAdam).  log_q_old: [B] (log_q_old_rows = 0) or the
+ * buffer's log_q_old, read at rows[b] (= 1).  stats[8] (device): loss, mean / min / max of exp(log_w_adjust) before the clip,
+ * mean(log_q), gradient norm - the reference's logging keys (:188-196).  struct_bytes = sizeof(fabhip_train_step_args). */
+typedef struct {
+    size_t struct_bytes;
+    const fabhip_flow_params* params;
+    float* packed;
+    int32_t repack, log_q_old_rows;
+    const float* x;
+    const int64_t* rows;
+    const float* log_q_old;
+    int64_t B;
+    float alpha, w_adjust_max_clip;
+    float *buf_log_w, *buf_log_q_old;
+    float *log_q, *log_w_adjust, *coef, *grads, *stats;      /* outputs: [B], [B], [B], [n_params], [8] */
+    float *theta, *m, *v;
+    int64_t n_params;
+    float lr, beta1, beta2, eps, max_grad_norm;
+    int32_t* step_count;
+    void* workspace;                                         /* 256-byte aligned */
+    size_t workspace_bytes;
+} fabhip_train_step_args;
+/* PrioritisedReplayBuffer.add (fab/utils/prioritised_replay_buffer.py:71-85) in one launch: the n new rows go to rows
+ * (start + i) mod max_length of the ring (x [max_length][dim], log_w, log_q_old [max_length]). */
+int fabhip_buffer_add(const float* x, const float* log_w, const float* log_q_old, int64_t n, int32_t dim, int64_t start,
+                      int64_t max_length, float* buf_x, float* buf_log_w, float* buf_log_q_old, fabhip_stream_t stream);
+/* PrioritisedReplayBuffer.sample's row selection without replacement (:10-17, :88-97) given the uniform draws: the k rows with
+ * the largest log_w + Gumbel(u_gumbel[n]) (fabhip_topk), in a pseudo-random order (`indices[torch.randperm(k)]`): a keyed
+ * bijection of [0, k) - four Feistel rounds with cycle walking - whose round keys come from the four uniforms u_order[4]. */
+size_t fabhip_buffer_sample_workspace_bytes(int64_t n, int64_t k);
+int fabhip_buffer_sample(const float* log_w, const float* u_gumbel, const float* u_order, int64_t n, int64_t k, int64_t* idx_out,
+                         void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
+size_t fabhip_train_step_workspace_bytes(int32_t dim, int32_t n_layers, int32_t width, int64_t B, int64_t n_params);
+int fabhip_buffer_train_step(const fabhip_train_step_args* args, fabhip_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Targets (fab/target_distributions/many_well.py:81-90, double_well.py:44-58, gmm.py:57-66)
