@@ -228,6 +228,21 @@ def spline_cfg3(dev):
             "ess_ais": float(ais.get_logging_info()["ess_ais"])}
 
 
+def trainer_iteration(dev):
+    """The training half next to the sampler: one iteration of fab/train_with_prioritised_buffer.py:138-216 on
+    the reference's ManyWell-32 recipe (experiments/config/many_well.yaml: batch 2048, M = 4, HMC L = 5, 8 minibatches of 2048 from
+    a 512 000-entry prioritised buffer, alpha = 2) - tools/bench_trainer.py: N back-to-back trainer steps between two device
+    synchronisations, the AIS call of the same sampler alone by HIP events, the two training kernels stand-alone."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_trainer
+    out, trainer = bench_trainer.measure(dev, iters=20, warm=5)
+    out["kernels"] = bench_trainer.kernel_rows(trainer, dev)
+    out["profile"] = "profiles/r6/trainer_kernel_stats_rocprofv3.csv + trainer_iteration_timeline.txt (tools/trace_trainer.sh: the same script under rocprofv3 --kernel-trace --stats)"
+    del trainer
+    torch.cuda.empty_cache()
+    return out
+
+
 def _relaunch_under_torchrun(args):
     """`python bench.py --gpus N` started directly (no torchrun environment): start N ranks of this same script, one per
     GPU, under torch.distributed.run on 127.0.0.1 and hand its exit code back.  (The driver's own torchrun command line
@@ -383,8 +398,8 @@ def main():
         return pt.x, log_w, pt.log_q
 
     for _ in range(200):                        # untimed, same count on every rank (step() holds collectives): a fresh
-        step()                                  # box needs ~1 s of work to reach steady clocks (first process on a box
-    sync()                                      # after 30 such steps: 177.8k samples/s, any later process: 185.0k)
+        step()                                  # box needs ~1 s of work to reach steady clocks (measured in round 3: the first
+    sync()                                      # process on a box read 4 % low after 30 such steps)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -514,6 +529,7 @@ def main():
         ess_trained = trained_flow_ess(dev)
         ess_trained_fast = trained_flow_ess(dev, fast=True)
     spline3 = spline_cfg3(dev) if (rank == 0 and world == 1 and not custom and args.workload == "headline") else None
+    trainer_row = trainer_iteration(dev) if (rank == 0 and world == 1 and not custom and args.workload == "headline") else None
 
     bad = []
     if rank == 0:
@@ -544,6 +560,7 @@ def main():
             "roofline_resample": roof_extra,
             "ess_trained": ess_trained,
             "spline_cfg3": spline3,
+            "trainer_iteration": trainer_row,
             "fast_mode": {
                 "what": "NOT the parity path: the two 320x320 GEMMs of every coupling layer with bf16 operands (weights rounded at pack "
                         "time, activations as they are fetched; fp32 accumulation) inside the chain-initialisation and transition "

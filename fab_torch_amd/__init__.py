@@ -15,7 +15,6 @@ from .core import FABModel
 from .buffer import PrioritisedReplayBuffer, sample_without_replacement
 from .train import PrioritisedBufferTrainer, Trainer
 from .optim import FlatAdam
-from .wrappers import WrappedTorchDist
 from .spline_flow import CircularCoupledRQSFlow, make_wrapped_normflow_spline
 from .resample import resample, multinomial_indices, systematic_indices, multinomial_torch_compat, gather_rows
 
@@ -45,5 +44,5 @@ __all__ = [
     "get_grad_intermediate_log_prob", "AnnealedImportanceSampler", "LoggingInfo", "NoValidPoints",
     "effective_sample_size", "ess_and_log_z", "resample", "multinomial_indices", "systematic_indices",
     "multinomial_torch_compat", "gather_rows", "FABModel", "PrioritisedReplayBuffer",
-    "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam", "WrappedTorchDist", "CircularCoupledRQSFlow", "make_wrapped_normflow_spline", "fast_mode",
+    "sample_without_replacement", "PrioritisedBufferTrainer", "Trainer", "FlatAdam", "CircularCoupledRQSFlow", "make_wrapped_normflow_spline", "fast_mode",
 ]

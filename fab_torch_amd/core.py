@@ -3,8 +3,11 @@ toggles the AIS target (`set_ais_target`, core.py:102-110), the FAB alpha-diverg
 (`fab_alpha_div_inner`, core.py:112-118: -sign(alpha) * mean(softmax(log_w) * log q(x))), iteration / evaluation
 info and checkpoints `{'flow': state_dict, 'trans_op': state_dict}` (core.py:222-260).
 
-The AIS call is the fused HIP path; `flow.log_prob(x)` inside the losses records an autograd graph w.r.t. the
-parameters (PyTorch-ROCm expression of the same maps)."""
+The AIS call is the fused HIP path; `flow.log_prob(x)` inside the losses is the differentiable custom op
+`fabhip::realnvp_logprob_tape` (HIP forward with a tape, HIP parameter-gradient kernels as its registered backward), the
+reparameterised baseline losses go through `fabhip::realnvp_sample_tape`.  The reference's experimental losses
+(core.py:134-170: `flow_alpha_2_div`, `flow_alpha_2_div_unbiased`, `fab_ub_alpha_2_div`), which its constructor refuses, are not
+carried."""
 import warnings
 from typing import Any, Dict, Optional
 
@@ -83,33 +86,11 @@ class FABModel:
     def inner_loss(self, point: Point, log_w_ais) -> torch.Tensor:
         if self.loss_type == "fab_alpha_div":
             return self.fab_alpha_div_inner(point, log_w_ais)
-        if self.loss_type == "fab_ub_alpha_2_div":
-            return self.fab_ub_alpha_div_loss_inner(point, log_w_ais)
-        raise NotImplementedError
+        raise NotImplementedError                          # ("fab_ub_alpha_2_div": experimental in the reference, refused at construction)
 
     def flow_reverse_kl(self, batch_size: int) -> torch.Tensor:
         x, log_q = self.flow.sample_and_log_prob((batch_size,))
         return torch.mean(log_q) - torch.mean(self.target_distribution.log_prob(x))
-
-    # the reference's experimental losses (core.py:134-170): refused by the constructor there and here, callable directly
-    def flow_alpha_2_div(self, batch_size: int) -> torch.Tensor:
-        x, log_q = self.flow.sample_and_log_prob((batch_size,))
-        return torch.logsumexp(2 * (self.target_distribution.log_prob(x) - log_q), 0)
-
-    def flow_alpha_2_div_unbiased(self, batch_size: int) -> torch.Tensor:
-        x, log_q_x = self.flow.sample_and_log_prob((batch_size,))
-        log_p_x = self.target_distribution.log_prob(x)
-        return torch.mean(torch.exp(2 * (log_p_x - log_q_x)) * log_q_x)
-
-    def fab_ub_alpha_div_loss_inner(self, point: Point, log_w_ais: torch.Tensor) -> torch.Tensor:
-        log_q_x = self.flow.log_prob(point.x)
-        return torch.logsumexp(log_w_ais + (point.log_p - log_q_x), dim=0)
-
-    def fab_ub_alpha_div_loss(self, batch_size: int) -> torch.Tensor:
-        # (the reference passes three arguments to the two-argument inner function here, core.py:166-168; the evident
-        # intent is the call below)
-        point_ais, log_w_ais = self.annealed_importance_sampler.sample_and_log_weights(batch_size)
-        return self.fab_ub_alpha_div_loss_inner(point_ais, log_w_ais)
 
     def flow_alpha_2_div_nis(self, batch_size: int) -> torch.Tensor:
         x, log_q_x = self.flow.sample_and_log_prob((batch_size,))

@@ -762,6 +762,10 @@ long long* debug_timeline(hipStream_t st) {
 }  // namespace fab
 
 namespace fab {
+bool r4f_lds_fits(const FlowDims& f) {
+    const R4Lds l = make_r4_lds(f, true);
+    return (size_t)(l.total + 4 * R4 * f.D + 4) * 4 <= 160 * 1024;
+}
 static int g_fast_mode = 0;
 int fast_mode() { return g_fast_mode; }
 

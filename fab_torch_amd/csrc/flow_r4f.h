@@ -228,21 +228,22 @@ struct R4FRing {
             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu & 0xffffffffull)));
         const unsigned dst = stash_m0 + K * G * 1024;
         // M0 = LDS byte address of the first tile; the immediate offset moves the global AND the LDS address (lane l -> + 16 l)
+        // (M0 is declared clobbered: hipcc may hold an indexing base in it across the statement otherwise - ADVICE r5)
         static_assert(G >= 2 && G <= 5, "");
         if constexpr (G == 2)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\t"
-                         "global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(voff0), "s"(b), "s"(dst) : "memory");
+                         "global_load_lds_dwordx4 %0, %1 offset:1024" :: "v"(voff0), "s"(b), "s"(dst) : "memory", "m0");
         else if constexpr (G == 3)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\t"
                          "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048"
-                         :: "v"(voff0), "s"(b), "s"(dst) : "memory");
+                         :: "v"(voff0), "s"(b), "s"(dst) : "memory", "m0");
         else
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\t"
                          "global_load_lds_dwordx4 %0, %1 offset:1024\n\tglobal_load_lds_dwordx4 %0, %1 offset:2048\n\t"
-                         "global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(voff0), "s"(b), "s"(dst) : "memory");
+                         "global_load_lds_dwordx4 %0, %1 offset:3072" :: "v"(voff0), "s"(b), "s"(dst) : "memory", "m0");
         if constexpr (G == 5)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:0"
-                         :: "v"(voff1), "s"(b), "s"(dst + 4096u) : "memory");
+                         :: "v"(voff1), "s"(b), "s"(dst + 4096u) : "memory", "m0");
     }
     // the tiles of stash item I have landed in LDS (loads return in order: at most `inflight_behind` younger ones are outstanding)
     template <int I>
@@ -497,7 +498,7 @@ __device__ __forceinline__ void r4f_prefetch_l2(const float* junk, unsigned voff
             ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu >> 32)) << 32) |
             (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(bu & 0xffffffffull)));
         const unsigned m0v = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)junk);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(b), "s"(m0v) : "memory");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 4\n\tglobal_load_lds_dword %0, %1" :: "v"(voff), "s"(b), "s"(m0v) : "memory", "m0");
     }
 }
 
@@ -792,10 +793,10 @@ __device__ float flow_sample_r4f(const FlowDims& f, const R4Lds& l, const float*
 // host side: the fused-stage variant is chosen where its image exists, FABHIP_OPT_R4_STREAM >= 2 (default) and the bias blocks of
 // all layers fit the CU's LDS next to the tile state (the transition kernel adds 4 x [4][D] floats of HMC state)
 int option(int key);                                   // (launch.h)
+bool r4f_lds_fits(const FlowDims& f);                  // (flow_kernels.hip)
 static inline bool use_r4_fused(const FlowDims& f) {
     if (f.o_r4f < 0 || f.NTW / 4 < 2 || f.NTW / 4 > 5 || option(FABHIP_OPT_R4_STREAM) < 2) return false;
-    const R4Lds l = make_r4_lds(f, true);
-    return (size_t)(l.total + 4 * R4 * f.D + 4) * 4 <= 160 * 1024;
+    return r4f_lds_fits(f);
 }
 
 }  // namespace fab

@@ -98,10 +98,12 @@ int tail_small(const TailArgs& a, int* dest, hipStream_t st);
 // mode (no bf16 variant).  FABHIP_OPT_TILE_SHAPE = 16 / 4 forces the choice (tests exercise both).  D <= 32 and hidden width <= 320
 // only (the other instantiations spill registers and are not compiled).  Used by the transitions, the chain initialisation and
 // the flow sample alike.
+bool r4f_lds_fits(const FlowDims& f);                  // (flow_kernels.hip: the LDS-fit test of use_r4_fused, flow_r4f.h)
 static inline bool use_r4_tiles(const FlowDims& f, long B) {
     if (f.D > 32 || f.NTW / 4 > 5) return false;
-    // fast mode: only where the fused-stage stream has its bf16 image (flow_r4f.h; round 5) - else the 16-chain fast kernels
-    if (f.fast && !(f.o_r4fh >= 0 && f.NTW / 4 >= 2 && option(FABHIP_OPT_R4_STREAM) >= 2)) return false;
+    // fast mode: only where the fused-stage stream has its bf16 image AND the fused kernel's LDS plan fits (flow_r4f.h; its bias
+    // blocks and ReLU masks grow with the layer count) - else the 16-chain fast kernels, never silently the fp32 stream
+    if (f.fast && !(f.o_r4fh >= 0 && f.NTW / 4 >= 2 && option(FABHIP_OPT_R4_STREAM) >= 2 && r4f_lds_fits(f))) return false;
     const int shape = option(FABHIP_OPT_TILE_SHAPE);
     if (shape == 16 || shape == 8) return false;
     if (shape == 4) return true;

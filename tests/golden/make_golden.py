@@ -482,6 +482,66 @@ def g16_rejecting(name="g16_ais_headline_rejecting.npz", std=0.01, eps_init=0.26
     return out
 
 
+def g17_step_size_trajectory(name="g17_step_size_trajectory.npz", std=0.01, seed=170, B=64, calls=6):
+    """a MULTI-CALL step-size trajectory at the headline architecture (D = 32, 10 x (16-320-320-32), M = 8,
+    L = 5) from the shipped `init_step_size: 1.0` (experiments/config/many_well.yaml:24-29) with tuning ON: the reference's
+    `sample_and_log_weights` called `calls` times in a row on ONE sampler, so that every call starts from the step sizes the
+    previous one left (hmc.py:90-100,162-170).  At this step size nearly every proposal is rejected (p_accept ~ 0): the rule
+    divides on every transition, the chains stay where the flow put them, and an accept decision is never close to its threshold -
+    the fixture therefore needs no selection of chains (asserted below: the smallest reject margin over all calls).  Stored per call:
+    base noise, momenta, Exp(1) draws, incoming / outgoing step sizes, the returned point and log-weights."""
+    from helpers import seeded_oracle_flow
+    D, K, nodes, M, L, alpha = 32, 10, 10, 8, 5, 2.0
+    nf = seeded_oracle_flow(D, K, nodes, seed, std)
+    target = ManyWellEnergy(dim=D, use_gpu=False)
+    hmc = tuned_hmc(M, D, nf, target, 1.0, L, 1, alpha, False, tune=True)
+    base = EpsFlow(nf, None)
+    ais = AnnealedImportanceSampler(base, target.log_prob, hmc, p_target=False, alpha=alpha, n_intermediate_distributions=M)
+    torch.manual_seed(seed + 1)
+    rec = {k: [] for k in ("eps0", "noise_p", "noise_e", "in_epsilons", "in_common_epsilon", "out_epsilons", "out_common_epsilon",
+                           "out_x", "out_log_q", "out_log_p", "log_w", "p_accept_first", "moved")}
+    margins = []
+    orig_accept = hmc.metropolis_accept
+
+    def recording_accept(point_proposed, point_current, p_proposed, p_current, beta):        # hmc.py:105-124
+        with Capture() as c2:
+            out = orig_accept(point_proposed, point_current, p_proposed, p_current, beta)
+        recording_accept.expo.append(c2.expo[-1])
+        return out
+    for c in range(calls):
+        base.eps = torch.randn(B, D)
+        rec["eps0"].append(base.eps.clone())
+        rec["in_epsilons"].append(hmc.epsilons.clone()); rec["in_common_epsilon"].append(hmc.common_epsilon.clone())
+        with Capture() as cap:
+            pt, log_w = ais.sample_and_log_weights(B)
+        info = ais.get_logging_info()
+        with torch.no_grad():
+            x0, _ = nf.sample_eps(base.eps)
+        rec["noise_p"].append(torch.stack(cap.randn_like)[:, None]); rec["noise_e"].append(torch.stack(cap.expo)[:, None])
+        rec["out_epsilons"].append(hmc.epsilons.clone()); rec["out_common_epsilon"].append(hmc.common_epsilon.clone())
+        rec["out_x"].append(pt.x.clone()); rec["out_log_q"].append(pt.log_q.clone()); rec["out_log_p"].append(pt.log_p.clone())
+        rec["log_w"].append(log_w.clone()); rec["p_accept_first"].append(torch.tensor(float(info["dist0_p_accept_0"])))
+        rec["moved"].append((pt.x != x0).any(1))
+        assert pt.x.shape[0] == B, "a chain was dropped: pick another seed"
+    out = {k: torch.stack(v) for k, v in rec.items()}
+    frac_moved = float(out["moved"].float().mean())
+    print(f"g17: {calls} calls from epsilon 1.0: common_epsilon {float(out['in_common_epsilon'][0]):.4f} -> "
+          f"{float(out['out_common_epsilon'][-1]):.4f}, epsilons[0] {float(out['in_epsilons'][0][0, 0]):.4f} -> "
+          f"{float(out['out_epsilons'][-1][0, 0]):.4f}; p_accept (first transition) per call "
+          f"{[round(float(v), 5) for v in out['p_accept_first']]}; chains that moved at all: {frac_moved:.3f}")
+    # every transition of every call divided its step size (the mean acceptance stayed far below 0.65, hmc.py:165-170)
+    for c in range(calls):
+        assert torch.allclose(out["out_epsilons"][c], out["in_epsilons"][c] / 1.05)
+        assert torch.allclose(out["out_common_epsilon"][c], out["in_common_epsilon"][c] / 1.02 ** M)
+        if c:
+            assert torch.equal(out["in_epsilons"][c], out["out_epsilons"][c - 1])
+    out.update(D=D, K=K, nodes=nodes, flow_seed=seed, flow_std=std, M=M, L=L, alpha=alpha, p_target=0, B_space=ais.B_space,
+               flow_probe=torch.stack([nf.flows[0].flows[1].param_map.net[2].weight[0, :8].detach(),
+                                       nf.flows[-2].flows[1].param_map.net[4].weight[1, :8].detach()]))
+    npz(name, **out)
+    return out
+
+
 def g9_buffer():
     """Deterministic part of the reference's PrioritisedReplayBuffer (add ring wrap-around, adjust incl. the
     invalid-entry kill); sampling itself is random and is tested through properties."""
@@ -765,3 +825,5 @@ if __name__ == "__main__":
     g14_headline_arch("g15_ais_headline_mild.npz", std=0.01, eps_init=0.05, seed=150)
     # g16: the same architecture with BOTH accept outcomes and no ill-conditioned chain (a selection from a pool, see g16_rejecting)
     g16_rejecting()
+    # g17: six calls in a row from the shipped initial step size, tuning on (the step-size state carried from call to call)
+    g17_step_size_trajectory()

@@ -118,8 +118,9 @@ def test_wrapped_torch_dist_base_with_a_native_target_runs_the_generic_path():
     WrappedTorchDist.  Statistical check: AIS towards p improves the ESS over plain importance sampling."""
     D, M, B = 6, 8, 512
     torch.manual_seed(0)
-    base = fa.WrappedTorchDist(torch.distributions.MultivariateNormal(torch.zeros(D, device=DEV),
-                                                                      scale_tril=1.5 * torch.eye(D, device=DEV)))
+    from torch_dist_plugin import WrappedTorchDist
+    base = WrappedTorchDist(torch.distributions.MultivariateNormal(torch.zeros(D, device=DEV),
+                                                                   scale_tril=1.5 * torch.eye(D, device=DEV)))
     target = fa.ManyWellEnergy(D)
     hmc = fa.HamiltonianMonteCarlo(M, D, base.log_prob, target.log_prob, alpha=2.0, p_target=True, epsilon=0.3, L=5).to(DEV)
     ais = fa.AnnealedImportanceSampler(base, target.log_prob, hmc, True, None, M)

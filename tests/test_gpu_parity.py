@@ -545,6 +545,51 @@ def test_headline_architecture_mild_regime_no_waivers(shape, fixture):
         assert abs(info["dist0_p_accept_0"] - float(g["dist0_p_accept_0"])) < 1e-3
 
 
+@pytest.mark.parametrize("shape", [4, 8, 16])
+def test_multi_call_step_size_trajectory_from_the_shipped_initial_step_size(shape):
+    """the reference's `sample_and_log_weights` called six times in a row on one sampler from
+    `init_step_size: 1.0` (experiments/config/many_well.yaml:24-29), tuning on, headline architecture (D = 32, W = 320, M = 8, L = 5),
+    64 chains.  At this step size every proposal is rejected (hmc.py:105-124: the proposals overflow), every transition divides its
+    step sizes (hmc.py:162-170) and each call starts from what the previous one left (hmc.py:90-100).  On all three tile shapes:
+    (a) every call teacher-forced on the reference's INCOMING step sizes: the returned point / log-weights within 1e-4, no chain
+        moved, outgoing epsilons / common_epsilon BIT-equal to the reference's, p_accept exactly 0;
+    (b) ONE sampler free-running over the six calls: the epsilons / common_epsilon sequence bit-equal after every call."""
+    from helpers import flow_from_g14
+    g = load_golden("g17_step_size_trajectory.npz")
+    nf = flow_from_g14(g)
+    hf = hip_flow_from_oracle(nf)
+    D, M, L, alpha = int(g["D"]), int(g["M"]), int(g["L"]), float(g["alpha"])
+    calls, B = g["eps0"].shape[0], g["eps0"].shape[1]
+    assert calls == 6 and B == 64 and not g["moved"].any() and float(g["p_accept_first"].max()) == 0.0
+    target = fa.ManyWellEnergy(D)
+    T = lambda k, c: torch.tensor(g[k][c]).to(DEV)      # noqa: E731
+    with _ops.option(_ops.OPT_TILE_SHAPE, shape):
+        free = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=alpha, p_target=False, epsilon=1.0, L=L).to(DEV)
+        np.testing.assert_array_equal(free.epsilons.cpu().numpy(), g["in_epsilons"][0])           # the shipped initialisation
+        np.testing.assert_array_equal(free.common_epsilon.cpu().numpy(), g["in_common_epsilon"][0])
+        ais_free = fa.AnnealedImportanceSampler(hf, target.log_prob, free, False, alpha, M)
+        np.testing.assert_array_equal(ais_free.B_space.numpy(), g["B_space"])
+        for c in range(calls):
+            # (a) teacher-forced on the reference's incoming state
+            hmc = fa.HamiltonianMonteCarlo(M, D, hf.log_prob, target.log_prob, alpha=alpha, p_target=False, epsilon=1.0, L=L).to(DEV)
+            hmc.epsilons.copy_(T("in_epsilons", c)); hmc.common_epsilon.copy_(T("in_common_epsilon", c))
+            ais = fa.AnnealedImportanceSampler(hf, target.log_prob, hmc, False, alpha, M)
+            pt, log_w = ais.sample_and_log_weights(B, eps0=T("eps0", c), noise_a=T("noise_p", c), noise_b=T("noise_e", c))
+            assert pt.x.shape[0] == B
+            x0, _ = hf.sample_and_log_prob((B,), eps=T("eps0", c))
+            assert torch.equal(pt.x, x0), f"call {c}: a chain moved"
+            assert max_rel_err(pt.x, g["out_x"][c]) <= RTOL
+            assert close(pt.log_q, g["out_log_q"][c], RTOL) and close(pt.log_p, g["out_log_p"][c], RTOL)
+            assert close(log_w, g["log_w"][c], RTOL), f"call {c}: log_w err {max_rel_err(log_w, g['log_w'][c]):.2e}"
+            np.testing.assert_array_equal(hmc.epsilons.cpu().numpy(), g["out_epsilons"][c])
+            np.testing.assert_array_equal(hmc.common_epsilon.cpu().numpy(), g["out_common_epsilon"][c])
+            assert ais.get_logging_info()["dist0_p_accept_0"] == 0.0
+            # (b) the free-running sampler: its own state from the previous call
+            ais_free.sample_and_log_weights(B, eps0=T("eps0", c), noise_a=T("noise_p", c), noise_b=T("noise_e", c))
+            np.testing.assert_array_equal(free.epsilons.cpu().numpy(), g["out_epsilons"][c])
+            np.testing.assert_array_equal(free.common_epsilon.cpu().numpy(), g["out_common_epsilon"][c])
+
+
 def test_full_ais_metropolis_vs_reference_golden():
     g = load_golden("g8_ais_gmm_metropolis.npz")
     nf = oracle_flow_from_golden(g)

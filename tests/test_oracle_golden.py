@@ -216,6 +216,29 @@ def test_g14_headline_architecture_ais_matches_reference(fixture):
     assert abs(info.log_Z - float(g["log_Z"])) <= RTOL * abs(float(g["log_Z"])) + 1e-4
 
 
+def test_g17_multi_call_step_size_trajectory_matches_reference():
+    """g17: six reference calls in a row from `init_step_size: 1.0`, tuning on, at the headline architecture -
+    every proposal rejected, every transition divides its step sizes, each call starts from the previous call's state.  The oracle
+    (ONE sampler, its own state carried from call to call) reproduces every call's outputs and the step sizes bit for bit."""
+    from helpers import flow_from_g14
+    g = load_golden("g17_step_size_trajectory.npz")
+    nf = flow_from_g14(g)
+    D, M = int(g["D"]), int(g["M"])
+    target = otgt.ManyWell(D)
+    hmc = oais.HMC(M, D, nf.log_prob, target.log_prob, alpha=float(g["alpha"]), p_target=False, epsilon=1.0, L=int(g["L"]))
+    ais = oais.AIS(lambda e: _noq(nf, e), nf.log_prob, target.log_prob, hmc, False, float(g["alpha"]), M)
+    for c in range(g["eps0"].shape[0]):
+        np.testing.assert_array_equal(hmc.epsilons.numpy(), g["in_epsilons"][c])
+        np.testing.assert_array_equal(hmc.common_epsilon.numpy(), g["in_common_epsilon"][c])
+        pt, log_w, info = ais.sample_and_log_weights(torch.tensor(g["eps0"][c]), torch.tensor(g["noise_p"][c]),
+                                                     torch.tensor(g["noise_e"][c]))
+        assert close(pt.x, g["out_x"][c], 1e-5) and close(log_w, g["log_w"][c], 1e-4)
+        assert close(pt.log_q, g["out_log_q"][c], 1e-4) and close(pt.log_p, g["out_log_p"][c], 1e-4)
+        np.testing.assert_array_equal(hmc.epsilons.numpy(), g["out_epsilons"][c])
+        np.testing.assert_array_equal(hmc.common_epsilon.numpy(), g["out_common_epsilon"][c])
+    assert not g["moved"].any()
+
+
 def _noq(nf, e):
     with torch.no_grad():
         return nf.sample_eps(e)

@@ -1,7 +1,7 @@
-"""`WrappedTorchDist` - a `torch.distributions` object behind the `Distribution` plug-in interface, as in
-fab/wrappers/torch.py:7-24 (the base distribution of the reference's own AIS tests, ais_test.py:98-99).  It is a
-GENERIC plug-in: the sampler evaluates it with its own torch code and runs the transitions through the generic HIP
-path (transition_operators.py)."""
+"""Test infrastructure (not part of the package: the reference's alternative flow adapters are out of scope, SURVEY.md section 2
+row 4): a `torch.distributions` object behind the `Distribution` plug-in interface (fab/types_.py:8-27), the kind of base
+distribution the reference's own AIS tests use (ais_test.py:98-99) - a GENERIC plug-in for tests/test_gpu_generic_path.py: the
+sampler evaluates it with its own torch code and runs the transitions through the generic HIP path."""
 from typing import Tuple
 
 import torch

@@ -76,31 +76,70 @@ def measure(dev, iters=20, warm=5):
     return out, trainer
 
 
-def kernel_rows(trainer, dev, n=20):
-    """Stand-alone HIP-event timings of the two training kernels on a 2048-row minibatch (medians of n)."""
-    flow = trainer.model.flow
-    x = torch.randn(BATCH, D, device=dev)
-    coef = torch.full((BATCH,), -1.0 / BATCH, device=dev)
-
-    def ev_time(fn):
+def _graph_time(fn, dev, n=20):
+    """Seconds per call of `fn` as the GPU executes it: the call is captured into a HIP graph once (its launches, no host work)
+    and replayed n times between two HIP events - a Python-level loop of op calls measures the host (one op call costs more
+    host time than these kernels take)."""
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream(dev))
+    with torch.cuda.stream(s):
         for _ in range(3):
             fn()
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
-        ev[0].record()
-        for i in range(n):
-            fn()
-            ev[i + 1].record()
-        torch.cuda.synchronize(dev)
-        return sorted(ev[i].elapsed_time(ev[i + 1]) for i in range(n))[n // 2] * 1e-3
+    torch.cuda.current_stream(dev).wait_stream(s)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        fn()
+    for _ in range(3):
+        g.replay()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return e0.elapsed_time(e1) * 1e-3 / n
 
-    t_tape = ev_time(lambda: flow.log_prob_with_tape(x))
-    _, tape = flow.log_prob_with_tape(x)
-    t_pg = ev_time(lambda: flow.param_grad_flat(tape, coef))
-    rows = {}
-    for name, t, flop in (("tape_forward_reverse", t_tape, 2 * BATCH * F_FWD), ("param_grad", t_pg, BATCH * F_PGRAD)):
+
+def kernel_rows(trainer, dev, n=20):
+    """GPU time of the two training computations on a 2048-row minibatch (HIP-graph replays, see _graph_time) and of one whole
+    minibatch step (fabhip::buffer_train_step: pack, tape, weights, gradients, Adam)."""
+    from fab_torch_amd import _ops
+    flow, opt, buf = trainer.model.flow, trainer.optimizer, trainer.buffer
+    x = torch.randn(BATCH, D, device=dev)
+    coef = torch.full((BATCH,), -1.0 / BATCH, device=dev)
+    with torch.no_grad():
+        t_tape = _graph_time(lambda: flow.log_prob_with_tape(x), dev, n)
+        _, tape = flow.log_prob_with_tape(x)
+        t_pg = _graph_time(lambda: flow.param_grad_flat(tape, coef), dev, n)
+        ops = _ops.load()
+        packed, Dd, K, W = flow.native(need_inverse=False)
+        rows = torch.randperm(buf.current_index if not buf.is_full else buf.max_length, device=dev)[:BATCH].contiguous()
+        grp = opt.param_groups[0]
+        theta = opt.theta.detach()
+        blw, blq = buf.buffer.log_w.clone(), buf.buffer.log_q_old.clone()       # (the timing replays must not walk the real buffer)
+        th, m, v, steps = theta.clone(), opt.m.clone(), opt.v.clone(), opt.steps.clone()
+
+        def one_step():
+            ops.buffer_train_step(flow._own_handle(), packed, Dd, K, W, True, buf.buffer.x, rows, blq, True, ALPHA, 0.0, blw, blq,
+                                  theta, opt.m, opt.v, float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
+                                  float(grp["eps"]), opt.steps, MAX_GRAD_NORM)
+        t_step = _graph_time(one_step, dev, n)
+        theta.copy_(th); opt.m.copy_(m); opt.v.copy_(v); opt.steps.copy_(steps)    # undo the timing replays' optimiser steps
+        flow._packed_key = None
+    out = {}
+    for name, kern, t, flop in (("tape_forward_reverse", "k_flow_log_prob_tape_r8<5> (8 chains per workgroup, 256 workgroups)", t_tape,
+                                 2 * BATCH * F_FWD),
+                                ("param_grad", "k_pgrad_tiles<0> + k_pgrad_tiles<1> (one workgroup per output tile) + k_affine_grads",
+                                 t_pg, BATCH * F_PGRAD)):
         ach = flop / t / 1e12
-        rows[name] = {"us_per_call": t * 1e6, "flop": flop, "achieved_TFLOPs": ach, "frac_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS}
-    return rows
+        out[name] = {"kernel": kern, "us_per_call": t * 1e6, "flop": flop, "achieved_TFLOPs": ach,
+                     "frac_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
+                     "timing": "HIP-graph replays of the op between two HIP events (GPU time of its launches, no host gaps); "
+                               "per-kernel rows: profiles/r6/trainer_kernel_stats_rocprofv3.csv"}
+    out["minibatch_step"] = {"op": "fabhip::buffer_train_step (training pack, tape, loss weights + buffer.adjust, parameter "
+                                   "gradients, LU chain rule, clipped Adam)", "us_per_call": t_step * 1e6,
+                             "timing": "HIP-graph replays"}
+    return out
 
 
 if __name__ == "__main__":
