@@ -50,9 +50,28 @@ static inline size_t tape_ga_offset(const TapeDims& td) { return (size_t)td.tota
 // all weight / bias gradients + the affine dW scratch (ga_ws) + the base distribution's gradients from a tape (train_step.hip)
 int launch_param_grad_tiles(const FlowDims& f, const TapeDims& td, const GradLayout& gl, const float* tape, const float* coef,
                             long B, float* grads, float* ga_ws, hipStream_t st);
+// The arithmetic between `log_q_x = flow.log_prob(x)` and `loss.backward()` of one replay-buffer minibatch, and the buffer's
+// `adjust`, in the TAIL of the 8-chain tape kernel (each workgroup has the log q of its 8 rows): per row log_w_adjust, the weight
+// w (coef = -w / B), the buffer update; per wave (4 rows) the partial sums of the loss and of the logging statistics.  The optimiser
+// step's first launch adds the partials in order and decides the skip of a non-finite loss.  coef == nullptr: no tail.
+struct MbTail {
+    const float* log_q_old;            // the buffer's log_q_old (read at rows[g]) or, rows_old == 0, the minibatch's own [B]
+    int rows_old;
+    float one_minus_alpha, w_clip, neg_inv_B;
+    float *coef, *log_w_adjust;        // [B] out
+    float *buf_log_w, *buf_log_q_old;  // adjusted in place at rows[g] (nullptr: no adjust)
+    float* partials;                   // [2 * workgroups][8]: sum w lq | sum exp(adj) | sum lq | min | max | saw NaN
+};
+constexpr int MB_PART = 8;
+
 // the 8-chain-tile tape forward (train_step.hip); FABHIP_ENOTSUP where the 8-chain image does not exist
 int launch_log_prob_tape_r8(const FlowDims& f, const TapeDims& td, const float* packed, const float* x, const int64_t* rows,
-                            float* log_q, float* grad, float* tape, long B, hipStream_t st);
+                            float* log_q, float* grad, float* tape, long B, hipStream_t st, const MbTail* mb = nullptr);
+// fabhip_adam_clip_step with the minibatch's loss partials (train_kernels.hip): the norm launch's block 0 adds them, writes
+// stats[0 .. 4] (loss, mean / min / max of exp(log_w_adjust), mean log q) and the update is skipped when the loss is not finite
+int adam_clip_step_impl(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        int32_t* step_count, float max_norm, float* grad_norm_out, void* workspace, size_t workspace_bytes,
+                        const float* mb_partials, int n_partials, float* stats, long B, hipStream_t st);
 // LU chain rule of the InvertibleAffine layers (+ ActNorm) from ga_ws (train_kernels.hip)
 int launch_affine_grads(const FlowDims& f, const TapeDims& td, const GradLayout& gl, const fabhip_flow_params* params,
                         const float* ga_ws, float* grads, const float* tape, const float* coef, long B, hipStream_t st);

@@ -656,17 +656,54 @@ namespace fab {
 
 constexpr int ADAM_BLOCKS = 512;
 
-__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, long n, double* __restrict__ part,
-                                                        int* __restrict__ steps_copy, const int* __restrict__ step_count) {
-    __shared__ double red[256];
+// the minibatch's loss and logging statistics from the partial sums the tape kernel's tail left (MbTail): one extra workgroup of the
+// norm launch, thread t adds partials t, t + 256, ... in order, then a fixed tree over the threads; the flag `loss_ok` makes
+// k_adam_clip skip the update of a non-finite loss (fab/train_with_prioritised_buffer.py:172-181)
+__device__ void mb_finish(const float* __restrict__ part, int n_part, long B, float* __restrict__ stats, int* __restrict__ loss_ok,
+                          float (*red)[256]) {
     const int tid = threadIdx.x;
+    float t[6] = {0.f, 0.f, 0.f, INFINITY, -INFINITY, 0.f};
+    for (int i = tid; i < n_part; i += 256) {
+        const float* p = part + (size_t)i * MB_PART;
+        t[0] += p[0]; t[1] += p[1]; t[2] += p[2]; t[3] = fminf(t[3], p[3]); t[4] = fmaxf(t[4], p[4]); t[5] += p[5];
+    }
+    for (int q = 0; q < 6; ++q) red[q][tid] = t[q];
+    __syncthreads();
+    for (int k = 128; k > 0; k >>= 1) {
+        if (tid < k) {
+            red[0][tid] += red[0][tid + k]; red[1][tid] += red[1][tid + k]; red[2][tid] += red[2][tid + k];
+            red[3][tid] = fminf(red[3][tid], red[3][tid + k]); red[4][tid] = fmaxf(red[4][tid], red[4][tid + k]);
+            red[5][tid] += red[5][tid + k];
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const float Bf = (float)B, loss = -(red[0][0] / Bf);
+        const bool sawnan = red[5][0] > 0.f;                  // torch.min / max propagate NaN
+        stats[0] = loss; stats[1] = red[1][0] / Bf; stats[2] = sawnan ? NAN : red[3][0]; stats[3] = sawnan ? NAN : red[4][0];
+        stats[4] = red[2][0] / Bf; stats[6] = 0.f; stats[7] = 0.f;
+        *loss_ok = isfinite(loss) ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sqnorm_partial(const float* __restrict__ g, long n, double* __restrict__ part, int nblk,
+                                                        int* __restrict__ steps_copy, const int* __restrict__ step_count,
+                                                        const float* __restrict__ mb_part, int n_mb, long B,
+                                                        float* __restrict__ stats) {
+    __shared__ double red[256];
+    __shared__ float redf[6][256];
+    const int tid = threadIdx.x;
+    if ((int)blockIdx.x == nblk) {                            // the extra workgroup (launched only with a minibatch tail)
+        mb_finish(mb_part, n_mb, B, stats, steps_copy + 1, redf);
+        return;
+    }
     // the step counter as k_adam_clip (the launch behind this one) sees it: its blocks read this copy, its block 0 writes the
     // counter itself - no third launch and no block reads what another one writes
-    if (blockIdx.x == 0 && tid == 0) *steps_copy = *step_count;
+    if (blockIdx.x == 0 && tid == 0) { steps_copy[0] = *step_count; if (!mb_part) steps_copy[1] = 1; }
     double s = 0.0;
     const long n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
-    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)gridDim.x * 256) {
+    for (long i = (long)blockIdx.x * 256 + tid; i < n4; i += (long)nblk * 256) {
         const float4 v = g4[i];
         s += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
     }
@@ -720,7 +757,8 @@ __global__ __launch_bounds__(256) void k_adam_clip(float* __restrict__ theta, co
         }
     }
     __syncthreads();
-    const float total = bc[0];
+    const bool loss_ok = steps_copy[1] != 0;                    // (a non-finite minibatch loss: "nan loss in replay step")
+    const float total = loss_ok ? bc[0] : NAN;
     if (blockIdx.x == 0 && tid == 0) *norm_out = total;
     const bool apply = isfinite(total);                         // "nan grad norm": no step
     if (apply) {
@@ -752,6 +790,35 @@ __global__ __launch_bounds__(256) void k_adam_clip(float* __restrict__ theta, co
     if (blockIdx.x == 0 && tid == 0 && apply) *step_count = *steps_copy + 1;
 }
 
+int adam_clip_step_impl(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        int32_t* step_count, float max_norm, float* grad_norm_out, void* workspace, size_t workspace_bytes,
+                        const float* mb_partials, int n_partials, float* stats, long B, hipStream_t st) {
+    if (!theta || !grad || !m || !v || n < 1 || !step_count || !workspace) return FABHIP_EINVAL;
+    if (workspace_bytes < fabhip_adam_workspace_bytes(n)) return FABHIP_ENOSPC;
+    if (((uintptr_t)grad & 15) != 0 || ((uintptr_t)workspace & 7) != 0) return FABHIP_EINVAL;
+    if (mb_partials && (!stats || n_partials < 1 || B < 1)) return FABHIP_EINVAL;
+    double* part = (double*)workspace;
+    int* steps_copy = (int*)(part + ADAM_BLOCKS);             // [0] the step counter as the update launch sees it, [1] loss finite
+    const long per = 256 * 4;
+    int nb = (int)((n + per - 1) / per);
+    if (nb > ADAM_BLOCKS) nb = ADAM_BLOCKS;
+    hipLaunchKernelGGL(k_sqnorm_partial, dim3(nb + (mb_partials ? 1 : 0)), dim3(256), 0, st, grad, (long)n, part, nb, steps_copy,
+                       (const int*)step_count, mb_partials, n_partials, B, stats);
+    AdamK a;
+    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
+    float* norm = grad_norm_out ? grad_norm_out : (float*)(steps_copy + 2);
+    const bool vec = (((uintptr_t)theta | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
+    int nb2 = (int)((n + per - 1) / per);          // one float4 per thread (a second trip of a few threads doubles the launch)
+    if (nb2 > 8192) nb2 = 8192;
+    if (vec)
+        hipLaunchKernelGGL(k_adam_clip<true>, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
+                           (int*)step_count, norm, (const int*)steps_copy);
+    else
+        hipLaunchKernelGGL(k_adam_clip<false>, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
+                           (int*)step_count, norm, (const int*)steps_copy);
+    return check_launch();
+}
+
 }  // namespace fab
 
 extern "C" {
@@ -761,29 +828,8 @@ size_t fabhip_adam_workspace_bytes(int64_t n) { (void)n; return (size_t)fab::ADA
 int fabhip_adam_clip_step(float* theta, const float* grad, float* m, float* v, int64_t n, float lr, float beta1,
                           float beta2, float eps, int32_t* step_count, float max_norm, float* grad_norm_out,
                           void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
-    if (!theta || !grad || !m || !v || n < 1 || !step_count || !workspace) return FABHIP_EINVAL;
-    if (workspace_bytes < fabhip_adam_workspace_bytes(n)) return FABHIP_ENOSPC;
-    if (((uintptr_t)grad & 15) != 0 || ((uintptr_t)workspace & 7) != 0) return FABHIP_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
-    double* part = (double*)workspace;
-    int* steps_copy = (int*)(part + fab::ADAM_BLOCKS);
-    const long per = 256 * 4;
-    int nb = (int)((n + per - 1) / per);
-    if (nb > fab::ADAM_BLOCKS) nb = fab::ADAM_BLOCKS;
-    hipLaunchKernelGGL(fab::k_sqnorm_partial, dim3(nb), dim3(256), 0, st, grad, (long)n, part, steps_copy, (const int*)step_count);
-    fab::AdamK a;
-    a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.max_norm = max_norm;
-    float* norm = grad_norm_out ? grad_norm_out : (float*)(steps_copy + 2);
-    const bool vec = (((uintptr_t)theta | (uintptr_t)m | (uintptr_t)v) & 15) == 0;
-    int nb2 = (int)((n + per - 1) / per);          // one float4 per thread (a second trip of a few threads doubles the launch)
-    if (nb2 > 8192) nb2 = 8192;
-    if (vec)
-        hipLaunchKernelGGL(fab::k_adam_clip<true>, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
-                           (int*)step_count, norm, (const int*)steps_copy);
-    else
-        hipLaunchKernelGGL(fab::k_adam_clip<false>, dim3(nb2), dim3(256), 0, st, theta, grad, m, v, (long)n, a, part, nb,
-                           (int*)step_count, norm, (const int*)steps_copy);
-    return fab::check_launch();
+    return fab::adam_clip_step_impl(theta, grad, m, v, n, lr, beta1, beta2, eps, step_count, max_norm, grad_norm_out, workspace,
+                                    workspace_bytes, nullptr, 0, nullptr, 0, (hipStream_t)stream);
 }
 
 int fabhip_tape_gemm(const float* Y, int64_t y_layer_stride, int32_t ldy, int32_t P, const float* X, int64_t x_layer_stride,

@@ -349,7 +349,7 @@ template <int G>
 __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape_r8(FlowDims f, R8Lds l, TapeDims td, const float* __restrict__ packed,
                                                                     const float* __restrict__ x, const int64_t* __restrict__ rows,
                                                                     float* __restrict__ log_q, float* __restrict__ grad,
-                                                                    float* __restrict__ tape, long B) {
+                                                                    float* __restrict__ tape, long B, MbTail mb) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NT = NTHREADS;
     Tid8f t8;
@@ -377,19 +377,49 @@ __global__ __launch_bounds__(NTHREADS) void k_flow_log_prob_tape_r8(FlowDims f, 
         if (grad)
             for (int j = t8.c; j < D; j += 16) grad[g * D + j] = lds[goff + t8.row * R4_DS + j];
     }
+    if (!mb.coef) return;
+    // the minibatch arithmetic (train_with_prioritised_buffer.py:162-170, prioritised_replay_buffer.py:117-131) on this row
+    float s_wl = 0.f, s_w = 0.f, s_l = 0.f, mn = INFINITY, mx = -INFINITY, nanf_ = 0.f;
+    if (g < B && t8.c == 0) {
+        const long row = rows ? (long)rows[g] : g;
+        const float lqo = mb.log_q_old[mb.rows_old ? row : g];
+        const float adj = mb.one_minus_alpha * (lq - lqo);
+        const float wp = expf(adj);
+        const float w = (mb.w_clip > 0.f && wp > mb.w_clip) ? mb.w_clip : wp;     // torch.clip(max=): NaN stays NaN
+        mb.log_w_adjust[g] = adj;
+        mb.coef[g] = w * mb.neg_inv_B;
+        s_wl = w * lq; s_w = wp; s_l = lq; mn = wp; mx = wp; nanf_ = wp != wp ? 1.f : 0.f;
+        if (mb.buf_log_w) {
+            const bool valid = isfinite(adj) && isfinite(lq);
+            mb.buf_log_w[row] = valid ? mb.buf_log_w[row] + adj : -INFINITY;
+            if (valid) mb.buf_log_q_old[row] = lq;
+        }
+    }
+    // the wave's four rows (lanes 0, 16, 32, 48) in row order
+    const int lane = t8.lane;
+    auto rowsum = [&](float v) { return (__shfl(v, 0) + __shfl(v, 16)) + (__shfl(v, 32) + __shfl(v, 48)); };
+    const float a0 = rowsum(s_wl), a1 = rowsum(s_w), a2 = rowsum(s_l), a5 = rowsum(nanf_);
+    const float a3 = fminf(fminf(__shfl(mn, 0), __shfl(mn, 16)), fminf(__shfl(mn, 32), __shfl(mn, 48)));
+    const float a4 = fmaxf(fmaxf(__shfl(mx, 0), __shfl(mx, 16)), fmaxf(__shfl(mx, 32), __shfl(mx, 48)));
+    if (lane == 0) {
+        float* p = mb.partials + ((size_t)2 * blockIdx.x + t8.wave) * MB_PART;
+        p[0] = a0; p[1] = a1; p[2] = a2; p[3] = a3; p[4] = a4; p[5] = a5;
+    }
 }
 
 int launch_log_prob_tape_r8(const FlowDims& f, const TapeDims& td, const float* packed, const float* x, const int64_t* rows,
-                            float* log_q, float* grad, float* tape, long B, hipStream_t st) {
+                            float* log_q, float* grad, float* tape, long B, hipStream_t st, const MbTail* mb) {
     if (!r8_shape_ok(f)) return FABHIP_ENOTSUP;
     const R8Lds l = make_r8_lds(f);
     const size_t bytes = (size_t)l.total * 4;
     const dim3 grid((unsigned)(td.Bp / R8));                  // every row of the tape (Bp: a multiple of 16) is written
+    MbTail m;
+    if (mb) m = *mb; else { m = MbTail(); m.coef = nullptr; }
 #define FAB_R8_TAPE(G)                                                                                              \
     do {                                                                                                            \
         FAB_TRY(set_max_lds((const void*)k_flow_log_prob_tape_r8<G>, bytes));                                       \
         hipLaunchKernelGGL((k_flow_log_prob_tape_r8<G>), grid, dim3(NTHREADS), bytes, st, f, l, td, packed, x, rows, log_q, grad, \
-                           tape, B);                                                                                \
+                           tape, B, m);                                                                                \
     } while (0)
     if (f.Wp == 320) FAB_R8_TAPE(5);
     else if (f.Wp == 256) FAB_R8_TAPE(4);
@@ -513,7 +543,9 @@ extern "C" {
 size_t fabhip_train_step_workspace_bytes(int32_t dim, int32_t n_layers, int32_t width, int64_t B, int64_t n_params) {
     const size_t tape = fabhip_flow_tape_bytes(dim, n_layers, width, B);
     if (tape == 0 || B < 1 || n_params < 1) return 0;
-    return ((tape + 255) & ~(size_t)255) + ((fabhip_adam_workspace_bytes(n_params) + 255) & ~(size_t)255);
+    // tape | optimiser scratch | loss partials of the tape kernel's tail (two per 8-row workgroup)
+    return ((tape + 255) & ~(size_t)255) + ((fabhip_adam_workspace_bytes(n_params) + 255) & ~(size_t)255) +
+           (((size_t)(B + 15) / 16 * 4 * MB_PART * sizeof(float) + 255) & ~(size_t)255);
 }
 
 int fabhip_buffer_train_step(const fabhip_train_step_args* a, fabhip_stream_t stream) {
@@ -532,24 +564,40 @@ int fabhip_buffer_train_step(const fabhip_train_step_args* a, fabhip_stream_t st
     hipStream_t st = (hipStream_t)stream;
     // 1. the image of the current parameters (the optimiser step of the previous minibatch changed them)
     if (a->repack) FAB_TRY(fabhip_flow_pack_train(p, a->packed, stream));
-    // 2. log q(x) with the tape, the minibatch read in place from the buffer
+    // 2. log q(x) with the tape, the minibatch read in place from the buffer; 3. weights of the loss, its value, the buffer's
+    // adjustment: in the tail of the 8-chain tape kernel where the flow has those tiles, else a launch of their own
     fabhip_flow fl;
     fl.dim = p->dim; fl.n_layers = p->n_layers; fl.width = p->width; fl.precision = FABHIP_PRECISION_FP32; fl.packed = a->packed;
-    if (a->rows) FAB_TRY(fabhip_flow_log_prob_tape_rows(&fl, a->x, a->rows, a->log_q, nullptr, a->B, a->workspace, tape_bytes, stream));
-    else FAB_TRY(fabhip_flow_log_prob_tape(&fl, a->x, a->log_q, nullptr, a->B, a->workspace, tape_bytes, stream));
-    // 3. weights of the loss, its value, the buffer's adjustment
-    MinibatchK k;
-    k.log_q = a->log_q; k.log_q_old = a->log_q_old; k.rows = (a->log_q_old_rows || a->buf_log_w) ? a->rows : nullptr;
     if (!a->log_q_old_rows && a->buf_log_w) return FABHIP_EINVAL;       // (adjusting in place needs the buffer's own log_q_old)
-    k.one_minus_alpha = 1.f - a->alpha; k.w_clip = a->w_adjust_max_clip; k.neg_inv_B = -1.f / (float)a->B;
-    k.coef = a->coef; k.log_w_adjust = a->log_w_adjust; k.buf_log_w = a->buf_log_w; k.buf_log_q_old = a->buf_log_q_old;
-    k.stats = a->stats; k.B = (long)a->B;
-    hipLaunchKernelGGL(k_buffer_minibatch, dim3(1), dim3(1024), 0, st, k);
-    // 4. d loss / d theta, 5. clipped Adam step (skipped on the device when the norm is not finite)
+    const FlowDims f = make_flow_dims(p->dim, p->n_layers, p->width);
+    const TapeDims td = make_tape_dims(f, (long)a->B);
+    char* adam_ws = (char*)a->workspace + tape_al;
+    const size_t adam_bytes = a->workspace_bytes - tape_al;
+    const bool tail = f.o_r8 >= 0 && option(FABHIP_OPT_TAPE_TILES) == 0;       // (8: the 8-chain tiles without the fused tail, A/B)
+    const int n_part = 2 * (int)(td.Bp / R8);
+    float* partials = (float*)(adam_ws + ((fabhip_adam_workspace_bytes(a->n_params) + 255) & ~(size_t)255));
+    if (tail) {
+        MbTail mb;
+        mb.log_q_old = a->log_q_old; mb.rows_old = a->log_q_old_rows ? 1 : 0;
+        mb.one_minus_alpha = 1.f - a->alpha; mb.w_clip = a->w_adjust_max_clip; mb.neg_inv_B = -1.f / (float)a->B;
+        mb.coef = a->coef; mb.log_w_adjust = a->log_w_adjust; mb.buf_log_w = a->buf_log_w; mb.buf_log_q_old = a->buf_log_q_old;
+        mb.partials = partials;
+        FAB_TRY(launch_log_prob_tape_r8(f, td, a->packed, a->x, a->rows, a->log_q, nullptr, (float*)a->workspace, (long)a->B, st, &mb));
+    } else {
+        if (a->rows) FAB_TRY(fabhip_flow_log_prob_tape_rows(&fl, a->x, a->rows, a->log_q, nullptr, a->B, a->workspace, tape_bytes, stream));
+        else FAB_TRY(fabhip_flow_log_prob_tape(&fl, a->x, a->log_q, nullptr, a->B, a->workspace, tape_bytes, stream));
+        MinibatchK k;
+        k.log_q = a->log_q; k.log_q_old = a->log_q_old; k.rows = (a->log_q_old_rows || a->buf_log_w) ? a->rows : nullptr;
+        k.one_minus_alpha = 1.f - a->alpha; k.w_clip = a->w_adjust_max_clip; k.neg_inv_B = -1.f / (float)a->B;
+        k.coef = a->coef; k.log_w_adjust = a->log_w_adjust; k.buf_log_w = a->buf_log_w; k.buf_log_q_old = a->buf_log_q_old;
+        k.stats = a->stats; k.B = (long)a->B;
+        hipLaunchKernelGGL(k_buffer_minibatch, dim3(1), dim3(1024), 0, st, k);
+    }
+    // 4. d loss / d theta, 5. clipped Adam step (skipped on the device when the norm - or, with the tail, the loss - is not finite)
     FAB_TRY(fabhip_flow_param_grad(p, &fl, a->workspace, tape_bytes, a->coef, a->B, a->grads, stream));
-    return fabhip_adam_clip_step(a->theta, a->grads, a->m, a->v, a->n_params, a->lr, a->beta1, a->beta2, a->eps, a->step_count,
-                                 a->max_grad_norm, a->stats + 5, (char*)a->workspace + tape_al,
-                                 a->workspace_bytes - tape_al, stream);
+    return adam_clip_step_impl(a->theta, a->grads, a->m, a->v, a->n_params, a->lr, a->beta1, a->beta2, a->eps, a->step_count,
+                               a->max_grad_norm, a->stats + 5, adam_ws, adam_bytes, tail ? partials : nullptr, tail ? n_part : 0,
+                               a->stats, (long)a->B, st);
 }
 
 }  // extern "C"

@@ -118,7 +118,8 @@ int fabhip_get_fast_mode(void);
                                             layers (default; dense 64 x 64 / narrow tiles straight from HBM into the matrix cores, work cut
                                             into equal shares), 0 = the round-1 64 x 64 block kernel (A/B; other summation order) */
 #define FABHIP_OPT_TAPE_TILES 11         /* FABHIP_TAPE_TILES: fabhip_flow_log_prob_tape: 0 = 8-chain stream tiles (flow_r8.h) where the flow has
-                                            that image (default), 16 = always the 16-chain kernel (A/B; other summation order) */
+                                            that image (default; inside fabhip_buffer_train_step with the minibatch arithmetic in the kernel's tail), 8 = the same
+                                            tiles, the minibatch arithmetic as its own launch (A/B), 16 = always the 16-chain kernel (A/B; other summation order) */
 #define FABHIP_OPT_COUNT 12
 int fabhip_set_option(int key, int value);
 int fabhip_get_option(int key);

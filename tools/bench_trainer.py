@@ -76,10 +76,10 @@ def measure(dev, iters=20, warm=5):
     return out, trainer
 
 
-def _graph_time(fn, dev, n=20):
-    """Seconds per call of `fn` as the GPU executes it: the call is captured into a HIP graph once (its launches, no host work)
-    and replayed n times between two HIP events - a Python-level loop of op calls measures the host (one op call costs more
-    host time than these kernels take)."""
+def _graph_time(fn, dev, n=20, reps=10):
+    """Seconds per call of `fn` as the GPU executes it: `reps` calls are captured into ONE HIP graph (their launches back to back,
+    no host work) and the graph is replayed n times between two HIP events - a Python-level loop of op calls measures the host
+    (one op call costs more host time than these kernels take), a one-call graph its own launch latency."""
     s = torch.cuda.Stream(device=dev)
     s.wait_stream(torch.cuda.current_stream(dev))
     with torch.cuda.stream(s):
@@ -88,8 +88,9 @@ def _graph_time(fn, dev, n=20):
     torch.cuda.current_stream(dev).wait_stream(s)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        fn()
-    for _ in range(3):
+        for _ in range(reps):
+            fn()
+    for _ in range(2):
         g.replay()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -97,7 +98,7 @@ def _graph_time(fn, dev, n=20):
         g.replay()
     e1.record()
     torch.cuda.synchronize(dev)
-    return e0.elapsed_time(e1) * 1e-3 / n
+    return e0.elapsed_time(e1) * 1e-3 / (n * reps)
 
 
 def kernel_rows(trainer, dev, n=20):
@@ -108,9 +109,9 @@ def kernel_rows(trainer, dev, n=20):
     x = torch.randn(BATCH, D, device=dev)
     coef = torch.full((BATCH,), -1.0 / BATCH, device=dev)
     with torch.no_grad():
-        t_tape = _graph_time(lambda: flow.log_prob_with_tape(x), dev, n)
+        t_tape = _graph_time(lambda: flow.log_prob_with_tape(x), dev, 5, 4)       # (4 tapes of 118 MB live in the graph's pool)
         _, tape = flow.log_prob_with_tape(x)
-        t_pg = _graph_time(lambda: flow.param_grad_flat(tape, coef), dev, n)
+        t_pg = _graph_time(lambda: flow.param_grad_flat(tape, coef), dev, 5)
         ops = _ops.load()
         packed, Dd, K, W = flow.native(need_inverse=False)
         rows = torch.randperm(buf.current_index if not buf.is_full else buf.max_length, device=dev)[:BATCH].contiguous()
@@ -123,7 +124,7 @@ def kernel_rows(trainer, dev, n=20):
             ops.buffer_train_step(flow._own_handle(), packed, Dd, K, W, True, buf.buffer.x, rows, blq, True, ALPHA, 0.0, blw, blq,
                                   theta, opt.m, opt.v, float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]),
                                   float(grp["eps"]), opt.steps, MAX_GRAD_NORM)
-        t_step = _graph_time(one_step, dev, n)
+        t_step = _graph_time(one_step, dev, 5, 4)
         theta.copy_(th); opt.m.copy_(m); opt.v.copy_(v); opt.steps.copy_(steps)    # undo the timing replays' optimiser steps
         flow._packed_key = None
     out = {}
