@@ -198,33 +198,6 @@ __device__ __forceinline__ void pg_store_sum(const PgOut& o, int id, int layer, 
     }
 }
 
-// a finished tile (registers of one wave) to its destination
-template <int TP, int TQ>
-__device__ __forceinline__ void pg_emit(const PgOut& o, const PgKind& k, int layer, int ti, int lane, PgAcc<TP, TQ>& acc) {
-    const int pi = ti / k.nq, qi = ti - pi * k.nq;
-    const int p0 = pi * 16 * TP, q0 = qi * 16 * TQ;
-    const int n = lane & 15, kg = lane >> 4;
-    if constexpr (TQ > 0) {
-#pragma unroll
-        for (int t = 0; t < TP; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = p0 + TP * (4 * kg + r) + t;
-#pragma unroll
-                for (int u = 0; u < TQ; ++u) pg_store(o, k.id, layer, p, q0 + TQ * n + u, acc.c[t][u][r]);
-            }
-    }
-    if (qi == 0) {                                                    // column sums: the four row groups (kg) in a fixed order
-#pragma unroll
-        for (int t = 0; t < TP; ++t) {
-            const float v = acc.s[t];
-            const float v1 = __shfl(v, n + 16), v2 = __shfl(v, n + 32), v3 = __shfl(v, n + 48), v0 = __shfl(v, n);
-            const float s = (v0 + v1) + (v2 + v3);
-            if (kg == 0) pg_store_sum(o, k.id, layer, p0 + TP * n + t, s);
-        }
-    }
-}
-
 // register image <-> memory: 16 accumulator quads [quad][lane] (16 bytes per lane: coalesced, conflict-free), then the column sums
 template <int TP, int TQ>
 __device__ __forceinline__ void pg_put(float* img, int lane, const PgAcc<TP, TQ>& acc) {
@@ -279,15 +252,38 @@ __device__ __forceinline__ void pg_tile(const PgPlan& p, const PgOut& o, const P
     const int w0 = __builtin_amdgcn_readfirstlane((int)((long)p.S * wave / PG_WAVES));
     const int w1 = __builtin_amdgcn_readfirstlane((int)((long)p.S * (wave + 1) / PG_WAVES));
     if (w0 < w1) pg_run<TP, TQ, U>(Y, k.ldy, X, k.ldx, coef, B, ymask, w0, w1, kg, acc);
-    // the waves' sums as a fixed tree (wave w + wave w + half, half = 8, 4, 2, 1)
+    // the sixteen waves' sums in a fixed order, three barriers: waves 8 .. 15 leave their register images in the eight LDS slots and
+    // waves 0 .. 7 add them (w + (w + 8)); those eight sums go back to the slots, and wave w adds accumulator quad w (one quad =
+    // 4 rows x 64 lanes of one (t, u) pair) over the slots as ((0 + 1) + (2 + 3)) + ((4 + 5) + (6 + 7)) and writes it out - the
+    // finished tile leaves from ALL waves (written by wave 0 alone, the 64 scattered stores per lane cost a fifth of the main loop)
+    static_assert(PG_WAVES == 16, "the reduction below is written for 16 waves");
+    if (wave >= 8) pg_put(red + (size_t)(wave - 8) * PG_SLOT, lane, acc);
+    __syncthreads();
+    if (wave < 8) pg_add(red + (size_t)wave * PG_SLOT, lane, acc);
+    __syncthreads();
+    if (wave < 8) pg_put(red + (size_t)wave * PG_SLOT, lane, acc);
+    __syncthreads();
+    auto slot_sum = [&](auto get) {
+        return ((get(0) + get(1)) + (get(2) + get(3))) + ((get(4) + get(5)) + (get(6) + get(7)));
+    };
+    if constexpr (TQ > 0) {
+        if (wave < TP * TQ) {
+            const int tt = wave / TQ, u = wave - tt * TQ;
+            const f32x4 q = slot_sum([&](int sl) { return reinterpret_cast<const f32x4*>(red + (size_t)sl * PG_SLOT)[wave * 64 + lane]; });
+            const int p0 = pi * 16 * TP, q0 = qi * 16 * TQ;
 #pragma unroll
-    for (int half = PG_WAVES / 2; half >= 1; half /= 2) {
-        if (wave >= half && wave < 2 * half) pg_put(red + (size_t)(wave - half) * PG_SLOT, lane, acc);
-        __syncthreads();
-        if (wave < half) pg_add(red + (size_t)wave * PG_SLOT, lane, acc);
-        __syncthreads();
+            for (int r = 0; r < 4; ++r) pg_store(o, k.id, t.layer, p0 + TP * (4 * kg + r) + tt, q0 + TQ * n + u, q[r]);
+        }
     }
-    if (wave == 0) pg_emit(o, k, t.layer, t.ti, lane, acc);
+    if (wave == PG_WAVES - 1 && qi == 0) {                            // column sums: the eight slots, then the four row groups (kg)
+#pragma unroll
+        for (int tt = 0; tt < TP; ++tt) {
+            const float v = slot_sum([&](int sl) { return red[(size_t)sl * PG_SLOT + (64 + tt) * 64 + lane]; });
+            const float v1 = __shfl(v, n + 16), v2 = __shfl(v, n + 32), v3 = __shfl(v, n + 48), v0 = __shfl(v, n);
+            const float sum = (v0 + v1) + (v2 + v3);
+            if (kg == 0) pg_store_sum(o, k.id, t.layer, pi * 16 * TP + TP * n + tt, sum);
+        }
+    }
 }
 
 // tile shapes of the narrow launch by flow class: D <= 32: dW3 (2,2), dW1 (2,1), affine (2,2); D > 32: dW3 (4,2), dW1 (4,2),
