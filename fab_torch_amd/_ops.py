@@ -166,7 +166,7 @@ POLL_READS = os.environ.get("FABHIP_POLL_READS", "1") != "0"
 _pinned = threading.local()          # (per thread: the buffer is handed back to the caller)
 
 
-def _read_small(t: torch.Tensor) -> torch.Tensor:
+def _read_small(t: torch.Tensor, between=None) -> torch.Tensor:
     """Device -> host copy of a few words at the END of a call the host is waiting for: into a pinned buffer, then the copy's
     event is polled (hipEventQuery) instead of sleeping in a blocking synchronise - the wake-up of a blocked thread costs tens of
     microseconds during which the GPU has nothing queued.  Polling is bounded (a call of this library lasts milliseconds); past
@@ -187,6 +187,8 @@ def _read_small(t: torch.Tensor) -> torch.Tensor:
         with torch.cuda.device(t.device):
             buf.copy_(t, non_blocking=True)
             ev.record(torch.cuda.current_stream(t.device))
+    if between is not None:                             # work to enqueue BEHIND the copy while the host waits for it
+        between()
     if POLL_READS:
         for _ in range(200000):
             if ev.query():
@@ -198,7 +200,7 @@ def _read_small(t: torch.Tensor) -> torch.Tensor:
     return buf                                          # (valid until the next read of the same size on this device)
 
 
-def read_counts_and_stats(n_valid: torch.Tensor, stats: torch.Tensor):
+def read_counts_and_stats(n_valid: torch.Tensor, stats: torch.Tensor, between=None):
     """(stats[:6] on the host, (n_valid[0], n_valid[1])) with ONE device->host copy: the AIS ops allocate `stats` (float[16]) and
     `n_valid` (int32[2]) as views of one 18-word buffer, which is read whole; tensors from elsewhere (the phase ops of the
     sharded sampler own theirs) take the two-kernel route."""
@@ -206,9 +208,11 @@ def read_counts_and_stats(n_valid: torch.Tensor, stats: torch.Tensor):
         st = stats.untyped_storage()
         if (n_valid.untyped_storage().data_ptr() == st.data_ptr() and st.nbytes() == 72 and stats.storage_offset() == 0
                 and n_valid.storage_offset() == 16 and stats.numel() == 16 and n_valid.numel() == 2):
-            h = _read_small(stats.as_strided((18,), (1,)))
+            h = _read_small(stats.as_strided((18,), (1,)), between)
             n = h[16:18].view(torch.int32)
             return h[:6], (int(n[0]), int(n[1]))
+    if between is not None:
+        between()
     h = torch.cat([n_valid.float(), stats[:6]]).cpu()
     return h[2:], (int(h[0]), int(h[1]))
 

@@ -167,6 +167,84 @@ class AnnealedImportanceSampler:
         point = Point(x, lq, lp, gq if hmc else None, gp if hmc else None)
         return point, log_w, n_valid, stats, base_x, base_lw
 
+    # ---- repeated identical calls: the NEXT call's chain initialisation behind this call's device-to-host read ------------------
+    # A fused call ends in a blocking 72-byte read; between that read and the next call's first kernel the GPU idles for the
+    # host's post- and pre-processing (~85 us of a 4.3 ms call at the headline shape).  When a call repeats the previous one
+    # unchanged (same batch, same parameter values, same operator settings: evaluation loops, the benchmark), the call runs in
+    # two pieces of the SAME code (fabhip_ais_phase: INIT, then transitions 1 .. M + FINISH) and enqueues the next call's INIT
+    # piece - its base noise drawn from the generator in the order the next call would draw it - right behind its own read.
+    # Same kernels, same draws in the same order: results are bit-identical with the switch on or off.  The prefetched piece is
+    # used only if the call it was made for arrives unchanged AND the device generator is exactly where the prefetch left it; a
+    # changed key (a training step moved the parameters, another batch size, ...) drops it and rewinds the generator over its one
+    # draw, so the call draws what it would have drawn; a generator the caller has touched meanwhile (set_rng_state, manual_seed,
+    # any draw) drops it without a rewind.  `prefetch = False` turns the mechanism off.
+    prefetch = True
+
+    def _pf_key(self, flow, target, op, B):
+        tg = tuple(id(t) if torch.is_tensor(t) else (tuple(t) if isinstance(t, (list, tuple)) else t)
+                   for t in target.native_target())
+        return (B, flow._packed_key, flow.__dict__.get("_pack_count", 0), tg, id(self.B_space), getattr(self.B_space, "_version", None), self.alpha,
+                bool(self.p_target), _ops.precision_of(flow), op.L, op.n_outer, float(op.max_grad), float(op.target_p_accept),
+                bool(op.eval_mode), id(op.mass_vector), op.mass_vector._version, int(_ops.load().get_fast_mode()))
+
+    def _pf_new_state(self, flow, op, B, D):
+        M = self.n_intermediate_distributions
+        f32 = dict(dtype=torch.float32, device=flow._nf_model.q0.loc.device)
+        counts_stats = torch.zeros(18, **f32)                 # stats[16] | n_valid[2]: ONE device->host read at the end
+        # (the transition noise is DRAWN when the call itself runs - `normal_()` / `exponential_()` into these buffers, the draws
+        #  `torch.randn` / `empty().exponential_()` of the one-op call make - so that the generator is consumed in call order)
+        return {"eps0": torch.randn((B, D), **f32), "x": torch.empty((B, D), **f32), "lq": torch.empty(B, **f32),
+                "lp": torch.empty(B, **f32), "gq": torch.empty((B, D), **f32), "gp": torch.empty((B, D), **f32),
+                "log_w": torch.empty(B, **f32), "cs": counts_stats, "n_valid": counts_stats[16:18].view(torch.int32),
+                "stats": counts_stats[:16], "noise_a": torch.empty((M, op.n_outer, B, D), **f32),
+                "noise_b": torch.empty((M, op.n_outer, B), **f32)}
+
+    def _pf_phase(self, flow, target, op, st, phases, j0, j1):
+        ops = _ops.load()
+        alpha = float(self.alpha) if self.alpha is not None else 0.0
+        na, nb = st["noise_a"], st["noise_b"]                                   # (the INIT piece reads eps0 only)
+        ops.ais_phase(*flow.native(), *target.native_target(), self._betas(), alpha, bool(self.p_target), _ops.TRANSITION_HMC,
+                      int(phases), int(j0), int(j1), st["eps0"], na, nb, op.epsilons, op.common_epsilon, op.mass_vector,
+                      op.n_outer, op.L, float(op.max_grad), float(op.target_p_accept), not op.eval_mode, st["x"], st["lq"],
+                      st["lp"], st["gq"], st["gp"], st["log_w"], st["n_valid"], st["stats"], None, op._p_accept_first,
+                      op._p_accept_last, op._dist_first, op._dist_last, None, None, _ops.precision_of(flow))
+
+    def _pf_take(self, key):
+        """The prefetched piece made for `key`, if the generator is where the prefetch left it; else it is dropped (and, when only
+        the key changed, the generator rewound over the prefetch's draw)."""
+        pf = self.__dict__.pop("_pf_state", None)
+        if pf is None:
+            return None
+        k, st, before, after, dev = pf
+        untouched = torch.equal(torch.cuda.get_rng_state(dev), after)
+        if untouched and k == key:
+            return st
+        if untouched:
+            torch.cuda.set_rng_state(before, dev)
+        return None
+
+    def _sample_repeated(self, flow, target, op, B, key):
+        """One call in two pieces with the next call's chain initialisation enqueued behind this call's read (see above)."""
+        D, M = flow.dim, self.n_intermediate_distributions
+        st = self._pf_take(key)
+        if st is None:
+            st = self._pf_new_state(flow, op, B, D)
+            self._pf_phase(flow, target, op, st, 1, 1, 0)                        # FABHIP_AIS_INIT
+        st["noise_a"].normal_()
+        st["noise_b"].exponential_(1.0)
+        self._pf_phase(flow, target, op, st, 2, 1, M)                            # transitions 1 .. M, FABHIP_AIS_FINISH
+
+        dev = st["x"].device
+
+        def enqueue_next():
+            before = torch.cuda.get_rng_state(dev)
+            nxt = self._pf_new_state(flow, op, B, D)
+            after = torch.cuda.get_rng_state(dev)
+            self._pf_phase(flow, target, op, nxt, 1, 1, 0)
+            self.__dict__["_pf_state"] = (key, nxt, before, after, dev)
+        host, counts = _ops.read_counts_and_stats(st["n_valid"], st["stats"], between=enqueue_next)
+        return Point(st["x"], st["lq"], st["lp"], st["gq"], st["gp"]), st["log_w"], host, counts
+
     def _betas(self):
         """B_space as a list of Python floats (the ops' `float[] betas`), converted once per B_space tensor / version."""
         bs = self.B_space
@@ -261,11 +339,27 @@ class AnnealedImportanceSampler:
                 raise _ops.FabhipError("eps0 is the base noise of a fab_torch_amd RealNVP; a generic base_distribution "
                                        "draws its own samples in sample_and_log_prob")
             return self._sample_generic(batch_size, logging, noise_a, noise_b)
-        if fused_spline:
-            point, log_w, n_valid, stats, _, _ = self._run_spline(batch_size, eps0, noise_a, noise_b, u0=u0)
+        repeated = None
+        if (not fused_spline and self.prefetch and eps0 is None and noise_a is None and noise_b is None
+                and isinstance(self.transition_operator, HamiltonianMonteCarlo)):
+            flow, target = self._native_parts()
+            op = self.transition_operator
+            if bool(op.p_target) == bool(self.p_target) and (self.p_target or op.alpha == self.alpha):
+                flow.native()                                                    # (the image - and its key - of the current parameters)
+                key = self._pf_key(flow, target, op, int(batch_size))
+                if self.__dict__.get("_pf_last_key") == key:
+                    repeated = self._sample_repeated(flow, target, op, int(batch_size), key)
+                else:
+                    self._pf_take(None)                                          # (drops a piece made for another key)
+                self.__dict__["_pf_last_key"] = key
+        if repeated is not None:
+            point, log_w, host, (n_init, n_end) = repeated
         else:
-            point, log_w, n_valid, stats, _, _ = self.run(batch_size, eps0, noise_a, noise_b)
-        host, (n_init, n_end) = _ops.read_counts_and_stats(n_valid, stats)   # the single device->host read
+            if fused_spline:
+                point, log_w, n_valid, stats, _, _ = self._run_spline(batch_size, eps0, noise_a, noise_b, u0=u0)
+            else:
+                point, log_w, n_valid, stats, _, _ = self.run(batch_size, eps0, noise_a, noise_b)
+            host, (n_init, n_end) = _ops.read_counts_and_stats(n_valid, stats)   # the single device->host read
         if n_init == 0:
             raise NoValidPoints("init")
         if n_end == 0:

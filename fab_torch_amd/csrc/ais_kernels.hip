@@ -1714,8 +1714,15 @@ int fabhip_ais_phase(const fabhip_ais_args* a, int32_t phases, int32_t j_begin, 
     const size_t ess_bytes = fabhip_ess_workspace_bytes(B);
     // step-size rule inside the transition kernels (hmc_adapt_last): only where the ticket word is known to be zero (this call's or,
     // with FABHIP_AIS_CONTINUE, an earlier call's init phase zeroed it; every transition kernel leaves it zero)
-    int* ticket = (ws_kept && hmc && !partials && option(FABHIP_OPT_ADAPT_FOLD) != 0 && nblk_of(B) <= 2048 &&
+    int* ticket = (hmc && !partials && option(FABHIP_OPT_ADAPT_FOLD) != 0 && nblk_of(B) <= 2048 &&
                    (use_r8_tiles(f, B) || use_r4_tiles(f, B))) ? (int*)ws : nullptr;      // (2 nblk floats of LDS scratch)
+    // (round 6: a call that runs transitions on a workspace nobody zeroed - the second piece of a call whose INIT piece was its own
+    //  fabhip_ais_phase call, fab_torch_amd/ais.py: repeated calls - zeroes the word itself: one 4-byte fill instead of a
+    //  k_hmc_adapt launch per transition)
+    if (ticket && !ws_kept) {
+        if (j_begin > j_end) ticket = nullptr;
+        else if (hipMemsetAsync(ticket, 0, 4, st) != hipSuccess) return FABHIP_ELAUNCH;
+    }
 
     if (do_init) {
     // 1. chain initialisation

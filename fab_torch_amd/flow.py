@@ -397,6 +397,9 @@ class RealNVP(nn.Module):
                                  self._packed)
             self._packed_has_inverse = need_inverse
             self._packed_key = key
+            # (how often the image was rebuilt: FlatAdam moves the parameters without touching autograd's version counters and
+            #  asks for a re-pack by clearing `_packed_key` - the key alone then repeats; ais.py keys its prefetch on this count)
+            self.__dict__["_pack_count"] = self.__dict__.get("_pack_count", 0) + 1
         return self._packed, self.dim, self.n_layers, self.width
 
     def native_sample(self, eps: torch.Tensor):
