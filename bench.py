@@ -235,7 +235,7 @@ def trainer_iteration(dev):
     synchronisations, the AIS call of the same sampler alone by HIP events, the two training kernels stand-alone."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_trainer
-    out, trainer = bench_trainer.measure(dev, iters=20, warm=5)
+    out, trainer = bench_trainer.measure(dev)
     out["kernels"] = bench_trainer.kernel_rows(trainer, dev)
     out["profile"] = "profiles/r6/trainer_kernel_stats_rocprofv3.csv + trainer_iteration_timeline.txt (tools/trace_trainer.sh: the same script under rocprofv3 --kernel-trace --stats)"
     del trainer

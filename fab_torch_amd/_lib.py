@@ -100,7 +100,7 @@ SYMBOLS = [
     "fabhip_hmc_generic_leap_post", "fabhip_hmc_generic_accept", "fabhip_anneal_log_prob", "fabhip_log_w_update",
     "fabhip_metropolis_generic_propose", "fabhip_metropolis_generic_accept", "fabhip_fixed_cdf",
     "fabhip_spline_packed_floats", "fabhip_spline_pack", "fabhip_spline_workspace_bytes", "fabhip_spline_log_prob",
-    "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape",
+    "fabhip_spline_sample", "fabhip_spline_tape_layout", "fabhip_spline_log_prob_tape", "fabhip_spline_sample_vjp_tape",
     "fabhip_set_fast_mode", "fabhip_get_fast_mode", "fabhip_set_option", "fabhip_get_option", "fabhip_ais_phase", "fabhip_hmc_partials_floats",
     "fabhip_hmc_adapt_gathered", "fabhip_spline_hmc_workspace_bytes", "fabhip_spline_hmc_transition",
     "fabhip_spline_ais_workspace_bytes", "fabhip_spline_ais_run", "fabhip_tape_gemm", "fabhip_debug_spline_timeline",
@@ -108,7 +108,7 @@ SYMBOLS = [
     "fabhip_flow_pack_train", "fabhip_flow_log_prob_tape_rows", "fabhip_train_step_workspace_bytes", "fabhip_buffer_train_step",
     "fabhip_buffer_add", "fabhip_buffer_sample_workspace_bytes", "fabhip_buffer_sample",
 ]
-ABI_VERSION = 215          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
+ABI_VERSION = 216          # FABHIP_ABI_VERSION of include/fabhip.h this binding was written against
 
 
 def _declare(lib):

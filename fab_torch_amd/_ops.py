@@ -14,7 +14,7 @@ import torch
 
 from . import _build
 
-ABI_VERSION = 215          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
+ABI_VERSION = 216          # FABHIP_ABI_VERSION of include/fabhip.h the Python side was written against
 
 TARGET_MANYWELL, TARGET_GMM = 1, 2
 TRANSITION_HMC, TRANSITION_METROPOLIS = 1, 2

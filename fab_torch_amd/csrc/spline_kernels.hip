@@ -648,7 +648,9 @@ __device__ __forceinline__ void rqs_inverse(const Rqs& s, float y, float tb, flo
 }
 
 // reverse mode of rqs_forward with cotangents (gy, 1 on logabsdet): returns d/dx and, if dp != nullptr, the cotangents
-// of the 3K+1 unnormalised parameters (scaled by `wh_scale` for widths / heights)
+// of the 3K+1 unnormalised parameters (scaled by `wh_scale` for widths / heights).  LD = false: cotangents (gy, 0) - the map
+// alone, without its log-derivative (k_spline_vsweep)
+template <bool LD = true>
 __device__ __forceinline__ float rqs_backward(const Rqs& s, const float* p, bool circ, float x, float tb, float gy,
                                               float wh_scale, float* dp) {
     if (dp) {
@@ -669,9 +671,9 @@ __device__ __forceinline__ float rqs_backward(const Rqs& s, const float* p, bool
     const float e = d1 * (th * th) + 2.f * dl * t1 + d0 * ((1.f - th) * (1.f - th));
     const float iden = sp_rcp(den);
     const float nb = gy * iden;                                    // cotangent of num
-    const float db = -gy * num * (iden * iden) - 2.f * iden;       // of den
-    const float eb = sp_rcp(e);                                    // of e
-    const float sb = 2.f * (w * ih) + eb * 2.f * t1 + db * (1.f - 2.f * t1) + nb * h * (th * th);   // (2 / dl = 2 w / h)
+    const float db = LD ? -gy * num * (iden * iden) - 2.f * iden : -gy * num * (iden * iden);       // of den
+    const float eb = LD ? sp_rcp(e) : 0.f;                         // of e
+    const float sb = (LD ? 2.f * (w * ih) : 0.f) + eb * 2.f * t1 + db * (1.f - 2.f * t1) + nb * h * (th * th);   // (2 / dl = 2 w / h)
     const float t1b = eb * 2.f * dl + db * A + nb * h * d0;
     const float d0b = eb * ((1.f - th) * (1.f - th)) + db * t1 + nb * h * t1;
     const float d1b = eb * (th * th) + db * t1;
@@ -727,12 +729,12 @@ __device__ __forceinline__ float wave_sum64(float v) {
 
 // One wave per chain, lane = coordinate.  MODE 0: log_prob direction (evaluate), 1: sampling direction, identity
 // coordinates only (unconditional inverse, before the conditioner runs), 2: sampling direction, transformed
-// coordinates (needs P) + post shift.
+// coordinates (needs P) + post shift (Ypre, nullable: the state before that shift, kept for fabhip_spline_sample_vjp_tape).
 template <int MODE>
 __global__ __launch_bounds__(256) void k_spline_apply(SplineDims f, const float* __restrict__ packed, int layer,
                                                       const float* __restrict__ Zin, const float* __restrict__ P,
                                                       float* __restrict__ Zout, float* __restrict__ log_q, float ld_sign,
-                                                      long B) {
+                                                      long B, float* __restrict__ Ypre) {
     const int lane = threadIdx.x & 63;
     const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= B) return;
@@ -772,6 +774,7 @@ __global__ __launch_bounds__(256) void k_spline_apply(SplineDims f, const float*
             const float* mn = packed + (size_t)(layer - 1) * f.layer_stride + f.o_meta;
             if (mn[M_PREON * 64 + lane] != 0.f) out = sp_wrap(out - mn[M_PRESH * 64 + lane], tb);
         }
+        if (MODE == 2 && Ypre) Ypre[g * f.D + lane] = out;         // the layer's output before the shift = the log_prob direction's input
         if (MODE == 2 && meta[M_POSTON * 64 + lane] != 0.f) out = sp_wrap(out + meta[M_POSTSH * 64 + lane], tb);
         Zout[g * f.D + lane] = out;
     }
@@ -881,6 +884,68 @@ __global__ __launch_bounds__(256) void k_spline_apply_bwd(SplineDims f, const fl
         for (int j = 0; j < SP_NP; ++j) dP[g * f.NFP + pos_tr * SP_NP + j] = dp[j];
     }
     Gin[g * f.D + lane] = gx;
+}
+
+// Sampling-direction gradients (x = S^-1(z0; theta) with the noise z0 fixed, S = the log_prob direction): for a cotangent gx of
+// x and gl of log q(x), d/d theta = gl d log q / d theta |_x  -  v^T dS / d theta with v = (dS / dx)^-T (gx + gl d log q / dx)
+// (implicit function theorem).  The first term is the density tape's; this kernel carries v through ONE coupling layer
+// y -> z = (g_u(y_id), g(y_tr; c(y_id))) from the x side to the base side and leaves  -v_z dz / d(parameters)  where the
+// density tape keeps its parameter cotangents, so the SAME conditioner backward and the SAME tape GEMMs finish the job:
+//   PART 0 (before the conditioner backward): transformed coordinates  v_z = v_y / g'(y),  dP = -v_z dg / dP;  identity
+//          coordinates copied (the conditioner backward then ADDS  -A^T v_z,tr  to them, A = dg / dy_id through the net)
+//   PART 1 (after it): identity coordinates  v_z = (v_y - A^T v_z,tr) / g_u'(y),  dU = -v_z dg_u / dU
+// v = gx + gl * (d log q / dx), in place in v (gx / gl nullable: a cotangent that is not there)
+__global__ void k_spline_vjp_seed(float* __restrict__ v, const float* __restrict__ gx, const float* __restrict__ gl, long B, int D) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < B * D; e += (long)gridDim.x * blockDim.x)
+        v[e] = (gx ? gx[e] : 0.f) + (gl ? gl[e / D] * v[e] : 0.f);
+}
+
+template <int PART>
+__global__ __launch_bounds__(256) void k_spline_vsweep(SplineDims f, const float* __restrict__ packed, int layer,
+                                                       const float* __restrict__ Zin, const float* __restrict__ P,
+                                                       const float* __restrict__ Vin, float* __restrict__ Vout,
+                                                       float* __restrict__ dP, long B, float* __restrict__ dU) {
+    const int lane = threadIdx.x & 63;
+    const long g = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= B) return;
+    const float* Lp = packed + (size_t)layer * f.layer_stride;
+    const float* meta = Lp + f.o_meta;
+    const int n_tr = (int)meta[M_CNT * 64 + 1];
+    const float isq = 1.f / sqrtf((float)f.W);
+    if (PART == 0)
+        for (int j = n_tr * SP_NP + lane; j < f.NFP; j += 64) dP[g * f.NFP + j] = 0.f;
+    if (lane >= f.D) return;
+    const int pos_id = (int)meta[M_POSID * 64 + lane], pos_tr = (int)meta[M_POSTR * 64 + lane];
+    const bool circ = meta[M_CIRC * 64 + lane] != 0.f;
+    const float tb = meta[M_TB * 64 + lane];
+    const float y = Zin[g * f.D + lane];
+    float p[SP_NP], dp[SP_NP];
+    Rqs s;
+    if (PART == 0) {
+        float v = Vin[g * f.D + lane];
+        if (pos_tr >= 0) {
+#pragma unroll
+            for (int j = 0; j < SP_NP; ++j) {
+                const float c = P[g * f.NFP + pos_tr * SP_NP + j];
+                p[j] = j < 2 * SP_K ? c * isq : c;
+            }
+            rqs_setup(p, circ, tb, s);
+            v = v / rqs_backward<false>(s, p, circ, y, tb, 1.f, isq, nullptr);
+            rqs_backward<false>(s, p, circ, y, tb, -v, isq, dp);
+#pragma unroll
+            for (int j = 0; j < SP_NP; ++j) dP[g * f.NFP + pos_tr * SP_NP + j] = dp[j];
+        }
+        Vout[g * f.D + lane] = v;
+    } else if (pos_id >= 0) {
+#pragma unroll
+        for (int j = 0; j < SP_NP; ++j) p[j] = Lp[f.o_unc + pos_id * SP_NP + j];
+        rqs_setup(p, circ, tb, s);
+        const float v = Vout[g * f.D + lane] / rqs_backward<false>(s, p, circ, y, tb, 1.f, 1.f, nullptr);
+        rqs_backward<false>(s, p, circ, y, tb, -v, 1.f, dp);
+#pragma unroll
+        for (int j = 0; j < SP_NP; ++j) dU[g * (SP_MD * SP_NP) + pos_id * SP_NP + j] = dp[j];
+        Vout[g * f.D + lane] = v;
+    }
 }
 
 
@@ -1405,7 +1470,7 @@ static int spline_log_prob_impl(const fabhip_spline_flow* flow, const float* x, 
         float* Pl = P + (grad_x ? (size_t)l * ps : 0);
         FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, Pl, nullptr, nullptr, (long)B, st));
         hipLaunchKernelGGL(k_spline_apply<0>, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs, Pl, Z + (size_t)l * zs,
-                           log_q, 1.f, (long)B);
+                           log_q, 1.f, (long)B, (float*)nullptr);
     }
     hipLaunchKernelGGL(k_spline_base, wgrid, wblock, 0, st, f, pk, Z, log_q, Ga, (long)B);
     if (grad_x) {
@@ -1449,6 +1514,73 @@ int fabhip_spline_log_prob_tape(const fabhip_spline_flow* flow, const float* x, 
     return spline_log_prob_impl(flow, x, log_q, grad_x, B, tape, workspace, workspace_bytes, stream);
 }
 
+int fabhip_spline_sample_vjp_tape(const fabhip_spline_flow* flow, const float* u, const float* eps, const float* gx, const float* gl,
+                                  float* v_x, float* v_base, int64_t B, float* tape_density, float* tape_inverse,
+                                  int64_t tape_floats, void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
+    if (!flow || !flow->packed || !u || !eps || !v_x || !tape_density || !tape_inverse || !workspace || B < 0 || (!gx && !gl))
+        return FABHIP_EINVAL;
+    FAB_TRY(check_spline_shape(flow->dim, flow->n_layers, flow->hidden));
+    int64_t lay[16];
+    FAB_TRY(fabhip_spline_tape_layout(flow->dim, flow->n_layers, flow->hidden, B, lay));
+    if (tape_floats < lay[0]) return FABHIP_ENOSPC;
+    if (B == 0) return FABHIP_OK;
+    if (workspace_bytes < fabhip_spline_workspace_bytes(flow->dim, flow->n_layers, flow->hidden, B, 1)) return FABHIP_ENOSPC;
+    const SplineDims f = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
+    hipStream_t st = (hipStream_t)stream;
+    char* ws = (char*)workspace;
+    float* Z = (float*)ws; ws += sp_al((size_t)(f.L + 1) * B * f.D * 4);
+    float* P = (float*)ws; ws += sp_al((size_t)f.L * B * f.NFP * 4);
+    float* lq = (float*)ws; ws += sp_al((size_t)B * f.NFP * 4);         // (the density sweep's dP scratch: here log q row sums)
+    float* Ga = (float*)ws; ws += sp_al((size_t)B * f.D * 4);
+    float* Gb = (float*)ws;
+    const size_t zs = (size_t)B * f.D, ps = (size_t)B * f.NFP;
+    const float* pk = flow->packed;
+    const dim3 wgrid((unsigned)((B + 3) / 4)), wblock(256);
+    // 1. the sampler again (same kernels, same noise: the same states), every layer's output before its shift and its
+    //    conditioner outputs kept: Z[l + 1] / P[l] are what the log_prob direction would recompute from x up to rounding - and
+    //    the inverse of a stiff chain of splines amplifies that rounding, so the sweeps below linearise where the sample was made
+    hipLaunchKernelGGL(k_spline_base_sample, wgrid, wblock, 0, st, f, pk, u, eps, Z, lq, (long)B);
+    const float* zin = Z;
+    for (int l = 0; l < f.L; ++l) {
+        hipLaunchKernelGGL(k_spline_apply<1>, wgrid, wblock, 0, st, f, pk, l, zin, (const float*)nullptr, v_x, lq, -1.f, (long)B,
+                           (float*)nullptr);
+        FAB_TRY(net(f, pk, l, v_x, P + (size_t)l * ps, nullptr, nullptr, (long)B, st));
+        float* out = (zin == Ga) ? Gb : Ga;
+        hipLaunchKernelGGL(k_spline_apply<2>, wgrid, wblock, 0, st, f, pk, l, v_x, P + (size_t)l * ps, out, lq, -1.f, (long)B,
+                           Z + (size_t)(l + 1) * zs);
+        zin = out;
+    }
+    // 2. the log_prob direction's reverse sweep on these states (seed 1 per sample): tape_density, d log q / dx -> v_x
+    const SplineTape t1 = make_spline_tape(f, (long)B, tape_density);
+    hipLaunchKernelGGL(k_spline_base, wgrid, wblock, 0, st, f, pk, Z, lq, Ga, (long)B);
+    float* gin = Ga;
+    for (int l = 0; l < f.L; ++l) {
+        float* out = (l == f.L - 1) ? v_x : (gin == Ga ? Gb : Ga);
+        float* tl = tape_density + (size_t)l * t1.layer_stride;
+        hipLaunchKernelGGL(k_spline_apply_bwd, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs, P + (size_t)l * ps, gin, out,
+                           tl + t1.o_dP, (long)B, tl + t1.o_dU);
+        FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, tl + t1.o_dP, out, (long)B, st, t1));
+        gin = out;
+    }
+    // 3. v at x = gx + gl * d log q / dx (in place)
+    hipLaunchKernelGGL(k_spline_vjp_seed, dim3((unsigned)((B * f.D + 255) / 256 > 4096 ? 4096 : (B * f.D + 255) / 256)), dim3(256), 0,
+                       st, v_x, gx, gl, (long)B, f.D);
+    // 4. v from the x side to the base side (the stage-boundary shifts and wraps have unit derivative): tape_inverse
+    const SplineTape t2 = make_spline_tape(f, (long)B, tape_inverse);
+    const float* vin = v_x;
+    for (int l = f.L - 1; l >= 0; --l) {
+        float* out = (l == 0 && v_base) ? v_base : (vin == Ga ? Gb : Ga);
+        float* tl = tape_inverse + (size_t)l * t2.layer_stride;
+        hipLaunchKernelGGL(k_spline_vsweep<0>, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs, P + (size_t)l * ps, vin,
+                           out, tl + t2.o_dP, (long)B, (float*)nullptr);
+        FAB_TRY(net(f, pk, l, Z + (size_t)(l + 1) * zs, nullptr, tl + t2.o_dP, out, (long)B, st, t2));
+        hipLaunchKernelGGL(k_spline_vsweep<1>, wgrid, wblock, 0, st, f, pk, l, Z + (size_t)(l + 1) * zs, (const float*)nullptr,
+                           (const float*)nullptr, out, (float*)nullptr, (long)B, tl + t2.o_dU);
+        vin = out;
+    }
+    return check_launch();
+}
+
 int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const float* eps, float* x, float* log_q,
                          int64_t B, void* workspace, size_t workspace_bytes, fabhip_stream_t stream) {
     if (!flow || !flow->packed || !u || !eps || !x || !log_q || !workspace || B < 0) return FABHIP_EINVAL;
@@ -1467,10 +1599,11 @@ int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const f
     hipLaunchKernelGGL(k_spline_base_sample, wgrid, wblock, 0, st, f, pk, u, eps, za, log_q, (long)B);
     for (int l = 0; l < f.L; ++l) {
         // identity coordinates through the inverse unconditional spline (zb), conditioner on them, then the rest
-        hipLaunchKernelGGL(k_spline_apply<1>, wgrid, wblock, 0, st, f, pk, l, za, (const float*)nullptr, zb, log_q, -1.f, (long)B);
+        hipLaunchKernelGGL(k_spline_apply<1>, wgrid, wblock, 0, st, f, pk, l, za, (const float*)nullptr, zb, log_q, -1.f, (long)B,
+                           (float*)nullptr);
         FAB_TRY(net(f, pk, l, zb, P, nullptr, nullptr, (long)B, st));
         float* out = (l == f.L - 1) ? x : zc;
-        hipLaunchKernelGGL(k_spline_apply<2>, wgrid, wblock, 0, st, f, pk, l, zb, P, out, log_q, -1.f, (long)B);
+        hipLaunchKernelGGL(k_spline_apply<2>, wgrid, wblock, 0, st, f, pk, l, zb, P, out, log_q, -1.f, (long)B, (float*)nullptr);
         float* tmp = za; za = zc; zc = tmp;
     }
     return check_launch();

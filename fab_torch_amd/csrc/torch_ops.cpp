@@ -483,6 +483,29 @@ std::tuple<Tensor, Tensor, Tensor> spline_logprob_tape(const Tensor& packed, int
     return {log_q, grad, tape};
 }
 
+// the backward of flow.sample_and_log_prob (fabhip_spline_sample_vjp_tape): the two tapes for the tape GEMMs (coefficients gl and
+// 1) and v at the base side
+std::tuple<Tensor, Tensor, Tensor> spline_sample_vjp_tape(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden,
+                                                          const Tensor& u, const Tensor& eps, const optional<Tensor>& gx,
+                                                          const optional<Tensor>& gl) {
+    c10::DeviceGuard g(u.device());
+    const fabhip_spline_flow f = make_spline(packed, dim, n_layers, hidden);
+    TORCH_CHECK(u.dim() == 2 && u.size(1) == dim && eps.sizes() == u.sizes(), "fabhip: u, eps must be [B, dim]");
+    TORCH_CHECK(!gx.has_value() || gx->sizes() == u.sizes(), "fabhip: gx must be [B, dim]");
+    const int64_t B = u.size(0);
+    TORCH_CHECK(!gl.has_value() || (gl->dim() == 1 && gl->size(0) == B), "fabhip: gl must be [B]");
+    int64_t lay[16];
+    chk(fabhip_spline_tape_layout(f.dim, f.n_layers, f.hidden, B, lay), "spline_tape_layout");
+    Tensor tape1 = fempty({lay[0]}, u), tape2 = fempty({lay[0]}, u), v_x = at::empty_like(u), v_base = at::empty_like(u);
+    const size_t nb = fabhip_spline_workspace_bytes(f.dim, f.n_layers, f.hidden, B, 1);
+    Tensor ws = scratch(nb, u);
+    chk(fabhip_spline_sample_vjp_tape(&f, fp(u, "u"), fp(eps, "eps"), fp_opt(gx, "gx"), fp_opt(gl, "gl"), v_x.data_ptr<float>(),
+                                      v_base.data_ptr<float>(), B, tape1.data_ptr<float>(), tape2.data_ptr<float>(), lay[0],
+                                      aligned(ws), nb, stream_of(u)),
+        "spline_sample_vjp_tape");
+    return {tape1, tape2, v_base};
+}
+
 std::tuple<Tensor, Tensor> spline_sample(const Tensor& packed, int64_t dim, int64_t n_layers, int64_t hidden,
                                          const Tensor& u, const Tensor& eps) {
     c10::DeviceGuard g(u.device());
@@ -1263,6 +1286,7 @@ TORCH_LIBRARY(fabhip, m) {
     m.def("spline_tape_layout(int dim, int n_layers, int hidden, int B) -> int[]", spline_tape_layout);
     m.def("spline_logprob_tape(Tensor packed, int dim, int n_layers, int hidden, Tensor x) -> (Tensor, Tensor, Tensor)");
     m.def("spline_sample(Tensor packed, int dim, int n_layers, int hidden, Tensor u, Tensor eps) -> (Tensor, Tensor)");
+    m.def("spline_sample_vjp_tape(Tensor packed, int dim, int n_layers, int hidden, Tensor u, Tensor eps, Tensor? gx, Tensor? gl) -> (Tensor, Tensor, Tensor)");
     m.def("target_logp_grad(" TGT ", Tensor x, bool with_grad) -> (Tensor, Tensor)");
     m.def("manywell_logp_grad(Tensor x, float a, float b, float c, float log_norm) -> (Tensor, Tensor)");
     m.def("gmm_logp_grad(Tensor x, Tensor locs, Tensor scales) -> (Tensor, Tensor)");
@@ -1356,6 +1380,7 @@ TORCH_LIBRARY_IMPL(fabhip, CUDA, m) {      // CUDA == HIP on PyTorch-ROCm; delib
     m.impl("spline_logprob_grad", spline_logprob_grad);
     m.impl("spline_logprob_tape", spline_logprob_tape);
     m.impl("spline_sample", spline_sample);
+    m.impl("spline_sample_vjp_tape", spline_sample_vjp_tape);
     m.impl("target_logp_grad", target_logp_grad);
     m.impl("manywell_logp_grad", manywell_logp_grad);
     m.impl("gmm_logp_grad", gmm_logp_grad);

@@ -164,6 +164,42 @@ class _SplineLogProbTape(torch.autograd.Function):
         return (None, c[:, None] * gx if ctx.needs_input_grad[1] else None, *grads)
 
 
+class _SplineSampleTape(torch.autograd.Function):
+    """x, log_q = flow.sample_and_log_prob() with gradients w.r.t. the flow parameters and the base noise (the reparameterised
+    baseline losses, fab/core.py:130-152).  Forward = the HIP sampler.  Backward = `fabhip::spline_sample_vjp_tape` (include/fabhip.h,
+    fabhip_spline_sample_vjp_tape): with S the log_prob direction (x = S^-1(z0; theta)), d/d theta = g_lq d log q(x)/d theta |_x -
+    v^T dS/d theta, v = (dS/dx)^-T (g_x + g_lq d log q/dx) - two tapes in the density tape's layout, turned into parameter gradients
+    by the same tape GEMMs (coefficients g_lq and 1)."""
+
+    @staticmethod
+    def forward(ctx, flow, u, eps, *params):
+        ud, ed = u.detach().contiguous().float(), eps.detach().contiguous().float()
+        x, lq = _ops.load().spline_sample(*flow.native(), ud, ed)
+        ctx.flow, ctx.B = flow, x.shape[0]
+        ctx.save_for_backward(ud, ed)
+        return x, lq
+
+    @staticmethod
+    def backward(ctx, gx, glq):
+        ud, ed = ctx.saved_tensors
+        flow, B = ctx.flow, ctx.B
+        gx = None if gx is None else gx.detach().float().contiguous()
+        c = None if glq is None else glq.detach().float().contiguous()
+        if gx is None and c is None:
+            return (None,) * (3 + len(ctx.needs_input_grad[3:]))
+        tape1, tape2, v_base = _ops.load().spline_sample_vjp_tape(*flow.native(), ud, ed, gx, c)
+        grads = [None] * len(ctx.needs_input_grad[3:])
+        if any(ctx.needs_input_grad[3:]):
+            grads = flow._param_grads_from_tape(tape2, torch.ones(B, device=ud.device), B)
+            if c is not None:
+                grads = [a + b for a, b in zip(grads, flow._param_grads_from_tape(tape1, c, B))]
+        g_noise = v_base * flow._nf_model.q0.scale if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else None
+        circ = flow._circ
+        g_u = g_noise * circ if ctx.needs_input_grad[1] else None
+        g_eps = g_noise * (~circ) if ctx.needs_input_grad[2] else None
+        return (None, g_u, g_eps, *grads)
+
+
 class CircularCoupledRQSFlow(nn.Module):
     def __init__(self, dim: int, n_layers: int, hidden_units: int, ind_circ: Sequence[int], tail_bound,
                  num_bins: int = 8, blocks_per_layer: int = 1, seed: int = 0, circ_shift: str = "random",
@@ -219,6 +255,10 @@ class CircularCoupledRQSFlow(nn.Module):
         if eps is None:
             eps = torch.randn((shape[0], self.dim), dtype=torch.float32, device=dev)
         _ops.require_device(u, "u")
+        if torch.is_grad_enabled():
+            params = self._train_params()
+            if u.requires_grad or eps.requires_grad or any(p.requires_grad for p in params):
+                return _SplineSampleTape.apply(self, u, eps, *params)
         x, log_q = _ops.load().spline_sample(*self.native(), u.contiguous().float(), eps.contiguous().float())
         return x, log_q
 

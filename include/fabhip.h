@@ -37,7 +37,7 @@ const char* fabhip_strerror(int code);
 /* ABI revision of this header: bumped on every change of a struct layout or a function signature.  The host
  * binding compares it (and the struct sizes below) with what it was written against and refuses to run on a
  * mismatch, so that a stale library can never be driven with newer struct layouts. */
-#define FABHIP_ABI_VERSION 215
+#define FABHIP_ABI_VERSION 216
 int fabhip_version(void);
 /* sizeof() of the argument structs as the library was compiled:
  * {fabhip_flow_params, fabhip_flow, fabhip_target, fabhip_point, fabhip_anneal, fabhip_hmc_args,
@@ -238,6 +238,19 @@ int fabhip_tape_gemm(const float* Y, int64_t y_layer_stride, int32_t ldy, int32_
 int fabhip_spline_log_prob_tape(const fabhip_spline_flow* flow, const float* x, float* log_q, float* grad_x, int64_t B,
                                 float* tape, int64_t tape_floats, void* workspace, size_t workspace_bytes,
                                 fabhip_stream_t stream);
+/* The backward of `x, log_q = flow.sample_and_log_prob()` w.r.t. the parameters and the base noise (the reparameterised baseline
+ * losses, fab/core.py:130-152 with the spline flow of experiments/make_flow/make_aldp_model.py), by the implicit function theorem
+ * on the log_prob direction S (x = S^-1(z0; theta), z0 = the base sample): for cotangents gx of x and gl of log_q (either nullable),
+ *   d/d theta = gl * d log q(x) / d theta |_x  -  v_l^T dS_l / d theta_l,   v = (dS/dx)^-T (gx + gl * d log q / dx).
+ * The call re-runs the sampler from (u, eps) keeping every layer's state (the sweeps linearise where the sample was made, not on a
+ * trajectory re-derived from the rounded x), runs the log_prob direction's reverse sweep on them (tape_density: seed 1 per sample,
+ * as fabhip_spline_log_prob_tape writes it) and carries v from the x side to the base side (tape_inverse, same layout).  The
+ * parameter gradients are the tape GEMMs of tape_density with coefficients gl plus those of tape_inverse with coefficients 1.
+ * v_x [B][dim]: scratch, on return v at x.  v_base (nullable) [B][dim]: v at the base side = the cotangent of z0.
+ * Workspace: fabhip_spline_workspace_bytes(.., with_grad = 1); each tape fabhip_spline_tape_layout's out16[0] floats. */
+int fabhip_spline_sample_vjp_tape(const fabhip_spline_flow* flow, const float* u, const float* eps, const float* gx, const float* gl,
+                                  float* v_x, float* v_base, int64_t B, float* tape_density, float* tape_inverse,
+                                  int64_t tape_floats, void* workspace, size_t workspace_bytes, fabhip_stream_t stream);
 /* x, log_q = flow.sample given u[B][dim] ~ U(0,1) (circular coordinates) and eps[B][dim] ~ N(0,1) (the others). */
 int fabhip_spline_sample(const fabhip_spline_flow* flow, const float* u, const float* eps, float* x, float* log_q,
                          int64_t B, void* workspace, size_t workspace_bytes, fabhip_stream_t stream);

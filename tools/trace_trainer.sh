@@ -3,8 +3,8 @@
 cd ${GRAFT_REPO_ROOT:-.}
 export TMPDIR=/tmp
 O=gpurun_out/trace_trainer; mkdir -p $O
-ITERS=${ITERS:-10} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python tools/bench_trainer.py > $O/log.txt 2>&1
-tail -1 $O/log.txt > $O/bench.json
+ITERS=${ITERS:-8} timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof -- python tools/bench_trainer.py > $O/log.txt 2>&1
+grep "^{\"workload\"" $O/log.txt | tail -1 > $O/bench.json
 find $O/prof -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $O/kernel_stats.csv
 f=$(find $O/prof -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY' > $O/iteration_timeline.txt
