@@ -421,7 +421,8 @@ __global__ __launch_bounds__(256) void k_pack_r4(FlowDims f, R4Dims rd, MlpTab t
 // of 1-KiB tiles (lane = column, float4 = 4 consecutive k) in the order the wave consumes them, every layer and direction
 // padded to r8_tiles_p(G) tiles (a multiple of the ring depth).  Forward [AW 4 | W1 4 (+1) | W2 16 G (+4 G) | W3 2 G],
 // reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T G | AWT 4]; N-split matrices: columns 64 wave + lane, all of K; (+..): the
-// fifth column group (columns 256 + lane) of a 320-wide layer, this wave's quarter of the k-quads; K-split (W3, W1T): this
+// fifth column group of a 320-wide layer, N-split as well (r6): columns 256 + 16 wave + (lane & 15), all of K as DENSE tiles
+// (4 k-quads side by side in the lane quarters); K-split (W3, W1T): this
 // wave's quarter of K as DENSE tiles (2 / 4 k-quads side by side); the D x D maps (dense) are the same tiles for every wave.
 __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0, float* __restrict__ packed) {
     const int D = f.D, d = f.d, DO = f.DO, W = f.W, G = f.Wp / 64, EX = G - 4, K = f.K;
@@ -450,9 +451,9 @@ __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0,
         if (fwd) {
             if (ti < R8_TD) { mat = 0; q = 2 * ti + (lane >> 5); n = lane & 31; }               // dense: 2 k-quads x 32 columns
             else if ((ti -= R8_TD) < R8_Kd4) { mat = 1; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= R8_Kd4) < EX * (R8_Kd4 / 4)) { mat = 1; q = (R8_Kd4 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= R8_Kd4) < EX * (R8_Kd4 / 4)) { mat = 1; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else if ((ti -= EX * (R8_Kd4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else { ti -= EX * NQK; mat = 3; q = NQK * wave + 2 * ti + (lane >> 5); n = lane & 31; }   // dense: 2 k-quads x (shift | scale)
             const int k = 4 * q + kk;
             if (mat == 0) { if (k < D && n < D) v = Wm[k * D + n]; }
@@ -461,9 +462,9 @@ __global__ __launch_bounds__(256) void k_pack_r8(FlowDims f, MlpTab tab, int k0,
             else { const int o = prm_orig(n, DO, f.DOp); if (k < W && n < 2 * f.DOp && o >= 0) v = w3[o * W + k]; }
         } else {
             if (ti < R8_Ko4) { mat = 3; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= R8_Ko4) < EX * (R8_Ko4 / 4)) { mat = 3; q = (R8_Ko4 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= R8_Ko4) < EX * (R8_Ko4 / 4)) { mat = 3; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else if ((ti -= EX * (R8_Ko4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else if ((ti -= EX * NQK) < NQK / 4) { mat = 1; q = NQK * wave + 4 * ti + (lane >> 4); n = lane & 15; }   // dense: 4 k-quads x 16
             else { ti -= NQK / 4; mat = 0; q = 2 * ti + (lane >> 5); n = lane & 31; }
             const int k = 4 * q + kk;
@@ -511,9 +512,9 @@ __global__ __launch_bounds__(256) void k_pack_r8f(FlowDims f, MlpTab tab, int k0
         if (fwd) {
             if (ti < R8_TD) { mat = 0; q = 2 * ti + (lane >> 5); n = lane & 31; }
             else if ((ti -= R8_TD) < NQ1) { mat = 1; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= NQ1) < EX * (NQ1 / 4)) { mat = 1; q = (NQ1 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= NQ1) < EX * (NQ1 / 4)) { mat = 1; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else if ((ti -= EX * (NQ1 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else { ti -= EX * NQK; mat = 3; q = NQK * wave + 2 * ti + (lane >> 5); n = lane & 31; }
             const int k = 4 * q + kk;
             if (mat == 0) { if (k < D && n < D) v = Wm[k * D + n]; }
@@ -522,9 +523,9 @@ __global__ __launch_bounds__(256) void k_pack_r8f(FlowDims f, MlpTab tab, int k0
             else { const int o = prm_orig(n, DO, f.DOp); if (k < W && n < 2 * f.DOp && o >= 0) v = w3[o * W + k]; }
         } else {
             if (ti < R8_Ko4) { mat = 3; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= R8_Ko4) < EX * (R8_Ko4 / 4)) { mat = 3; q = (R8_Ko4 / 4) * wave + ti; n = 256 + lane; }
+            else if ((ti -= R8_Ko4) < EX * (R8_Ko4 / 4)) { mat = 3; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else if ((ti -= EX * (R8_Ko4 / 4)) < NQW) { mat = 2; q = ti; n = 64 * wave + lane; }
-            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = NQK * wave + ti; n = 256 + lane; }
+            else if ((ti -= NQW) < EX * NQK) { mat = 2; q = 4 * ti + (lane >> 4); n = 256 + 16 * wave + (lane & 15); }
             else if ((ti -= EX * NQK) < NQK / 2) { mat = 1; q = NQK * wave + 2 * ti + (lane >> 5); n = lane & 31; }   // dense: 2 k-quads x 32
             else { mat = 0; q = 2 * wave + (lane >> 5); n = lane & 31; }
             const int k = 4 * q + kk;

@@ -65,6 +65,9 @@ FAB_HD long r8f_wave_tiles(int G, int K) { return 2L * K * r8f_tiles_p(G) + R8_T
 FAB_HD long r8f_image_floats(int G, int K) { return (long)NWAVE * r8f_wave_tiles(G, K) * 256; }
 FAB_HD bool r8f_shape_ok(const FlowDims& f) { return f.o_r8f >= 0; }
 
+// ballot words of a stage: the four 64-column groups + (G == 5) one word per wave for its 16 columns of the fifth group
+FAB_HD int r8_mask_groups(int G) { return 4 + 4 * (G - 4); }
+
 // LDS plan of an r8 workgroup (floats)
 struct R8Lds {
     int WS, HF;                        // leading dim of the hidden tiles; floats per layer of the head block
@@ -86,7 +89,7 @@ FAB_HD R8Lds make_r8_lds(const FlowDims& f) {
     l.o_PART = o; o += NWAVE * R8 * R4_DS;           // K-split partials: narrow outputs / the fifth column group
     l.o_ES = o; o += f.K * R8 * f.DOp;
     l.o_V2 = o; o += f.K * R8 * f.DOp;
-    l.o_MASK = o; o += f.K * 2 * G * R8 * 2;         // u64 ballots [layer][stage][column group][chain]
+    l.o_MASK = o; o += f.K * 2 * r8_mask_groups(G) * R8 * 2;   // u64 ballots [layer][stage][column group][chain]
     l.o_HEAD = o; o += f.K * l.HF;
     l.total = (o + 3) & ~3;
     return l;
@@ -168,6 +171,14 @@ __device__ __forceinline__ float r8_sum_halves(float v) {
     return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// sum of the four k-quad quarters of a dense 16-column product (lanes l, l ^ 16, l ^ 32, l ^ 48 hold the partial products of
+// column l & 15), on every lane: (q0 + q1) + (q2 + q3) with v_permlane16_swap / v_permlane32_swap
+__device__ __forceinline__ float r8_sum_quarters(float v) {
+    const unsigned u = __float_as_uint(v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return r8_sum_halves(__uint_as_float(r[0]) + __uint_as_float(r[1]));
+}
+
 // One product into the hidden width: OUT[8][Wp] = epilogue(ACT[8][4 NQ] @ B).  Stream tiles T0 .. : NQ of this wave's own
 // column group, then (G == 5) NQ / 4 of the fifth group (this wave's quarter of K).  `epi(v, col)` -> stored value of an
 // output BEFORE masking; EP 1: ReLU, decisions kept in mk; EP 2: multiplied by the decisions in mk.
@@ -204,36 +215,52 @@ __device__ __forceinline__ void r8_dense_wide(ST& s, const float* act, float* ou
                 out[(4 * rb + r) * ldo + col] = v;
             }
     }
-    // (the main epilogue comes FIRST: with the two GEMMs back to back hipcc's allocator runs out of registers - 500 spilled)
-    if constexpr (EX) {                // partial products of the fifth group: k-quads [w NQ / 4, (w + 1) NQ / 4)
-        static_assert(NQ % 4 == 0, "the fifth column group is K-split over 4 waves");
-        f32x4 ox[2];
-        S8Acc<2> acc;
-        s8_zero(acc);
-        s8_run<T0 + NQ, NQ / 4, TOTAL>(s, act + t.arow * lda + NQ * t.wave, 4 * lda, acc);
-        s8_fold(acc, ox);
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) PART[(t.wave * R8 + 4 * rb + r) * R4_DS + t.lane] = ox[rb][r];
-    }
+    // (the main epilogue comes FIRST: with the two GEMMs back to back hipcc's allocator runs out of registers - 500 spilled; its
+    //  rows issued among the fifth group's MFMAs - tried in r6 - cost more than they hide: an LDS access there sits in front of every
+    //  tile's operand wait, and the register-only form of the rows spills)
     if constexpr (EX) {
-        s8_barrier();
-        const int col = 256 + t.lane;
-        const float bv = bias(col);
-        unsigned long long* mw = mk + 4 * R8;
+        // the fifth column group, N-split like the other four: wave w owns columns 256 + 16 w .. + 15 for ALL of K, streamed as
+        // dense tiles (4 k-quads side by side in the lane quarters, each quarter multiplying its own k-quad); the four quarters'
+        // partial products are added by lane swaps - no partial sums through LDS, no barrier, no second epilogue pass
+        // (r6; before: K split over the waves, PART round trip + barrier + finish: ~0.5 k cycles per stage, 4 stages per layer pair)
+        static_assert(NQ % 4 == 0, "a dense 16-column tile holds 4 k-quads");
+        f32x4 ox[2];
+        {
+            S8Acc<2> acc;
+            s8_zero(acc);
+            s8_run_k<16, T0 + NQ, NQ / 4, TOTAL>(s, act + t.arow * lda + 4 * (t.lane >> 4), 4 * lda, acc);
+            s8_fold(acc, ox);
+        }
+        // transpose-reduce: 8 rows x 4 quarters of partial products per lane -> lane (q, n) keeps the totals of rows 2 q and 2 q + 1
+        // of column n.  permlane32_swap(a, b) -> [a.lo | b.lo], [a.hi | b.hi]: their sum holds a's half-sums in the lower half and
+        // b's in the upper; permlane16_swap the same one level down.  Every total = (q0 + q2) + (q1 + q3).
+        auto pair32 = [](float a, float b) {
+            const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+            return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        };
+        auto pair16 = [](float a, float b) {
+            const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+            return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+        };
+        float tt[4];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {                                   // wave w finishes chains 2 w, 2 w + 1 of the fifth group
-            const int rr = 2 * t.wave + i;
-            float v = r8_part_sum(PART + rr * R4_DS + t.lane) + bv;
+        for (int r = 0; r < 4; ++r) tt[r] = pair32(ox[0][r], ox[1][r]);          // lower half: row r, upper half: row r + 4
+        float u2[2] = {pair16(tt[0], tt[2]), pair16(tt[1], tt[3])};             // quarter q: row 2 q | row 2 q + 1
+        const int q = t.lane >> 4;
+        const int col = 256 + 16 * t.wave + (t.lane & 15);
+        const float bv = bias(col);
+        unsigned long long* mw = mk + (4 + t.wave) * R8;                       // (two words per wave: bit = lane)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = u2[i] + bv;
             if constexpr (EP == 1) {
                 const unsigned long long m = __ballot(v > 0.f);
-                if (t.lane == 0) mw[rr] = m;
+                if (t.lane == 0) mw[i] = m;
                 v = v > 0.f ? v : 0.f;
             } else if constexpr (EP == 2) {
-                v = ((mw[rr] >> t.lane) & 1ull) ? v : 0.f;
+                v = ((mw[i] >> t.lane) & 1ull) ? v : 0.f;
             }
-            out[rr * ldo + col] = v;
+            out[(2 * q + i) * ldo + col] = v;
         }
     }
     s8_barrier();
@@ -277,6 +304,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
                                   const Tid8f& t, ST& s, int* grad_off, const R8Tape* tp = nullptr) {
     static_assert(!(TAPE && FUSED), "the tape holds z and the full cotangent of z: one stage per matrix");
     constexpr int EX = G - 4, NQW = 16 * G, NQK = 4 * G;                  // k-quads of K = Wp; of a wave's quarter of it
+    constexpr int MG = 4 + 4 * EX;                                          // ballot words per stage and chain (r8_mask_groups)
     constexpr int NQ1 = FUSED ? R8_KD4 : R8_Kd4;                            // k-quads of the first Linear's K (fused: the whole state)
     constexpr int F_AW = 0, F_W1 = R8_TD, F_W2 = F_W1 + NQ1 + EX * (NQ1 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK / 2;
     constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK,
@@ -309,7 +337,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         float* HB = lds + l.o_HB;
         float* PART = lds + l.o_PART;
         const float* HD = lds + l.o_HEAD + (size_t)layer * l.HF;
-        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * G * R8;
+        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * MG * R8;
         const bool tl = layer == f.K - 2;
         if (tl) FAB_TL(f, 0);
         float* tl_layer = nullptr;
@@ -346,7 +374,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         // first read by the coupling, three barriers from here)
         r8_dense_wide<G, F_W1, NQ1, CONT + TP, 1, R4_DS, WS>(s, FUSED ? lds + cur : Z, HA, PART, mk, t, [&](int col) { return HD[64 + col]; });
         if (tl) FAB_TL(f, 2);
-        r8_dense_wide<G, F_W2, NQW, CONT + TP, 1, WS, WS>(s, HA, HB, PART, mk + G * R8, t, [&](int col) { return HD[64 + f.Wp + col]; });
+        r8_dense_wide<G, F_W2, NQW, CONT + TP, 1, WS, WS>(s, HA, HB, PART, mk + MG * R8, t, [&](int col) { return HD[64 + f.Wp + col]; });
         if (tl) FAB_TL(f, 3);
         {   // (shift | scale) = HB W3: K split over the waves, partial [8][64] products to PART
             f32x4 o[2];
@@ -441,7 +469,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         float* HB = lds + l.o_HB;
         float* DP = lds + l.o_DP;
         float* PART = lds + l.o_PART;
-        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * G * R8;
+        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * MG * R8;
         float* Gs = lds + cur;
         const bool tl = layer == 1;
         if (tl) FAB_TL(f, 16);
@@ -451,7 +479,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             r8_tape_narrow(tl_layer + tp->td->o_DP + tp->row0 * tp->td->wp, tp->td->wp, DP, t.tid);
         }
         // d relu(h2) = DP W3T masked by h2 > 0 -> HA;  d relu(h1) = HA W2T masked by h1 > 0 -> HB
-        r8_dense_wide<G, B_W3T, R8_Ko4, CONT + TP, 2, R4_DS, WS>(s, DP, HA, PART, mk + G * R8, t, [](int) { return 0.f; });
+        r8_dense_wide<G, B_W3T, R8_Ko4, CONT + TP, 2, R4_DS, WS>(s, DP, HA, PART, mk + MG * R8, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 17);
         r8_dense_wide<G, B_W2T, NQW, CONT + TP, 2, WS, WS>(s, HA, HB, PART, mk, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 18);
