@@ -496,7 +496,7 @@ def main():
                                              "item 1); over the whole launch incl. the short stages"}
         # HBM-side traffic per launch: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes restricted to this kernel
         # (tools/pmc_traffic.sh; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), committed summary
-        for path in ((os.path.join("profiles", "r5", "hmc_step_r4_traffic_pmc_summary.json"),) if r4 else
+        for path in (tuple(os.path.join("profiles", rnd, "hmc_step_r4_traffic_pmc_summary.json") for rnd in ("r6", "r5")) if r4 else
                      tuple(os.path.join("profiles", rnd, "hmc_step_pmc_summary.json") for rnd in ("r5", "r4"))):
             if os.path.exists(os.path.join(ROOT, path)) and args.workload == "headline" and not custom:
                 with open(os.path.join(ROOT, path)) as f:

@@ -119,6 +119,11 @@ def kernel_rows(trainer, dev, n=20):
         t_tape = _graph_time(lambda: flow.log_prob_with_tape(x), dev, 20, 1)
         _, tape = flow.log_prob_with_tape(x)
         t_pg = _graph_time(lambda: flow.param_grad_flat(tape, coef), dev, 5)
+
+        def pair():                                  # the two in the order the trainer runs them
+            _, tp = flow.log_prob_with_tape(x)
+            flow.param_grad_flat(tp, coef)
+        t_pair = _graph_time(pair, dev, 5, 4)
         ops = _ops.load()
         packed, Dd, K, W = flow.native(need_inverse=False)
         rows = torch.randperm(buf.current_index if not buf.is_full else buf.max_length, device=dev)[:BATCH].contiguous()
@@ -144,6 +149,10 @@ def kernel_rows(trainer, dev, n=20):
                      "frac_fp32_mfma_peak": ach / PEAK_FP32_MFMA_TFLOPS,
                      "timing": "HIP-graph replays of the op between two HIP events (GPU time of its launches, no host gaps); "
                                "per-kernel rows: profiles/r6/trainer_kernel_stats_rocprofv3.csv"}
+    out["tape_then_param_grad"] = {"us_per_call": t_pair * 1e6, "flop": 2 * BATCH * F_FWD + BATCH * F_PGRAD,
+                                   "frac_fp32_mfma_peak": (2 * BATCH * F_FWD + BATCH * F_PGRAD) / t_pair / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                                   "note": "the two ops alternating as in the trainer (the tape kernel replayed back to back on its own "
+                                           "runs ~30 us slower than inside an iteration: 165 us in profiles/r6/trainer_iteration_timeline.txt)"}
     out["minibatch_step"] = {"op": "fabhip::buffer_train_step (training pack, tape, loss weights + buffer.adjust, parameter "
                                    "gradients, LU chain rule, clipped Adam)", "us_per_call": t_step * 1e6,
                              "timing": "HIP-graph replays"}
