@@ -19,7 +19,7 @@
 //   * every wave reads its tiles of a layer and direction as ONE stream through a 32-tile AGPR ring (stream_r8.h): forward
 //     [AW 4 | W1 4 (+1) | W2 16 G (+4 G) | W3 2 G], reverse [W3T 8 (+2) | W2T 16 G (+4 G) | W1T G | AWT 4] tiles of 1 KiB
 //     ((+..): its share of the fifth group); the next layer's ring is requested before the layer's last element-wise stage;
-//   * biases / log-det constants of ALL layers sit in LDS (copied once per kernel), ReLU decisions as ballots in LDS.
+//   * biases / log-det constants of ALL layers sit in LDS (copied once per kernel), ReLU decisions as one word per thread and layer in LDS.
 // Same arithmetic as flow_log_prob_r4 / flow_log_prob_tile up to the summation order inside the GEMMs.
 #pragma once
 #include "flow_r4.h"
@@ -65,9 +65,6 @@ FAB_HD long r8f_wave_tiles(int G, int K) { return 2L * K * r8f_tiles_p(G) + R8_T
 FAB_HD long r8f_image_floats(int G, int K) { return (long)NWAVE * r8f_wave_tiles(G, K) * 256; }
 FAB_HD bool r8f_shape_ok(const FlowDims& f) { return f.o_r8f >= 0; }
 
-// ballot words of a stage: the four 64-column groups + (G == 5) one word per wave for its 16 columns of the fifth group
-FAB_HD int r8_mask_groups(int G) { return 4 + 4 * (G - 4); }
-
 // LDS plan of an r8 workgroup (floats)
 struct R8Lds {
     int WS, HF;                        // leading dim of the hidden tiles; floats per layer of the head block
@@ -89,7 +86,7 @@ FAB_HD R8Lds make_r8_lds(const FlowDims& f) {
     l.o_PART = o; o += NWAVE * R8 * R4_DS;           // K-split partials: narrow outputs / the fifth column group
     l.o_ES = o; o += f.K * R8 * f.DOp;
     l.o_V2 = o; o += f.K * R8 * f.DOp;
-    l.o_MASK = o; o += f.K * 2 * r8_mask_groups(G) * R8 * 2;   // u64 ballots [layer][stage][column group][chain]
+    l.o_MASK = o; o += f.K * NWAVE * 64;             // ReLU decisions: one word per layer and thread (see r8_dense_wide)
     l.o_HEAD = o; o += f.K * l.HF;
     l.total = (o + 3) & ~3;
     return l;
@@ -181,13 +178,16 @@ __device__ __forceinline__ float r8_sum_quarters(float v) {
 
 // One product into the hidden width: OUT[8][Wp] = epilogue(ACT[8][4 NQ] @ B).  Stream tiles T0 .. : NQ of this wave's own
 // column group, then (G == 5) NQ / 4 of the fifth group (this wave's quarter of K).  `epi(v, col)` -> stored value of an
-// output BEFORE masking; EP 1: ReLU, decisions kept in mk; EP 2: multiplied by the decisions in mk.
-// mk: ballots of this layer and stage, [column group][chain].  Ends with a workgroup barrier.
+// output BEFORE masking; EP 1: ReLU, decisions kept in mb; EP 2: multiplied by the decisions in mb.
+// mb: THIS thread's two decision bytes of this layer and stage - byte 0: bit i = output row i of its column in the 64-column groups,
+// byte 1: its two rows of the fifth group (r6: a lane keeps the decisions of its own outputs - the reverse sweep's products have the
+// same thread-to-output mapping - instead of 8 + 2 wave ballots per stage written by lane 0 and read back as broadcasts: ~55 VALU /
+// LDS instructions fewer per stage in the epilogues, which nothing overlaps).  Ends with a workgroup barrier.
 // (leading dimensions are template parameters: with run-time strides hipcc hoists one address register per LDS access out of
 // the layer loop - several hundred of them - and spills)
 template <int G, int T0, int NQ, int TOTAL, int EP, int lda, int ldo, class ST, class Bias>
 __device__ __forceinline__ void r8_dense_wide(ST& s, const float* act, float* out, float* PART,
-                                              unsigned long long* mk, const Tid8f& t, Bias bias) {
+                                              unsigned char* mb, const Tid8f& t, Bias bias) {
     constexpr int EX = G - 4;
     f32x4 o[2];
     {
@@ -199,21 +199,23 @@ __device__ __forceinline__ void r8_dense_wide(ST& s, const float* act, float* ou
     {
         const int col = 64 * t.wave + t.lane;
         const float bv = bias(col);
-        unsigned long long* mw = mk + t.wave * R8;
+        unsigned bits = 0;
+        if constexpr (EP == 2) bits = mb[0];
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float v = o[rb][r] + bv;
                 if constexpr (EP == 1) {
-                    const unsigned long long m = __ballot(v > 0.f);
-                    if (t.lane == 0) mw[4 * rb + r] = m;
-                    v = v > 0.f ? v : 0.f;
+                    const bool p = v > 0.f;
+                    bits |= p ? (1u << (4 * rb + r)) : 0u;
+                    v = p ? v : 0.f;
                 } else if constexpr (EP == 2) {
-                    v = ((mw[4 * rb + r] >> t.lane) & 1ull) ? v : 0.f;
+                    v = (bits & (1u << (4 * rb + r))) ? v : 0.f;
                 }
                 out[(4 * rb + r) * ldo + col] = v;
             }
+        if constexpr (EP == 1) mb[0] = (unsigned char)bits;
     }
     // (the main epilogue comes FIRST: with the two GEMMs back to back hipcc's allocator runs out of registers - 500 spilled; its
     //  rows issued among the fifth group's MFMAs - tried in r6 - cost more than they hide: an LDS access there sits in front of every
@@ -249,19 +251,21 @@ __device__ __forceinline__ void r8_dense_wide(ST& s, const float* act, float* ou
         const int q = t.lane >> 4;
         const int col = 256 + 16 * t.wave + (t.lane & 15);
         const float bv = bias(col);
-        unsigned long long* mw = mk + (4 + t.wave) * R8;                       // (two words per wave: bit = lane)
+        unsigned bits = 0;
+        if constexpr (EP == 2) bits = mb[1];
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float v = u2[i] + bv;
             if constexpr (EP == 1) {
-                const unsigned long long m = __ballot(v > 0.f);
-                if (t.lane == 0) mw[i] = m;
-                v = v > 0.f ? v : 0.f;
+                const bool p = v > 0.f;
+                bits |= p ? (1u << i) : 0u;
+                v = p ? v : 0.f;
             } else if constexpr (EP == 2) {
-                v = ((mw[i] >> t.lane) & 1ull) ? v : 0.f;
+                v = (bits & (1u << i)) ? v : 0.f;
             }
             out[(2 * q + i) * ldo + col] = v;
         }
+        if constexpr (EP == 1) mb[1] = (unsigned char)bits;
     }
     s8_barrier();
 }
@@ -304,7 +308,6 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
                                   const Tid8f& t, ST& s, int* grad_off, const R8Tape* tp = nullptr) {
     static_assert(!(TAPE && FUSED), "the tape holds z and the full cotangent of z: one stage per matrix");
     constexpr int EX = G - 4, NQW = 16 * G, NQK = 4 * G;                  // k-quads of K = Wp; of a wave's quarter of it
-    constexpr int MG = 4 + 4 * EX;                                          // ballot words per stage and chain (r8_mask_groups)
     constexpr int NQ1 = FUSED ? R8_KD4 : R8_Kd4;                            // k-quads of the first Linear's K (fused: the whole state)
     constexpr int F_AW = 0, F_W1 = R8_TD, F_W2 = F_W1 + NQ1 + EX * (NQ1 / 4), F_W3 = F_W2 + NQW + EX * NQK, TF = F_W3 + NQK / 2;
     constexpr int B_W3T = 0, B_W2T = R8_Ko4 + EX * (R8_Ko4 / 4), B_W1T = B_W2T + NQW + EX * NQK,
@@ -337,7 +340,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         float* HB = lds + l.o_HB;
         float* PART = lds + l.o_PART;
         const float* HD = lds + l.o_HEAD + (size_t)layer * l.HF;
-        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * MG * R8;
+        unsigned char* mk = reinterpret_cast<unsigned char*>(lds + l.o_MASK + (size_t)layer * (NWAVE * 64) + t.tid);   // bytes 0, 1: h1; 2, 3: h2
         const bool tl = layer == f.K - 2;
         if (tl) FAB_TL(f, 0);
         float* tl_layer = nullptr;
@@ -374,7 +377,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         // first read by the coupling, three barriers from here)
         r8_dense_wide<G, F_W1, NQ1, CONT + TP, 1, R4_DS, WS>(s, FUSED ? lds + cur : Z, HA, PART, mk, t, [&](int col) { return HD[64 + col]; });
         if (tl) FAB_TL(f, 2);
-        r8_dense_wide<G, F_W2, NQW, CONT + TP, 1, WS, WS>(s, HA, HB, PART, mk + MG * R8, t, [&](int col) { return HD[64 + f.Wp + col]; });
+        r8_dense_wide<G, F_W2, NQW, CONT + TP, 1, WS, WS>(s, HA, HB, PART, mk + 2, t, [&](int col) { return HD[64 + f.Wp + col]; });
         if (tl) FAB_TL(f, 3);
         {   // (shift | scale) = HB W3: K split over the waves, partial [8][64] products to PART
             f32x4 o[2];
@@ -469,7 +472,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
         float* HB = lds + l.o_HB;
         float* DP = lds + l.o_DP;
         float* PART = lds + l.o_PART;
-        unsigned long long* mk = reinterpret_cast<unsigned long long*>(lds + l.o_MASK) + (size_t)layer * 2 * MG * R8;
+        unsigned char* mk = reinterpret_cast<unsigned char*>(lds + l.o_MASK + (size_t)layer * (NWAVE * 64) + t.tid);   // bytes 0, 1: h1; 2, 3: h2
         float* Gs = lds + cur;
         const bool tl = layer == 1;
         if (tl) FAB_TL(f, 16);
@@ -479,7 +482,7 @@ __device__ __forceinline__ float flow_log_prob_r8(const FlowDims& f, const R8Lds
             r8_tape_narrow(tl_layer + tp->td->o_DP + tp->row0 * tp->td->wp, tp->td->wp, DP, t.tid);
         }
         // d relu(h2) = DP W3T masked by h2 > 0 -> HA;  d relu(h1) = HA W2T masked by h1 > 0 -> HB
-        r8_dense_wide<G, B_W3T, R8_Ko4, CONT + TP, 2, R4_DS, WS>(s, DP, HA, PART, mk + MG * R8, t, [](int) { return 0.f; });
+        r8_dense_wide<G, B_W3T, R8_Ko4, CONT + TP, 2, R4_DS, WS>(s, DP, HA, PART, mk + 2, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 17);
         r8_dense_wide<G, B_W2T, NQW, CONT + TP, 2, WS, WS>(s, HA, HB, PART, mk, t, [](int) { return 0.f; });
         if (tl) FAB_TL(f, 18);

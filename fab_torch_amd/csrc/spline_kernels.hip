@@ -1346,14 +1346,19 @@ static inline size_t sp_al(size_t v) { return (v + 255) & ~(size_t)255; }
 // launch.h: the outer step's begin / accept / step-size rule inside the leapfrog launches - where the one-launch leapfrog
 // applies, the switch is on and the last wave's 2 nblk block sums fit the conditioner-output tile it uses as scratch
 size_t spline_fold_scratch_floats(int64_t B) { return (size_t)32 * ((B + 15) / 16) + 64; }
+// THE applicability test of the one-launch leapfrog, shared by the query below and by spline_log_prob_leap itself (a precondition
+// added to one of them only would turn the caller's fallback into a failure half-way through an outer step): chains per
+// workgroup / 8 of the kernel that would run, 0 where it does not apply
+static int spline_leap_row_blocks(const fabhip_spline_flow* flow, int64_t B, SplineDims* dims) {
+    if (!flow || !flow->packed || B < 1 || !option(FABHIP_OPT_SPLINE_LEAP) || option(FABHIP_OPT_SPLINE_STAGED)) return 0;
+    if (check_spline_shape(flow->dim, flow->n_layers, flow->hidden) != FABHIP_OK) return 0;
+    *dims = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
+    return r8_row_blocks(*dims, (long)B, resolve_fast(flow->precision), true);
+}
 bool spline_leap_fold_supported(const fabhip_spline_flow* flow, int64_t B) {
-    if (!flow || !flow->packed || B < 1 || !option(FABHIP_OPT_SPLINE_LEAP) || option(FABHIP_OPT_SPLINE_STAGED) ||
-        !option(FABHIP_OPT_ADAPT_FOLD))
-        return false;
-    if (check_spline_shape(flow->dim, flow->n_layers, flow->hidden) != FABHIP_OK) return false;
-    const SplineDims f = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
-    const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision), true);
-    if (rb == 0) return false;
+    SplineDims f;
+    const int rb = spline_leap_row_blocks(flow, B, &f);
+    if (rb == 0 || !option(FABHIP_OPT_ADAPT_FOLD)) return false;
     const S8Lds l = make_s8_lds(f, true, 4 * rb);
     return 2 * ((B + 15) / 16) <= (int64_t)(4 * rb) * l.PS;
 }
@@ -1362,14 +1367,13 @@ bool spline_leap_fold_supported(const fabhip_spline_flow* flow, int64_t B) {
 int spline_log_prob_leap(const fabhip_spline_flow* flow, const SplineLeap& a, float* log_q, float* grad_x, int64_t B,
                          void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (!flow || !flow->packed || !a.XP || !a.x_out || !a.P || !a.GU || !log_q || !grad_x || !workspace || B < 0) return FABHIP_EINVAL;
-    if (!option(FABHIP_OPT_SPLINE_LEAP) || option(FABHIP_OPT_SPLINE_STAGED)) return FABHIP_ENOTSUP;
     FAB_TRY(check_spline_shape(flow->dim, flow->n_layers, flow->hidden));
     FAB_TRY(check_target(&a.tg, flow->dim));
     if (B == 0) return FABHIP_OK;
-    if (workspace_bytes < fabhip_spline_workspace_bytes(flow->dim, flow->n_layers, flow->hidden, B, 1)) return FABHIP_ENOSPC;
-    const SplineDims f = make_spline_dims(flow->dim, flow->n_layers, flow->hidden);
-    const int rb = r8_row_blocks(f, (long)B, resolve_fast(flow->precision), true);
+    SplineDims f;
+    const int rb = spline_leap_row_blocks(flow, B, &f);
     if (rb == 0) return FABHIP_ENOTSUP;
+    if (workspace_bytes < fabhip_spline_workspace_bytes(flow->dim, flow->n_layers, flow->hidden, B, 1)) return FABHIP_ENOSPC;
     char* ws = (char*)workspace;
     float* Z = (float*)ws; ws += sp_al((size_t)(f.L + 1) * B * f.D * 4);
     float* P = (float*)ws;
