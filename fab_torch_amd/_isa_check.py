@@ -247,6 +247,35 @@ def check_adapt_fold(name, insns):
     return bad
 
 
+def check_bf16_mfma_overlap(name, insns):
+    """No bf16 MFMA may write a destination that overlaps its A or B operand.  With the accumulators in architectural registers
+    (_build.py: -amdgpu-mfma-vgpr-form) hipcc hands an operand that dies in the MFMA to it as the destination, and gfx950 then
+    returns a wrong first row of every 4-row group for v_mfma_f32_16x16x32_bf16 / v_mfma_f32_4x4x4_16b_bf16 (found round 6: two
+    fast-mode tests; round 5 met it with a ring slot as the destination).  flow_device.h / flow_r4f.h keep the operands alive until
+    the result exists; this check refuses a build in which the allocator got around that."""
+    bad = []
+
+    def rng(tok):
+        m = re.match(r"([va])\[(\d+):(\d+)\]$", tok) or re.match(r"([va])(\d+)()$", tok)
+        if not m:
+            return None
+        lo = int(m.group(2))
+        return m.group(1), lo, int(m.group(3)) if m.group(3) else lo
+
+    for i, (_, text, _) in enumerate(insns):
+        if not text.startswith("v_mfma") or "bf16" not in text:
+            continue
+        ops = [o.strip() for o in text.split(None, 1)[1].split(",")]
+        if len(ops) < 3:
+            continue
+        d = rng(ops[0])
+        for which, tok in (("A", ops[1]), ("B", ops[2])):
+            r = rng(tok)
+            if d and r and d[0] == r[0] and not (r[2] < d[1] or r[1] > d[2]):
+                bad.append((i, f"bf16 MFMA destination overlaps its {which} operand", text))
+    return bad
+
+
 def check_object(obj, patterns=None, verbose=False):
     """{kernel: findings} for the kernels of `obj` whose name contains one of `patterns` (all when None)."""
     out = {}
@@ -255,7 +284,7 @@ def check_object(obj, patterns=None, verbose=False):
             continue
         if not insns:
             continue
-        bad = check_kernel(name, insns) + check_adapt_fold(name, insns)
+        bad = check_kernel(name, insns) + check_adapt_fold(name, insns) + check_bf16_mfma_overlap(name, insns)
         out[name] = bad
         if verbose:
             n_ld = sum(1 for _, l, _ in insns if l.startswith("global_load_dwordx4"))

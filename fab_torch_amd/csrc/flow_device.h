@@ -732,12 +732,23 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 
+// v_mfma_f32_16x16x32_bf16 whose destination never overlaps its A / B operands.  With the accumulators in architectural registers
+// (_build.py: -amdgpu-mfma-vgpr-form) hipcc hands a B tile that dies in the MFMA to it as the destination (v_mfma v[92:95],
+// v[160:163], v[92:95], v[148:151]); gfx950 then returns a wrong first row of every 4-row group (round 5 met the same with the
+// 4x4x4 bf16 form and a ring slot as the destination, flow_r4f.h).  The fp32 forms are unaffected (the whole GPU suite compares them).
+// The empty asm keeps both operands alive until the result exists, so the allocator cannot reuse their registers for it.
+__device__ __forceinline__ f32x4 mfma_bf16_16x16x32(const bf16x8& a, const bf16x8& b, const f32x4& c) {
+    f32x4 d = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    asm volatile("" : "+v"(d) : "v"(a), "v"(b));       // (reads the RESULT too: the scheduler cannot lift it above the MFMA)
+    return d;
+}
+
 __device__ __forceinline__ f32x4 mfma_bf16(const float4& a0, const float4& a1, const uint4& b, f32x4 c) {
     union { unsigned u[4]; bf16x8 v; } ua, ub;
     ua.u[0] = cvt_pk_bf16(a0.x, a0.y); ua.u[1] = cvt_pk_bf16(a0.z, a0.w);
     ua.u[2] = cvt_pk_bf16(a1.x, a1.y); ua.u[3] = cvt_pk_bf16(a1.z, a1.w);
     ub.u[0] = b.x; ub.u[1] = b.y; ub.u[2] = b.z; ub.u[3] = b.w;
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, c, 0, 0, 0);
+    return mfma_bf16_16x16x32(ua.v, ub.v, c);
 }
 
 // acc[i] += A[16 x 64 NTWM] (fp32, LDS) @ B[:, tile wave + 4 i] (bf16 image), K = 64 NTWM = 2 NTWM blocks of 32.
@@ -768,7 +779,7 @@ __device__ __forceinline__ void gemm_bf16_chunk(uint4 (&b0)[CH][NTWM], uint4 (&b
                     constexpr int i = decltype(ic)::value;
                     union { uint4 q; bf16x8 v; } ub;
                     ub.q = b[c][i];
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
+                    acc[i] = mfma_bf16_16x16x32(ua.v, ub.v, acc[i]);
                     // block (C + 1) CH + c, tile i of the next chunk.  (No sched_barrier pins around this load: pinned, the
                     // spline kernel's reverse sweep gave run-to-run different gradients at NTWM = 4 - hipcc's own
                     // placement is deterministic over 30 x 4096-chain repeats and as fast.)
@@ -856,7 +867,7 @@ __device__ __forceinline__ void gemm_bf16(const float* __restrict__ A, int lda, 
                 constexpr int i = decltype(ic)::value;
                 union { uint4 q; bf16x8 v; } ub;
                 ub.q = pre.b[S][i];
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc[i], 0, 0, 0);
+                acc[i] = mfma_bf16_16x16x32(ua.v, ub.v, acc[i]);
                 mid.template step<S * NTWM + i>();            // one of the later stages' requests behind each MFMA
             });
         });

@@ -421,6 +421,10 @@ __device__ __forceinline__ void r4f_dense_wide_bf16(const float* act, int lda, R
         // the same overlap is fine, a single bf16 MFMA with it as well)
 #pragma unroll
         for (int g = 0; g < G; ++g) asm volatile("" : : "a"(ring.r[SL][g]));
+        // (r6, accumulators in architectural registers - _build.py's -amdgpu-mfma-vgpr-form: the same holds for the A operands, which
+        //  hipcc would otherwise hand to the last MFMA that reads them as its destination)
+#pragma unroll
+        for (int g = 0; g < G; ++g) asm volatile("" : "+v"(acc0[g]), "+v"(acc1[g]) : "v"(a0), "v"(a1));
         ring.refill(IC<I0 + i>{});
         __builtin_amdgcn_sched_barrier(0);
     });
