@@ -56,7 +56,7 @@ FAB_HD S8Lds make_s8_lds(const SplineDims& f, bool grad, int rows) {
     l.o_ZT = o; o += rows * 64;
     l.o_GT = o; if (grad) o += rows * 64;
     l.o_HD = o; o += s8_head_floats(f);
-    l.o_MASK = o; if (grad) o += f.L * 2 * NWAVE * rows * 2;          // u64 words
+    l.o_MASK = o; if (grad) o += f.L * NWAVE * 64;                    // ReLU decisions: one word per layer and thread
     l.total = (o + 3) & ~3;
     return l;
 }
@@ -256,7 +256,10 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
     float* A0 = lds + l.o_A0; float* X1 = lds + l.o_X1; float* X2 = lds + l.o_X2; float* T = lds + l.o_T;
     float* PT = lds + l.o_PT; float* ZT = lds + l.o_ZT; float* GT = lds + l.o_GT; float* HD = lds + l.o_HD;
     float* PART = X1;
-    unsigned long long* MASK = reinterpret_cast<unsigned long long*>(lds + l.o_MASK);
+    // ReLU decisions of the two hidden stages, kept per THREAD (r6, as flow_r8.h): bit 4 rb + r of the low / high half of the
+    // thread's word of a layer = its output row of h0 / t; the reverse sweep's products have the same thread-to-output mapping
+    static_assert(4 * RB <= 16, "one halfword of decisions per stage");
+    float* MASK = lds + l.o_MASK;
     const float* meta = HD + S8H_META;
     const float isq = 1.f / sqrtf((float)f.W);
     const int H = s8_head_floats(f), TPL = s8_tiles_per_wave(f);
@@ -406,13 +409,14 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
         if (tl) S8_TL(1);
         f32x4 o[RB];
         float h0[RB][4];
-        unsigned long long* mk = GRAD ? MASK + ((size_t)layer * 2 * NWAVE + t.wave) * R8 : nullptr;
+        unsigned short* mk = GRAD ? reinterpret_cast<unsigned short*>(MASK + (size_t)layer * (NWAVE * 64) + t.tid) : nullptr;
         {   // h0 = A0 W0 + b0; X2 = relu(h0)
             S8Acc<RB> acc;
             s8_zero(acc);
             s8_iter<K0Q, K0Q, 0, S8_INF>(s, A0 + t.arow * S8_AS, 4 * S8_AS, acc);
             s8_fold(acc, o);
             const float bv = HD[S8H_B0 + col];
+            unsigned bits = 0;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
@@ -420,22 +424,25 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                     const float v = o[rb][r] + bv;
                     h0[rb][r] = v;
                     X2[(4 * rb + r) * S8_WS + col] = v > 0.f ? v : 0.f;
-                    if (GRAD) { const unsigned long long m = __ballot(v > 0.f); if (t.lane == 0) mk[4 * rb + r] = m; }
+                    if (GRAD) bits |= v > 0.f ? (1u << (4 * rb + r)) : 0u;
                 }
+            if (GRAD) mk[0] = (unsigned short)bits;
         }
         s8_barrier();
         {   // t = relu(h0) Wa + ba; X1 = relu(t)
             if (layer > 0) head_fetch(Lr - lfl);
             s8_gemm64<PHF, RB>(s, X2, S8_WS, t, o);
             const float bv = HD[S8H_BA + col];
+            unsigned bits = 0;
 #pragma unroll
             for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = o[rb][r] + bv;
                     X1[(4 * rb + r) * S8_WS + col] = v > 0.f ? v : 0.f;
-                    if (GRAD) { const unsigned long long m = __ballot(v > 0.f); if (t.lane == 0) mk[NWAVE * R8 + 4 * rb + r] = m; }
+                    if (GRAD) bits |= v > 0.f ? (1u << (4 * rb + r)) : 0u;
                 }
+            if (GRAD) mk[1] = (unsigned short)bits;
         }
         s8_barrier();
         {   // h1 = h0 + relu(t) Wb + bb -> T
@@ -553,7 +560,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
             }
             s8_barrier();
             if (tl) S8_TL(10);
-            const unsigned long long* mk = MASK + ((size_t)layer * 2 * NWAVE + t.wave) * R8;
+            const unsigned mbits = *reinterpret_cast<const unsigned*>(MASK + (size_t)layer * (NWAVE * 64) + t.tid);
             f32x4 o[RB];
             float dh1[RB][4];
             {   // dh1 = dP WfT   (K = NFP)
@@ -577,7 +584,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        X2[(4 * rb + r) * S8_WS + col] = ((mk[NWAVE * R8 + 4 * rb + r] >> t.lane) & 1ull) ? o[rb][r] : 0.f;
+                        X2[(4 * rb + r) * S8_WS + col] = (mbits & (0x10000u << (4 * rb + r))) ? o[rb][r] : 0.f;
             }
             s8_barrier();
             {   // dh0 = dh1 + (d t WaT masked by h0 > 0)
@@ -586,7 +593,7 @@ __global__ __launch_bounds__(NTHREADS) void k_spline_logprob_r8(SplineDims f, S8
                 for (int rb = 0; rb < RB; ++rb)
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        T[(4 * rb + r) * S8_WS + col] = dh1[rb][r] + (((mk[4 * rb + r] >> t.lane) & 1ull) ? o[rb][r] : 0.f);
+                        T[(4 * rb + r) * S8_WS + col] = dh1[rb][r] + ((mbits & (1u << (4 * rb + r))) ? o[rb][r] : 0.f);
             }
             s8_barrier();
             if (tl) S8_TL(12);
